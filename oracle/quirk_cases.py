@@ -1,0 +1,106 @@
+"""TEST INFRASTRUCTURE ONLY -- hand-written SAM inputs that exercise every branch and
+quirk of the reference's CIGAR walk (/root/reference/kindel/kindel.py:40-81) and of
+consensus_sequence (:384-430); see SURVEY.md section 8a "#1 semantics".
+
+oracle/make_golden.py feeds each case to the *unmodified* reference and stores what it
+returned (tables, consensus, or the exception type) in tests/golden/quirks.json.
+"""
+
+_HDR1 = "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:c1\tLN:30\n"
+_HDR2 = "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:c1\tLN:30\n@SQ\tSN:c2\tLN:20\n"
+
+
+def _r(name, flag, rname, pos, cigar, seq):
+    return "\t".join([name, str(flag), rname, str(pos), "60", cigar, "*", "0", "0", seq,
+                      "*" if seq == "*" else "I" * len(seq)]) + "\n"
+
+
+def _mk(hdr, *reads):
+    return hdr + "".join(_r(*r) for r in reads)
+
+
+A10 = "ACGTACGTAC"
+CASES = {
+    "plain_M": _mk(_HDR1, ("a", 0, "c1", 1, "10M", A10), ("b", 16, "c1", 5, "10M", "TTTTTGGGGG")),
+    "pos0_wraps_to_last_site": _mk(_HDR1, ("a", 0, "c1", 0, "5M", "ACGTN")),
+    "pos0_deletion_first": _mk(_HDR1, ("a", 0, "c1", 0, "2D5M", "ACGTA")),
+    "pos0_leading_softclip": _mk(_HDR1, ("a", 0, "c1", 0, "3S4M", "ACGTACG")),
+    "pos0_insertion_first": _mk(_HDR1, ("a", 0, "c1", 0, "2I4M", "ACGTAC")),
+    "pos0_nonfirst_softclip": _mk(_HDR1, ("a", 0, "c1", 0, "2H3S4M", "ACGTACG")),
+    "negative_pos": _mk(_HDR1, ("a", 0, "c1", -4, "8M", "ACGTACGT")),
+    "leading_S_at_pos1": _mk(_HDR1, ("a", 0, "c1", 1, "4S6M", A10)),
+    "leading_S_partial_overlap": _mk(_HDR1, ("a", 0, "c1", 3, "4S6M", A10)),
+    "leading_S_inside": _mk(_HDR1, ("a", 0, "c1", 11, "4S6M", A10), ("b", 0, "c1", 11, "2S8M", A10)),
+    "H_then_S_is_nonfirst": _mk(_HDR1, ("a", 0, "c1", 5, "3H4S6M", A10)),
+    "trailing_S": _mk(_HDR1, ("a", 0, "c1", 5, "6M4S", A10)),
+    "trailing_S_clamped_at_L": _mk(_HDR1, ("a", 0, "c1", 24, "6M4S", A10)),
+    "trailing_S_exactly_to_L": _mk(_HDR1, ("a", 0, "c1", 21, "6M4S", A10)),
+    "trailing_S_starts_at_L": _mk(_HDR1, ("a", 0, "c1", 25, "6M4S", A10)),
+    "trailing_S_then_H": _mk(_HDR1, ("a", 0, "c1", 5, "6M4S5H", A10)),
+    "middle_S_advances_ref": _mk(_HDR1, ("a", 0, "c1", 5, "3M2S5M", A10)),
+    "two_leading_S": _mk(_HDR1, ("a", 0, "c1", 8, "2S2S6M", A10)),
+    "only_softclip": _mk(_HDR1, ("a", 0, "c1", 8, "10S", A10)),
+    "N_op_ignored_no_advance": _mk(_HDR1, ("a", 0, "c1", 2, "4M100N6M", A10)),
+    "P_eq_X_ops": _mk(_HDR1, ("a", 0, "c1", 2, "3=2X1P5M", "ACGTACGTACG")),
+    "lowercase_bases": _mk(_HDR1, ("a", 0, "c1", 2, "10M", "acgtnACGTN")),
+    "insertion_simple": _mk(_HDR1, ("a", 0, "c1", 2, "4M2I4M", A10), ("b", 0, "c1", 2, "4M2I4M", A10),
+                            ("c", 0, "c1", 2, "10M", A10)),
+    "insertion_at_site0": _mk(_HDR1, ("a", 0, "c1", 1, "3I7M", A10), ("b", 0, "c1", 1, "3I7M", A10)),
+    "insertion_at_L": _mk(_HDR1, ("a", 0, "c1", 25, "6M4I", A10)),
+    "insertion_iupac_allowed": _mk(_HDR1, ("a", 0, "c1", 2, "4M2I4M", "ACGTRYACGT"),
+                                   ("b", 0, "c1", 2, "4M2I4M", "ACGTRYACGT")),
+    "insertion_zero_length": _mk(_HDR1, ("a", 0, "c1", 2, "4M0I6M", A10), ("b", 0, "c1", 2, "4M0I6M", A10)),
+    "insertion_slice_truncated": _mk(_HDR1, ("a", 0, "c1", 2, "6M9I", A10), ("b", 0, "c1", 2, "6M9I", A10)),
+    "insertion_slice_empty": _mk(_HDR1, ("a", 0, "c1", 2, "10M3I", A10)),
+    "insertion_tie": _mk(_HDR1, ("a", 0, "c1", 2, "4M2I4M", "ACGTAAACGT"), ("b", 0, "c1", 2, "4M2I4M", "ACGTCCACGT")),
+    "insertion_majority_unique": _mk(_HDR1, ("a", 0, "c1", 2, "4M2I4M", "ACGTAAACGT"),
+                                     ("b", 0, "c1", 2, "4M2I4M", "ACGTAAACGT"),
+                                     ("c", 0, "c1", 2, "4M2I4M", "ACGTCCACGT")),
+    "insertion_minority": _mk(_HDR1, ("a", 0, "c1", 2, "4M2I4M", "ACGTAAACGT"), ("b", 0, "c1", 2, "8M", "ACGTACGT"),
+                              ("c", 0, "c1", 2, "8M", "ACGTACGT"), ("d", 0, "c1", 2, "8M", "ACGTACGT")),
+    "insertion_next_site_low_depth": _mk(_HDR1, ("a", 0, "c1", 2, "4M2I", "ACGTAA"), ("b", 0, "c1", 2, "4M", "ACGT"),
+                                         ("c", 0, "c1", 2, "4M", "ACGT")),
+    "deletion_simple": _mk(_HDR1, ("a", 0, "c1", 2, "4M3D6M", A10), ("b", 0, "c1", 2, "4M3D6M", A10),
+                           ("c", 0, "c1", 2, "10M", A10)),
+    "deletion_half_is_not_majority": _mk(_HDR1, ("a", 0, "c1", 2, "4M3D6M", A10), ("b", 0, "c1", 2, "10M", A10),
+                                         ("c", 0, "c1", 2, "10M", A10)),
+    "deletion_to_slot_L": _mk(_HDR1, ("a", 0, "c1", 25, "4M2D", "ACGT")),
+    "base_tie": _mk(_HDR1, ("a", 0, "c1", 2, "6M", "ACGTAC"), ("b", 0, "c1", 2, "6M", "ACCTAG")),
+    "base_tie_three_way": _mk(_HDR1, ("a", 0, "c1", 2, "4M", "ACGT"), ("b", 0, "c1", 2, "4M", "CCGT"),
+                              ("c", 0, "c1", 2, "4M", "GCGT")),
+    "N_majority": _mk(_HDR1, ("a", 0, "c1", 2, "4M", "NNGT"), ("b", 0, "c1", 2, "4M", "NAGT"),
+                      ("c", 0, "c1", 2, "4M", "AAGT")),
+    "unmapped_and_short_reads_skipped": _mk(_HDR1, ("a", 4, "c1", 2, "4M", "ACGT"), ("b", 0, "c1", 2, "1M", "A"),
+                                            ("c", 0, "c1", 2, "*", "*"), ("d", 0, "c1", 3, "4M", "ACGT")),
+    "unmapped_placed_only_contig_all_N": _mk(_HDR2, ("a", 4, "c2", 2, "4M", "ACGT"), ("b", 0, "c1", 3, "4M", "ACGT")),
+    "star_rname_dropped": _mk(_HDR2, ("a", 4, "*", 0, "*", "ACGT"), ("b", 0, "c1", 3, "4M", "ACGT")),
+    "contig_order_first_appearance": _mk(_HDR2, ("a", 0, "c2", 3, "4M", "ACGT"), ("b", 0, "c1", 3, "4M", "ACGT"),
+                                         ("c", 0, "c2", 5, "4M", "ACGT")),
+    "secondary_supplementary_dup_counted": _mk(_HDR1, ("a", 256, "c1", 2, "4M", "ACGT"), ("b", 2048, "c1", 2, "4M", "ACGT"),
+                                               ("c", 1024, "c1", 2, "4M", "ACGT"), ("d", 512, "c1", 2, "4M", "ACGT")),
+    "many_ops_long_cigar": _mk(_HDR1, ("a", 0, "c1", 1, "1M1I1M1D1M1I1M1D1M1I1M1D1M1I1M1D2M", "ACGTACGTACGTAC"),
+                               ("b", 0, "c1", 1, "1M1I1M1D1M1I1M1D1M1I1M1D1M1I1M1D2M", "ACGTACGTACGTAC"),
+                               ("c", 0, "c1", 1, "14M", "ACGTACGTACGTAC")),
+    "clip_both_ends_pair": _mk(_HDR1, ("a", 0, "c1", 10, "3S5M2S", A10), ("b", 16, "c1", 12, "2S6M2S", A10),
+                               ("c", 0, "c1", 10, "3S5M2S", "TTTACGTAGG")),
+    # ---- cases where the reference raises ----
+    "ERR_M_overhang_past_L": _mk(_HDR1, ("a", 0, "c1", 25, "10M", A10)),
+    "ERR_iupac_in_M": _mk(_HDR1, ("a", 0, "c1", 2, "10M", "ACGTRCGTAC")),
+    "ERR_iupac_in_leading_S_inside": _mk(_HDR1, ("a", 0, "c1", 11, "4S6M", "ACRTACGTAC")),
+    "OK_iupac_in_leading_S_offref": _mk(_HDR1, ("a", 0, "c1", 1, "4S6M", "ARYTACGTAC")),
+    "ERR_iupac_in_trailing_S": _mk(_HDR1, ("a", 0, "c1", 5, "6M4S", "ACGTACGRAC")),
+    "OK_iupac_in_trailing_S_past_L": _mk(_HDR1, ("a", 0, "c1", 25, "6M4S", "ACGTACGRAC")),
+    "ERR_cigar_star_mapped": _mk(_HDR1, ("a", 0, "c1", 2, "*", "ACGT")),
+    "ERR_seq_shorter_than_M": _mk(_HDR1, ("a", 0, "c1", 2, "10M", "ACGT")),
+    "ERR_seq_shorter_than_leading_S": _mk(_HDR1, ("a", 0, "c1", 12, "10S", "ACGT")),
+    "ERR_deletion_past_slot_L": _mk(_HDR1, ("a", 0, "c1", 26, "4M3D", "ACGT")),
+    "deletion_exactly_to_slot_L": _mk(_HDR1, ("a", 0, "c1", 25, "4M3D", "ACGT")),
+    "ERR_pos_far_past_L": _mk(_HDR1, ("a", 0, "c1", 40, "4M", "ACGT")),
+    "ERR_insertion_past_slot_L": _mk(_HDR1, ("a", 0, "c1", 25, "4M3D2I", "ACGTAA")),
+    "ERR_leading_S_past_slot_L": _mk(_HDR1, ("a", 0, "c1", 32, "4S", "ACGT")),
+    "ERR_eq_base_in_M": _mk(_HDR1, ("a", 0, "c1", 2, "4M", "AC=T")),
+    "ERR_second_contig_only": _mk(_HDR2, ("a", 0, "c1", 3, "4M", "ACGT"), ("b", 0, "c2", 18, "6M", "ACGTAC")),
+}
+
+#: option sets every non-error case is run with: (min_depth, trim_ends, uppercase)
+OPTION_SETS = [(1, False, False), (0, False, False), (2, False, False), (3, True, False), (1, True, True)]
