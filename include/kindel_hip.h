@@ -1,0 +1,201 @@
+/*
+ * kindel_hip.h -- C-ABI of libkindel_hip.so, the MI355X (gfx950) pileup + consensus engine.
+ *
+ * The reference (bede/kindel, /root/reference) is pure Python and has no FFI layer; its
+ * de-facto boundary for the hot path is the pair of Python calls
+ *     parse_records(ref_id, ref_len, records) -> alignment     kindel/kindel.py:21-128
+ *     consensus_sequence(weights, insertions, deletions, cdr_patches, trim_ends,
+ *                        min_depth, uppercase) -> (str, changes) kindel/kindel.py:384-430
+ * called from parse_bam (:131-153) and bam_to_consensus (:488-555).  Every entry point
+ * below names the reference lines it replaces.  The Python host mirror that keeps the
+ * reference's API on top of this ABI is kindel_amd/kindel.py (ctypes binding in
+ * kindel_amd/_native.py); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - return 0 on success, a negative KD_E_* code otherwise; kd_last_error() gives text.
+ *   - one kd_ctx = one GPU + one HIP stream; a context is NOT thread-safe, distinct
+ *     contexts (one per GPU / per process) are independent.
+ *   - "G-space": all contigs are laid out back to back on one site axis,
+ *     g = kd_contig_base(ctx, c) + site; each contig owns len+1 slots (the reference keeps
+ *     len+1 slots for deletions / clip_starts / clip_ends / insertions, kindel.py:36-39)
+ *     rounded up to a multiple of 64.
+ */
+#ifndef KINDEL_HIP_H
+#define KINDEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KD_ABI_VERSION 1
+
+/* error codes; the Python mirror re-raises the exception the reference would raise */
+#define KD_OK 0
+#define KD_E_BASE (-1)   /* KeyError   : base outside A,C,G,T,N in M/=/X or clip   kindel.py:52,72,79 */
+#define KD_E_RANGE (-2)  /* IndexError : read/indel/clip runs off the contig        kindel.py:51-52,57,61,67,75 */
+#define KD_E_CIGAR (-3)  /* RuntimeError: mapped read, real SEQ, CIGAR '*'          kindel.py:47 */
+#define KD_E_HIP (-4)    /* HIP runtime failure (incl. no device)                            */
+#define KD_E_NOMEM (-5)
+#define KD_E_ARG (-6)    /* bad argument / bad state                                         */
+#define KD_E_IO (-7)     /* decoder: unreadable or malformed SAM/BAM                         */
+#define KD_E_INTERNAL (-8)
+
+/* table channels of kd_get_tables(); order of the reference's dicts is A,T,G,C,N (kindel.py:29) */
+enum {
+    KD_CH_A = 0, KD_CH_T = 1, KD_CH_G = 2, KD_CH_C = 3, KD_CH_N = 4, /* weights            :29    */
+    KD_CH_DEL = 5,                                                    /* deletions          :39    */
+    KD_CH_CSW = 6,  /* ..10  clip_start_weights A,T,G,C,N                                   :30-32 */
+    KD_CH_CEW = 11, /* ..15  clip_end_weights   A,T,G,C,N                                   :33-35 */
+    KD_CH_CLIP_STARTS = 16,                                           /* clip_starts        :36    */
+    KD_CH_CLIP_ENDS = 17,                                             /* clip_ends          :37    */
+    KD_CH_INS_TOTAL = 18, /* sum(insertions[site].values())                                 :402   */
+    KD_NCH = 19
+};
+
+/* pileup kernel selection for kd_set_mode() */
+#define KD_MODE_AUTO 0   /* windowed LDS histograms, falling back per read where needed */
+#define KD_MODE_GLOBAL 1 /* one wavefront per read, 32-bit atomics straight into HBM     */
+#define KD_MODE_WINDOW 2 /* force the windowed path                                      */
+
+typedef struct kd_ctx kd_ctx;
+
+/*
+ * A batch of decoded reads, structure-of-arrays, BAM-native encodings
+ * (what simplesam.Reader hands parse_bam, kindel.py:136-145, minus the text).
+ * Records with RNAME '*' must already be dropped (kindel.py:147-148); everything else --
+ * unmapped-but-placed, secondary, supplementary, SEQ '*' -- is passed through and the
+ * engine applies the reference's own skip rule (flag & 4, len(seq) <= 1; kindel.py:43-46).
+ */
+typedef struct kd_batch {
+    uint64_t n_reads;
+    const uint32_t *contig;  /* [n] index into the contig table given to kd_create          */
+    const int32_t *pos0;     /* [n] POS-1 (kindel.py:42); -1 when SAM POS is 0              */
+    const uint32_t *flag;    /* [n] SAM FLAG                                                */
+    const uint64_t *seq_off; /* [n] byte offset of the read's first base in seq4            */
+    const uint32_t *seq_len; /* [n] l_seq in bases (0 for SEQ '*')                          */
+    const uint64_t *cig_off; /* [n] index of the read's first CIGAR word in cigar           */
+    const uint32_t *n_cig;   /* [n] number of CIGAR words (0 for CIGAR '*')                 */
+    const uint8_t *seq4;     /* 4-bit bases "=ACMGRSVTWYHKDBN", high nibble first, each read
+                                starts on a byte boundary (BAM layout)                      */
+    uint64_t seq4_bytes;
+    const uint32_t *cigar;   /* len<<4 | op, op in "MIDNSHP=X" (BAM layout)                 */
+    uint64_t cigar_words;
+} kd_batch;
+
+/* ---- lifetime -------------------------------------------------------------------- */
+
+/* Replaces the table allocation of parse_records, kindel.py:29-39.  Allocates and zeroes
+ * KD_NCH u32 channels over G-space on `device`.  stream: a hipStream_t to launch on
+ * (e.g. torch's current stream) or NULL to create a private one. */
+int kd_create(kd_ctx **out, int device, uint32_t n_contigs, const uint32_t *contig_len,
+              void *stream);
+void kd_destroy(kd_ctx *ctx);
+const char *kd_last_error(const kd_ctx *ctx); /* ctx may be NULL: last create/decoder error */
+int kd_abi_version(void);
+
+/* zero all tables and drop all insertion events (fresh parse_records state) */
+int kd_reset(kd_ctx *ctx);
+int kd_set_mode(kd_ctx *ctx, int mode);
+/* window-path tuning (0 = keep default): sites per LDS window, reads per work item */
+int kd_set_tuning(kd_ctx *ctx, uint32_t window_sites, uint32_t slice_reads);
+
+/* G-space geometry */
+uint64_t kd_contig_base(const kd_ctx *ctx, uint32_t contig);
+uint64_t kd_total_sites(const kd_ctx *ctx);
+
+/* Multi-GPU: restrict this context to G-space interval [g_lo, g_hi).  Table increments
+ * landing outside [g_lo, g_hi] (one halo site for aligned_depth_next, kindel.py:405-410)
+ * are dropped; consensus is emitted for [g_lo, g_hi) only.  Default: everything. */
+int kd_set_shard(kd_ctx *ctx, uint64_t g_lo, uint64_t g_hi);
+
+/* ---- pileup: the record loop of parse_records, kindel.py:40-81 ---------------------- */
+
+/* Host arrays; copied to the device before returning, buffers are reusable at once. */
+int kd_push_batch(kd_ctx *ctx, const kd_batch *host_batch);
+/* Same, but every pointer in *dev_batch is a DEVICE pointer on ctx's GPU (inputs already
+ * resident in HBM); the arrays must stay valid until the next kd_sync/kd_finalize. */
+int kd_push_batch_device(kd_ctx *ctx, const kd_batch *dev_batch);
+int kd_sync(kd_ctx *ctx);
+
+/* After the last batch: reduce the insertion events into per-site
+ * {total, unique-majority string | tie}  (insertions dicts + consensus(insertions[pos]),
+ * kindel.py:55-58, :402, :420-421).  Raises the deferred reference exception, if any
+ * (returns KD_E_BASE / KD_E_RANGE / KD_E_CIGAR; *err_read = index of the first failing
+ * read counted over all pushed batches, may be NULL). */
+int kd_finalize(kd_ctx *ctx, uint64_t *err_read);
+
+/* counters since the last kd_reset: [0] reads counted (kindel.py:43-46 passed),
+ * [1] aligned-base events (M/=/X lengths), [2] walked events (M,=,X,I,D,S lengths),
+ * [3] insertion events */
+int kd_get_stats(kd_ctx *ctx, uint64_t out[4]);
+
+/* what the last kd_push_batch* did: [0] 1 if the windowed LDS path ran (0: global atomics),
+ * [1] regular reads, [2] reads with soft-clip / insertion side effects (cold pass),
+ * [3] irregular reads (exact-semantics wave kernel), [4] long-CIGAR reads, [5] work items,
+ * [6] max reference span of a regular read, [7] reads out of G-start order */
+int kd_get_batch_info(kd_ctx *ctx, uint64_t out[8]);
+
+/* ---- tables: the `alignment` fields, kindel.py:97-128 -------------------------------- */
+
+/* Copy `n_ch` channels of one contig to host: out is [n_ch][len+1] u32, row i = channel
+ * channels[i] (KD_CH_*).  Slot len of the weight channels is always 0. */
+int kd_get_tables(kd_ctx *ctx, uint32_t contig, uint32_t n_ch, const uint32_t *channels,
+                  uint32_t *out);
+
+/* insertions[site] dicts of one contig (kindel.py:38,55-58) as flat arrays: call with
+ * all-NULL outputs to get *n_keys / *n_bytes, then again with buffers.  Keys of one site
+ * are adjacent; string k is bytes[off[k] .. off[k]+len[k]) in upper-case ASCII. */
+int kd_get_insertions(kd_ctx *ctx, uint32_t contig, uint64_t *n_keys, uint64_t *n_bytes,
+                      uint32_t *site, uint32_t *count, uint32_t *len, uint64_t *off,
+                      uint8_t *bytes);
+
+/* ---- consensus: consensus_sequence, kindel.py:384-430 -------------------------------- */
+
+/* Run the per-site pass over every contig (this context's shard).
+ * patches: n_patches site ranges [patch_start, patch_end) in G-space that emit nothing and
+ * record no change (the skip logic of kindel.py:393-401; the patch text itself is spliced
+ * by the caller at patch_off).  Raw output: before trim_ends / uppercase (kindel.py:425-428). */
+int kd_consensus_run(kd_ctx *ctx, uint32_t min_depth, uint32_t n_patches,
+                     const uint64_t *patch_start, const uint64_t *patch_end);
+/* Fetch one contig's result of the last kd_consensus_run: sequence bytes (upper-case site
+ * bases, lower-case insertions), changes[len] in {0,'D','N','I'} (may be NULL),
+ * depth_minmax[2] = min,max of A+C+G+T (build_report, kindel.py:450,477-479; may be NULL),
+ * patch_off[n_patches] = offset in seq_out where each patch starting in this contig splices
+ * (UINT64_MAX for patches of other contigs; may be NULL). */
+int kd_consensus_fetch(kd_ctx *ctx, uint32_t contig, uint8_t *seq_out, uint64_t cap,
+                       uint64_t *len_out, uint8_t *changes, uint32_t *depth_minmax,
+                       uint64_t *patch_off);
+/* Device-side view of the whole shard's consensus (for the multi-GPU all-gather):
+ * *dev_ptr = device pointer to the concatenated bytes, *n_bytes its length. */
+int kd_consensus_device(kd_ctx *ctx, void **dev_ptr, uint64_t *n_bytes);
+
+/* ---- profiling ---------------------------------------------------------------------- */
+
+/* When enabled every kernel launch is bracketed by hipEvents on ctx's stream. */
+int kd_profile_enable(kd_ctx *ctx, int on);
+/* Accumulated since enable/reset: number of kernel rows (call with names==NULL), then
+ * per row: name (<=63 chars + NUL in names[i*64]), launches, total milliseconds. */
+int kd_profile_get(kd_ctx *ctx, uint32_t *n_rows, char *names, uint64_t *launches, double *ms);
+int kd_profile_reset(kd_ctx *ctx);
+
+/* ---- host decoder: what simplesam.Reader does for parse_bam, kindel.py:136-145 -------- */
+
+typedef struct kd_file kd_file;
+/* Decode a SAM text or BAM (BGZF) file into one kd_batch held by the handle.  No GPU use. */
+int kd_decode_open(kd_file **out, const char *path, int n_threads);
+const kd_batch *kd_decode_batch(const kd_file *f);
+uint32_t kd_decode_n_contigs(const kd_file *f);
+const char *kd_decode_contig_name(const kd_file *f, uint32_t i);
+uint32_t kd_decode_contig_len(const kd_file *f, uint32_t i);
+uint64_t kd_decode_n_records(const kd_file *f); /* all records in the file, incl. dropped RNAME '*' */
+void kd_decode_close(kd_file *f);
+const char *kd_decode_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KINDEL_HIP_H */

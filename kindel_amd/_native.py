@@ -1,0 +1,335 @@
+"""ctypes binding of libkindel_hip.so (C-ABI: include/kindel_hip.h).
+
+This is the only place the Python host code touches the native engine.  The library is the
+HIP/gfx950 build kept in-tree next to this file; if it is missing or cannot be loaded the
+import of the hot path fails loudly -- there is no CPU fallback in this package.
+
+Reference correspondence: ``Engine`` is the device-side replacement of the body of
+``parse_records`` / ``consensus_sequence`` (/root/reference/kindel/kindel.py:21-128, :384-430);
+``decode_file`` replaces ``simplesam.Reader`` as used by ``parse_bam`` (:136-148).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libkindel_hip.so")
+
+KD_OK, KD_E_BASE, KD_E_RANGE, KD_E_CIGAR, KD_E_HIP, KD_E_NOMEM, KD_E_ARG, KD_E_IO, KD_E_INTERNAL = (
+    0, -1, -2, -3, -4, -5, -6, -7, -8)
+KD_MODE_AUTO, KD_MODE_GLOBAL, KD_MODE_WINDOW = 0, 1, 2
+(KD_CH_A, KD_CH_T, KD_CH_G, KD_CH_C, KD_CH_N, KD_CH_DEL, KD_CH_CSW, KD_CH_CEW, KD_CH_CLIP_STARTS,
+ KD_CH_CLIP_ENDS, KD_CH_INS_TOTAL, KD_NCH) = (0, 1, 2, 3, 4, 5, 6, 11, 16, 17, 18, 19)
+
+#: every symbol include/kindel_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = (
+    "kd_abi_version kd_create kd_destroy kd_last_error kd_reset kd_set_mode kd_set_tuning kd_contig_base "
+    "kd_total_sites kd_set_shard kd_push_batch kd_push_batch_device kd_sync kd_finalize kd_get_stats "
+    "kd_get_batch_info kd_get_tables kd_get_insertions kd_consensus_run kd_consensus_fetch kd_consensus_device "
+    "kd_profile_enable kd_profile_get kd_profile_reset kd_decode_open kd_decode_batch kd_decode_n_contigs "
+    "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error"
+).split()
+
+#: the reference exception each error code stands for (kindel.py:47,51-52,57,61,67,72,75,79)
+_EXC = {KD_E_BASE: KeyError, KD_E_RANGE: IndexError, KD_E_CIGAR: RuntimeError, KD_E_NOMEM: MemoryError,
+        KD_E_IO: OSError}
+
+
+class KindelNativeError(RuntimeError):
+    pass
+
+
+class kd_batch(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("contig", C.c_void_p), ("pos0", C.c_void_p), ("flag", C.c_void_p),
+                ("seq_off", C.c_void_p), ("seq_len", C.c_void_p), ("cig_off", C.c_void_p), ("n_cig", C.c_void_p),
+                ("seq4", C.c_void_p), ("seq4_bytes", C.c_uint64), ("cigar", C.c_void_p), ("cigar_words", C.c_uint64)]
+
+
+_BATCH_FIELDS = (("contig", np.uint32), ("pos0", np.int32), ("flag", np.uint32), ("seq_off", np.uint64),
+                 ("seq_len", np.uint32), ("cig_off", np.uint64), ("n_cig", np.uint32), ("seq4", np.uint8),
+                 ("cigar", np.uint32))
+
+
+class Library:
+    """A loaded C-ABI library with typed prototypes."""
+
+    def __init__(self, path=DEFAULT_LIB):
+        if not os.path.exists(path):
+            raise ImportError(
+                "kindel_amd: native library %s not found. Build it with `python -c \"import __graft_entry__ as g; "
+                "g.build()\"` (hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+        try:
+            self.dll = C.CDLL(path)
+        except OSError as e:
+            raise ImportError("kindel_amd: cannot load %s: %s" % (path, e))
+        self.path = path
+        L, p, u32, u64 = self.dll, C.c_void_p, C.c_uint32, C.c_uint64
+        L.kd_abi_version.restype = C.c_int
+        L.kd_create.argtypes = [C.POINTER(p), C.c_int, u32, p, p]
+        L.kd_destroy.argtypes = [p]
+        L.kd_destroy.restype = None
+        L.kd_last_error.argtypes = [p]
+        L.kd_last_error.restype = C.c_char_p
+        L.kd_reset.argtypes = [p]
+        L.kd_set_mode.argtypes = [p, C.c_int]
+        L.kd_set_tuning.argtypes = [p, u32, u32]
+        L.kd_contig_base.argtypes = [p, u32]
+        L.kd_contig_base.restype = u64
+        L.kd_total_sites.argtypes = [p]
+        L.kd_total_sites.restype = u64
+        L.kd_set_shard.argtypes = [p, u64, u64]
+        L.kd_push_batch.argtypes = [p, C.POINTER(kd_batch)]
+        L.kd_push_batch_device.argtypes = [p, C.POINTER(kd_batch)]
+        L.kd_sync.argtypes = [p]
+        L.kd_finalize.argtypes = [p, C.POINTER(u64)]
+        L.kd_get_stats.argtypes = [p, p]
+        L.kd_get_batch_info.argtypes = [p, p]
+        L.kd_get_tables.argtypes = [p, u32, u32, p, p]
+        L.kd_get_insertions.argtypes = [p, u32, C.POINTER(u64), C.POINTER(u64), p, p, p, p, p]
+        L.kd_consensus_run.argtypes = [p, u32, u32, p, p]
+        L.kd_consensus_fetch.argtypes = [p, u32, p, u64, C.POINTER(u64), p, p, p]
+        L.kd_consensus_device.argtypes = [p, C.POINTER(p), C.POINTER(u64)]
+        L.kd_profile_enable.argtypes = [p, C.c_int]
+        L.kd_profile_get.argtypes = [p, C.POINTER(u32), p, p, p]
+        L.kd_profile_reset.argtypes = [p]
+        L.kd_decode_open.argtypes = [C.POINTER(p), C.c_char_p, C.c_int]
+        L.kd_decode_batch.argtypes = [p]
+        L.kd_decode_batch.restype = C.POINTER(kd_batch)
+        L.kd_decode_n_contigs.argtypes = [p]
+        L.kd_decode_n_contigs.restype = u32
+        L.kd_decode_contig_name.argtypes = [p, u32]
+        L.kd_decode_contig_name.restype = C.c_char_p
+        L.kd_decode_contig_len.argtypes = [p, u32]
+        L.kd_decode_contig_len.restype = u32
+        L.kd_decode_n_records.argtypes = [p]
+        L.kd_decode_n_records.restype = u64
+        L.kd_decode_close.argtypes = [p]
+        L.kd_decode_close.restype = None
+        L.kd_decode_last_error.restype = C.c_char_p
+        if L.kd_abi_version() != 1:
+            raise ImportError("kindel_amd: ABI version mismatch in %s" % path)
+
+
+_default = None
+
+
+def default_library():
+    """The product library (HIP, gfx950).  Raises ImportError when it is not built."""
+    global _default
+    if _default is None:
+        _default = Library(DEFAULT_LIB)
+    return _default
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def decode_file(path, threads=0, lib=None):
+    """SAM/BAM file -> SoA batch dict (numpy, host) via the native decoder.
+
+    Keys: contig,pos0,flag,seq_off,seq_len,cig_off,n_cig,seq4,cigar + contig_names, contig_lens,
+    n_records.  Records with RNAME '*' are dropped (kindel.py:147-148)."""
+    lib = lib or default_library()
+    h = C.c_void_p()
+    rc = lib.dll.kd_decode_open(C.byref(h), os.fsencode(str(path)), int(threads))
+    if rc:
+        raise _EXC.get(rc, KindelNativeError)("%s: %s" % (path, lib.dll.kd_decode_last_error().decode()))
+    try:
+        b = lib.dll.kd_decode_batch(h).contents
+        n = int(b.n_reads)
+        sizes = dict(contig=n, pos0=n, flag=n, seq_off=n, seq_len=n, cig_off=n, n_cig=n,
+                     seq4=int(b.seq4_bytes), cigar=int(b.cigar_words))
+        out = {}
+        for name, dt in _BATCH_FIELDS:
+            cnt = sizes[name]
+            addr = getattr(b, name)
+            if cnt and addr:
+                buf = (C.c_char * (cnt * np.dtype(dt).itemsize)).from_address(addr)
+                out[name] = np.frombuffer(buf, dtype=dt, count=cnt).copy()
+            else:
+                out[name] = np.zeros(0, dt)
+        nc = lib.dll.kd_decode_n_contigs(h)
+        out["contig_names"] = np.asarray([lib.dll.kd_decode_contig_name(h, i).decode() for i in range(nc)])
+        out["contig_lens"] = np.asarray([lib.dll.kd_decode_contig_len(h, i) for i in range(nc)], np.uint32)
+        out["n_records"] = int(lib.dll.kd_decode_n_records(h))
+        return out
+    finally:
+        lib.dll.kd_decode_close(h)
+
+
+class Engine:
+    """One kd_ctx: device tables for a set of contigs on one GPU."""
+
+    def __init__(self, contig_lens, device=0, stream=None, lib=None, mode=KD_MODE_AUTO):
+        self.lib = lib or default_library()
+        self.contig_lens = np.ascontiguousarray(contig_lens, np.uint32)
+        self._h = C.c_void_p()
+        rc = self.lib.dll.kd_create(C.byref(self._h), int(device), len(self.contig_lens), _ptr(self.contig_lens),
+                                    C.c_void_p(stream) if stream else None)
+        if rc:
+            self._h = None
+            raise _EXC.get(rc, KindelNativeError)(
+                "kd_create failed (%d): %s" % (rc, self.lib.dll.kd_last_error(None).decode()))
+        if mode != KD_MODE_AUTO:
+            self.set_mode(mode)
+        self._keep = None
+
+    # -- plumbing --
+    def _check(self, rc, what):
+        if rc:
+            msg = "%s failed (%d): %s" % (what, rc, self.lib.dll.kd_last_error(self._h).decode())
+            raise _EXC.get(rc, KindelNativeError)(msg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.dll.kd_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_mode(self, mode):
+        self._check(self.lib.dll.kd_set_mode(self._h, mode), "kd_set_mode")
+
+    def set_tuning(self, window_sites=0, slice_reads=0):
+        self._check(self.lib.dll.kd_set_tuning(self._h, window_sites, slice_reads), "kd_set_tuning")
+
+    def set_shard(self, g_lo, g_hi):
+        self._check(self.lib.dll.kd_set_shard(self._h, g_lo, g_hi), "kd_set_shard")
+
+    def reset(self):
+        self._check(self.lib.dll.kd_reset(self._h), "kd_reset")
+
+    def contig_base(self, c):
+        return int(self.lib.dll.kd_contig_base(self._h, c))
+
+    def total_sites(self):
+        return int(self.lib.dll.kd_total_sites(self._h))
+
+    # -- pileup --
+    @staticmethod
+    def _struct(arrs, n):
+        b = kd_batch()
+        b.n_reads = n
+        for name, _ in _BATCH_FIELDS:
+            setattr(b, name, arrs[name])
+        return b
+
+    def push(self, batch):
+        """Host batch (dict of numpy arrays, see decode_file)."""
+        arrs = {name: np.ascontiguousarray(batch[name], dt) for name, dt in _BATCH_FIELDS}
+        b = self._struct({k: v.ctypes.data for k, v in arrs.items()}, len(arrs["contig"]))
+        b.seq4_bytes = arrs["seq4"].size
+        b.cigar_words = arrs["cigar"].size
+        self._check(self.lib.dll.kd_push_batch(self._h, C.byref(b)), "kd_push_batch")
+
+    def push_device(self, ptrs, n_reads, seq4_bytes, cigar_words):
+        """Device-resident batch: ptrs maps field name -> device address (e.g. tensor.data_ptr())."""
+        b = self._struct(ptrs, n_reads)
+        b.seq4_bytes, b.cigar_words = seq4_bytes, cigar_words
+        self._check(self.lib.dll.kd_push_batch_device(self._h, C.byref(b)), "kd_push_batch_device")
+
+    def sync(self):
+        self._check(self.lib.dll.kd_sync(self._h), "kd_sync")
+
+    def finalize(self):
+        bad = C.c_uint64(0)
+        self._check(self.lib.dll.kd_finalize(self._h, C.byref(bad)), "kd_finalize")
+
+    def stats(self):
+        out = np.zeros(4, np.uint64)
+        self._check(self.lib.dll.kd_get_stats(self._h, _ptr(out)), "kd_get_stats")
+        return dict(reads=int(out[0]), aligned=int(out[1]), walked=int(out[2]), ins_events=int(out[3]))
+
+    def batch_info(self):
+        out = np.zeros(8, np.uint64)
+        self._check(self.lib.dll.kd_get_batch_info(self._h, _ptr(out)), "kd_get_batch_info")
+        keys = ("windowed", "regular", "cold", "irregular", "long_cigar", "work_items", "max_span", "unsorted")
+        return dict(zip(keys, (int(x) for x in out)))
+
+    # -- tables --
+    def tables(self, contig, channels=None):
+        """-> uint32 array [len(channels), L+1] (row i = channel channels[i])."""
+        ch = np.arange(KD_NCH, dtype=np.uint32) if channels is None else np.ascontiguousarray(channels, np.uint32)
+        L1 = int(self.contig_lens[contig]) + 1
+        out = np.zeros((len(ch), L1), np.uint32)
+        self._check(self.lib.dll.kd_get_tables(self._h, contig, len(ch), _ptr(ch), _ptr(out)), "kd_get_tables")
+        return out
+
+    def insertions(self, contig):
+        """-> (site[u32], count[u32], strings[list of str]) of the insertion dicts of one contig."""
+        nk, nb = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.dll.kd_get_insertions(self._h, contig, C.byref(nk), C.byref(nb), None, None, None,
+                                                   None, None), "kd_get_insertions")
+        n = nk.value
+        site, count, ln = (np.zeros(n, np.uint32) for _ in range(3))
+        off = np.zeros(n, np.uint64)
+        byts = np.zeros(max(nb.value, 1), np.uint8)
+        if n:
+            self._check(self.lib.dll.kd_get_insertions(self._h, contig, C.byref(nk), C.byref(nb), _ptr(site),
+                                                       _ptr(count), _ptr(ln), _ptr(off), _ptr(byts)),
+                        "kd_get_insertions")
+        raw = byts.tobytes()
+        strings = [raw[int(o):int(o) + int(l)].decode() for o, l in zip(off, ln)]
+        return site, count, strings
+
+    # -- consensus --
+    def consensus_run(self, min_depth=1, patches=()):
+        """patches: iterable of (g_start, g_end) skip ranges in G-space."""
+        ps = np.asarray([p[0] for p in patches], np.uint64)
+        pe = np.asarray([p[1] for p in patches], np.uint64)
+        self._n_patches = len(ps)
+        self._check(self.lib.dll.kd_consensus_run(self._h, int(min_depth), len(ps), _ptr(ps), _ptr(pe)),
+                    "kd_consensus_run")
+
+    def consensus_fetch(self, contig, want_changes=True):
+        """-> (bytes, changes uint8[L] | None, (min_depth, max_depth), patch_off uint64[n_patches])."""
+        ln = C.c_uint64(0)
+        self._check(self.lib.dll.kd_consensus_fetch(self._h, contig, None, 0, C.byref(ln), None, None, None),
+                    "kd_consensus_fetch")
+        L = int(self.contig_lens[contig])
+        seq = np.zeros(max(ln.value, 1), np.uint8)
+        changes = np.zeros(max(L, 1), np.uint8) if want_changes else None
+        mm = np.zeros(2, np.uint32)
+        poff = np.zeros(max(self._n_patches, 1), np.uint64)
+        self._check(self.lib.dll.kd_consensus_fetch(self._h, contig, _ptr(seq), seq.size, C.byref(ln),
+                                                    _ptr(changes) if want_changes else None, _ptr(mm), _ptr(poff)),
+                    "kd_consensus_fetch")
+        return (seq[: ln.value].tobytes(), changes[:L] if want_changes else None, (int(mm[0]), int(mm[1])),
+                poff[: self._n_patches])
+
+    def consensus_device(self):
+        p, n = C.c_void_p(), C.c_uint64(0)
+        self._check(self.lib.dll.kd_consensus_device(self._h, C.byref(p), C.byref(n)), "kd_consensus_device")
+        return p.value, n.value
+
+    # -- profiling --
+    def profile_enable(self, on=True):
+        self._check(self.lib.dll.kd_profile_enable(self._h, int(on)), "kd_profile_enable")
+
+    def profile_reset(self):
+        self._check(self.lib.dll.kd_profile_reset(self._h), "kd_profile_reset")
+
+    def profile(self):
+        """-> {kernel name: (launches, total_ms)}"""
+        n = C.c_uint32(0)
+        self._check(self.lib.dll.kd_profile_get(self._h, C.byref(n), None, None, None), "kd_profile_get")
+        k = n.value
+        names = C.create_string_buffer(64 * max(k, 1))
+        launches = np.zeros(max(k, 1), np.uint64)
+        ms = np.zeros(max(k, 1), np.float64)
+        n = C.c_uint32(k)
+        self._check(self.lib.dll.kd_profile_get(self._h, C.byref(n), names, _ptr(launches), _ptr(ms)),
+                    "kd_profile_get")
+        out = {}
+        for i in range(min(k, n.value)):
+            nm = names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode()
+            out[nm] = (int(launches[i]), float(ms[i]))
+        return out

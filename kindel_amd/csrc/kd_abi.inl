@@ -1,0 +1,125 @@
+// kd_abi.inl -- extern "C" entry points of include/kindel_hip.h over KdEngine<KD_RT>.
+// Included once by the translation unit that defines KD_RT (kindel_hip.hip for the product,
+// tests/emu/emu_lib.cpp for the kernel-logic emulator).  Decoder entry points live in
+// kd_decode.cpp.
+#include <new>
+
+struct kd_ctx {
+    KdEngine<KD_RT> e;
+};
+
+static std::string g_kd_create_error;
+
+extern "C" {
+
+int kd_abi_version(void) { return KD_ABI_VERSION; }
+
+int kd_create(kd_ctx **out, int device, uint32_t n_contigs, const uint32_t *contig_len, void *stream) {
+    if (!out) return KD_E_ARG;
+    *out = nullptr;
+    kd_ctx *c = new (std::nothrow) kd_ctx();
+    if (!c) return KD_E_NOMEM;
+    int rc = c->e.create(device, n_contigs, contig_len, stream);
+    if (rc) {
+        g_kd_create_error = c->e.err;
+        c->e.destroy();
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return KD_OK;
+}
+
+void kd_destroy(kd_ctx *ctx) {
+    if (!ctx) return;
+    ctx->e.destroy();
+    delete ctx;
+}
+
+const char *kd_last_error(const kd_ctx *ctx) { return ctx ? ctx->e.err.c_str() : g_kd_create_error.c_str(); }
+
+int kd_reset(kd_ctx *ctx) { return ctx ? ctx->e.reset() : KD_E_ARG; }
+
+int kd_set_mode(kd_ctx *ctx, int mode) {
+    if (!ctx || mode < KD_MODE_AUTO || mode > KD_MODE_WINDOW) return KD_E_ARG;
+    ctx->e.mode = mode;
+    return KD_OK;
+}
+
+int kd_set_tuning(kd_ctx *ctx, uint32_t window_sites, uint32_t slice_reads) {
+    if (!ctx) return KD_E_ARG;
+    if (window_sites) {
+        if (window_sites < 64 || window_sites > 6144 || (window_sites & 63)) return ctx->e.fail(KD_E_ARG, "kd_set_tuning: window must be a multiple of 64 in [64, 6144]");
+        ctx->e.W = window_sites;
+    }
+    ctx->e.slice_cfg = slice_reads;
+    return KD_OK;
+}
+
+uint64_t kd_contig_base(const kd_ctx *ctx, uint32_t contig) {
+    return (ctx && contig < ctx->e.n_contigs) ? ctx->e.cbase[contig] : ~0ULL;
+}
+uint64_t kd_total_sites(const kd_ctx *ctx) { return ctx ? ctx->e.S : 0; }
+
+int kd_set_shard(kd_ctx *ctx, uint64_t g_lo, uint64_t g_hi) { return ctx ? ctx->e.set_shard(g_lo, g_hi) : KD_E_ARG; }
+
+int kd_push_batch(kd_ctx *ctx, const kd_batch *b) { return (ctx && b) ? ctx->e.push_host(*b) : KD_E_ARG; }
+int kd_push_batch_device(kd_ctx *ctx, const kd_batch *b) { return (ctx && b) ? ctx->e.push_device(*b) : KD_E_ARG; }
+int kd_sync(kd_ctx *ctx) {
+    if (!ctx) return KD_E_ARG;
+    return ctx->e.rt.sync() ? ctx->e.hipfail("kd_sync") : KD_OK;
+}
+int kd_finalize(kd_ctx *ctx, uint64_t *err_read) { return ctx ? ctx->e.finalize(err_read) : KD_E_ARG; }
+int kd_get_stats(kd_ctx *ctx, uint64_t out[4]) { return (ctx && out) ? ctx->e.get_stats(out) : KD_E_ARG; }
+
+int kd_get_batch_info(kd_ctx *ctx, uint64_t out[8]) {
+    if (!ctx || !out) return KD_E_ARG;
+    int rc = ctx->e.fetch_status();
+    if (rc) return rc;
+    const auto &h = ctx->e.h_status;
+    out[0] = ctx->e.last_windowed; out[1] = h[KDS_B_N_REG]; out[2] = h[KDS_B_N_COLD]; out[3] = h[KDS_B_N_IRREG];
+    out[4] = h[KDS_B_N_LONG]; out[5] = h[KDS_TOTAL_ITEMS]; out[6] = h[KDS_B_MAXSPAN]; out[7] = h[KDS_B_UNSORTED];
+    return KD_OK;
+}
+
+int kd_get_tables(kd_ctx *ctx, uint32_t contig, uint32_t n_ch, const uint32_t *channels, uint32_t *out) {
+    return (ctx && channels && out) ? ctx->e.get_tables(contig, n_ch, channels, out) : KD_E_ARG;
+}
+int kd_get_insertions(kd_ctx *ctx, uint32_t contig, uint64_t *n_keys, uint64_t *n_bytes, uint32_t *site,
+                      uint32_t *count, uint32_t *len, uint64_t *off, uint8_t *bytes) {
+    return ctx ? ctx->e.get_insertions(contig, n_keys, n_bytes, site, count, len, off, bytes) : KD_E_ARG;
+}
+
+int kd_consensus_run(kd_ctx *ctx, uint32_t min_depth, uint32_t n_patches, const uint64_t *patch_start,
+                     const uint64_t *patch_end) {
+    if (!ctx || (n_patches && (!patch_start || !patch_end))) return KD_E_ARG;
+    return ctx->e.consensus_run(min_depth, n_patches, patch_start, patch_end);
+}
+int kd_consensus_fetch(kd_ctx *ctx, uint32_t contig, uint8_t *seq_out, uint64_t cap, uint64_t *len_out,
+                       uint8_t *changes, uint32_t *depth_minmax, uint64_t *patch_off) {
+    return ctx ? ctx->e.consensus_fetch(contig, seq_out, cap, len_out, changes, depth_minmax, patch_off) : KD_E_ARG;
+}
+int kd_consensus_device(kd_ctx *ctx, void **dev_ptr, uint64_t *n_bytes) {
+    if (!ctx || !dev_ptr || !n_bytes) return KD_E_ARG;
+    if (!ctx->e.have_cns) return ctx->e.fail(KD_E_ARG, "kd_consensus_device: call kd_consensus_run first");
+    *dev_ptr = ctx->e.b_cns.p;
+    *n_bytes = ctx->e.h_coff[ctx->e.n_contigs];
+    return KD_OK;
+}
+
+int kd_profile_enable(kd_ctx *ctx, int on) {
+    if (!ctx) return KD_E_ARG;
+    ctx->e.rt.profile_enable(on != 0);
+    return KD_OK;
+}
+int kd_profile_get(kd_ctx *ctx, uint32_t *n_rows, char *names, uint64_t *launches, double *ms) {
+    if (!ctx || !n_rows) return KD_E_ARG;
+    return ctx->e.rt.profile_get(n_rows, names, launches, ms) ? ctx->e.hipfail("kd_profile_get") : KD_OK;
+}
+int kd_profile_reset(kd_ctx *ctx) {
+    if (!ctx) return KD_E_ARG;
+    ctx->e.rt.profile_reset();
+    return KD_OK;
+}
+
+}  // extern "C"

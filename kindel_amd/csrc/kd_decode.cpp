@@ -1,0 +1,351 @@
+// kd_decode.cpp -- host decoder: SAM text / BAM (BGZF) -> kd_batch (include/kindel_hip.h).
+//
+// Replaces what simplesam.Reader + `samtools view` do for parse_bam
+// (/root/reference/kindel/kindel.py:136-148): header @SQ -> {name: LN}, record iteration,
+// dropping RNAME '*'.  No arithmetic of the hot path lives here and no GPU is touched.
+// Formats: SAMv1 spec sections 1.3-1.4 (text), 4.1 (BGZF), 4.2 (BAM records).
+// BGZF blocks are independent deflate streams, so they are inflated by a thread pool into
+// their final positions (ISIZE prefix sum) before the records are walked.
+#include <zlib.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/kindel_hip.h"
+
+namespace {
+
+std::string g_decode_error;
+
+struct File {
+    std::vector<std::string> names;
+    std::vector<uint32_t> lens;
+    std::vector<uint32_t> contig, flag, seq_len, n_cig, cigar;
+    std::vector<int32_t> pos0;
+    std::vector<uint64_t> seq_off, cig_off;
+    std::vector<uint8_t> seq4;
+    uint64_t n_records = 0;
+    kd_batch view;
+};
+
+inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | p[1] << 8); }
+
+bool read_all(const char *path, std::vector<uint8_t> &out) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize(n > 0 ? (size_t)n : 0);
+    size_t got = out.empty() ? 0 : fread(out.data(), 1, out.size(), f);
+    fclose(f);
+    return got == out.size();
+}
+
+struct Block { size_t in_off, in_len, out_off, out_len; };
+
+// Split a BGZF file into its blocks using the BC extra subfield (SAMv1 4.1).
+bool scan_bgzf(const std::vector<uint8_t> &raw, std::vector<Block> &blocks, size_t &total) {
+    size_t o = 0;
+    total = 0;
+    while (o + 18 <= raw.size()) {
+        const uint8_t *p = raw.data() + o;
+        if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return false;
+        const size_t xlen = rd16(p + 10);
+        size_t x = 12, bsize = 0;
+        while (x + 4 <= 12 + xlen) {
+            const size_t slen = rd16(p + x + 2);
+            if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2) bsize = (size_t)rd16(p + x + 4) + 1;
+            x += 4 + slen;
+        }
+        if (!bsize || o + bsize > raw.size() || bsize < 12 + xlen + 8) return false;
+        const size_t isize = rd32(p + bsize - 4);
+        blocks.push_back({o + 12 + xlen, bsize - (12 + xlen) - 8, total, isize});
+        total += isize;
+        o += bsize;
+    }
+    return o == raw.size();
+}
+
+bool inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len) {
+    if (!out_len) return true;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<uint8_t *>(in);
+    zs.avail_in = (uInt)in_len;
+    zs.next_out = out;
+    zs.avail_out = (uInt)out_len;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.total_out == out_len;
+    inflateEnd(&zs);
+    return ok;
+}
+
+// generic (non-BGZF) gzip: single stream, possibly several members
+bool inflate_generic(const std::vector<uint8_t> &raw, std::vector<uint8_t> &out) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 32) != Z_OK) return false;
+    zs.next_in = const_cast<uint8_t *>(raw.data());
+    zs.avail_in = (uInt)raw.size();
+    out.resize(raw.size() * 4 + 65536);
+    size_t have = 0;
+    for (;;) {
+        if (have == out.size()) out.resize(out.size() * 2);
+        zs.next_out = out.data() + have;
+        zs.avail_out = (uInt)std::min<size_t>(out.size() - have, 1u << 30);
+        const int rc = inflate(&zs, Z_NO_FLUSH);
+        have = zs.total_out;
+        if (rc == Z_STREAM_END) {
+            if (zs.avail_in == 0) break;
+            if (inflateReset(&zs) != Z_OK) { inflateEnd(&zs); return false; }
+        } else if (rc != Z_OK) { inflateEnd(&zs); return false; }
+    }
+    inflateEnd(&zs);
+    out.resize(have);
+    return true;
+}
+
+bool decompress(const std::vector<uint8_t> &raw, std::vector<uint8_t> &out, int n_threads) {
+    std::vector<Block> blocks;
+    size_t total = 0;
+    if (!scan_bgzf(raw, blocks, total)) return inflate_generic(raw, out);
+    out.resize(total);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> ok{true};
+    auto work = [&]() {
+        for (;;) {
+            const size_t b = next.fetch_add(1);
+            if (b >= blocks.size()) break;
+            const Block &B = blocks[b];
+            if (!inflate_raw(raw.data() + B.in_off, B.in_len, out.data() + B.out_off, B.out_len)) ok = false;
+        }
+    };
+    unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+    nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, blocks.size()));
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    return ok;
+}
+
+void finish_view(File &f) {
+    f.seq4.resize(f.seq4.size() + 8, 0);  // slack so vector loads at the tail stay in bounds
+    f.cigar.resize(f.cigar.size() + 2, 0);
+    kd_batch &v = f.view;
+    v.n_reads = f.contig.size();
+    v.contig = f.contig.data(); v.pos0 = f.pos0.data(); v.flag = f.flag.data(); v.seq_off = f.seq_off.data();
+    v.seq_len = f.seq_len.data(); v.cig_off = f.cig_off.data(); v.n_cig = f.n_cig.data();
+    v.seq4 = f.seq4.data(); v.seq4_bytes = f.seq4.size() - 8;
+    v.cigar = f.cigar.data(); v.cigar_words = f.cigar.size() - 2;
+}
+
+int parse_bam(const std::vector<uint8_t> &d, File &f) {
+    const size_t n = d.size();
+    if (n < 12 || memcmp(d.data(), "BAM\1", 4) != 0) { g_decode_error = "not a BAM stream"; return KD_E_IO; }
+    size_t o = 8 + (size_t)rd32(d.data() + 4);
+    if (o + 4 > n) { g_decode_error = "truncated BAM header"; return KD_E_IO; }
+    const uint32_t n_ref = rd32(d.data() + o);
+    o += 4;
+    for (uint32_t r = 0; r < n_ref; r++) {
+        if (o + 4 > n) { g_decode_error = "truncated BAM reference list"; return KD_E_IO; }
+        const uint32_t l_name = rd32(d.data() + o);
+        if (o + 8 + l_name > n || !l_name) { g_decode_error = "truncated BAM reference list"; return KD_E_IO; }
+        f.names.emplace_back((const char *)d.data() + o + 4, l_name - 1);
+        f.lens.push_back(rd32(d.data() + o + 4 + l_name));
+        o += 8 + l_name;
+    }
+    // pass 1: count, so the SoA vectors are allocated once
+    size_t n_keep = 0, seq_bytes = 0, cig_words = 0, p = o;
+    while (p + 4 <= n) {
+        const uint32_t bs = rd32(d.data() + p);
+        if (p + 4 + bs > n || bs < 32) { g_decode_error = "truncated BAM record"; return KD_E_IO; }
+        const uint8_t *r = d.data() + p + 4;
+        const int32_t refid = (int32_t)rd32(r);
+        f.n_records++;
+        if (refid >= 0) {
+            if ((uint32_t)refid >= n_ref) { g_decode_error = "BAM record with refID out of range"; return KD_E_IO; }
+            n_keep++;
+            seq_bytes += ((size_t)rd32(r + 16) + 1) / 2;
+            cig_words += rd16(r + 12);
+        }
+        p += 4 + bs;
+    }
+    f.contig.resize(n_keep); f.pos0.resize(n_keep); f.flag.resize(n_keep); f.seq_off.resize(n_keep);
+    f.seq_len.resize(n_keep); f.cig_off.resize(n_keep); f.n_cig.resize(n_keep);
+    f.seq4.resize(seq_bytes); f.cigar.resize(cig_words);
+    size_t k = 0, so = 0, co = 0;
+    p = o;
+    while (p + 4 <= n) {
+        const uint32_t bs = rd32(d.data() + p);
+        const uint8_t *r = d.data() + p + 4;
+        const int32_t refid = (int32_t)rd32(r);
+        if (refid >= 0) {
+            const uint32_t l_rn = r[8], n_cig = rd16(r + 12), flag = rd16(r + 14), l_seq = rd32(r + 16);
+            const size_t need = 32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2;
+            if (need > bs) { g_decode_error = "malformed BAM record"; return KD_E_IO; }
+            f.contig[k] = (uint32_t)refid;
+            f.pos0[k] = (int32_t)rd32(r + 4);
+            f.flag[k] = flag;
+            f.seq_len[k] = l_seq;
+            f.n_cig[k] = n_cig;
+            f.cig_off[k] = co;
+            f.seq_off[k] = so;
+            const uint8_t *cg = r + 32 + l_rn;
+            for (uint32_t c = 0; c < n_cig; c++) f.cigar[co + c] = rd32(cg + 4 * c);
+            co += n_cig;
+            const size_t sb = ((size_t)l_seq + 1) / 2;
+            memcpy(f.seq4.data() + so, cg + 4 * (size_t)n_cig, sb);
+            if (l_seq & 1) f.seq4[so + sb - 1] &= 0xf0;
+            so += sb;
+            k++;
+        }
+        p += 4 + bs;
+    }
+    return KD_OK;
+}
+
+int parse_sam(const std::vector<uint8_t> &raw, File &f) {
+    static int8_t nibtab[256];
+    static int8_t optab[256];
+    static bool init = false;
+    if (!init) {
+        memset(nibtab, 0, sizeof nibtab);  // unknown characters -> '=' (0): a KeyError in M / clip context
+        memset(optab, 15, sizeof optab);   // unknown CIGAR letters are ignored by the reference's if/elif chain
+        const char *nibs = "=ACMGRSVTWYHKDBN";
+        for (int i = 0; i < 16; i++) {
+            nibtab[(uint8_t)nibs[i]] = (int8_t)i;
+            nibtab[(uint8_t)tolower(nibs[i])] = (int8_t)i;
+        }
+        const char *ops = "MIDNSHP=X";
+        for (int i = 0; i < 9; i++) optab[(uint8_t)ops[i]] = (int8_t)i;
+        init = true;
+    }
+    std::unordered_map<std::string, uint32_t> ids;
+    const char *p = (const char *)raw.data(), *end = p + raw.size();
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        const char *e = le;
+        if (e > p && e[-1] == '\r') e--;
+        if (e > p) {
+            if (*p == '@') {
+                if (e - p >= 3 && p[1] == 'S' && p[2] == 'Q') {
+                    std::string name;
+                    long ln = -1;
+                    const char *q = p;
+                    while (q < e) {
+                        const char *t = (const char *)memchr(q, '\t', (size_t)(e - q));
+                        const char *fe = t ? t : e;
+                        if (fe - q > 3 && q[0] == 'S' && q[1] == 'N' && q[2] == ':') name.assign(q + 3, fe);
+                        if (fe - q > 3 && q[0] == 'L' && q[1] == 'N' && q[2] == ':') ln = strtol(std::string(q + 3, fe).c_str(), nullptr, 10);
+                        q = t ? t + 1 : e;
+                    }
+                    if (name.empty() || ln < 0) { g_decode_error = "@SQ line without SN/LN"; return KD_E_IO; }
+                    ids[name] = (uint32_t)f.names.size();
+                    f.names.push_back(name);
+                    f.lens.push_back((uint32_t)ln);
+                }
+            } else {
+                const char *fld[11];
+                int nf = 0;
+                const char *q = p;
+                while (nf < 11 && q <= e) {
+                    fld[nf++] = q;
+                    const char *t = (const char *)memchr(q, '\t', (size_t)(e - q));
+                    if (!t) break;
+                    q = t + 1;
+                }
+                if (nf < 10) { g_decode_error = "SAM record with fewer than 10 fields"; return KD_E_IO; }
+                auto flen = [&](int i) { return (size_t)((i + 1 < nf ? fld[i + 1] - 1 : e) - fld[i]); };
+                f.n_records++;
+                std::string rname(fld[2], flen(2));
+                if (rname != "*") {
+                    auto it = ids.find(rname);
+                    if (it == ids.end()) { g_decode_error = "RNAME '" + rname + "' has no @SQ line"; return KD_E_IO; }
+                    f.contig.push_back(it->second);
+                    f.flag.push_back((uint32_t)strtoul(std::string(fld[1], flen(1)).c_str(), nullptr, 10));
+                    f.pos0.push_back((int32_t)(strtol(std::string(fld[3], flen(3)).c_str(), nullptr, 10) - 1));
+                    f.cig_off.push_back(f.cigar.size());
+                    uint32_t nc = 0;
+                    const char *c = fld[5], *ce = c + flen(5);
+                    if (!(ce - c == 1 && *c == '*')) {
+                        uint64_t num = 0;
+                        for (; c < ce; c++) {
+                            if (*c >= '0' && *c <= '9') num = num * 10 + (uint64_t)(*c - '0');
+                            else {
+                                if (num >= (1ULL << 28)) { g_decode_error = "CIGAR length too large"; return KD_E_IO; }
+                                f.cigar.push_back((uint32_t)(num << 4) | (uint32_t)(uint8_t)optab[(uint8_t)*c]);
+                                num = 0; nc++;
+                            }
+                        }
+                    }
+                    f.n_cig.push_back(nc);
+                    const char *s = fld[9];
+                    size_t sl = flen(9);
+                    if (sl == 1 && *s == '*') sl = 0;
+                    f.seq_off.push_back(f.seq4.size());
+                    f.seq_len.push_back((uint32_t)sl);
+                    for (size_t i = 0; i < sl; i += 2) {
+                        const uint8_t hi = (uint8_t)nibtab[(uint8_t)s[i]];
+                        const uint8_t lo = i + 1 < sl ? (uint8_t)nibtab[(uint8_t)s[i + 1]] : 0;
+                        f.seq4.push_back((uint8_t)(hi << 4 | lo));
+                    }
+                }
+            }
+        }
+        if (!nl) break;
+        p = nl + 1;
+    }
+    return KD_OK;
+}
+
+}  // namespace
+
+struct kd_file {
+    File f;
+};
+
+extern "C" {
+
+int kd_decode_open(kd_file **out, const char *path, int n_threads) {
+    if (!out || !path) return KD_E_ARG;
+    *out = nullptr;
+    std::vector<uint8_t> raw;
+    if (!read_all(path, raw)) { g_decode_error = std::string("cannot read ") + path; return KD_E_IO; }
+    kd_file *h = new kd_file();
+    int rc;
+    if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) {
+        std::vector<uint8_t> data;
+        if (!decompress(raw, data, n_threads)) { delete h; g_decode_error = "gzip/BGZF inflate failed"; return KD_E_IO; }
+        raw.clear();
+        raw.shrink_to_fit();
+        rc = parse_bam(data, h->f);
+    } else {
+        rc = parse_sam(raw, h->f);
+    }
+    if (rc) { delete h; return rc; }
+    finish_view(h->f);
+    *out = h;
+    return KD_OK;
+}
+
+const char *kd_decode_last_error(void) { return g_decode_error.c_str(); }
+const kd_batch *kd_decode_batch(const kd_file *f) { return f ? &f->f.view : nullptr; }
+uint32_t kd_decode_n_contigs(const kd_file *f) { return f ? (uint32_t)f->f.names.size() : 0; }
+const char *kd_decode_contig_name(const kd_file *f, uint32_t i) { return (f && i < f->f.names.size()) ? f->f.names[i].c_str() : nullptr; }
+uint32_t kd_decode_contig_len(const kd_file *f, uint32_t i) { return (f && i < f->f.lens.size()) ? f->f.lens[i] : 0; }
+uint64_t kd_decode_n_records(const kd_file *f) { return f ? f->f.n_records : 0; }
+void kd_decode_close(kd_file *f) { delete f; }
+
+}  // extern "C"

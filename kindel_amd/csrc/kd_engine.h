@@ -1,0 +1,475 @@
+// kd_engine.h -- host-side orchestration of the kernels in kd_kernels.h.
+//
+// KdEngine<Rt> owns the device tables and sequences the launches for one GPU / one stream.
+// `Rt` is the runtime policy: kindel_hip.hip instantiates it with the HIP runtime (the
+// product); tests/emu/emu_lib.cpp instantiates it with the CPU kernel emulator (test
+// infrastructure for kernel logic, never shipped).
+//
+// Reference correspondence: push_batch = the record loop of parse_records
+// (/root/reference/kindel/kindel.py:40-81), finalize = the insertions dicts (:38,55-58) +
+// consensus(insertions[pos]) (:420), consensus_run = consensus_sequence (:384-430).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kindel_hip.h"
+#include "kd_kernels.h"
+
+template <class Rt>
+struct KdEngine {
+    Rt rt;
+    std::string err;
+    uint32_t n_contigs = 0;
+    std::vector<uint32_t> clen;
+    std::vector<uint64_t> cbase;
+    uint64_t S = 0;  // G-space sites, multiple of 1024 (consensus tile)
+    uint64_t g_lo = 0, g_hi = 0;  // emit interval [g_lo, g_hi)
+    int mode = KD_MODE_AUTO;
+    uint32_t W = 2048, slice_cfg = 0;
+
+    uint32_t *d_tab = nullptr, *d_clen = nullptr, *d_seg = nullptr;
+    kd_u64 *d_cbase = nullptr, *d_status = nullptr;
+    std::vector<kd_u64> h_status = std::vector<kd_u64>(KDS_COUNT, 0);
+
+    // grow-only device buffers
+    struct Buf {
+        void *p = nullptr;
+        size_t cap = 0;
+    };
+    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff;
+    Buf b_stage[9];
+    Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
+    uint64_t ev_cap = 0, pool_cap = 0;
+    Buf b_hkey, b_hcnt, b_hrep, b_evslot, b_best, b_win;
+    uint64_t hash_cap = 0;
+    Buf b_cns, b_changes, b_tilesum, b_tileoff, b_coff, b_minmax, b_pstart, b_pend, b_poff;
+
+    uint64_t reads_pushed = 0;
+    uint64_t last_windowed = 0;
+    bool finalized = false, have_cns = false;
+    uint64_t n_ev_final = 0, pool_final = 0;
+    // host copies of the last consensus run
+    std::vector<kd_u64> h_coff;
+    std::vector<uint32_t> h_minmax;
+    std::vector<kd_u64> h_pstart, h_poff;
+    // host copy of the insertion table (kd_get_insertions)
+    struct InsKey { uint32_t site, count, len; uint64_t off; uint32_t rep; };
+    std::vector<InsKey> h_inskeys;
+    std::vector<uint8_t> h_insbytes;
+    bool have_inskeys = false;
+
+    int fail(int code, const std::string &m) { err = m; return code; }
+    int hipfail(const char *what) { return fail(KD_E_HIP, std::string(what) + ": " + rt.err()); }
+
+    int ensure(Buf &b, size_t bytes, bool keep = false, size_t keep_bytes = 0) {
+        if (bytes <= b.cap) return KD_OK;
+        size_t ncap = std::max(bytes, b.cap + b.cap / 2);
+        ncap = (ncap + 255) & ~size_t(255);
+        void *np = rt.alloc(ncap);
+        if (!np) return fail(KD_E_NOMEM, "device allocation of " + std::to_string(ncap) + " bytes failed: " + rt.err());
+        if (keep && b.p && keep_bytes) {
+            if (rt.d2d(np, b.p, keep_bytes)) return hipfail("d2d");
+            if (rt.sync()) return hipfail("sync");
+        }
+        if (b.p) rt.free(b.p);
+        b.p = np; b.cap = ncap;
+        return KD_OK;
+    }
+    void release(Buf &b) { if (b.p) rt.free(b.p); b.p = nullptr; b.cap = 0; }
+
+    KdTabs tabs() const {
+        KdTabs T;
+        T.tab = d_tab; T.stride = S; T.contig_len = d_clen; T.contig_base = d_cbase;
+        T.g_lo = g_lo; T.g_hi = g_hi;  // commit includes the halo site g_hi
+        return T;
+    }
+    KdIns insdesc() const {
+        KdIns I;
+        I.ev_site = (uint32_t *)b_ev_site.p; I.ev_len = (uint32_t *)b_ev_len.p; I.ev_off = (kd_u64 *)b_ev_off.p;
+        I.pool = (uint8_t *)b_pool.p; I.ev_cap = ev_cap; I.pool_cap = pool_cap;
+        return I;
+    }
+
+    int create(int device, uint32_t n, const uint32_t *lens, void *stream) {
+        if (!n || !lens) return fail(KD_E_ARG, "kd_create: no contigs");
+        if (rt.init(device, stream)) return hipfail("kd_create: device init");
+        n_contigs = n;
+        clen.assign(lens, lens + n);
+        cbase.resize(n);
+        uint64_t g = 0;
+        for (uint32_t c = 0; c < n; c++) {
+            cbase[c] = g;
+            g += ((uint64_t)lens[c] + 1 + 63) & ~uint64_t(63);  // len+1 slots (kindel.py:36-39), padded to 64
+        }
+        S = (g + KD_CNS_TILE - 1) / KD_CNS_TILE * KD_CNS_TILE;
+        if (S >= 0xfffffff0ULL) return fail(KD_E_ARG, "kd_create: more than 2^32 reference sites");
+        g_lo = 0; g_hi = S;
+        d_tab = (uint32_t *)rt.alloc((size_t)KDC_NCH * S * 4);
+        d_clen = (uint32_t *)rt.alloc((size_t)n * 4);
+        d_cbase = (kd_u64 *)rt.alloc((size_t)n * 8);
+        d_seg = (uint32_t *)rt.alloc((size_t)(S / 64) * 4);
+        d_status = (kd_u64 *)rt.alloc(KDS_COUNT * 8);
+        if (!d_tab || !d_clen || !d_cbase || !d_seg || !d_status)
+            return fail(KD_E_NOMEM, "kd_create: device allocation failed (" + std::to_string((size_t)KDC_NCH * S * 4) + " table bytes): " + rt.err());
+        std::vector<uint32_t> seg(S / 64, n - 1);
+        for (uint32_t c = 0; c < n; c++) {
+            uint64_t e = c + 1 < n ? cbase[c + 1] : S;
+            for (uint64_t s = cbase[c] / 64; s < e / 64; s++) seg[s] = c;
+        }
+        if (rt.h2d(d_clen, clen.data(), (size_t)n * 4) || rt.h2d(d_cbase, cbase.data(), (size_t)n * 8) ||
+            rt.h2d(d_seg, seg.data(), seg.size() * 4))
+            return hipfail("kd_create: upload");
+        if (rt.sync()) return hipfail("kd_create: sync");
+        return reset();
+    }
+
+    void destroy() {
+        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_ev_site, &b_ev_len,
+                      &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_win, &b_cns, &b_changes,
+                      &b_tilesum, &b_tileoff, &b_coff, &b_minmax, &b_pstart, &b_pend, &b_poff};
+        for (Buf *b : all) release(*b);
+        for (Buf &b : b_stage) release(b);
+        if (d_tab) rt.free(d_tab);
+        if (d_clen) rt.free(d_clen);
+        if (d_cbase) rt.free(d_cbase);
+        if (d_seg) rt.free(d_seg);
+        if (d_status) rt.free(d_status);
+        d_tab = d_clen = d_seg = nullptr; d_cbase = d_status = nullptr;
+        rt.shutdown();
+    }
+
+    int reset() {
+        if (rt.memset(d_tab, 0, (size_t)KDC_NCH * S * 4)) return hipfail("reset: memset tables");
+        std::fill(h_status.begin(), h_status.end(), 0);
+        h_status[KDS_ERR_READ] = ~0ULL;
+        if (rt.h2d(d_status, h_status.data(), KDS_COUNT * 8)) return hipfail("reset: status");
+        reads_pushed = 0; finalized = false; have_cns = false; have_inskeys = false;
+        return KD_OK;
+    }
+
+    int set_shard(uint64_t lo, uint64_t hi) {
+        if (lo > hi || hi > S) return fail(KD_E_ARG, "kd_set_shard: bad interval");
+        if (reads_pushed) return fail(KD_E_ARG, "kd_set_shard: call before the first batch (or after kd_reset)");
+        g_lo = lo; g_hi = hi;
+        return KD_OK;
+    }
+
+    int fetch_status() {
+        if (rt.d2h(h_status.data(), d_status, KDS_COUNT * 8)) return hipfail("status d2h");
+        return KD_OK;
+    }
+
+    // ---- pileup ----
+    int push_device(const kd_batch &B) {
+        const uint64_t n = B.n_reads;
+        if (!n) return KD_OK;
+        if (n >= 0xffffffffULL) return fail(KD_E_ARG, "kd_push_batch: more than 2^32-1 reads in one batch");
+        int rc;
+        if ((rc = ensure(b_rinfo, n * sizeof(KdRInfo))) || (rc = ensure(b_cold, n * 4)) ||
+            (rc = ensure(b_irreg, n * 4)) || (rc = ensure(b_long, n * 4)))
+            return rc;
+        KdReads R;
+        R.n = n; R.base_index = reads_pushed;
+        R.contig = B.contig; R.pos0 = B.pos0; R.flag = B.flag; R.seq_off = (const kd_u64 *)B.seq_off;
+        R.seq_len = B.seq_len; R.cig_off = (const kd_u64 *)B.cig_off; R.n_cig = B.n_cig; R.seq4 = B.seq4;
+        R.cigar = B.cigar;
+        KdTabs T = tabs();
+        KdRInfo *rinfo = (KdRInfo *)b_rinfo.p;
+        uint32_t *cold = (uint32_t *)b_cold.p, *irreg = (uint32_t *)b_irreg.p, *lng = (uint32_t *)b_long.p;
+        // per-batch status words are contiguous: KDS_B_INS_OPS .. KDS_TOTAL_ITEMS
+        if (rt.memset(d_status + KDS_B_INS_OPS, 0, (size_t)(KDS_TOTAL_ITEMS - KDS_B_INS_OPS + 1) * 8))
+            return hipfail("push: memset status");
+        const unsigned prep_grid = (unsigned)((n + KD_PREP_CHUNK - 1) / KD_PREP_CHUNK);
+        if (rt.launch("k_prep", k_prep, prep_grid, KD_BLOCK, 0, R, T, rinfo, cold, irreg, lng, d_status))
+            return hipfail("k_prep");
+        if ((rc = fetch_status())) return rc;
+        if (h_status[KDS_B_N_LONG]) {
+            if (rt.launch("k_prep_long", k_prep_long, (unsigned)h_status[KDS_B_N_LONG], KD_BLOCK, 0, R, T, rinfo,
+                          (const uint32_t *)lng, cold, irreg, d_status))
+                return hipfail("k_prep_long");
+            if ((rc = fetch_status())) return rc;
+        }
+        // size the insertion event buffers from the exact counts of this batch
+        const uint64_t need_ev = h_status[KDS_N_EV] + h_status[KDS_B_INS_OPS];
+        const uint64_t need_pool = h_status[KDS_POOL] + h_status[KDS_B_INS_BASES];
+        if (need_ev > ev_cap) {
+            uint64_t ncap = std::max<uint64_t>(need_ev, ev_cap + ev_cap / 2);
+            const uint64_t used = h_status[KDS_N_EV];
+            if ((rc = ensure(b_ev_site, ncap * 4, true, used * 4)) || (rc = ensure(b_ev_len, ncap * 4, true, used * 4)) ||
+                (rc = ensure(b_ev_off, ncap * 8, true, used * 8)))
+                return rc;
+            ev_cap = ncap;
+        }
+        if (need_pool > pool_cap) {
+            uint64_t ncap = std::max<uint64_t>(need_pool, pool_cap + pool_cap / 2);
+            if ((rc = ensure(b_pool, ncap, true, h_status[KDS_POOL]))) return rc;
+            pool_cap = ncap;
+        }
+        KdIns I = insdesc();
+        const uint64_t n_reg = h_status[KDS_B_N_REG], n_cold = h_status[KDS_B_N_COLD], n_irreg = h_status[KDS_B_N_IRREG];
+        const bool windowed = (mode != KD_MODE_GLOBAL) && h_status[KDS_B_UNSORTED] == 0 && n_reg > 0;
+        last_windowed = windowed ? 1 : 0;
+        if (windowed) {
+            const uint32_t n_win = (uint32_t)((S + W - 1) / W);
+            uint32_t slice = slice_cfg;
+            if (!slice) {  // aim for a few thousand work items, slices big enough to amortise the LDS flush
+                uint64_t s = n / 4096;
+                slice = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(256, s));
+            }
+            if ((rc = ensure(b_winlo, (size_t)n_win * 8)) || (rc = ensure(b_winhi, (size_t)n_win * 8)) ||
+                (rc = ensure(b_itemoff, ((size_t)n_win + 1) * 8)))
+                return rc;
+            kd_u64 *wl = (kd_u64 *)b_winlo.p, *wh = (kd_u64 *)b_winhi.p, *io = (kd_u64 *)b_itemoff.p;
+            if (rt.launch("k_plan", k_plan, 1u, KD_BLOCK, 0, (const KdRInfo *)rinfo, (kd_u64)n, n_win, W, slice, wl, wh,
+                          io, d_status))
+                return hipfail("k_plan");
+            const size_t lds = (size_t)6 * W * 4;
+            const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 1024) / (lds + 64)));
+            const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
+            if (rt.launch("k_window", k_window, grid, KD_BLOCK, lds, R, (const KdRInfo *)rinfo, T, (const kd_u64 *)wl,
+                          (const kd_u64 *)wh, (const kd_u64 *)io, n_win, W, slice, d_status))
+                return hipfail("k_window");
+            if (n_cold &&
+                rt.launch("k_pileup_wave_cold", k_pileup_wave<false, true>,
+                          (unsigned)((n_cold + KD_WAVES_PER_BLOCK - 1) / KD_WAVES_PER_BLOCK), KD_BLOCK, 0, R, T, I,
+                          (const uint32_t *)cold, (kd_u64)n_cold, (const KdRInfo *)rinfo, d_status))
+                return hipfail("k_pileup_wave_cold");
+            if (n_irreg &&
+                rt.launch("k_pileup_wave_irreg", k_pileup_wave<true, true>,
+                          (unsigned)((n_irreg + KD_WAVES_PER_BLOCK - 1) / KD_WAVES_PER_BLOCK), KD_BLOCK, 0, R, T, I,
+                          (const uint32_t *)irreg, (kd_u64)n_irreg, (const KdRInfo *)rinfo, d_status))
+                return hipfail("k_pileup_wave_irreg");
+        } else {
+            if (rt.launch("k_pileup_wave_all", k_pileup_wave<true, true>,
+                          (unsigned)((n + KD_WAVES_PER_BLOCK - 1) / KD_WAVES_PER_BLOCK), KD_BLOCK, 0, R, T, I,
+                          (const uint32_t *)nullptr, (kd_u64)n, (const KdRInfo *)rinfo, d_status))
+                return hipfail("k_pileup_wave_all");
+        }
+        if (rt.launch("k_diagnose", k_diagnose, 1u, KD_WAVE, 0, R, T, d_status)) return hipfail("k_diagnose");
+        reads_pushed += n;
+        finalized = false; have_cns = false; have_inskeys = false;
+        return KD_OK;
+    }
+
+    int push_host(const kd_batch &B) {
+        const uint64_t n = B.n_reads;
+        if (!n) return KD_OK;
+        const void *src[9] = {B.contig, B.pos0, B.flag, B.seq_off, B.seq_len, B.cig_off, B.n_cig, B.seq4, B.cigar};
+        const size_t bytes[9] = {n * 4, n * 4, n * 4, n * 8, n * 4, n * 8, n * 4, (size_t)B.seq4_bytes + 8,
+                                 (size_t)B.cigar_words * 4 + 8};
+        const size_t copy[9] = {n * 4, n * 4, n * 4, n * 8, n * 4, n * 8, n * 4, (size_t)B.seq4_bytes,
+                                (size_t)B.cigar_words * 4};
+        int rc;
+        // the previous batch's kernels read the staging buffers: drain before overwriting
+        if (rt.sync()) return hipfail("push: sync");
+        for (int k = 0; k < 9; k++) {
+            if ((rc = ensure(b_stage[k], bytes[k]))) return rc;
+            if (copy[k] && rt.h2d(b_stage[k].p, src[k], copy[k])) return hipfail("push: h2d");
+        }
+        kd_batch D = B;
+        D.contig = (const uint32_t *)b_stage[0].p; D.pos0 = (const int32_t *)b_stage[1].p;
+        D.flag = (const uint32_t *)b_stage[2].p; D.seq_off = (const uint64_t *)b_stage[3].p;
+        D.seq_len = (const uint32_t *)b_stage[4].p; D.cig_off = (const uint64_t *)b_stage[5].p;
+        D.n_cig = (const uint32_t *)b_stage[6].p; D.seq4 = (const uint8_t *)b_stage[7].p;
+        D.cigar = (const uint32_t *)b_stage[8].p;
+        return push_device(D);
+    }
+
+    // ---- finalize: insertion multiset -> per-site winner ----
+    int finalize(uint64_t *err_read) {
+        int rc;
+        if ((rc = fetch_status())) return rc;
+        if (h_status[KDS_INTERNAL]) return fail(KD_E_INTERNAL, "insertion event buffers overran (internal error)");
+        if (h_status[KDS_ERR_READ] != ~0ULL) {
+            if (err_read) *err_read = h_status[KDS_ERR_READ];
+            const uint64_t code = h_status[KDS_ERR_CODE];
+            const std::string at = " (read " + std::to_string(h_status[KDS_ERR_READ]) + ")";
+            if (code == 1) return fail(KD_E_BASE, "base outside A,C,G,T,N in an aligned or clipped segment" + at);
+            if (code == 2) return fail(KD_E_RANGE, "list index out of range: alignment runs off the reference" + at);
+            if (code == 3) return fail(KD_E_CIGAR, "mapped read with CIGAR '*'" + at);
+            return fail(KD_E_INTERNAL, "read flagged by a kernel but no reference exception reproduced" + at);
+        }
+        if ((rc = ensure(b_win, (size_t)S * 4))) return rc;
+        if (rt.memset(b_win.p, 0xff, (size_t)S * 4)) return hipfail("finalize: memset win");
+        const uint64_t n_ev = h_status[KDS_N_EV];
+        n_ev_final = n_ev; pool_final = h_status[KDS_POOL];
+        if (n_ev) {
+            uint64_t cap = 1024;
+            while (cap < 2 * n_ev) cap <<= 1;
+            if (cap >= 0xfffffff0ULL) return fail(KD_E_NOMEM, "too many insertion events");
+            hash_cap = cap;
+            if ((rc = ensure(b_hkey, cap * 8)) || (rc = ensure(b_hcnt, cap * 4)) || (rc = ensure(b_hrep, cap * 4)) ||
+                (rc = ensure(b_evslot, n_ev * 4)) || (rc = ensure(b_best, (size_t)S * 8)))
+                return rc;
+            KdIns I = insdesc();
+            KdInsTab H;
+            H.key = (kd_u64 *)b_hkey.p; H.cnt = (uint32_t *)b_hcnt.p; H.rep = (uint32_t *)b_hrep.p;
+            H.ev_slot = (uint32_t *)b_evslot.p; H.cap = cap;
+            const unsigned ge = (unsigned)((n_ev + KD_BLOCK - 1) / KD_BLOCK), gs = (unsigned)((cap + KD_BLOCK - 1) / KD_BLOCK);
+            bool ok = false;
+            for (int attempt = 0; attempt < 8 && !ok; attempt++) {
+                H.seed = 0x9e3779b97f4a7c15ULL * (uint64_t)(attempt + 1);
+                if (rt.memset(H.key, 0, cap * 8) || rt.memset(H.cnt, 0, cap * 4) || rt.memset(H.rep, 0xff, cap * 4) ||
+                    rt.memset(d_status + KDS_INS_COLLISION, 0, 8))
+                    return hipfail("finalize: memset hash");
+                if (rt.launch("k_ins_insert", k_ins_insert, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev)) return hipfail("k_ins_insert");
+                if (rt.launch("k_ins_verify", k_ins_verify, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev, d_status))
+                    return hipfail("k_ins_verify");
+                if ((rc = fetch_status())) return rc;
+                ok = h_status[KDS_INS_COLLISION] == 0;
+            }
+            if (!ok) return fail(KD_E_INTERNAL, "insertion hash: repeated 64-bit collisions");
+            if (rt.memset(b_best.p, 0, (size_t)S * 8)) return hipfail("finalize: memset best");
+            kd_u64 *best = (kd_u64 *)b_best.p;
+            uint32_t *win = (uint32_t *)b_win.p;
+            if (rt.launch("k_ins_site_max", k_ins_site_max, gs, KD_BLOCK, 0, I, H, best) ||
+                rt.launch("k_ins_site_tie", k_ins_site_tie, gs, KD_BLOCK, 0, I, H, (const kd_u64 *)best, win) ||
+                rt.launch("k_ins_site_win", k_ins_site_win, gs, KD_BLOCK, 0, I, H, (const kd_u64 *)best, win))
+                return hipfail("k_ins_site_*");
+        }
+        finalized = true; have_cns = false; have_inskeys = false;
+        return KD_OK;
+    }
+
+    int get_stats(uint64_t out[4]) {
+        int rc;
+        if ((rc = fetch_status())) return rc;
+        out[0] = h_status[KDS_ST_READS]; out[1] = h_status[KDS_ST_ALIGNED]; out[2] = h_status[KDS_ST_WALKED];
+        out[3] = h_status[KDS_ST_INS];
+        return KD_OK;
+    }
+
+    int get_tables(uint32_t contig, uint32_t n_ch, const uint32_t *channels, uint32_t *out) {
+        if (contig >= n_contigs) return fail(KD_E_ARG, "kd_get_tables: bad contig");
+        const size_t L1 = (size_t)clen[contig] + 1;
+        for (uint32_t k = 0; k < n_ch; k++) {
+            if (channels[k] >= KDC_NCH) return fail(KD_E_ARG, "kd_get_tables: bad channel");
+            if (rt.d2h(out + (size_t)k * L1, d_tab + (size_t)channels[k] * S + cbase[contig], L1 * 4))
+                return hipfail("kd_get_tables: d2h");
+        }
+        return KD_OK;
+    }
+
+    int load_inskeys() {
+        if (have_inskeys) return KD_OK;
+        h_inskeys.clear(); h_insbytes.clear();
+        if (n_ev_final) {
+            std::vector<kd_u64> key(hash_cap), off(n_ev_final);
+            std::vector<uint32_t> cnt(hash_cap), rep(hash_cap), site(n_ev_final), len(n_ev_final);
+            std::vector<uint8_t> pool(pool_final + 1);
+            if (rt.d2h(key.data(), b_hkey.p, hash_cap * 8) || rt.d2h(cnt.data(), b_hcnt.p, hash_cap * 4) ||
+                rt.d2h(rep.data(), b_hrep.p, hash_cap * 4) || rt.d2h(site.data(), b_ev_site.p, n_ev_final * 4) ||
+                rt.d2h(len.data(), b_ev_len.p, n_ev_final * 4) || rt.d2h(off.data(), b_ev_off.p, n_ev_final * 8) ||
+                (pool_final && rt.d2h(pool.data(), b_pool.p, pool_final)))
+                return hipfail("kd_get_insertions: d2h");
+            for (uint64_t s = 0; s < hash_cap; s++)
+                if (key[s]) {
+                    const uint32_t r = rep[s];
+                    h_inskeys.push_back({site[r], cnt[s], len[r], off[r], r});
+                }
+            std::sort(h_inskeys.begin(), h_inskeys.end(), [](const InsKey &a, const InsKey &b) {
+                return a.site != b.site ? a.site < b.site : a.rep < b.rep;
+            });
+            static const char N2C[17] = "=ACMGRSVTWYHKDBN";
+            for (auto &k : h_inskeys) {
+                const uint64_t o = h_insbytes.size();
+                for (uint32_t b = 0; b < k.len; b++) h_insbytes.push_back((uint8_t)N2C[pool[k.off + b] & 15]);
+                k.off = o;
+            }
+        }
+        have_inskeys = true;
+        return KD_OK;
+    }
+
+    int get_insertions(uint32_t contig, uint64_t *n_keys, uint64_t *n_bytes, uint32_t *site, uint32_t *count,
+                       uint32_t *len, uint64_t *off, uint8_t *bytes) {
+        if (contig >= n_contigs) return fail(KD_E_ARG, "kd_get_insertions: bad contig");
+        if (!finalized) return fail(KD_E_ARG, "kd_get_insertions: call kd_finalize first");
+        int rc;
+        if ((rc = load_inskeys())) return rc;
+        const uint64_t lo = cbase[contig], hi = cbase[contig] + clen[contig];  // slots 0..len inclusive
+        uint64_t nk = 0, nb = 0;
+        for (const auto &k : h_inskeys)
+            if (k.site >= lo && k.site <= hi) {
+                if (site) {
+                    site[nk] = (uint32_t)(k.site - lo); count[nk] = k.count; len[nk] = k.len; off[nk] = nb;
+                    if (k.len) memcpy(bytes + nb, h_insbytes.data() + k.off, k.len);
+                }
+                nk++; nb += k.len;
+            }
+        if (n_keys) *n_keys = nk;
+        if (n_bytes) *n_bytes = nb;
+        return KD_OK;
+    }
+
+    // ---- consensus ----
+    int consensus_run(uint32_t min_depth, uint32_t n_patches, const uint64_t *ps, const uint64_t *pe) {
+        if (!finalized) return fail(KD_E_ARG, "kd_consensus_run: call kd_finalize first");
+        int rc;
+        const uint64_t n_tiles = S / KD_CNS_TILE;
+        const uint64_t cap = S + pool_final + 64;
+        if ((rc = ensure(b_cns, cap)) || (rc = ensure(b_changes, S)) || (rc = ensure(b_tilesum, n_tiles * 8)) ||
+            (rc = ensure(b_tileoff, (n_tiles + 1) * 8)) || (rc = ensure(b_coff, ((size_t)n_contigs + 1) * 8)) ||
+            (rc = ensure(b_minmax, (size_t)n_contigs * 8)) || (rc = ensure(b_pstart, (size_t)(n_patches + 1) * 8)) ||
+            (rc = ensure(b_pend, (size_t)(n_patches + 1) * 8)) || (rc = ensure(b_poff, (size_t)(n_patches + 1) * 8)))
+            return rc;
+        std::vector<uint32_t> mm(2 * (size_t)n_contigs);
+        for (uint32_t c = 0; c < n_contigs; c++) { mm[2 * c] = 0xffffffffu; mm[2 * c + 1] = 0; }
+        if (rt.h2d(b_minmax.p, mm.data(), mm.size() * 4)) return hipfail("consensus: h2d");
+        if (n_patches && (rt.h2d(b_pstart.p, ps, (size_t)n_patches * 8) || rt.h2d(b_pend.p, pe, (size_t)n_patches * 8)))
+            return hipfail("consensus: h2d patches");
+        if (rt.memset(b_poff.p, 0xff, (size_t)(n_patches + 1) * 8)) return hipfail("consensus: memset");
+        KdTabs T = tabs();
+        KdIns I = insdesc();
+        KdCns C;
+        C.seg_contig = d_seg; C.ins_win = (const uint32_t *)b_win.p; C.min_depth = min_depth; C.n_patches = n_patches;
+        C.patch_start = (const kd_u64 *)b_pstart.p; C.patch_end = (const kd_u64 *)b_pend.p;
+        C.g_lo = g_lo; C.g_hi = g_hi;
+        if (rt.launch("k_cns_count", k_cns_count, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64 *)b_tilesum.p,
+                      (uint32_t *)b_minmax.p))
+            return hipfail("k_cns_count");
+        if (rt.launch("k_cns_scan", k_cns_scan, 1u, KD_BLOCK, 0, (const kd_u64 *)b_tilesum.p, (kd_u64 *)b_tileoff.p,
+                      (kd_u64)n_tiles))
+            return hipfail("k_cns_scan");
+        if (rt.launch("k_cns_emit", k_cns_emit, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (const kd_u64 *)b_tileoff.p,
+                      (uint8_t *)b_cns.p, (uint8_t *)b_changes.p, (kd_u64 *)b_coff.p, n_contigs, (kd_u64 *)b_poff.p))
+            return hipfail("k_cns_emit");
+        h_coff.assign((size_t)n_contigs + 1, 0);
+        h_minmax.assign(2 * (size_t)n_contigs, 0);
+        h_pstart.assign(ps, ps + n_patches);
+        h_poff.assign(n_patches, ~0ULL);
+        if (rt.d2h(h_coff.data(), b_coff.p, (size_t)n_contigs * 8) ||
+            rt.d2h(&h_coff[n_contigs], (kd_u64 *)b_tileoff.p + n_tiles, 8) ||
+            rt.d2h(h_minmax.data(), b_minmax.p, h_minmax.size() * 4) ||
+            (n_patches && rt.d2h(h_poff.data(), b_poff.p, (size_t)n_patches * 8)))
+            return hipfail("consensus: d2h");
+        if (h_coff[n_contigs] > cap) return fail(KD_E_INTERNAL, "consensus longer than its buffer");
+        have_cns = true;
+        return KD_OK;
+    }
+
+    int consensus_fetch(uint32_t contig, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint8_t *changes,
+                        uint32_t *depth_minmax, uint64_t *patch_off) {
+        if (!have_cns) return fail(KD_E_ARG, "kd_consensus_fetch: call kd_consensus_run first");
+        if (contig >= n_contigs) return fail(KD_E_ARG, "kd_consensus_fetch: bad contig");
+        const uint64_t o0 = h_coff[contig], o1 = h_coff[contig + 1];
+        if (len_out) *len_out = o1 - o0;
+        if (seq_out) {
+            if (o1 - o0 > cap) return fail(KD_E_ARG, "kd_consensus_fetch: buffer too small");
+            if (o1 > o0 && rt.d2h(seq_out, (uint8_t *)b_cns.p + o0, o1 - o0)) return hipfail("consensus fetch: d2h");
+        }
+        if (changes && clen[contig] && rt.d2h(changes, (uint8_t *)b_changes.p + cbase[contig], clen[contig]))
+            return hipfail("consensus fetch: d2h changes");
+        if (depth_minmax) { depth_minmax[0] = h_minmax[2 * contig]; depth_minmax[1] = h_minmax[2 * contig + 1]; }
+        if (patch_off)
+            for (size_t k = 0; k < h_pstart.size(); k++) {
+                const bool mine = h_pstart[k] >= cbase[contig] && h_pstart[k] < cbase[contig] + clen[contig];
+                patch_off[k] = (mine && h_poff[k] != ~0ULL) ? h_poff[k] - o0 : ~0ULL;
+            }
+        return KD_OK;
+    }
+};

@@ -1,0 +1,1000 @@
+// kd_kernels.h -- device code of the MI355X (gfx950 / CDNA4) pileup + consensus engine.
+//
+// Replaces the two Python loops of the reference:
+//   parse_records record/CIGAR loop      /root/reference/kindel/kindel.py:40-81
+//   consensus_sequence per-site loop     /root/reference/kindel/kindel.py:384-430
+// (plus consensus() :369-381 and the depth min/max of build_report :450,477-479).
+//
+// This is integer histogramming: HBM/LDS-atomic bound, no MFMA.  Layout and kernels are
+// described in DESIGN.md.  Short version:
+//   tables   u32 tab[KD_NCH][S]  channel-major over "G-space" (all contigs back to back,
+//            len+1 slots each, padded to 64) so that 64 lanes walking 64 consecutive sites
+//            hit 64 consecutive dwords (coalesced atomics / stores, conflict-free LDS banks).
+//   k_prep        lane per read: classify, reference span, counts -> sizes the event buffers
+//   k_plan        window -> candidate-read range (binary search on sorted starts) -> work items
+//   k_window      persistent workgroups pull (window, slice) items; one wavefront walks one
+//                 read's CIGAR; base tallies go to an LDS histogram [6][W]; one coalesced
+//                 flush of the non-zero counters per item (atomicAdd, u32) into HBM
+//   k_pileup_wave one wavefront per read, every reference quirk, 32-bit atomics straight to
+//                 HBM: soft-clip tables, insertion events, irregular reads, KD_MODE_GLOBAL
+//   k_ins_*       insertion events -> open-addressing hash multiset -> per-site unique max
+//   k_cns_*       per-site argmax / tie / indel rules, exclusive scan, byte emission
+//
+// The file has no host API calls and only uses __syncthreads + atomics across lanes, so
+// tests/emu/ can execute the same source on the CPU for logic checks (test infrastructure).
+#pragma once
+#include <stdint.h>
+
+typedef unsigned long long kd_u64;
+
+#ifndef KD_DYN_SHARED
+#define KD_DYN_SHARED(type, name)                                                  \
+    extern __shared__ __attribute__((aligned(16))) unsigned char kd_dyn_smem_[];  \
+    type *name = reinterpret_cast<type *>(kd_dyn_smem_)
+#endif
+
+#define KD_WAVE 64
+#define KD_BLOCK 256
+#define KD_WAVES_PER_BLOCK (KD_BLOCK / KD_WAVE)
+
+// channel ids (mirrors include/kindel_hip.h)
+#define KDC_A 0
+#define KDC_T 1
+#define KDC_G 2
+#define KDC_C 3
+#define KDC_N 4
+#define KDC_DEL 5
+#define KDC_CSW 6
+#define KDC_CEW 11
+#define KDC_CLIP_STARTS 16
+#define KDC_CLIP_ENDS 17
+#define KDC_INS_TOTAL 18
+#define KDC_NCH 19
+
+// read classes written by k_prep
+#define KD_CLS_SKIP 0u    // flag & 4 or len(seq) <= 1                      kindel.py:43-46
+#define KD_CLS_REG 1u     // no wrap, no overhang, no reference exception possible except a bad base
+#define KD_CLS_IRREG 2u   // everything else: walked with exact Python semantics by k_pileup_wave
+#define KD_CLS_LONG 3u    // transient: CIGAR too long for the per-lane scan, k_prep_long decides
+#define KD_INFO_COLD 4u   // read has S or I ops (soft-clip tables / insertion events)
+
+// device status words (kd_u64 each)
+enum {
+    KDS_ERR_READ = 0,   // atomicMin of the global index of the first failing read (init ~0)
+    KDS_ERR_CODE,       // written by k_diagnose
+    KDS_N_EV,           // insertion events used
+    KDS_POOL,           // insertion pool bytes used
+    KDS_ST_READS,       // reads counted
+    KDS_ST_ALIGNED,     // aligned-base events
+    KDS_ST_WALKED,      // walked events
+    KDS_ST_INS,         // insertion ops seen
+    KDS_B_INS_OPS,      // per batch: insertion ops
+    KDS_B_INS_BASES,    // per batch: insertion bases
+    KDS_B_MAXSPAN,      // per batch: max hot span of regular reads
+    KDS_B_UNSORTED,     // per batch: reads not sorted by G-start
+    KDS_B_N_COLD,       // per batch: entries in the cold list
+    KDS_B_N_IRREG,      // per batch: entries in the irregular list
+    KDS_B_N_LONG,       // per batch: entries in the long-CIGAR list
+    KDS_B_N_REG,        // per batch: regular reads
+    KDS_NEXT_ITEM,      // window work queue head
+    KDS_TOTAL_ITEMS,    // window work queue length
+    KDS_INS_COLLISION,  // hash verification failed
+    KDS_INTERNAL,       // capacity overrun etc.
+    KDS_COUNT
+};
+
+struct KdTabs {
+    uint32_t *tab;               // [KDC_NCH][stride]
+    kd_u64 stride;               // S = total G-space sites (multiple of 64)
+    const uint32_t *contig_len;  // [n_contigs]
+    const kd_u64 *contig_base;   // [n_contigs]
+    kd_u64 g_lo, g_hi;           // commit increments with g_lo <= g <= g_hi (g_hi = halo site)
+};
+
+struct KdReads {
+    kd_u64 n;
+    kd_u64 base_index;  // global index of read 0 (over all pushed batches)
+    const uint32_t *contig;
+    const int32_t *pos0;
+    const uint32_t *flag;
+    const kd_u64 *seq_off;
+    const uint32_t *seq_len;
+    const kd_u64 *cig_off;
+    const uint32_t *n_cig;
+    const uint8_t *seq4;
+    const uint32_t *cigar;
+};
+
+struct KdRInfo {
+    uint32_t gstart;    // contig_base + max(pos0, 0)
+    uint32_t span_cls;  // hot span << 3 | KD_INFO_COLD | class
+};
+
+struct KdIns {
+    uint32_t *ev_site;  // [ev_cap] G-space site
+    uint32_t *ev_len;   // [ev_cap] bases
+    kd_u64 *ev_off;     // [ev_cap] offset into pool
+    uint8_t *pool;      // one 4-bit base code per byte
+    kd_u64 ev_cap, pool_cap;
+};
+
+// ---------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------
+
+// BAM nibble -> weight channel in the reference's dict order A,T,G,C,N (kindel.py:29);
+// 7 = not a key of that dict (KeyError in the reference).
+__device__ __forceinline__ uint32_t kd_chan(uint32_t nib) {
+    return (uint32_t)((0x4777777177727307ULL >> (nib * 4)) & 7ULL);
+}
+
+__device__ __forceinline__ uint32_t kd_nib(const uint8_t *seq, int64_t q) {
+    uint32_t b = seq[q >> 1];
+    return (q & 1) ? (b & 15u) : (b >> 4);
+}
+
+__device__ __forceinline__ bool kd_commit(const KdTabs &T, kd_u64 g) { return g >= T.g_lo && g <= T.g_hi; }
+
+__device__ __forceinline__ void kd_flag_error(kd_u64 *status, kd_u64 gidx) { atomicMin(&status[KDS_ERR_READ], gidx); }
+
+// ---------------------------------------------------------------------------------------
+// k_prep: classify reads, compute the reference span of their table writes, count events.
+// One lane per read, KD_PREP_PER_THREAD reads per lane so that the per-block reductions
+// (stats, list reservations) cost one global atomic per 8192 reads.
+// ---------------------------------------------------------------------------------------
+#define KD_PREP_PER_THREAD 32
+#define KD_PREP_CHUNK (KD_BLOCK * KD_PREP_PER_THREAD)
+#define KD_PREP_MAX_OPS 16
+
+// result of scanning one CIGAR
+struct KdScan {
+    uint32_t cls, cold;
+    kd_u64 span, n_ins, ins_bases, aligned, walked;
+};
+
+// Serial scan of ops [0, nc) of a read; shared by k_prep (short CIGARs) and k_diagnose-free
+// paths.  "Regular" means: k_window / the COLD pass can process the read with plain
+// G-space arithmetic and no Python wrap-around or exception can occur (bad bases aside).
+__device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc, int64_t pos0, int64_t sl, int64_t L) {
+    KdScan s;
+    s.cls = KD_CLS_REG; s.cold = 0; s.span = 0; s.n_ins = 0; s.ins_bases = 0; s.aligned = 0; s.walked = 0;
+    bool regular = pos0 >= 0;
+    bool seen_nfs = false;  // a non-first S was seen: r is no longer plain prefix arithmetic
+    int64_t r = pos0, q = 0, hot_hi = pos0;
+    for (uint32_t k = 0; k < nc; k++) {
+        const uint32_t c = cg[k];
+        const int64_t len = c >> 4;
+        const uint32_t op = c & 15u;
+        if (op == 0 || op == 7 || op == 8) {  // M = X
+            if (seen_nfs || r + len > L || q + len > sl) regular = false;
+            r += len; q += len; hot_hi = r;
+            s.aligned += (kd_u64)len; s.walked += (kd_u64)len;
+        } else if (op == 1) {  // I
+            s.cold = KD_INFO_COLD;
+            if (seen_nfs || r > L) regular = false;
+            int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
+            s.n_ins += 1; s.ins_bases += (kd_u64)(q1 - q0);
+            q += len; s.walked += (kd_u64)len;
+        } else if (op == 2) {  // D
+            if (seen_nfs || r + len > L + 1) regular = false;
+            r += len; hot_hi = r;
+            s.walked += (kd_u64)len;
+        } else if (op == 4) {  // S
+            s.cold = KD_INFO_COLD;
+            s.walked += (kd_u64)len;
+            if (k == 0) {
+                if (r > L || len > sl) regular = false;
+                q += len;
+            } else {
+                if (seen_nfs) regular = false;
+                seen_nfs = true;
+                int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
+                if (n_adv > sl - q || (len > n_adv && q + n_adv >= sl)) regular = false;
+                r += n_adv; q += n_adv;
+            }
+        }
+    }
+    if (!regular) s.cls = KD_CLS_IRREG;
+    s.span = hot_hi > pos0 ? (kd_u64)(hot_hi - pos0) : 0;
+    return s;
+}
+
+__global__ void __launch_bounds__(KD_BLOCK)
+k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irreg_list, uint32_t *long_list,
+       kd_u64 *status) {
+    __shared__ kd_u64 s_red[8];       // reads, aligned, walked, ins_ops, ins_bases, n_reg, unsorted
+    __shared__ uint32_t s_maxspan;
+    __shared__ uint32_t s_cnt[3];     // cold, irreg, long (block totals / running offsets)
+    __shared__ kd_u64 s_base[3];
+    const uint32_t t = threadIdx.x;
+    if (t < 8) s_red[t] = 0;
+    if (t < 3) s_cnt[t] = 0;
+    if (t == 0) s_maxspan = 0;
+    __syncthreads();
+    const kd_u64 chunk0 = (kd_u64)blockIdx.x * KD_PREP_CHUNK;
+    kd_u64 a_reads = 0, a_aligned = 0, a_walked = 0, a_ins = 0, a_insb = 0, a_reg = 0, a_unsorted = 0;
+    uint32_t a_maxspan = 0, n_cold = 0, n_irreg = 0, n_long = 0;
+    for (int it = 0; it < KD_PREP_PER_THREAD; it++) {
+        const kd_u64 i = chunk0 + (kd_u64)it * KD_BLOCK + t;
+        if (i >= rd.n) break;
+        const uint32_t c = rd.contig[i];
+        const int64_t pos0 = rd.pos0[i];
+        const kd_u64 cb = T.contig_base[c];
+        const kd_u64 gkey = cb + (kd_u64)(pos0 > 0 ? pos0 : 0);
+        if (i > 0) {  // sortedness of G-start over ALL reads of the batch (window ranges rely on it)
+            const int64_t pp = rd.pos0[i - 1];
+            const kd_u64 pk = T.contig_base[rd.contig[i - 1]] + (kd_u64)(pp > 0 ? pp : 0);
+            if (pk > gkey) a_unsorted++;
+        }
+        const int64_t sl = rd.seq_len[i];
+        const uint32_t nc = rd.n_cig[i];
+        uint32_t cls, cold = 0;
+        kd_u64 span = 0;
+        if ((rd.flag[i] & 4u) || sl <= 1) {
+            cls = KD_CLS_SKIP;
+        } else if (nc == 0) {
+            cls = KD_CLS_IRREG;  // CIGAR '*': k_pileup_wave raises KD_E_CIGAR
+            a_reads++;
+        } else if (nc > KD_PREP_MAX_OPS) {
+            cls = KD_CLS_LONG;
+            a_reads++;
+        } else {
+            KdScan s = kd_scan_cigar(rd.cigar + rd.cig_off[i], nc, pos0, sl, (int64_t)T.contig_len[c]);
+            cls = s.cls; cold = s.cold; span = s.span;
+            a_reads++; a_aligned += s.aligned; a_walked += s.walked; a_ins += s.n_ins; a_insb += s.ins_bases;
+        }
+        if (span > 0x1fffffffULL) { cls = KD_CLS_IRREG; span = 0; }
+        if (cls == KD_CLS_REG) { a_reg++; if ((uint32_t)span > a_maxspan) a_maxspan = (uint32_t)span; }
+        if (cls == KD_CLS_REG && cold) n_cold++;
+        if (cls == KD_CLS_IRREG) n_irreg++;
+        if (cls == KD_CLS_LONG) n_long++;
+        KdRInfo ri;
+        ri.gstart = (uint32_t)gkey;
+        ri.span_cls = ((uint32_t)span << 3) | cold | cls;
+        rinfo[i] = ri;
+    }
+    // block reduction through LDS atomics, then one global atomic per word per block
+    if (a_reads) atomicAdd(&s_red[0], a_reads);
+    if (a_aligned) atomicAdd(&s_red[1], a_aligned);
+    if (a_walked) atomicAdd(&s_red[2], a_walked);
+    if (a_ins) atomicAdd(&s_red[3], a_ins);
+    if (a_insb) atomicAdd(&s_red[4], a_insb);
+    if (a_reg) atomicAdd(&s_red[5], a_reg);
+    if (a_unsorted) atomicAdd(&s_red[6], a_unsorted);
+    if (a_maxspan) atomicMax(&s_maxspan, a_maxspan);
+    // list slots: thread-local offset inside the block
+    uint32_t o_cold = n_cold ? atomicAdd(&s_cnt[0], n_cold) : 0;
+    uint32_t o_irreg = n_irreg ? atomicAdd(&s_cnt[1], n_irreg) : 0;
+    uint32_t o_long = n_long ? atomicAdd(&s_cnt[2], n_long) : 0;
+    __syncthreads();
+    if (t == 0) {
+        if (s_red[0]) atomicAdd(&status[KDS_ST_READS], s_red[0]);
+        if (s_red[1]) atomicAdd(&status[KDS_ST_ALIGNED], s_red[1]);
+        if (s_red[2]) atomicAdd(&status[KDS_ST_WALKED], s_red[2]);
+        if (s_red[3]) { atomicAdd(&status[KDS_ST_INS], s_red[3]); atomicAdd(&status[KDS_B_INS_OPS], s_red[3]); }
+        if (s_red[4]) atomicAdd(&status[KDS_B_INS_BASES], s_red[4]);
+        if (s_red[5]) atomicAdd(&status[KDS_B_N_REG], s_red[5]);
+        if (s_red[6]) atomicAdd(&status[KDS_B_UNSORTED], s_red[6]);
+        if (s_maxspan) atomicMax(&status[KDS_B_MAXSPAN], (kd_u64)s_maxspan);
+        s_base[0] = s_cnt[0] ? atomicAdd(&status[KDS_B_N_COLD], (kd_u64)s_cnt[0]) : 0;
+        s_base[1] = s_cnt[1] ? atomicAdd(&status[KDS_B_N_IRREG], (kd_u64)s_cnt[1]) : 0;
+        s_base[2] = s_cnt[2] ? atomicAdd(&status[KDS_B_N_LONG], (kd_u64)s_cnt[2]) : 0;
+    }
+    __syncthreads();
+    if (n_cold | n_irreg | n_long) {
+        kd_u64 w_cold = s_base[0] + o_cold, w_irreg = s_base[1] + o_irreg, w_long = s_base[2] + o_long;
+        for (int it = 0; it < KD_PREP_PER_THREAD; it++) {
+            const kd_u64 i = chunk0 + (kd_u64)it * KD_BLOCK + t;
+            if (i >= rd.n) break;
+            const uint32_t sc = rinfo[i].span_cls;
+            const uint32_t cls = sc & 3u;
+            if (cls == KD_CLS_REG && (sc & KD_INFO_COLD)) cold_list[w_cold++] = (uint32_t)i;
+            if (cls == KD_CLS_IRREG) irreg_list[w_irreg++] = (uint32_t)i;
+            if (cls == KD_CLS_LONG) long_list[w_long++] = (uint32_t)i;
+        }
+    }
+}
+
+// k_prep_long: one workgroup per read whose CIGAR has more than KD_PREP_MAX_OPS words
+// (long-read aligners: thousands of ops).  Each thread sums the reference / query advance
+// of a contiguous run of ops, an LDS scan turns the sums into start coordinates, and a
+// second sweep applies the same regularity rules as kd_scan_cigar.
+__global__ void __launch_bounds__(KD_BLOCK)
+k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uint32_t *cold_list,
+            uint32_t *irreg_list, kd_u64 *status) {
+    __shared__ int64_t s_r[KD_BLOCK], s_q[KD_BLOCK];
+    __shared__ kd_u64 s_acc[6];       // aligned, walked, n_ins, ins_bases, bad, cold
+    __shared__ uint32_t s_first_nfs, s_last_rel;
+    const uint32_t t = threadIdx.x;
+    const kd_u64 i = long_list[blockIdx.x];
+    const uint32_t c = rd.contig[i];
+    const int64_t L = T.contig_len[c];
+    const int64_t pos0 = rd.pos0[i];
+    const int64_t sl = rd.seq_len[i];
+    const uint32_t nc = rd.n_cig[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    const uint32_t per = (nc + KD_BLOCK - 1) / KD_BLOCK;
+    const uint32_t k0 = t * per < nc ? t * per : nc, k1 = k0 + per < nc ? k0 + per : nc;
+    if (t < 6) s_acc[t] = 0;
+    if (t == 0) { s_first_nfs = 0xffffffffu; s_last_rel = 0; }
+    int64_t dr = 0, dq = 0;
+    for (uint32_t k = k0; k < k1; k++) {
+        const uint32_t w = cg[k];
+        const int64_t len = w >> 4;
+        const uint32_t op = w & 15u;
+        if (op == 0 || op == 7 || op == 8) { dr += len; dq += len; }
+        else if (op == 1) dq += len;
+        else if (op == 2) dr += len;
+        else if (op == 4 && k == 0) dq += len;
+        // a non-first S contributes nothing here: anything after it makes the read irregular,
+        // and if nothing follows its own advance is irrelevant to the span
+    }
+    s_r[t] = dr; s_q[t] = dq;
+    __syncthreads();
+    // inclusive Hillis-Steele scan over the 256 partial sums
+    for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
+        int64_t ar = 0, aq = 0;
+        if (t >= d) { ar = s_r[t - d]; aq = s_q[t - d]; }
+        __syncthreads();
+        s_r[t] += ar; s_q[t] += aq;
+        __syncthreads();
+    }
+    int64_t r = pos0 + (t ? s_r[t - 1] : 0), q = t ? s_q[t - 1] : 0;
+    const int64_t r_end = pos0 + s_r[KD_BLOCK - 1];
+    kd_u64 aligned = 0, walked = 0, n_ins = 0, insb = 0, bad = 0, cold = 0;
+    uint32_t first_nfs = 0xffffffffu, last_rel = 0;
+    for (uint32_t k = k0; k < k1; k++) {
+        const uint32_t w = cg[k];
+        const int64_t len = w >> 4;
+        const uint32_t op = w & 15u;
+        if (op == 0 || op == 7 || op == 8) {
+            if (r + len > L || q + len > sl) bad = 1;
+            r += len; q += len; aligned += (kd_u64)len; walked += (kd_u64)len; last_rel = k;
+        } else if (op == 1) {
+            cold = 1;
+            if (r > L) bad = 1;
+            int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
+            n_ins++; insb += (kd_u64)(q1 - q0); q += len; walked += (kd_u64)len; last_rel = k;
+        } else if (op == 2) {
+            if (r + len > L + 1) bad = 1;
+            r += len; walked += (kd_u64)len; last_rel = k;
+        } else if (op == 4) {
+            cold = 1; walked += (kd_u64)len;
+            if (k == 0) { if (r > L || len > sl) bad = 1; q += len; }
+            else {
+                if (k < first_nfs) first_nfs = k;
+                int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
+                if (n_adv > sl - q || (len > n_adv && q + n_adv >= sl)) bad = 1;
+                last_rel = k;
+            }
+        }
+    }
+    if (aligned) atomicAdd(&s_acc[0], aligned);
+    if (walked) atomicAdd(&s_acc[1], walked);
+    if (n_ins) atomicAdd(&s_acc[2], n_ins);
+    if (insb) atomicAdd(&s_acc[3], insb);
+    if (bad) atomicAdd(&s_acc[4], bad);
+    if (cold) atomicAdd(&s_acc[5], cold);
+    if (first_nfs != 0xffffffffu) atomicMin(&s_first_nfs, first_nfs);
+    if (last_rel) atomicMax(&s_last_rel, last_rel);
+    __syncthreads();
+    if (t == 0) {
+        bool regular = pos0 >= 0 && s_acc[4] == 0;
+        // a non-first S must be the last op that touches r (M, I, D or S)
+        if (s_first_nfs != 0xffffffffu && s_last_rel > s_first_nfs) regular = false;
+        kd_u64 span = r_end > pos0 ? (kd_u64)(r_end - pos0) : 0;
+        if (span > 0x1fffffffULL) { regular = false; span = 0; }
+        const uint32_t coldbit = s_acc[5] ? KD_INFO_COLD : 0u;
+        KdRInfo ri = rinfo[i];
+        ri.span_cls = ((uint32_t)span << 3) | coldbit | (regular ? KD_CLS_REG : KD_CLS_IRREG);
+        rinfo[i] = ri;
+        atomicAdd(&status[KDS_ST_ALIGNED], s_acc[0]);
+        atomicAdd(&status[KDS_ST_WALKED], s_acc[1]);
+        if (s_acc[2]) { atomicAdd(&status[KDS_ST_INS], s_acc[2]); atomicAdd(&status[KDS_B_INS_OPS], s_acc[2]); }
+        if (s_acc[3]) atomicAdd(&status[KDS_B_INS_BASES], s_acc[3]);
+        if (regular) {
+            atomicAdd(&status[KDS_B_N_REG], 1ULL);
+            atomicMax(&status[KDS_B_MAXSPAN], span);
+            if (coldbit) cold_list[atomicAdd(&status[KDS_B_N_COLD], 1ULL)] = (uint32_t)i;
+        } else {
+            irreg_list[atomicAdd(&status[KDS_B_N_IRREG], 1ULL)] = (uint32_t)i;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_pileup_wave<HOT, COLD>: one wavefront per read, exact reference semantics
+// (kindel.py:40-81 incl. Python negative-index wrap-around), 32-bit atomics into HBM.
+//   HOT : commit M/=/X and D tallies (weights, deletions)
+//   COLD: commit soft-clip tables and emit insertion events
+// <true,true>  irregular reads and KD_MODE_GLOBAL;  <false,true> the S/I side of regular reads.
+// All control flow is wave-uniform (every value steering it comes from uniform loads).
+// ---------------------------------------------------------------------------------------
+template <bool HOT, bool COLD>
+__global__ void __launch_bounds__(KD_BLOCK)
+k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list, const KdRInfo *rinfo,
+              kd_u64 *status) {
+    const uint32_t lane = threadIdx.x & (KD_WAVE - 1);
+    const kd_u64 slot = (kd_u64)blockIdx.x * KD_WAVES_PER_BLOCK + (threadIdx.x / KD_WAVE);
+    if (slot >= n_list) return;
+    const kd_u64 i = list ? (kd_u64)list[slot] : slot;
+    const int64_t sl = rd.seq_len[i];
+    if ((rd.flag[i] & 4u) || sl <= 1) return;  // kindel.py:43-46
+    const kd_u64 gidx = rd.base_index + i;
+    const uint32_t nc = rd.n_cig[i];
+    if (nc == 0) { if (lane == 0) kd_flag_error(status, gidx); return; }  // kindel.py:47
+    const uint32_t c = rd.contig[i];
+    const int64_t L = T.contig_len[c];
+    const kd_u64 cb = T.contig_base[c];
+    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    uint32_t *tab = T.tab;
+    const kd_u64 S = T.stride;
+    int64_t r = rd.pos0[i], q = 0;  // kindel.py:41-42
+    for (uint32_t k = 0; k < nc; k++) {
+        const uint32_t w = cg[k];
+        const int64_t len = w >> 4;
+        const uint32_t op = w & 15u;
+        if (op == 0 || op == 7 || op == 8) {  // M = X  kindel.py:49-54
+            if (len > 0 && (q + len > sl || r + len > L || r < -L)) { if (lane == 0) kd_flag_error(status, gidx); return; }
+            if (HOT) {
+                for (int64_t j = lane; j < len; j += KD_WAVE) {
+                    int64_t idx = r + j;
+                    if (idx < 0) idx += L;
+                    const uint32_t ch = kd_chan(kd_nib(seq, q + j));
+                    const kd_u64 g = cb + (kd_u64)idx;
+                    if (ch == 7u) kd_flag_error(status, gidx);
+                    else if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)ch * S + g], 1u);
+                }
+            }
+            r += len; q += len;
+        } else if (op == 1) {  // I  kindel.py:55-58
+            if (r > L || r < -(L + 1)) { if (lane == 0) kd_flag_error(status, gidx); return; }
+            if (COLD && lane == 0) {
+                const int64_t idx = r < 0 ? r + L + 1 : r;
+                const kd_u64 g = cb + (kd_u64)idx;
+                if (kd_commit(T, g)) {
+                    const int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
+                    const kd_u64 n = (kd_u64)(q1 - q0);
+                    const kd_u64 e = atomicAdd(&status[KDS_N_EV], 1ULL);
+                    const kd_u64 po = atomicAdd(&status[KDS_POOL], n);
+                    if (e >= ins.ev_cap || po + n > ins.pool_cap) {
+                        atomicAdd(&status[KDS_INTERNAL], 1ULL);
+                    } else {
+                        ins.ev_site[e] = (uint32_t)g; ins.ev_len[e] = (uint32_t)n; ins.ev_off[e] = po;
+                        for (kd_u64 b = 0; b < n; b++) ins.pool[po + b] = (uint8_t)kd_nib(seq, q0 + (int64_t)b);
+                        atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g], 1u);
+                    }
+                }
+            }
+            q += len;
+        } else if (op == 2) {  // D  kindel.py:59-62
+            if (len > 0 && (r + len - 1 > L || r < -(L + 1))) { if (lane == 0) kd_flag_error(status, gidx); return; }
+            if (HOT) {
+                for (int64_t j = lane; j < len; j += KD_WAVE) {
+                    int64_t idx = r + j;
+                    if (idx < 0) idx += L + 1;
+                    const kd_u64 g = cb + (kd_u64)idx;
+                    if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_DEL * S + g], 1u);
+                }
+            }
+            r += len;
+        } else if (op == 4) {  // S
+            if (k == 0) {  // kindel.py:64-73
+                if (r > L || r < -(L + 1) || len > sl) { if (lane == 0) kd_flag_error(status, gidx); return; }
+                if (COLD) {
+                    if (lane == 0) {
+                        const kd_u64 g = cb + (kd_u64)(r < 0 ? r + L + 1 : r);
+                        if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g], 1u);
+                    }
+                    for (int64_t j = lane; j < len; j += KD_WAVE) {
+                        const int64_t rel = r - len + j;
+                        if (rel >= 0) {
+                            const uint32_t ch = kd_chan(kd_nib(seq, j));
+                            const kd_u64 g = cb + (kd_u64)rel;
+                            if (ch == 7u) kd_flag_error(status, gidx);
+                            else if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)(KDC_CEW + ch) * S + g], 1u);
+                        }
+                    }
+                }
+                q += len;
+            } else {  // kindel.py:74-81
+                const int64_t x = r - 1;
+                if (x > L || x < -(L + 1)) { if (lane == 0) kd_flag_error(status, gidx); return; }
+                const int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
+                if (n_adv > sl - q || (len > n_adv && q + n_adv >= sl) || (n_adv > 0 && r < -L)) {
+                    if (lane == 0) kd_flag_error(status, gidx);
+                    return;
+                }
+                if (COLD) {
+                    if (lane == 0) {
+                        const kd_u64 g = cb + (kd_u64)(x < 0 ? x + L + 1 : x);
+                        if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
+                    }
+                    for (int64_t j = lane; j < n_adv; j += KD_WAVE) {
+                        int64_t idx = r + j;
+                        if (idx < 0) idx += L;
+                        const uint32_t ch = kd_chan(kd_nib(seq, q + j));
+                        const kd_u64 g = cb + (kd_u64)idx;
+                        if (ch == 7u) kd_flag_error(status, gidx);
+                        else if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)(KDC_CSW + ch) * S + g], 1u);
+                    }
+                }
+                r += n_adv; q += n_adv;
+            }
+        }
+        // H, N, P, anything else: ignored entirely
+    }
+    (void)rinfo;
+}
+
+// k_diagnose: one thread re-walks the first failing read serially, in the reference's own
+// statement order, to decide WHICH exception the reference raises (KeyError vs IndexError
+// vs RuntimeError).  Error classification only -- it writes no table.
+__global__ void k_diagnose(KdReads rd, KdTabs T, kd_u64 *status) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const kd_u64 gidx = status[KDS_ERR_READ];
+    if (gidx == ~0ULL || gidx < rd.base_index || gidx >= rd.base_index + rd.n) return;
+    const kd_u64 i = gidx - rd.base_index;
+    const int64_t sl = rd.seq_len[i];
+    const uint32_t nc = rd.n_cig[i];
+    const int64_t L = T.contig_len[rd.contig[i]];
+    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    kd_u64 code = 8;  // KD_E_INTERNAL magnitude: flagged but no exception reproduced
+    if (nc == 0) { status[KDS_ERR_CODE] = 3; return; }
+    int64_t r = rd.pos0[i], q = 0;
+    for (uint32_t k = 0; k < nc && code == 8; k++) {
+        const int64_t len = cg[k] >> 4;
+        const uint32_t op = cg[k] & 15u;
+        if (op == 0 || op == 7 || op == 8) {
+            for (int64_t j = 0; j < len; j++) {
+                if (q >= sl) { code = 2; break; }
+                int64_t idx = r < 0 ? r + L : r;
+                if (idx < 0 || idx >= L) { code = 2; break; }
+                if (kd_chan(kd_nib(seq, q)) == 7u) { code = 1; break; }
+                r++; q++;
+            }
+        } else if (op == 1) {
+            int64_t idx = r < 0 ? r + L + 1 : r;
+            if (idx < 0 || idx > L) { code = 2; break; }
+            q += len;
+        } else if (op == 2) {
+            for (int64_t j = 0; j < len; j++) {
+                int64_t idx = r + j < 0 ? r + j + L + 1 : r + j;
+                if (idx < 0 || idx > L) { code = 2; break; }
+            }
+            r += len;
+        } else if (op == 4) {
+            if (k == 0) {
+                int64_t idx = r < 0 ? r + L + 1 : r;
+                if (idx < 0 || idx > L) { code = 2; break; }
+                for (int64_t j = 0; j < len; j++) {
+                    if (j >= sl) { code = 2; break; }
+                    const int64_t rel = r - len + j;
+                    if (rel >= 0) {
+                        if (rel >= L) { code = 2; break; }
+                        if (kd_chan(kd_nib(seq, j)) == 7u) { code = 1; break; }
+                    }
+                }
+                q += len;
+            } else {
+                int64_t idx = r - 1 < 0 ? r - 1 + L + 1 : r - 1;
+                if (idx < 0 || idx > L) { code = 2; break; }
+                for (int64_t j = 0; j < len; j++) {
+                    if (q >= sl) { code = 2; break; }
+                    if (r < L) {
+                        int64_t wi = r < 0 ? r + L : r;
+                        if (wi < 0 || wi >= L) { code = 2; break; }
+                        if (kd_chan(kd_nib(seq, q)) == 7u) { code = 1; break; }
+                        r++; q++;
+                    }
+                }
+            }
+        }
+    }
+    status[KDS_ERR_CODE] = code;
+}
+
+// ---------------------------------------------------------------------------------------
+// Windowed path: k_plan + k_window
+// ---------------------------------------------------------------------------------------
+
+// first index in [0,n) with rinfo[idx].gstart >= key
+__device__ __forceinline__ kd_u64 kd_lower_bound(const KdRInfo *rinfo, kd_u64 n, kd_u64 key) {
+    kd_u64 lo = 0, hi = n;
+    while (lo < hi) {
+        const kd_u64 mid = (lo + hi) >> 1;
+        if ((kd_u64)rinfo[mid].gstart < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// One workgroup.  For every window w of W sites: the candidate reads are those whose
+// G-start lies in [w*W - maxspan, (w+1)*W) -- contiguous because the batch is sorted --
+// cut into slices of `slice` reads; item_off[w] = exclusive prefix of the slice counts.
+__global__ void __launch_bounds__(KD_BLOCK)
+k_plan(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t n_win, uint32_t W, uint32_t slice, kd_u64 *win_lo,
+       kd_u64 *win_hi, kd_u64 *item_off, kd_u64 *status) {
+    __shared__ kd_u64 s_scan[KD_BLOCK];
+    __shared__ kd_u64 s_carry;
+    const uint32_t t = threadIdx.x;
+    const kd_u64 maxspan = status[KDS_B_MAXSPAN];
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t w0 = 0; w0 < n_win; w0 += KD_BLOCK) {
+        const uint32_t w = w0 + t;
+        kd_u64 items = 0;
+        if (w < n_win) {
+            const kd_u64 wlo = (kd_u64)w * W, whi = wlo + W;
+            const kd_u64 lo = kd_lower_bound(rinfo, n_reads, wlo > maxspan ? wlo - maxspan : 0);
+            const kd_u64 hi = kd_lower_bound(rinfo, n_reads, whi);
+            win_lo[w] = lo; win_hi[w] = hi;
+            items = (hi - lo + slice - 1) / slice;
+        }
+        s_scan[t] = items;
+        __syncthreads();
+        for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
+            kd_u64 a = t >= d ? s_scan[t - d] : 0;
+            __syncthreads();
+            s_scan[t] += a;
+            __syncthreads();
+        }
+        if (w < n_win) item_off[w] = s_carry + s_scan[t] - items;
+        __syncthreads();
+        if (t == KD_BLOCK - 1) s_carry += s_scan[t];
+        __syncthreads();
+    }
+    if (t == 0) { item_off[n_win] = s_carry; status[KDS_TOTAL_ITEMS] = s_carry; status[KDS_NEXT_ITEM] = 0; }
+}
+
+// Persistent workgroups.  LDS: u32 hist[6][W] (A,T,G,C,N,del), channel-major so that the 64
+// lanes of a wavefront -- 64 consecutive reference sites of one read -- hit 64 consecutive
+// dwords of one channel: no bank conflict inside an instruction.  Only REGULAR reads are
+// handled here; their S/I side effects are done by k_pileup_wave<false,true>.
+__global__ void __launch_bounds__(KD_BLOCK)
+k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
+         const kd_u64 *item_off, uint32_t n_win, uint32_t W, uint32_t slice, kd_u64 *status) {
+    KD_DYN_SHARED(uint32_t, hist);
+    __shared__ kd_u64 s_item;
+    const uint32_t t = threadIdx.x;
+    const uint32_t lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
+    const kd_u64 total = status[KDS_TOTAL_ITEMS];
+    const uint32_t nh = 6u * W;
+    for (;;) {
+        if (t == 0) s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL);
+        __syncthreads();
+        const kd_u64 item = s_item;
+        if (item >= total) break;
+        // window of this item: largest w with item_off[w] <= item
+        uint32_t lo = 0, hi = n_win;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (item_off[mid] <= item) lo = mid; else hi = mid;
+        }
+        const uint32_t w = lo;
+        const kd_u64 wlo = (kd_u64)w * W, whi = wlo + W;
+        const kd_u64 first = win_lo[w] + (item - item_off[w]) * slice;
+        const kd_u64 last = first + slice < win_hi[w] ? first + slice : win_hi[w];
+        for (uint32_t x = t; x < nh; x += KD_BLOCK) hist[x] = 0;
+        __syncthreads();
+        for (kd_u64 i = first + wave; i < last; i += KD_WAVES_PER_BLOCK) {
+            const KdRInfo ri = rinfo[i];
+            if ((ri.span_cls & 3u) != KD_CLS_REG) continue;
+            const kd_u64 gs = ri.gstart, span = ri.span_cls >> 3;
+            if (gs + span <= wlo || gs >= whi) continue;
+            const uint8_t *seq = rd.seq4 + rd.seq_off[i];
+            const uint32_t *cg = rd.cigar + rd.cig_off[i];
+            const uint32_t nc = rd.n_cig[i];
+            int64_t g = (int64_t)gs, q = 0;
+            for (uint32_t k = 0; k < nc; k++) {
+                const uint32_t cw = cg[k];
+                const int64_t len = cw >> 4;
+                const uint32_t op = cw & 15u;
+                if (op == 0 || op == 7 || op == 8 || op == 2) {
+                    // overlap of [g, g+len) with the window, as offsets into the op
+                    const int64_t j0 = (int64_t)wlo > g ? (int64_t)wlo - g : 0;
+                    const int64_t j1 = (int64_t)whi - g < len ? (int64_t)whi - g : len;
+                    if (op == 2) {
+                        for (int64_t j = j0 + lane; j < j1; j += KD_WAVE)
+                            atomicAdd(&hist[5u * W + (uint32_t)(g + j - (int64_t)wlo)], 1u);
+                    } else {
+                        for (int64_t j = j0 + lane; j < j1; j += KD_WAVE) {
+                            const uint32_t ch = kd_chan(kd_nib(seq, q + j));
+                            if (ch == 7u) kd_flag_error(status, rd.base_index + i);
+                            else atomicAdd(&hist[ch * W + (uint32_t)(g + j - (int64_t)wlo)], 1u);
+                        }
+                        q += len;
+                    }
+                    g += len;
+                    if (g >= (int64_t)whi) break;
+                } else if (op == 1) {
+                    q += len;
+                } else if (op == 4) {
+                    if (k == 0) q += len; else break;  // regular: nothing after a non-first S touches r
+                }
+            }
+        }
+        __syncthreads();
+        // flush: channel-major, consecutive lanes -> consecutive HBM dwords; zeros are skipped
+        for (uint32_t x = t; x < nh; x += KD_BLOCK) {
+            const uint32_t v = hist[x];
+            if (v) {
+                const uint32_t ch = x / W;
+                const kd_u64 g = wlo + (x - ch * W);
+                if (g < T.stride && kd_commit(T, g)) atomicAdd(&T.tab[(kd_u64)ch * T.stride + g], v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Insertion multiset: insertions[site][string] += 1 (kindel.py:55-58) and
+// consensus(insertions[site]) (kindel.py:420-421) -> per site: unique majority string or tie.
+// ---------------------------------------------------------------------------------------
+#define KD_INS_NONE 0xffffffffu
+#define KD_INS_TIE 0xfffffffeu
+
+struct KdInsTab {
+    kd_u64 *key;     // [cap] 0 = empty
+    uint32_t *cnt;   // [cap]
+    uint32_t *rep;   // [cap] smallest event index with this key
+    uint32_t *ev_slot;  // [n_ev]
+    kd_u64 cap;      // power of two
+    kd_u64 seed;
+};
+
+__device__ __forceinline__ kd_u64 kd_mix64(kd_u64 x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+
+__global__ void __launch_bounds__(KD_BLOCK)
+k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev) {
+    const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (e >= n_ev) return;
+    const uint32_t site = ins.ev_site[e], len = ins.ev_len[e];
+    const uint8_t *p = ins.pool + ins.ev_off[e];
+    kd_u64 h = kd_mix64(H.seed ^ ((kd_u64)site << 32 | len));
+    for (uint32_t b = 0; b < len; b++) h = (h ^ p[b]) * 0x100000001b3ULL;
+    h = kd_mix64(h) | 1ULL;
+    kd_u64 s = (h >> 1) & (H.cap - 1);
+    for (;;) {
+        kd_u64 cur = H.key[s];
+        if (cur == 0) cur = atomicCAS(&H.key[s], 0ULL, h);
+        if (cur == 0 || cur == h) break;
+        s = (s + 1) & (H.cap - 1);
+    }
+    atomicAdd(&H.cnt[s], 1u);
+    atomicMin(&H.rep[s], (uint32_t)e);
+    H.ev_slot[e] = (uint32_t)s;
+}
+
+// exactness: every event must be byte-identical to the representative of its slot
+__global__ void __launch_bounds__(KD_BLOCK)
+k_ins_verify(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *status) {
+    const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (e >= n_ev) return;
+    const uint32_t r = H.rep[H.ev_slot[e]];
+    if (r == (uint32_t)e) return;
+    bool same = ins.ev_site[e] == ins.ev_site[r] && ins.ev_len[e] == ins.ev_len[r];
+    if (same) {
+        const uint8_t *a = ins.pool + ins.ev_off[e], *b = ins.pool + ins.ev_off[r];
+        for (uint32_t k = 0; k < ins.ev_len[e]; k++) if (a[k] != b[k]) { same = false; break; }
+    }
+    if (!same) atomicAdd(&status[KDS_INS_COLLISION], 1ULL);
+}
+
+// pass 1: best[site] = max over slots of (count << 32 | slot)
+__global__ void __launch_bounds__(KD_BLOCK)
+k_ins_site_max(KdIns ins, KdInsTab H, kd_u64 *best) {
+    const kd_u64 s = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (s >= H.cap || H.key[s] == 0) return;
+    atomicMax(&best[ins.ev_site[H.rep[s]]], ((kd_u64)H.cnt[s] << 32) | s);
+}
+// pass 2: another slot of the same site with the same count -> tie (kindel.py:377, :421)
+__global__ void __launch_bounds__(KD_BLOCK)
+k_ins_site_tie(KdIns ins, KdInsTab H, const kd_u64 *best, uint32_t *win) {
+    const kd_u64 s = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (s >= H.cap || H.key[s] == 0) return;
+    const uint32_t site = ins.ev_site[H.rep[s]];
+    const kd_u64 b = best[site];
+    if ((uint32_t)(b >> 32) == H.cnt[s] && (uint32_t)b != (uint32_t)s) win[site] = KD_INS_TIE;
+}
+// pass 3: sites without a tie get the representative event of their best slot
+__global__ void __launch_bounds__(KD_BLOCK)
+k_ins_site_win(KdIns ins, KdInsTab H, const kd_u64 *best, uint32_t *win) {
+    const kd_u64 s = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (s >= H.cap || H.key[s] == 0) return;
+    const uint32_t site = ins.ev_site[H.rep[s]];
+    if ((uint32_t)best[site] == (uint32_t)s && win[site] != KD_INS_TIE) win[site] = H.rep[s];
+}
+
+// ---------------------------------------------------------------------------------------
+// Consensus: kindel.py:384-430.  Each thread owns 4 consecutive G-space sites (one 16-byte
+// load per channel), a workgroup owns 1024.
+// ---------------------------------------------------------------------------------------
+#define KD_CNS_PER_THREAD 4
+#define KD_CNS_TILE (KD_BLOCK * KD_CNS_PER_THREAD)
+
+struct KdCns {
+    const uint32_t *seg_contig;  // [S/64] contig of each 64-site segment
+    const uint32_t *ins_win;     // [S] KD_INS_NONE / KD_INS_TIE / event index of the unique majority
+    uint32_t min_depth;
+    uint32_t n_patches;
+    const kd_u64 *patch_start, *patch_end;  // skip ranges in G-space (kindel.py:393-401)
+    kd_u64 g_lo, g_hi;           // emit [g_lo, g_hi)
+};
+
+struct KdSite {
+    uint32_t ins_len;  // bytes of insertion text emitted before the site's own character
+    uint32_t ins_ev;   // event index when ins == 1
+    uint32_t depth;    // A+C+G+T
+    uint8_t ins;       // 0 none, 1 unique majority string, 2 tie -> 'N'
+    uint8_t has_base;  // the site emits its own character
+    uint8_t base;      // that character ('A','T','G','C','N')
+    uint8_t change;    // 0, 'D', 'N', 'I'
+    bool live;         // a real site of a contig inside the emit interval
+};
+
+__device__ __forceinline__ KdSite kd_site_eval(const KdTabs &T, const KdCns &C, const KdIns &ins, kd_u64 g,
+                                               uint32_t a, uint32_t tt, uint32_t gg, uint32_t cc, uint32_t nn,
+                                               uint32_t del, uint32_t ins_total, uint32_t ad_next_raw) {
+    KdSite s;
+    s.ins_len = 0; s.ins_ev = 0; s.depth = 0; s.ins = 0; s.has_base = 0; s.base = 'N'; s.change = 0; s.live = false;
+    if (g >= T.stride || g < C.g_lo || g >= C.g_hi) return s;
+    const uint32_t c = C.seg_contig[g >> 6];
+    const kd_u64 p = g - T.contig_base[c];
+    const kd_u64 L = T.contig_len[c];
+    if (p >= L) return s;  // the len-th slot and the padding emit nothing
+    s.live = true;
+    const kd_u64 ad = (kd_u64)a + cc + gg + tt;  // kindel.py:404 (no N)
+    s.depth = (uint32_t)ad;
+    for (uint32_t k = 0; k < C.n_patches; k++)
+        if (g >= C.patch_start[k] && g < C.patch_end[k]) return s;  // patched / skipped: no change recorded
+    const kd_u64 ad_next = (p + 1 < L) ? (kd_u64)ad_next_raw : 0;  // kindel.py:405-410
+    const kd_u64 ind2 = ad < ad_next ? ad : ad_next;               // 2 * indel_threshold_freq, :412
+    if (2ULL * del > ad) { s.change = 'D'; return s; }             // :413-414
+    if (ad < (kd_u64)C.min_depth) { s.has_base = 1; s.change = 'N'; s.base = 'N'; return s; }  // :415-417
+    if (2ULL * ins_total > ind2) {                                 // :419-422
+        s.change = 'I';
+        const uint32_t wv = C.ins_win[g];
+        if (wv == KD_INS_TIE || wv == KD_INS_NONE) { s.ins = 2; s.ins_len = 1; }
+        else { s.ins = 1; s.ins_ev = wv; s.ins_len = ins.ev_len[wv]; }
+    }
+    // consensus(weight): first max in A,T,G,C,N order, tie -> 'N'  (kindel.py:369-381, :423-424)
+    uint32_t best = a; uint8_t bc = 'A';
+    if (tt > best) { best = tt; bc = 'T'; }
+    if (gg > best) { best = gg; bc = 'G'; }
+    if (cc > best) { best = cc; bc = 'C'; }
+    if (nn > best) { best = nn; bc = 'N'; }
+    const uint32_t n_at_max = (a == best) + (tt == best) + (gg == best) + (cc == best) + (nn == best);
+    s.base = (best == 0 || n_at_max > 1) ? 'N' : bc;
+    s.has_base = 1;
+    return s;
+}
+
+// load the 4 sites of this thread and evaluate them
+__device__ __forceinline__ void kd_cns_load_eval(const KdTabs &T, const KdCns &C, const KdIns &ins, kd_u64 g0,
+                                                 KdSite out[KD_CNS_PER_THREAD]) {
+    uint32_t v[8][KD_CNS_PER_THREAD + 1];
+    const int chs[7] = {KDC_A, KDC_T, KDC_G, KDC_C, KDC_N, KDC_DEL, KDC_INS_TOTAL};
+    const kd_u64 S = T.stride;
+#pragma unroll
+    for (int c = 0; c < 7; c++) {
+        const uint32_t *row = T.tab + (kd_u64)chs[c] * S;
+        if (g0 + KD_CNS_PER_THREAD <= S) {
+            const uint4 x = *reinterpret_cast<const uint4 *>(row + g0);
+            v[c][0] = x.x; v[c][1] = x.y; v[c][2] = x.z; v[c][3] = x.w;
+        } else {
+            for (int k = 0; k < KD_CNS_PER_THREAD; k++) v[c][k] = g0 + k < S ? row[g0 + k] : 0;
+        }
+        v[c][KD_CNS_PER_THREAD] = (c < 4 && g0 + KD_CNS_PER_THREAD < S) ? row[g0 + KD_CNS_PER_THREAD] : 0;
+    }
+    for (int k = 0; k < KD_CNS_PER_THREAD; k++) {
+        const uint32_t adn = v[0][k + 1] + v[1][k + 1] + v[2][k + 1] + v[3][k + 1];
+        out[k] = kd_site_eval(T, C, ins, g0 + k, v[0][k], v[1][k], v[2][k], v[3][k], v[4][k], v[5][k], v[6][k], adn);
+    }
+}
+
+// pass 1: bytes emitted per 1024-site tile + per-contig min/max depth
+__global__ void __launch_bounds__(KD_BLOCK)
+k_cns_count(KdTabs T, KdCns C, KdIns ins, kd_u64 *tile_sum, uint32_t *depth_minmax) {
+    __shared__ uint32_t s_sum, s_min, s_max;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) { s_sum = 0; s_min = 0xffffffffu; s_max = 0; }
+    __syncthreads();
+    const kd_u64 tile0 = (kd_u64)blockIdx.x * KD_CNS_TILE;
+    const kd_u64 g0 = tile0 + (kd_u64)t * KD_CNS_PER_THREAD;
+    const uint32_t cfirst = tile0 < T.stride ? C.seg_contig[tile0 >> 6] : 0;
+    KdSite s[KD_CNS_PER_THREAD];
+    kd_cns_load_eval(T, C, ins, g0, s);
+    uint32_t sum = 0, mn = 0xffffffffu, mx = 0;
+    for (int k = 0; k < KD_CNS_PER_THREAD; k++) {
+        sum += s[k].ins_len + s[k].has_base;
+        if (s[k].live) {
+            const uint32_t c = C.seg_contig[(g0 + k) >> 6];
+            if (c == cfirst) { mn = s[k].depth < mn ? s[k].depth : mn; mx = s[k].depth > mx ? s[k].depth : mx; }
+            else { atomicMin(&depth_minmax[2 * c], s[k].depth); atomicMax(&depth_minmax[2 * c + 1], s[k].depth); }
+        }
+    }
+    if (sum) atomicAdd(&s_sum, sum);
+    if (mn != 0xffffffffu) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
+    __syncthreads();
+    if (t == 0) {
+        tile_sum[blockIdx.x] = s_sum;
+        if (s_min != 0xffffffffu) { atomicMin(&depth_minmax[2 * cfirst], s_min); atomicMax(&depth_minmax[2 * cfirst + 1], s_max); }
+    }
+}
+
+// pass 2: exclusive scan of the tile sums (one workgroup), tile_off[n_tiles] = total
+__global__ void __launch_bounds__(KD_BLOCK)
+k_cns_scan(const kd_u64 *tile_sum, kd_u64 *tile_off, kd_u64 n_tiles) {
+    __shared__ kd_u64 s_scan[KD_BLOCK];
+    __shared__ kd_u64 s_carry;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (kd_u64 b0 = 0; b0 < n_tiles; b0 += KD_BLOCK) {
+        const kd_u64 b = b0 + t;
+        const kd_u64 v = b < n_tiles ? tile_sum[b] : 0;
+        s_scan[t] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
+            kd_u64 a = t >= d ? s_scan[t - d] : 0;
+            __syncthreads();
+            s_scan[t] += a;
+            __syncthreads();
+        }
+        if (b < n_tiles) tile_off[b] = s_carry + s_scan[t] - v;
+        __syncthreads();
+        if (t == KD_BLOCK - 1) s_carry += s_scan[t];
+        __syncthreads();
+    }
+    if (t == 0) tile_off[n_tiles] = s_carry;
+}
+
+// pass 3: recompute, scan inside the tile, write bytes / changes / per-contig start offsets
+__global__ void __launch_bounds__(KD_BLOCK)
+k_cns_emit(KdTabs T, KdCns C, KdIns ins, const kd_u64 *tile_off, uint8_t *out, uint8_t *changes,
+           kd_u64 *contig_off, uint32_t n_contigs, kd_u64 *patch_off) {
+    __shared__ uint32_t s_scan[KD_BLOCK];
+    const uint32_t t = threadIdx.x;
+    const kd_u64 tile0 = (kd_u64)blockIdx.x * KD_CNS_TILE;
+    const kd_u64 g0 = tile0 + (kd_u64)t * KD_CNS_PER_THREAD;
+    KdSite s[KD_CNS_PER_THREAD];
+    kd_cns_load_eval(T, C, ins, g0, s);
+    uint32_t sum = 0;
+    for (int k = 0; k < KD_CNS_PER_THREAD; k++) sum += s[k].ins_len + s[k].has_base;
+    s_scan[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
+        uint32_t a = t >= d ? s_scan[t - d] : 0;
+        __syncthreads();
+        s_scan[t] += a;
+        __syncthreads();
+    }
+    kd_u64 o = tile_off[blockIdx.x] + s_scan[t] - sum;
+    const char lower[17] = "=acmgrsvtwyhkdbn";
+    for (int k = 0; k < KD_CNS_PER_THREAD; k++) {
+        const kd_u64 g = g0 + k;
+        if (g >= T.stride) break;
+        changes[g] = s[k].change;
+        // contig c starts at G-site contig_base[c]: record the output offset there
+        if ((g & 63) == 0) {
+            const uint32_t c = C.seg_contig[g >> 6];
+            if (T.contig_base[c] == g) contig_off[c] = o;
+        }
+        for (uint32_t pk = 0; pk < C.n_patches; pk++) if (C.patch_start[pk] == g) patch_off[pk] = o;
+        if (s[k].ins == 1) {
+            const uint8_t *p = ins.pool + ins.ev_off[s[k].ins_ev];
+            for (uint32_t b = 0; b < s[k].ins_len; b++) out[o + b] = (uint8_t)lower[p[b] & 15];  // .lower(), :421
+            o += s[k].ins_len;
+        } else if (s[k].ins == 2) {
+            out[o++] = 'N';
+        }
+        if (s[k].has_base) out[o++] = s[k].base;
+    }
+    (void)n_contigs;
+}

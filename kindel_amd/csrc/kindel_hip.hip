@@ -1,0 +1,119 @@
+// kindel_hip.hip -- the product: libkindel_hip.so for AMD Instinct MI355X (gfx950, CDNA4).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC kindel_hip.hip kd_decode.cpp -lz
+// HIP runtime policy for KdEngine + the C-ABI of include/kindel_hip.h.  There is no CPU
+// fallback: without a usable GPU kd_create() fails with KD_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kd_engine.h"
+
+struct HipRt {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int dev = 0, cus = 256;
+    std::string e;
+    bool prof = false;
+    struct Pending { std::string name; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::map<std::string, std::pair<uint64_t, double>> rows;
+
+    bool bad(hipError_t rc) {
+        if (rc == hipSuccess) return false;
+        e = hipGetErrorString(rc);
+        return true;
+    }
+    const char *err() const { return e.c_str(); }
+
+    int init(int device, void *s) {
+        int n = 0;
+        if (bad(hipGetDeviceCount(&n))) return 1;
+        if (device < 0 || device >= n) { e = "no such HIP device (" + std::to_string(n) + " visible)"; return 1; }
+        dev = device;
+        if (bad(hipSetDevice(dev))) return 1;
+        hipDeviceProp_t p;
+        if (bad(hipGetDeviceProperties(&p, dev))) return 1;
+        cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+        if (s) { stream = (hipStream_t)s; own_stream = false; }
+        else { if (bad(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking))) return 1; own_stream = true; }
+        return 0;
+    }
+    void shutdown() {
+        profile_reset();
+        if (own_stream && stream) { (void)hipSetDevice(dev); (void)hipStreamDestroy(stream); }
+        stream = nullptr;
+    }
+    int n_cus() const { return cus; }
+    void *alloc(size_t bytes) {
+        void *p = nullptr;
+        if (bad(hipSetDevice(dev))) return nullptr;
+        if (bad(hipMalloc(&p, bytes ? bytes : 1))) return nullptr;
+        return p;
+    }
+    void free(void *p) { (void)hipSetDevice(dev); (void)hipFree(p); }
+    int memset(void *p, int v, size_t n) { return n ? bad(hipMemsetAsync(p, v, n, stream)) : 0; }
+    int h2d(void *d, const void *h, size_t n) { return n ? bad(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream)) : 0; }
+    int d2d(void *d, const void *s, size_t n) { return n ? bad(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, stream)) : 0; }
+    int d2h(void *h, const void *d, size_t n) {
+        if (n && bad(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream))) return 1;
+        return bad(hipStreamSynchronize(stream));
+    }
+    int sync() { return bad(hipStreamSynchronize(stream)); }
+
+    template <class K, class... A>
+    int launch(const char *name, K k, unsigned grid, unsigned block, size_t shmem, A... args) {
+        if (bad(hipSetDevice(dev))) return 1;
+        if (shmem > 48 * 1024 &&
+            bad(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)))
+            return 1;
+        Pending p;
+        if (prof) {
+            if (bad(hipEventCreate(&p.a)) || bad(hipEventCreate(&p.b))) return 1;
+            if (bad(hipEventRecord(p.a, stream))) return 1;
+        }
+        k<<<dim3(grid), dim3(block), shmem, stream>>>(args...);
+        if (bad(hipGetLastError())) return 1;
+        if (prof) {
+            if (bad(hipEventRecord(p.b, stream))) return 1;
+            p.name = name;
+            pending.push_back(p);
+        }
+        return 0;
+    }
+
+    void profile_enable(bool on) { prof = on; }
+    int drain() {
+        if (pending.empty()) return 0;
+        if (bad(hipStreamSynchronize(stream))) return 1;
+        for (auto &p : pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                auto &r = rows[p.name];
+                r.first++; r.second += ms;
+            }
+            (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+        }
+        pending.clear();
+        return 0;
+    }
+    int profile_get(uint32_t *n_rows, char *names, uint64_t *launches, double *ms) {
+        if (drain()) return 1;
+        if (names) {
+            uint32_t i = 0;
+            for (auto &kv : rows) {
+                if (i >= *n_rows) break;
+                snprintf(names + (size_t)i * 64, 64, "%s", kv.first.c_str());
+                launches[i] = kv.second.first; ms[i] = kv.second.second;
+                i++;
+            }
+        }
+        *n_rows = (uint32_t)rows.size();
+        return 0;
+    }
+    void profile_reset() { (void)drain(); rows.clear(); }
+};
+
+#define KD_RT HipRt
+#include "kd_abi.inl"

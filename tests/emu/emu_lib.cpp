@@ -1,0 +1,37 @@
+// emu_lib.cpp -- TEST INFRASTRUCTURE ONLY: builds tests/emu/libkindel_emu.so, which exports
+// the same C-ABI as libkindel_hip.so but executes kindel_amd/csrc/kd_kernels.h on the CPU
+// through tests/emu/hip_emu.h.  Used by `-m "not gpu"` tests to check kernel *logic*
+// (indexing, quirks, window planning, hash multiset, scan) against the oracle in a
+// container without a GPU.  Never imported by kindel_amd/, never used for measurements.
+//   g++ -O1 -std=c++20 -shared -fPIC -pthread emu_lib.cpp ../../kindel_amd/csrc/kd_decode.cpp -lz
+#include "hip_emu.h"
+
+#include <string>
+
+#include "../../kindel_amd/csrc/kd_engine.h"
+
+struct EmuRt {
+    std::string e;
+    const char *err() const { return e.c_str(); }
+    int init(int, void *) { return 0; }
+    void shutdown() {}
+    int n_cus() const { return 2; }
+    void *alloc(size_t bytes) { return aligned_alloc(256, (bytes + 255) & ~size_t(255)); }
+    void free(void *p) { ::free(p); }
+    int memset(void *p, int v, size_t n) { ::memset(p, v, n); return 0; }
+    int h2d(void *d, const void *h, size_t n) { ::memcpy(d, h, n); return 0; }
+    int d2d(void *d, const void *s, size_t n) { ::memcpy(d, s, n); return 0; }
+    int d2h(void *h, const void *d, size_t n) { ::memcpy(h, d, n); return 0; }
+    int sync() { return 0; }
+    template <class K, class... A>
+    int launch(const char *, K k, unsigned grid, unsigned block, size_t shmem, A... args) {
+        emu::launch(k, dim3(grid), dim3(block), shmem, args...);
+        return 0;
+    }
+    void profile_enable(bool) {}
+    int profile_get(uint32_t *n_rows, char *, uint64_t *, double *) { *n_rows = 0; return 0; }
+    void profile_reset() {}
+};
+
+#define KD_RT EmuRt
+#include "../../kindel_amd/csrc/kd_abi.inl"
