@@ -1,0 +1,257 @@
+#!/usr/bin/env python
+"""bench.py -- aligned-base events/s of pileup + consensus on synthetic alignments (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--scale 1.0]
+
+One "step" = one full pass of the hot path over the whole synthetic batch, inputs already
+resident in HBM: zero the tables, record loop (k_prep / k_plan / k_window / k_pileup_wave),
+insertion multiset reduction, per-site consensus, and the consensus bytes back on the host
+(N > 1: the all-gather stitch instead).  N > 1: one process per GPU (torchrun), reference
+positions sharded by G-space interval with no collective on the pileup path.  WEAK scaling: the
+N-GPU workload is N copies of the config's contig set (N x 5 Mbp at 500x for C3), so every rank
+owns one config-sized interval and synthesises the reads of its own interval.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
+kernel (per-launch durations from hipEvents on the engine's stream) and, at N = 1,
+`cpu_baseline`: the C oracle (oracle/kindel_oracle.c, a port of the reference's loops) timed on
+one host core over the same batch, which doubles as a full-size bit-exactness check.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_bytes(n_reads, query_bases, cigar_ops, sites):
+    """B = Q/2 + 4*O + 28*R + 144*S + 40*S"""
+    return query_bases / 2.0 + 4.0 * cigar_ops + 28.0 * n_reads + 184.0 * sites
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C3", help="C2 | C3 | C4 | C5 (SURVEY.md section 8d)")
+    ap.add_argument("--scale", type=float, default=1.0, help="depth multiplier (1.0 = the config as specified)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "global", "window"])
+    ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--slice", type=int, default=0)
+    ap.add_argument("--sweep", default="", help="extra tunings to time on the same batch: mode:window:slice,...")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=float, default=0.0, help="fraction of reads for the CPU baseline (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from kindel_amd import _native as N
+    from kindel_amd import shard, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+
+    cfg = dict(synth.CONFIGS[args.config])
+    if world > 1 and cfg["kind"] != "short":
+        raise SystemExit("multi-GPU bench: short-read configs only (C2, C3, C4)")
+    cfg["contig_lens"] = list(cfg["contig_lens"]) * world  # weak scaling: one config-sized interval per rank
+    cfg["depth"] = cfg["depth"] * args.scale
+    contig_lens = cfg["contig_lens"]
+    t0 = time.time()
+    batch = synth.make(cfg, device=dev, shard=(rank, world) if world > 1 else None)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    n_reads = int(batch["contig"].numel())
+    # events are credited to the rank that owns the read's start, so every read counts once
+    if world > 1:
+        own = shard.owned_mask(contig_lens, batch["contig"], batch["pos0"], rank, world)
+        cg_owner = torch.repeat_interleave(own, batch["n_cig"].long())
+        cg = batch["cigar"][: batch["cigar_words"]].long()[cg_owner]
+        n_owned = int(own.sum())
+    else:
+        cg = batch["cigar"][: batch["cigar_words"]].long()
+        n_owned = n_reads
+    ln, op = cg >> 4, cg & 15
+    aligned = int(ln[(op == 0) | (op == 7) | (op == 8)].sum())
+    query = aligned + int(ln[(op == 1) | (op == 4)].sum())
+    walked = query + int(ln[op == 2].sum())
+    n_ops = int(cg.numel())
+    tot = torch.tensor([aligned, query, walked, n_ops, n_owned], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot)
+    aligned_g, query_g, walked_g, ops_g, reads_g = (int(x) for x in tot.cpu())
+
+    mode = dict(auto=N.KD_MODE_AUTO, window=N.KD_MODE_WINDOW)[args.mode] if args.mode != "global" else N.KD_MODE_GLOBAL
+    eng = N.Engine(np.asarray(contig_lens, np.uint32), device=local_rank, mode=mode)
+    if args.window or args.slice:
+        eng.set_tuning(args.window, args.slice)
+    interval = shard.partition(contig_lens, world)[rank] if world > 1 else (0, eng.total_sites())
+    ptrs = synth.device_ptrs(batch)
+    n_contigs = len(contig_lens)
+
+    if world > 1:
+        eng.set_shard(*interval)
+
+    def step():
+        eng.reset()
+        eng.push_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"])
+        eng.finalize()
+        eng.consensus_run(1)
+        if world > 1:
+            seqs, _, _ = shard.stitch(eng, interval, dev)
+        else:
+            seqs = [eng.consensus_fetch(c, want_changes=False)[0] for c in range(n_contigs)]
+        return seqs
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        eng.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        seqs = step()
+    eng.profile_enable(True)
+    eng.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        seqs = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.profile()
+    eng.profile_enable(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    info = eng.batch_info()
+    stats = eng.stats()
+    fasta_sha = hashlib.sha256(b"\n".join(seqs)).hexdigest()
+
+    out = None
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = aligned_g / (dt / args.steps)
+        sites = int(sum(contig_lens))
+        B = algorithmic_bytes(reads_g, query_g, ops_g, sites)
+        rows = {k: (n, ms / max(n, 1)) for k, (n, ms) in prof.items()}
+        dom = max(rows.items(), key=lambda kv: kv[1][0] * kv[1][1])[0] if rows else None
+        kernel_ms_per_step = sum(n * avg for n, avg in rows.values()) / args.steps
+        roofline = None
+        if dom:
+            # per-launch algorithmic bytes of the whole path (SURVEY 8d figure x events of one launch; at N > 1
+            # one launch sees 1/N of them) over the dominant kernel's average launch duration
+            launches_per_step = rows[dom][0] / args.steps
+            a = B / world / max(launches_per_step, 1) / (rows[dom][1] * 1e-3) / 1e9
+            roofline = dict(bound="hbm", kernel=dom, achieved=round(a, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(a / HBM_PEAK_GBS, 5), traffic=_pmc_traffic(dom),
+                            avg_launch_ms=round(rows[dom][1], 4),
+                            algorithmic_bytes=int(B), bytes_per_event=round(B / max(aligned_g, 1), 4),
+                            step_achieved=round(B / (dt / args.steps) / 1e9, 2),
+                            step_frac=round(B / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5))
+        out = dict(
+            metric="aligned-base events/sec pileup+consensus", value=value, unit="events/s", n_gpus=world,
+            steps=args.steps, warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True,
+            scaling="weak", vs_baseline=None, dtype="u32", data="synthetic",
+            config=dict(workload="%s: synthetic %s, %d contig(s), %d sites, depth %gx%s" % (
+                args.config, "150 bp short reads" if cfg["kind"] == "short" else "ONT-like long reads",
+                n_contigs, sites, cfg["depth"], "" if args.scale == 1.0 else " (scaled)"),
+                reads=reads_g, aligned_events=aligned_g, walked_events=walked_g, cigar_ops=ops_g,
+                parallelism="interval-sharded x%d" % world if world > 1 else "single GPU",
+                pileup_path="window-lds" if info["windowed"] else "global-atomics",
+                window_sites=args.window or 2048, work_items=info["work_items"]),
+            roofline=roofline,
+            kernels={k: dict(launches_per_step=n / args.steps, avg_ms=round(avg, 4)) for k, (n, avg) in sorted(rows.items())},
+            kernel_ms_per_step=round(kernel_ms_per_step, 4),
+            fasta_sha256=fasta_sha, consensus_len=sum(len(s) for s in seqs), gen_seconds=round(t_gen, 1),
+            engine_stats=stats,
+        )
+    if args.sweep and world == 1:
+        # tuning sweep on the resident batch: "mode:window:slice,..." -> one JSON line each on stderr
+        for spec in args.sweep.split(","):
+            m, w, s = (spec.split(":") + ["0", "0"])[:3]
+            eng.set_mode(dict(auto=N.KD_MODE_AUTO, window=N.KD_MODE_WINDOW, **{"global": N.KD_MODE_GLOBAL})[m])
+            eng.set_tuning(int(w), int(s))
+            step()
+            eng.profile_enable(True)
+            eng.profile_reset()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            d = (time.perf_counter() - t0) / args.steps
+            pr = eng.profile()
+            eng.profile_enable(False)
+            print(json.dumps(dict(sweep=spec, ms_per_step=round(d * 1e3, 4), events_per_s=aligned_g / d,
+                                  items=eng.batch_info()["work_items"],
+                                  kernels={k: round(ms / max(n, 1), 4) for k, (n, ms) in sorted(pr.items())})),
+                  file=sys.stderr, flush=True)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(batch, contig_lens, seqs, args.cpu_sample, aligned_g)
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*pmc*.json), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get(kernel)
+        except Exception:
+            return None
+    return None
+
+
+def cpu_baseline(batch, contig_lens, gpu_seqs, sample, aligned_total):
+    """The C oracle (port of the reference's two loops) on ONE host core, same batch; bounded to
+    ~10-30 s by sub-sampling reads when the batch is large.  With the full batch it is also the
+    full-size bit-exactness check of the GPU consensus."""
+    from kindel_amd import synth
+    from oracle import oracle as ko
+    host = synth.to_numpy(batch)
+    n = len(host["contig"])
+    frac = sample if sample > 0 else min(1.0, 4.0e9 / max(aligned_total, 1))  # oracle walks ~2e8 events/s
+    if frac < 1.0:
+        keep = np.arange(n) % max(1, int(round(1.0 / frac))) == 0
+        for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+            host[k] = host[k][keep]
+    t0 = time.perf_counter()
+    ev = 0
+    same = True
+    for cid in range(len(contig_lens)):
+        oa = ko.parse_records(host, cid)
+        seq, _ = oa.consensus_sequence()
+        ev += oa.n_events_aligned
+        if frac >= 1.0:
+            same = same and (seq.encode() == gpu_seqs[cid])
+    dt = time.perf_counter() - t0
+    return dict(value=ev / dt, unit="events/s", cores=1, kind="port", host_cores=os.cpu_count(),
+                sample="%s of the %d reads (%d aligned-base events), all contigs, pileup + consensus; %.1f s" % (
+                    "all" if frac >= 1.0 else "every %d-th" % int(round(1.0 / frac)), n, ev, dt),
+                bit_exact_vs_gpu=(same if frac >= 1.0 else None))
+
+
+if __name__ == "__main__":
+    main()

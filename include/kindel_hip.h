@@ -172,6 +172,11 @@ int kd_consensus_fetch(kd_ctx *ctx, uint32_t contig, uint8_t *seq_out, uint64_t 
 /* Device-side view of the whole shard's consensus (for the multi-GPU all-gather):
  * *dev_ptr = device pointer to the concatenated bytes, *n_bytes its length. */
 int kd_consensus_device(kd_ctx *ctx, void **dev_ptr, uint64_t *n_bytes);
+/* Same for the per-site change codes: *dev_ptr = device pointer to changes[kd_total_sites] (G-space). */
+int kd_changes_device(kd_ctx *ctx, void **dev_ptr);
+/* Host-side metadata of the last run: contig_off[n_contigs+1] = byte offset of each contig in the
+ * concatenated consensus (last entry = total), depth_minmax[2*n_contigs]. Either may be NULL. */
+int kd_consensus_offsets(kd_ctx *ctx, uint64_t *contig_off, uint32_t *depth_minmax);
 
 /* ---- profiling ---------------------------------------------------------------------- */
 

@@ -26,7 +26,7 @@ KD_MODE_AUTO, KD_MODE_GLOBAL, KD_MODE_WINDOW = 0, 1, 2
 ABI_SYMBOLS = (
     "kd_abi_version kd_create kd_destroy kd_last_error kd_reset kd_set_mode kd_set_tuning kd_contig_base "
     "kd_total_sites kd_set_shard kd_push_batch kd_push_batch_device kd_sync kd_finalize kd_get_stats "
-    "kd_get_batch_info kd_get_tables kd_get_insertions kd_consensus_run kd_consensus_fetch kd_consensus_device "
+    "kd_get_batch_info kd_get_tables kd_get_insertions kd_consensus_run kd_consensus_fetch kd_consensus_device kd_changes_device kd_consensus_offsets "
     "kd_profile_enable kd_profile_get kd_profile_reset kd_decode_open kd_decode_batch kd_decode_n_contigs "
     "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error"
 ).split()
@@ -90,6 +90,8 @@ class Library:
         L.kd_consensus_run.argtypes = [p, u32, u32, p, p]
         L.kd_consensus_fetch.argtypes = [p, u32, p, u64, C.POINTER(u64), p, p, p]
         L.kd_consensus_device.argtypes = [p, C.POINTER(p), C.POINTER(u64)]
+        L.kd_changes_device.argtypes = [p, C.POINTER(p)]
+        L.kd_consensus_offsets.argtypes = [p, p, p]
         L.kd_profile_enable.argtypes = [p, C.c_int]
         L.kd_profile_get.argtypes = [p, C.POINTER(u32), p, p, p]
         L.kd_profile_reset.argtypes = [p]
@@ -309,6 +311,19 @@ class Engine:
         p, n = C.c_void_p(), C.c_uint64(0)
         self._check(self.lib.dll.kd_consensus_device(self._h, C.byref(p), C.byref(n)), "kd_consensus_device")
         return p.value, n.value
+
+    def changes_device(self):
+        p = C.c_void_p()
+        self._check(self.lib.dll.kd_changes_device(self._h, C.byref(p)), "kd_changes_device")
+        return p.value
+
+    def consensus_offsets(self):
+        """-> (contig_off uint64[n+1], depth_minmax uint32[n,2]) of the last consensus_run"""
+        n = len(self.contig_lens)
+        off = np.zeros(n + 1, np.uint64)
+        mm = np.zeros((n, 2), np.uint32)
+        self._check(self.lib.dll.kd_consensus_offsets(self._h, _ptr(off), _ptr(mm)), "kd_consensus_offsets")
+        return off, mm
 
     # -- profiling --
     def profile_enable(self, on=True):

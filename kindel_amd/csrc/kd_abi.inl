@@ -107,6 +107,20 @@ int kd_consensus_device(kd_ctx *ctx, void **dev_ptr, uint64_t *n_bytes) {
     return KD_OK;
 }
 
+int kd_changes_device(kd_ctx *ctx, void **dev_ptr) {
+    if (!ctx || !dev_ptr) return KD_E_ARG;
+    if (!ctx->e.have_cns) return ctx->e.fail(KD_E_ARG, "kd_changes_device: call kd_consensus_run first");
+    *dev_ptr = ctx->e.b_changes.p;
+    return KD_OK;
+}
+int kd_consensus_offsets(kd_ctx *ctx, uint64_t *contig_off, uint32_t *depth_minmax) {
+    if (!ctx) return KD_E_ARG;
+    if (!ctx->e.have_cns) return ctx->e.fail(KD_E_ARG, "kd_consensus_offsets: call kd_consensus_run first");
+    if (contig_off) memcpy(contig_off, ctx->e.h_coff.data(), ctx->e.h_coff.size() * 8);
+    if (depth_minmax) memcpy(depth_minmax, ctx->e.h_minmax.data(), ctx->e.h_minmax.size() * 4);
+    return KD_OK;
+}
+
 int kd_profile_enable(kd_ctx *ctx, int on) {
     if (!ctx) return KD_E_ARG;
     ctx->e.rt.profile_enable(on != 0);

@@ -1,0 +1,591 @@
+"""Host-side mirror of the reference module ``kindel.kindel`` on top of the HIP engine.
+
+Same function names, arguments, defaults, return shapes and exceptions as
+/root/reference/kindel/kindel.py, so ``from kindel_amd import kindel`` is a drop-in for
+``from kindel import kindel``:
+
+    parse_bam            :131-153   decode (native C++) -> device pileup -> ``alignment`` tuples
+    parse_records        :21-128    same, from an iterable of simplesam-like records
+    consensus            :369-381   (host helper on one weight dict; unchanged semantics)
+    consensus_sequence   :384-430   device per-site pass + host splice/trim/upper
+    build_report         :437-485
+    bam_to_consensus     :488-555
+    weights / features   :558-664   integer columns from device tables, float columns numpy/scipy
+    cdr_* / merge_*      :156-366   --realign host logic over device tables (O(L) numpy scans)
+
+The record loop and the per-site loop run in kindel_amd/csrc/kd_kernels.h on the GPU through
+the C-ABI (kindel_amd/_native.py).  There is no CPU implementation of either loop here.
+"""
+import logging
+import os
+from collections import OrderedDict, namedtuple
+
+import numpy as np
+
+from . import _native as N
+
+Region = namedtuple("Region", ["start", "end", "seq", "direction"])
+
+_CH = "ATGCN"  # key order of the reference's weight dicts (kindel.py:29)
+_CHB = np.frombuffer(b"ATGCN", np.uint8)
+
+
+class Sequence:
+    """Stand-in for dnaio.Sequence (kindel.py:433-434): .name, .sequence, .qualities"""
+
+    def __init__(self, name, sequence, qualities=None):
+        self.name, self.sequence, self.qualities = name, sequence, qualities
+
+    def __repr__(self):
+        s = self.sequence
+        return "Sequence(name=%r, sequence=%r)" % (self.name, s if len(s) < 60 else s[:57] + "...")
+
+
+# --------------------------------------------------------------------------------------
+# array-backed views that look like the reference's lists of dicts
+# --------------------------------------------------------------------------------------
+class SiteDicts:
+    """list-of-dicts view of an [L,5] uint32 table: view[i] == {"A":..,"T":..,"G":..,"C":..,"N":..}"""
+
+    def __init__(self, table, owner=None, role=None):
+        self.table, self._owner, self._role = table, owner, role
+
+    def __len__(self):
+        return self.table.shape[0]
+
+    def _one(self, i):
+        r = self.table[i]
+        return {"A": int(r[0]), "T": int(r[1]), "G": int(r[2]), "C": int(r[3]), "N": int(r[4])}
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._one(k) for k in range(*i.indices(len(self)))]
+        return self._one(i)
+
+    def __iter__(self):
+        return (self._one(i) for i in range(len(self)))
+
+
+class InsertionDicts:
+    """list-of-dicts view of the insertion multiset: view[site] == {"ACG": 3, ...} (L+1 slots)"""
+
+    def __init__(self, n_slots, site, count, strings, owner=None):
+        self._n, self._owner = n_slots, owner
+        self.site, self.count, self.strings = site, count, strings
+        self._by_site = None
+
+    def _index(self):
+        if self._by_site is None:
+            d = {}
+            for s, c, t in zip(self.site.tolist(), self.count.tolist(), self.strings):
+                d.setdefault(s, {})[t] = c
+            self._by_site = d
+        return self._by_site
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError("list index out of range")
+        return dict(self._index().get(i, {}))
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
+    def totals(self):
+        out = np.zeros(self._n, np.int64)
+        np.add.at(out, self.site.astype(np.int64), self.count.astype(np.int64))
+        return out
+
+
+alignment = namedtuple(
+    "alignment",
+    ["ref_id", "weights", "insertions", "deletions", "clip_starts", "clip_ends", "clip_start_weights",
+     "clip_end_weights", "clip_start_depth", "clip_end_depth", "clip_depth", "consensus_depth"],
+)
+
+
+class Pileup:
+    """Device-resident result of the record loop for one input (all contigs)."""
+
+    def __init__(self, engine, names, lens, order, bam_path=None):
+        self.engine, self.names, self.lens, self.order, self.bam_path = engine, names, lens, order, bam_path
+        self._tables = {}
+        self._alns = {}
+
+    def tables(self, cid):
+        """uint32 [KD_NCH, L+1] of contig cid (cached host copy)."""
+        if cid not in self._tables:
+            self._tables[cid] = self.engine.tables(cid)
+        return self._tables[cid]
+
+    def alignment(self, cid):
+        if cid in self._alns:
+            return self._alns[cid]
+        t = self.tables(cid)
+        L = int(self.lens[cid])
+        W = np.ascontiguousarray(t[0:5, :L].T)
+        S = np.ascontiguousarray(t[N.KD_CH_CSW:N.KD_CH_CSW + 5, :L].T)
+        E = np.ascontiguousarray(t[N.KD_CH_CEW:N.KD_CH_CEW + 5, :L].T)
+        site, count, strings = self.engine.insertions(cid)
+        owner = (self, cid)
+        csd = (S[:, 0] + S[:, 1] + S[:, 2] + S[:, 3]).astype(np.int64)  # A,T,G,C without N (kindel.py:90-95)
+        ced = (E[:, 0] + E[:, 1] + E[:, 2] + E[:, 3]).astype(np.int64)
+        aln = alignment(
+            self.names[cid],
+            SiteDicts(W, owner, "weights"),
+            InsertionDicts(L + 1, site, count, strings, owner),
+            t[N.KD_CH_DEL].astype(np.int64).tolist(),
+            t[N.KD_CH_CLIP_STARTS].astype(np.int64).tolist(),
+            t[N.KD_CH_CLIP_ENDS].astype(np.int64).tolist(),
+            SiteDicts(S, owner, "csw"),
+            SiteDicts(E, owner, "cew"),
+            csd.tolist(),
+            ced.tolist(),
+            (csd + ced).tolist(),                       # kindel.py:96
+            W.max(axis=1).astype(np.int64) if L else np.zeros(0, np.int64),  # aligned - discordant, :83-89
+        )
+        self._alns[cid] = aln
+        return aln
+
+
+def _first_appearance(contig):
+    if len(contig) == 0:
+        return []
+    _, first = np.unique(contig, return_index=True)
+    return [int(contig[i]) for i in np.sort(first)]
+
+
+def pileup_batch(batch, bam_path=None, device=0, lib=None, mode=N.KD_MODE_AUTO):
+    """Run the device record loop over one decoded batch -> Pileup (raises what the reference raises)."""
+    names = [str(x) for x in batch["contig_names"]]
+    lens = np.asarray(batch["contig_lens"], np.uint32)
+    if len(lens) == 0:
+        raise KeyError("no @SQ lines in header")
+    eng = N.Engine(lens, device=device, lib=lib, mode=mode)
+    eng.push(batch)
+    eng.finalize()
+    return Pileup(eng, names, lens, _first_appearance(np.asarray(batch["contig"])), bam_path)
+
+
+def pileup_file(bam_path, device=0, lib=None, threads=0):
+    return pileup_batch(N.decode_file(bam_path, threads=threads, lib=lib), bam_path=bam_path, device=device, lib=lib)
+
+
+def parse_bam(bam_path):
+    """Returns alignment information for each reference sequence as an OrderedDict (kindel.py:131-153)"""
+    pl = pileup_file(bam_path)
+    return OrderedDict((pl.names[cid], pl.alignment(cid)) for cid in pl.order)
+
+
+_NIB = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+_OPS = {c: i for i, c in enumerate("MIDNSHP=X")}
+
+
+def parse_records(ref_id, ref_len, records):
+    """parse_records(ref_id, ref_len, records) of kindel.py:21-128 for an iterable of
+    simplesam-like records (.pos, .mapped, .seq, .cigars); packs them and runs the device loop."""
+    contig, pos0, flag, seq_off, seq_len, cig_off, n_cig, seq4, cigar = [], [], [], [], [], [], [], bytearray(), []
+    for r in records:
+        s = "" if r.seq == "*" else r.seq
+        ops = []
+        try:
+            for ln, op in r.cigars:
+                if op is not None:
+                    ops.append((int(ln) << 4) | _OPS.get(op, 15))
+        except RuntimeError:
+            ops = []  # CIGAR '*': the engine raises RuntimeError for a mapped read with real SEQ (kindel.py:47)
+        contig.append(0); pos0.append(r.pos - 1); flag.append(0 if r.mapped else 4)
+        seq_off.append(len(seq4)); seq_len.append(len(s)); cig_off.append(len(cigar)); n_cig.append(len(ops))
+        nib = [_NIB.get(c.upper(), 0) for c in s] + [0]
+        seq4.extend((nib[i] << 4) | nib[i + 1] for i in range(0, len(s), 2))
+        cigar.extend(ops)
+    batch = dict(contig=np.asarray(contig, np.uint32), pos0=np.asarray(pos0, np.int32), flag=np.asarray(flag, np.uint32),
+                 seq_off=np.asarray(seq_off, np.uint64), seq_len=np.asarray(seq_len, np.uint32),
+                 cig_off=np.asarray(cig_off, np.uint64), n_cig=np.asarray(n_cig, np.uint32),
+                 seq4=np.frombuffer(bytes(seq4) + b"\0", np.uint8), cigar=np.asarray(cigar + [0], np.uint32),
+                 contig_names=np.asarray([ref_id]), contig_lens=np.asarray([ref_len], np.uint32))
+    return pileup_batch(batch).alignment(0)
+
+
+# --------------------------------------------------------------------------------------
+# realign: clip-dominant regions (kindel.py:156-366), host scans over device tables
+# --------------------------------------------------------------------------------------
+def _cns_chars(tab5):
+    """consensus(w)[0] per site for an [n,5] table: first max in A,T,G,C,N order, 'N' if empty (kindel.py:373-375)"""
+    idx = np.argmax(tab5, axis=1)
+    ch = _CHB[idx].copy()
+    ch[tab5.sum(axis=1) == 0] = ord("N")
+    return ch
+
+
+def _tab(x):
+    return x.table if isinstance(x, SiteDicts) else np.asarray([[d[c] for c in _CH] for d in x], np.int64).reshape(-1, 5)
+
+
+def _masked(L, mask_ends):
+    m = np.zeros(L, bool)
+    m[:mask_ends] = True          # positions[:mask_ends]
+    m[L - mask_ends if mask_ends else 0:] = True  # positions[-mask_ends:] (mask_ends == 0 masks everything, :168)
+    return m
+
+
+def cdr_start_consensuses(weights, deletions, clip_start_weights, clip_start_depth, clip_decay_threshold, mask_ends):
+    """Returns list of Region instances for right clipped consensuses of clip-dominant region (kindel.py:156-213)"""
+    W, S = _tab(weights).astype(np.int64), _tab(clip_start_weights).astype(np.int64)
+    L = W.shape[0]
+    d = np.asarray(deletions, np.int64)[:L]
+    csd = np.asarray(clip_start_depth, np.int64)[:L]
+    wsum = W.sum(axis=1)
+    cand = (2 * csd > wsum + d + 1) & ~_masked(L, mask_ends)            # csd/(sum+d+1) > 0.5, :183
+    ext = csd > (wsum + d).astype(np.float64) * clip_decay_threshold    # :202
+    stops = np.flatnonzero(~ext)
+    chars = _cns_chars(S)
+    regions = []
+    covered_to = -1  # regions are created left to right and only grow rightwards
+    for pos in np.flatnonzero(cand).tolist():
+        if any(r.start <= pos < r.end for r in regions):
+            continue
+        k = np.searchsorted(stops, pos)
+        if k < len(stops):
+            end_pos = int(stops[k])
+            seq = chars[pos:end_pos].tobytes().decode()
+        else:  # ran to the end of the contig without break: end_pos is the last index, its base included
+            end_pos = L - 1
+            seq = chars[pos:L].tobytes().decode()
+        regions.append(Region(pos, end_pos, seq, "→"))
+    for region in regions:
+        logging.debug(region)
+    del covered_to
+    return regions
+
+
+def cdr_end_consensuses(weights, deletions, clip_end_weights, clip_end_depth, clip_decay_threshold, mask_ends):
+    """Returns list of Region instances for left clipped consensuses of clip-dominant region (kindel.py:216-275)"""
+    W, E = _tab(weights).astype(np.int64), _tab(clip_end_weights).astype(np.int64)
+    L = W.shape[0]
+    d = np.asarray(deletions, np.int64)[:L]
+    ced = np.asarray(clip_end_depth, np.int64)[:L]
+    wsum = W.sum(axis=1)
+    cand = (2 * ced > wsum + d + 1) & ~_masked(L, mask_ends)            # :244
+    ext = ced > (wsum + d).astype(np.float64) * clip_decay_threshold    # :256
+    stops = np.flatnonzero(~ext)
+    chars = _cns_chars(E)
+    regions = []
+    for pos in np.flatnonzero(cand)[::-1].tolist():
+        if any(r.start <= pos < r.end for r in regions):
+            continue
+        end_pos = pos + 1
+        if pos == 0:  # reversed_weights[L:] is empty: for-else with nothing accumulated (:251,268-270)
+            regions.append(Region(pos, end_pos, "", "←"))
+            continue
+        k = np.searchsorted(stops, pos - 1, side="right") - 1  # largest stop index <= pos-1
+        if k >= 0:
+            b = int(stops[k])  # extension breaks here; start_pos = b, bases b+1 .. pos
+            start_pos = b
+            seq = chars[b + 1:pos + 1].tobytes().decode() if b < pos - 1 else ""
+        else:  # never broke: walked down to site 0, bases 0 .. pos
+            start_pos = 0
+            seq = chars[0:pos + 1].tobytes().decode()
+        regions.append(Region(start_pos, end_pos, seq, "←"))
+    for region in regions:
+        logging.debug(region)
+    return regions
+
+
+def cdrp_consensuses(weights, deletions, clip_start_weights, clip_end_weights, clip_start_depth, clip_end_depth,
+                     clip_decay_threshold, mask_ends):
+    """Returns list of 2-tuples of L&R clipped consensus sequences around clip-dominant regions (kindel.py:278-320)"""
+    fwd_cdrs = cdr_start_consensuses(weights, deletions, clip_start_weights, clip_start_depth,
+                                     clip_decay_threshold, mask_ends)
+    rev_cdrs = cdr_end_consensuses(weights, deletions, clip_end_weights, clip_end_depth,
+                                   clip_decay_threshold, mask_ends)
+    paired_cdrs = []
+    for f in fwd_cdrs:
+        for r in rev_cdrs:
+            if max(f.start, r.start) < min(f.end, r.end):  # set(range) & set(range) non-empty, :314
+                paired_cdrs.append((f, r))
+                break
+    return paired_cdrs
+
+
+def merge_by_lcs(s1, s2, min_overlap):
+    """Returns superstring of s1 and s2 about an exact overlap of len > min_overlap (kindel.py:323-347)"""
+    a = np.frombuffer(s1.encode(), np.uint8)
+    b = np.frombuffer(s2.encode(), np.uint8)
+    longest, x_longest = 0, 0
+    prev = np.zeros(len(b) + 1, np.int64)
+    for x in range(1, len(a) + 1):  # row-wise form of the reference's DP; first strict maximum wins
+        row = np.zeros(len(b) + 1, np.int64)
+        eq = b == a[x - 1]
+        row[1:][eq] = prev[:-1][eq] + 1
+        m = int(row.max()) if len(b) else 0
+        if m > longest:
+            longest, x_longest = m, x
+        prev = row
+    lcs = s1[x_longest - longest:x_longest]
+    logging.debug(f"merge_by_lcs(): s1: {s1}, s2: {s2}, min_overlap: {min_overlap}")
+    if len(lcs) < min_overlap:
+        return None
+    return s1.split(lcs, 1)[0] + lcs + s2.split(lcs, 1)[1]
+
+
+def merge_cdrps(cdrps, min_overlap):
+    """Returns merged clip-dominant region pairs as Region instances (kindel.py:350-366)"""
+    merged = []
+    for fwd_cdr, rev_cdr in cdrps:
+        merged_seq = merge_by_lcs(fwd_cdr.seq, rev_cdr.seq, min_overlap)
+        if not merged_seq:
+            logging.warning(
+                f"No overlap found for clip dominant region spanning positions {fwd_cdr.start}-{rev_cdr.end} (min_overlap = {min_overlap})")
+        merged.append(Region(fwd_cdr.start, rev_cdr.end, merged_seq, None))
+    return merged
+
+
+# --------------------------------------------------------------------------------------
+# consensus
+# --------------------------------------------------------------------------------------
+def consensus(weight):
+    """Returns tuple of consensus base, weight and flag indicating a tie for consensus (kindel.py:369-381)"""
+    base, frequency = max(weight.items(), key=lambda x: x[1]) if sum(weight.values()) else ("N", 0)
+    weight_sans_consensus = {k: d for k, d in weight.items() if k != base}
+    tie = True if frequency and frequency in weight_sans_consensus.values() else False
+    aligned_depth = sum(weight.values())
+    proportion = round(frequency / aligned_depth, 2) if aligned_depth else 0
+    return (base, frequency, proportion, tie)
+
+
+def _patch_plan(L, cdr_patches):
+    """The skip/patch control flow of consensus_sequence (kindel.py:393-401) as data:
+    -> [(start, end, text)]: sites [start, end) emit nothing, `text` is spliced at start."""
+    plan = []
+    if not cdr_patches:
+        return plan
+    starts = sorted({r.start for r in cdr_patches if r.seq and 0 <= r.start < L})
+    pos = 0
+    for s in starts:
+        if s < pos:
+            continue  # inside a span being skipped: never examined
+        patch = next(r for r in cdr_patches if r.start == s)
+        text = patch.seq.lower()  # AttributeError if the first patch at s has seq None, as in the reference
+        span = patch.end - patch.start
+        if span - 1 < 0:  # skip_positions goes negative and stays truthy: nothing else is ever emitted
+            plan.append((s, L, text))
+            break
+        plan.append((s, min(L, s + span), text))
+        pos = s + span
+    return plan
+
+
+def _device_consensus(pl, cid, cdr_patches, trim_ends, min_depth, uppercase):
+    L = int(pl.lens[cid])
+    base = pl.engine.contig_base(cid)
+    plan = _patch_plan(L, cdr_patches)
+    pl.engine.consensus_run(min_depth, [(base + s, base + e) for s, e, _ in plan])
+    raw, ch, mm, poff = pl.engine.consensus_fetch(cid)
+    if plan:
+        parts, prev = [], 0
+        for (s, e, text), o in zip(plan, poff.tolist()):
+            parts.append(raw[prev:o]); parts.append(text.encode()); prev = o
+        parts.append(raw[prev:])
+        raw = b"".join(parts)
+    seq = raw.decode("ascii")
+    if trim_ends:
+        seq = seq.strip("N")        # kindel.py:425-426
+    if uppercase:
+        seq = seq.upper()           # kindel.py:427-428
+    return seq, ch, mm
+
+
+_CHG = {0: None, ord("D"): "D", ord("N"): "N", ord("I"): "I"}
+
+
+def _changes_list(ch):
+    out = [None] * len(ch)
+    for i in np.flatnonzero(ch).tolist():
+        out[i] = _CHG[int(ch[i])]
+    return out
+
+
+def consensus_sequence(weights, insertions, deletions, cdr_patches, trim_ends, min_depth, uppercase):
+    """consensus_sequence of kindel.py:384-430.  `weights` must come from this package's
+    parse_bam()/parse_records() (it carries a handle to the device tables)."""
+    owner = getattr(weights, "_owner", None)
+    if owner is None:
+        raise TypeError("kindel_amd.consensus_sequence needs the weights object returned by kindel_amd.parse_bam(); "
+                        "arbitrary list-of-dict tables have no device pileup behind them")
+    pl, cid = owner
+    seq, ch, _ = _device_consensus(pl, cid, cdr_patches, trim_ends, min_depth, uppercase)
+    return seq, _changes_list(ch)
+
+
+def consensus_seqrecord(consensus, ref_id):
+    return Sequence(name=f"{ref_id}_cns", sequence=consensus, qualities=None)
+
+
+def _report(ref_id, depth_minmax, ch, cdr_patches, bam_path, realign, min_depth, min_overlap, clip_decay_threshold,
+            trim_ends, uppercase):
+    def sites(code):
+        return ", ".join(str(p + 1) for p in np.flatnonzero(ch == ord(code)).tolist())
+
+    cdr_patches_fmt = ["{}-{}: {}".format(r.start, r.end, r.seq) for r in cdr_patches] if cdr_patches else ""
+    report = "========================= REPORT ===========================\n"
+    report += "reference: {}\n".format(ref_id)
+    report += "options:\n"
+    report += "- bam_path: {}\n".format(bam_path)
+    report += "- min_depth: {}\n".format(min_depth)
+    report += "- realign: {}\n".format(realign)
+    report += "    - min_overlap: {}\n".format(min_overlap)
+    report += "    - clip_decay_threshold: {}\n".format(clip_decay_threshold)
+    report += "- trim_ends: {}\n".format(trim_ends)
+    report += "- uppercase: {}\n".format(uppercase)
+    report += "observations:\n"
+    report += "- min, max observed depth: {}, {}\n".format(depth_minmax[0], depth_minmax[1])
+    report += "- ambiguous sites: {}\n".format(sites("N"))
+    report += "- insertion sites: {}\n".format(sites("I"))
+    report += "- deletion sites: {}\n".format(sites("D"))
+    report += "- clip-dominant regions: {}\n".format(", ".join(cdr_patches_fmt))
+    return report
+
+
+def build_report(ref_id, weights, changes, cdr_patches, bam_path, realign, min_depth, min_overlap,
+                 clip_decay_threshold, trim_ends, uppercase):
+    """build_report of kindel.py:437-485 (host text formatting)."""
+    W = _tab(weights)
+    ad = W[:, 0] + W[:, 1] + W[:, 2] + W[:, 3]  # A,T,G,C: no N (:450)
+    ch = np.asarray([0 if c is None else ord(c) for c in changes], np.uint8)
+    return _report(ref_id, (int(ad.min()), int(ad.max())), ch, cdr_patches, bam_path, realign, min_depth, min_overlap,
+                   clip_decay_threshold, trim_ends, uppercase)
+
+
+def bam_to_consensus(bam_path, realign=False, min_depth=1, min_overlap=9, clip_decay_threshold=0.1, mask_ends=50,
+                     trim_ends=False, uppercase=False):
+    """bam_to_consensus of kindel.py:488-555: same arguments, same result tuple."""
+    consensuses, refs_changes, refs_reports = [], {}, {}
+    pl = pileup_file(bam_path)
+    for cid in pl.order:
+        ref_id = pl.names[cid]
+        if realign:
+            aln = pl.alignment(cid)
+            cdrps = cdrp_consensuses(aln.weights, aln.deletions, aln.clip_start_weights, aln.clip_end_weights,
+                                     aln.clip_start_depth, aln.clip_end_depth, clip_decay_threshold, mask_ends)
+            cdr_patches = merge_cdrps(cdrps, min_overlap)
+        else:
+            cdr_patches = None
+        seq, ch, mm = _device_consensus(pl, cid, cdr_patches, trim_ends, min_depth, uppercase)
+        report = _report(ref_id, mm, ch, cdr_patches, bam_path, realign, min_depth, min_overlap, clip_decay_threshold,
+                         trim_ends, uppercase)
+        consensuses.append(consensus_seqrecord(seq, ref_id))
+        refs_reports[ref_id] = report
+        refs_changes[ref_id] = _changes_list(ch)
+    result = namedtuple("result", ["consensuses", "refs_changes", "refs_reports"])
+    return result(consensuses, refs_changes, refs_reports)
+
+
+# --------------------------------------------------------------------------------------
+# tables as DataFrames (kindel.py:558-664): integer columns from the device, floats on host
+# --------------------------------------------------------------------------------------
+def weights(bam_path, relative=False, confidence=True, confidence_alpha=0.01):
+    """Returns DataFrame of per-site nucleotide frequencies, depth, consensus, clip start/end,
+    confidence intervals and entropy (kindel.py:558-630)."""
+    import pandas as pd
+    import scipy.stats
+
+    pl = pileup_file(bam_path)
+    frames = []
+    for cid in pl.order:
+        t = pl.tables(cid).astype(np.int64)
+        L = int(pl.lens[cid])
+        ins = t[N.KD_CH_INS_TOTAL]
+        frames.append(pd.DataFrame(OrderedDict([
+            ("chrom", np.full(L, pl.names[cid], dtype=object)),
+            ("pos", np.arange(1, L + 1, dtype=np.int64)),
+            ("A", t[N.KD_CH_A, :L]), ("C", t[N.KD_CH_C, :L]), ("G", t[N.KD_CH_G, :L]), ("T", t[N.KD_CH_T, :L]),
+            ("N", t[N.KD_CH_N, :L]),
+            ("insertions", ins[1:L + 1]),                  # sum(aln.insertions[i]), i = 1..L   (:581)
+            ("deletions", t[N.KD_CH_DEL, :L]),             # aln.deletions[i - 1]              (:582)
+            ("clip_starts", t[N.KD_CH_CLIP_STARTS, :L]),   # (:583)
+            ("clip_ends", t[N.KD_CH_CLIP_ENDS, :L]),       # (:584)
+        ])))
+    weights_df = pd.concat(frames, ignore_index=True) if frames else pd.DataFrame(
+        columns=["chrom", "pos", "A", "C", "G", "T", "N", "insertions", "deletions", "clip_starts", "clip_ends"])
+    six = ["A", "C", "G", "T", "N", "deletions"]
+    weights_df["depth"] = weights_df[six].sum(axis=1)
+    consensus_depths_df = weights_df[six].max(axis=1)
+    weights_df["consensus"] = consensus_depths_df.divide(weights_df.depth)
+    rel_weights_df = pd.DataFrame()
+    for nt in six:
+        rel_weights_df[[nt]] = weights_df[[nt]].divide(weights_df.depth, axis=0)
+    rel_weights_df = rel_weights_df.round({nt: 4 for nt in six})
+    with np.errstate(invalid="ignore", divide="ignore"):
+        weights_df["shannon"] = scipy.stats.entropy(rel_weights_df[["A", "C", "G", "T"]].values, axis=1)
+    if confidence:
+        c = consensus_depths_df.to_numpy()
+        n = weights_df["depth"].to_numpy()
+        lo, hi = scipy.stats.beta.interval(1 - confidence_alpha, c + 0.5, n - c + 0.5)  # Jeffreys, :569-574
+        weights_df["lower_ci"] = lo
+        weights_df["upper_ci"] = hi
+    if relative:
+        for nt in ["A", "C", "G", "T", "N"]:
+            weights_df[[nt]] = rel_weights_df[[nt]]
+    return weights_df.round(dict(consensus=3, lower_ci=3, upper_ci=3, shannon=3))
+
+
+def features(bam_path):
+    """Returns DataFrame of relative per-site nucleotide frequencies, insertions, deletions and
+    entropy (kindel.py:633-664).  Deliberate divergence: the reference indexes the *last* contig's
+    indel tables with a global row counter (:644-646) and so crashes on multi-contig input; here
+    every contig uses its own tables (identical for single-contig input)."""
+    import pandas as pd
+    import scipy.stats
+
+    pl = pileup_file(bam_path)
+    frames = []
+    for cid in pl.order:
+        t = pl.tables(cid).astype(np.int64)
+        L = int(pl.lens[cid])
+        frames.append(pd.DataFrame(OrderedDict([
+            ("chrom", np.full(L, pl.names[cid], dtype=object)), ("pos", np.arange(1, L + 1, dtype=np.int64)),
+            ("A", t[N.KD_CH_A, :L]), ("C", t[N.KD_CH_C, :L]), ("G", t[N.KD_CH_G, :L]), ("T", t[N.KD_CH_T, :L]),
+            ("N", t[N.KD_CH_N, :L]), ("i", t[N.KD_CH_INS_TOTAL, :L]), ("d", t[N.KD_CH_DEL, :L])])))
+    df = pd.concat(frames, ignore_index=True)
+    df["depth"] = df[["A", "C", "G", "T", "N", "d"]].sum(axis=1)
+    consensus_depths = df[["A", "C", "G", "T", "N"]].max(axis=1)
+    df["consensus"] = consensus_depths.divide(df.depth)
+    for nt in ["A", "C", "G", "T", "N", "i", "d"]:
+        df[[nt]] = df[[nt]].divide(df.depth, axis=0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        df["shannon"] = scipy.stats.entropy(df[["A", "C", "G", "T", "i", "d"]].values.astype(float), axis=1)
+    return df.round(3)
+
+
+def plotly_clips(bam_path):
+    """kindel.py:667-703: HTML depth / soft-clip plot of the first contig (needs plotly)."""
+    import plotly.graph_objs as go
+    import plotly.offline as py
+
+    pl = pileup_file(bam_path)
+    aln = pl.alignment(pl.order[0])
+    t = pl.tables(pl.order[0]).astype(np.int64)
+    aligned_depth = t[0:5, :-1].sum(axis=0).tolist()
+    ins = t[N.KD_CH_INS_TOTAL].tolist()
+    x_axis = list(range(1, len(aligned_depth) + 1))
+    traces = [
+        go.Scattergl(x=x_axis, y=aligned_depth, mode="lines", name="Aligned depth"),
+        go.Scattergl(x=x_axis, y=aln.clip_depth, mode="lines", name="Soft clip total depth"),
+        go.Scattergl(x=x_axis, y=aln.clip_start_depth, mode="lines", name="Soft clip start depth"),
+        go.Scattergl(x=x_axis, y=aln.clip_end_depth, mode="lines", name="Soft clip end depth"),
+        go.Scattergl(x=x_axis, y=aln.clip_starts, mode="markers", name="Soft clip starts"),
+        go.Scattergl(x=x_axis, y=aln.clip_ends, mode="markers", name="Soft clip ends"),
+        go.Scattergl(x=x_axis, y=ins, mode="markers", name="Insertions"),
+        go.Scattergl(x=x_axis, y=aln.deletions, mode="markers", name="Deletions"),
+    ]
+    layout = go.Layout(xaxis=dict(type="linear", autorange=True), yaxis=dict(type="linear", autorange=True))
+    fig = go.Figure(data=traces, layout=layout)
+    out_fn = os.path.splitext(os.path.split(bam_path)[1])[0]
+    py.plot(fig, filename=out_fn + ".plot.html", auto_open=False)

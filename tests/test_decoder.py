@@ -1,0 +1,69 @@
+"""Native SAM/BAM decoder (kd_decode.cpp) against the independent pure-Python reader (oracle/samio_py.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from kindel_amd import _native as N
+from kindel_amd import synth
+from oracle import quirk_cases, samio_py
+from tests import parity as P
+
+KEYS = ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig")
+
+
+def same_batch(a, b):
+    for k in KEYS:
+        assert np.array_equal(np.asarray(a[k]).astype(np.int64), np.asarray(b[k]).astype(np.int64)), k
+    assert a["seq4"][: int(a["seq_off"][-1]) if len(a["seq_off"]) else 0].tobytes() == \
+        b["seq4"][: int(b["seq_off"][-1]) if len(b["seq_off"]) else 0].tobytes()
+    nw = int(np.asarray(a["n_cig"]).sum())
+    assert np.array_equal(a["cigar"][:nw], b["cigar"][:nw])
+    assert [str(x) for x in a["contig_names"]] == [str(x) for x in b["contig_names"]]
+    assert np.array_equal(a["contig_lens"], b["contig_lens"])
+
+
+@pytest.mark.parametrize("name", ["plain_M", "lowercase_bases", "star_rname_dropped", "ERR_cigar_star_mapped",
+                                  "many_ops_long_cigar", "unmapped_and_short_reads_skipped", "P_eq_X_ops"])
+def test_sam_text(tmp_path, name):
+    p = tmp_path / "x.sam"
+    p.write_text(quirk_cases.CASES[name])
+    same_batch(N.decode_file(p), samio_py.load_batch(str(p)))
+
+
+def test_bam_roundtrip_synthetic(tmp_path):
+    batch = synth.to_numpy(synth.short_reads([3000, 1500], 20, seed=7))
+    p = tmp_path / "x.bam"
+    synth.write_bam(str(p), batch)
+    for threads in (1, 4):
+        got = N.decode_file(p, threads=threads)
+        same_batch(got, batch)
+        assert got["n_records"] == len(batch["contig"])
+    same_batch(samio_py.load_batch(str(p)), batch)
+
+
+def test_bam_long_reads_roundtrip(tmp_path):
+    batch = synth.to_numpy(synth.long_reads([40000], 5, seed=9))
+    p = tmp_path / "l.bam"
+    synth.write_bam(str(p), batch)
+    same_batch(N.decode_file(p), batch)
+
+
+def test_unreadable_file(tmp_path):
+    with pytest.raises(OSError):
+        N.decode_file(tmp_path / "missing.bam")
+    bad = tmp_path / "bad.bam"
+    bad.write_bytes(b"\x1f\x8b\x08\x04garbage")
+    with pytest.raises(OSError):
+        N.decode_file(bad)
+
+
+@pytest.mark.skipif(not os.path.isdir(P.REF_TESTS), reason="reference fixtures only exist in the build container")
+@pytest.mark.parametrize("rel", ["data_bwa_mem/1.1.sub_test.bam", "data_minimap2/1.1.multi.bam",
+                                 "data_minimap2/hxb2-gp120-mutated.bam", "data_minimap2_bact/bact.tiny.bam",
+                                 "data_ext/1.issue23.debug.sam", "data_segemehl/6.1.sub_test.bam"])
+def test_reference_fixture_files(rel):
+    path = os.path.join(P.REF_TESTS, rel)
+    key = rel.replace("data_", "").replace("/", "__").rsplit(".", 1)[0]
+    got = N.decode_file(path)
+    same_batch(got, P.load_fixture(key))

@@ -1,0 +1,116 @@
+"""Kernel LOGIC under the CPU emulator (tests/emu) against the oracle.  Same kernel source, same host
+orchestration, same C-ABI as the product; only the runtime policy differs.  Not a measurement and
+not a substitute for the `-m gpu` parity tests -- it exists so indexing / quirk bugs are caught in a
+container without a GPU."""
+import numpy as np
+import pytest
+
+from kindel_amd import _native as N
+from kindel_amd import shard, synth
+from oracle import oracle as ko
+from tests import parity as P
+
+QUIRKS = P.golden_quirks()
+MODES = [N.KD_MODE_GLOBAL, N.KD_MODE_AUTO]
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", sorted(k for k in QUIRKS if not k.startswith("__")))
+def test_quirk_case(emu_lib, name, mode):
+    entry = QUIRKS[name]
+    batch = P.sam_to_batch(entry["sam"])
+    exc = P.quirk_expect(entry)
+    if exc:
+        with pytest.raises(exc):
+            P.Run(emu_lib, batch, mode=mode, window=64)
+        return
+    run = P.Run(emu_lib, batch, mode=mode, window=64)
+    P.assert_matches_oracle(run, what=name)
+    for md in (0, 2):
+        P.assert_matches_oracle(P.Run(emu_lib, batch, mode=mode, window=64, min_depth=md), min_depth=md, what=name)
+
+
+@pytest.mark.parametrize("key,n0,n1,window,slice_reads", [
+    ("bwa_mem__1.1.sub_test", 0, 1200, 256, 64),
+    ("bwa_mem__2.1.sub_test", 5000, 5600, 128, 0),
+    ("segemehl__1.1.sub_test", 3000, 3800, 512, 0),
+    ("minimap2__1.1.multi", 0, 100000, 64, 32),
+    ("minimap2__hxb2-gp120-mutated", 0, 1000, 256, 16),
+    ("ext__3.issue23.bc75", 0, 100, 256, 8),
+    ("ext__2.issue23.bc63", 0, 150, 2048, 0),
+])
+@pytest.mark.parametrize("mode", MODES)
+def test_fixture_subset(emu_lib, key, n0, n1, window, slice_reads, mode):
+    batch = P.subset(P.load_fixture(key), n0, n1)
+    run = P.Run(emu_lib, batch, mode=mode, window=window, slice_reads=slice_reads)
+    P.assert_matches_oracle(run, what=key)
+
+
+def test_full_small_fixtures_match_reference_goldens(emu_lib):
+    gold = P.golden_outputs()
+    for key in ("ext__3.issue23.bc75", "minimap2__1.1.multi"):
+        run = P.Run(emu_lib, P.load_fixture(key), window=128)
+        P.assert_matches_golden(run, key, gold)
+
+
+def test_window_path_is_taken_and_unsorted_falls_back(emu_lib):
+    b = P.subset(P.load_fixture("bwa_mem__1.1.sub_test"), 0, 300)
+    run = P.Run(emu_lib, b, window=128)
+    assert run.info["windowed"] == 1 and run.info["unsorted"] == 0 and run.info["work_items"] > 1
+    assert run.info["regular"] + run.info["irregular"] <= 300
+    rev = dict(b)
+    for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+        rev[k] = b[k][::-1].copy()
+    run2 = P.Run(emu_lib, rev, window=128)
+    assert run2.info["windowed"] == 0 and run2.info["unsorted"] > 0
+    P.assert_matches_oracle(run2)
+    for cid in run.order:
+        assert np.array_equal(run.tables[cid], run2.tables[cid])  # sums are order independent
+
+
+def test_multiple_pushes_accumulate(emu_lib):
+    b = P.subset(P.load_fixture("segemehl__2.1.sub_test"), 100, 700)
+    P.assert_matches_oracle(P.Run(emu_lib, b, window=256, n_pushes=3))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_synthetic_short_reads_with_planted_features(emu_lib, mode):
+    batch = synth.to_numpy(synth.short_reads([7000, 6200], 12, seed=5))
+    run = P.Run(emu_lib, batch, mode=mode, window=512, slice_reads=100)
+    P.assert_matches_oracle(run)
+    ch = np.concatenate([run.cns[c][1] for c in run.order])
+    assert (ch == ord("D")).any() and (ch == ord("I")).any() and (ch == ord("N")).any()
+    seqs = b"".join(run.cns[c][0] for c in run.order)
+    assert any(chr(c).islower() for c in seqs)
+
+
+def test_synthetic_long_reads(emu_lib):
+    batch = synth.to_numpy(synth.long_reads([30000], 4, seed=6, median_len=3000, min_len=1000, max_len=6000))
+    run = P.Run(emu_lib, batch, window=1024)
+    assert run.info["long_cigar"] > 0 and run.info["windowed"] == 1
+    P.assert_matches_oracle(run)
+
+
+def test_virtual_shards_stitch_to_the_unsharded_result(emu_lib):
+    """N shards on one device: the union of the per-interval pieces equals the single-context result."""
+    batch = synth.to_numpy(synth.short_reads([5000, 4000], 10, seed=8))
+    full = P.Run(emu_lib, batch, window=256)
+    world = 3
+    ivs = shard.partition(batch["contig_lens"], world)
+    base, S = shard.g_layout(batch["contig_lens"])
+    pieces = {c: [] for c in full.order}
+    for r in range(world):
+        keep = shard.reads_of_rank(batch["contig_lens"], batch["contig"], batch["pos0"], batch["pos0"] + 300, r, world)
+        sub = dict(batch)
+        for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+            sub[k] = batch[k][keep]
+        run = P.Run(emu_lib, sub, window=256, shard=ivs[r])
+        for c in full.order:
+            if c in run.cns:
+                pieces[c].append(run.cns[c][0])
+            lo = max(int(base[c]), ivs[r][0]) - int(base[c])
+            hi = min(int(base[c]) + int(batch["contig_lens"][c]), ivs[r][1]) - int(base[c])
+            if hi > lo and c in run.tables:
+                assert np.array_equal(run.tables[c][:, lo:hi], full.tables[c][:, lo:hi])
+    for c in full.order:
+        assert b"".join(pieces[c]) == full.cns[c][0]

@@ -1,0 +1,219 @@
+"""`-m gpu`: the HIP kernels on a real MI355X, through the C-ABI, against the oracle and the reference's
+golden outputs.  Bit-exact: every integer table, every insertion dict, consensus bytes, change codes."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from kindel_amd import _native as N
+from kindel_amd import shard, synth
+from oracle import oracle as ko
+from tests import parity as P
+
+pytestmark = pytest.mark.gpu
+QUIRKS = P.golden_quirks()
+GOLD = P.golden_outputs()
+MODES = [N.KD_MODE_GLOBAL, N.KD_MODE_AUTO]
+ROOT = P.ROOT
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", sorted(k for k in QUIRKS if not k.startswith("__")))
+def test_quirk_case(hip_lib, name, mode):
+    entry = QUIRKS[name]
+    batch = P.sam_to_batch(entry["sam"])
+    exc = P.quirk_expect(entry)
+    if exc:
+        with pytest.raises(exc):
+            P.Run(hip_lib, batch, mode=mode, window=64)
+        return
+    for md in (1, 0, 2):
+        P.assert_matches_oracle(P.Run(hip_lib, batch, mode=mode, window=64, min_depth=md), min_depth=md, what=name)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("key", P.fixture_keys())
+def test_reference_fixture(hip_lib, key, mode):
+    batch = P.load_fixture(key)
+    run = P.Run(hip_lib, batch, mode=mode)
+    P.assert_matches_golden(run, key, GOLD)   # what the unmodified reference produced
+    P.assert_matches_oracle(run, what=key)    # full tables, element by element
+
+
+@pytest.mark.parametrize("window,slice_reads", [(64, 16), (256, 0), (1024, 64), (2048, 0), (4096, 1000), (6144, 0)])
+def test_window_tunings(hip_lib, window, slice_reads):
+    for key in ("bwa_mem__3.1.sub_test", "segemehl__6.1.sub_test", "minimap2__1.1.multi"):
+        run = P.Run(hip_lib, P.load_fixture(key), window=window, slice_reads=slice_reads)
+        assert run.info["windowed"] == 1
+        P.assert_matches_golden(run, key, GOLD)
+
+
+def test_unsorted_input_and_multiple_pushes(hip_lib):
+    b = P.load_fixture("minimap2__hxb2-gp120-mutated")      # SO:unsorted in the reference's own fixture
+    run = P.Run(hip_lib, b)
+    assert run.info["windowed"] == 0 and run.info["unsorted"] > 0
+    P.assert_matches_golden(run, "minimap2__hxb2-gp120-mutated", GOLD)
+    b = P.load_fixture("segemehl__2.1.sub_test")
+    P.assert_matches_golden(P.Run(hip_lib, b, n_pushes=5), "segemehl__2.1.sub_test", GOLD)
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(len(b["contig"]))
+    sh = dict(b)
+    for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+        sh[k] = b[k][perm]
+    P.assert_matches_golden(P.Run(hip_lib, sh), "segemehl__2.1.sub_test", GOLD)   # order independence
+
+
+SYN = {
+    "C2-small": lambda dev: synth.short_reads([10_000], 1500, seed=2, device=dev),
+    "C3-small": lambda dev: synth.short_reads([5_000_000], 8, seed=3, device=dev),
+    "C3-mid": lambda dev: synth.short_reads([1_000_000], 120, seed=33, device=dev),
+    "C4-small": lambda dev: synth.short_reads([50_000] * 100, 25, seed=4, device=dev),
+    "C5-small": lambda dev: synth.long_reads([400_000], 25, seed=5, device=dev),
+}
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("cfg", sorted(SYN))
+def test_synthetic_config_device_resident(hip_lib, cfg, mode):
+    """BASELINE.json configs (scaled so the oracle finishes in seconds), inputs resident in HBM."""
+    tb = SYN[cfg]("cuda:0")
+    host = synth.to_numpy(tb)
+    eng = N.Engine(host["contig_lens"], lib=hip_lib, mode=mode)
+    eng.push_device(synth.device_ptrs(tb), tb["contig"].numel(), tb["seq4_bytes"], tb["cigar_words"])
+    eng.finalize()
+    info, stats = eng.batch_info(), eng.stats()
+    assert info["windowed"] == (0 if mode == N.KD_MODE_GLOBAL else 1)
+    reads, aligned, walked = synth.counts(tb)
+    assert stats["aligned"] == aligned and stats["walked"] == walked and stats["reads"] == reads
+    eng.consensus_run(1)
+    tot_w = 0
+    for cid in ko.contig_order(host):
+        oa = ko.parse_records(host, cid)
+        t, L = eng.tables(cid), oa.L
+        assert np.array_equal(t[0:5, :L].T, oa.weights) and np.array_equal(t[5], oa.deletions), cfg
+        assert np.array_equal(t[6:11, :L].T, oa.clip_start_weights) and np.array_equal(t[11:16, :L].T, oa.clip_end_weights)
+        assert np.array_equal(t[16], oa.clip_starts) and np.array_equal(t[17], oa.clip_ends)
+        assert np.array_equal(t[18], oa.ins_totals)
+        site, count, strings = eng.insertions(cid)
+        assert sorted((int(p), s, int(c)) for p, c, s in zip(site, count, strings)) == sorted(oa.insertions)
+        seq, ch, mm, _ = eng.consensus_fetch(cid)
+        oseq, och = oa.consensus_sequence()
+        assert seq.decode() == oseq and [None if c == 0 else chr(c) for c in ch] == och
+        assert mm == oa.depth_minmax()
+        tot_w += int(t[0:5].sum())
+    assert tot_w == aligned   # size-independent property: every aligned base lands in exactly one counter
+    eng.close()
+
+
+def test_host_push_equals_device_push(hip_lib):
+    tb = synth.short_reads([200_000], 40, seed=12, device="cuda:0")
+    host = synth.to_numpy(tb)
+    a = P.Run(hip_lib, host)
+    eng = N.Engine(host["contig_lens"], lib=hip_lib)
+    eng.push_device(synth.device_ptrs(tb), tb["contig"].numel(), tb["seq4_bytes"], tb["cigar_words"])
+    eng.finalize()
+    assert np.array_equal(eng.tables(0), a.tables[0])
+    eng.reset()   # idempotence: a second pass after reset gives the same tables
+    eng.push_device(synth.device_ptrs(tb), tb["contig"].numel(), tb["seq4_bytes"], tb["cigar_words"])
+    eng.finalize()
+    assert np.array_equal(eng.tables(0), a.tables[0])
+    eng.close()
+
+
+def test_virtual_shards_and_stitch(hip_lib):
+    tb = synth.short_reads([60_000, 45_000, 30_000], 30, seed=13, device="cuda:0")
+    batch = synth.to_numpy(tb)
+    full = P.Run(hip_lib, batch)
+    world = 4
+    ivs = shard.partition(batch["contig_lens"], world)
+    pieces = {c: [] for c in full.order}
+    for r in range(world):
+        keep = shard.reads_of_rank(batch["contig_lens"], batch["contig"], batch["pos0"], batch["pos0"] + 300, r, world)
+        sub = dict(batch)
+        for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+            sub[k] = batch[k][keep]
+        eng = N.Engine(batch["contig_lens"], lib=hip_lib)
+        eng.set_shard(*ivs[r])
+        eng.push(sub)
+        eng.finalize()
+        eng.consensus_run(1)
+        seqs, changes, mm = shard.stitch(eng, ivs[r], "cuda:0")   # world 1: exercises the device-pointer path
+        for c in full.order:
+            pieces[c].append(seqs[c])
+        eng.close()
+    for c in full.order:
+        assert b"".join(pieces[c]) == full.cns[c][0]
+
+
+def _bam_from_fixture(tmp_path, key):
+    b = P.load_fixture(key)
+    p = str(tmp_path / (key + ".bam"))
+    synth.write_bam(p, b, sort_order="unknown")
+    return p
+
+
+@pytest.mark.parametrize("key", ["bwa_mem__1.1.sub_test", "bwa_mem__5.1.sub_test", "minimap2__1.1.multi",
+                                 "ext__1.issue23.debug", "ext__2.issue23.bc63", "minimap2__hxb2-gp120-mutated"])
+def test_python_api_end_to_end(hip_lib, tmp_path, key):
+    """decode (native) -> HIP pileup -> HIP consensus -> host splice/report, vs the reference's outputs."""
+    from kindel_amd import kindel as K
+    path = _bam_from_fixture(tmp_path, key)
+    res = K.bam_to_consensus(path)
+    res_r = K.bam_to_consensus(path, realign=True, min_overlap=7)
+    for i, g in enumerate(GOLD[key]["contigs"]):
+        assert res.consensuses[i].name == g["name"] + "_cns"
+        assert res.consensuses[i].sequence == g["consensus"]
+        assert res.refs_reports[g["name"]] == g["report"].replace("{bam_path}", path)
+        assert "".join("." if c is None else c for c in res.refs_changes[g["name"]]) == g["changes"]
+        assert res_r.consensuses[i].sequence == g["realign_consensus"]
+        assert res_r.refs_reports[g["name"]] == g["realign_report"].replace("{bam_path}", path)
+
+
+def test_known_answers_through_parse_bam(hip_lib, tmp_path):
+    """/root/reference/tests/test_kindel.py:63-111 restated against kindel_amd.parse_bam."""
+    from kindel_amd import kindel as K
+    aln = list(K.parse_bam(_bam_from_fixture(tmp_path, "bwa_mem__1.1.sub_test")).values())[0]
+    aln2 = list(K.parse_bam(_bam_from_fixture(tmp_path, "ext__3.issue23.bc75")).values())[0]
+    assert aln.ref_id == "ENA|EU155341|EU155341.2" and len(aln.weights) == 9306
+    assert aln.weights[0]["A"] == 22 and aln.weights[23]["A"] == 57
+    assert aln2.weights[68]["G"] == 1 and aln2.weights[2368]["T"] == 13
+    assert [aln2.deletions[i] for i in (399, 402, 411, 1048, 1049, 1050)] == [14, 14, 15, 14, 14, 14]
+    assert aln2.clip_ends[1748] == 12
+    assert aln.clip_starts[525] == 16 and aln.clip_starts[1437] == 84
+    assert sum(aln2.insertions[453].values()) == 14 and sum(aln2.insertions[457].values()) == 14
+    cdrps = K.cdrp_consensuses(aln.weights, aln.deletions, aln.clip_start_weights, aln.clip_end_weights,
+                               aln.clip_start_depth, aln.clip_end_depth, 0.1, 10)
+    assert cdrps[0][0].seq == "AACTGCCGCTAGGGGCGCGTTCGGGCTCGCCAACATCTTCAGTCCGGGCGCTAAGCAGAACATCCAGCTGATCAACA"
+    assert cdrps[0][1].seq == ("AGCGTCGATGCAGATACCTACACCACCGGGGGAACTGCCGCTAGGGGCGCGTTCGGGCTCGCCAACATCTTCAGTCCGGGCGCTAAG"
+                               "CAGAACA")
+
+
+def test_weights_dataframe(hip_lib, tmp_path):
+    from kindel_amd import kindel as K
+    for key in ("bwa_mem__1.1.sub_test", "minimap2__1.1.multi"):
+        path = _bam_from_fixture(tmp_path, key)
+        for rel, tag in ((False, "abs"), (True, "rel")):
+            df = K.weights(path, relative=rel)
+            g = np.load(os.path.join(P.GOLD, "weights_%s_%s.npz" % (key, tag)), allow_pickle=True)
+            assert list(df.columns) == [str(c) for c in g["columns"]]
+            for c in df.columns:
+                a, b = df[c].to_numpy(), g[c]
+                if a.dtype.kind == "f":
+                    assert np.allclose(a, b, rtol=0, atol=1e-12, equal_nan=True), (key, tag, c)
+                else:
+                    assert (a.astype(str) == b.astype(str)).all() if a.dtype == object else np.array_equal(a, b), (key, tag, c)
+
+
+def test_cli_consensus_stdout(hip_lib, tmp_path):
+    key = "ext__3.issue23.bc75"
+    path = _bam_from_fixture(tmp_path, key)
+    r = subprocess.run([sys.executable, "-m", "kindel_amd", "consensus", path], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    g = GOLD[key]["contigs"][0]
+    assert r.stdout == ">%s_cns\n%s\n" % (g["name"], g["consensus"])
+    assert "REPORT" in r.stderr
+    r = subprocess.run([sys.executable, "-m", "kindel_amd", "consensus", "-r", "-t", "-u", path], cwd=ROOT,
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split("\n")[1] == g["realign_consensus"].strip("N").upper()

@@ -1,0 +1,158 @@
+"""Host-side logic of kindel_amd.kindel / cli (report text, patch splicing, realign scans, DataFrames),
+driven through the kernel emulator on CPU and compared with the reference's golden outputs."""
+import io
+import os
+from contextlib import redirect_stderr, redirect_stdout
+
+import numpy as np
+import pytest
+
+from kindel_amd import synth
+from tests import parity as P
+
+GOLD = P.golden_outputs()
+QUIRKS = P.golden_quirks()
+
+
+def _bam(tmp_path, key, n=None):
+    b = P.load_fixture(key)
+    p = str(tmp_path / (key + ".bam"))
+    synth.write_bam(p, b if n is None else P.subset(b, 0, n), sort_order="unknown")
+    return p
+
+
+def test_consensus_helper_matches_reference_unit_test():
+    """/root/reference/tests/test_kindel.py:25-32"""
+    from kindel_amd import kindel as K
+    w = {"A": 1, "C": 2, "G": 3, "T": 4, "N": 5}
+    assert K.consensus(w) == ("N", 5, 0.33, False)
+    assert K.consensus({"A": 5, "C": 5, "G": 3, "T": 4, "N": 1})[3] is True
+    assert K.consensus({"A": 0, "T": 0, "G": 0, "C": 0, "N": 0}) == ("N", 0, 0, False)
+
+
+def test_merge_by_lcs_matches_reference_unit_test():
+    """/root/reference/tests/test_kindel.py:35-53"""
+    from kindel_amd import kindel as K
+    one = ("AACTGCCGCTAGGGGCGCGTTCGGGCTCGCCAACATCTTCAGTCCGGG",
+           "GCCGCTAGGGGCGCGTTCGGGCTCGCCAACATCTTCAGTCCGGGCGCTAAGCAGAACA")
+    two = ("AACTGCCGCTAGGGGCGCGTTCGGGCTCGCCAACATCTTCAGTCCGGGCGCTAAGCAGAACATC",
+           "GCAGATACCTACACCACCGGGGGAACTGCCGCTAGGGGCGCGTTCGGGCTCGCCAACATCTTCAGTCCGGGCGCTAAGCAGAACA")
+    want = "AACTGCCGCTAGGGGCGCGTTCGGGCTCGCCAACATCTTCAGTCCGGGCGCTAAGCAGAACA"
+    assert K.merge_by_lcs(*one, min_overlap=7) == want
+    assert K.merge_by_lcs(*two, min_overlap=7) == want
+    assert K.merge_by_lcs("AT", "CG", min_overlap=7) is None
+
+
+@pytest.mark.parametrize("key", ["ext__3.issue23.bc75", "ext__2.issue23.bc63", "minimap2__1.1.multi"])
+def test_bam_to_consensus_default_and_realign(api_on_emu, tmp_path, key):
+    from kindel_amd import kindel as K
+    path = _bam(tmp_path, key)
+    res = K.bam_to_consensus(path)
+    res_r = K.bam_to_consensus(path, realign=True, min_overlap=7)
+    assert [c.name for c in res.consensuses] == [g["name"] + "_cns" for g in GOLD[key]["contigs"]]
+    for i, g in enumerate(GOLD[key]["contigs"]):
+        assert res.consensuses[i].sequence == g["consensus"]
+        assert "".join("." if c is None else c for c in res.refs_changes[g["name"]]) == g["changes"]
+        assert res.refs_reports[g["name"]] == g["report"].replace("{bam_path}", path)
+        assert res_r.consensuses[i].sequence == g["realign_consensus"]
+        assert res_r.refs_reports[g["name"]] == g["realign_report"].replace("{bam_path}", path)
+
+
+def test_realign_regions_on_issue23_debug(api_on_emu, tmp_path):
+    """CDR scan over device tables vs the reference's cdrp_consensuses (golden, two mask_ends values)."""
+    from kindel_amd import kindel as K
+    key = "ext__1.issue23.debug"
+    aln = list(K.parse_bam(_bam(tmp_path, key)).values())[0]
+    g = GOLD[key]["contigs"][0]
+    for me in (50, 10):
+        got = K.cdrp_consensuses(aln.weights, aln.deletions, aln.clip_start_weights, aln.clip_end_weights,
+                                 aln.clip_start_depth, aln.clip_end_depth, 0.1, me)
+        assert [[list(r) for r in pair] for pair in got] == g["cdrps_0.1_%d" % me]
+    res_r = K.bam_to_consensus(_bam(tmp_path, key), realign=True, min_overlap=7)
+    assert res_r.consensuses[0].sequence == g["realign_consensus"]
+
+
+def test_patch_splicing_matches_reference(api_on_emu, tmp_path):
+    """consensus_sequence with cdr_patches (kindel.py:393-401), incl. overlapping / None / empty patches."""
+    from kindel_amd import kindel as K
+    pc = QUIRKS["__patches__"]
+    p = tmp_path / "p.sam"
+    p.write_text(pc["sam"])
+    aln = list(K.parse_bam(str(p)).values())[0]
+    for name, v in pc["sets"].items():
+        patches = [K.Region(s, e, q, None) for s, e, q in v["patches"]]
+        seq, ch = K.consensus_sequence(aln.weights, aln.insertions, aln.deletions, patches, False, 1, False)
+        assert seq == v["consensus"], name
+        assert "".join("." if c is None else c for c in ch) == v["changes"], name
+
+
+@pytest.mark.parametrize("name", ["clip_both_ends_pair", "insertion_tie", "deletion_simple", "unmapped_placed_only_contig_all_N",
+                                  "contig_order_first_appearance", "base_tie", "pos0_wraps_to_last_site"])
+def test_quirk_reports_and_options(api_on_emu, tmp_path, name):
+    from kindel_amd import kindel as K
+    entry = QUIRKS[name]
+    p = tmp_path / "q.sam"
+    p.write_text(entry["sam"])
+    res = K.bam_to_consensus(str(p))
+    assert [c.name for c in res.consensuses] == entry["names"]
+    assert list(res.refs_reports.values()) == [r.replace("{bam_path}", str(p)) for r in entry["reports"]]
+    alns = K.parse_bam(str(p))
+    for g in entry["contigs"]:
+        aln = alns[g["name"]]
+        assert [[d[c] for c in "ATGCN"] for d in aln.weights] == g["weights"]
+        assert list(aln.deletions) == g["deletions"] and list(aln.clip_starts) == g["clip_starts"]
+        assert [int(x) for x in aln.consensus_depth] == g["consensus_depth"]
+        assert list(aln.clip_start_depth) == g["clip_start_depth"] and list(aln.clip_end_depth) == g["clip_end_depth"]
+        got_ins = sorted([p_, s, c] for p_, d in enumerate(aln.insertions) for s, c in d.items())
+        assert got_ins == sorted([p_, s.upper(), c] for p_, s, c in g["insertions"])
+        for run in g["runs"]:
+            seq, ch = K.consensus_sequence(aln.weights, aln.insertions, aln.deletions, None, run["trim_ends"],
+                                           run["min_depth"], run["uppercase"])
+            assert seq == run["consensus"]
+
+
+@pytest.mark.parametrize("name", ["ERR_M_overhang_past_L", "ERR_iupac_in_M", "ERR_cigar_star_mapped"])
+def test_reference_exceptions_surface(api_on_emu, tmp_path, name):
+    from kindel_amd import kindel as K
+    p = tmp_path / "e.sam"
+    p.write_text(QUIRKS[name]["sam"])
+    with pytest.raises(P.quirk_expect(QUIRKS[name])):
+        K.bam_to_consensus(str(p))
+
+
+def test_weights_dataframe_multi_contig(api_on_emu, tmp_path):
+    from kindel_amd import kindel as K
+    key = "minimap2__1.1.multi"
+    path = _bam(tmp_path, key)
+    for rel, tag in ((False, "abs"), (True, "rel")):
+        df = K.weights(path, relative=rel)
+        g = np.load(os.path.join(P.GOLD, "weights_%s_%s.npz" % (key, tag)), allow_pickle=True)
+        assert list(df.columns) == [str(c) for c in g["columns"]]
+        for c in df.columns:
+            a, b = df[c].to_numpy(), g[c]
+            if a.dtype.kind == "f":
+                assert np.allclose(a, b, rtol=0, atol=1e-12, equal_nan=True), (tag, c)
+            elif a.dtype == object:
+                assert (a.astype(str) == b.astype(str)).all()
+            else:
+                assert np.array_equal(a, b), (tag, c)
+    K.features(path)   # smoke, like the reference's test (and: no multi-contig crash)
+
+
+def test_cli_in_process(api_on_emu, tmp_path):
+    from kindel_amd import cli
+    key = "ext__3.issue23.bc75"
+    path = _bam(tmp_path, key)
+    out, err = io.StringIO(), io.StringIO()
+    with redirect_stdout(out), redirect_stderr(err):
+        assert cli.main(["consensus", path]) == 0
+    g = GOLD[key]["contigs"][0]
+    assert out.getvalue() == ">%s_cns\n%s\n" % (g["name"], g["consensus"])
+    assert err.getvalue().startswith("========================= REPORT")
+    out = io.StringIO()
+    with redirect_stdout(out):
+        assert cli.main(["version"]) == 0
+    assert out.getvalue().strip() == "kindel 1.2.1"
+    a = cli.build_parser().parse_args(["consensus", "x.bam"])
+    assert (a.realign, a.min_depth, a.min_overlap, a.clip_decay_threshold, a.mask_ends, a.trim_ends, a.uppercase) == \
+        (False, 1, 7, 0.1, 50, False, False)   # cli.py:11-18 defaults
