@@ -29,7 +29,7 @@ struct KdEngine {
     uint64_t S = 0;  // G-space sites, multiple of 1024 (consensus tile)
     uint64_t g_lo = 0, g_hi = 0;  // emit interval [g_lo, g_hi)
     int mode = KD_MODE_AUTO;
-    uint32_t W = 2048, slice_cfg = 0;
+    uint32_t W = 1024, slice_cfg = 0;
 
     uint32_t *d_tab = nullptr, *d_clen = nullptr, *d_seg = nullptr;
     kd_u64 *d_cbase = nullptr, *d_status = nullptr;
@@ -40,7 +40,7 @@ struct KdEngine {
         void *p = nullptr;
         size_t cap = 0;
     };
-    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff;
+    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_readev, b_readpool;
     Buf b_stage[9];
     Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
     uint64_t ev_cap = 0, pool_cap = 0;
@@ -91,6 +91,7 @@ struct KdEngine {
         KdIns I;
         I.ev_site = (uint32_t *)b_ev_site.p; I.ev_len = (uint32_t *)b_ev_len.p; I.ev_off = (kd_u64 *)b_ev_off.p;
         I.pool = (uint8_t *)b_pool.p; I.ev_cap = ev_cap; I.pool_cap = pool_cap;
+        I.read_ev = (uint32_t *)b_readev.p; I.read_pool = (kd_u64 *)b_readpool.p;
         return I;
     }
 
@@ -128,7 +129,7 @@ struct KdEngine {
     }
 
     void destroy() {
-        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_ev_site, &b_ev_len,
+        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_readev, &b_readpool, &b_ev_site, &b_ev_len,
                       &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_win, &b_cns, &b_changes,
                       &b_tilesum, &b_tileoff, &b_coff, &b_minmax, &b_pstart, &b_pend, &b_poff};
         for (Buf *b : all) release(*b);
@@ -168,9 +169,11 @@ struct KdEngine {
         const uint64_t n = B.n_reads;
         if (!n) return KD_OK;
         if (n >= 0xffffffffULL) return fail(KD_E_ARG, "kd_push_batch: more than 2^32-1 reads in one batch");
+        if (reinterpret_cast<uintptr_t>(B.seq4) & 15u) return fail(KD_E_ARG, "kd_push_batch_device: seq4 must be 16-byte aligned");
         int rc;
         if ((rc = ensure(b_rinfo, n * sizeof(KdRInfo))) || (rc = ensure(b_cold, n * 4)) ||
-            (rc = ensure(b_irreg, n * 4)) || (rc = ensure(b_long, n * 4)))
+            (rc = ensure(b_irreg, n * 4)) || (rc = ensure(b_long, n * 4)) || (rc = ensure(b_readev, n * 4)) ||
+            (rc = ensure(b_readpool, n * 8)))
             return rc;
         KdReads R;
         R.n = n; R.base_index = reads_pushed;
@@ -184,21 +187,23 @@ struct KdEngine {
         if (rt.memset(d_status + KDS_B_INS_OPS, 0, (size_t)(KDS_TOTAL_ITEMS - KDS_B_INS_OPS + 1) * 8))
             return hipfail("push: memset status");
         const unsigned prep_grid = (unsigned)((n + KD_PREP_CHUNK - 1) / KD_PREP_CHUNK);
-        if (rt.launch("k_prep", k_prep, prep_grid, KD_BLOCK, 0, R, T, rinfo, cold, irreg, lng, d_status))
+        const uint64_t ev_before = h_status[KDS_N_EV], pool_before = h_status[KDS_POOL];  // as of the last fetch
+        if (rt.launch("k_prep", k_prep, prep_grid, KD_BLOCK, 0, R, T, rinfo, cold, irreg, lng, (uint32_t *)b_readev.p,
+                      (kd_u64 *)b_readpool.p, d_status))
             return hipfail("k_prep");
         if ((rc = fetch_status())) return rc;
         if (h_status[KDS_B_N_LONG]) {
             if (rt.launch("k_prep_long", k_prep_long, (unsigned)h_status[KDS_B_N_LONG], KD_BLOCK, 0, R, T, rinfo,
-                          (const uint32_t *)lng, cold, irreg, d_status))
+                          (const uint32_t *)lng, cold, irreg, (uint32_t *)b_readev.p, (kd_u64 *)b_readpool.p, d_status))
                 return hipfail("k_prep_long");
             if ((rc = fetch_status())) return rc;
         }
         // size the insertion event buffers from the exact counts of this batch
-        const uint64_t need_ev = h_status[KDS_N_EV] + h_status[KDS_B_INS_OPS];
-        const uint64_t need_pool = h_status[KDS_POOL] + h_status[KDS_B_INS_BASES];
+        // k_prep / k_prep_long have already reserved this batch's slots in KDS_N_EV / KDS_POOL
+        const uint64_t need_ev = h_status[KDS_N_EV], need_pool = h_status[KDS_POOL];
         if (need_ev > ev_cap) {
             uint64_t ncap = std::max<uint64_t>(need_ev, ev_cap + ev_cap / 2);
-            const uint64_t used = h_status[KDS_N_EV];
+            const uint64_t used = ev_before;
             if ((rc = ensure(b_ev_site, ncap * 4, true, used * 4)) || (rc = ensure(b_ev_len, ncap * 4, true, used * 4)) ||
                 (rc = ensure(b_ev_off, ncap * 8, true, used * 8)))
                 return rc;
@@ -206,7 +211,7 @@ struct KdEngine {
         }
         if (need_pool > pool_cap) {
             uint64_t ncap = std::max<uint64_t>(need_pool, pool_cap + pool_cap / 2);
-            if ((rc = ensure(b_pool, ncap, true, h_status[KDS_POOL]))) return rc;
+            if ((rc = ensure(b_pool, ncap, true, pool_before))) return rc;
             pool_cap = ncap;
         }
         KdIns I = insdesc();
@@ -224,11 +229,12 @@ struct KdEngine {
                 (rc = ensure(b_itemoff, ((size_t)n_win + 1) * 8)))
                 return rc;
             kd_u64 *wl = (kd_u64 *)b_winlo.p, *wh = (kd_u64 *)b_winhi.p, *io = (kd_u64 *)b_itemoff.p;
-            if (rt.launch("k_plan", k_plan, 1u, KD_BLOCK, 0, (const KdRInfo *)rinfo, (kd_u64)n, n_win, W, slice, wl, wh,
-                          io, d_status))
+            if (rt.launch("k_plan_ranges", k_plan_ranges, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
+                          (const KdRInfo *)rinfo, (kd_u64)n, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status) ||
+                rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, d_status))
                 return hipfail("k_plan");
-            const size_t lds = (size_t)6 * W * 4;
-            const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 1024) / (lds + 64)));
+            const size_t lds = KD_WINDOW_LDS_BYTES(W);
+            const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
             const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
             if (rt.launch("k_window", k_window, grid, KD_BLOCK, lds, R, (const KdRInfo *)rinfo, T, (const kd_u64 *)wl,
                           (const kd_u64 *)wh, (const kd_u64 *)io, n_win, W, slice, d_status))
@@ -259,7 +265,7 @@ struct KdEngine {
         const uint64_t n = B.n_reads;
         if (!n) return KD_OK;
         const void *src[9] = {B.contig, B.pos0, B.flag, B.seq_off, B.seq_len, B.cig_off, B.n_cig, B.seq4, B.cigar};
-        const size_t bytes[9] = {n * 4, n * 4, n * 4, n * 8, n * 4, n * 8, n * 4, (size_t)B.seq4_bytes + 8,
+        const size_t bytes[9] = {n * 4, n * 4, n * 4, n * 8, n * 4, n * 8, n * 4, (size_t)B.seq4_bytes + 64,
                                  (size_t)B.cigar_words * 4 + 8};
         const size_t copy[9] = {n * 4, n * 4, n * 4, n * 8, n * 4, n * 8, n * 4, (size_t)B.seq4_bytes,
                                 (size_t)B.cigar_words * 4};

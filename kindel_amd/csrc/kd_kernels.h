@@ -33,6 +33,11 @@ typedef unsigned long long kd_u64;
     type *name = reinterpret_cast<type *>(kd_dyn_smem_)
 #endif
 
+// A value every lane of the wavefront holds identically -> SGPR, so branches on it are scalar.
+#ifndef KD_UNIFORM
+#define KD_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#endif
+
 #define KD_WAVE 64
 #define KD_BLOCK 256
 #define KD_WAVES_PER_BLOCK (KD_BLOCK / KD_WAVE)
@@ -57,6 +62,9 @@ typedef unsigned long long kd_u64;
 #define KD_CLS_IRREG 2u   // everything else: walked with exact Python semantics by k_pileup_wave
 #define KD_CLS_LONG 3u    // transient: CIGAR too long for the per-lane scan, k_prep_long decides
 #define KD_INFO_COLD 4u   // read has S or I ops (soft-clip tables / insertion events)
+#define KD_INFO_INS 8u    // read has I ops: k_prep reserved its insertion-event / pool slots
+#define KD_SPAN_SHIFT 4
+#define KD_EV_DROPPED 0xffffffffu  // reserved insertion-event slot whose site belongs to another shard
 
 // device status words (kd_u64 each)
 enum {
@@ -107,7 +115,7 @@ struct KdReads {
 
 struct KdRInfo {
     uint32_t gstart;    // contig_base + max(pos0, 0)
-    uint32_t span_cls;  // hot span << 3 | KD_INFO_COLD | class
+    uint32_t span_cls;  // hot span << KD_SPAN_SHIFT | KD_INFO_INS | KD_INFO_COLD | class
 };
 
 struct KdIns {
@@ -116,6 +124,8 @@ struct KdIns {
     kd_u64 *ev_off;     // [ev_cap] offset into pool
     uint8_t *pool;      // one 4-bit base code per byte
     kd_u64 ev_cap, pool_cap;
+    uint32_t *read_ev;  // [n reads of the batch] first event slot of the read (valid when KD_INFO_INS)
+    kd_u64 *read_pool;  // [n reads of the batch] first pool byte of the read
 };
 
 // ---------------------------------------------------------------------------------------
@@ -201,14 +211,16 @@ __device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc,
 
 __global__ void __launch_bounds__(KD_BLOCK)
 k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irreg_list, uint32_t *long_list,
-       kd_u64 *status) {
+       uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
     __shared__ kd_u64 s_red[8];       // reads, aligned, walked, ins_ops, ins_bases, n_reg, unsorted
     __shared__ uint32_t s_maxspan;
     __shared__ uint32_t s_cnt[3];     // cold, irreg, long (block totals / running offsets)
-    __shared__ kd_u64 s_base[3];
+    __shared__ kd_u64 s_base[5];
+    __shared__ kd_u64 s_ins[2];       // insertion events / insertion bases of the block's short-CIGAR reads
     const uint32_t t = threadIdx.x;
     if (t < 8) s_red[t] = 0;
     if (t < 3) s_cnt[t] = 0;
+    if (t < 2) s_ins[t] = 0;
     if (t == 0) s_maxspan = 0;
     __syncthreads();
     const kd_u64 chunk0 = (kd_u64)blockIdx.x * KD_PREP_CHUNK;
@@ -230,6 +242,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
         const uint32_t nc = rd.n_cig[i];
         uint32_t cls, cold = 0;
         kd_u64 span = 0;
+        bool has_ins = false;
         if ((rd.flag[i] & 4u) || sl <= 1) {
             cls = KD_CLS_SKIP;
         } else if (nc == 0) {
@@ -240,17 +253,17 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
             a_reads++;
         } else {
             KdScan s = kd_scan_cigar(rd.cigar + rd.cig_off[i], nc, pos0, sl, (int64_t)T.contig_len[c]);
-            cls = s.cls; cold = s.cold; span = s.span;
+            cls = s.cls; cold = s.cold; span = s.span; has_ins = s.n_ins != 0;
             a_reads++; a_aligned += s.aligned; a_walked += s.walked; a_ins += s.n_ins; a_insb += s.ins_bases;
         }
-        if (span > 0x1fffffffULL) { cls = KD_CLS_IRREG; span = 0; }
+        if (span > 0x0fffffffULL) { cls = KD_CLS_IRREG; span = 0; }
         if (cls == KD_CLS_REG) { a_reg++; if ((uint32_t)span > a_maxspan) a_maxspan = (uint32_t)span; }
         if (cls == KD_CLS_REG && cold) n_cold++;
         if (cls == KD_CLS_IRREG) n_irreg++;
         if (cls == KD_CLS_LONG) n_long++;
         KdRInfo ri;
         ri.gstart = (uint32_t)gkey;
-        ri.span_cls = ((uint32_t)span << 3) | cold | cls;
+        ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | (has_ins ? KD_INFO_INS : 0u) | cold | cls;
         rinfo[i] = ri;
     }
     // block reduction through LDS atomics, then one global atomic per word per block
@@ -266,6 +279,10 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
     uint32_t o_cold = n_cold ? atomicAdd(&s_cnt[0], n_cold) : 0;
     uint32_t o_irreg = n_irreg ? atomicAdd(&s_cnt[1], n_irreg) : 0;
     uint32_t o_long = n_long ? atomicAdd(&s_cnt[2], n_long) : 0;
+    // insertion event / pool slots: thread-local offsets inside the block, one global reservation per block
+    // (a global counter bumped per event serialises at ~11 ns per returning atomic on one address)
+    const kd_u64 o_ev = a_ins ? atomicAdd(&s_ins[0], a_ins) : 0;
+    const kd_u64 o_pool = a_ins ? atomicAdd(&s_ins[1], a_insb) : 0;
     __syncthreads();
     if (t == 0) {
         if (s_red[0]) atomicAdd(&status[KDS_ST_READS], s_red[0]);
@@ -273,6 +290,8 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
         if (s_red[2]) atomicAdd(&status[KDS_ST_WALKED], s_red[2]);
         if (s_red[3]) { atomicAdd(&status[KDS_ST_INS], s_red[3]); atomicAdd(&status[KDS_B_INS_OPS], s_red[3]); }
         if (s_red[4]) atomicAdd(&status[KDS_B_INS_BASES], s_red[4]);
+        s_base[3] = s_ins[0] ? atomicAdd(&status[KDS_N_EV], s_ins[0]) : 0;
+        s_base[4] = s_ins[0] ? atomicAdd(&status[KDS_POOL], s_ins[1]) : 0;
         if (s_red[5]) atomicAdd(&status[KDS_B_N_REG], s_red[5]);
         if (s_red[6]) atomicAdd(&status[KDS_B_UNSORTED], s_red[6]);
         if (s_maxspan) atomicMax(&status[KDS_B_MAXSPAN], (kd_u64)s_maxspan);
@@ -281,13 +300,20 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
         s_base[2] = s_cnt[2] ? atomicAdd(&status[KDS_B_N_LONG], (kd_u64)s_cnt[2]) : 0;
     }
     __syncthreads();
-    if (n_cold | n_irreg | n_long) {
+    if (n_cold | n_irreg | n_long | (a_ins != 0)) {
         kd_u64 w_cold = s_base[0] + o_cold, w_irreg = s_base[1] + o_irreg, w_long = s_base[2] + o_long;
+        kd_u64 w_ev = s_base[3] + o_ev, w_pool = s_base[4] + o_pool;
         for (int it = 0; it < KD_PREP_PER_THREAD; it++) {
             const kd_u64 i = chunk0 + (kd_u64)it * KD_BLOCK + t;
             if (i >= rd.n) break;
             const uint32_t sc = rinfo[i].span_cls;
             const uint32_t cls = sc & 3u;
+            if (sc & KD_INFO_INS) {  // rescan (cached) to hand this read its event / pool slots
+                KdScan s = kd_scan_cigar(rd.cigar + rd.cig_off[i], rd.n_cig[i], rd.pos0[i], rd.seq_len[i],
+                                         (int64_t)T.contig_len[rd.contig[i]]);
+                read_ev[i] = (uint32_t)w_ev; read_pool[i] = w_pool;
+                w_ev += s.n_ins; w_pool += s.ins_bases;
+            }
             if (cls == KD_CLS_REG && (sc & KD_INFO_COLD)) cold_list[w_cold++] = (uint32_t)i;
             if (cls == KD_CLS_IRREG) irreg_list[w_irreg++] = (uint32_t)i;
             if (cls == KD_CLS_LONG) long_list[w_long++] = (uint32_t)i;
@@ -301,7 +327,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
 // second sweep applies the same regularity rules as kd_scan_cigar.
 __global__ void __launch_bounds__(KD_BLOCK)
 k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uint32_t *cold_list,
-            uint32_t *irreg_list, kd_u64 *status) {
+            uint32_t *irreg_list, uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
     __shared__ int64_t s_r[KD_BLOCK], s_q[KD_BLOCK];
     __shared__ kd_u64 s_acc[6];       // aligned, walked, n_ins, ins_bases, bad, cold
     __shared__ uint32_t s_first_nfs, s_last_rel;
@@ -383,11 +409,16 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
         // a non-first S must be the last op that touches r (M, I, D or S)
         if (s_first_nfs != 0xffffffffu && s_last_rel > s_first_nfs) regular = false;
         kd_u64 span = r_end > pos0 ? (kd_u64)(r_end - pos0) : 0;
-        if (span > 0x1fffffffULL) { regular = false; span = 0; }
+        if (span > 0x0fffffffULL) { regular = false; span = 0; }
         const uint32_t coldbit = s_acc[5] ? KD_INFO_COLD : 0u;
         KdRInfo ri = rinfo[i];
-        ri.span_cls = ((uint32_t)span << 3) | coldbit | (regular ? KD_CLS_REG : KD_CLS_IRREG);
+        ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | (s_acc[2] ? KD_INFO_INS : 0u) | coldbit |
+                      (regular ? KD_CLS_REG : KD_CLS_IRREG);
         rinfo[i] = ri;
+        if (s_acc[2]) {
+            read_ev[i] = (uint32_t)atomicAdd(&status[KDS_N_EV], s_acc[2]);
+            read_pool[i] = atomicAdd(&status[KDS_POOL], s_acc[3]);
+        }
         atomicAdd(&status[KDS_ST_ALIGNED], s_acc[0]);
         atomicAdd(&status[KDS_ST_WALKED], s_acc[1]);
         if (s_acc[2]) { atomicAdd(&status[KDS_ST_INS], s_acc[2]); atomicAdd(&status[KDS_B_INS_OPS], s_acc[2]); }
@@ -431,6 +462,8 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
     uint32_t *tab = T.tab;
     const kd_u64 S = T.stride;
     int64_t r = rd.pos0[i], q = 0;  // kindel.py:41-42
+    kd_u64 ev_next = 0, pool_next = 0;  // this read's reserved insertion slots (k_prep), loaded at its first I
+    bool ev_loaded = false;
     for (uint32_t k = 0; k < nc; k++) {
         const uint32_t w = cg[k];
         const int64_t len = w >> 4;
@@ -450,20 +483,23 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
             r += len; q += len;
         } else if (op == 1) {  // I  kindel.py:55-58
             if (r > L || r < -(L + 1)) { if (lane == 0) kd_flag_error(status, gidx); return; }
-            if (COLD && lane == 0) {
-                const int64_t idx = r < 0 ? r + L + 1 : r;
-                const kd_u64 g = cb + (kd_u64)idx;
-                if (kd_commit(T, g)) {
-                    const int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
-                    const kd_u64 n = (kd_u64)(q1 - q0);
-                    const kd_u64 e = atomicAdd(&status[KDS_N_EV], 1ULL);
-                    const kd_u64 po = atomicAdd(&status[KDS_POOL], n);
+            if (COLD) {
+                if (!ev_loaded) { ev_next = ins.read_ev[i]; pool_next = ins.read_pool[i]; ev_loaded = true; }
+                const int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
+                const kd_u64 n = (kd_u64)(q1 - q0);
+                const kd_u64 e = ev_next, po = pool_next;
+                ev_next += 1; pool_next += n;
+                if (lane == 0) {
+                    const int64_t idx = r < 0 ? r + L + 1 : r;
+                    const kd_u64 g = cb + (kd_u64)idx;
                     if (e >= ins.ev_cap || po + n > ins.pool_cap) {
                         atomicAdd(&status[KDS_INTERNAL], 1ULL);
-                    } else {
+                    } else if (kd_commit(T, g)) {
                         ins.ev_site[e] = (uint32_t)g; ins.ev_len[e] = (uint32_t)n; ins.ev_off[e] = po;
                         for (kd_u64 b = 0; b < n; b++) ins.pool[po + b] = (uint8_t)kd_nib(seq, q0 + (int64_t)b);
                         atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g], 1u);
+                    } else {
+                        ins.ev_site[e] = KD_EV_DROPPED; ins.ev_len[e] = 0; ins.ev_off[e] = po;  // other shard's site
                     }
                 }
             }
@@ -610,28 +646,33 @@ __device__ __forceinline__ kd_u64 kd_lower_bound(const KdRInfo *rinfo, kd_u64 n,
     return lo;
 }
 
-// One workgroup.  For every window w of W sites: the candidate reads are those whose
-// G-start lies in [w*W - maxspan, (w+1)*W) -- contiguous because the batch is sorted --
-// cut into slices of `slice` reads; item_off[w] = exclusive prefix of the slice counts.
+// k_plan_ranges: one thread per window w of W sites.  The candidate reads are those whose G-start
+// lies in [w*W - maxspan, (w+1)*W) -- a contiguous index range because the batch is sorted -- cut
+// into slices of `slice` reads (one work item each).
 __global__ void __launch_bounds__(KD_BLOCK)
-k_plan(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t n_win, uint32_t W, uint32_t slice, kd_u64 *win_lo,
-       kd_u64 *win_hi, kd_u64 *item_off, kd_u64 *status) {
+k_plan_ranges(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t n_win, uint32_t W, uint32_t slice, kd_u64 *win_lo,
+              kd_u64 *win_hi, kd_u64 *item_off, const kd_u64 *status) {
+    const uint32_t w = blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (w >= n_win) return;
+    const kd_u64 maxspan = status[KDS_B_MAXSPAN];
+    const kd_u64 wlo = (kd_u64)w * W, whi = wlo + W;
+    const kd_u64 lo = kd_lower_bound(rinfo, n_reads, wlo > maxspan ? wlo - maxspan : 0);
+    const kd_u64 hi = kd_lower_bound(rinfo, n_reads, whi);
+    win_lo[w] = lo; win_hi[w] = hi;
+    item_off[w] = (hi - lo + slice - 1) / slice;  // item count; k_plan_scan turns it into an offset
+}
+
+// k_plan_scan: one workgroup, in-place exclusive scan of the per-window item counts.
+__global__ void __launch_bounds__(KD_BLOCK)
+k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
     __shared__ kd_u64 s_scan[KD_BLOCK];
     __shared__ kd_u64 s_carry;
     const uint32_t t = threadIdx.x;
-    const kd_u64 maxspan = status[KDS_B_MAXSPAN];
     if (t == 0) s_carry = 0;
     __syncthreads();
     for (uint32_t w0 = 0; w0 < n_win; w0 += KD_BLOCK) {
         const uint32_t w = w0 + t;
-        kd_u64 items = 0;
-        if (w < n_win) {
-            const kd_u64 wlo = (kd_u64)w * W, whi = wlo + W;
-            const kd_u64 lo = kd_lower_bound(rinfo, n_reads, wlo > maxspan ? wlo - maxspan : 0);
-            const kd_u64 hi = kd_lower_bound(rinfo, n_reads, whi);
-            win_lo[w] = lo; win_hi[w] = hi;
-            items = (hi - lo + slice - 1) / slice;
-        }
+        const kd_u64 items = w < n_win ? item_off[w] : 0;
         s_scan[t] = items;
         __syncthreads();
         for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
@@ -648,14 +689,29 @@ k_plan(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t n_win, uint32_t W, uint32_
     if (t == 0) { item_off[n_win] = s_carry; status[KDS_TOTAL_ITEMS] = s_carry; status[KDS_NEXT_ITEM] = 0; }
 }
 
-// Persistent workgroups.  LDS: u32 hist[6][W] (A,T,G,C,N,del), channel-major so that the 64
-// lanes of a wavefront -- 64 consecutive reference sites of one read -- hit 64 consecutive
-// dwords of one channel: no bank conflict inside an instruction.  Only REGULAR reads are
-// handled here; their S/I side effects are done by k_pileup_wave<false,true>.
+// k_window: persistent workgroups pull (window, slice) work items.
+// LDS (dynamic): u32 hist[6][W] (A,T,G,C,N,del) channel-major -- the 64 lanes of a wavefront walk 64
+// consecutive reference sites of one read, i.e. 64 consecutive dwords of one channel: no bank
+// conflict inside an instruction -- followed by a staging area for KD_BLOCK reads.
+// Per batch of KD_BLOCK reads:  phase A, one THREAD per read: metadata, the first KD_STAGE_CIG CIGAR
+// words and the packed bases are copied global -> LDS with every load of the workgroup in flight at
+// once (this replaces a 4-5 deep dependent-load chain per read with one round trip per 256 reads);
+// phase B, one WAVEFRONT per read: lanes = bases, nibbles come from LDS, tallies go to hist with
+// ds_add_u32.  Reads that do not fit the staging slot (long CIGAR / long read) take the direct path
+// (loads from HBM inside phase B).  Only REGULAR reads are handled here; their S/I side effects are
+// done by k_pileup_wave<false,true>.
+#define KD_STAGE_CIG 4
+#define KD_STAGE_SEQ 96          // bytes per read slot: up to 162 bases at any 16-byte misalignment
+#define KD_STAGE_META 8          // u32 per read: gstart, span_cls(0 = inactive), n_cig, flags, cigar[4]
+#define KD_STAGE_DIRECT 0x100u
+#define KD_WINDOW_LDS_BYTES(W) ((size_t)6 * (W) * 4 + (size_t)KD_BLOCK * (KD_STAGE_META * 4 + KD_STAGE_SEQ))
+
 __global__ void __launch_bounds__(KD_BLOCK)
 k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
          const kd_u64 *item_off, uint32_t n_win, uint32_t W, uint32_t slice, kd_u64 *status) {
     KD_DYN_SHARED(uint32_t, hist);
+    uint32_t *st_meta = hist + 6u * W;
+    uint8_t *st_seq = reinterpret_cast<uint8_t *>(st_meta + KD_BLOCK * KD_STAGE_META);
     __shared__ kd_u64 s_item;
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
@@ -677,45 +733,81 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
         const kd_u64 first = win_lo[w] + (item - item_off[w]) * slice;
         const kd_u64 last = first + slice < win_hi[w] ? first + slice : win_hi[w];
         for (uint32_t x = t; x < nh; x += KD_BLOCK) hist[x] = 0;
-        __syncthreads();
-        for (kd_u64 i = first + wave; i < last; i += KD_WAVES_PER_BLOCK) {
-            const KdRInfo ri = rinfo[i];
-            if ((ri.span_cls & 3u) != KD_CLS_REG) continue;
-            const kd_u64 gs = ri.gstart, span = ri.span_cls >> 3;
-            if (gs + span <= wlo || gs >= whi) continue;
-            const uint8_t *seq = rd.seq4 + rd.seq_off[i];
-            const uint32_t *cg = rd.cigar + rd.cig_off[i];
-            const uint32_t nc = rd.n_cig[i];
-            int64_t g = (int64_t)gs, q = 0;
-            for (uint32_t k = 0; k < nc; k++) {
-                const uint32_t cw = cg[k];
-                const int64_t len = cw >> 4;
-                const uint32_t op = cw & 15u;
-                if (op == 0 || op == 7 || op == 8 || op == 2) {
-                    // overlap of [g, g+len) with the window, as offsets into the op
-                    const int64_t j0 = (int64_t)wlo > g ? (int64_t)wlo - g : 0;
-                    const int64_t j1 = (int64_t)whi - g < len ? (int64_t)whi - g : len;
-                    if (op == 2) {
-                        for (int64_t j = j0 + lane; j < j1; j += KD_WAVE)
-                            atomicAdd(&hist[5u * W + (uint32_t)(g + j - (int64_t)wlo)], 1u);
-                    } else {
-                        for (int64_t j = j0 + lane; j < j1; j += KD_WAVE) {
-                            const uint32_t ch = kd_chan(kd_nib(seq, q + j));
-                            if (ch == 7u) kd_flag_error(status, rd.base_index + i);
-                            else atomicAdd(&hist[ch * W + (uint32_t)(g + j - (int64_t)wlo)], 1u);
+        for (kd_u64 b0 = first; b0 < last; b0 += KD_BLOCK) {
+            // ---- phase A: stage read b0 + t ----
+            {
+                const kd_u64 i = b0 + t;
+                uint32_t m[KD_STAGE_META] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (i < last) {
+                    const KdRInfo ri = rinfo[i];
+                    const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
+                    if ((ri.span_cls & 3u) == KD_CLS_REG && gs + span > wlo && gs < whi) {
+                        const uint32_t nc = rd.n_cig[i];
+                        const kd_u64 soff = rd.seq_off[i];
+                        const uint32_t nbytes = (rd.seq_len[i] + 1u) >> 1;
+                        const uint32_t mis = (uint32_t)(soff & 15u);
+                        m[0] = ri.gstart; m[1] = ri.span_cls; m[2] = nc; m[3] = mis;
+                        if (nc > KD_STAGE_CIG || mis + nbytes > KD_STAGE_SEQ) {
+                            m[3] |= KD_STAGE_DIRECT;
+                        } else {
+                            const uint32_t *cg = rd.cigar + rd.cig_off[i];
+                            for (uint32_t k = 0; k < nc; k++) m[4 + k] = cg[k];
+                            const uint4 *src = reinterpret_cast<const uint4 *>(rd.seq4 + (soff - mis));
+                            uint4 *dst = reinterpret_cast<uint4 *>(st_seq + (size_t)t * KD_STAGE_SEQ);
+                            const uint32_t nchunk = (mis + nbytes + 15u) >> 4;
+                            for (uint32_t c = 0; c < nchunk; c++) dst[c] = src[c];
                         }
-                        q += len;
                     }
-                    g += len;
-                    if (g >= (int64_t)whi) break;
-                } else if (op == 1) {
-                    q += len;
-                } else if (op == 4) {
-                    if (k == 0) q += len; else break;  // regular: nothing after a non-first S touches r
+                }
+                uint4 *md = reinterpret_cast<uint4 *>(st_meta + (size_t)t * KD_STAGE_META);
+                uint4 v0, v1;
+                v0.x = m[0]; v0.y = m[1]; v0.z = m[2]; v0.w = m[3];
+                v1.x = m[4]; v1.y = m[5]; v1.z = m[6]; v1.w = m[7];
+                md[0] = v0; md[1] = v1;
+            }
+            __syncthreads();
+            // ---- phase B: wavefront `wave` walks its 64 staged reads ----
+            for (uint32_t r = 0; r < KD_WAVE; r++) {
+                const uint32_t slot = wave * KD_WAVE + r;
+                const uint32_t *m = st_meta + (size_t)slot * KD_STAGE_META;
+                const uint32_t sc = KD_UNIFORM(m[1]);
+                if ((sc & 3u) != KD_CLS_REG) continue;
+                const uint32_t nc = KD_UNIFORM(m[2]), fl = KD_UNIFORM(m[3]);
+                int64_t g = (int64_t)KD_UNIFORM(m[0]), q = 0;
+                const bool direct = (fl & KD_STAGE_DIRECT) != 0;
+                const kd_u64 i = b0 + slot;
+                const uint8_t *seq = direct ? rd.seq4 + rd.seq_off[i] : st_seq + (size_t)slot * KD_STAGE_SEQ + (fl & 15u);
+                const uint32_t *cg = direct ? rd.cigar + rd.cig_off[i] : m + 4;
+                for (uint32_t k = 0; k < nc; k++) {
+                    const uint32_t cw = direct ? cg[k] : KD_UNIFORM(cg[k]);
+                    const int64_t len = cw >> 4;
+                    const uint32_t op = cw & 15u;
+                    if (op == 0 || op == 7 || op == 8 || op == 2) {
+                        // overlap of [g, g+len) with the window, as offsets into the op
+                        const int64_t j0 = (int64_t)wlo > g ? (int64_t)wlo - g : 0;
+                        const int64_t j1 = (int64_t)whi - g < len ? (int64_t)whi - g : len;
+                        if (op == 2) {
+                            for (int64_t j = j0 + lane; j < j1; j += KD_WAVE)
+                                atomicAdd(&hist[5u * W + (uint32_t)(g + j - (int64_t)wlo)], 1u);
+                        } else {
+                            for (int64_t j = j0 + lane; j < j1; j += KD_WAVE) {
+                                const uint32_t ch = kd_chan(kd_nib(seq, q + j));
+                                if (ch == 7u) kd_flag_error(status, rd.base_index + i);
+                                else atomicAdd(&hist[ch * W + (uint32_t)(g + j - (int64_t)wlo)], 1u);
+                            }
+                            q += len;
+                        }
+                        g += len;
+                        if (g >= (int64_t)whi) break;
+                    } else if (op == 1) {
+                        q += len;
+                    } else if (op == 4) {
+                        if (k == 0) q += len; else break;  // regular: nothing after a non-first S touches r
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
         // flush: channel-major, consecutive lanes -> consecutive HBM dwords; zeros are skipped
         for (uint32_t x = t; x < nh; x += KD_BLOCK) {
             const uint32_t v = hist[x];
@@ -755,6 +847,7 @@ k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev) {
     const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
     if (e >= n_ev) return;
     const uint32_t site = ins.ev_site[e], len = ins.ev_len[e];
+    if (site == KD_EV_DROPPED) { H.ev_slot[e] = KD_EV_DROPPED; return; }
     const uint8_t *p = ins.pool + ins.ev_off[e];
     kd_u64 h = kd_mix64(H.seed ^ ((kd_u64)site << 32 | len));
     for (uint32_t b = 0; b < len; b++) h = (h ^ p[b]) * 0x100000001b3ULL;
@@ -775,7 +868,7 @@ k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev) {
 __global__ void __launch_bounds__(KD_BLOCK)
 k_ins_verify(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *status) {
     const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (e >= n_ev) return;
+    if (e >= n_ev || H.ev_slot[e] == KD_EV_DROPPED) return;
     const uint32_t r = H.rep[H.ev_slot[e]];
     if (r == (uint32_t)e) return;
     bool same = ins.ev_site[e] == ins.ev_site[r] && ins.ev_len[e] == ins.ev_len[r];

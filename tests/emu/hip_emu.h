@@ -43,6 +43,7 @@ inline unsigned char *emu_dyn_shared_ptr = nullptr;
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define __launch_bounds__(...)
+#define KD_UNIFORM(x) ((uint32_t)(x))
 #define KD_DYN_SHARED(type, name) type *name = reinterpret_cast<type *>(emu_dyn_shared_ptr)
 
 static inline void __syncthreads() { emu_block_barrier->arrive_and_wait(); }
