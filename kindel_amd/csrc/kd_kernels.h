@@ -706,6 +706,44 @@ k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
 #define KD_STAGE_DIRECT 0x100u
 #define KD_WINDOW_LDS_BYTES(W) ((size_t)6 * (W) * 4 + (size_t)KD_BLOCK * (KD_STAGE_META * 4 + KD_STAGE_SEQ))
 
+// Phase-B walk of one read straight from HBM (CIGAR longer than KD_STAGE_CIG words or bases that do
+// not fit a staging slot: long-read aligners).  Same arithmetic as the staged path.
+__device__ __forceinline__ void kd_window_direct(const KdReads &rd, kd_u64 i, uint32_t nc, int32_t grel, int32_t Wi,
+                                                 uint32_t *hist, uint32_t lane, kd_u64 *status) {
+    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    const uint32_t W = (uint32_t)Wi;
+    int64_t q = 0;
+    for (uint32_t k = 0; k < nc; k++) {
+        const uint32_t cw = KD_UNIFORM(cg[k]);
+        const int32_t len = (int32_t)(cw >> 4);
+        const uint32_t op = cw & 15u;
+        if (op == 0 || op == 7 || op == 8 || op == 2) {
+            if (grel + len > 0) {  // the op reaches into the window
+                const int32_t j0 = grel < 0 ? -grel : 0;
+                const int32_t j1 = Wi - grel < len ? Wi - grel : len;
+                if (op == 2) {
+                    for (int32_t j = j0 + (int32_t)lane; j < j1; j += KD_WAVE)
+                        atomicAdd(&hist[5u * W + (uint32_t)(grel + j)], 1u);
+                } else {
+                    for (int32_t j = j0 + (int32_t)lane; j < j1; j += KD_WAVE) {
+                        const uint32_t ch = kd_chan(kd_nib(seq, q + j));
+                        if (ch == 7u) kd_flag_error(status, rd.base_index + i);
+                        else atomicAdd(&hist[ch * W + (uint32_t)(grel + j)], 1u);
+                    }
+                }
+            }
+            if (op != 2) q += len;
+            grel += len;
+            if (grel >= Wi) break;
+        } else if (op == 1) {
+            q += len;
+        } else if (op == 4) {
+            if (k == 0) q += len; else break;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(KD_BLOCK)
 k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
          const kd_u64 *item_off, uint32_t n_win, uint32_t W, uint32_t slice, kd_u64 *status) {
@@ -751,7 +789,10 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
                             m[3] |= KD_STAGE_DIRECT;
                         } else {
                             const uint32_t *cg = rd.cigar + rd.cig_off[i];
-                            for (uint32_t k = 0; k < nc; k++) m[4 + k] = cg[k];
+                            m[4] = cg[0];                       // nc >= 1 for every regular read
+                            m[5] = nc > 1 ? cg[1] : 0u;
+                            m[6] = nc > 2 ? cg[2] : 0u;
+                            m[7] = nc > 3 ? cg[3] : 0u;
                             const uint4 *src = reinterpret_cast<const uint4 *>(rd.seq4 + (soff - mis));
                             uint4 *dst = reinterpret_cast<uint4 *>(st_seq + (size_t)t * KD_STAGE_SEQ);
                             const uint32_t nchunk = (mis + nbytes + 15u) >> 4;
@@ -767,38 +808,45 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
             }
             __syncthreads();
             // ---- phase B: wavefront `wave` walks its 64 staged reads ----
+            // Everything that steers control flow is wave-uniform (SGPR); coordinates are 32-bit and
+            // relative to the window start, so the per-base work is a handful of VALU ops + 2 LDS ops.
             for (uint32_t r = 0; r < KD_WAVE; r++) {
                 const uint32_t slot = wave * KD_WAVE + r;
                 const uint32_t *m = st_meta + (size_t)slot * KD_STAGE_META;
                 const uint32_t sc = KD_UNIFORM(m[1]);
                 if ((sc & 3u) != KD_CLS_REG) continue;
                 const uint32_t nc = KD_UNIFORM(m[2]), fl = KD_UNIFORM(m[3]);
-                int64_t g = (int64_t)KD_UNIFORM(m[0]), q = 0;
-                const bool direct = (fl & KD_STAGE_DIRECT) != 0;
-                const kd_u64 i = b0 + slot;
-                const uint8_t *seq = direct ? rd.seq4 + rd.seq_off[i] : st_seq + (size_t)slot * KD_STAGE_SEQ + (fl & 15u);
-                const uint32_t *cg = direct ? rd.cigar + rd.cig_off[i] : m + 4;
+                int32_t grel = (int32_t)(KD_UNIFORM(m[0]) - (uint32_t)wlo);  // G-start - window start (may be < 0)
+                const int32_t Wi = (int32_t)W;
+                if (fl & KD_STAGE_DIRECT) {
+                    kd_window_direct(rd, b0 + slot, nc, grel, Wi, hist, lane, status);
+                    continue;
+                }
+                const uint8_t *sq = st_seq + (size_t)slot * KD_STAGE_SEQ + (fl & 15u);
+                int32_t q = 0;
                 for (uint32_t k = 0; k < nc; k++) {
-                    const uint32_t cw = direct ? cg[k] : KD_UNIFORM(cg[k]);
-                    const int64_t len = cw >> 4;
+                    const uint32_t cw = KD_UNIFORM(m[4 + k]);
+                    const int32_t len = (int32_t)(cw >> 4);
                     const uint32_t op = cw & 15u;
-                    if (op == 0 || op == 7 || op == 8 || op == 2) {
-                        // overlap of [g, g+len) with the window, as offsets into the op
-                        const int64_t j0 = (int64_t)wlo > g ? (int64_t)wlo - g : 0;
-                        const int64_t j1 = (int64_t)whi - g < len ? (int64_t)whi - g : len;
-                        if (op == 2) {
-                            for (int64_t j = j0 + lane; j < j1; j += KD_WAVE)
-                                atomicAdd(&hist[5u * W + (uint32_t)(g + j - (int64_t)wlo)], 1u);
-                        } else {
-                            for (int64_t j = j0 + lane; j < j1; j += KD_WAVE) {
-                                const uint32_t ch = kd_chan(kd_nib(seq, q + j));
-                                if (ch == 7u) kd_flag_error(status, rd.base_index + i);
-                                else atomicAdd(&hist[ch * W + (uint32_t)(g + j - (int64_t)wlo)], 1u);
-                            }
-                            q += len;
+                    if (op == 0 || op == 7 || op == 8) {
+                        const int32_t j0 = grel < 0 ? -grel : 0;
+                        const int32_t j1 = Wi - grel < len ? Wi - grel : len;
+                        for (int32_t j = j0 + (int32_t)lane; j < j1; j += KD_WAVE) {
+                            const uint32_t x = (uint32_t)(q + j);
+                            const uint32_t byte = sq[x >> 1];
+                            const uint32_t ch = kd_chan((x & 1u) ? (byte & 15u) : (byte >> 4));
+                            if (ch == 7u) kd_flag_error(status, rd.base_index + b0 + slot);
+                            else atomicAdd(&hist[ch * W + (uint32_t)(grel + j)], 1u);
                         }
-                        g += len;
-                        if (g >= (int64_t)whi) break;
+                        q += len; grel += len;
+                        if (grel >= Wi) break;
+                    } else if (op == 2) {
+                        const int32_t j0 = grel < 0 ? -grel : 0;
+                        const int32_t j1 = Wi - grel < len ? Wi - grel : len;
+                        for (int32_t j = j0 + (int32_t)lane; j < j1; j += KD_WAVE)
+                            atomicAdd(&hist[5u * W + (uint32_t)(grel + j)], 1u);
+                        grel += len;
+                        if (grel >= Wi) break;
                     } else if (op == 1) {
                         q += len;
                     } else if (op == 4) {
