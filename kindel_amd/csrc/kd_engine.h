@@ -255,6 +255,8 @@ struct KdEngine {
                           (const uint32_t *)nullptr, (kd_u64)n, (const KdRInfo *)rinfo, d_status))
                 return hipfail("k_pileup_wave_all");
         }
+        if (windowed && rt.launch("k_find_bad_base", k_find_bad_base, 1u, KD_BLOCK, 0, R, (const KdRInfo *)rinfo, d_status))
+            return hipfail("k_find_bad_base");
         if (rt.launch("k_diagnose", k_diagnose, 1u, KD_WAVE, 0, R, T, d_status)) return hipfail("k_diagnose");
         reads_pushed += n;
         finalized = false; have_cns = false; have_inskeys = false;

@@ -88,6 +88,7 @@ enum {
     KDS_TOTAL_ITEMS,    // window work queue length
     KDS_INS_COLLISION,  // hash verification failed
     KDS_INTERNAL,       // capacity overrun etc.
+    KDS_BAD_BASE,       // k_window: windows that saw a base outside A,C,G,T,N
     KDS_COUNT
 };
 
@@ -690,57 +691,39 @@ k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
 }
 
 // k_window: persistent workgroups pull (window, slice) work items.
-// LDS (dynamic): u32 hist[6][W] (A,T,G,C,N,del) channel-major -- the 64 lanes of a wavefront walk 64
-// consecutive reference sites of one read, i.e. 64 consecutive dwords of one channel: no bank
-// conflict inside an instruction -- followed by a staging area for KD_BLOCK reads.
-// Per batch of KD_BLOCK reads:  phase A, one THREAD per read: metadata, the first KD_STAGE_CIG CIGAR
-// words and the packed bases are copied global -> LDS with every load of the workgroup in flight at
-// once (this replaces a 4-5 deep dependent-load chain per read with one round trip per 256 reads);
-// phase B, one WAVEFRONT per read: lanes = bases, nibbles come from LDS, tallies go to hist with
-// ds_add_u32.  Reads that do not fit the staging slot (long CIGAR / long read) take the direct path
-// (loads from HBM inside phase B).  Only REGULAR reads are handled here; their S/I side effects are
-// done by k_pileup_wave<false,true>.
-#define KD_STAGE_CIG 4
-#define KD_STAGE_SEQ 96          // bytes per read slot: up to 162 bases at any 16-byte misalignment
-#define KD_STAGE_META 8          // u32 per read: gstart, span_cls(0 = inactive), n_cig, flags, cigar[4]
-#define KD_STAGE_DIRECT 0x100u
-#define KD_WINDOW_LDS_BYTES(W) ((size_t)6 * (W) * 4 + (size_t)KD_BLOCK * (KD_STAGE_META * 4 + KD_STAGE_SEQ))
+//
+// LDS (dynamic): u32 hist[8][W], channel-major: channels 0-4 = A,T,G,C,N, 5 = deletions, 6 = sink for
+// masked-out lanes, 7 = bases outside A,C,G,T,N (checked at flush) -- followed by one private staging
+// slot of 25 dwords per thread (odd stride: the 64 lanes of a wavefront hit 64 different banks).
+//
+// One LANE per read.  Each lane copies its read's packed bases global -> LDS with up to six 16-byte
+// loads in flight, then walks its CIGAR: an M run is consumed 8 bases (one dword of nibbles) at a
+// time, every base one ds_add_u32 into hist.  Lanes start at different dwords of their runs
+// (rotation), so that the 64 reads of a wavefront -- neighbours in a coordinate-sorted batch, i.e.
+// nearly the same reference positions -- do not pile onto the same LDS addresses in the same
+// instruction.  No idle lanes on 150 bp reads, no per-read scalar work, no barriers in the loop.
+// Reads whose bases do not fit the slot (long reads) are walked straight from HBM, same arithmetic.
+// Only REGULAR reads are handled here; their S/I side effects are done by k_pileup_wave<false,true>.
+#define KD_HCH 8
+#define KD_SLOT_DW 25            // dwords per staging slot (24 used: six 16-byte chunks)
+#define KD_SLOT_BYTES 96
+#define KD_WINDOW_LDS_BYTES(W) ((size_t)KD_HCH * (W) * 4 + (size_t)KD_BLOCK * KD_SLOT_DW * 4)
 
-// Phase-B walk of one read straight from HBM (CIGAR longer than KD_STAGE_CIG words or bases that do
-// not fit a staging slot: long-read aligners).  Same arithmetic as the staged path.
-__device__ __forceinline__ void kd_window_direct(const KdReads &rd, kd_u64 i, uint32_t nc, int32_t grel, int32_t Wi,
-                                                 uint32_t *hist, uint32_t lane, kd_u64 *status) {
-    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
-    const uint32_t *cg = rd.cigar + rd.cig_off[i];
-    const uint32_t W = (uint32_t)Wi;
-    int64_t q = 0;
-    for (uint32_t k = 0; k < nc; k++) {
-        const uint32_t cw = KD_UNIFORM(cg[k]);
-        const int32_t len = (int32_t)(cw >> 4);
-        const uint32_t op = cw & 15u;
-        if (op == 0 || op == 7 || op == 8 || op == 2) {
-            if (grel + len > 0) {  // the op reaches into the window
-                const int32_t j0 = grel < 0 ? -grel : 0;
-                const int32_t j1 = Wi - grel < len ? Wi - grel : len;
-                if (op == 2) {
-                    for (int32_t j = j0 + (int32_t)lane; j < j1; j += KD_WAVE)
-                        atomicAdd(&hist[5u * W + (uint32_t)(grel + j)], 1u);
-                } else {
-                    for (int32_t j = j0 + (int32_t)lane; j < j1; j += KD_WAVE) {
-                        const uint32_t ch = kd_chan(kd_nib(seq, q + j));
-                        if (ch == 7u) kd_flag_error(status, rd.base_index + i);
-                        else atomicAdd(&hist[ch * W + (uint32_t)(grel + j)], 1u);
-                    }
-                }
-            }
-            if (op != 2) q += len;
-            grel += len;
-            if (grel >= Wi) break;
-        } else if (op == 1) {
-            q += len;
-        } else if (op == 4) {
-            if (k == 0) q += len; else break;
-        }
+#ifndef KD_ALIGNBYTE
+#define KD_ALIGNBYTE(hi, lo, sh) __builtin_amdgcn_alignbyte((hi), (lo), (sh))
+#endif
+
+// 8 bases of one dword `v` (BAM nibble order inside little-endian bytes): base b sits at bit shift
+// 8*(b>>1) + (b&1 ? 0 : 4).  s0 = window-relative site of base 0; bases [blo, bhi) are live.
+__device__ __forceinline__ void kd_add8(uint32_t *hist, uint32_t W, uint32_t v, int32_t s0, int32_t blo, int32_t bhi,
+                                        uint32_t sink) {
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const uint32_t nib = (v >> (8 * (b >> 1) + ((b & 1) ? 0 : 4))) & 15u;
+        const uint32_t ch = kd_chan(nib);
+        const bool ok = b >= blo && b < bhi;
+        const uint32_t addr = ok ? ch * W + (uint32_t)(s0 + b) : sink;
+        atomicAdd(&hist[addr], 1u);
     }
 }
 
@@ -748,13 +731,14 @@ __global__ void __launch_bounds__(KD_BLOCK)
 k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
          const kd_u64 *item_off, uint32_t n_win, uint32_t W, uint32_t slice, kd_u64 *status) {
     KD_DYN_SHARED(uint32_t, hist);
-    uint32_t *st_meta = hist + 6u * W;
-    uint8_t *st_seq = reinterpret_cast<uint8_t *>(st_meta + KD_BLOCK * KD_STAGE_META);
+    uint32_t *slot = hist + (size_t)KD_HCH * W + (size_t)threadIdx.x * KD_SLOT_DW;
     __shared__ kd_u64 s_item;
     const uint32_t t = threadIdx.x;
-    const uint32_t lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
+    const uint32_t lane = t & (KD_WAVE - 1);
     const kd_u64 total = status[KDS_TOTAL_ITEMS];
-    const uint32_t nh = 6u * W;
+    const uint32_t nh = (uint32_t)KD_HCH * W;
+    const uint32_t sink = 6u * W + lane;   // masked-out adds land on 64 distinct dwords of channel 6
+    const int32_t Wi = (int32_t)W;
     for (;;) {
         if (t == 0) s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL);
         __syncthreads();
@@ -771,93 +755,72 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
         const kd_u64 first = win_lo[w] + (item - item_off[w]) * slice;
         const kd_u64 last = first + slice < win_hi[w] ? first + slice : win_hi[w];
         for (uint32_t x = t; x < nh; x += KD_BLOCK) hist[x] = 0;
-        for (kd_u64 b0 = first; b0 < last; b0 += KD_BLOCK) {
-            // ---- phase A: stage read b0 + t ----
-            {
-                const kd_u64 i = b0 + t;
-                uint32_t m[KD_STAGE_META] = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (i < last) {
-                    const KdRInfo ri = rinfo[i];
-                    const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
-                    if ((ri.span_cls & 3u) == KD_CLS_REG && gs + span > wlo && gs < whi) {
-                        const uint32_t nc = rd.n_cig[i];
-                        const kd_u64 soff = rd.seq_off[i];
-                        const uint32_t nbytes = (rd.seq_len[i] + 1u) >> 1;
-                        const uint32_t mis = (uint32_t)(soff & 15u);
-                        m[0] = ri.gstart; m[1] = ri.span_cls; m[2] = nc; m[3] = mis;
-                        if (nc > KD_STAGE_CIG || mis + nbytes > KD_STAGE_SEQ) {
-                            m[3] |= KD_STAGE_DIRECT;
-                        } else {
-                            const uint32_t *cg = rd.cigar + rd.cig_off[i];
-                            m[4] = cg[0];                       // nc >= 1 for every regular read
-                            m[5] = nc > 1 ? cg[1] : 0u;
-                            m[6] = nc > 2 ? cg[2] : 0u;
-                            m[7] = nc > 3 ? cg[3] : 0u;
-                            const uint4 *src = reinterpret_cast<const uint4 *>(rd.seq4 + (soff - mis));
-                            uint4 *dst = reinterpret_cast<uint4 *>(st_seq + (size_t)t * KD_STAGE_SEQ);
-                            const uint32_t nchunk = (mis + nbytes + 15u) >> 4;
-                            for (uint32_t c = 0; c < nchunk; c++) dst[c] = src[c];
-                        }
-                    }
-                }
-                uint4 *md = reinterpret_cast<uint4 *>(st_meta + (size_t)t * KD_STAGE_META);
-                uint4 v0, v1;
-                v0.x = m[0]; v0.y = m[1]; v0.z = m[2]; v0.w = m[3];
-                v1.x = m[4]; v1.y = m[5]; v1.z = m[6]; v1.w = m[7];
-                md[0] = v0; md[1] = v1;
-            }
-            __syncthreads();
-            // ---- phase B: wavefront `wave` walks its 64 staged reads ----
-            // Everything that steers control flow is wave-uniform (SGPR); coordinates are 32-bit and
-            // relative to the window start, so the per-base work is a handful of VALU ops + 2 LDS ops.
-            for (uint32_t r = 0; r < KD_WAVE; r++) {
-                const uint32_t slot = wave * KD_WAVE + r;
-                const uint32_t *m = st_meta + (size_t)slot * KD_STAGE_META;
-                const uint32_t sc = KD_UNIFORM(m[1]);
-                if ((sc & 3u) != KD_CLS_REG) continue;
-                const uint32_t nc = KD_UNIFORM(m[2]), fl = KD_UNIFORM(m[3]);
-                int32_t grel = (int32_t)(KD_UNIFORM(m[0]) - (uint32_t)wlo);  // G-start - window start (may be < 0)
-                const int32_t Wi = (int32_t)W;
-                if (fl & KD_STAGE_DIRECT) {
-                    kd_window_direct(rd, b0 + slot, nc, grel, Wi, hist, lane, status);
-                    continue;
-                }
-                const uint8_t *sq = st_seq + (size_t)slot * KD_STAGE_SEQ + (fl & 15u);
-                int32_t q = 0;
-                for (uint32_t k = 0; k < nc; k++) {
-                    const uint32_t cw = KD_UNIFORM(m[4 + k]);
-                    const int32_t len = (int32_t)(cw >> 4);
-                    const uint32_t op = cw & 15u;
-                    if (op == 0 || op == 7 || op == 8) {
-                        const int32_t j0 = grel < 0 ? -grel : 0;
-                        const int32_t j1 = Wi - grel < len ? Wi - grel : len;
-                        for (int32_t j = j0 + (int32_t)lane; j < j1; j += KD_WAVE) {
-                            const uint32_t x = (uint32_t)(q + j);
-                            const uint32_t byte = sq[x >> 1];
-                            const uint32_t ch = kd_chan((x & 1u) ? (byte & 15u) : (byte >> 4));
-                            if (ch == 7u) kd_flag_error(status, rd.base_index + b0 + slot);
-                            else atomicAdd(&hist[ch * W + (uint32_t)(grel + j)], 1u);
-                        }
-                        q += len; grel += len;
-                        if (grel >= Wi) break;
-                    } else if (op == 2) {
-                        const int32_t j0 = grel < 0 ? -grel : 0;
-                        const int32_t j1 = Wi - grel < len ? Wi - grel : len;
-                        for (int32_t j = j0 + (int32_t)lane; j < j1; j += KD_WAVE)
-                            atomicAdd(&hist[5u * W + (uint32_t)(grel + j)], 1u);
-                        grel += len;
-                        if (grel >= Wi) break;
-                    } else if (op == 1) {
-                        q += len;
-                    } else if (op == 4) {
-                        if (k == 0) q += len; else break;  // regular: nothing after a non-first S touches r
+        __syncthreads();
+        for (kd_u64 i = first + t; i < last; i += KD_BLOCK) {
+            const KdRInfo ri = rinfo[i];
+            const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
+            if ((ri.span_cls & 3u) != KD_CLS_REG || gs + span <= wlo || gs >= whi) continue;
+            const uint32_t nc = rd.n_cig[i];
+            const kd_u64 soff = rd.seq_off[i];
+            const uint32_t nbytes = (rd.seq_len[i] + 1u) >> 1;
+            const uint32_t *cg = rd.cigar + rd.cig_off[i];
+            const uint32_t mis = (uint32_t)(soff & 15u);
+            const bool staged = mis + nbytes <= KD_SLOT_BYTES;
+            if (staged) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(rd.seq4 + (soff - mis));
+                const uint32_t nchunk = (mis + nbytes + 15u) >> 4;
+#pragma unroll
+                for (uint32_t c = 0; c < KD_SLOT_BYTES / 16; c++) {
+                    if (c < nchunk) {
+                        const uint4 v = src[c];
+                        slot[4 * c + 0] = v.x; slot[4 * c + 1] = v.y; slot[4 * c + 2] = v.z; slot[4 * c + 3] = v.w;
                     }
                 }
             }
-            __syncthreads();
+            // dword d of the read's bases = bytes [4d, 4d+4) after its first byte
+            const uint32_t sh = staged ? (mis & 3u) : (uint32_t)(soff & 3u);
+            const uint32_t *gsrc = reinterpret_cast<const uint32_t *>(rd.seq4 + (soff - (soff & 3u)));
+            const uint32_t sbase = mis >> 2;
+            int32_t grel = (int32_t)((uint32_t)gs - (uint32_t)wlo);  // may be negative
+            int32_t q = 0;
+            for (uint32_t k = 0; k < nc; k++) {
+                const uint32_t cw = cg[k];
+                const int32_t len = (int32_t)(cw >> 4);
+                const uint32_t op = cw & 15u;
+                if (op == 0 || op == 7 || op == 8) {
+                    if (len > 0 && grel + len > 0) {
+                        const int32_t x0 = q, x1 = q + len;
+                        const int32_t d0 = x0 >> 3, n = ((x1 - 1) >> 3) - d0 + 1;
+                        int32_t d = d0 + (int32_t)((lane * (uint32_t)n) >> 6);  // rotated start
+                        for (int32_t it = 0; it < n; it++) {
+                            uint32_t w0, w1;
+                            if (staged) { w0 = slot[sbase + d]; w1 = slot[sbase + d + 1]; }
+                            else { w0 = gsrc[d]; w1 = gsrc[d + 1]; }
+                            const uint32_t v = sh ? KD_ALIGNBYTE(w1, w0, sh) : w0;
+                            const int32_t s0 = grel + (8 * d - x0);
+                            int32_t blo = x0 - 8 * d; if (-s0 > blo) blo = -s0; if (blo < 0) blo = 0;
+                            int32_t bhi = x1 - 8 * d; if (Wi - s0 < bhi) bhi = Wi - s0; if (bhi > 8) bhi = 8;
+                            if (bhi > blo) kd_add8(hist, W, v, s0, blo, bhi, sink);
+                            if (++d >= d0 + n) d = d0;
+                        }
+                    }
+                    q += len; grel += len;
+                    if (grel >= Wi) break;
+                } else if (op == 2) {
+                    for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
+                        atomicAdd(&hist[5u * W + (uint32_t)(grel + j)], 1u);
+                    grel += len;
+                    if (grel >= Wi) break;
+                } else if (op == 1) {
+                    q += len;
+                } else if (op == 4) {
+                    if (k == 0) q += len; else break;  // regular: nothing after a non-first S touches r
+                }
+            }
         }
+        __syncthreads();
         // flush: channel-major, consecutive lanes -> consecutive HBM dwords; zeros are skipped
-        for (uint32_t x = t; x < nh; x += KD_BLOCK) {
+        for (uint32_t x = t; x < 6u * W; x += KD_BLOCK) {
             const uint32_t v = hist[x];
             if (v) {
                 const uint32_t ch = x / W;
@@ -865,7 +828,39 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
                 if (g < T.stride && kd_commit(T, g)) atomicAdd(&T.tab[(kd_u64)ch * T.stride + g], v);
             }
         }
+        // channel 7: a base outside A,C,G,T,N inside an aligned segment (KeyError in the reference);
+        // k_find_bad_base pins down the read
+        bool bad = false;
+        for (uint32_t x = 7u * W + t; x < 8u * W; x += KD_BLOCK) bad |= hist[x] != 0;
+        if (bad) atomicAdd(&status[KDS_BAD_BASE], 1ULL);
         __syncthreads();
+    }
+}
+
+// Rare path: k_window saw a base outside A,C,G,T,N.  One workgroup walks the regular reads of the
+// batch and records the first offender (atomicMin of the read index), for k_diagnose to classify.
+__global__ void __launch_bounds__(KD_BLOCK)
+k_find_bad_base(KdReads rd, const KdRInfo *rinfo, kd_u64 *status) {
+    if (status[KDS_BAD_BASE] == 0) return;
+    for (kd_u64 i = threadIdx.x; i < rd.n; i += KD_BLOCK) {
+        if ((rinfo[i].span_cls & 3u) != KD_CLS_REG) continue;
+        if (rd.base_index + i >= status[KDS_ERR_READ]) continue;
+        const uint8_t *seq = rd.seq4 + rd.seq_off[i];
+        const uint32_t *cg = rd.cigar + rd.cig_off[i];
+        const uint32_t nc = rd.n_cig[i];
+        int64_t q = 0;
+        bool found = false;
+        for (uint32_t k = 0; k < nc && !found; k++) {
+            const int64_t len = cg[k] >> 4;
+            const uint32_t op = cg[k] & 15u;
+            if (op == 0 || op == 7 || op == 8) {
+                for (int64_t j = 0; j < len; j++)
+                    if (kd_chan(kd_nib(seq, q + j)) == 7u) { found = true; break; }
+                q += len;
+            } else if (op == 1) q += len;
+            else if (op == 4) { if (k == 0) q += len; else break; }
+        }
+        if (found) kd_flag_error(status, rd.base_index + i);
     }
 }
 
