@@ -23,6 +23,7 @@ struct HipRt {
     bool bad(hipError_t rc) {
         if (rc == hipSuccess) return false;
         e = hipGetErrorString(rc);
+        (void)hipGetLastError();  // clear the sticky per-thread error so it cannot leak into the next call
         return true;
     }
     const char *err() const { return e.c_str(); }
