@@ -240,10 +240,9 @@ struct KdEngine {
                           (const kd_u64 *)wh, (const kd_u64 *)io, n_win, W, slice, d_status))
                 return hipfail("k_window");
             if (n_cold &&
-                rt.launch("k_pileup_wave_cold", k_pileup_wave<false, true>,
-                          (unsigned)((n_cold + KD_WAVES_PER_BLOCK - 1) / KD_WAVES_PER_BLOCK), KD_BLOCK, 0, R, T, I,
-                          (const uint32_t *)cold, (kd_u64)n_cold, (const KdRInfo *)rinfo, d_status))
-                return hipfail("k_pileup_wave_cold");
+                rt.launch("k_cold_lane", k_cold_lane, (unsigned)((n_cold + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, R, T, I,
+                          (const uint32_t *)cold, (kd_u64)n_cold, d_status))
+                return hipfail("k_cold_lane");
             if (n_irreg &&
                 rt.launch("k_pileup_wave_irreg", k_pileup_wave<true, true>,
                           (unsigned)((n_irreg + KD_WAVES_PER_BLOCK - 1) / KD_WAVES_PER_BLOCK), KD_BLOCK, 0, R, T, I,

@@ -565,6 +565,78 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
     (void)rinfo;
 }
 
+// k_cold_lane: the soft-clip / insertion side of REGULAR reads (kindel.py:55-58, :63-81), one LANE per
+// read of the cold list.  Regular reads cannot raise and never wrap (k_prep checked), so this is plain
+// G-space arithmetic: clip tallies go to HBM with 32-bit atomics (they are ~1 % of all events and land
+// on scattered sites), insertion events into the slots k_prep reserved for the read.
+__global__ void __launch_bounds__(KD_BLOCK)
+k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list, kd_u64 *status) {
+    const kd_u64 slot = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (slot >= n_list) return;
+    const kd_u64 i = list[slot];
+    const int64_t sl = rd.seq_len[i];
+    const uint32_t nc = rd.n_cig[i];
+    const uint32_t c = rd.contig[i];
+    const int64_t L = T.contig_len[c];
+    const kd_u64 cb = T.contig_base[c];
+    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    uint32_t *tab = T.tab;
+    const kd_u64 S = T.stride;
+    int64_t r = rd.pos0[i], q = 0;
+    kd_u64 ev_next = 0, pool_next = 0;
+    bool ev_loaded = false;
+    for (uint32_t k = 0; k < nc; k++) {
+        const uint32_t w = cg[k];
+        const int64_t len = w >> 4;
+        const uint32_t op = w & 15u;
+        if (op == 0 || op == 7 || op == 8) { r += len; q += len; }
+        else if (op == 2) { r += len; }
+        else if (op == 1) {
+            if (!ev_loaded) { ev_next = ins.read_ev[i]; pool_next = ins.read_pool[i]; ev_loaded = true; }
+            const int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
+            const kd_u64 n = (kd_u64)(q1 - q0);
+            const kd_u64 e = ev_next, po = pool_next;
+            ev_next += 1; pool_next += n;
+            const kd_u64 g = cb + (kd_u64)r;  // 0 <= r <= L for a regular read
+            if (e >= ins.ev_cap || po + n > ins.pool_cap) {
+                atomicAdd(&status[KDS_INTERNAL], 1ULL);
+            } else if (kd_commit(T, g)) {
+                ins.ev_site[e] = (uint32_t)g; ins.ev_len[e] = (uint32_t)n; ins.ev_off[e] = po;
+                for (kd_u64 b = 0; b < n; b++) ins.pool[po + b] = (uint8_t)kd_nib(seq, q0 + (int64_t)b);
+                atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g], 1u);
+            } else {
+                ins.ev_site[e] = KD_EV_DROPPED; ins.ev_len[e] = 0; ins.ev_off[e] = po;
+            }
+            q += len;
+        } else if (op == 4) {
+            if (k == 0) {  // kindel.py:64-73
+                const kd_u64 g = cb + (kd_u64)r;
+                if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g], 1u);
+                for (int64_t j = r < len ? len - r : 0; j < len; j++) {  // rel = r - len + j >= 0
+                    const uint32_t ch = kd_chan(kd_nib(seq, j));
+                    const kd_u64 gg = cb + (kd_u64)(r - len + j);
+                    if (ch == 7u) kd_flag_error(status, rd.base_index + i);
+                    else if (kd_commit(T, gg)) atomicAdd(&tab[(kd_u64)(KDC_CEW + ch) * S + gg], 1u);
+                }
+                q += len;
+            } else {  // kindel.py:74-81; regular: the last op that touches r
+                const int64_t x = r - 1;
+                const kd_u64 g = cb + (kd_u64)(x < 0 ? x + L + 1 : x);
+                if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
+                const int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
+                for (int64_t j = 0; j < n_adv; j++) {
+                    const uint32_t ch = kd_chan(kd_nib(seq, q + j));
+                    const kd_u64 gg = cb + (kd_u64)(r + j);
+                    if (ch == 7u) kd_flag_error(status, rd.base_index + i);
+                    else if (kd_commit(T, gg)) atomicAdd(&tab[(kd_u64)(KDC_CSW + ch) * S + gg], 1u);
+                }
+                r += n_adv; q += n_adv;
+            }
+        }
+    }
+}
+
 // k_diagnose: one thread re-walks the first failing read serially, in the reference's own
 // statement order, to decide WHICH exception the reference raises (KeyError vs IndexError
 // vs RuntimeError).  Error classification only -- it writes no table.
@@ -692,52 +764,63 @@ k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
 
 // k_window: persistent workgroups pull (window, slice) work items.
 //
-// LDS (dynamic): u32 hist[8][W], channel-major: channels 0-4 = A,T,G,C,N, 5 = deletions, 6 = sink for
-// masked-out lanes, 7 = bases outside A,C,G,T,N (checked at flush) -- followed by one private staging
-// slot of 25 dwords per thread (odd stride: the 64 lanes of a wavefront hit 64 different banks).
+// LDS (dynamic): u32 hist[7][W], channel-major: channels 0-4 = A,T,G,C,N, 5 = deletions, 6 = bases
+// outside A,C,G,T,N (checked at flush; KeyError in the reference).  28 B per site, so W = 1024 lets
+// five workgroups (20 wavefronts) share a CU's 160 KB.
 //
-// One LANE per read.  Each lane copies its read's packed bases global -> LDS with up to six 16-byte
-// loads in flight, then walks its CIGAR: an M run is consumed 8 bases (one dword of nibbles) at a
-// time, every base one ds_add_u32 into hist.  Lanes start at different dwords of their runs
-// (rotation), so that the 64 reads of a wavefront -- neighbours in a coordinate-sorted batch, i.e.
-// nearly the same reference positions -- do not pile onto the same LDS addresses in the same
-// instruction.  No idle lanes on 150 bp reads, no per-read scalar work, no barriers in the loop.
-// Reads whose bases do not fit the slot (long reads) are walked straight from HBM, same arithmetic.
-// Only REGULAR reads are handled here; their S/I side effects are done by k_pileup_wave<false,true>.
-#define KD_HCH 8
-#define KD_SLOT_DW 25            // dwords per staging slot (24 used: six 16-byte chunks)
-#define KD_SLOT_BYTES 96
-#define KD_WINDOW_LDS_BYTES(W) ((size_t)KD_HCH * (W) * 4 + (size_t)KD_BLOCK * KD_SLOT_DW * 4)
+// One LANE per read; thread t owns a contiguous run of the item's reads, so the 64 lanes of a
+// wavefront sit ~16 reads apart in the coordinate-sorted batch and rarely hit the same site in the
+// same instruction.  A read's packed bases are fetched with up to six 16-byte loads (all in flight
+// together) into registers -- aligned 16-byte chunks as they lie in HBM, no re-alignment: memory
+// dword m of the chunk holds query bases 2*(4m - mis) .. +7.  An M run is then consumed one dword
+// (8 bases) at a time by fully unrolled code, every base one ds_add_u32 into hist:
+//   nibble -> bfe, channel -> 64-bit LUT shift, address -> mad, ds_add with the base index as the
+//   instruction's immediate offset: 6 instructions per base when the dword is fully inside the run
+//   and the window, a masked variant at run / window edges.
+// Reads whose bases do not fit six chunks (long reads: thousands of short ops) are walked op by op
+// with dword loads straight from HBM/L2, same arithmetic.
+// Only REGULAR reads are handled here; their S/I side effects are done by k_cold_lane.
+#define KD_HCH 7
+#define KD_HCH_BAD 6u
+#define KD_CHUNKS 6                                   // 16-byte chunks held in registers
+#define KD_CHUNK_DW (4 * KD_CHUNKS)                   // 24 dwords = 192 bases
+#define KD_WINDOW_LDS_BYTES(W) ((size_t)KD_HCH * (W) * 4)
 
-#ifndef KD_ALIGNBYTE
-#define KD_ALIGNBYTE(hi, lo, sh) __builtin_amdgcn_alignbyte((hi), (lo), (sh))
-#endif
+// BAM nibble -> LDS channel: A,T,G,C,N -> 0..4, everything else -> KD_HCH_BAD
+__device__ __forceinline__ uint32_t kd_hchan(uint32_t nib) {
+    return (uint32_t)((0x4666666166626306ULL >> (nib * 4)) & 7ULL);
+}
+#define KD_NIB_SHIFT(b) (8 * ((b) >> 1) + (((b) & 1) ? 0 : 4))
 
-// 8 bases of one dword `v` (BAM nibble order inside little-endian bytes): base b sits at bit shift
-// 8*(b>>1) + (b&1 ? 0 : 4).  s0 = window-relative site of base 0; bases [blo, bhi) are live.
-__device__ __forceinline__ void kd_add8(uint32_t *hist, uint32_t W, uint32_t v, int32_t s0, int32_t blo, int32_t bhi,
-                                        uint32_t sink) {
+// all 8 bases of dword v are live; s0 = window-relative site of its first base
+__device__ __forceinline__ void kd_add8_full(uint32_t *hist, uint32_t W, uint32_t v, int32_t s0) {
+    uint32_t *h = hist + s0;
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
-        const uint32_t nib = (v >> (8 * (b >> 1) + ((b & 1) ? 0 : 4))) & 15u;
-        const uint32_t ch = kd_chan(nib);
-        const bool ok = b >= blo && b < bhi;
-        const uint32_t addr = ok ? ch * W + (uint32_t)(s0 + b) : sink;
-        atomicAdd(&hist[addr], 1u);
-    }
+    for (int b = 0; b < 8; b++) atomicAdd(&h[kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u) * W + b], 1u);
+}
+// only bases [blo, bhi) are live
+__device__ __forceinline__ void kd_add8_part(uint32_t *hist, uint32_t W, uint32_t v, int32_t s0, int32_t blo, int32_t bhi) {
+#pragma unroll
+    for (int b = 0; b < 8; b++)
+        if (b >= blo && b < bhi) atomicAdd(&hist[kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u) * W + (uint32_t)(s0 + b)], 1u);
+}
+// one memory dword against the live query range [xa, xb): xs = query index of the dword's first base,
+// sx = window-relative site of query base 0 of this run (site of base x is sx + x)
+__device__ __forceinline__ void kd_add_dword(uint32_t *hist, uint32_t W, uint32_t v, int32_t xs, int32_t xa, int32_t xb,
+                                             int32_t sx) {
+    if (xs + 8 <= xa || xs >= xb) return;
+    if (xs >= xa && xs + 8 <= xb) kd_add8_full(hist, W, v, sx + xs);
+    else kd_add8_part(hist, W, v, sx + xs, xa - xs, xb - xs);
 }
 
 __global__ void __launch_bounds__(KD_BLOCK)
 k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
          const kd_u64 *item_off, uint32_t n_win, uint32_t W, uint32_t slice, kd_u64 *status) {
     KD_DYN_SHARED(uint32_t, hist);
-    uint32_t *slot = hist + (size_t)KD_HCH * W + (size_t)threadIdx.x * KD_SLOT_DW;
     __shared__ kd_u64 s_item;
     const uint32_t t = threadIdx.x;
-    const uint32_t lane = t & (KD_WAVE - 1);
     const kd_u64 total = status[KDS_TOTAL_ITEMS];
     const uint32_t nh = (uint32_t)KD_HCH * W;
-    const uint32_t sink = 6u * W + lane;   // masked-out adds land on 64 distinct dwords of channel 6
     const int32_t Wi = (int32_t)W;
     for (;;) {
         if (t == 0) s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL);
@@ -756,7 +839,10 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
         const kd_u64 last = first + slice < win_hi[w] ? first + slice : win_hi[w];
         for (uint32_t x = t; x < nh; x += KD_BLOCK) hist[x] = 0;
         __syncthreads();
-        for (kd_u64 i = first + t; i < last; i += KD_BLOCK) {
+        // thread t owns reads [first + t*per, first + (t+1)*per)
+        const kd_u64 per = (last - first + KD_BLOCK - 1) / KD_BLOCK;
+        const kd_u64 i_end = first + (t + 1) * per < last ? first + (t + 1) * per : last;
+        for (kd_u64 i = first + t * per; i < i_end; i++) {
             const KdRInfo ri = rinfo[i];
             const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
             if ((ri.span_cls & 3u) != KD_CLS_REG || gs + span <= wlo || gs >= whi) continue;
@@ -764,44 +850,34 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
             const kd_u64 soff = rd.seq_off[i];
             const uint32_t nbytes = (rd.seq_len[i] + 1u) >> 1;
             const uint32_t *cg = rd.cigar + rd.cig_off[i];
-            const uint32_t mis = (uint32_t)(soff & 15u);
-            const bool staged = mis + nbytes <= KD_SLOT_BYTES;
-            if (staged) {
-                const uint4 *src = reinterpret_cast<const uint4 *>(rd.seq4 + (soff - mis));
-                const uint32_t nchunk = (mis + nbytes + 15u) >> 4;
-#pragma unroll
-                for (uint32_t c = 0; c < KD_SLOT_BYTES / 16; c++) {
-                    if (c < nchunk) {
-                        const uint4 v = src[c];
-                        slot[4 * c + 0] = v.x; slot[4 * c + 1] = v.y; slot[4 * c + 2] = v.z; slot[4 * c + 3] = v.w;
-                    }
-                }
-            }
-            // dword d of the read's bases = bytes [4d, 4d+4) after its first byte
-            const uint32_t sh = staged ? (mis & 3u) : (uint32_t)(soff & 3u);
-            const uint32_t *gsrc = reinterpret_cast<const uint32_t *>(rd.seq4 + (soff - (soff & 3u)));
-            const uint32_t sbase = mis >> 2;
-            int32_t grel = (int32_t)((uint32_t)gs - (uint32_t)wlo);  // may be negative
+            const int32_t mis = (int32_t)(soff & 15u);
+            const uint4 *src = reinterpret_cast<const uint4 *>(rd.seq4 + (soff - (kd_u64)mis));
+            (void)nbytes;
+            int32_t grel = (int32_t)((uint32_t)gs - (uint32_t)wlo);  // window-relative site, may be negative
             int32_t q = 0;
             for (uint32_t k = 0; k < nc; k++) {
                 const uint32_t cw = cg[k];
                 const int32_t len = (int32_t)(cw >> 4);
                 const uint32_t op = cw & 15u;
                 if (op == 0 || op == 7 || op == 8) {
-                    if (len > 0 && grel + len > 0) {
-                        const int32_t x0 = q, x1 = q + len;
-                        const int32_t d0 = x0 >> 3, n = ((x1 - 1) >> 3) - d0 + 1;
-                        int32_t d = d0 + (int32_t)((lane * (uint32_t)n) >> 6);  // rotated start
-                        for (int32_t it = 0; it < n; it++) {
-                            uint32_t w0, w1;
-                            if (staged) { w0 = slot[sbase + d]; w1 = slot[sbase + d + 1]; }
-                            else { w0 = gsrc[d]; w1 = gsrc[d + 1]; }
-                            const uint32_t v = sh ? KD_ALIGNBYTE(w1, w0, sh) : w0;
-                            const int32_t s0 = grel + (8 * d - x0);
-                            int32_t blo = x0 - 8 * d; if (-s0 > blo) blo = -s0; if (blo < 0) blo = 0;
-                            int32_t bhi = x1 - 8 * d; if (Wi - s0 < bhi) bhi = Wi - s0; if (bhi > 8) bhi = 8;
-                            if (bhi > blo) kd_add8(hist, W, v, s0, blo, bhi, sink);
-                            if (++d >= d0 + n) d = d0;
+                    // live query range: inside the run and inside the window
+                    const int32_t xa = grel < 0 ? q - grel : q;
+                    const int32_t xb = Wi - grel < len ? q + (Wi - grel) : q + len;
+                    if (xb > xa) {
+                        const int32_t sx = grel - q;          // site of query base x is sx + x
+                        const int32_t xm = -2 * mis;          // query index of the first base of memory dword 0
+                        // 16-byte chunks [ca, cb] hold the live bases; one chunk of prefetch
+                        const int32_t ca = (xa - xm) >> 5, cb = (xb - 1 - xm) >> 5;
+                        uint4 cur = src[ca];
+                        for (int32_t c = ca; c <= cb; c++) {
+                            uint4 nxt = cur;
+                            if (c < cb) nxt = src[c + 1];
+                            const int32_t xs = xm + 32 * c;
+                            kd_add_dword(hist, W, cur.x, xs, xa, xb, sx);
+                            kd_add_dword(hist, W, cur.y, xs + 8, xa, xb, sx);
+                            kd_add_dword(hist, W, cur.z, xs + 16, xa, xb, sx);
+                            kd_add_dword(hist, W, cur.w, xs + 24, xa, xb, sx);
+                            cur = nxt;
                         }
                     }
                     q += len; grel += len;
@@ -828,10 +904,9 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
                 if (g < T.stride && kd_commit(T, g)) atomicAdd(&T.tab[(kd_u64)ch * T.stride + g], v);
             }
         }
-        // channel 7: a base outside A,C,G,T,N inside an aligned segment (KeyError in the reference);
-        // k_find_bad_base pins down the read
+        // a base outside A,C,G,T,N inside an aligned segment: k_find_bad_base pins down the read
         bool bad = false;
-        for (uint32_t x = 7u * W + t; x < 8u * W; x += KD_BLOCK) bad |= hist[x] != 0;
+        for (uint32_t x = KD_HCH_BAD * W + t; x < (KD_HCH_BAD + 1u) * W; x += KD_BLOCK) bad |= hist[x] != 0;
         if (bad) atomicAdd(&status[KDS_BAD_BASE], 1ULL);
         __syncthreads();
     }
