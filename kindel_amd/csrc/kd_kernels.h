@@ -782,9 +782,11 @@ k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
 // Only REGULAR reads are handled here; their S/I side effects are done by k_cold_lane.
 #define KD_HCH 7
 #define KD_HCH_BAD 6u
-#define KD_CHUNKS 6                                   // 16-byte chunks held in registers
-#define KD_CHUNK_DW (4 * KD_CHUNKS)                   // 24 dwords = 192 bases
 #define KD_WINDOW_LDS_BYTES(W) ((size_t)KD_HCH * (W) * 4)
+
+// 16 packed bases-bytes at ANY byte address: gfx950 global loads are unaligned-capable, hipcc emits one
+// global_load_dwordx4 for this type.  Chunk c of a read holds its query bases 32c .. 32c+31.
+struct __attribute__((packed, aligned(1))) KdChunk { uint32_t x, y, z, w; };
 
 // BAM nibble -> LDS channel: A,T,G,C,N -> 0..4, everything else -> KD_HCH_BAD
 __device__ __forceinline__ uint32_t kd_hchan(uint32_t nib) {
@@ -839,20 +841,19 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
         const kd_u64 last = first + slice < win_hi[w] ? first + slice : win_hi[w];
         for (uint32_t x = t; x < nh; x += KD_BLOCK) hist[x] = 0;
         __syncthreads();
-        // thread t owns reads [first + t*per, first + (t+1)*per)
-        const kd_u64 per = (last - first + KD_BLOCK - 1) / KD_BLOCK;
-        const kd_u64 i_end = first + (t + 1) * per < last ? first + (t + 1) * per : last;
-        for (kd_u64 i = first + t * per; i < i_end; i++) {
+        // tiles of 256 consecutive reads; lane l of wavefront v takes read 4*l + v of the tile: the four
+        // wavefronts sweep the same cache lines together, the lanes of one wavefront sit 4 reads apart
+        const uint32_t lane4 = 4u * (t & (KD_WAVE - 1)) + (t / KD_WAVE);
+        for (kd_u64 tb = first; tb < last; tb += KD_BLOCK) {
+            const kd_u64 i = tb + lane4;
+            if (i >= last) continue;
             const KdRInfo ri = rinfo[i];
             const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
             if ((ri.span_cls & 3u) != KD_CLS_REG || gs + span <= wlo || gs >= whi) continue;
             const uint32_t nc = rd.n_cig[i];
             const kd_u64 soff = rd.seq_off[i];
-            const uint32_t nbytes = (rd.seq_len[i] + 1u) >> 1;
             const uint32_t *cg = rd.cigar + rd.cig_off[i];
-            const int32_t mis = (int32_t)(soff & 15u);
-            const uint4 *src = reinterpret_cast<const uint4 *>(rd.seq4 + (soff - (kd_u64)mis));
-            (void)nbytes;
+            const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + soff);
             int32_t grel = (int32_t)((uint32_t)gs - (uint32_t)wlo);  // window-relative site, may be negative
             int32_t q = 0;
             for (uint32_t k = 0; k < nc; k++) {
@@ -865,14 +866,13 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
                     const int32_t xb = Wi - grel < len ? q + (Wi - grel) : q + len;
                     if (xb > xa) {
                         const int32_t sx = grel - q;          // site of query base x is sx + x
-                        const int32_t xm = -2 * mis;          // query index of the first base of memory dword 0
                         // 16-byte chunks [ca, cb] hold the live bases; one chunk of prefetch
-                        const int32_t ca = (xa - xm) >> 5, cb = (xb - 1 - xm) >> 5;
-                        uint4 cur = src[ca];
+                        const int32_t ca = xa >> 5, cb = (xb - 1) >> 5;
+                        KdChunk cur = src[ca];
                         for (int32_t c = ca; c <= cb; c++) {
-                            uint4 nxt = cur;
+                            KdChunk nxt = cur;
                             if (c < cb) nxt = src[c + 1];
-                            const int32_t xs = xm + 32 * c;
+                            const int32_t xs = 32 * c;
                             kd_add_dword(hist, W, cur.x, xs, xa, xb, sx);
                             kd_add_dword(hist, W, cur.y, xs + 8, xa, xb, sx);
                             kd_add_dword(hist, W, cur.z, xs + 16, xa, xb, sx);
