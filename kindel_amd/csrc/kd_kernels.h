@@ -856,42 +856,44 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
             const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + soff);
             int32_t grel = (int32_t)((uint32_t)gs - (uint32_t)wlo);  // window-relative site, may be negative
             int32_t q = 0;
-            for (uint32_t k = 0; k < nc; k++) {
-                const uint32_t cw = cg[k];
-                const int32_t len = (int32_t)(cw >> 4);
-                const uint32_t op = cw & 15u;
-                if (op == 0 || op == 7 || op == 8) {
-                    // live query range: inside the run and inside the window
-                    const int32_t xa = grel < 0 ? q - grel : q;
-                    const int32_t xb = Wi - grel < len ? q + (Wi - grel) : q + len;
-                    if (xb > xa) {
-                        const int32_t sx = grel - q;          // site of query base x is sx + x
-                        // 16-byte chunks [ca, cb] hold the live bases; one chunk of prefetch
-                        const int32_t ca = xa >> 5, cb = (xb - 1) >> 5;
-                        KdChunk cur = src[ca];
-                        for (int32_t c = ca; c <= cb; c++) {
-                            KdChunk nxt = cur;
-                            if (c < cb) nxt = src[c + 1];
-                            const int32_t xs = 32 * c;
-                            kd_add_dword(hist, W, cur.x, xs, xa, xb, sx);
-                            kd_add_dword(hist, W, cur.y, xs + 8, xa, xb, sx);
-                            kd_add_dword(hist, W, cur.z, xs + 16, xa, xb, sx);
-                            kd_add_dword(hist, W, cur.w, xs + 24, xa, xb, sx);
-                            cur = nxt;
-                        }
+            // Per-lane state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the
+            // current M run), not over CIGAR ops: lanes whose reads have clips or indels still add
+            // bases in the same wavefront instructions as their single-run neighbours.
+            uint32_t k = 0;
+            int32_t xa = 0, xb = 0, sx = 0, c = 1, cb = 0;   // c > cb: no live run
+            for (;;) {
+                while (c > cb && k < nc) {   // advance to the next run with live bases
+                    const uint32_t cw = cg[k];
+                    const int32_t len = (int32_t)(cw >> 4);
+                    const uint32_t op = cw & 15u;
+                    k++;
+                    if (op == 0 || op == 7 || op == 8) {
+                        // live query range: inside the run and inside the window
+                        xa = grel < 0 ? q - grel : q;
+                        xb = Wi - grel < len ? q + (Wi - grel) : q + len;
+                        sx = grel - q;                      // site of query base x is sx + x
+                        if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                        q += len; grel += len;
+                        if (grel >= Wi) k = nc;
+                    } else if (op == 2) {
+                        for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
+                            atomicAdd(&hist[5u * W + (uint32_t)(grel + j)], 1u);
+                        grel += len;
+                        if (grel >= Wi) k = nc;
+                    } else if (op == 1) {
+                        q += len;
+                    } else if (op == 4) {
+                        if (k == 1) q += len; else k = nc;  // regular: nothing after a non-first S touches r
                     }
-                    q += len; grel += len;
-                    if (grel >= Wi) break;
-                } else if (op == 2) {
-                    for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
-                        atomicAdd(&hist[5u * W + (uint32_t)(grel + j)], 1u);
-                    grel += len;
-                    if (grel >= Wi) break;
-                } else if (op == 1) {
-                    q += len;
-                } else if (op == 4) {
-                    if (k == 0) q += len; else break;  // regular: nothing after a non-first S touches r
                 }
+                if (c > cb) break;
+                const KdChunk cur = src[c];
+                const int32_t xs = 32 * c;
+                kd_add_dword(hist, W, cur.x, xs, xa, xb, sx);
+                kd_add_dword(hist, W, cur.y, xs + 8, xa, xb, sx);
+                kd_add_dword(hist, W, cur.z, xs + 16, xa, xb, sx);
+                kd_add_dword(hist, W, cur.w, xs + 24, xa, xb, sx);
+                c++;
             }
         }
         __syncthreads();
