@@ -144,6 +144,12 @@ __device__ __forceinline__ uint32_t kd_nib(const uint8_t *seq, int64_t q) {
     return (q & 1) ? (b & 15u) : (b >> 4);
 }
 
+// 16 packed bases-bytes at ANY byte address: gfx950 global loads are unaligned-capable, hipcc emits one
+// global_load_dwordx4 for this type.  Chunk c of a read holds its query bases 32c .. 32c+31.
+struct __attribute__((packed, aligned(1))) KdChunk { uint32_t x, y, z, w; };
+// bit position of base b (0..7) inside a little-endian dword of BAM nibbles (high nibble first)
+#define KD_NIB_SHIFT(b) (8 * ((b) >> 1) + (((b) & 1) ? 0 : 4))
+
 __device__ __forceinline__ bool kd_commit(const KdTabs &T, kd_u64 g) { return g >= T.g_lo && g <= T.g_hi; }
 
 __device__ __forceinline__ void kd_flag_error(kd_u64 *status, kd_u64 gidx) { atomicMin(&status[KDS_ERR_READ], gidx); }
@@ -227,45 +233,68 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
     const kd_u64 chunk0 = (kd_u64)blockIdx.x * KD_PREP_CHUNK;
     kd_u64 a_reads = 0, a_aligned = 0, a_walked = 0, a_ins = 0, a_insb = 0, a_reg = 0, a_unsorted = 0;
     uint32_t a_maxspan = 0, n_cold = 0, n_irreg = 0, n_long = 0;
-    for (int it = 0; it < KD_PREP_PER_THREAD; it++) {
-        const kd_u64 i = chunk0 + (kd_u64)it * KD_BLOCK + t;
-        if (i >= rd.n) break;
-        const uint32_t c = rd.contig[i];
-        const int64_t pos0 = rd.pos0[i];
-        const kd_u64 cb = T.contig_base[c];
-        const kd_u64 gkey = cb + (kd_u64)(pos0 > 0 ? pos0 : 0);
-        if (i > 0) {  // sortedness of G-start over ALL reads of the batch (window ranges rely on it)
-            const int64_t pp = rd.pos0[i - 1];
-            const kd_u64 pk = T.contig_base[rd.contig[i - 1]] + (kd_u64)(pp > 0 ? pp : 0);
-            if (pk > gkey) a_unsorted++;
+    uint32_t m_cold = 0, m_irreg = 0, m_long = 0, m_ins = 0;  // bit `it` = this thread's it-th read is in the list
+    uint32_t c_cached = 0xffffffffu;                             // one-entry cache of the contig table
+    kd_u64 cb_cached = 0;
+    int64_t L_cached = 0;
+    // 4 reads per step: all of their metadata loads are issued before any is consumed
+    for (int it0 = 0; it0 < KD_PREP_PER_THREAD; it0 += 4) {
+        uint32_t v_c[4], v_pc[4], v_nc[4], v_fl[4];
+        int64_t v_pos[4], v_ppos[4], v_sl[4];
+        kd_u64 v_coff[4];
+        bool v_ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const kd_u64 i = chunk0 + (kd_u64)(it0 + u) * KD_BLOCK + t;
+            v_ok[u] = i < rd.n;
+            const kd_u64 j = v_ok[u] ? i : 0, jp = (v_ok[u] && i > 0) ? i - 1 : j;
+            v_c[u] = rd.contig[j]; v_pos[u] = rd.pos0[j];
+            v_pc[u] = rd.contig[jp]; v_ppos[u] = rd.pos0[jp];
+            v_sl[u] = rd.seq_len[j]; v_nc[u] = rd.n_cig[j]; v_fl[u] = rd.flag[j]; v_coff[u] = rd.cig_off[j];
         }
-        const int64_t sl = rd.seq_len[i];
-        const uint32_t nc = rd.n_cig[i];
-        uint32_t cls, cold = 0;
-        kd_u64 span = 0;
-        bool has_ins = false;
-        if ((rd.flag[i] & 4u) || sl <= 1) {
-            cls = KD_CLS_SKIP;
-        } else if (nc == 0) {
-            cls = KD_CLS_IRREG;  // CIGAR '*': k_pileup_wave raises KD_E_CIGAR
-            a_reads++;
-        } else if (nc > KD_PREP_MAX_OPS) {
-            cls = KD_CLS_LONG;
-            a_reads++;
-        } else {
-            KdScan s = kd_scan_cigar(rd.cigar + rd.cig_off[i], nc, pos0, sl, (int64_t)T.contig_len[c]);
-            cls = s.cls; cold = s.cold; span = s.span; has_ins = s.n_ins != 0;
-            a_reads++; a_aligned += s.aligned; a_walked += s.walked; a_ins += s.n_ins; a_insb += s.ins_bases;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!v_ok[u]) continue;
+            const int it = it0 + u;
+            const kd_u64 i = chunk0 + (kd_u64)it * KD_BLOCK + t;
+            const uint32_t c = v_c[u];
+            if (c != c_cached) { c_cached = c; cb_cached = T.contig_base[c]; L_cached = (int64_t)T.contig_len[c]; }
+            const int64_t pos0 = v_pos[u];
+            const kd_u64 gkey = cb_cached + (kd_u64)(pos0 > 0 ? pos0 : 0);
+            {   // sortedness of G-start over ALL reads of the batch (window ranges rely on it)
+                const kd_u64 pcb = v_pc[u] == c ? cb_cached : T.contig_base[v_pc[u]];
+                const kd_u64 pk = pcb + (kd_u64)(v_ppos[u] > 0 ? v_ppos[u] : 0);
+                if (pk > gkey) a_unsorted++;
+            }
+            const int64_t sl = v_sl[u];
+            const uint32_t nc = v_nc[u];
+            uint32_t cls, cold = 0;
+            kd_u64 span = 0;
+            bool has_ins = false;
+            if ((v_fl[u] & 4u) || sl <= 1) {
+                cls = KD_CLS_SKIP;
+            } else if (nc == 0) {
+                cls = KD_CLS_IRREG;  // CIGAR '*': k_pileup_wave raises KD_E_CIGAR
+                a_reads++;
+            } else if (nc > KD_PREP_MAX_OPS) {
+                cls = KD_CLS_LONG;
+                a_reads++;
+            } else {
+                KdScan s = kd_scan_cigar(rd.cigar + v_coff[u], nc, pos0, sl, L_cached);
+                cls = s.cls; cold = s.cold; span = s.span; has_ins = s.n_ins != 0;
+                a_reads++; a_aligned += s.aligned; a_walked += s.walked; a_ins += s.n_ins; a_insb += s.ins_bases;
+            }
+            if (span > 0x0fffffffULL) { cls = KD_CLS_IRREG; span = 0; }
+            if (cls == KD_CLS_REG) { a_reg++; if ((uint32_t)span > a_maxspan) a_maxspan = (uint32_t)span; }
+            if (cls == KD_CLS_REG && cold) { n_cold++; m_cold |= 1u << it; }
+            if (cls == KD_CLS_IRREG) { n_irreg++; m_irreg |= 1u << it; }
+            if (cls == KD_CLS_LONG) { n_long++; m_long |= 1u << it; }
+            if (has_ins) m_ins |= 1u << it;
+            KdRInfo ri;
+            ri.gstart = (uint32_t)gkey;
+            ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | (has_ins ? KD_INFO_INS : 0u) | cold | cls;
+            rinfo[i] = ri;
         }
-        if (span > 0x0fffffffULL) { cls = KD_CLS_IRREG; span = 0; }
-        if (cls == KD_CLS_REG) { a_reg++; if ((uint32_t)span > a_maxspan) a_maxspan = (uint32_t)span; }
-        if (cls == KD_CLS_REG && cold) n_cold++;
-        if (cls == KD_CLS_IRREG) n_irreg++;
-        if (cls == KD_CLS_LONG) n_long++;
-        KdRInfo ri;
-        ri.gstart = (uint32_t)gkey;
-        ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | (has_ins ? KD_INFO_INS : 0u) | cold | cls;
-        rinfo[i] = ri;
     }
     // block reduction through LDS atomics, then one global atomic per word per block
     if (a_reads) atomicAdd(&s_red[0], a_reads);
@@ -301,23 +330,22 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
         s_base[2] = s_cnt[2] ? atomicAdd(&status[KDS_B_N_LONG], (kd_u64)s_cnt[2]) : 0;
     }
     __syncthreads();
-    if (n_cold | n_irreg | n_long | (a_ins != 0)) {
+    if (m_cold | m_irreg | m_long | m_ins) {
         kd_u64 w_cold = s_base[0] + o_cold, w_irreg = s_base[1] + o_irreg, w_long = s_base[2] + o_long;
         kd_u64 w_ev = s_base[3] + o_ev, w_pool = s_base[4] + o_pool;
-        for (int it = 0; it < KD_PREP_PER_THREAD; it++) {
+        for (uint32_t todo = m_cold | m_irreg | m_long | m_ins; todo; todo &= todo - 1) {
+            const int it = __builtin_ctz(todo);
             const kd_u64 i = chunk0 + (kd_u64)it * KD_BLOCK + t;
-            if (i >= rd.n) break;
-            const uint32_t sc = rinfo[i].span_cls;
-            const uint32_t cls = sc & 3u;
-            if (sc & KD_INFO_INS) {  // rescan (cached) to hand this read its event / pool slots
+            const uint32_t bit = 1u << it;
+            if (m_ins & bit) {  // rescan (cached) to hand this read its event / pool slots
                 KdScan s = kd_scan_cigar(rd.cigar + rd.cig_off[i], rd.n_cig[i], rd.pos0[i], rd.seq_len[i],
                                          (int64_t)T.contig_len[rd.contig[i]]);
                 read_ev[i] = (uint32_t)w_ev; read_pool[i] = w_pool;
                 w_ev += s.n_ins; w_pool += s.ins_bases;
             }
-            if (cls == KD_CLS_REG && (sc & KD_INFO_COLD)) cold_list[w_cold++] = (uint32_t)i;
-            if (cls == KD_CLS_IRREG) irreg_list[w_irreg++] = (uint32_t)i;
-            if (cls == KD_CLS_LONG) long_list[w_long++] = (uint32_t)i;
+            if (m_cold & bit) cold_list[w_cold++] = (uint32_t)i;
+            if (m_irreg & bit) irreg_list[w_irreg++] = (uint32_t)i;
+            if (m_long & bit) long_list[w_long++] = (uint32_t)i;
         }
     }
 }
@@ -565,6 +593,36 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
     (void)rinfo;
 }
 
+// Soft-clip bases [xa, xb) of a read -> tab[ch0 + channel][gx + x] (G-space site of query base x is
+// gx + x), consumed from 16-byte chunks like k_window does.  Returns true if a base outside A,C,G,T,N
+// was met (KeyError in the reference, kindel.py:72,79).
+__device__ __forceinline__ bool kd_clip_bases(const KdTabs &T, const uint8_t *seq, int64_t xa, int64_t xb, int64_t gx,
+                                              uint32_t ch0) {
+    bool bad = false;
+    if (xb <= xa) return false;
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(seq);
+    for (int64_t c = xa >> 5; c <= (xb - 1) >> 5; c++) {
+        const KdChunk cur = src[c];
+        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int64_t xs = 32 * c + 8 * d;
+            if (xs + 8 <= xa || xs >= xb) continue;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const int64_t x = xs + b;
+                if (x >= xa && x < xb) {
+                    const uint32_t ch = kd_chan((w[d] >> KD_NIB_SHIFT(b)) & 15u);
+                    const kd_u64 g = (kd_u64)(gx + x);
+                    if (ch == 7u) bad = true;
+                    else if (kd_commit(T, g)) atomicAdd(&T.tab[(kd_u64)(ch0 + ch) * T.stride + g], 1u);
+                }
+            }
+        }
+    }
+    return bad;
+}
+
 // k_cold_lane: the soft-clip / insertion side of REGULAR reads (kindel.py:55-58, :63-81), one LANE per
 // read of the cold list.  Regular reads cannot raise and never wrap (k_prep checked), so this is plain
 // G-space arithmetic: clip tallies go to HBM with 32-bit atomics (they are ~1 % of all events and land
@@ -613,24 +671,17 @@ k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list
             if (k == 0) {  // kindel.py:64-73
                 const kd_u64 g = cb + (kd_u64)r;
                 if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g], 1u);
-                for (int64_t j = r < len ? len - r : 0; j < len; j++) {  // rel = r - len + j >= 0
-                    const uint32_t ch = kd_chan(kd_nib(seq, j));
-                    const kd_u64 gg = cb + (kd_u64)(r - len + j);
-                    if (ch == 7u) kd_flag_error(status, rd.base_index + i);
-                    else if (kd_commit(T, gg)) atomicAdd(&tab[(kd_u64)(KDC_CEW + ch) * S + gg], 1u);
-                }
+                // query bases [xa, len) land on sites r - len + x  (those with r - len + x >= 0)
+                const int64_t xa = r < len ? len - r : 0;
+                if (kd_clip_bases(T, seq, xa, len, (int64_t)cb + r - len, KDC_CEW)) kd_flag_error(status, rd.base_index + i);
                 q += len;
             } else {  // kindel.py:74-81; regular: the last op that touches r
                 const int64_t x = r - 1;
                 const kd_u64 g = cb + (kd_u64)(x < 0 ? x + L + 1 : x);
                 if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
                 const int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
-                for (int64_t j = 0; j < n_adv; j++) {
-                    const uint32_t ch = kd_chan(kd_nib(seq, q + j));
-                    const kd_u64 gg = cb + (kd_u64)(r + j);
-                    if (ch == 7u) kd_flag_error(status, rd.base_index + i);
-                    else if (kd_commit(T, gg)) atomicAdd(&tab[(kd_u64)(KDC_CSW + ch) * S + gg], 1u);
-                }
+                // query bases [q, q + n_adv) land on sites r + (x - q)
+                if (kd_clip_bases(T, seq, q, q + n_adv, (int64_t)cb + r - q, KDC_CSW)) kd_flag_error(status, rd.base_index + i);
                 r += n_adv; q += n_adv;
             }
         }
@@ -784,15 +835,10 @@ k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
 #define KD_HCH_BAD 6u
 #define KD_WINDOW_LDS_BYTES(W) ((size_t)KD_HCH * (W) * 4)
 
-// 16 packed bases-bytes at ANY byte address: gfx950 global loads are unaligned-capable, hipcc emits one
-// global_load_dwordx4 for this type.  Chunk c of a read holds its query bases 32c .. 32c+31.
-struct __attribute__((packed, aligned(1))) KdChunk { uint32_t x, y, z, w; };
-
 // BAM nibble -> LDS channel: A,T,G,C,N -> 0..4, everything else -> KD_HCH_BAD
 __device__ __forceinline__ uint32_t kd_hchan(uint32_t nib) {
     return (uint32_t)((0x4666666166626306ULL >> (nib * 4)) & 7ULL);
 }
-#define KD_NIB_SHIFT(b) (8 * ((b) >> 1) + (((b) & 1) ? 0 : 4))
 
 // all 8 bases of dword v are live; s0 = window-relative site of its first base
 __device__ __forceinline__ void kd_add8_full(uint32_t *hist, uint32_t W, uint32_t v, int32_t s0) {
