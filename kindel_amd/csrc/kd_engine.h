@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -29,7 +30,8 @@ struct KdEngine {
     uint64_t S = 0;  // G-space sites, multiple of 1024 (consensus tile)
     uint64_t g_lo = 0, g_hi = 0;  // emit interval [g_lo, g_hi)
     int mode = KD_MODE_AUTO;
-    uint32_t W = 1024, slice_cfg = 0;
+    uint32_t W = 512, slice_cfg = 0;
+    uint32_t dbg = getenv("KD_DEBUG") ? (uint32_t)atoi(getenv("KD_DEBUG")) : 0u;  // experiments only
 
     uint32_t *d_tab = nullptr, *d_clen = nullptr, *d_seg = nullptr;
     kd_u64 *d_cbase = nullptr, *d_status = nullptr;
@@ -241,7 +243,7 @@ struct KdEngine {
                 return hipfail("k_window");
             if (n_cold &&
                 rt.launch("k_cold_lane", k_cold_lane, (unsigned)((n_cold + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, R, T, I,
-                          (const uint32_t *)cold, (kd_u64)n_cold, d_status))
+                          (const uint32_t *)cold, (kd_u64)n_cold, d_status, dbg))
                 return hipfail("k_cold_lane");
             if (n_irreg &&
                 rt.launch("k_pileup_wave_irreg", k_pileup_wave<true, true>,
@@ -254,7 +256,7 @@ struct KdEngine {
                           (const uint32_t *)nullptr, (kd_u64)n, (const KdRInfo *)rinfo, d_status))
                 return hipfail("k_pileup_wave_all");
         }
-        if (windowed && rt.launch("k_find_bad_base", k_find_bad_base, 1u, KD_BLOCK, 0, R, (const KdRInfo *)rinfo, d_status))
+        if (windowed && rt.launch("k_find_bad_base", k_find_bad_base, 1u, KD_BLOCK, 0, R, T, (const KdRInfo *)rinfo, d_status))
             return hipfail("k_find_bad_base");
         if (rt.launch("k_diagnose", k_diagnose, 1u, KD_WAVE, 0, R, T, d_status)) return hipfail("k_diagnose");
         reads_pushed += n;

@@ -78,7 +78,8 @@ enum {
     KDS_ST_INS,         // insertion ops seen
     KDS_B_INS_OPS,      // per batch: insertion ops
     KDS_B_INS_BASES,    // per batch: insertion bases
-    KDS_B_MAXSPAN,      // per batch: max hot span of regular reads
+    KDS_B_MAXSPAN,      // per batch: max span of regular reads
+    KDS_B_MAXLEAD,      // per batch: max leading-clip reach of regular reads
     KDS_B_UNSORTED,     // per batch: reads not sorted by G-start
     KDS_B_N_COLD,       // per batch: entries in the cold list
     KDS_B_N_IRREG,      // per batch: entries in the irregular list
@@ -116,7 +117,10 @@ struct KdReads {
 
 struct KdRInfo {
     uint32_t gstart;    // contig_base + max(pos0, 0)
-    uint32_t span_cls;  // hot span << KD_SPAN_SHIFT | KD_INFO_INS | KD_INFO_COLD | class
+    uint32_t span_cls;  // span << KD_SPAN_SHIFT | KD_INFO_INS | KD_INFO_COLD | class; span = sites from
+                        // gstart to the end of the last M / D / trailing-S write
+    uint32_t lead;      // sites before gstart written by a leading soft clip (kindel.py:68-72)
+    uint32_t pad;
 };
 
 struct KdIns {
@@ -165,7 +169,7 @@ __device__ __forceinline__ void kd_flag_error(kd_u64 *status, kd_u64 gidx) { ato
 
 // result of scanning one CIGAR
 struct KdScan {
-    uint32_t cls, cold;
+    uint32_t cls, cold, lead;
     kd_u64 span, n_ins, ins_bases, aligned, walked;
 };
 
@@ -174,7 +178,7 @@ struct KdScan {
 // G-space arithmetic and no Python wrap-around or exception can occur (bad bases aside).
 __device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc, int64_t pos0, int64_t sl, int64_t L) {
     KdScan s;
-    s.cls = KD_CLS_REG; s.cold = 0; s.span = 0; s.n_ins = 0; s.ins_bases = 0; s.aligned = 0; s.walked = 0;
+    s.cls = KD_CLS_REG; s.cold = 0; s.lead = 0; s.span = 0; s.n_ins = 0; s.ins_bases = 0; s.aligned = 0; s.walked = 0;
     bool regular = pos0 >= 0;
     bool seen_nfs = false;  // a non-first S was seen: r is no longer plain prefix arithmetic
     int64_t r = pos0, q = 0, hot_hi = pos0;
@@ -201,6 +205,7 @@ __device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc,
             s.walked += (kd_u64)len;
             if (k == 0) {
                 if (r > L || len > sl) regular = false;
+                s.lead = (uint32_t)(len < r ? len : (r > 0 ? r : 0));
                 q += len;
             } else {
                 if (seen_nfs) regular = false;
@@ -208,6 +213,7 @@ __device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc,
                 int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
                 if (n_adv > sl - q || (len > n_adv && q + n_adv >= sl)) regular = false;
                 r += n_adv; q += n_adv;
+                hot_hi = r;  // the clip_start_weights writes extend the read's footprint
             }
         }
     }
@@ -220,7 +226,7 @@ __global__ void __launch_bounds__(KD_BLOCK)
 k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irreg_list, uint32_t *long_list,
        uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
     __shared__ kd_u64 s_red[8];       // reads, aligned, walked, ins_ops, ins_bases, n_reg, unsorted
-    __shared__ uint32_t s_maxspan;
+    __shared__ uint32_t s_maxspan, s_maxlead;
     __shared__ uint32_t s_cnt[3];     // cold, irreg, long (block totals / running offsets)
     __shared__ kd_u64 s_base[5];
     __shared__ kd_u64 s_ins[2];       // insertion events / insertion bases of the block's short-CIGAR reads
@@ -228,11 +234,11 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
     if (t < 8) s_red[t] = 0;
     if (t < 3) s_cnt[t] = 0;
     if (t < 2) s_ins[t] = 0;
-    if (t == 0) s_maxspan = 0;
+    if (t == 0) { s_maxspan = 0; s_maxlead = 0; }
     __syncthreads();
     const kd_u64 chunk0 = (kd_u64)blockIdx.x * KD_PREP_CHUNK;
     kd_u64 a_reads = 0, a_aligned = 0, a_walked = 0, a_ins = 0, a_insb = 0, a_reg = 0, a_unsorted = 0;
-    uint32_t a_maxspan = 0, n_cold = 0, n_irreg = 0, n_long = 0;
+    uint32_t a_maxspan = 0, a_maxlead = 0, n_cold = 0, n_irreg = 0, n_long = 0;
     uint32_t m_cold = 0, m_irreg = 0, m_long = 0, m_ins = 0;  // bit `it` = this thread's it-th read is in the list
     uint32_t c_cached = 0xffffffffu;                             // one-entry cache of the contig table
     kd_u64 cb_cached = 0;
@@ -268,7 +274,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
             }
             const int64_t sl = v_sl[u];
             const uint32_t nc = v_nc[u];
-            uint32_t cls, cold = 0;
+            uint32_t cls, cold = 0, lead = 0;
             kd_u64 span = 0;
             bool has_ins = false;
             if ((v_fl[u] & 4u) || sl <= 1) {
@@ -281,11 +287,15 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
                 a_reads++;
             } else {
                 KdScan s = kd_scan_cigar(rd.cigar + v_coff[u], nc, pos0, sl, L_cached);
-                cls = s.cls; cold = s.cold; span = s.span; has_ins = s.n_ins != 0;
+                cls = s.cls; cold = s.cold; span = s.span; lead = s.lead; has_ins = s.n_ins != 0;
                 a_reads++; a_aligned += s.aligned; a_walked += s.walked; a_ins += s.n_ins; a_insb += s.ins_bases;
             }
             if (span > 0x0fffffffULL) { cls = KD_CLS_IRREG; span = 0; }
-            if (cls == KD_CLS_REG) { a_reg++; if ((uint32_t)span > a_maxspan) a_maxspan = (uint32_t)span; }
+            if (cls == KD_CLS_REG) {
+                a_reg++;
+                if ((uint32_t)span > a_maxspan) a_maxspan = (uint32_t)span;
+                if (lead > a_maxlead) a_maxlead = lead;
+            }
             if (cls == KD_CLS_REG && cold) { n_cold++; m_cold |= 1u << it; }
             if (cls == KD_CLS_IRREG) { n_irreg++; m_irreg |= 1u << it; }
             if (cls == KD_CLS_LONG) { n_long++; m_long |= 1u << it; }
@@ -293,6 +303,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
             KdRInfo ri;
             ri.gstart = (uint32_t)gkey;
             ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | (has_ins ? KD_INFO_INS : 0u) | cold | cls;
+            ri.lead = lead; ri.pad = 0;
             rinfo[i] = ri;
         }
     }
@@ -305,6 +316,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
     if (a_reg) atomicAdd(&s_red[5], a_reg);
     if (a_unsorted) atomicAdd(&s_red[6], a_unsorted);
     if (a_maxspan) atomicMax(&s_maxspan, a_maxspan);
+    if (a_maxlead) atomicMax(&s_maxlead, a_maxlead);
     // list slots: thread-local offset inside the block
     uint32_t o_cold = n_cold ? atomicAdd(&s_cnt[0], n_cold) : 0;
     uint32_t o_irreg = n_irreg ? atomicAdd(&s_cnt[1], n_irreg) : 0;
@@ -325,6 +337,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
         if (s_red[5]) atomicAdd(&status[KDS_B_N_REG], s_red[5]);
         if (s_red[6]) atomicAdd(&status[KDS_B_UNSORTED], s_red[6]);
         if (s_maxspan) atomicMax(&status[KDS_B_MAXSPAN], (kd_u64)s_maxspan);
+        if (s_maxlead) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)s_maxlead);
         s_base[0] = s_cnt[0] ? atomicAdd(&status[KDS_B_N_COLD], (kd_u64)s_cnt[0]) : 0;
         s_base[1] = s_cnt[1] ? atomicAdd(&status[KDS_B_N_IRREG], (kd_u64)s_cnt[1]) : 0;
         s_base[2] = s_cnt[2] ? atomicAdd(&status[KDS_B_N_LONG], (kd_u64)s_cnt[2]) : 0;
@@ -437,12 +450,22 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
         bool regular = pos0 >= 0 && s_acc[4] == 0;
         // a non-first S must be the last op that touches r (M, I, D or S)
         if (s_first_nfs != 0xffffffffu && s_last_rel > s_first_nfs) regular = false;
-        kd_u64 span = r_end > pos0 ? (kd_u64)(r_end - pos0) : 0;
+        int64_t foot_end = r_end;
+        uint32_t lead = 0;
+        if (regular) {
+            if ((cg[0] & 15u) == 4u) { const int64_t l0 = cg[0] >> 4; lead = (uint32_t)(l0 < pos0 ? l0 : pos0); }
+            if (s_first_nfs != 0xffffffffu) {  // trailing clip: r at that op is r_end (nothing after it moves r)
+                const int64_t ls = cg[s_first_nfs] >> 4;
+                foot_end += r_end < L ? (ls < L - r_end ? ls : L - r_end) : 0;
+            }
+        }
+        kd_u64 span = foot_end > pos0 ? (kd_u64)(foot_end - pos0) : 0;
         if (span > 0x0fffffffULL) { regular = false; span = 0; }
         const uint32_t coldbit = s_acc[5] ? KD_INFO_COLD : 0u;
         KdRInfo ri = rinfo[i];
         ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | (s_acc[2] ? KD_INFO_INS : 0u) | coldbit |
                       (regular ? KD_CLS_REG : KD_CLS_IRREG);
+        ri.lead = regular ? lead : 0u;
         rinfo[i] = ri;
         if (s_acc[2]) {
             read_ev[i] = (uint32_t)atomicAdd(&status[KDS_N_EV], s_acc[2]);
@@ -455,6 +478,7 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
         if (regular) {
             atomicAdd(&status[KDS_B_N_REG], 1ULL);
             atomicMax(&status[KDS_B_MAXSPAN], span);
+            if (lead) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)lead);
             if (coldbit) cold_list[atomicAdd(&status[KDS_B_N_COLD], 1ULL)] = (uint32_t)i;
         } else {
             irreg_list[atomicAdd(&status[KDS_B_N_IRREG], 1ULL)] = (uint32_t)i;
@@ -628,7 +652,7 @@ __device__ __forceinline__ bool kd_clip_bases(const KdTabs &T, const uint8_t *se
 // G-space arithmetic: clip tallies go to HBM with 32-bit atomics (they are ~1 % of all events and land
 // on scattered sites), insertion events into the slots k_prep reserved for the read.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list, kd_u64 *status) {
+k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list, kd_u64 *status, uint32_t dbg) {
     const kd_u64 slot = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
     if (slot >= n_list) return;
     const kd_u64 i = list[slot];
@@ -673,7 +697,7 @@ k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list
                 if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g], 1u);
                 // query bases [xa, len) land on sites r - len + x  (those with r - len + x >= 0)
                 const int64_t xa = r < len ? len - r : 0;
-                if (kd_clip_bases(T, seq, xa, len, (int64_t)cb + r - len, KDC_CEW)) kd_flag_error(status, rd.base_index + i);
+                (void)xa;  // clip_end_weights are tallied by k_window (LDS)
                 q += len;
             } else {  // kindel.py:74-81; regular: the last op that touches r
                 const int64_t x = r - 1;
@@ -681,7 +705,7 @@ k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list
                 if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
                 const int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
                 // query bases [q, q + n_adv) land on sites r + (x - q)
-                if (kd_clip_bases(T, seq, q, q + n_adv, (int64_t)cb + r - q, KDC_CSW)) kd_flag_error(status, rd.base_index + i);
+                // clip_start_weights are tallied by k_window (LDS)
                 r += n_adv; q += n_adv;
             }
         }
@@ -781,7 +805,7 @@ k_plan_ranges(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t n_win, uint32_t W, 
     const kd_u64 maxspan = status[KDS_B_MAXSPAN];
     const kd_u64 wlo = (kd_u64)w * W, whi = wlo + W;
     const kd_u64 lo = kd_lower_bound(rinfo, n_reads, wlo > maxspan ? wlo - maxspan : 0);
-    const kd_u64 hi = kd_lower_bound(rinfo, n_reads, whi);
+    const kd_u64 hi = kd_lower_bound(rinfo, n_reads, whi + status[KDS_B_MAXLEAD]);  // leading clips reach back
     win_lo[w] = lo; win_hi[w] = hi;
     item_off[w] = (hi - lo + slice - 1) / slice;  // item count; k_plan_scan turns it into an offset
 }
@@ -815,9 +839,11 @@ k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
 
 // k_window: persistent workgroups pull (window, slice) work items.
 //
-// LDS (dynamic): u32 hist[7][W], channel-major: channels 0-4 = A,T,G,C,N, 5 = deletions, 6 = bases
-// outside A,C,G,T,N (checked at flush; KeyError in the reference).  28 B per site, so W = 1024 lets
-// five workgroups (20 wavefronts) share a CU's 160 KB.
+// LDS (dynamic): u32 hist[19][W], channel-major, three groups of {A,T,G,C,N, bad}: weights (0-5),
+// clip_start_weights (7-12), clip_end_weights (13-18), plus deletions (6).  "bad" collects bases
+// outside A,C,G,T,N (KeyError in the reference; checked at flush).  76 B per site: W = 512 lets four
+// workgroups (16 wavefronts) share a CU's 160 KB.  Soft clips are tallied here too because 4 x 10^7
+// scattered device-scope atomics cost more than the whole LDS pass (measured: 1.4 ms vs 1.5 ms).
 //
 // One LANE per read; thread t owns a contiguous run of the item's reads, so the 64 lanes of a
 // wavefront sit ~16 reads apart in the coordinate-sorted batch and rarely hit the same site in the
@@ -831,13 +857,15 @@ k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
 // Reads whose bases do not fit six chunks (long reads: thousands of short ops) are walked op by op
 // with dword loads straight from HBM/L2, same arithmetic.
 // Only REGULAR reads are handled here; their S/I side effects are done by k_cold_lane.
-#define KD_HCH 7
-#define KD_HCH_BAD 6u
+#define KD_HCH 19
+#define KD_HCH_DEL 6u
+#define KD_HCH_CSW 7u
+#define KD_HCH_CEW 13u
 #define KD_WINDOW_LDS_BYTES(W) ((size_t)KD_HCH * (W) * 4)
 
-// BAM nibble -> LDS channel: A,T,G,C,N -> 0..4, everything else -> KD_HCH_BAD
+// BAM nibble -> channel inside a group: A,T,G,C,N -> 0..4, everything else -> 5 (the group's bad slot)
 __device__ __forceinline__ uint32_t kd_hchan(uint32_t nib) {
-    return (uint32_t)((0x4666666166626306ULL >> (nib * 4)) & 7ULL);
+    return (uint32_t)((0x4555555155525305ULL >> (nib * 4)) & 7ULL);
 }
 
 // all 8 bases of dword v are live; s0 = window-relative site of its first base
@@ -895,10 +923,12 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
             if (i >= last) continue;
             const KdRInfo ri = rinfo[i];
             const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
-            if ((ri.span_cls & 3u) != KD_CLS_REG || gs + span <= wlo || gs >= whi) continue;
+            if ((ri.span_cls & 3u) != KD_CLS_REG || gs + span <= wlo || gs - ri.lead >= whi) continue;
             const uint32_t nc = rd.n_cig[i];
             const kd_u64 soff = rd.seq_off[i];
             const uint32_t *cg = rd.cigar + rd.cig_off[i];
+            const int32_t lead = (int32_t)ri.lead;
+            const int32_t foot_end = (int32_t)((uint32_t)(gs + span) - (uint32_t)wlo);  // window-relative end of the footprint
             const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + soff);
             int32_t grel = (int32_t)((uint32_t)gs - (uint32_t)wlo);  // window-relative site, may be negative
             int32_t q = 0;
@@ -923,13 +953,31 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
                         if (grel >= Wi) k = nc;
                     } else if (op == 2) {
                         for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
-                            atomicAdd(&hist[5u * W + (uint32_t)(grel + j)], 1u);
+                            atomicAdd(&hist[KD_HCH_DEL * W + (uint32_t)(grel + j)], 1u);
                         grel += len;
                         if (grel >= Wi) k = nc;
                     } else if (op == 1) {
                         q += len;
                     } else if (op == 4) {
-                        if (k == 1) q += len; else k = nc;  // regular: nothing after a non-first S touches r
+                        if (k == 1) {
+                            // leading clip, kindel.py:64-73: base x -> site r - len + x, kept if >= contig start
+                            // (`lead` of the len bases); a run on the clip_end_weights channels
+                            const int32_t s_first = grel - len;           // site of base 0
+                            xa = len - lead; if (-s_first > xa) xa = -s_first;
+                            xb = Wi - s_first < len ? Wi - s_first : len;
+                            sx = s_first + (int32_t)(KD_HCH_CEW * W);
+                            if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                            q += len;
+                        } else {
+                            // non-first clip, kindel.py:74-81: bases q.. -> sites r.. while r < L; for a regular
+                            // read it is the last op that moves r, so its reach is the end of the footprint
+                            const int32_t n_adv = foot_end - grel;
+                            xa = grel < 0 ? q - grel : q;
+                            xb = Wi - grel < n_adv ? q + (Wi - grel) : q + n_adv;
+                            sx = grel - q + (int32_t)(KD_HCH_CSW * W);
+                            if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                            k = nc;
+                        }
                     }
                 }
                 if (c > cb) break;
@@ -943,18 +991,21 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
             }
         }
         __syncthreads();
-        // flush: channel-major, consecutive lanes -> consecutive HBM dwords; zeros are skipped
-        for (uint32_t x = t; x < 6u * W; x += KD_BLOCK) {
+        // flush: channel-major, consecutive lanes -> consecutive HBM dwords; zeros are skipped.
+        // LDS channel -> table channel (KD_CH_*): weights 0-4, deletions 5, csw 6-10, cew 11-15; 0xff = bad slot
+        bool bad = false;
+        for (uint32_t x = t; x < nh; x += KD_BLOCK) {
             const uint32_t v = hist[x];
             if (v) {
                 const uint32_t ch = x / W;
+                const uint32_t tch = ch < 5 ? ch : ch == KD_HCH_DEL ? (uint32_t)KDC_DEL
+                                   : (ch >= 7 && ch < 12) ? ch - 1 : (ch >= 13 && ch < 18) ? ch - 2 : 0xffu;
                 const kd_u64 g = wlo + (x - ch * W);
-                if (g < T.stride && kd_commit(T, g)) atomicAdd(&T.tab[(kd_u64)ch * T.stride + g], v);
+                if (tch == 0xffu) bad = true;
+                else if (g < T.stride && kd_commit(T, g)) atomicAdd(&T.tab[(kd_u64)tch * T.stride + g], v);
             }
         }
-        // a base outside A,C,G,T,N inside an aligned segment: k_find_bad_base pins down the read
-        bool bad = false;
-        for (uint32_t x = KD_HCH_BAD * W + t; x < (KD_HCH_BAD + 1u) * W; x += KD_BLOCK) bad |= hist[x] != 0;
+        // a base outside A,C,G,T,N inside an aligned or clipped segment: k_find_bad_base pins down the read
         if (bad) atomicAdd(&status[KDS_BAD_BASE], 1ULL);
         __syncthreads();
     }
@@ -963,7 +1014,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
 // Rare path: k_window saw a base outside A,C,G,T,N.  One workgroup walks the regular reads of the
 // batch and records the first offender (atomicMin of the read index), for k_diagnose to classify.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_find_bad_base(KdReads rd, const KdRInfo *rinfo, kd_u64 *status) {
+k_find_bad_base(KdReads rd, KdTabs T, const KdRInfo *rinfo, kd_u64 *status) {
     if (status[KDS_BAD_BASE] == 0) return;
     for (kd_u64 i = threadIdx.x; i < rd.n; i += KD_BLOCK) {
         if ((rinfo[i].span_cls & 3u) != KD_CLS_REG) continue;
@@ -971,17 +1022,22 @@ k_find_bad_base(KdReads rd, const KdRInfo *rinfo, kd_u64 *status) {
         const uint8_t *seq = rd.seq4 + rd.seq_off[i];
         const uint32_t *cg = rd.cigar + rd.cig_off[i];
         const uint32_t nc = rd.n_cig[i];
-        int64_t q = 0;
+        const int64_t L = T.contig_len[rd.contig[i]];
+        int64_t q = 0, r = rd.pos0[i];
         bool found = false;
         for (uint32_t k = 0; k < nc && !found; k++) {
             const int64_t len = cg[k] >> 4;
             const uint32_t op = cg[k] & 15u;
-            if (op == 0 || op == 7 || op == 8) {
-                for (int64_t j = 0; j < len; j++)
-                    if (kd_chan(kd_nib(seq, q + j)) == 7u) { found = true; break; }
-                q += len;
-            } else if (op == 1) q += len;
-            else if (op == 4) { if (k == 0) q += len; else break; }
+            int64_t x0 = 0, x1 = 0;  // query bases the reference looks up in a weight dict
+            if (op == 0 || op == 7 || op == 8) { x0 = q; x1 = q + len; q += len; r += len; }
+            else if (op == 1) q += len;
+            else if (op == 2) r += len;
+            else if (op == 4) {
+                if (k == 0) { x0 = r < len ? len - r : 0; x1 = len; q += len; }
+                else { const int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0; x0 = q; x1 = q + n_adv; k = nc; }
+            }
+            for (int64_t x = x0; x < x1; x++)
+                if (kd_chan(kd_nib(seq, x)) == 7u) { found = true; break; }
         }
         if (found) kd_flag_error(status, rd.base_index + i);
     }
