@@ -874,19 +874,29 @@ __device__ __forceinline__ void kd_add8_full(uint32_t *hist, uint32_t W, uint32_
 #pragma unroll
     for (int b = 0; b < 8; b++) atomicAdd(&h[kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u) * W + b], 1u);
 }
-// only bases [blo, bhi) are live
-__device__ __forceinline__ void kd_add8_part(uint32_t *hist, uint32_t W, uint32_t v, int32_t s0, int32_t blo, int32_t bhi) {
+// only bases [blo, bhi) are live; bases below g1 belong to the clip_end_weights group, bases from g2 on to the
+// clip_start_weights group (offsets relative to the dword, may lie outside 0..8)
+__device__ __forceinline__ void kd_add8_part(uint32_t *hist, uint32_t W, uint32_t v, int32_t s0, int32_t blo, int32_t bhi,
+                                             int32_t g1, int32_t g2) {
 #pragma unroll
     for (int b = 0; b < 8; b++)
-        if (b >= blo && b < bhi) atomicAdd(&hist[kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u) * W + (uint32_t)(s0 + b)], 1u);
+        if (b >= blo && b < bhi) {
+            const uint32_t grp = b < g1 ? KD_HCH_CEW : (b >= g2 ? KD_HCH_CSW : 0u);
+            atomicAdd(&hist[(grp + kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u)) * W + (uint32_t)(s0 + b)], 1u);
+        }
 }
-// one memory dword against the live query range [xa, xb): xs = query index of the dword's first base,
-// sx = window-relative site of query base 0 of this run (site of base x is sx + x)
+// One dword of a run: xs = query index of its first base; [xa, xb) live query range; site of query base x is
+// sx + x; bases < xg1 are a leading soft clip (clip_end_weights), bases >= xg2 a trailing one
+// (clip_start_weights), the rest aligned (weights).  A dword that lies inside ONE group takes the
+// unmasked path with the group's channel offset folded into the site offset.
 __device__ __forceinline__ void kd_add_dword(uint32_t *hist, uint32_t W, uint32_t v, int32_t xs, int32_t xa, int32_t xb,
-                                             int32_t sx) {
+                                             int32_t sx, int32_t xg1, int32_t xg2) {
     if (xs + 8 <= xa || xs >= xb) return;
-    if (xs >= xa && xs + 8 <= xb) kd_add8_full(hist, W, v, sx + xs);
-    else kd_add8_part(hist, W, v, sx + xs, xa - xs, xb - xs);
+    const bool live8 = xs >= xa && xs + 8 <= xb;
+    if (live8 && xs >= xg1 && xs + 8 <= xg2) kd_add8_full(hist, W, v, sx + xs);
+    else if (live8 && xs + 8 <= xg1) kd_add8_full(hist, W, v, sx + xs + (int32_t)(KD_HCH_CEW * W));
+    else if (live8 && xs >= xg2) kd_add8_full(hist, W, v, sx + xs + (int32_t)(KD_HCH_CSW * W));
+    else kd_add8_part(hist, W, v, sx + xs, xa - xs, xb - xs, xg1 - xs, xg2 - xs);
 }
 
 __global__ void __launch_bounds__(KD_BLOCK)
@@ -936,7 +946,8 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
             // current M run), not over CIGAR ops: lanes whose reads have clips or indels still add
             // bases in the same wavefront instructions as their single-run neighbours.
             uint32_t k = 0;
-            int32_t xa = 0, xb = 0, sx = 0, c = 1, cb = 0;   // c > cb: no live run
+            int32_t xa = 0, xb = 0, sx = 0, xg1 = 0, xg2 = 0, c = 1, cb = 0;   // c > cb: no live run
+            int32_t pend_lo = -1;   // >= 0: a leading clip waits to be merged into the run of the next op
             for (;;) {
                 while (c > cb && k < nc) {   // advance to the next run with live bases
                     const uint32_t cw = cg[k];
@@ -944,49 +955,66 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
                     const uint32_t op = cw & 15u;
                     k++;
                     if (op == 0 || op == 7 || op == 8) {
-                        // live query range: inside the run and inside the window
-                        xa = grel < 0 ? q - grel : q;
-                        xb = Wi - grel < len ? q + (Wi - grel) : q + len;
-                        sx = grel - q;                      // site of query base x is sx + x
-                        if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                        // query bases [x_lo, x_hi) of this run land on sites sx + x
+                        int32_t x_lo = q, x_hi = q + len;
+                        sx = grel - q;
+                        xg1 = q; xg2 = x_hi;
+                        if (pend_lo >= 0) { x_lo = pend_lo; pend_lo = -1; }   // leading clip: same site formula
                         q += len; grel += len;
+                        if (k < nc && (cg[k] & 15u) == 4u) {
+                            // trailing clip, kindel.py:74-81: its bases continue on the next sites while r < L;
+                            // for a regular read it is the last op that moves r: reach = end of the footprint
+                            x_hi += foot_end - grel;
+                            k = nc;
+                        }
+                        xa = -sx > x_lo ? -sx : x_lo;                     // inside the window
+                        xb = Wi - sx < x_hi ? Wi - sx : x_hi;
+                        if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
                         if (grel >= Wi) k = nc;
                     } else if (op == 2) {
+                        pend_lo = -1;
                         for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
                             atomicAdd(&hist[KD_HCH_DEL * W + (uint32_t)(grel + j)], 1u);
                         grel += len;
                         if (grel >= Wi) k = nc;
                     } else if (op == 1) {
-                        q += len;
+                        q += len;   // (a pending leading clip stays adjacent in site space: I does not move r)
                     } else if (op == 4) {
                         if (k == 1) {
                             // leading clip, kindel.py:64-73: base x -> site r - len + x, kept if >= contig start
-                            // (`lead` of the len bases); a run on the clip_end_weights channels
-                            const int32_t s_first = grel - len;           // site of base 0
-                            xa = len - lead; if (-s_first > xa) xa = -s_first;
-                            xb = Wi - s_first < len ? Wi - s_first : len;
-                            sx = s_first + (int32_t)(KD_HCH_CEW * W);
-                            if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                            // (`lead` of the len bases).  Same site formula as the run that follows (sx = grel - q).
                             q += len;
+                            if (k < nc && ((cg[k] & 15u) == 0u || (cg[k] & 15u) == 7u || (cg[k] & 15u) == 8u)) {
+                                pend_lo = len - lead;
+                            } else {   // not followed by an aligned run: a run of its own
+                                sx = grel - q;
+                                xg1 = q; xg2 = q;                          // every base is in the clip_end group
+                                const int32_t x_lo = len - lead;
+                                xa = -sx > x_lo ? -sx : x_lo;
+                                xb = Wi - sx < q ? Wi - sx : q;
+                                if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                            }
                         } else {
-                            // non-first clip, kindel.py:74-81: bases q.. -> sites r.. while r < L; for a regular
-                            // read it is the last op that moves r, so its reach is the end of the footprint
-                            const int32_t n_adv = foot_end - grel;
-                            xa = grel < 0 ? q - grel : q;
-                            xb = Wi - grel < n_adv ? q + (Wi - grel) : q + n_adv;
-                            sx = grel - q + (int32_t)(KD_HCH_CSW * W);
+                            // non-first clip not merged above (previous op was not an aligned run)
+                            sx = grel - q;
+                            xg1 = q; xg2 = q;                              // every base is in the clip_start group
+                            const int32_t x_hi = q + (foot_end - grel);
+                            xa = -sx > q ? -sx : q;
+                            xb = Wi - sx < x_hi ? Wi - sx : x_hi;
                             if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
                             k = nc;
                         }
+                    } else {
+                        // N, H, P: no effect (kindel.py:49-81 has no branch)
                     }
                 }
                 if (c > cb) break;
                 const KdChunk cur = src[c];
                 const int32_t xs = 32 * c;
-                kd_add_dword(hist, W, cur.x, xs, xa, xb, sx);
-                kd_add_dword(hist, W, cur.y, xs + 8, xa, xb, sx);
-                kd_add_dword(hist, W, cur.z, xs + 16, xa, xb, sx);
-                kd_add_dword(hist, W, cur.w, xs + 24, xa, xb, sx);
+                kd_add_dword(hist, W, cur.x, xs, xa, xb, sx, xg1, xg2);
+                kd_add_dword(hist, W, cur.y, xs + 8, xa, xb, sx, xg1, xg2);
+                kd_add_dword(hist, W, cur.z, xs + 16, xa, xb, sx, xg1, xg2);
+                kd_add_dword(hist, W, cur.w, xs + 24, xa, xb, sx, xg1, xg2);
                 c++;
             }
         }
