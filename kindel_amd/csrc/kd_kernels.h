@@ -63,7 +63,8 @@ typedef unsigned long long kd_u64;
 #define KD_CLS_LONG 3u    // transient: CIGAR too long for the per-lane scan, k_prep_long decides
 #define KD_INFO_COLD 4u   // read has S or I ops (soft-clip tables / insertion events)
 #define KD_INFO_INS 8u    // read has I ops: k_prep reserved its insertion-event / pool slots
-#define KD_SPAN_SHIFT 4
+#define KD_INFO_PLAIN 16u // regular read that is ONE M/=/X run covering the whole read (no clips, no indels)
+#define KD_SPAN_SHIFT 5
 #define KD_EV_DROPPED 0xffffffffu  // reserved insertion-event slot whose site belongs to another shard
 
 // device status words (kd_u64 each)
@@ -275,7 +276,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
             const int64_t sl = v_sl[u];
             const uint32_t nc = v_nc[u];
             uint32_t cls, cold = 0, lead = 0;
-            kd_u64 span = 0;
+            kd_u64 span = 0, al = 0;
             bool has_ins = false;
             if ((v_fl[u] & 4u) || sl <= 1) {
                 cls = KD_CLS_SKIP;
@@ -287,10 +288,10 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
                 a_reads++;
             } else {
                 KdScan s = kd_scan_cigar(rd.cigar + v_coff[u], nc, pos0, sl, L_cached);
-                cls = s.cls; cold = s.cold; span = s.span; lead = s.lead; has_ins = s.n_ins != 0;
+                cls = s.cls; cold = s.cold; span = s.span; lead = s.lead; has_ins = s.n_ins != 0; al = s.aligned;
                 a_reads++; a_aligned += s.aligned; a_walked += s.walked; a_ins += s.n_ins; a_insb += s.ins_bases;
             }
-            if (span > 0x0fffffffULL) { cls = KD_CLS_IRREG; span = 0; }
+            if (span > 0x07ffffffULL) { cls = KD_CLS_IRREG; span = 0; }
             if (cls == KD_CLS_REG) {
                 a_reg++;
                 if ((uint32_t)span > a_maxspan) a_maxspan = (uint32_t)span;
@@ -302,7 +303,9 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
             if (has_ins) m_ins |= 1u << it;
             KdRInfo ri;
             ri.gstart = (uint32_t)gkey;
-            ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | (has_ins ? KD_INFO_INS : 0u) | cold | cls;
+            // plain: the whole read is ONE aligned run: a single op whose aligned length is the read length
+            const uint32_t plain = (cls == KD_CLS_REG && nc == 1 && !cold && al == (kd_u64)sl && span == al) ? KD_INFO_PLAIN : 0u;
+            ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | plain | (has_ins ? KD_INFO_INS : 0u) | cold | cls;
             ri.lead = lead; ri.pad = 0;
             rinfo[i] = ri;
         }
@@ -460,7 +463,7 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
             }
         }
         kd_u64 span = foot_end > pos0 ? (kd_u64)(foot_end - pos0) : 0;
-        if (span > 0x0fffffffULL) { regular = false; span = 0; }
+        if (span > 0x07ffffffULL) { regular = false; span = 0; }
         const uint32_t coldbit = s_acc[5] ? KD_INFO_COLD : 0u;
         KdRInfo ri = rinfo[i];
         ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | (s_acc[2] ? KD_INFO_INS : 0u) | coldbit |
@@ -861,7 +864,6 @@ k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
 #define KD_HCH_DEL 6u
 #define KD_HCH_CSW 7u
 #define KD_HCH_CEW 13u
-#define KD_WINDOW_LDS_BYTES(W) ((size_t)KD_HCH * (W) * 4)
 
 // BAM nibble -> channel inside a group: A,T,G,C,N -> 0..4, everything else -> 5 (the group's bad slot)
 __device__ __forceinline__ uint32_t kd_hchan(uint32_t nib) {
@@ -874,37 +876,128 @@ __device__ __forceinline__ void kd_add8_full(uint32_t *hist, uint32_t W, uint32_
 #pragma unroll
     for (int b = 0; b < 8; b++) atomicAdd(&h[kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u) * W + b], 1u);
 }
-// only bases [blo, bhi) are live; bases below g1 belong to the clip_end_weights group, bases from g2 on to the
-// clip_start_weights group (offsets relative to the dword, may lie outside 0..8)
-__device__ __forceinline__ void kd_add8_part(uint32_t *hist, uint32_t W, uint32_t v, int32_t s0, int32_t blo, int32_t bhi,
-                                             int32_t g1, int32_t g2) {
+// only bases [blo, bhi) are live
+__device__ __forceinline__ void kd_add8_part(uint32_t *hist, uint32_t W, uint32_t v, int32_t s0, int32_t blo, int32_t bhi) {
 #pragma unroll
     for (int b = 0; b < 8; b++)
-        if (b >= blo && b < bhi) {
-            const uint32_t grp = b < g1 ? KD_HCH_CEW : (b >= g2 ? KD_HCH_CSW : 0u);
-            atomicAdd(&hist[(grp + kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u)) * W + (uint32_t)(s0 + b)], 1u);
-        }
+        if (b >= blo && b < bhi) atomicAdd(&hist[kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u) * W + (uint32_t)(s0 + b)], 1u);
 }
-// One dword of a run: xs = query index of its first base; [xa, xb) live query range; site of query base x is
-// sx + x; bases < xg1 are a leading soft clip (clip_end_weights), bases >= xg2 a trailing one
-// (clip_start_weights), the rest aligned (weights).  A dword that lies inside ONE group takes the
-// unmasked path with the group's channel offset folded into the site offset.
+// one memory dword against the live query range [xa, xb): xs = query index of the dword's first base,
+// sx = window-relative site of query base 0 of this run (site of base x is sx + x)
 __device__ __forceinline__ void kd_add_dword(uint32_t *hist, uint32_t W, uint32_t v, int32_t xs, int32_t xa, int32_t xb,
-                                             int32_t sx, int32_t xg1, int32_t xg2) {
+                                             int32_t sx) {
     if (xs + 8 <= xa || xs >= xb) return;
-    const bool live8 = xs >= xa && xs + 8 <= xb;
-    if (live8 && xs >= xg1 && xs + 8 <= xg2) kd_add8_full(hist, W, v, sx + xs);
-    else if (live8 && xs + 8 <= xg1) kd_add8_full(hist, W, v, sx + xs + (int32_t)(KD_HCH_CEW * W));
-    else if (live8 && xs >= xg2) kd_add8_full(hist, W, v, sx + xs + (int32_t)(KD_HCH_CSW * W));
-    else kd_add8_part(hist, W, v, sx + xs, xa - xs, xb - xs, xg1 - xs, xg2 - xs);
+    if (xs >= xa && xs + 8 <= xb) kd_add8_full(hist, W, v, sx + xs);
+    else kd_add8_part(hist, W, v, sx + xs, xa - xs, xb - xs);
 }
+
+// General per-lane walk of one regular read against the window (reads with clips, indels, long CIGARs).
+// A state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the current run), not over
+// CIGAR ops, so that lanes keep adding bases together whatever their op structure.  A soft clip is a
+// run of its own on the clip_start / clip_end channel group.
+__device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi,
+                                                uint32_t W, uint32_t *hist) {
+    const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
+    const uint32_t nc = rd.n_cig[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    const int32_t lead = (int32_t)ri.lead;
+    const int32_t foot_end = (int32_t)((uint32_t)(gs + span) - (uint32_t)wlo);  // window-relative end of the footprint
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
+    int32_t grel = (int32_t)((uint32_t)gs - (uint32_t)wlo);  // window-relative site, may be negative
+    int32_t q = 0;
+    // Per-lane state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the
+    // current M run), not over CIGAR ops: lanes whose reads have clips or indels still add
+    // bases in the same wavefront instructions as their single-run neighbours.
+    uint32_t k = 0;
+    int32_t xa = 0, xb = 0, sx = 0, c = 1, cb = 0;   // c > cb: no live run
+    for (;;) {
+        while (c > cb && k < nc) {   // advance to the next run with live bases
+            const uint32_t cw = cg[k];
+            const int32_t len = (int32_t)(cw >> 4);
+            const uint32_t op = cw & 15u;
+            k++;
+            if (op == 0 || op == 7 || op == 8) {
+                // live query range: inside the run and inside the window
+                xa = grel < 0 ? q - grel : q;
+                xb = Wi - grel < len ? q + (Wi - grel) : q + len;
+                sx = grel - q;                      // site of query base x is sx + x
+                if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                q += len; grel += len;
+                if (grel >= Wi) k = nc;
+            } else if (op == 2) {
+                for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
+                    atomicAdd(&hist[KD_HCH_DEL * W + (uint32_t)(grel + j)], 1u);
+                grel += len;
+                if (grel >= Wi) k = nc;
+            } else if (op == 1) {
+                q += len;
+            } else if (op == 4) {
+                if (k == 1) {
+                    // leading clip, kindel.py:64-73: base x -> site r - len + x, kept if >= contig start
+                    // (`lead` of the len bases); a run on the clip_end_weights channels
+                    const int32_t s_first = grel - len;           // site of base 0
+                    xa = len - lead; if (-s_first > xa) xa = -s_first;
+                    xb = Wi - s_first < len ? Wi - s_first : len;
+                    sx = s_first + (int32_t)(KD_HCH_CEW * W);
+                    if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                    q += len;
+                } else {
+                    // non-first clip, kindel.py:74-81: bases q.. -> sites r.. while r < L; for a regular
+                    // read it is the last op that moves r, so its reach is the end of the footprint
+                    const int32_t n_adv = foot_end - grel;
+                    xa = grel < 0 ? q - grel : q;
+                    xb = Wi - grel < n_adv ? q + (Wi - grel) : q + n_adv;
+                    sx = grel - q + (int32_t)(KD_HCH_CSW * W);
+                    if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                    k = nc;
+                }
+            }
+        }
+        if (c > cb) break;
+        const KdChunk cur = src[c];
+        const int32_t xs = 32 * c;
+        kd_add_dword(hist, W, cur.x, xs, xa, xb, sx);
+        kd_add_dword(hist, W, cur.y, xs + 8, xa, xb, sx);
+        kd_add_dword(hist, W, cur.z, xs + 16, xa, xb, sx);
+        kd_add_dword(hist, W, cur.w, xs + 24, xa, xb, sx);
+        c++;
+    }
+}
+
+// A PLAIN read: one M/=/X run covering the whole read, no clips (k_prep: KD_INFO_PLAIN).  Nothing to decode:
+// query base x lands on site grel + x, for x in [0, span).
+__device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi,
+                                              uint32_t W, uint32_t *hist) {
+    const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);
+    const int32_t len = (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
+    const int32_t xa = grel < 0 ? -grel : 0;
+    const int32_t xb = Wi - grel < len ? Wi - grel : len;
+    if (xb <= xa) return;
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
+    const int32_t cb = (xb - 1) >> 5;
+    for (int32_t c = xa >> 5; c <= cb; c++) {
+        const KdChunk cur = src[c];
+        const int32_t xs = 32 * c;
+        kd_add_dword(hist, W, cur.x, xs, xa, xb, grel);
+        kd_add_dword(hist, W, cur.y, xs + 8, xa, xb, grel);
+        kd_add_dword(hist, W, cur.z, xs + 16, xa, xb, grel);
+        kd_add_dword(hist, W, cur.w, xs + 24, xa, xb, grel);
+    }
+}
+
+#define KD_TILE 1024   // reads classified together; 4 per thread
+#define KD_WINDOW_LDS_BYTES(W) ((size_t)KD_HCH * (W) * 4 + (size_t)2 * KD_TILE * 2)
 
 __global__ void __launch_bounds__(KD_BLOCK)
 k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
          const kd_u64 *item_off, uint32_t n_win, uint32_t W, uint32_t slice, kd_u64 *status) {
     KD_DYN_SHARED(uint32_t, hist);
+    uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * W);  // tile-relative read indices
+    uint16_t *l_cplx = l_plain + KD_TILE;
     __shared__ kd_u64 s_item;
+    __shared__ uint32_t s_np, s_nc;
     const uint32_t t = threadIdx.x;
+    const uint32_t lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
     const kd_u64 total = status[KDS_TOTAL_ITEMS];
     const uint32_t nh = (uint32_t)KD_HCH * W;
     const int32_t Wi = (int32_t)W;
@@ -924,101 +1017,43 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
         const kd_u64 first = win_lo[w] + (item - item_off[w]) * slice;
         const kd_u64 last = first + slice < win_hi[w] ? first + slice : win_hi[w];
         for (uint32_t x = t; x < nh; x += KD_BLOCK) hist[x] = 0;
-        __syncthreads();
-        // tiles of 256 consecutive reads; lane l of wavefront v takes read 4*l + v of the tile: the four
-        // wavefronts sweep the same cache lines together, the lanes of one wavefront sit 4 reads apart
-        const uint32_t lane4 = 4u * (t & (KD_WAVE - 1)) + (t / KD_WAVE);
-        for (kd_u64 tb = first; tb < last; tb += KD_BLOCK) {
-            const kd_u64 i = tb + lane4;
-            if (i >= last) continue;
-            const KdRInfo ri = rinfo[i];
-            const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
-            if ((ri.span_cls & 3u) != KD_CLS_REG || gs + span <= wlo || gs - ri.lead >= whi) continue;
-            const uint32_t nc = rd.n_cig[i];
-            const kd_u64 soff = rd.seq_off[i];
-            const uint32_t *cg = rd.cigar + rd.cig_off[i];
-            const int32_t lead = (int32_t)ri.lead;
-            const int32_t foot_end = (int32_t)((uint32_t)(gs + span) - (uint32_t)wlo);  // window-relative end of the footprint
-            const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + soff);
-            int32_t grel = (int32_t)((uint32_t)gs - (uint32_t)wlo);  // window-relative site, may be negative
-            int32_t q = 0;
-            // Per-lane state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the
-            // current M run), not over CIGAR ops: lanes whose reads have clips or indels still add
-            // bases in the same wavefront instructions as their single-run neighbours.
-            uint32_t k = 0;
-            int32_t xa = 0, xb = 0, sx = 0, xg1 = 0, xg2 = 0, c = 1, cb = 0;   // c > cb: no live run
-            int32_t pend_lo = -1;   // >= 0: a leading clip waits to be merged into the run of the next op
-            for (;;) {
-                while (c > cb && k < nc) {   // advance to the next run with live bases
-                    const uint32_t cw = cg[k];
-                    const int32_t len = (int32_t)(cw >> 4);
-                    const uint32_t op = cw & 15u;
-                    k++;
-                    if (op == 0 || op == 7 || op == 8) {
-                        // query bases [x_lo, x_hi) of this run land on sites sx + x
-                        int32_t x_lo = q, x_hi = q + len;
-                        sx = grel - q;
-                        xg1 = q; xg2 = x_hi;
-                        if (pend_lo >= 0) { x_lo = pend_lo; pend_lo = -1; }   // leading clip: same site formula
-                        q += len; grel += len;
-                        if (k < nc && (cg[k] & 15u) == 4u) {
-                            // trailing clip, kindel.py:74-81: its bases continue on the next sites while r < L;
-                            // for a regular read it is the last op that moves r: reach = end of the footprint
-                            x_hi += foot_end - grel;
-                            k = nc;
-                        }
-                        xa = -sx > x_lo ? -sx : x_lo;                     // inside the window
-                        xb = Wi - sx < x_hi ? Wi - sx : x_hi;
-                        if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
-                        if (grel >= Wi) k = nc;
-                    } else if (op == 2) {
-                        pend_lo = -1;
-                        for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
-                            atomicAdd(&hist[KD_HCH_DEL * W + (uint32_t)(grel + j)], 1u);
-                        grel += len;
-                        if (grel >= Wi) k = nc;
-                    } else if (op == 1) {
-                        q += len;   // (a pending leading clip stays adjacent in site space: I does not move r)
-                    } else if (op == 4) {
-                        if (k == 1) {
-                            // leading clip, kindel.py:64-73: base x -> site r - len + x, kept if >= contig start
-                            // (`lead` of the len bases).  Same site formula as the run that follows (sx = grel - q).
-                            q += len;
-                            if (k < nc && ((cg[k] & 15u) == 0u || (cg[k] & 15u) == 7u || (cg[k] & 15u) == 8u)) {
-                                pend_lo = len - lead;
-                            } else {   // not followed by an aligned run: a run of its own
-                                sx = grel - q;
-                                xg1 = q; xg2 = q;                          // every base is in the clip_end group
-                                const int32_t x_lo = len - lead;
-                                xa = -sx > x_lo ? -sx : x_lo;
-                                xb = Wi - sx < q ? Wi - sx : q;
-                                if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
-                            }
-                        } else {
-                            // non-first clip not merged above (previous op was not an aligned run)
-                            sx = grel - q;
-                            xg1 = q; xg2 = q;                              // every base is in the clip_start group
-                            const int32_t x_hi = q + (foot_end - grel);
-                            xa = -sx > q ? -sx : q;
-                            xb = Wi - sx < x_hi ? Wi - sx : x_hi;
-                            if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
-                            k = nc;
-                        }
-                    } else {
-                        // N, H, P: no effect (kindel.py:49-81 has no branch)
+        for (kd_u64 tb = first; tb < last; tb += KD_TILE) {
+            if (t == 0) { s_np = 0; s_nc = 0; }
+            __syncthreads();
+            // classify the tile's reads: plain (single aligned run) / complex; drop those outside the window
+            for (uint32_t u = 0; u < KD_TILE / KD_BLOCK; u++) {
+                const uint32_t rel = u * KD_BLOCK + t;
+                const kd_u64 i = tb + rel;
+                if (i < last) {
+                    const KdRInfo ri = rinfo[i];
+                    const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
+                    if ((ri.span_cls & 3u) == KD_CLS_REG && gs + span > wlo && gs - ri.lead < whi) {
+                        if (ri.span_cls & KD_INFO_PLAIN) l_plain[atomicAdd(&s_np, 1u)] = (uint16_t)rel;
+                        else l_cplx[atomicAdd(&s_nc, 1u)] = (uint16_t)rel;
                     }
                 }
-                if (c > cb) break;
-                const KdChunk cur = src[c];
-                const int32_t xs = 32 * c;
-                kd_add_dword(hist, W, cur.x, xs, xa, xb, sx, xg1, xg2);
-                kd_add_dword(hist, W, cur.y, xs + 8, xa, xb, sx, xg1, xg2);
-                kd_add_dword(hist, W, cur.z, xs + 16, xa, xb, sx, xg1, xg2);
-                kd_add_dword(hist, W, cur.w, xs + 24, xa, xb, sx, xg1, xg2);
-                c++;
             }
+            __syncthreads();
+            // homogeneous wavefronts: first the plain reads, then the complex ones.  Lane l of a wavefront takes
+            // list entries l*rows + r: neighbours in a wavefront are `rows` reads apart in the sorted batch,
+            // which keeps them off the same LDS counters in the same instruction.
+            const uint32_t np = s_np, ncx = s_nc;
+            {
+                const uint32_t rows = (np + KD_WAVE - 1) / KD_WAVE;
+                for (uint32_t r = wave; r < rows; r += KD_WAVES_PER_BLOCK) {
+                    const uint32_t e = lane * rows + r;
+                    if (e < np) { const kd_u64 i = tb + l_plain[e]; kd_walk_plain(rd, i, rinfo[i], wlo, Wi, W, hist); }
+                }
+            }
+            {
+                const uint32_t rows = (ncx + KD_WAVE - 1) / KD_WAVE;
+                for (uint32_t r = wave; r < rows; r += KD_WAVES_PER_BLOCK) {
+                    const uint32_t e = lane * rows + r;
+                    if (e < ncx) { const kd_u64 i = tb + l_cplx[e]; kd_walk_complex(rd, i, rinfo[i], wlo, Wi, W, hist); }
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // flush: channel-major, consecutive lanes -> consecutive HBM dwords; zeros are skipped.
         // LDS channel -> table channel (KD_CH_*): weights 0-4, deletions 5, csw 6-10, cew 11-15; 0xff = bad slot
         bool bad = false;
