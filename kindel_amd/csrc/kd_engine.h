@@ -30,7 +30,7 @@ struct KdEngine {
     uint64_t S = 0;  // G-space sites, multiple of 1024 (consensus tile)
     uint64_t g_lo = 0, g_hi = 0;  // emit interval [g_lo, g_hi)
     int mode = KD_MODE_AUTO;
-    uint32_t W = 512, slice_cfg = 0;
+    uint32_t W = 256, slice_cfg = 0;
     uint32_t dbg = getenv("KD_DEBUG") ? (uint32_t)atoi(getenv("KD_DEBUG")) : 0u;  // experiments only
 
     uint32_t *d_tab = nullptr, *d_clen = nullptr, *d_seg = nullptr;

@@ -974,14 +974,20 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
     const int32_t xb = Wi - grel < len ? Wi - grel : len;
     if (xb <= xa) return;
     const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
-    const int32_t cb = (xb - 1) >> 5;
-    for (int32_t c = xa >> 5; c <= cb; c++) {
-        const KdChunk cur = src[c];
+    const int32_t ca = xa >> 5, cb = (xb - 1) >> 5;
+    // three chunks of prefetch: a 150-base read is 5 chunks, so its loads are (almost) all in flight at once
+    KdChunk cur = src[ca], n1 = cur, n2 = cur;
+    if (ca + 1 <= cb) n1 = src[ca + 1];
+    if (ca + 2 <= cb) n2 = src[ca + 2];
+    for (int32_t c = ca; c <= cb; c++) {
+        KdChunk n3 = n2;
+        if (c + 3 <= cb) n3 = src[c + 3];
         const int32_t xs = 32 * c;
         kd_add_dword(hist, W, cur.x, xs, xa, xb, grel);
         kd_add_dword(hist, W, cur.y, xs + 8, xa, xb, grel);
         kd_add_dword(hist, W, cur.z, xs + 16, xa, xb, grel);
         kd_add_dword(hist, W, cur.w, xs + 24, xa, xb, grel);
+        cur = n1; n1 = n2; n2 = n3;
     }
 }
 
