@@ -996,10 +996,14 @@ __device__ __forceinline__ void kd_walk_plain(const uint8_t *seq4, const KdPlain
     }
 }
 
-#define KD_TILE 1024   // reads classified together; 4 per thread
+#ifndef KD_WBLOCK
+#define KD_WBLOCK 1024  // threads per k_window workgroup: 16 wavefronts share one LDS histogram
+#endif
+#define KD_WWAVES (KD_WBLOCK / KD_WAVE)
+#define KD_TILE 2048   // reads classified together; 2 per thread
 #define KD_WINDOW_LDS_BYTES(W) ((size_t)KD_HCH * (W) * 4 + (size_t)KD_TILE * (sizeof(KdPlainEnt) + 2))
 
-__global__ void __launch_bounds__(KD_BLOCK)
+__global__ void __launch_bounds__(KD_WBLOCK)
 k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
          const kd_u64 *item_off, uint32_t n_win, uint32_t W, uint32_t slice, kd_u64 *status) {
     KD_DYN_SHARED(uint32_t, hist);
@@ -1027,13 +1031,13 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
         const kd_u64 wlo = (kd_u64)w * W, whi = wlo + W;
         const kd_u64 first = win_lo[w] + (item - item_off[w]) * slice;
         const kd_u64 last = first + slice < win_hi[w] ? first + slice : win_hi[w];
-        for (uint32_t x = t; x < nh; x += KD_BLOCK) hist[x] = 0;
+        for (uint32_t x = t; x < nh; x += KD_WBLOCK) hist[x] = 0;
         for (kd_u64 tb = first; tb < last; tb += KD_TILE) {
             if (t == 0) { s_np = 0; s_nc = 0; }
             __syncthreads();
             // classify the tile's reads: plain (single aligned run) / complex; drop those outside the window
-            for (uint32_t u = 0; u < KD_TILE / KD_BLOCK; u++) {
-                const uint32_t rel = u * KD_BLOCK + t;
+            for (uint32_t u = 0; u < KD_TILE / KD_WBLOCK; u++) {
+                const uint32_t rel = u * KD_WBLOCK + t;
                 const kd_u64 i = tb + rel;
                 if (i < last) {
                     const KdRInfo ri = rinfo[i];
@@ -1056,14 +1060,14 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
             const uint32_t np = s_np, ncx = s_nc;
             {
                 const uint32_t rows = (np + KD_WAVE - 1) / KD_WAVE;
-                for (uint32_t r = wave; r < rows; r += KD_WAVES_PER_BLOCK) {
+                for (uint32_t r = wave; r < rows; r += KD_WWAVES) {
                     const uint32_t e = lane * rows + r;
                     if (e < np) kd_walk_plain(rd.seq4, l_plain[e], Wi, W, hist);
                 }
             }
             {
                 const uint32_t rows = (ncx + KD_WAVE - 1) / KD_WAVE;
-                for (uint32_t r = wave; r < rows; r += KD_WAVES_PER_BLOCK) {
+                for (uint32_t r = wave; r < rows; r += KD_WWAVES) {
                     const uint32_t e = lane * rows + r;
                     if (e < ncx) { const kd_u64 i = tb + l_cplx[e]; kd_walk_complex(rd, i, rinfo[i], wlo, Wi, W, hist); }
                 }
@@ -1073,7 +1077,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
         // flush: channel-major, consecutive lanes -> consecutive HBM dwords; zeros are skipped.
         // LDS channel -> table channel (KD_CH_*): weights 0-4, deletions 5, csw 6-10, cew 11-15; 0xff = bad slot
         bool bad = false;
-        for (uint32_t x = t; x < nh; x += KD_BLOCK) {
+        for (uint32_t x = t; x < nh; x += KD_WBLOCK) {
             const uint32_t v = hist[x];
             if (v) {
                 const uint32_t ch = x / W;
