@@ -30,7 +30,7 @@ struct KdEngine {
     uint64_t S = 0;  // G-space sites, multiple of 1024 (consensus tile)
     uint64_t g_lo = 0, g_hi = 0;  // emit interval [g_lo, g_hi)
     int mode = KD_MODE_AUTO;
-    uint32_t W = 896, slice_cfg = 0;
+    uint32_t W = 256, slice_cfg = 0;
     uint32_t dbg = getenv("KD_DEBUG") ? (uint32_t)atoi(getenv("KD_DEBUG")) : 0u;  // experiments only
 
     uint32_t *d_tab = nullptr, *d_clen = nullptr, *d_seg = nullptr;
@@ -235,11 +235,12 @@ struct KdEngine {
                           (const KdRInfo *)rinfo, (kd_u64)n, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status) ||
                 rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, d_status))
                 return hipfail("k_plan");
-            const size_t lds = KD_WINDOW_LDS_BYTES(W);
-            const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(2048 / KD_WBLOCK, (160 * 1024 - 512) / (lds + 64)));
+            const uint32_t tile = getenv("KD_TILE") ? (uint32_t)atoi(getenv("KD_TILE")) : 1024u;  // multiple of KD_BLOCK, <= KD_TILE_MAX
+            const size_t lds = KD_WINDOW_LDS_BYTES(W, tile);
+            const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
             const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
-            if (rt.launch("k_window", k_window, grid, KD_WBLOCK, lds, R, (const KdRInfo *)rinfo, T, (const kd_u64 *)wl,
-                          (const kd_u64 *)wh, (const kd_u64 *)io, n_win, W, slice, d_status))
+            if (rt.launch("k_window", k_window, grid, KD_BLOCK, lds, R, (const KdRInfo *)rinfo, T, (const kd_u64 *)wl,
+                          (const kd_u64 *)wh, (const kd_u64 *)io, n_win, W, slice, tile, d_status))
                 return hipfail("k_window");
             if (n_cold &&
                 rt.launch("k_cold_lane", k_cold_lane, (unsigned)((n_cold + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, R, T, I,

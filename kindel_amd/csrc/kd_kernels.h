@@ -966,19 +966,14 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
 
 // A PLAIN read: one M/=/X run covering the whole read, no clips (k_prep: KD_INFO_PLAIN).  Nothing to decode:
 // query base x lands on site grel + x, for x in [0, span).
-struct KdPlainEnt {     // staged in LDS by the classification phase: everything the plain walk needs
-    int32_t grel;       // window-relative site of the read's first base (may be negative)
-    uint32_t len;       // bases = reference span
-    kd_u64 soff;        // byte offset of the packed bases
-};
-__device__ __forceinline__ void kd_walk_plain(const uint8_t *seq4, const KdPlainEnt ent, int32_t Wi, uint32_t W,
-                                              uint32_t *hist) {
-    const int32_t grel = ent.grel;
-    const int32_t len = (int32_t)ent.len;
+__device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi,
+                                              uint32_t W, uint32_t *hist) {
+    const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);
+    const int32_t len = (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
     const int32_t xa = grel < 0 ? -grel : 0;
     const int32_t xb = Wi - grel < len ? Wi - grel : len;
     if (xb <= xa) return;
-    const KdChunk *src = reinterpret_cast<const KdChunk *>(seq4 + ent.soff);
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
     const int32_t ca = xa >> 5, cb = (xb - 1) >> 5;
     // three chunks of prefetch: a 150-base read is 5 chunks, so its loads are (almost) all in flight at once
     KdChunk cur = src[ca], n1 = cur, n2 = cur;
@@ -996,19 +991,15 @@ __device__ __forceinline__ void kd_walk_plain(const uint8_t *seq4, const KdPlain
     }
 }
 
-#ifndef KD_WBLOCK
-#define KD_WBLOCK 1024  // threads per k_window workgroup: 16 wavefronts share one LDS histogram
-#endif
-#define KD_WWAVES (KD_WBLOCK / KD_WAVE)
-#define KD_TILE 2048   // reads classified together; 2 per thread
-#define KD_WINDOW_LDS_BYTES(W) ((size_t)KD_HCH * (W) * 4 + (size_t)KD_TILE * (sizeof(KdPlainEnt) + 2))
+#define KD_TILE_MAX 2048   // reads classified together (runtime `tile`, a multiple of KD_BLOCK)
+#define KD_WINDOW_LDS_BYTES(W, tile) ((size_t)KD_HCH * (W) * 4 + (size_t)2 * (tile) * 2)
 
-__global__ void __launch_bounds__(KD_WBLOCK)
+__global__ void __launch_bounds__(KD_BLOCK)
 k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
-         const kd_u64 *item_off, uint32_t n_win, uint32_t W, uint32_t slice, kd_u64 *status) {
+         const kd_u64 *item_off, uint32_t n_win, uint32_t W, uint32_t slice, uint32_t tile, kd_u64 *status) {
     KD_DYN_SHARED(uint32_t, hist);
-    KdPlainEnt *l_plain = reinterpret_cast<KdPlainEnt *>(hist + (size_t)KD_HCH * W);   // 16-byte aligned (W % 64 == 0)
-    uint16_t *l_cplx = reinterpret_cast<uint16_t *>(l_plain + KD_TILE);                // tile-relative read indices
+    uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * W);  // tile-relative read indices
+    uint16_t *l_cplx = l_plain + tile;
     __shared__ kd_u64 s_item;
     __shared__ uint32_t s_np, s_nc;
     const uint32_t t = threadIdx.x;
@@ -1031,25 +1022,20 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
         const kd_u64 wlo = (kd_u64)w * W, whi = wlo + W;
         const kd_u64 first = win_lo[w] + (item - item_off[w]) * slice;
         const kd_u64 last = first + slice < win_hi[w] ? first + slice : win_hi[w];
-        for (uint32_t x = t; x < nh; x += KD_WBLOCK) hist[x] = 0;
-        for (kd_u64 tb = first; tb < last; tb += KD_TILE) {
+        for (uint32_t x = t; x < nh; x += KD_BLOCK) hist[x] = 0;
+        for (kd_u64 tb = first; tb < last; tb += tile) {
             if (t == 0) { s_np = 0; s_nc = 0; }
             __syncthreads();
             // classify the tile's reads: plain (single aligned run) / complex; drop those outside the window
-            for (uint32_t u = 0; u < KD_TILE / KD_WBLOCK; u++) {
-                const uint32_t rel = u * KD_WBLOCK + t;
+            for (uint32_t u = 0; u < tile / KD_BLOCK; u++) {
+                const uint32_t rel = u * KD_BLOCK + t;
                 const kd_u64 i = tb + rel;
                 if (i < last) {
                     const KdRInfo ri = rinfo[i];
                     const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
                     if ((ri.span_cls & 3u) == KD_CLS_REG && gs + span > wlo && gs - ri.lead < whi) {
-                        if (ri.span_cls & KD_INFO_PLAIN) {
-                            KdPlainEnt ent;
-                            ent.grel = (int32_t)(ri.gstart - (uint32_t)wlo); ent.len = (uint32_t)span; ent.soff = rd.seq_off[i];
-                            l_plain[atomicAdd(&s_np, 1u)] = ent;
-                        } else {
-                            l_cplx[atomicAdd(&s_nc, 1u)] = (uint16_t)rel;
-                        }
+                        if (ri.span_cls & KD_INFO_PLAIN) l_plain[atomicAdd(&s_np, 1u)] = (uint16_t)rel;
+                        else l_cplx[atomicAdd(&s_nc, 1u)] = (uint16_t)rel;
                     }
                 }
             }
@@ -1060,14 +1046,14 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
             const uint32_t np = s_np, ncx = s_nc;
             {
                 const uint32_t rows = (np + KD_WAVE - 1) / KD_WAVE;
-                for (uint32_t r = wave; r < rows; r += KD_WWAVES) {
+                for (uint32_t r = wave; r < rows; r += KD_WAVES_PER_BLOCK) {
                     const uint32_t e = lane * rows + r;
-                    if (e < np) kd_walk_plain(rd.seq4, l_plain[e], Wi, W, hist);
+                    if (e < np) { const kd_u64 i = tb + l_plain[e]; kd_walk_plain(rd, i, rinfo[i], wlo, Wi, W, hist); }
                 }
             }
             {
                 const uint32_t rows = (ncx + KD_WAVE - 1) / KD_WAVE;
-                for (uint32_t r = wave; r < rows; r += KD_WWAVES) {
+                for (uint32_t r = wave; r < rows; r += KD_WAVES_PER_BLOCK) {
                     const uint32_t e = lane * rows + r;
                     if (e < ncx) { const kd_u64 i = tb + l_cplx[e]; kd_walk_complex(rd, i, rinfo[i], wlo, Wi, W, hist); }
                 }
@@ -1077,7 +1063,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
         // flush: channel-major, consecutive lanes -> consecutive HBM dwords; zeros are skipped.
         // LDS channel -> table channel (KD_CH_*): weights 0-4, deletions 5, csw 6-10, cew 11-15; 0xff = bad slot
         bool bad = false;
-        for (uint32_t x = t; x < nh; x += KD_WBLOCK) {
+        for (uint32_t x = t; x < nh; x += KD_BLOCK) {
             const uint32_t v = hist[x];
             if (v) {
                 const uint32_t ch = x / W;

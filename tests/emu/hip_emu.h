@@ -24,7 +24,6 @@
 #include <vector>
 
 #define KD_EMU 1
-#define KD_WBLOCK 256   // the emulator runs one OS thread per work-item: keep k_window workgroups small
 
 struct dim3 {
     unsigned x, y, z;
