@@ -291,6 +291,14 @@ class Engine:
         self._check(self.lib.dll.kd_consensus_run(self._h, int(min_depth), len(ps), _ptr(ps), _ptr(pe)),
                     "kd_consensus_run")
 
+    def consensus_fetch_into(self, contig, out):
+        """Copy contig's consensus bytes into `out` (a uint8 numpy array, ideally backed by pinned host memory so
+        the device-to-host copy needs no staging); -> number of bytes."""
+        ln = C.c_uint64(0)
+        self._check(self.lib.dll.kd_consensus_fetch(self._h, contig, _ptr(out), out.size, C.byref(ln), None, None, None),
+                    "kd_consensus_fetch")
+        return ln.value
+
     def consensus_fetch(self, contig, want_changes=True):
         """-> (bytes, changes uint8[L] | None, (min_depth, max_depth), patch_off uint64[n_patches])."""
         ln = C.c_uint64(0)

@@ -30,8 +30,7 @@ struct KdEngine {
     uint64_t S = 0;  // G-space sites, multiple of 1024 (consensus tile)
     uint64_t g_lo = 0, g_hi = 0;  // emit interval [g_lo, g_hi)
     int mode = KD_MODE_AUTO;
-    uint32_t W = 256, slice_cfg = 0;
-    uint32_t dbg = getenv("KD_DEBUG") ? (uint32_t)atoi(getenv("KD_DEBUG")) : 0u;  // experiments only
+    uint32_t W = 320, slice_cfg = 0;   // tuned on C3 (profiles/): 19 ch x 320 x 4 B = 24 KB -> 6 workgroups per CU
 
     uint32_t *d_tab = nullptr, *d_clen = nullptr, *d_seg = nullptr;
     kd_u64 *d_cbase = nullptr, *d_status = nullptr;
@@ -162,7 +161,7 @@ struct KdEngine {
     }
 
     int fetch_status() {
-        if (rt.d2h(h_status.data(), d_status, KDS_COUNT * 8)) return hipfail("status d2h");
+        if (rt.d2h_small(h_status.data(), d_status, KDS_COUNT * 8)) return hipfail("status d2h");
         return KD_OK;
     }
 
@@ -244,7 +243,7 @@ struct KdEngine {
                 return hipfail("k_window");
             if (n_cold &&
                 rt.launch("k_cold_lane", k_cold_lane, (unsigned)((n_cold + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, R, T, I,
-                          (const uint32_t *)cold, (kd_u64)n_cold, d_status, dbg))
+                          (const uint32_t *)cold, (kd_u64)n_cold, d_status))
                 return hipfail("k_cold_lane");
             if (n_irreg &&
                 rt.launch("k_pileup_wave_irreg", k_pileup_wave<true, true>,

@@ -655,7 +655,7 @@ __device__ __forceinline__ bool kd_clip_bases(const KdTabs &T, const uint8_t *se
 // G-space arithmetic: clip tallies go to HBM with 32-bit atomics (they are ~1 % of all events and land
 // on scattered sites), insertion events into the slots k_prep reserved for the read.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list, kd_u64 *status, uint32_t dbg) {
+k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list, kd_u64 *status) {
     const kd_u64 slot = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
     if (slot >= n_list) return;
     const kd_u64 i = list[slot];

@@ -43,6 +43,7 @@ struct HipRt {
     }
     void shutdown() {
         profile_reset();
+        if (pin) { (void)hipHostFree(pin); pin = nullptr; }
         if (own_stream && stream) { (void)hipSetDevice(dev); (void)hipStreamDestroy(stream); }
         stream = nullptr;
     }
@@ -62,6 +63,16 @@ struct HipRt {
         return bad(hipStreamSynchronize(stream));
     }
     int sync() { return bad(hipStreamSynchronize(stream)); }
+    // small readbacks (status words) go through a pinned bounce buffer: no pageable staging in the runtime
+    void *pin = nullptr;
+    int d2h_small(void *h, const void *d, size_t n) {
+        if (!pin && bad(hipHostMalloc(&pin, 4096, hipHostMallocDefault))) return 1;
+        if (n > 4096) return d2h(h, d, n);
+        if (bad(hipMemcpyAsync(pin, d, n, hipMemcpyDeviceToHost, stream))) return 1;
+        if (bad(hipStreamSynchronize(stream))) return 1;
+        memcpy(h, pin, n);
+        return 0;
+    }
 
     template <class K, class... A>
     int launch(const char *name, K k, unsigned grid, unsigned block, size_t shmem, A... args) {

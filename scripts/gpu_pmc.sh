@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 O=$PWD/gpurun_out
 R=$PWD
 cd /tmp
-rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ_[A-Z_0-9]*LDS[A-Z_0-9]*|SQ_INSTS_[A-Z_]+|SQ_WAVE_CYCLES|SQ_BUSY_CYCLES|SQ_WAIT_[A-Z_]+|SQ_ACTIVE_INST_[A-Z]+|FETCH_SIZE|WRITE_SIZE|TCC_EA0_[A-Z_]*REQ[A-Z_0-9]*|TCC_HIT_sum|TCC_MISS_sum|GRBM_GUI_ACTIVE)\b" | sort -u | tr '\n' ' ' > $O/pmc_available.txt
+true
 BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \

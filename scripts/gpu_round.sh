@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round summary on one MI355X: parity suite, smoke, bench C3 (JSON line incl. cpu_baseline), rocprofv3 stats + PMC.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; rm -rf $O/prof_c3 $O/pmc_*; mkdir -p $O
+echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+echo "== pytest gpu"; timeout 1200 python -m pytest tests -m gpu -q --maxfail=8 -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log
+echo "== bench C3"; timeout 900 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err; echo "bench rc=$?"
+echo "== rocprof stats"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python $R/bench.py --no-cpu-baseline > $O/prof_c3_bench.json 2> $O/prof_c3.err); echo "rc=$?"
+bash scripts/gpu_pmc.sh > $O/pmc_summary.txt 2>&1; grep -E "^[1-4] k_(window|prep|cold)" $O/pmc_summary.txt
+for c in ${CONFIGS:-C2 C4 C5}; do timeout 400 python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_$c.json 2> $O/bench_$c.err; done
+python - <<PY
+import json
+for c in ["c3","C2","C4","C5"]:
+    try:
+        d=json.load(open("$O/bench_%s.json"%c)); print(c, "%.3e ev/s"%d["value"], "%.2f ms"%d["ms_per_step"], "kern %.2f"%d["kernel_ms_per_step"], {k:v["avg_ms"] for k,v in d["kernels"].items() if v["avg_ms"]>0.2}, d.get("cpu_baseline",{}).get("bit_exact_vs_gpu"))
+    except Exception as e: print(c, "failed", e)
+PY
