@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--slice", type=int, default=0)
     ap.add_argument("--sweep", default="", help="extra tunings to time on the same batch: mode:window:slice,...")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; "
+                    "gloo only to exercise the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=0.0, help="fraction of reads for the CPU baseline (0 = auto)")
     args = ap.parse_args()
@@ -60,12 +62,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev_index = local_rank % max(1, torch.cuda.device_count())   # == local_rank on a node with >= N GPUs
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
+    torch.cuda.set_device(dev_index)
+    dev = "cuda:%d" % dev_index
 
     cfg = dict(synth.CONFIGS[args.config])
     if world > 1 and cfg["kind"] != "short":
@@ -98,7 +104,7 @@ def main():
     aligned_g, query_g, walked_g, ops_g, reads_g = (int(x) for x in tot.cpu())
 
     mode = dict(auto=N.KD_MODE_AUTO, window=N.KD_MODE_WINDOW)[args.mode] if args.mode != "global" else N.KD_MODE_GLOBAL
-    eng = N.Engine(np.asarray(contig_lens, np.uint32), device=local_rank, mode=mode)
+    eng = N.Engine(np.asarray(contig_lens, np.uint32), device=dev_index, mode=mode)
     if args.window or args.slice:
         eng.set_tuning(args.window, args.slice)
     interval = shard.partition(contig_lens, world)[rank] if world > 1 else (0, eng.total_sites())
@@ -226,7 +232,7 @@ def _pmc_traffic(kernel):
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(p):
         try:
-            return json.load(open(p)).get(kernel)
+            return (json.load(open(p)).get(kernel) or {}).get("bytes")
         except Exception:
             return None
     return None
