@@ -144,8 +144,16 @@ struct KdEngine {
         rt.shutdown();
     }
 
+    // 64-site aligned cover of the shard's commit range [g_lo, g_hi] (g_hi = halo site)
+    void shard_cover(uint64_t &lo, uint64_t &hi) const {
+        lo = g_lo & ~uint64_t(63);
+        hi = std::min<uint64_t>(S, (g_hi + 1 + 63) & ~uint64_t(63));
+    }
+
     int reset() {
-        if (rt.memset(d_tab, 0, (size_t)KDC_NCH * S * 4)) return hipfail("reset: memset tables");
+        uint64_t lo, hi;
+        shard_cover(lo, hi);   // increments outside the shard are never committed, so only this range needs zeroing
+        if (rt.memset2d(d_tab + lo, (size_t)S * 4, 0, (size_t)(hi - lo) * 4, KDC_NCH)) return hipfail("reset: memset tables");
         std::fill(h_status.begin(), h_status.end(), 0);
         h_status[KDS_ERR_READ] = ~0ULL;
         if (rt.h2d(d_status, h_status.data(), KDS_COUNT * 8)) return hipfail("reset: status");
@@ -156,8 +164,11 @@ struct KdEngine {
     int set_shard(uint64_t lo, uint64_t hi) {
         if (lo > hi || hi > S) return fail(KD_E_ARG, "kd_set_shard: bad interval");
         if (reads_pushed) return fail(KD_E_ARG, "kd_set_shard: call before the first batch (or after kd_reset)");
+        // the tables were zeroed over the old shard range; make sure the new one starts from zero as well
+        g_lo = 0; g_hi = S;
+        int rc = reset();
         g_lo = lo; g_hi = hi;
-        return KD_OK;
+        return rc;
     }
 
     int fetch_status() {
@@ -220,7 +231,8 @@ struct KdEngine {
         const bool windowed = (mode != KD_MODE_GLOBAL) && h_status[KDS_B_UNSORTED] == 0 && n_reg > 0;
         last_windowed = windowed ? 1 : 0;
         if (windowed) {
-            const uint32_t n_win = (uint32_t)((S + W - 1) / W);
+            const uint32_t w0 = (uint32_t)(g_lo / W);   // windows intersecting the shard's commit range only
+            const uint32_t n_win = (uint32_t)((std::min<uint64_t>(S, g_hi + 1) + W - 1) / W) - w0;
             uint32_t slice = slice_cfg;
             if (!slice) {  // aim for a few thousand work items, slices big enough to amortise the LDS flush
                 uint64_t s = n / 4096;
@@ -231,7 +243,7 @@ struct KdEngine {
                 return rc;
             kd_u64 *wl = (kd_u64 *)b_winlo.p, *wh = (kd_u64 *)b_winhi.p, *io = (kd_u64 *)b_itemoff.p;
             if (rt.launch("k_plan_ranges", k_plan_ranges, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
-                          (const KdRInfo *)rinfo, (kd_u64)n, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status) ||
+                          (const KdRInfo *)rinfo, (kd_u64)n, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status) ||
                 rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, d_status))
                 return hipfail("k_plan");
             const uint32_t tile = getenv("KD_TILE") ? (uint32_t)atoi(getenv("KD_TILE")) : 1024u;  // multiple of KD_BLOCK, <= KD_TILE_MAX
@@ -239,7 +251,7 @@ struct KdEngine {
             const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
             const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
             if (rt.launch("k_window", k_window, grid, KD_BLOCK, lds, R, (const KdRInfo *)rinfo, T, (const kd_u64 *)wl,
-                          (const kd_u64 *)wh, (const kd_u64 *)io, n_win, W, slice, tile, d_status))
+                          (const kd_u64 *)wh, (const kd_u64 *)io, w0, n_win, W, slice, tile, d_status))
                 return hipfail("k_window");
             if (n_cold &&
                 rt.launch("k_cold_lane", k_cold_lane, (unsigned)((n_cold + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, R, T, I,
@@ -302,8 +314,10 @@ struct KdEngine {
             if (code == 3) return fail(KD_E_CIGAR, "mapped read with CIGAR '*'" + at);
             return fail(KD_E_INTERNAL, "read flagged by a kernel but no reference exception reproduced" + at);
         }
+        uint64_t clo, chi;
+        shard_cover(clo, chi);
         if ((rc = ensure(b_win, (size_t)S * 4))) return rc;
-        if (rt.memset(b_win.p, 0xff, (size_t)S * 4)) return hipfail("finalize: memset win");
+        if (rt.memset((uint32_t *)b_win.p + clo, 0xff, (size_t)(chi - clo) * 4)) return hipfail("finalize: memset win");
         const uint64_t n_ev = h_status[KDS_N_EV];
         n_ev_final = n_ev; pool_final = h_status[KDS_POOL];
         if (n_ev) {
@@ -332,7 +346,7 @@ struct KdEngine {
                 ok = h_status[KDS_INS_COLLISION] == 0;
             }
             if (!ok) return fail(KD_E_INTERNAL, "insertion hash: repeated 64-bit collisions");
-            if (rt.memset(b_best.p, 0, (size_t)S * 8)) return hipfail("finalize: memset best");
+            if (rt.memset((kd_u64 *)b_best.p + clo, 0, (size_t)(chi - clo) * 8)) return hipfail("finalize: memset best");
             kd_u64 *best = (kd_u64 *)b_best.p;
             uint32_t *win = (uint32_t *)b_win.p;
             if (rt.launch("k_ins_site_max", k_ins_site_max, gs, KD_BLOCK, 0, I, H, best) ||
@@ -419,9 +433,13 @@ struct KdEngine {
     int consensus_run(uint32_t min_depth, uint32_t n_patches, const uint64_t *ps, const uint64_t *pe) {
         if (!finalized) return fail(KD_E_ARG, "kd_consensus_run: call kd_finalize first");
         int rc;
-        const uint64_t n_tiles = S / KD_CNS_TILE;
-        const uint64_t cap = S + pool_final + 64;
-        if ((rc = ensure(b_cns, cap)) || (rc = ensure(b_changes, S)) || (rc = ensure(b_tilesum, n_tiles * 8)) ||
+        const uint64_t tile_first = g_lo / KD_CNS_TILE;
+        const uint64_t n_tiles = std::max<uint64_t>(1, (std::min<uint64_t>(S, g_hi) + KD_CNS_TILE - 1) / KD_CNS_TILE - tile_first);
+        const uint64_t cap = n_tiles * KD_CNS_TILE + pool_final + 64;
+        const bool fresh_changes = b_changes.cap < S;
+        if ((rc = ensure(b_changes, S))) return rc;
+        if (fresh_changes && rt.memset(b_changes.p, 0, S)) return hipfail("consensus: memset changes");  // sites outside the shard stay 0
+        if ((rc = ensure(b_cns, cap)) || (rc = ensure(b_tilesum, n_tiles * 8)) ||
             (rc = ensure(b_tileoff, (n_tiles + 1) * 8)) || (rc = ensure(b_coff, ((size_t)n_contigs + 1) * 8)) ||
             (rc = ensure(b_minmax, (size_t)n_contigs * 8)) || (rc = ensure(b_pstart, (size_t)(n_patches + 1) * 8)) ||
             (rc = ensure(b_pend, (size_t)(n_patches + 1) * 8)) || (rc = ensure(b_poff, (size_t)(n_patches + 1) * 8)))
@@ -438,13 +456,13 @@ struct KdEngine {
         C.seg_contig = d_seg; C.ins_win = (const uint32_t *)b_win.p; C.min_depth = min_depth; C.n_patches = n_patches;
         C.patch_start = (const kd_u64 *)b_pstart.p; C.patch_end = (const kd_u64 *)b_pend.p;
         C.g_lo = g_lo; C.g_hi = g_hi;
-        if (rt.launch("k_cns_count", k_cns_count, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64 *)b_tilesum.p,
+        if (rt.launch("k_cns_count", k_cns_count, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64)tile_first, (kd_u64 *)b_tilesum.p,
                       (uint32_t *)b_minmax.p))
             return hipfail("k_cns_count");
         if (rt.launch("k_cns_scan", k_cns_scan, 1u, KD_BLOCK, 0, (const kd_u64 *)b_tilesum.p, (kd_u64 *)b_tileoff.p,
                       (kd_u64)n_tiles))
             return hipfail("k_cns_scan");
-        if (rt.launch("k_cns_emit", k_cns_emit, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (const kd_u64 *)b_tileoff.p,
+        if (rt.launch("k_cns_emit", k_cns_emit, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64)tile_first, (const kd_u64 *)b_tileoff.p,
                       (uint8_t *)b_cns.p, (uint8_t *)b_changes.p, (kd_u64 *)b_coff.p, n_contigs, (kd_u64 *)b_poff.p))
             return hipfail("k_cns_emit");
         h_coff.assign((size_t)n_contigs + 1, 0);
@@ -457,6 +475,11 @@ struct KdEngine {
             (n_patches && rt.d2h(h_poff.data(), b_poff.p, (size_t)n_patches * 8)))
             return hipfail("consensus: d2h");
         if (h_coff[n_contigs] > cap) return fail(KD_E_INTERNAL, "consensus longer than its buffer");
+        // contigs whose first site lies outside the processed tiles were not visited by k_cns_emit
+        for (uint32_t c = 0; c < n_contigs; c++) {
+            if (cbase[c] < tile_first * KD_CNS_TILE) h_coff[c] = 0;
+            else if (cbase[c] >= (tile_first + n_tiles) * KD_CNS_TILE) h_coff[c] = h_coff[n_contigs];
+        }
         have_cns = true;
         return KD_OK;
     }

@@ -801,12 +801,12 @@ __device__ __forceinline__ kd_u64 kd_lower_bound(const KdRInfo *rinfo, kd_u64 n,
 // lies in [w*W - maxspan, (w+1)*W) -- a contiguous index range because the batch is sorted -- cut
 // into slices of `slice` reads (one work item each).
 __global__ void __launch_bounds__(KD_BLOCK)
-k_plan_ranges(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t n_win, uint32_t W, uint32_t slice, kd_u64 *win_lo,
-              kd_u64 *win_hi, kd_u64 *item_off, const kd_u64 *status) {
-    const uint32_t w = blockIdx.x * KD_BLOCK + threadIdx.x;
+k_plan_ranges(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t slice,
+              kd_u64 *win_lo, kd_u64 *win_hi, kd_u64 *item_off, const kd_u64 *status) {
+    const uint32_t w = blockIdx.x * KD_BLOCK + threadIdx.x;   // local index; the window is w0 + w (shard-local planning)
     if (w >= n_win) return;
     const kd_u64 maxspan = status[KDS_B_MAXSPAN];
-    const kd_u64 wlo = (kd_u64)w * W, whi = wlo + W;
+    const kd_u64 wlo = (kd_u64)(w0 + w) * W, whi = wlo + W;
     const kd_u64 lo = kd_lower_bound(rinfo, n_reads, wlo > maxspan ? wlo - maxspan : 0);
     const kd_u64 hi = kd_lower_bound(rinfo, n_reads, whi + status[KDS_B_MAXLEAD]);  // leading clips reach back
     win_lo[w] = lo; win_hi[w] = hi;
@@ -996,7 +996,7 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
 
 __global__ void __launch_bounds__(KD_BLOCK)
 k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
-         const kd_u64 *item_off, uint32_t n_win, uint32_t W, uint32_t slice, uint32_t tile, kd_u64 *status) {
+         const kd_u64 *item_off, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t slice, uint32_t tile, kd_u64 *status) {
     KD_DYN_SHARED(uint32_t, hist);
     uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * W);  // tile-relative read indices
     uint16_t *l_cplx = l_plain + tile;
@@ -1019,7 +1019,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
             if (item_off[mid] <= item) lo = mid; else hi = mid;
         }
         const uint32_t w = lo;
-        const kd_u64 wlo = (kd_u64)w * W, whi = wlo + W;
+        const kd_u64 wlo = (kd_u64)(w0 + w) * W, whi = wlo + W;
         const kd_u64 first = win_lo[w] + (item - item_off[w]) * slice;
         const kd_u64 last = first + slice < win_hi[w] ? first + slice : win_hi[w];
         for (uint32_t x = t; x < nh; x += KD_BLOCK) hist[x] = 0;
@@ -1284,12 +1284,12 @@ __device__ __forceinline__ void kd_cns_load_eval(const KdTabs &T, const KdCns &C
 
 // pass 1: bytes emitted per 1024-site tile + per-contig min/max depth
 __global__ void __launch_bounds__(KD_BLOCK)
-k_cns_count(KdTabs T, KdCns C, KdIns ins, kd_u64 *tile_sum, uint32_t *depth_minmax) {
+k_cns_count(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, kd_u64 *tile_sum, uint32_t *depth_minmax) {
     __shared__ uint32_t s_sum, s_min, s_max;
     const uint32_t t = threadIdx.x;
     if (t == 0) { s_sum = 0; s_min = 0xffffffffu; s_max = 0; }
     __syncthreads();
-    const kd_u64 tile0 = (kd_u64)blockIdx.x * KD_CNS_TILE;
+    const kd_u64 tile0 = (tile_first + blockIdx.x) * KD_CNS_TILE;
     const kd_u64 g0 = tile0 + (kd_u64)t * KD_CNS_PER_THREAD;
     const uint32_t cfirst = tile0 < T.stride ? C.seg_contig[tile0 >> 6] : 0;
     KdSite s[KD_CNS_PER_THREAD];
@@ -1341,11 +1341,11 @@ k_cns_scan(const kd_u64 *tile_sum, kd_u64 *tile_off, kd_u64 n_tiles) {
 
 // pass 3: recompute, scan inside the tile, write bytes / changes / per-contig start offsets
 __global__ void __launch_bounds__(KD_BLOCK)
-k_cns_emit(KdTabs T, KdCns C, KdIns ins, const kd_u64 *tile_off, uint8_t *out, uint8_t *changes,
+k_cns_emit(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, const kd_u64 *tile_off, uint8_t *out, uint8_t *changes,
            kd_u64 *contig_off, uint32_t n_contigs, kd_u64 *patch_off) {
     __shared__ uint32_t s_scan[KD_BLOCK];
     const uint32_t t = threadIdx.x;
-    const kd_u64 tile0 = (kd_u64)blockIdx.x * KD_CNS_TILE;
+    const kd_u64 tile0 = (tile_first + blockIdx.x) * KD_CNS_TILE;
     const kd_u64 g0 = tile0 + (kd_u64)t * KD_CNS_PER_THREAD;
     KdSite s[KD_CNS_PER_THREAD];
     kd_cns_load_eval(T, C, ins, g0, s);

@@ -56,6 +56,9 @@ struct HipRt {
     }
     void free(void *p) { (void)hipSetDevice(dev); (void)hipFree(p); }
     int memset(void *p, int v, size_t n) { return n ? bad(hipMemsetAsync(p, v, n, stream)) : 0; }
+    int memset2d(void *p, size_t pitch, int v, size_t width, size_t height) {
+        return (width && height) ? bad(hipMemset2DAsync(p, pitch, v, width, height, stream)) : 0;
+    }
     int h2d(void *d, const void *h, size_t n) { return n ? bad(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream)) : 0; }
     int d2d(void *d, const void *s, size_t n) { return n ? bad(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, stream)) : 0; }
     int d2h(void *h, const void *d, size_t n) {

@@ -19,6 +19,10 @@ struct EmuRt {
     void *alloc(size_t bytes) { return aligned_alloc(256, (bytes + 255) & ~size_t(255)); }
     void free(void *p) { ::free(p); }
     int memset(void *p, int v, size_t n) { ::memset(p, v, n); return 0; }
+    int memset2d(void *p, size_t pitch, int v, size_t width, size_t height) {
+        for (size_t r = 0; r < height; r++) ::memset((char *)p + r * pitch, v, width);
+        return 0;
+    }
     int h2d(void *d, const void *h, size_t n) { ::memcpy(d, h, n); return 0; }
     int d2d(void *d, const void *s, size_t n) { ::memcpy(d, s, n); return 0; }
     int d2h(void *h, const void *d, size_t n) { ::memcpy(h, d, n); return 0; }
