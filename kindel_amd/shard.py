@@ -84,51 +84,52 @@ def _as_tensor(ptr, n, device):
     return torch.as_tensor(_DevArray(ptr, n), device=device)
 
 
-def stitch(engine, interval, device, group=None):
-    """All-gather the per-rank consensus pieces.  Call after engine.consensus_run().
-
-    -> (seqs, changes, minmax): seqs[c] = bytes of contig c's consensus, changes[c] = uint8[L_c],
-    minmax[c] = (min, max) ACGT depth -- identical on every rank.
-    """
+def gather(engine, interval, device, group=None):
+    """The exchange step: all-gather the per-rank payloads (offsets + depth min/max + change codes +
+    consensus bytes).  Call after engine.consensus_run().  Everything stays on `device`:
+    -> (gathered uint8 tensor [world, pad], world).  One tiny all-gather of sizes, ONE data all-gather."""
     import torch
     import torch.distributed as dist
 
     lens = engine.contig_lens
-    n = len(lens)
-    base, S = g_layout(lens)
     lo, hi = interval
     coff, mm = engine.consensus_offsets()
     cptr, cbytes = engine.consensus_device()
     chptr = engine.changes_device()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
     head = np.concatenate([coff.view(np.uint8), mm.reshape(-1).view(np.uint8)])
     my_size = head.size + (hi - lo) + cbytes
     sizes = torch.zeros(world, dtype=torch.int64, device=device)
     if world > 1:
         dist.all_gather_into_tensor(sizes, torch.tensor([my_size], dtype=torch.int64, device=device), group=group)
+        pad = int(sizes.max().item())
     else:
-        sizes[0] = my_size
-    sizes = sizes.cpu().numpy()
-    pad = int(sizes.max())
+        pad = my_size
     payload = torch.zeros(pad, dtype=torch.uint8, device=device)
     payload[: head.size] = torch.from_numpy(head).to(device)
     payload[head.size: head.size + (hi - lo)] = _as_tensor(chptr + lo, hi - lo, device)
     payload[head.size + (hi - lo): my_size] = _as_tensor(cptr, cbytes, device)
-    gathered = torch.zeros(world * pad, dtype=torch.uint8, device=device)
     if world > 1:
+        gathered = torch.empty(world * pad, dtype=torch.uint8, device=device)
         dist.all_gather_into_tensor(gathered, payload, group=group)  # the one data collective
     else:
         gathered = payload
-    g = gathered.cpu().numpy().reshape(world, pad)
+    return gathered.view(world, pad), world
+
+
+def assemble(rows, contig_lens, world, interval=None):
+    """Host side: per-rank payload rows (uint8 numpy [world, pad]) -> (seqs, changes, minmax) per contig."""
+    lens = np.asarray(contig_lens, np.uint32)
+    n = len(lens)
+    base, S = g_layout(lens)
     # every rank lays contigs out identically, so intervals are recomputable locally
-    ivs = partition(lens, world) if world > 1 else [interval]
+    ivs = partition(lens, world) if world > 1 else [interval if interval is not None else (0, S)]
     seq_parts = [[] for _ in range(n)]
     changes_g = np.zeros(S, np.uint8)
     mins = np.full(n, 0xFFFFFFFF, np.uint64)
     maxs = np.zeros(n, np.uint64)
     for r in range(world):
-        row = g[r]
+        row = rows[r]
         rcoff = row[: (n + 1) * 8].view(np.uint64)
         rmm = row[(n + 1) * 8: (n + 1) * 8 + n * 8].view(np.uint32).reshape(n, 2)
         rlo, rhi = ivs[r]
@@ -144,3 +145,11 @@ def stitch(engine, interval, device, group=None):
     changes = [changes_g[int(base[c]): int(base[c]) + int(lens[c])] for c in range(n)]
     minmax = [(int(mins[c]), int(maxs[c])) for c in range(n)]
     return seqs, changes, minmax
+
+
+def stitch(engine, interval, device, group=None):
+    """gather() + host assembly: -> (seqs, changes, minmax), identical on every rank.
+    seqs[c] = bytes of contig c's consensus, changes[c] = uint8[L_c], minmax[c] = (min, max) ACGT depth."""
+    gathered, world = gather(engine, interval, device, group)
+    rows = np.ascontiguousarray(gathered.cpu().numpy())
+    return assemble(rows, engine.contig_lens, world, interval)
