@@ -49,7 +49,7 @@ int kd_set_mode(kd_ctx *ctx, int mode) {
 int kd_set_tuning(kd_ctx *ctx, uint32_t window_sites, uint32_t slice_reads) {
     if (!ctx) return KD_E_ARG;
     if (window_sites) {
-        if (window_sites < 64 || window_sites > 2048 || (window_sites & 63)) return ctx->e.fail(KD_E_ARG, "kd_set_tuning: window must be a multiple of 64 in [64, 2048]");
+        if (window_sites < 64 || window_sites > 4096 || (window_sites & 63)) return ctx->e.fail(KD_E_ARG, "kd_set_tuning: window must be a multiple of 64 in [64, 4096]");
         ctx->e.W = window_sites;
     }
     ctx->e.slice_cfg = slice_reads;

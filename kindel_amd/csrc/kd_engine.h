@@ -30,7 +30,7 @@ struct KdEngine {
     uint64_t S = 0;  // G-space sites, multiple of 1024 (consensus tile)
     uint64_t g_lo = 0, g_hi = 0;  // emit interval [g_lo, g_hi)
     int mode = KD_MODE_AUTO;
-    uint32_t W = 320, slice_cfg = 0;   // tuned on C3 (profiles/): 19 ch x 320 x 4 B = 24 KB -> 6 workgroups per CU
+    uint32_t W = 640, slice_cfg = 0;   // tuned on C3 (profiles/): 19 ch x 640 x 2 B = 24 KB of LDS histogram per workgroup
 
     uint32_t *d_tab = nullptr, *d_clen = nullptr, *d_seg = nullptr;
     kd_u64 *d_cbase = nullptr, *d_status = nullptr;
@@ -238,6 +238,7 @@ struct KdEngine {
                 uint64_t s = n / 4096;
                 slice = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(256, s));
             }
+            slice = std::min<uint32_t>(slice, 32768u);   // u16 LDS counters: an item may not tally more reads than that
             if ((rc = ensure(b_winlo, (size_t)n_win * 8)) || (rc = ensure(b_winhi, (size_t)n_win * 8)) ||
                 (rc = ensure(b_itemoff, ((size_t)n_win + 1) * 8)))
                 return rc;

@@ -870,25 +870,40 @@ __device__ __forceinline__ uint32_t kd_hchan(uint32_t nib) {
     return (uint32_t)((0x4555555155525305ULL >> (nib * 4)) & 7ULL);
 }
 
-// all 8 bases of dword v are live; s0 = window-relative site of its first base
-__device__ __forceinline__ void kd_add8_full(uint32_t *hist, uint32_t W, uint32_t v, int32_t s0) {
-    uint32_t *h = hist + s0;
+// The LDS histogram packs TWO sites per dword (u16 halves): a work item tallies at most `slice` <= 32768 reads
+// and a read adds at most 1 to a counter, so a half cannot overflow into its neighbour.  Counter of
+// (channel ch, site s) = half (s & 1) of word ch*Wh + (s >> 1), Wh = W / 2.
+__device__ __forceinline__ void kd_hadd(uint32_t *hist, uint32_t Wh, uint32_t ch, int32_t s) {
+    atomicAdd(&hist[ch * Wh + ((uint32_t)s >> 1)], 1u << (16 * (s & 1)));
+}
+// all 8 bases of dword v are live; s0 = window-relative site of its first base.  Even bases go through pointer h
+// with add value vp, odd bases through hq = h + (s0 & 1) with vq: no per-base parity arithmetic.
+__device__ __forceinline__ void kd_add8_full(uint32_t *hist, uint32_t Wh, uint32_t v, int32_t s0) {
+    const uint32_t p = (uint32_t)s0 & 1u;
+    uint32_t *h = hist + ((uint32_t)s0 >> 1);
+    uint32_t *hq = h + p;
+    const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
 #pragma unroll
-    for (int b = 0; b < 8; b++) atomicAdd(&h[kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u) * W + b], 1u);
+    for (int b = 0; b < 8; b++) {
+        const uint32_t ch = kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u);
+        if (b & 1) atomicAdd(&hq[ch * Wh + (b >> 1)], vq);
+        else atomicAdd(&h[ch * Wh + (b >> 1)], vp);
+    }
 }
 // only bases [blo, bhi) are live
-__device__ __forceinline__ void kd_add8_part(uint32_t *hist, uint32_t W, uint32_t v, int32_t s0, int32_t blo, int32_t bhi) {
+__device__ __forceinline__ void kd_add8_part(uint32_t *hist, uint32_t Wh, uint32_t v, int32_t s0, int32_t blo, int32_t bhi) {
 #pragma unroll
     for (int b = 0; b < 8; b++)
-        if (b >= blo && b < bhi) atomicAdd(&hist[kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u) * W + (uint32_t)(s0 + b)], 1u);
+        if (b >= blo && b < bhi) kd_hadd(hist, Wh, kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u), s0 + b);
 }
 // one memory dword against the live query range [xa, xb): xs = query index of the dword's first base,
-// sx = window-relative site of query base 0 of this run (site of base x is sx + x)
-__device__ __forceinline__ void kd_add_dword(uint32_t *hist, uint32_t W, uint32_t v, int32_t xs, int32_t xa, int32_t xb,
+// sx = window-relative site of query base 0 of this run (site of base x is sx + x; for a clip run sx also
+// carries the channel-group offset grp*W, which is even, so the parity logic is unaffected)
+__device__ __forceinline__ void kd_add_dword(uint32_t *hist, uint32_t Wh, uint32_t v, int32_t xs, int32_t xa, int32_t xb,
                                              int32_t sx) {
     if (xs + 8 <= xa || xs >= xb) return;
-    if (xs >= xa && xs + 8 <= xb) kd_add8_full(hist, W, v, sx + xs);
-    else kd_add8_part(hist, W, v, sx + xs, xa - xs, xb - xs);
+    if (xs >= xa && xs + 8 <= xb) kd_add8_full(hist, Wh, v, sx + xs);
+    else kd_add8_part(hist, Wh, v, sx + xs, xa - xs, xb - xs);
 }
 
 // General per-lane walk of one regular read against the window (reads with clips, indels, long CIGARs).
@@ -926,7 +941,7 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
                 if (grel >= Wi) k = nc;
             } else if (op == 2) {
                 for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
-                    atomicAdd(&hist[KD_HCH_DEL * W + (uint32_t)(grel + j)], 1u);
+                    kd_hadd(hist, W >> 1, KD_HCH_DEL, grel + j);
                 grel += len;
                 if (grel >= Wi) k = nc;
             } else if (op == 1) {
@@ -956,10 +971,10 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
         if (c > cb) break;
         const KdChunk cur = src[c];
         const int32_t xs = 32 * c;
-        kd_add_dword(hist, W, cur.x, xs, xa, xb, sx);
-        kd_add_dword(hist, W, cur.y, xs + 8, xa, xb, sx);
-        kd_add_dword(hist, W, cur.z, xs + 16, xa, xb, sx);
-        kd_add_dword(hist, W, cur.w, xs + 24, xa, xb, sx);
+        kd_add_dword(hist, W >> 1, cur.x, xs, xa, xb, sx);
+        kd_add_dword(hist, W >> 1, cur.y, xs + 8, xa, xb, sx);
+        kd_add_dword(hist, W >> 1, cur.z, xs + 16, xa, xb, sx);
+        kd_add_dword(hist, W >> 1, cur.w, xs + 24, xa, xb, sx);
         c++;
     }
 }
@@ -983,29 +998,30 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
         KdChunk n3 = n2;
         if (c + 3 <= cb) n3 = src[c + 3];
         const int32_t xs = 32 * c;
-        kd_add_dword(hist, W, cur.x, xs, xa, xb, grel);
-        kd_add_dword(hist, W, cur.y, xs + 8, xa, xb, grel);
-        kd_add_dword(hist, W, cur.z, xs + 16, xa, xb, grel);
-        kd_add_dword(hist, W, cur.w, xs + 24, xa, xb, grel);
+        kd_add_dword(hist, W >> 1, cur.x, xs, xa, xb, grel);
+        kd_add_dword(hist, W >> 1, cur.y, xs + 8, xa, xb, grel);
+        kd_add_dword(hist, W >> 1, cur.z, xs + 16, xa, xb, grel);
+        kd_add_dword(hist, W >> 1, cur.w, xs + 24, xa, xb, grel);
         cur = n1; n1 = n2; n2 = n3;
     }
 }
 
 #define KD_TILE_MAX 2048   // reads classified together (runtime `tile`, a multiple of KD_BLOCK)
-#define KD_WINDOW_LDS_BYTES(W, tile) ((size_t)KD_HCH * (W) * 4 + (size_t)2 * (tile) * 2)
+#define KD_WINDOW_LDS_BYTES(W, tile) ((size_t)KD_HCH * (W) * 2 + (size_t)2 * (tile) * 2)
 
 __global__ void __launch_bounds__(KD_BLOCK)
 k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
          const kd_u64 *item_off, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t slice, uint32_t tile, kd_u64 *status) {
     KD_DYN_SHARED(uint32_t, hist);
-    uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * W);  // tile-relative read indices
+    uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * (W >> 1));  // tile-relative read indices
     uint16_t *l_cplx = l_plain + tile;
     __shared__ kd_u64 s_item;
     __shared__ uint32_t s_np, s_nc;
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
     const kd_u64 total = status[KDS_TOTAL_ITEMS];
-    const uint32_t nh = (uint32_t)KD_HCH * W;
+    const uint32_t Wh = W >> 1;
+    const uint32_t nh = (uint32_t)KD_HCH * Wh;   // histogram dwords (two u16 counters each)
     const int32_t Wi = (int32_t)W;
     for (;;) {
         if (t == 0) s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL);
@@ -1066,12 +1082,16 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
         for (uint32_t x = t; x < nh; x += KD_BLOCK) {
             const uint32_t v = hist[x];
             if (v) {
-                const uint32_t ch = x / W;
+                const uint32_t ch = x / Wh;
                 const uint32_t tch = ch < 5 ? ch : ch == KD_HCH_DEL ? (uint32_t)KDC_DEL
                                    : (ch >= 7 && ch < 12) ? ch - 1 : (ch >= 13 && ch < 18) ? ch - 2 : 0xffu;
-                const kd_u64 g = wlo + (x - ch * W);
+                const kd_u64 g = wlo + 2u * (x - ch * Wh);   // the word holds sites g (low half) and g + 1 (high half)
                 if (tch == 0xffu) bad = true;
-                else if (g < T.stride && kd_commit(T, g)) atomicAdd(&T.tab[(kd_u64)tch * T.stride + g], v);
+                else {
+                    uint32_t *row = T.tab + (kd_u64)tch * T.stride;
+                    if ((v & 0xffffu) && g < T.stride && kd_commit(T, g)) atomicAdd(&row[g], v & 0xffffu);
+                    if ((v >> 16) && g + 1 < T.stride && kd_commit(T, g + 1)) atomicAdd(&row[g + 1], v >> 16);
+                }
             }
         }
         // a base outside A,C,G,T,N inside an aligned or clipped segment: k_find_bad_base pins down the read

@@ -42,7 +42,7 @@ def test_reference_fixture(hip_lib, key, mode):
     P.assert_matches_oracle(run, what=key)    # full tables, element by element
 
 
-@pytest.mark.parametrize("window,slice_reads", [(64, 16), (256, 0), (320, 64), (1024, 0), (1536, 1000), (2048, 0)])
+@pytest.mark.parametrize("window,slice_reads", [(64, 16), (256, 0), (640, 64), (1024, 0), (2048, 1000), (4096, 0)])
 def test_window_tunings(hip_lib, window, slice_reads):
     for key in ("bwa_mem__3.1.sub_test", "segemehl__6.1.sub_test", "minimap2__1.1.multi"):
         run = P.Run(hip_lib, P.load_fixture(key), window=window, slice_reads=slice_reads)
