@@ -871,39 +871,46 @@ __device__ __forceinline__ uint32_t kd_hchan(uint32_t nib) {
 }
 
 // The LDS histogram packs TWO sites per dword (u16 halves): a work item tallies at most `slice` <= 32768 reads
-// and a read adds at most 1 to a counter, so a half cannot overflow into its neighbour.  Counter of
-// (channel ch, site s) = half (s & 1) of word ch*Wh + (s >> 1), Wh = W / 2.
-__device__ __forceinline__ void kd_hadd(uint32_t *hist, uint32_t Wh, uint32_t ch, int32_t s) {
-    atomicAdd(&hist[ch * Wh + ((uint32_t)s >> 1)], 1u << (16 * (s & 1)));
+// and a read adds at most 1 to a counter, so a half cannot overflow into its neighbour.  Every channel has
+// KD_HALO extra sites on both sides of the window: window clipping is done at DWORD granularity (a dword
+// that straddles the window edge is added whole, its outside bases land in the halo and are never flushed),
+// so the masked path below is only needed at the ends of a run -- which are the same step for all lanes of
+// a wavefront of equal-length reads -- and not wherever some lane happens to cross the window edge.
+// Counter of (channel ch, window-relative site s in [-KD_HALO, W + KD_HALO)) = half (s & 1) of word
+// ch*Wh + (s >> 1) of `hist0` = hist + KD_HALO/2, with Wh = (W + 2*KD_HALO) / 2.
+#define KD_HALO 8
+__device__ __forceinline__ void kd_hadd(uint32_t *hist0, int32_t Wh, uint32_t ch, int32_t s) {
+    atomicAdd(&hist0[(int32_t)ch * Wh + (s >> 1)], 1u << (16 * (s & 1)));
 }
-// all 8 bases of dword v are live; s0 = window-relative site of its first base.  Even bases go through pointer h
+// all 8 bases of dword v are added; s0 = window-relative site of its first base.  Even bases go through pointer h
 // with add value vp, odd bases through hq = h + (s0 & 1) with vq: no per-base parity arithmetic.
-__device__ __forceinline__ void kd_add8_full(uint32_t *hist, uint32_t Wh, uint32_t v, int32_t s0) {
-    const uint32_t p = (uint32_t)s0 & 1u;
-    uint32_t *h = hist + ((uint32_t)s0 >> 1);
+__device__ __forceinline__ void kd_add8_full(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t s0) {
+    const int32_t p = s0 & 1;
+    uint32_t *h = hist0 + (s0 >> 1);
     uint32_t *hq = h + p;
     const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-        const uint32_t ch = kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u);
+        const int32_t ch = (int32_t)kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u);
         if (b & 1) atomicAdd(&hq[ch * Wh + (b >> 1)], vq);
         else atomicAdd(&h[ch * Wh + (b >> 1)], vp);
     }
 }
-// only bases [blo, bhi) are live
-__device__ __forceinline__ void kd_add8_part(uint32_t *hist, uint32_t Wh, uint32_t v, int32_t s0, int32_t blo, int32_t bhi) {
+// only bases [blo, bhi) belong to the run
+__device__ __forceinline__ void kd_add8_part(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t s0, int32_t blo, int32_t bhi) {
 #pragma unroll
     for (int b = 0; b < 8; b++)
-        if (b >= blo && b < bhi) kd_hadd(hist, Wh, kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u), s0 + b);
+        if (b >= blo && b < bhi) kd_hadd(hist0, Wh, kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u), s0 + b);
 }
-// one memory dword against the live query range [xa, xb): xs = query index of the dword's first base,
-// sx = window-relative site of query base 0 of this run (site of base x is sx + x; for a clip run sx also
-// carries the channel-group offset grp*W, which is even, so the parity logic is unaffected)
-__device__ __forceinline__ void kd_add_dword(uint32_t *hist, uint32_t Wh, uint32_t v, int32_t xs, int32_t xa, int32_t xb,
-                                             int32_t sx) {
+// One memory dword of a run.  xs = query index of the dword's first base; [xa, xb) = the run's query bases that
+// fall inside the window (decides whether the dword is touched at all); [ra, rb) = the run's own query bases
+// (decides which of its 8 bases exist); site of base x is sx + x (for a clip run sx also carries the
+// channel-group offset, an even number of sites).
+__device__ __forceinline__ void kd_add_dword(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t xs, int32_t xa, int32_t xb,
+                                             int32_t ra, int32_t rb, int32_t sx) {
     if (xs + 8 <= xa || xs >= xb) return;
-    if (xs >= xa && xs + 8 <= xb) kd_add8_full(hist, Wh, v, sx + xs);
-    else kd_add8_part(hist, Wh, v, sx + xs, xa - xs, xb - xs);
+    if (xs >= ra && xs + 8 <= rb) kd_add8_full(hist0, Wh, v, sx + xs);
+    else kd_add8_part(hist0, Wh, v, sx + xs, ra - xs, rb - xs);
 }
 
 // General per-lane walk of one regular read against the window (reads with clips, indels, long CIGARs).
@@ -911,7 +918,8 @@ __device__ __forceinline__ void kd_add_dword(uint32_t *hist, uint32_t Wh, uint32
 // CIGAR ops, so that lanes keep adding bases together whatever their op structure.  A soft clip is a
 // run of its own on the clip_start / clip_end channel group.
 __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi,
-                                                uint32_t W, uint32_t *hist) {
+                                                int32_t Wh, uint32_t *hist0) {
+    const int32_t Wp = 2 * Wh;   // sites per channel row, halos included
     const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
     const uint32_t nc = rd.n_cig[i];
     const uint32_t *cg = rd.cigar + rd.cig_off[i];
@@ -924,7 +932,7 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
     // current M run), not over CIGAR ops: lanes whose reads have clips or indels still add
     // bases in the same wavefront instructions as their single-run neighbours.
     uint32_t k = 0;
-    int32_t xa = 0, xb = 0, sx = 0, c = 1, cb = 0;   // c > cb: no live run
+    int32_t xa = 0, xb = 0, ra = 0, rb = 0, sx = 0, c = 1, cb = 0;   // c > cb: no live run
     for (;;) {
         while (c > cb && k < nc) {   // advance to the next run with live bases
             const uint32_t cw = cg[k];
@@ -935,13 +943,14 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
                 // live query range: inside the run and inside the window
                 xa = grel < 0 ? q - grel : q;
                 xb = Wi - grel < len ? q + (Wi - grel) : q + len;
+                ra = q; rb = q + len;
                 sx = grel - q;                      // site of query base x is sx + x
                 if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
                 q += len; grel += len;
                 if (grel >= Wi) k = nc;
             } else if (op == 2) {
                 for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
-                    kd_hadd(hist, W >> 1, KD_HCH_DEL, grel + j);
+                    kd_hadd(hist0, Wh, KD_HCH_DEL, grel + j);
                 grel += len;
                 if (grel >= Wi) k = nc;
             } else if (op == 1) {
@@ -951,18 +960,20 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
                     // leading clip, kindel.py:64-73: base x -> site r - len + x, kept if >= contig start
                     // (`lead` of the len bases); a run on the clip_end_weights channels
                     const int32_t s_first = grel - len;           // site of base 0
-                    xa = len - lead; if (-s_first > xa) xa = -s_first;
+                    ra = len - lead; rb = len;
+                    xa = -s_first > ra ? -s_first : ra;
                     xb = Wi - s_first < len ? Wi - s_first : len;
-                    sx = s_first + (int32_t)(KD_HCH_CEW * W);
+                    sx = s_first + (int32_t)KD_HCH_CEW * Wp;
                     if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
                     q += len;
                 } else {
                     // non-first clip, kindel.py:74-81: bases q.. -> sites r.. while r < L; for a regular
                     // read it is the last op that moves r, so its reach is the end of the footprint
                     const int32_t n_adv = foot_end - grel;
+                    ra = q; rb = q + n_adv;
                     xa = grel < 0 ? q - grel : q;
                     xb = Wi - grel < n_adv ? q + (Wi - grel) : q + n_adv;
-                    sx = grel - q + (int32_t)(KD_HCH_CSW * W);
+                    sx = grel - q + (int32_t)KD_HCH_CSW * Wp;
                     if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
                     k = nc;
                 }
@@ -971,10 +982,10 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
         if (c > cb) break;
         const KdChunk cur = src[c];
         const int32_t xs = 32 * c;
-        kd_add_dword(hist, W >> 1, cur.x, xs, xa, xb, sx);
-        kd_add_dword(hist, W >> 1, cur.y, xs + 8, xa, xb, sx);
-        kd_add_dword(hist, W >> 1, cur.z, xs + 16, xa, xb, sx);
-        kd_add_dword(hist, W >> 1, cur.w, xs + 24, xa, xb, sx);
+        kd_add_dword(hist0, Wh, cur.x, xs, xa, xb, ra, rb, sx);
+        kd_add_dword(hist0, Wh, cur.y, xs + 8, xa, xb, ra, rb, sx);
+        kd_add_dword(hist0, Wh, cur.z, xs + 16, xa, xb, ra, rb, sx);
+        kd_add_dword(hist0, Wh, cur.w, xs + 24, xa, xb, ra, rb, sx);
         c++;
     }
 }
@@ -982,7 +993,7 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
 // A PLAIN read: one M/=/X run covering the whole read, no clips (k_prep: KD_INFO_PLAIN).  Nothing to decode:
 // query base x lands on site grel + x, for x in [0, span).
 __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi,
-                                              uint32_t W, uint32_t *hist) {
+                                              int32_t Wh, uint32_t *hist0) {
     const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);
     const int32_t len = (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
     const int32_t xa = grel < 0 ? -grel : 0;
@@ -998,30 +1009,31 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
         KdChunk n3 = n2;
         if (c + 3 <= cb) n3 = src[c + 3];
         const int32_t xs = 32 * c;
-        kd_add_dword(hist, W >> 1, cur.x, xs, xa, xb, grel);
-        kd_add_dword(hist, W >> 1, cur.y, xs + 8, xa, xb, grel);
-        kd_add_dword(hist, W >> 1, cur.z, xs + 16, xa, xb, grel);
-        kd_add_dword(hist, W >> 1, cur.w, xs + 24, xa, xb, grel);
+        kd_add_dword(hist0, Wh, cur.x, xs, xa, xb, 0, len, grel);
+        kd_add_dword(hist0, Wh, cur.y, xs + 8, xa, xb, 0, len, grel);
+        kd_add_dword(hist0, Wh, cur.z, xs + 16, xa, xb, 0, len, grel);
+        kd_add_dword(hist0, Wh, cur.w, xs + 24, xa, xb, 0, len, grel);
         cur = n1; n1 = n2; n2 = n3;
     }
 }
 
 #define KD_TILE_MAX 2048   // reads classified together (runtime `tile`, a multiple of KD_BLOCK)
-#define KD_WINDOW_LDS_BYTES(W, tile) ((size_t)KD_HCH * (W) * 2 + (size_t)2 * (tile) * 2)
+#define KD_WINDOW_LDS_BYTES(W, tile) ((size_t)KD_HCH * ((W) + 2 * KD_HALO) * 2 + (size_t)2 * (tile) * 2)
 
 __global__ void __launch_bounds__(KD_BLOCK)
 k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
          const kd_u64 *item_off, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t slice, uint32_t tile, kd_u64 *status) {
     KD_DYN_SHARED(uint32_t, hist);
-    uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * (W >> 1));  // tile-relative read indices
+    const int32_t Wh = (int32_t)(W + 2 * KD_HALO) >> 1;   // dwords per channel row (two u16 counters each, halos included)
+    uint32_t *hist0 = hist + KD_HALO / 2;                 // word of window-relative site 0
+    uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * Wh);  // tile-relative read indices
     uint16_t *l_cplx = l_plain + tile;
     __shared__ kd_u64 s_item;
     __shared__ uint32_t s_np, s_nc;
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
     const kd_u64 total = status[KDS_TOTAL_ITEMS];
-    const uint32_t Wh = W >> 1;
-    const uint32_t nh = (uint32_t)KD_HCH * Wh;   // histogram dwords (two u16 counters each)
+    const uint32_t nh = (uint32_t)KD_HCH * (uint32_t)Wh;   // histogram dwords
     const int32_t Wi = (int32_t)W;
     for (;;) {
         if (t == 0) s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL);
@@ -1064,14 +1076,14 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
                 const uint32_t rows = (np + KD_WAVE - 1) / KD_WAVE;
                 for (uint32_t r = wave; r < rows; r += KD_WAVES_PER_BLOCK) {
                     const uint32_t e = lane * rows + r;
-                    if (e < np) { const kd_u64 i = tb + l_plain[e]; kd_walk_plain(rd, i, rinfo[i], wlo, Wi, W, hist); }
+                    if (e < np) { const kd_u64 i = tb + l_plain[e]; kd_walk_plain(rd, i, rinfo[i], wlo, Wi, Wh, hist0); }
                 }
             }
             {
                 const uint32_t rows = (ncx + KD_WAVE - 1) / KD_WAVE;
                 for (uint32_t r = wave; r < rows; r += KD_WAVES_PER_BLOCK) {
                     const uint32_t e = lane * rows + r;
-                    if (e < ncx) { const kd_u64 i = tb + l_cplx[e]; kd_walk_complex(rd, i, rinfo[i], wlo, Wi, W, hist); }
+                    if (e < ncx) { const kd_u64 i = tb + l_cplx[e]; kd_walk_complex(rd, i, rinfo[i], wlo, Wi, Wh, hist0); }
                 }
             }
             __syncthreads();
@@ -1082,15 +1094,19 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
         for (uint32_t x = t; x < nh; x += KD_BLOCK) {
             const uint32_t v = hist[x];
             if (v) {
-                const uint32_t ch = x / Wh;
+                const uint32_t ch = x / (uint32_t)Wh;
                 const uint32_t tch = ch < 5 ? ch : ch == KD_HCH_DEL ? (uint32_t)KDC_DEL
                                    : (ch >= 7 && ch < 12) ? ch - 1 : (ch >= 13 && ch < 18) ? ch - 2 : 0xffu;
-                const kd_u64 g = wlo + 2u * (x - ch * Wh);   // the word holds sites g (low half) and g + 1 (high half)
-                if (tch == 0xffu) bad = true;
-                else {
-                    uint32_t *row = T.tab + (kd_u64)tch * T.stride;
-                    if ((v & 0xffffu) && g < T.stride && kd_commit(T, g)) atomicAdd(&row[g], v & 0xffffu);
-                    if ((v >> 16) && g + 1 < T.stride && kd_commit(T, g + 1)) atomicAdd(&row[g + 1], v >> 16);
+                // the word holds window-relative sites s (low half) and s + 1 (high half); halo sites are dropped
+                const int32_t sw = 2 * (int32_t)(x - ch * (uint32_t)Wh) - KD_HALO;
+                uint32_t *row = T.tab + (kd_u64)(tch == 0xffu ? 0u : tch) * T.stride;
+                for (int hlf = 0; hlf < 2; hlf++) {
+                    const uint32_t cnt = hlf ? v >> 16 : v & 0xffffu;
+                    const int32_t sw2 = sw + hlf;
+                    if (!cnt || sw2 < 0 || sw2 >= Wi) continue;
+                    const kd_u64 g = wlo + (kd_u64)sw2;
+                    if (tch == 0xffu) bad = true;
+                    else if (g < T.stride && kd_commit(T, g)) atomicAdd(&row[g], cnt);
                 }
             }
         }
