@@ -34,6 +34,10 @@ typedef unsigned long long kd_u64;
 #endif
 
 // A value every lane of the wavefront holds identically -> SGPR, so branches on it are scalar.
+// 24-bit multiply (operands < 2^24): full-rate on the VALU
+#ifndef KD_MUL24
+#define KD_MUL24(a, b) __umul24((a), (b))
+#endif
 #ifndef KD_UNIFORM
 #define KD_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #endif
@@ -880,20 +884,23 @@ __device__ __forceinline__ uint32_t kd_hchan(uint32_t nib) {
 // ch*Wh + (s >> 1) of `hist0` = hist + KD_HALO/2, with Wh = (W + 2*KD_HALO) / 2.
 #define KD_HALO 8
 __device__ __forceinline__ void kd_hadd(uint32_t *hist0, int32_t Wh, uint32_t ch, int32_t s) {
-    atomicAdd(&hist0[(int32_t)ch * Wh + (s >> 1)], 1u << (16 * (s & 1)));
+    atomicAdd(&hist0[(int32_t)KD_MUL24(ch, (uint32_t)Wh) + (s >> 1)], 1u << (16 * (s & 1)));
 }
 // all 8 bases of dword v are added; s0 = window-relative site of its first base.  Even bases go through pointer h
 // with add value vp, odd bases through hq = h + (s0 & 1) with vq: no per-base parity arithmetic.
 __device__ __forceinline__ void kd_add8_full(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t s0) {
     const int32_t p = s0 & 1;
-    uint32_t *h = hist0 + (s0 >> 1);
-    uint32_t *hq = h + p;
+    // byte addressing: address = row base + ch * (row bytes) + constant, one 24-bit multiply-add per base
+    // (v_mad_u32_u24 is full rate; a 32-bit v_mul_lo_u32 is not)
+    unsigned char *h = reinterpret_cast<unsigned char *>(hist0 + (s0 >> 1));
+    unsigned char *hq = h + 4 * p;
+    const uint32_t rowb = (uint32_t)Wh * 4u;
     const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-        const int32_t ch = (int32_t)kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u);
-        if (b & 1) atomicAdd(&hq[ch * Wh + (b >> 1)], vq);
-        else atomicAdd(&h[ch * Wh + (b >> 1)], vp);
+        const uint32_t ch = kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u);
+        unsigned char *a = ((b & 1) ? hq : h) + KD_MUL24(ch, rowb) + 4 * (b >> 1);
+        atomicAdd(reinterpret_cast<uint32_t *>(a), (b & 1) ? vq : vp);
     }
 }
 // only bases [blo, bhi) belong to the run
