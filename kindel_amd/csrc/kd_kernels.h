@@ -181,14 +181,16 @@ struct KdScan {
 // Serial scan of ops [0, nc) of a read; shared by k_prep (short CIGARs) and k_diagnose-free
 // paths.  "Regular" means: k_window / the COLD pass can process the read with plain
 // G-space arithmetic and no Python wrap-around or exception can occur (bad bases aside).
-__device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc, int64_t pos0, int64_t sl, int64_t L) {
+// `pre` = the first 4 CIGAR words, already in registers (loaded together with those of other reads), or NULL
+__device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc, int64_t pos0, int64_t sl, int64_t L,
+                                                const uint32_t *pre = nullptr) {
     KdScan s;
     s.cls = KD_CLS_REG; s.cold = 0; s.lead = 0; s.span = 0; s.n_ins = 0; s.ins_bases = 0; s.aligned = 0; s.walked = 0;
     bool regular = pos0 >= 0;
     bool seen_nfs = false;  // a non-first S was seen: r is no longer plain prefix arithmetic
     int64_t r = pos0, q = 0, hot_hi = pos0;
     for (uint32_t k = 0; k < nc; k++) {
-        const uint32_t c = cg[k];
+        const uint32_t c = (pre && k < 4) ? (k == 0 ? pre[0] : k == 1 ? pre[1] : k == 2 ? pre[2] : pre[3]) : cg[k];
         const int64_t len = c >> 4;
         const uint32_t op = c & 15u;
         if (op == 0 || op == 7 || op == 8) {  // M = X
@@ -263,6 +265,15 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
             v_pc[u] = rd.contig[jp]; v_ppos[u] = rd.pos0[jp];
             v_sl[u] = rd.seq_len[j]; v_nc[u] = rd.n_cig[j]; v_fl[u] = rd.flag[j]; v_coff[u] = rd.cig_off[j];
         }
+        // second level: the first 4 CIGAR words of each of the 4 reads, again all in flight together
+        uint32_t v_cw[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t *cgp = rd.cigar + v_coff[u];
+            const uint32_t ncu = v_ok[u] ? v_nc[u] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v_cw[u][k] = (uint32_t)k < ncu ? cgp[k] : 0u;
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (!v_ok[u]) continue;
@@ -291,7 +302,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
                 cls = KD_CLS_LONG;
                 a_reads++;
             } else {
-                KdScan s = kd_scan_cigar(rd.cigar + v_coff[u], nc, pos0, sl, L_cached);
+                KdScan s = kd_scan_cigar(rd.cigar + v_coff[u], nc, pos0, sl, L_cached, v_cw[u]);
                 cls = s.cls; cold = s.cold; span = s.span; lead = s.lead; has_ins = s.n_ins != 0; al = s.aligned;
                 a_reads++; a_aligned += s.aligned; a_walked += s.walked; a_ins += s.n_ins; a_insb += s.ins_bases;
             }
