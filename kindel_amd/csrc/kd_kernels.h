@@ -10,13 +10,16 @@
 //   tables   u32 tab[KD_NCH][S]  channel-major over "G-space" (all contigs back to back,
 //            len+1 slots each, padded to 64) so that 64 lanes walking 64 consecutive sites
 //            hit 64 consecutive dwords (coalesced atomics / stores, conflict-free LDS banks).
-//   k_prep        lane per read: classify, reference span, counts -> sizes the event buffers
-//   k_plan        window -> candidate-read range (binary search on sorted starts) -> work items
-//   k_window      persistent workgroups pull (window, slice) items; one wavefront walks one
-//                 read's CIGAR; base tallies go to an LDS histogram [6][W]; one coalesced
-//                 flush of the non-zero counters per item (atomicAdd, u32) into HBM
-//   k_pileup_wave one wavefront per read, every reference quirk, 32-bit atomics straight to
-//                 HBM: soft-clip tables, insertion events, irregular reads, KD_MODE_GLOBAL
+//   k_prep        lane per read: classify (skip / regular / irregular / long CIGAR, plain), footprint,
+//                 stats, deterministic insertion-event slots; k_prep_long for CIGARs of > 16 words
+//   k_plan_*      window -> candidate-read range (binary search on sorted starts) -> work items
+//   k_window      persistent workgroups pull (window, slice) items; ONE LANE PER READ, 8 bases per
+//                 dword, every base one ds_add_u32 into an LDS histogram (weights, deletions and both
+//                 soft-clip weight tables; u16 counters, two sites per dword); one coalesced flush of
+//                 the non-zero counters per item (atomicAdd, u32) into HBM
+//   k_cold_lane   lane per read with S or I: clip start/end counters, insertion events
+//   k_pileup_wave one wavefront per read, every reference quirk incl. Python negative-index wrap,
+//                 32-bit atomics straight to HBM: irregular reads, unsorted batches, KD_MODE_GLOBAL
 //   k_ins_*       insertion events -> open-addressing hash multiset -> per-site unique max
 //   k_cns_*       per-site argmax / tie / indel rules, exclusive scan, byte emission
 //
@@ -33,13 +36,9 @@ typedef unsigned long long kd_u64;
     type *name = reinterpret_cast<type *>(kd_dyn_smem_)
 #endif
 
-// A value every lane of the wavefront holds identically -> SGPR, so branches on it are scalar.
 // 24-bit multiply (operands < 2^24): full-rate on the VALU
 #ifndef KD_MUL24
 #define KD_MUL24(a, b) __umul24((a), (b))
-#endif
-#ifndef KD_UNIFORM
-#define KD_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #endif
 
 #define KD_WAVE 64
@@ -509,7 +508,7 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
 // (kindel.py:40-81 incl. Python negative-index wrap-around), 32-bit atomics into HBM.
 //   HOT : commit M/=/X and D tallies (weights, deletions)
 //   COLD: commit soft-clip tables and emit insertion events
-// <true,true>  irregular reads and KD_MODE_GLOBAL;  <false,true> the S/I side of regular reads.
+// <true,true> is what runs: irregular reads, unsorted batches and KD_MODE_GLOBAL.
 // All control flow is wave-uniform (every value steering it comes from uniform loads).
 // ---------------------------------------------------------------------------------------
 template <bool HOT, bool COLD>
@@ -635,40 +634,10 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
     (void)rinfo;
 }
 
-// Soft-clip bases [xa, xb) of a read -> tab[ch0 + channel][gx + x] (G-space site of query base x is
-// gx + x), consumed from 16-byte chunks like k_window does.  Returns true if a base outside A,C,G,T,N
-// was met (KeyError in the reference, kindel.py:72,79).
-__device__ __forceinline__ bool kd_clip_bases(const KdTabs &T, const uint8_t *seq, int64_t xa, int64_t xb, int64_t gx,
-                                              uint32_t ch0) {
-    bool bad = false;
-    if (xb <= xa) return false;
-    const KdChunk *src = reinterpret_cast<const KdChunk *>(seq);
-    for (int64_t c = xa >> 5; c <= (xb - 1) >> 5; c++) {
-        const KdChunk cur = src[c];
-        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            const int64_t xs = 32 * c + 8 * d;
-            if (xs + 8 <= xa || xs >= xb) continue;
-#pragma unroll
-            for (int b = 0; b < 8; b++) {
-                const int64_t x = xs + b;
-                if (x >= xa && x < xb) {
-                    const uint32_t ch = kd_chan((w[d] >> KD_NIB_SHIFT(b)) & 15u);
-                    const kd_u64 g = (kd_u64)(gx + x);
-                    if (ch == 7u) bad = true;
-                    else if (kd_commit(T, g)) atomicAdd(&T.tab[(kd_u64)(ch0 + ch) * T.stride + g], 1u);
-                }
-            }
-        }
-    }
-    return bad;
-}
-
-// k_cold_lane: the soft-clip / insertion side of REGULAR reads (kindel.py:55-58, :63-81), one LANE per
-// read of the cold list.  Regular reads cannot raise and never wrap (k_prep checked), so this is plain
-// G-space arithmetic: clip tallies go to HBM with 32-bit atomics (they are ~1 % of all events and land
-// on scattered sites), insertion events into the slots k_prep reserved for the read.
+// k_cold_lane: what is left of the soft-clip / insertion side of REGULAR reads (kindel.py:55-58, :63-81) once
+// k_window has tallied the clipped bases: the clip_ends / clip_starts counters (one 32-bit atomic each) and
+// the insertion events, written into the slots k_prep reserved for the read.  One LANE per read of the cold
+// list.  Regular reads cannot raise and never wrap (k_prep checked), so this is plain G-space arithmetic.
 __global__ void __launch_bounds__(KD_BLOCK)
 k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list, kd_u64 *status) {
     const kd_u64 slot = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
@@ -714,8 +683,7 @@ k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list
                 const kd_u64 g = cb + (kd_u64)r;
                 if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g], 1u);
                 // query bases [xa, len) land on sites r - len + x  (those with r - len + x >= 0)
-                const int64_t xa = r < len ? len - r : 0;
-                (void)xa;  // clip_end_weights are tallied by k_window (LDS)
+                // (clip_end_weights of these bases are tallied by k_window)
                 q += len;
             } else {  // kindel.py:74-81; regular: the last op that touches r
                 const int64_t x = r - 1;

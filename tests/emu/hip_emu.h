@@ -43,7 +43,6 @@ inline unsigned char *emu_dyn_shared_ptr = nullptr;
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define __launch_bounds__(...)
-#define KD_UNIFORM(x) ((uint32_t)(x))
 #define KD_MUL24(a, b) ((uint32_t)(a) * (uint32_t)(b))
 #define KD_ALIGNBYTE(hi, lo, sh) ((uint32_t)((((uint64_t)(hi) << 32) | (uint64_t)(lo)) >> (8 * (sh))))
 #define KD_DYN_SHARED(type, name) type *name = reinterpret_cast<type *>(emu_dyn_shared_ptr)
