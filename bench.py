@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--sweep", default="", help="extra tunings to time on the same batch: mode:window:slice,...")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; "
                     "gloo only to exercise the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--shuffle", action="store_true", help="permute the read order (unsorted input: exercises the device bucket sort)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=0.0, help="fraction of reads for the CPU baseline (0 = auto)")
     args = ap.parse_args()
@@ -85,6 +86,10 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     n_reads = int(batch["contig"].numel())
+    if args.shuffle:
+        perm = torch.randperm(n_reads, device=dev)
+        for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+            batch[k] = batch[k][perm].contiguous()
     # events are credited to the rank that owns the read's start, so every read counts once
     if world > 1:
         own = shard.owned_mask(contig_lens, batch["contig"], batch["pos0"], rank, world)

@@ -41,7 +41,7 @@ struct KdEngine {
         void *p = nullptr;
         size_t cap = 0;
     };
-    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_readev, b_readpool;
+    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_readev, b_readpool, b_order, b_bincnt, b_binoff;
     Buf b_stage[9];
     Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
     uint64_t ev_cap = 0, pool_cap = 0;
@@ -130,7 +130,7 @@ struct KdEngine {
     }
 
     void destroy() {
-        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_readev, &b_readpool, &b_ev_site, &b_ev_len,
+        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ev_site, &b_ev_len,
                       &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_win, &b_cns, &b_changes,
                       &b_tilesum, &b_tileoff, &b_coff, &b_minmax, &b_pstart, &b_pend, &b_poff};
         for (Buf *b : all) release(*b);
@@ -228,7 +228,8 @@ struct KdEngine {
         }
         KdIns I = insdesc();
         const uint64_t n_reg = h_status[KDS_B_N_REG], n_cold = h_status[KDS_B_N_COLD], n_irreg = h_status[KDS_B_N_IRREG];
-        const bool windowed = (mode != KD_MODE_GLOBAL) && h_status[KDS_B_UNSORTED] == 0 && n_reg > 0;
+        const bool windowed = (mode != KD_MODE_GLOBAL) && n_reg > 0;
+        const bool sorted_input = h_status[KDS_B_UNSORTED] == 0;
         last_windowed = windowed ? 1 : 0;
         if (windowed) {
             const uint32_t w0 = (uint32_t)(g_lo / W);   // windows intersecting the shard's commit range only
@@ -243,15 +244,36 @@ struct KdEngine {
                 (rc = ensure(b_itemoff, ((size_t)n_win + 1) * 8)))
                 return rc;
             kd_u64 *wl = (kd_u64 *)b_winlo.p, *wh = (kd_u64 *)b_winhi.p, *io = (kd_u64 *)b_itemoff.p;
-            if (rt.launch("k_plan_ranges", k_plan_ranges, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
-                          (const KdRInfo *)rinfo, (kd_u64)n, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status) ||
-                rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, d_status))
-                return hipfail("k_plan");
+            const uint32_t *order = nullptr;
+            if (sorted_input) {
+                if (rt.launch("k_plan_ranges", k_plan_ranges, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
+                              (const KdRInfo *)rinfo, (kd_u64)n, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status))
+                    return hipfail("k_plan_ranges");
+            } else {
+                // unsorted batch: counting sort of the regular reads by window -> permutation `order`
+                const uint32_t n_bins = (uint32_t)((S + W - 1) / W);
+                if ((rc = ensure(b_order, n * 4)) || (rc = ensure(b_bincnt, ((size_t)n_bins + 1) * 4)) ||
+                    (rc = ensure(b_binoff, ((size_t)n_bins + 1) * 8)))
+                    return rc;
+                uint32_t *ord = (uint32_t *)b_order.p, *bc = (uint32_t *)b_bincnt.p;
+                kd_u64 *bo = (kd_u64 *)b_binoff.p;
+                const unsigned gr = (unsigned)((n + KD_BLOCK - 1) / KD_BLOCK);
+                if (rt.memset(bc, 0, ((size_t)n_bins + 1) * 4) ||
+                    rt.launch("k_sort_count", k_sort_count, gr, KD_BLOCK, 0, (const KdRInfo *)rinfo, (kd_u64)n, W, bc) ||
+                    rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, n_bins) ||
+                    rt.launch("k_sort_scatter", k_sort_scatter, gr, KD_BLOCK, 0, (const KdRInfo *)rinfo, (kd_u64)n, W, bc,
+                              (const kd_u64 *)bo, ord) ||
+                    rt.launch("k_plan_ranges_sorted", k_plan_ranges_sorted, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
+                              (const kd_u64 *)bo, n_bins, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status))
+                    return hipfail("k_sort_*");
+                order = ord;
+            }
+            if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, d_status)) return hipfail("k_plan_scan");
             const uint32_t tile = getenv("KD_TILE") ? (uint32_t)atoi(getenv("KD_TILE")) : 1024u;  // multiple of KD_BLOCK, <= KD_TILE_MAX
             const size_t lds = KD_WINDOW_LDS_BYTES(W, tile);
             const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
             const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
-            if (rt.launch("k_window", k_window, grid, KD_BLOCK, lds, R, (const KdRInfo *)rinfo, T, (const kd_u64 *)wl,
+            if (rt.launch("k_window", k_window, grid, KD_BLOCK, lds, R, (const KdRInfo *)rinfo, order, T, (const kd_u64 *)wl,
                           (const kd_u64 *)wh, (const kd_u64 *)io, w0, n_win, W, slice, tile, d_status))
                 return hipfail("k_window");
             if (n_cold &&

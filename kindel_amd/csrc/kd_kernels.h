@@ -796,6 +796,68 @@ k_plan_ranges(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t w0, uint32_t n_win,
     item_off[w] = (hi - lo + slice - 1) / slice;  // item count; k_plan_scan turns it into an offset
 }
 
+// ---- unsorted batches: bucket the regular reads by window (counting sort), so that the candidate reads of
+// a window are again a contiguous range -- of the permutation `order` instead of the batch itself.
+__global__ void __launch_bounds__(KD_BLOCK)
+k_sort_count(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t W, uint32_t *bin_cnt) {
+    const kd_u64 i = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (i >= n_reads) return;
+    const KdRInfo ri = rinfo[i];
+    if ((ri.span_cls & 3u) == KD_CLS_REG) atomicAdd(&bin_cnt[ri.gstart / W], 1u);
+}
+// one workgroup: bin_off = exclusive scan of bin_cnt (n_bins + 1 entries), bin_cnt is reset to 0 (it becomes
+// the fill cursor of k_sort_scatter)
+__global__ void __launch_bounds__(KD_BLOCK)
+k_sort_scan(uint32_t *bin_cnt, kd_u64 *bin_off, uint32_t n_bins) {
+    __shared__ kd_u64 s_scan[KD_BLOCK];
+    __shared__ kd_u64 s_carry;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n_bins; b0 += KD_BLOCK) {
+        const uint32_t b = b0 + t;
+        const kd_u64 v = b < n_bins ? bin_cnt[b] : 0;
+        s_scan[t] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
+            kd_u64 a = t >= d ? s_scan[t - d] : 0;
+            __syncthreads();
+            s_scan[t] += a;
+            __syncthreads();
+        }
+        if (b < n_bins) { bin_off[b] = s_carry + s_scan[t] - v; bin_cnt[b] = 0; }
+        __syncthreads();
+        if (t == KD_BLOCK - 1) s_carry += s_scan[t];
+        __syncthreads();
+    }
+    if (t == 0) bin_off[n_bins] = s_carry;
+}
+__global__ void __launch_bounds__(KD_BLOCK)
+k_sort_scatter(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t W, uint32_t *bin_fill, const kd_u64 *bin_off,
+               uint32_t *order) {
+    const kd_u64 i = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (i >= n_reads) return;
+    const KdRInfo ri = rinfo[i];
+    if ((ri.span_cls & 3u) != KD_CLS_REG) return;
+    const uint32_t b = ri.gstart / W;
+    order[bin_off[b] + atomicAdd(&bin_fill[b], 1u)] = (uint32_t)i;
+}
+// candidate range of window w0 + w in `order`: whole bins covering [wlo - maxspan, whi + maxlead)
+__global__ void __launch_bounds__(KD_BLOCK)
+k_plan_ranges_sorted(const kd_u64 *bin_off, uint32_t n_bins, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t slice,
+                     kd_u64 *win_lo, kd_u64 *win_hi, kd_u64 *item_off, const kd_u64 *status) {
+    const uint32_t w = blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (w >= n_win) return;
+    const kd_u64 wlo = (kd_u64)(w0 + w) * W, whi = wlo + W;
+    const kd_u64 maxspan = status[KDS_B_MAXSPAN], maxlead = status[KDS_B_MAXLEAD];
+    const kd_u64 blo = (wlo > maxspan ? wlo - maxspan : 0) / W;
+    kd_u64 bhi = (whi + maxlead + W - 1) / W;   // exclusive
+    if (bhi > n_bins) bhi = n_bins;
+    const kd_u64 lo = bin_off[blo < n_bins ? blo : n_bins], hi = bin_off[bhi];
+    win_lo[w] = lo; win_hi[w] = hi;
+    item_off[w] = (hi - lo + slice - 1) / slice;
+}
+
 // k_plan_scan: one workgroup, in-place exclusive scan of the per-window item counts.
 __global__ void __launch_bounds__(KD_BLOCK)
 k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
@@ -1007,7 +1069,7 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
 #define KD_WINDOW_LDS_BYTES(W, tile) ((size_t)KD_HCH * ((W) + 2 * KD_HALO) * 2 + (size_t)2 * (tile) * 2)
 
 __global__ void __launch_bounds__(KD_BLOCK)
-k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
+k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
          const kd_u64 *item_off, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t slice, uint32_t tile, kd_u64 *status) {
     KD_DYN_SHARED(uint32_t, hist);
     const int32_t Wh = (int32_t)(W + 2 * KD_HALO) >> 1;   // dwords per channel row (two u16 counters each, halos included)
@@ -1043,8 +1105,8 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
             // classify the tile's reads: plain (single aligned run) / complex; drop those outside the window
             for (uint32_t u = 0; u < tile / KD_BLOCK; u++) {
                 const uint32_t rel = u * KD_BLOCK + t;
-                const kd_u64 i = tb + rel;
-                if (i < last) {
+                if (tb + rel < last) {
+                    const kd_u64 i = order ? (kd_u64)order[tb + rel] : tb + rel;   // `order`: bucket-sorted permutation
                     const KdRInfo ri = rinfo[i];
                     const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
                     if ((ri.span_cls & 3u) == KD_CLS_REG && gs + span > wlo && gs - ri.lead < whi) {
@@ -1062,14 +1124,20 @@ k_window(KdReads rd, const KdRInfo *rinfo, KdTabs T, const kd_u64 *win_lo, const
                 const uint32_t rows = (np + KD_WAVE - 1) / KD_WAVE;
                 for (uint32_t r = wave; r < rows; r += KD_WAVES_PER_BLOCK) {
                     const uint32_t e = lane * rows + r;
-                    if (e < np) { const kd_u64 i = tb + l_plain[e]; kd_walk_plain(rd, i, rinfo[i], wlo, Wi, Wh, hist0); }
+                    if (e < np) {
+                        const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
+                        kd_walk_plain(rd, i, rinfo[i], wlo, Wi, Wh, hist0);
+                    }
                 }
             }
             {
                 const uint32_t rows = (ncx + KD_WAVE - 1) / KD_WAVE;
                 for (uint32_t r = wave; r < rows; r += KD_WAVES_PER_BLOCK) {
                     const uint32_t e = lane * rows + r;
-                    if (e < ncx) { const kd_u64 i = tb + l_cplx[e]; kd_walk_complex(rd, i, rinfo[i], wlo, Wi, Wh, hist0); }
+                    if (e < ncx) {
+                        const kd_u64 j = tb + l_cplx[e], i = order ? (kd_u64)order[j] : j;
+                        kd_walk_complex(rd, i, rinfo[i], wlo, Wi, Wh, hist0);
+                    }
                 }
             }
             __syncthreads();

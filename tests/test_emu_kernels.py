@@ -53,7 +53,7 @@ def test_full_small_fixtures_match_reference_goldens(emu_lib):
         P.assert_matches_golden(run, key, gold)
 
 
-def test_window_path_is_taken_and_unsorted_falls_back(emu_lib):
+def test_window_path_is_taken_also_for_unsorted_batches(emu_lib):
     b = P.subset(P.load_fixture("bwa_mem__1.1.sub_test"), 0, 300)
     run = P.Run(emu_lib, b, window=128)
     assert run.info["windowed"] == 1 and run.info["unsorted"] == 0 and run.info["work_items"] > 1
@@ -61,8 +61,8 @@ def test_window_path_is_taken_and_unsorted_falls_back(emu_lib):
     rev = dict(b)
     for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
         rev[k] = b[k][::-1].copy()
-    run2 = P.Run(emu_lib, rev, window=128)
-    assert run2.info["windowed"] == 0 and run2.info["unsorted"] > 0
+    run2 = P.Run(emu_lib, rev, window=128)   # unsorted: device bucket sort, then the same windowed kernel
+    assert run2.info["windowed"] == 1 and run2.info["unsorted"] > 0
     P.assert_matches_oracle(run2)
     for cid in run.order:
         assert np.array_equal(run.tables[cid], run2.tables[cid])  # sums are order independent
