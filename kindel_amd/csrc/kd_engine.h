@@ -41,7 +41,7 @@ struct KdEngine {
         void *p = nullptr;
         size_t cap = 0;
     };
-    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_readev, b_readpool, b_order, b_bincnt, b_binoff;
+    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_ckpt;
     Buf b_stage[9];
     Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
     uint64_t ev_cap = 0, pool_cap = 0;
@@ -130,7 +130,7 @@ struct KdEngine {
     }
 
     void destroy() {
-        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ev_site, &b_ev_len,
+        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ckpt, &b_ev_site, &b_ev_len,
                       &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_win, &b_cns, &b_changes,
                       &b_tilesum, &b_tileoff, &b_coff, &b_minmax, &b_pstart, &b_pend, &b_poff};
         for (Buf *b : all) release(*b);
@@ -204,9 +204,11 @@ struct KdEngine {
                       (kd_u64 *)b_readpool.p, d_status))
             return hipfail("k_prep");
         if ((rc = fetch_status())) return rc;
-        if (h_status[KDS_B_N_LONG]) {
-            if (rt.launch("k_prep_long", k_prep_long, (unsigned)h_status[KDS_B_N_LONG], KD_BLOCK, 0, R, T, rinfo,
-                          (const uint32_t *)lng, cold, irreg, (uint32_t *)b_readev.p, (kd_u64 *)b_readpool.p, d_status))
+        const uint64_t n_long = h_status[KDS_B_N_LONG];
+        if (n_long) {
+            if ((rc = ensure(b_ckpt, (size_t)n_long * KD_BLOCK * sizeof(KdCkpt)))) return rc;
+            if (rt.launch("k_prep_long", k_prep_long, (unsigned)n_long, KD_BLOCK, 0, R, T, rinfo,
+                          (const uint32_t *)lng, (KdCkpt *)b_ckpt.p, irreg, (uint32_t *)b_readev.p, (kd_u64 *)b_readpool.p, d_status))
                 return hipfail("k_prep_long");
             if ((rc = fetch_status())) return rc;
         }
@@ -273,13 +275,17 @@ struct KdEngine {
             const size_t lds = KD_WINDOW_LDS_BYTES(W, tile);
             const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
             const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
-            if (rt.launch("k_window", k_window, grid, KD_BLOCK, lds, R, (const KdRInfo *)rinfo, order, T, (const kd_u64 *)wl,
+            if (rt.launch("k_window", k_window, grid, KD_BLOCK, lds, R, (const KdRInfo *)rinfo, order, (const KdCkpt *)b_ckpt.p, T, (const kd_u64 *)wl,
                           (const kd_u64 *)wh, (const kd_u64 *)io, w0, n_win, W, slice, tile, d_status))
                 return hipfail("k_window");
             if (n_cold &&
                 rt.launch("k_cold_lane", k_cold_lane, (unsigned)((n_cold + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, R, T, I,
                           (const uint32_t *)cold, (kd_u64)n_cold, d_status))
                 return hipfail("k_cold_lane");
+            if (n_long &&
+                rt.launch("k_cold_long", k_cold_long, (unsigned)n_long, KD_BLOCK, 0, R, T, I, (const KdRInfo *)rinfo,
+                          (const uint32_t *)lng, (const KdCkpt *)b_ckpt.p, d_status))
+                return hipfail("k_cold_long");
             if (n_irreg &&
                 rt.launch("k_pileup_wave_irreg", k_pileup_wave<true, true>,
                           (unsigned)((n_irreg + KD_WAVES_PER_BLOCK - 1) / KD_WAVES_PER_BLOCK), KD_BLOCK, 0, R, T, I,

@@ -124,7 +124,17 @@ struct KdRInfo {
     uint32_t span_cls;  // span << KD_SPAN_SHIFT | KD_INFO_INS | KD_INFO_COLD | class; span = sites from
                         // gstart to the end of the last M / D / trailing-S write
     uint32_t lead;      // sites before gstart written by a leading soft clip (kindel.py:68-72)
-    uint32_t pad;
+    uint32_t pad;       // long-CIGAR reads: 1 + index of the read's KdCkpt[256] block; 0 otherwise
+};
+
+// Long-CIGAR reads (k_prep_long): the state at the first op of each of the 256 per-thread op runs.  Lets
+// k_cold_long emit a read's insertion events with 256 threads and lets k_window enter the read near a window
+// instead of walking thousands of ops from the start.
+struct KdCkpt {
+    uint32_t r_rel;   // reference advance (r - pos0) before the run
+    uint32_t q;       // query advance before the run
+    uint32_t ev;      // insertion events of the read before the run
+    uint32_t pool;    // insertion bases of the read before the run
 };
 
 struct KdIns {
@@ -385,9 +395,10 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
 // of a contiguous run of ops, an LDS scan turns the sums into start coordinates, and a
 // second sweep applies the same regularity rules as kd_scan_cigar.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uint32_t *cold_list,
+k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdCkpt *ckpt,
             uint32_t *irreg_list, uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
     __shared__ int64_t s_r[KD_BLOCK], s_q[KD_BLOCK];
+    __shared__ uint32_t s_ni[KD_BLOCK], s_nb[KD_BLOCK];
     __shared__ kd_u64 s_acc[6];       // aligned, walked, n_ins, ins_bases, bad, cold
     __shared__ uint32_t s_first_nfs, s_last_rel;
     const uint32_t t = threadIdx.x;
@@ -426,6 +437,7 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
     }
     int64_t r = pos0 + (t ? s_r[t - 1] : 0), q = t ? s_q[t - 1] : 0;
     const int64_t r_end = pos0 + s_r[KD_BLOCK - 1];
+    const int64_t r_run = r, q_run = q;   // checkpoint: state before this thread's run of ops
     kd_u64 aligned = 0, walked = 0, n_ins = 0, insb = 0, bad = 0, cold = 0;
     uint32_t first_nfs = 0xffffffffu, last_rel = 0;
     for (uint32_t k = k0; k < k1; k++) {
@@ -462,7 +474,22 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
     if (cold) atomicAdd(&s_acc[5], cold);
     if (first_nfs != 0xffffffffu) atomicMin(&s_first_nfs, first_nfs);
     if (last_rel) atomicMax(&s_last_rel, last_rel);
+    // exclusive prefix of the per-run insertion counts -> event / pool offsets inside the read
+    s_ni[t] = (uint32_t)n_ins; s_nb[t] = (uint32_t)insb;
     __syncthreads();
+    for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
+        uint32_t a = 0, b = 0;
+        if (t >= d) { a = s_ni[t - d]; b = s_nb[t - d]; }
+        __syncthreads();
+        s_ni[t] += a; s_nb[t] += b;
+        __syncthreads();
+    }
+    {
+        KdCkpt ck;
+        ck.r_rel = (uint32_t)(r_run - pos0); ck.q = (uint32_t)q_run;
+        ck.ev = s_ni[t] - (uint32_t)n_ins; ck.pool = s_nb[t] - (uint32_t)insb;
+        ckpt[(kd_u64)blockIdx.x * KD_BLOCK + t] = ck;
+    }
     if (t == 0) {
         bool regular = pos0 >= 0 && s_acc[4] == 0;
         // a non-first S must be the last op that touches r (M, I, D or S)
@@ -483,6 +510,7 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
         ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | (s_acc[2] ? KD_INFO_INS : 0u) | coldbit |
                       (regular ? KD_CLS_REG : KD_CLS_IRREG);
         ri.lead = regular ? lead : 0u;
+        ri.pad = regular ? blockIdx.x + 1u : 0u;
         rinfo[i] = ri;
         if (s_acc[2]) {
             read_ev[i] = (uint32_t)atomicAdd(&status[KDS_N_EV], s_acc[2]);
@@ -496,7 +524,7 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
             atomicAdd(&status[KDS_B_N_REG], 1ULL);
             atomicMax(&status[KDS_B_MAXSPAN], span);
             if (lead) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)lead);
-            if (coldbit) cold_list[atomicAdd(&status[KDS_B_N_COLD], 1ULL)] = (uint32_t)i;
+            // (its S / I side effects are done by k_cold_long, 256 threads per read)
         } else {
             irreg_list[atomicAdd(&status[KDS_B_N_IRREG], 1ULL)] = (uint32_t)i;
         }
@@ -693,6 +721,65 @@ k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list
                 // query bases [q, q + n_adv) land on sites r + (x - q)
                 // clip_start_weights are tallied by k_window (LDS)
                 r += n_adv; q += n_adv;
+            }
+        }
+    }
+}
+
+// k_cold_long: k_cold_lane's work for regular long-CIGAR reads, one WORKGROUP per read: thread t starts from
+// checkpoint t (state before its run of ops, incl. how many insertion events / bases precede it).
+__global__ void __launch_bounds__(KD_BLOCK)
+k_cold_long(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint32_t *long_list, const KdCkpt *ckpt,
+            kd_u64 *status) {
+    const uint32_t t = threadIdx.x;
+    const kd_u64 i = long_list[blockIdx.x];
+    const uint32_t sc = rinfo[i].span_cls;
+    if ((sc & 3u) != KD_CLS_REG || !(sc & KD_INFO_COLD)) return;
+    const uint32_t nc = rd.n_cig[i];
+    const uint32_t per = (nc + KD_BLOCK - 1) / KD_BLOCK;
+    const uint32_t k0 = t * per < nc ? t * per : nc, k1 = k0 + per < nc ? k0 + per : nc;
+    if (k0 >= k1) return;
+    const uint32_t c = rd.contig[i];
+    const int64_t L = T.contig_len[c];
+    const kd_u64 cb = T.contig_base[c];
+    const int64_t sl = rd.seq_len[i];
+    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    const KdCkpt ck = ckpt[(kd_u64)blockIdx.x * KD_BLOCK + t];
+    int64_t r = rd.pos0[i] + (int64_t)ck.r_rel, q = ck.q;
+    kd_u64 e = 0, po = 0;
+    if (sc & KD_INFO_INS) { e = (kd_u64)ins.read_ev[i] + ck.ev; po = ins.read_pool[i] + ck.pool; }
+    uint32_t *tab = T.tab;
+    const kd_u64 S = T.stride;
+    for (uint32_t k = k0; k < k1; k++) {
+        const uint32_t w = cg[k];
+        const int64_t len = w >> 4;
+        const uint32_t op = w & 15u;
+        if (op == 0 || op == 7 || op == 8) { r += len; q += len; }
+        else if (op == 2) { r += len; }
+        else if (op == 1) {
+            const int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
+            const kd_u64 n = (kd_u64)(q1 - q0);
+            const kd_u64 g = cb + (kd_u64)r;
+            if (e >= ins.ev_cap || po + n > ins.pool_cap) {
+                atomicAdd(&status[KDS_INTERNAL], 1ULL);
+            } else if (kd_commit(T, g)) {
+                ins.ev_site[e] = (uint32_t)g; ins.ev_len[e] = (uint32_t)n; ins.ev_off[e] = po;
+                for (kd_u64 b = 0; b < n; b++) ins.pool[po + b] = (uint8_t)kd_nib(seq, q0 + (int64_t)b);
+                atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g], 1u);
+            } else {
+                ins.ev_site[e] = KD_EV_DROPPED; ins.ev_len[e] = 0; ins.ev_off[e] = po;
+            }
+            e += 1; po += n; q += len;
+        } else if (op == 4) {
+            if (k == 0) {
+                const kd_u64 g = cb + (kd_u64)r;
+                if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g], 1u);
+                q += len;
+            } else {  // regular: the last op that touches r
+                const int64_t x = r - 1;
+                const kd_u64 g = cb + (kd_u64)(x < 0 ? x + L + 1 : x);
+                if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
             }
         }
     }
@@ -965,8 +1052,8 @@ __device__ __forceinline__ void kd_add_dword(uint32_t *hist0, int32_t Wh, uint32
 // A state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the current run), not over
 // CIGAR ops, so that lanes keep adding bases together whatever their op structure.  A soft clip is a
 // run of its own on the clip_start / clip_end channel group.
-__device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi,
-                                                int32_t Wh, uint32_t *hist0) {
+__device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, const KdRInfo ri, const KdCkpt *ckpt, kd_u64 wlo,
+                                                int32_t Wi, int32_t Wh, uint32_t *hist0) {
     const int32_t Wp = 2 * Wh;   // sites per channel row, halos included
     const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
     const uint32_t nc = rd.n_cig[i];
@@ -976,10 +1063,22 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
     const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
     int32_t grel = (int32_t)((uint32_t)gs - (uint32_t)wlo);  // window-relative site, may be negative
     int32_t q = 0;
+    uint32_t k = 0;
+    if (ri.pad && grel < 0) {
+        // long CIGAR: enter at the last checkpoint whose reference position is still left of the window
+        const KdCkpt *ck = ckpt + (kd_u64)(ri.pad - 1u) * KD_BLOCK;
+        const uint32_t target = (uint32_t)(-grel);
+        uint32_t lo = 0, hi = KD_BLOCK;   // largest t with ck[t].r_rel <= target (ck[0].r_rel == 0)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (ck[mid].r_rel <= target) lo = mid; else hi = mid;
+        }
+        const uint32_t per = (nc + KD_BLOCK - 1) / KD_BLOCK;
+        if (lo * per < nc) { k = lo * per; grel += (int32_t)ck[lo].r_rel; q = (int32_t)ck[lo].q; }
+    }
     // Per-lane state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the
     // current M run), not over CIGAR ops: lanes whose reads have clips or indels still add
     // bases in the same wavefront instructions as their single-run neighbours.
-    uint32_t k = 0;
     int32_t xa = 0, xb = 0, ra = 0, rb = 0, sx = 0, c = 1, cb = 0;   // c > cb: no live run
     for (;;) {
         while (c > cb && k < nc) {   // advance to the next run with live bases
@@ -1069,7 +1168,7 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
 #define KD_WINDOW_LDS_BYTES(W, tile) ((size_t)KD_HCH * ((W) + 2 * KD_HALO) * 2 + (size_t)2 * (tile) * 2)
 
 __global__ void __launch_bounds__(KD_BLOCK)
-k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
+k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *ckpt, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
          const kd_u64 *item_off, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t slice, uint32_t tile, kd_u64 *status) {
     KD_DYN_SHARED(uint32_t, hist);
     const int32_t Wh = (int32_t)(W + 2 * KD_HALO) >> 1;   // dwords per channel row (two u16 counters each, halos included)
@@ -1136,7 +1235,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, cons
                     const uint32_t e = lane * rows + r;
                     if (e < ncx) {
                         const kd_u64 j = tb + l_cplx[e], i = order ? (kd_u64)order[j] : j;
-                        kd_walk_complex(rd, i, rinfo[i], wlo, Wi, Wh, hist0);
+                        kd_walk_complex(rd, i, rinfo[i], ckpt, wlo, Wi, Wh, hist0);
                     }
                 }
             }
