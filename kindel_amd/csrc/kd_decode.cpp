@@ -24,13 +24,42 @@ namespace {
 
 std::string g_decode_error;
 
+// Growable array WITHOUT value-initialisation: resize() of a fresh array does not touch the pages, so the
+// worker threads that fill it take the page faults in parallel (a zero-filling std::vector::resize of a few
+// hundred MB on one thread was most of the decode time).
+template <class T>
+struct Arr {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    Arr() = default;
+    Arr(const Arr &) = delete;
+    Arr &operator=(const Arr &) = delete;
+    ~Arr() { free(p); }
+    bool resize(size_t m) {
+        if (m > cap) {
+            size_t c = std::max(m, cap + cap / 2 + 16);
+            T *q = (T *)realloc(p, c * sizeof(T));
+            if (!q) return false;
+            p = q; cap = c;
+        }
+        n = m;
+        return true;
+    }
+    void push_back(const T &v) { resize(n + 1); p[n - 1] = v; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
 struct File {
     std::vector<std::string> names;
     std::vector<uint32_t> lens;
-    std::vector<uint32_t> contig, flag, seq_len, n_cig, cigar;
-    std::vector<int32_t> pos0;
-    std::vector<uint64_t> seq_off, cig_off;
-    std::vector<uint8_t> seq4;
+    Arr<uint32_t> contig, flag, seq_len, n_cig, cigar;
+    Arr<int32_t> pos0;
+    Arr<uint64_t> seq_off, cig_off;
+    Arr<uint8_t> seq4;
     uint64_t n_records = 0;
     kd_batch view;
 };
@@ -38,14 +67,14 @@ struct File {
 inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | p[1] << 8); }
 
-bool read_all(const char *path, std::vector<uint8_t> &out) {
+bool read_all(const char *path, Arr<uint8_t> &out) {
     FILE *f = fopen(path, "rb");
     if (!f) return false;
     fseek(f, 0, SEEK_END);
     long n = ftell(f);
     fseek(f, 0, SEEK_SET);
     out.resize(n > 0 ? (size_t)n : 0);
-    size_t got = out.empty() ? 0 : fread(out.data(), 1, out.size(), f);
+    size_t got = out.size() ? fread(out.data(), 1, out.size(), f) : 0;
     fclose(f);
     return got == out.size();
 }
@@ -53,7 +82,7 @@ bool read_all(const char *path, std::vector<uint8_t> &out) {
 struct Block { size_t in_off, in_len, out_off, out_len; };
 
 // Split a BGZF file into its blocks using the BC extra subfield (SAMv1 4.1).
-bool scan_bgzf(const std::vector<uint8_t> &raw, std::vector<Block> &blocks, size_t &total) {
+bool scan_bgzf(const Arr<uint8_t> &raw, std::vector<Block> &blocks, size_t &total) {
     size_t o = 0;
     total = 0;
     while (o + 18 <= raw.size()) {
@@ -91,7 +120,7 @@ bool inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
 }
 
 // generic (non-BGZF) gzip: single stream, possibly several members
-bool inflate_generic(const std::vector<uint8_t> &raw, std::vector<uint8_t> &out) {
+bool inflate_generic(const Arr<uint8_t> &raw, Arr<uint8_t> &out) {
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, 15 + 32) != Z_OK) return false;
@@ -115,7 +144,7 @@ bool inflate_generic(const std::vector<uint8_t> &raw, std::vector<uint8_t> &out)
     return true;
 }
 
-bool decompress(const std::vector<uint8_t> &raw, std::vector<uint8_t> &out, int n_threads) {
+bool decompress(const Arr<uint8_t> &raw, Arr<uint8_t> &out, int n_threads) {
     std::vector<Block> blocks;
     size_t total = 0;
     if (!scan_bgzf(raw, blocks, total)) return inflate_generic(raw, out);
@@ -140,8 +169,9 @@ bool decompress(const std::vector<uint8_t> &raw, std::vector<uint8_t> &out, int 
 }
 
 void finish_view(File &f) {
-    f.seq4.resize(f.seq4.size() + 8, 0);  // slack so vector loads at the tail stay in bounds
-    f.cigar.resize(f.cigar.size() + 2, 0);
+    // slack so vector loads at the tail stay in bounds
+    for (int k = 0; k < 8; k++) f.seq4.push_back(0);
+    for (int k = 0; k < 2; k++) f.cigar.push_back(0);
     kd_batch &v = f.view;
     v.n_reads = f.contig.size();
     v.contig = f.contig.data(); v.pos0 = f.pos0.data(); v.flag = f.flag.data(); v.seq_off = f.seq_off.data();
@@ -150,7 +180,7 @@ void finish_view(File &f) {
     v.cigar = f.cigar.data(); v.cigar_words = f.cigar.size() - 2;
 }
 
-int parse_bam(const std::vector<uint8_t> &d, File &f) {
+int parse_bam(const Arr<uint8_t> &d, File &f, int n_threads) {
     const size_t n = d.size();
     if (n < 12 || memcmp(d.data(), "BAM\1", 4) != 0) { g_decode_error = "not a BAM stream"; return KD_E_IO; }
     size_t o = 8 + (size_t)rd32(d.data() + 4);
@@ -165,8 +195,10 @@ int parse_bam(const std::vector<uint8_t> &d, File &f) {
         f.lens.push_back(rd32(d.data() + o + 4 + l_name));
         o += 8 + l_name;
     }
-    // pass 1: count, so the SoA vectors are allocated once
-    size_t n_keep = 0, seq_bytes = 0, cig_words = 0, p = o;
+    // pass 1 (sequential, touches 4 + 20 bytes per record): follow the block_size chain, record where every kept
+    // record starts and the running totals of packed-base bytes / CIGAR words
+    std::vector<uint64_t> rec_at, seq_at, cig_at;
+    size_t seq_bytes = 0, cig_words = 0, p = o;
     while (p + 4 <= n) {
         const uint32_t bs = rd32(d.data() + p);
         if (p + 4 + bs > n || bs < 32) { g_decode_error = "truncated BAM record"; return KD_E_IO; }
@@ -175,47 +207,48 @@ int parse_bam(const std::vector<uint8_t> &d, File &f) {
         f.n_records++;
         if (refid >= 0) {
             if ((uint32_t)refid >= n_ref) { g_decode_error = "BAM record with refID out of range"; return KD_E_IO; }
-            n_keep++;
-            seq_bytes += ((size_t)rd32(r + 16) + 1) / 2;
-            cig_words += rd16(r + 12);
+            const uint32_t l_rn = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
+            if (32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 > bs) { g_decode_error = "malformed BAM record"; return KD_E_IO; }
+            rec_at.push_back(p + 4); seq_at.push_back(seq_bytes); cig_at.push_back(cig_words);
+            seq_bytes += ((size_t)l_seq + 1) / 2;
+            cig_words += n_cig;
         }
         p += 4 + bs;
     }
+    const size_t n_keep = rec_at.size();
     f.contig.resize(n_keep); f.pos0.resize(n_keep); f.flag.resize(n_keep); f.seq_off.resize(n_keep);
     f.seq_len.resize(n_keep); f.cig_off.resize(n_keep); f.n_cig.resize(n_keep);
     f.seq4.resize(seq_bytes); f.cigar.resize(cig_words);
-    size_t k = 0, so = 0, co = 0;
-    p = o;
-    while (p + 4 <= n) {
-        const uint32_t bs = rd32(d.data() + p);
-        const uint8_t *r = d.data() + p + 4;
-        const int32_t refid = (int32_t)rd32(r);
-        if (refid >= 0) {
-            const uint32_t l_rn = r[8], n_cig = rd16(r + 12), flag = rd16(r + 14), l_seq = rd32(r + 16);
-            const size_t need = 32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2;
-            if (need > bs) { g_decode_error = "malformed BAM record"; return KD_E_IO; }
-            f.contig[k] = (uint32_t)refid;
+    // pass 2 (parallel): every record writes its own slots of the SoA arrays
+    auto fill = [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; k++) {
+            const uint8_t *r = d.data() + rec_at[k];
+            const uint32_t l_rn = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
+            f.contig[k] = rd32(r);
             f.pos0[k] = (int32_t)rd32(r + 4);
-            f.flag[k] = flag;
+            f.flag[k] = rd16(r + 14);
             f.seq_len[k] = l_seq;
             f.n_cig[k] = n_cig;
-            f.cig_off[k] = co;
-            f.seq_off[k] = so;
+            f.cig_off[k] = cig_at[k];
+            f.seq_off[k] = seq_at[k];
             const uint8_t *cg = r + 32 + l_rn;
-            for (uint32_t c = 0; c < n_cig; c++) f.cigar[co + c] = rd32(cg + 4 * c);
-            co += n_cig;
+            for (uint32_t c = 0; c < n_cig; c++) f.cigar[cig_at[k] + c] = rd32(cg + 4 * c);
             const size_t sb = ((size_t)l_seq + 1) / 2;
-            memcpy(f.seq4.data() + so, cg + 4 * (size_t)n_cig, sb);
-            if (l_seq & 1) f.seq4[so + sb - 1] &= 0xf0;
-            so += sb;
-            k++;
+            memcpy(f.seq4.data() + seq_at[k], cg + 4 * (size_t)n_cig, sb);
+            if (l_seq & 1) f.seq4[seq_at[k] + sb - 1] &= 0xf0;
         }
-        p += 4 + bs;
-    }
+    };
+    unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+    nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, n_keep / 4096));
+    std::vector<std::thread> th;
+    const size_t per = (n_keep + nt - 1) / std::max(1u, nt);
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(fill, std::min(n_keep, t * per), std::min(n_keep, (t + 1) * per));
+    fill(0, std::min(n_keep, per));
+    for (auto &t : th) t.join();
     return KD_OK;
 }
 
-int parse_sam(const std::vector<uint8_t> &raw, File &f) {
+int parse_sam(const Arr<uint8_t> &raw, File &f) {
     static int8_t nibtab[256];
     static int8_t optab[256];
     static bool init = false;
@@ -321,16 +354,14 @@ extern "C" {
 int kd_decode_open(kd_file **out, const char *path, int n_threads) {
     if (!out || !path) return KD_E_ARG;
     *out = nullptr;
-    std::vector<uint8_t> raw;
+    Arr<uint8_t> raw;
     if (!read_all(path, raw)) { g_decode_error = std::string("cannot read ") + path; return KD_E_IO; }
     kd_file *h = new kd_file();
     int rc;
     if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) {
-        std::vector<uint8_t> data;
+        Arr<uint8_t> data;
         if (!decompress(raw, data, n_threads)) { delete h; g_decode_error = "gzip/BGZF inflate failed"; return KD_E_IO; }
-        raw.clear();
-        raw.shrink_to_fit();
-        rc = parse_bam(data, h->f);
+        rc = parse_bam(data, h->f, n_threads);
     } else {
         rc = parse_sam(raw, h->f);
     }

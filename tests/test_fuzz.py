@@ -1,0 +1,55 @@
+"""Seeded CIGAR fuzzing: random reads with arbitrary op sequences -- valid and invalid -- engine vs oracle.
+CPU: kernel logic under the emulator.  GPU (`-m gpu`): the HIP library."""
+import numpy as np
+import pytest
+
+from kindel_amd import _native as N
+from tests import fuzz
+
+MODES = [N.KD_MODE_GLOBAL, N.KD_MODE_AUTO]
+
+
+def _campaign(lib, seeds, n_reads, wild):
+    outcomes = {"ok": 0, "raise": 0}
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        batch = fuzz.random_batch(rng, n_reads, wild=wild, sort=bool(seed & 1))
+        for mode in MODES:
+            outcomes[fuzz.check_engine(lib, batch, mode, window=64, slice_reads=[0, 16][seed % 2])] += 1
+    return outcomes
+
+
+def test_fuzz_valid_reads_emulated(emu_lib):
+    out = _campaign(emu_lib, range(100, 112), n_reads=60, wild=0.0)
+    assert out["ok"] >= 8      # mostly valid inputs: the comparison is on full tables
+
+
+def test_fuzz_wild_reads_emulated(emu_lib):
+    out = _campaign(emu_lib, range(200, 212), n_reads=12, wild=0.3)
+    assert out["raise"] >= 2 and out["ok"] >= 2
+
+
+def test_oracle_fuzz_is_deterministic():
+    a = fuzz.random_batch(np.random.default_rng(5), 30)
+    b = fuzz.random_batch(np.random.default_rng(5), 30)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+
+
+@pytest.mark.gpu
+def test_fuzz_valid_reads_gpu(hip_lib):
+    out = _campaign(hip_lib, range(1000, 1150), n_reads=300, wild=0.0)
+    assert out["ok"] >= 100
+
+
+@pytest.mark.gpu
+def test_fuzz_wild_reads_gpu(hip_lib):
+    out = _campaign(hip_lib, range(2000, 2400), n_reads=10, wild=0.25)
+    assert out["raise"] >= 50 and out["ok"] >= 50
+
+
+@pytest.mark.gpu
+def test_fuzz_large_valid_batch_gpu(hip_lib):
+    rng = np.random.default_rng(77)
+    batch = fuzz.random_batch(rng, 20000, contig_lens=(5000, 3000, 800), wild=0.0, sort=True)
+    for mode in MODES:
+        assert fuzz.check_engine(hip_lib, batch, mode, window=256) in ("ok", "raise")
