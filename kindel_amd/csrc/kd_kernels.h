@@ -224,7 +224,7 @@ __device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc,
                 s.lead = (uint32_t)(len < r ? len : (r > 0 ? r : 0));
                 q += len;
             } else {
-                if (seen_nfs) regular = false;
+                if (seen_nfs || r - 1 > L) regular = false;   // clip_starts[r - 1] must exist (kindel.py:75)
                 seen_nfs = true;
                 int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
                 if (n_adv > sl - q || (len > n_adv && q + n_adv >= sl)) regular = false;
@@ -460,6 +460,7 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdC
             if (k == 0) { if (r > L || len > sl) bad = 1; q += len; }
             else {
                 if (k < first_nfs) first_nfs = k;
+                if (r - 1 > L) bad = 1;   // clip_starts[r - 1] must exist (kindel.py:75)
                 int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
                 if (n_adv > sl - q || (len > n_adv && q + n_adv >= sl)) bad = 1;
                 last_rel = k;

@@ -98,6 +98,8 @@ CASES = {
     "ERR_pos_far_past_L": _mk(_HDR1, ("a", 0, "c1", 40, "4M", "ACGT")),
     "ERR_insertion_past_slot_L": _mk(_HDR1, ("a", 0, "c1", 25, "4M3D2I", "ACGTAA")),
     "ERR_leading_S_past_slot_L": _mk(_HDR1, ("a", 0, "c1", 32, "4S", "ACGT")),
+    "ERR_nonfirst_S_past_slot_L": _mk(_HDR1, ("a", 0, "c1", 33, "4P0H6S", "ACGTA")),
+    "nonfirst_S_at_slot_L": _mk(_HDR1, ("a", 0, "c1", 32, "4P0H6S", "ACGTA")),
     "ERR_eq_base_in_M": _mk(_HDR1, ("a", 0, "c1", 2, "4M", "AC=T")),
     "ERR_second_contig_only": _mk(_HDR2, ("a", 0, "c1", 3, "4M", "ACGT"), ("b", 0, "c2", 18, "6M", "ACGTAC")),
 }
