@@ -1166,13 +1166,14 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
 }
 
 #define KD_TILE_MAX 2048   // reads classified together (runtime `tile`, a multiple of KD_BLOCK)
-#define KD_WINDOW_LDS_BYTES(W, tile) ((size_t)KD_HCH * ((W) + 2 * KD_HALO) * 2 + (size_t)2 * (tile) * 2)
+#define KD_WINDOW_LDS_BYTES(Wh, tile) ((size_t)KD_HCH * (Wh) * 4 + (size_t)2 * (tile) * 2)   // Wh = dwords per channel row
 
 __global__ void __launch_bounds__(KD_BLOCK)
 k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *ckpt, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
-         const kd_u64 *item_off, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t slice, uint32_t tile, kd_u64 *status) {
+         const kd_u64 *item_off, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t Wh_, uint32_t slice, uint32_t tile,
+         kd_u64 *status) {
     KD_DYN_SHARED(uint32_t, hist);
-    const int32_t Wh = (int32_t)(W + 2 * KD_HALO) >> 1;   // dwords per channel row (two u16 counters each, halos included)
+    const int32_t Wh = (int32_t)Wh_;   // dwords per channel row (two u16 counters each, halos included; >= (W + 2*KD_HALO)/2)
     uint32_t *hist0 = hist + KD_HALO / 2;                 // word of window-relative site 0
     uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * Wh);  // tile-relative read indices
     uint16_t *l_cplx = l_plain + tile;
