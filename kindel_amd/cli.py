@@ -30,6 +30,12 @@ def features(args):
     kindel.features(args.bam_path).to_csv(sys.stdout, sep="\t", index=False)
 
 
+def variants(args):
+    from . import kindel
+    df = kindel.variants(args.bam_path, args.abs_threshold, args.rel_threshold, not args.all_alleles, args.absolute)
+    df.to_csv(sys.stdout, sep="\t", index=False)
+
+
 def plot(args):
     from . import kindel
     return kindel.plotly_clips(args.bam_path)
@@ -65,6 +71,14 @@ def build_parser():
     f = sub.add_parser("features", help="Returns table of per-site nucleotide frequencies and coverage including indels")
     f.add_argument("bam_path", help="path to SAM/BAM file")
     f.set_defaults(func=features)
+    va = sub.add_parser("variants", help="Output variants exceeding specified absolute and relative frequency "
+                        "thresholds (extension: announced in the reference README, not implemented there)")
+    va.add_argument("bam_path", help="path to SAM/BAM file")
+    va.add_argument("-a", "--abs-threshold", type=int, default=1, help="minimum allele count")
+    va.add_argument("-r", "--rel-threshold", type=float, default=0.01, help="minimum allele frequency")
+    va.add_argument("--all-alleles", action="store_true", default=False, help="also list the majority allele")
+    va.add_argument("--absolute", action="store_true", default=False, help="omit the frequency column")
+    va.set_defaults(func=variants)
     pl = sub.add_parser("plot", help="Plot sitewise soft clipping frequency across reference and genome")
     pl.add_argument("bam_path", help="path to SAM/BAM file")
     pl.set_defaults(func=plot)

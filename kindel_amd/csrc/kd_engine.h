@@ -273,7 +273,6 @@ struct KdEngine {
             if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, d_status)) return hipfail("k_plan_scan");
             const uint32_t tile = getenv("KD_TILE") ? (uint32_t)atoi(getenv("KD_TILE")) : 1024u;  // multiple of KD_BLOCK, <= KD_TILE_MAX
             uint32_t Wh = (W + 2 * KD_HALO) / 2;   // dwords per channel row
-            if (getenv("KD_WHPAD")) Wh = (Wh + 31u) & ~31u;   // experiment: row stride a multiple of the 32 LDS banks
             const size_t lds = KD_WINDOW_LDS_BYTES(Wh, tile);
             const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
             const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);

@@ -564,6 +564,70 @@ def features(bam_path):
     return df.round(3)
 
 
+def variants(bam_path, abs_threshold=1, rel_threshold=0.01, only_variants=True, absolute=False):
+    """EXTENSION -- parity unpinned.  The reference advertises a `variants` sub-command ("Output variants
+    exceeding specified absolute and relative frequency thresholds", README.md:106) but ships no
+    implementation (cli.py:64-66 registers consensus/weights/features/plot/version only), so there is nothing
+    to be bit-exact against.  This is a thresholded filter over the same device tables `weights()` uses:
+
+    one row per (site, allele) whose count >= abs_threshold and count / depth >= rel_threshold, where
+    depth = A+C+G+T+N+deletions (the `depth` column of weights(), kindel.py:586), alleles are A,C,G,T,
+    "-" (deletion of the site) and "+<TEXT>" (insertion keyed before the site, upper-case as stored, :55-58);
+    `ref` is the site's majority allele over A,T,G,C,N (first max in that order, "N" when empty, :369-381).
+    only_variants drops rows whose allele equals `ref`; absolute=True reports counts instead of frequencies.
+    Columns: chrom, pos (1-based), ref, alt, type (snv|del|ins), count, depth, frequency."""
+    import pandas as pd
+
+    pl = pileup_file(bam_path)
+    frames = []
+    for cid in pl.order:
+        t = pl.tables(cid).astype(np.int64)
+        L = int(pl.lens[cid])
+        if L == 0:
+            continue
+        five = t[0:5, :L]                                        # A,T,G,C,N
+        depth = five.sum(axis=0) + t[N.KD_CH_DEL, :L]
+        ref = np.array(list("ATGCN"))[np.argmax(five, axis=0)]
+        ref[five.sum(axis=0) == 0] = "N"
+        safe = np.maximum(depth, 1)
+
+        def rows(sites, alt, kind, count):
+            if len(sites) == 0:
+                return None
+            d = depth[sites]
+            return pd.DataFrame(OrderedDict([
+                ("chrom", np.full(len(sites), pl.names[cid], dtype=object)), ("pos", sites + 1),
+                ("ref", ref[sites]), ("alt", alt), ("type", np.full(len(sites), kind, dtype=object)),
+                ("count", count), ("depth", d), ("frequency", np.round(count / np.maximum(d, 1), 4))]))
+
+        for ch, nt in ((N.KD_CH_A, "A"), (N.KD_CH_C, "C"), (N.KD_CH_G, "G"), (N.KD_CH_T, "T")):
+            c = t[ch, :L]
+            keep = (c >= max(abs_threshold, 1)) & (c >= rel_threshold * safe) & (depth > 0)
+            if only_variants:
+                keep &= ref != nt
+            sites = np.flatnonzero(keep)
+            frames.append(rows(sites, np.full(len(sites), nt, dtype=object), "snv", c[sites]))
+        c = t[N.KD_CH_DEL, :L]
+        sites = np.flatnonzero((c >= max(abs_threshold, 1)) & (c >= rel_threshold * safe))
+        frames.append(rows(sites, np.full(len(sites), "-", dtype=object), "del", c[sites]))
+        site, count, strings = pl.engine.insertions(cid)
+        site, count = np.asarray(site, np.int64), np.asarray(count, np.int64)
+        ok = site < L                                            # slot L is never emitted (kindel.py:390)
+        ok &= (count >= max(abs_threshold, 1)) & (count >= rel_threshold * safe[np.minimum(site, L - 1)])
+        idx = np.flatnonzero(ok)
+        frames.append(rows(site[idx], np.array(["+" + strings[i] for i in idx], dtype=object), "ins", count[idx]))
+    frames = [f for f in frames if f is not None]
+    cols = ["chrom", "pos", "ref", "alt", "type", "count", "depth", "frequency"]
+    if not frames:
+        return pd.DataFrame(columns=cols)
+    df = pd.concat(frames, ignore_index=True)
+    order = {name: i for i, name in enumerate(pl.names[c] for c in pl.order)}
+    df = df.assign(_c=df.chrom.map(order)).sort_values(["_c", "pos", "type", "alt"], kind="stable").drop(columns="_c")
+    if absolute:
+        df = df.drop(columns="frequency")
+    return df.reset_index(drop=True)
+
+
 def plotly_clips(bam_path):
     """kindel.py:667-703: HTML depth / soft-clip plot of the first contig (needs plotly)."""
     import plotly.graph_objs as go

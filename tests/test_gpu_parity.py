@@ -208,6 +208,18 @@ def test_weights_dataframe(hip_lib, tmp_path):
                     assert (a.astype(str) == b.astype(str)).all() if a.dtype == object else np.array_equal(a, b), (key, tag, c)
 
 
+def test_variants_extension(hip_lib, tmp_path):
+    from kindel_amd import kindel as K
+    for key in ("minimap2__1.1.multi", "bwa_mem__1.1.sub_test"):
+        path = _bam_from_fixture(tmp_path, key)
+        for a, r, only in ((1, 0.01, True), (5, 0.1, False)):
+            df = K.variants(path, abs_threshold=a, rel_threshold=r, only_variants=only)
+            assert P.variants_rows(df) == P.expected_variants(P.load_fixture(key), a, r, only), (key, a, r, only)
+    r = subprocess.run([sys.executable, "-m", "kindel_amd", "variants", "-a", "5", path], cwd=ROOT, capture_output=True,
+                       text=True)
+    assert r.returncode == 0 and r.stdout.startswith("chrom\tpos\tref\talt\ttype\tcount\tdepth\tfrequency")
+
+
 def test_cli_consensus_stdout(hip_lib, tmp_path):
     key = "ext__3.issue23.bc75"
     path = _bam_from_fixture(tmp_path, key)

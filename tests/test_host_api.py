@@ -139,6 +139,20 @@ def test_weights_dataframe_multi_contig(api_on_emu, tmp_path):
     K.features(path)   # smoke, like the reference's test (and: no multi-contig crash)
 
 
+@pytest.mark.parametrize("key", ["minimap2__1.1.multi", "ext__3.issue23.bc75"])
+def test_variants_extension(api_on_emu, tmp_path, key):
+    """variants() has no reference implementation (README.md:106 only): checked against a brute-force filter
+    over the oracle's tables."""
+    from kindel_amd import kindel as K
+    path = _bam(tmp_path, key)
+    for a, r, only in ((1, 0.01, True), (3, 0.2, True), (1, 0.0, False)):
+        df = K.variants(path, abs_threshold=a, rel_threshold=r, only_variants=only)
+        assert P.variants_rows(df) == P.expected_variants(P.load_fixture(key), a, r, only), (a, r, only)
+        assert list(df.columns) == ["chrom", "pos", "ref", "alt", "type", "count", "depth", "frequency"]
+        assert np.allclose(df["frequency"], np.round(df["count"] / df["depth"].clip(lower=1), 4))
+    assert "frequency" not in K.variants(path, absolute=True).columns
+
+
 def test_cli_in_process(api_on_emu, tmp_path):
     from kindel_amd import cli
     key = "ext__3.issue23.bc75"
