@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C3", help="C2 | C3 | C4 | C5 (SURVEY.md section 8d)")
+    ap.add_argument("--synth", action="append", default=[], metavar="KEY=VALUE",
+                    help="override a synthetic-generator parameter (sensitivity runs; not the BASELINE workload)")
     ap.add_argument("--scale", type=float, default=1.0, help="depth multiplier (1.0 = the config as specified)")
     ap.add_argument("--mode", default="auto", choices=["auto", "global", "window"])
     ap.add_argument("--window", type=int, default=0)
@@ -76,6 +78,9 @@ def main():
     dev = "cuda:%d" % dev_index
 
     cfg = dict(synth.CONFIGS[args.config])
+    for kv in args.synth:            # sensitivity runs only, e.g. --synth clip_p=0 --synth indel_p=0 --synth planted=0
+        k, v = kv.split("=")
+        cfg[k] = float(v) if "." in v else int(v)
     if world > 1 and cfg["kind"] != "short":
         raise SystemExit("multi-GPU bench: short-read configs only (C2, C3, C4)")
     cfg["contig_lens"] = list(cfg["contig_lens"]) * world  # weak scaling: one config-sized interval per rank
@@ -198,7 +203,8 @@ def main():
             scaling="weak", vs_baseline=None, dtype="u32", data="synthetic",
             config=dict(workload="%s: synthetic %s, %d contig(s), %d sites, depth %gx%s" % (
                 args.config, "150 bp short reads" if cfg["kind"] == "short" else "ONT-like long reads",
-                n_contigs, sites, cfg["depth"], "" if args.scale == 1.0 else " (scaled)"),
+                n_contigs, sites, cfg["depth"], ("" if args.scale == 1.0 else " (scaled)") +
+                (" [generator overrides: %s]" % ",".join(args.synth) if args.synth else "")),
                 reads=reads_g, aligned_events=aligned_g, walked_events=walked_g, cigar_ops=ops_g,
                 parallelism="interval-sharded x%d" % world if world > 1 else "single GPU",
                 pileup_path="window-lds" if info["windowed"] else "global-atomics",

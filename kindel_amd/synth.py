@@ -46,8 +46,11 @@ def _pack_nibbles(codes):
 
 
 def short_reads(contig_lens, depth, read_len=150, seed=0, device="cpu", planted=True, chunk=1 << 20,
-                shard=None):
+                shard=None, clip_p=0.05, indel_p=0.075):
     """-> dict of torch tensors (FIELDS + contig_lens) for a coordinate-sorted short-read batch.
+
+    clip_p: probability of a leading (and, independently, trailing) soft clip; indel_p: probability of one
+    insertion (and, separately, one deletion) per read -- the SURVEY section 8d error model is the default.
 
     shard=(rank, world): generate only the reads whose contig/interval belongs to `rank` under
     kindel_amd.shard.partition (used by bench.py --gpus N so every rank synthesises its own part).
@@ -83,12 +86,12 @@ def short_reads(contig_lens, depth, read_len=150, seed=0, device="cpu", planted=
             gap0, gap1 = L // 2, L // 2 + 4 * rl                      # zero-coverage gap (ties live inside)
         for s0 in range(0, n, chunk):
             m = min(chunk, n - s0)
-            s1 = torch.where(torch.rand(m, generator=g, device=dev) < 0.05,
+            s1 = torch.where(torch.rand(m, generator=g, device=dev) < clip_p,
                              torch.randint(5, 41, (m,), generator=g, device=dev), torch.zeros(m, dtype=torch.int64, device=dev))
-            s2 = torch.where(torch.rand(m, generator=g, device=dev) < 0.05,
+            s2 = torch.where(torch.rand(m, generator=g, device=dev) < clip_p,
                              torch.randint(5, 41, (m,), generator=g, device=dev), torch.zeros(m, dtype=torch.int64, device=dev))
             u = torch.rand(m, generator=g, device=dev)
-            ityp = torch.where(u < 0.075, 1, torch.where(u < 0.15, 2, 0)).to(torch.int64)  # 1 = I, 2 = D
+            ityp = torch.where(u < indel_p, 1, torch.where(u < 2 * indel_p, 2, 0)).to(torch.int64)  # 1 = I, 2 = D
             ilen = torch.minimum(_geom(g, m, 0.7, dev), torch.tensor(20, device=dev))
             qins = torch.where(ityp == 1, ilen, torch.zeros_like(ilen))
             alen = rl - s1 - s2 - qins                                # aligned query bases

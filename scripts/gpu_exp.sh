@@ -1,15 +1,12 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out
-run() { python bench.py --steps 3 --warmup 1 --no-cpu-baseline --sweep "auto:448:0,auto:896:0" > gpurun_out/exp.json 2> gpurun_out/exp.err; python - <<PY
-import json; d=json.load(open("gpurun_out/exp.json")); print("$1", "W=640 %.2f ms"%d["ms_per_step"], "k_window", d["kernels"]["k_window"]["avg_ms"], end=" | ")
-for l in open("gpurun_out/exp.err"):
-    if l.startswith('{"sweep'):
-        s=json.loads(l); print(s["sweep"], s["kernels"]["k_window"], end=" ")
-print()
+run() { tag=$1; shift; python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/exp_$tag.json 2> gpurun_out/exp_$tag.err || tail -3 gpurun_out/exp_$tag.err; python - <<PY
+import json; d=json.load(open("gpurun_out/exp_$tag.json")); k=d["kernels"]
+print("$tag", "%.2f ms"%d["ms_per_step"], "events %.3g"%d["config"]["aligned_events"], " ".join("%s=%.3f"%(n[2:],k[n]["avg_ms"]) for n in ("k_window","k_prep","k_cold_lane","k_ins_insert","k_cns_count") if n in k))
 PY
 }
-KD_TILE=1024 run "tile1024"
-KD_TILE=512 run "tile512"
-KD_TILE=1024 KD_WHPAD=1 run "tile1024+pad"
-KD_TILE=512 KD_WHPAD=1 run "tile512+pad"
-KD_TILE=256 KD_WHPAD=1 run "tile256+pad"
+run base
+run plain --synth clip_p=0.0 --synth indel_p=0.0 --synth planted=0
+run noclip --synth clip_p=0.0
+run noindel --synth indel_p=0.0 --synth planted=0
+python scripts/e2e_bench.py --config C3 --scale 0.1 --out gpurun_out/e2e_c3.json
