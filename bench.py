@@ -77,6 +77,9 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = "cuda:%d" % dev_index
 
+    if os.environ.get("KD_BENCH_LIB"):   # kernel experiments: a differently built library (never the default)
+        from kindel_amd import _native as _N
+        _N._default = _N.Library(os.environ["KD_BENCH_LIB"])
     cfg = dict(synth.CONFIGS[args.config])
     for kv in args.synth:            # sensitivity runs only, e.g. --synth clip_p=0 --synth indel_p=0 --synth planted=0
         k, v = kv.split("=")

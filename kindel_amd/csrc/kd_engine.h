@@ -273,6 +273,9 @@ struct KdEngine {
             if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, d_status)) return hipfail("k_plan_scan");
             const uint32_t tile = getenv("KD_TILE") ? (uint32_t)atoi(getenv("KD_TILE")) : 1024u;  // multiple of KD_BLOCK, <= KD_TILE_MAX
             uint32_t Wh = (W + 2 * KD_HALO) / 2;   // dwords per channel row
+#if defined(KD_EXP) && (KD_EXP == 4 || KD_EXP == 5)
+            Wh = (Wh + 31u) & ~31u;   // timing experiment: row stride a multiple of the 32 LDS banks
+#endif
             const size_t lds = KD_WINDOW_LDS_BYTES(Wh, tile);
             const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
             const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
@@ -335,6 +338,16 @@ struct KdEngine {
         int rc;
         if ((rc = fetch_status())) return rc;
         if (h_status[KDS_INTERNAL]) return fail(KD_E_INTERNAL, "insertion event buffers overran (internal error)");
+#if defined(KD_EXP) && KD_EXP == 20
+        {
+            const char *nm[8] = {"dequeue", "zero", "classify", "plain", "complex", "barrier-wait", "flush", "waves"};
+            double tot = 0;
+            for (int k = 0; k < 7; k++) tot += (double)h_status[KDS_DBG0 + k];
+            fprintf(stderr, "k_window phase clocks (sum over wavefronts):");
+            for (int k = 0; k < 8; k++) fprintf(stderr, " %s=%.3g(%.1f%%)", nm[k], (double)h_status[KDS_DBG0 + k], 100.0 * h_status[KDS_DBG0 + k] / tot);
+            fprintf(stderr, "\n");
+        }
+#endif
         if (h_status[KDS_ERR_READ] != ~0ULL) {
             if (err_read) *err_read = h_status[KDS_ERR_READ];
             const uint64_t code = h_status[KDS_ERR_CODE];

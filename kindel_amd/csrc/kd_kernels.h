@@ -94,6 +94,9 @@ enum {
     KDS_INS_COLLISION,  // hash verification failed
     KDS_INTERNAL,       // capacity overrun etc.
     KDS_BAD_BASE,       // k_window: windows that saw a base outside A,C,G,T,N
+#if defined(KD_EXP) && KD_EXP == 20
+    KDS_DBG0, KDS_DBG1, KDS_DBG2, KDS_DBG3, KDS_DBG4, KDS_DBG5, KDS_DBG6, KDS_DBG7,   // phase clocks (profiling build only)
+#endif
     KDS_COUNT
 };
 
@@ -1018,6 +1021,15 @@ __device__ __forceinline__ void kd_hadd(uint32_t *hist0, int32_t Wh, uint32_t ch
 // all 8 bases of dword v are added; s0 = window-relative site of its first base.  Even bases go through pointer h
 // with add value vp, odd bases through hq = h + (s0 & 1) with vq: no per-base parity arithmetic.
 __device__ __forceinline__ void kd_add8_full(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t s0) {
+#if defined(KD_EXP) && (KD_EXP == 4 || KD_EXP == 5)   /* timing experiment: lane-determined, bank-conflict-free start sites */
+    {
+        const int32_t ln = (int32_t)(threadIdx.x & 63u);
+        int32_t s1 = (s0 & ~63) | ((ln & 31) << 1) | (ln >> 5);
+        if (s1 > 2 * Wh - 2 * KD_HALO - 80) s1 -= 64;
+        if (s1 < 0) s1 += 64;
+        s0 = s1;
+    }
+#endif
     const int32_t p = s0 & 1;
     // byte addressing: address = row base + ch * (row bytes) + constant, one 24-bit multiply-add per base
     // (v_mad_u32_u24 is full rate; a 32-bit v_mul_lo_u32 is not)
@@ -1027,9 +1039,19 @@ __device__ __forceinline__ void kd_add8_full(uint32_t *hist0, int32_t Wh, uint32
     const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
+#if defined(KD_EXP) && KD_EXP == 2   /* timing experiment: no LUT */
+        const uint32_t ch = 0;
+#elif defined(KD_EXP) && (KD_EXP == 3 || KD_EXP == 5) /* timing experiment: row = nibble & 7 */
+        const uint32_t ch = (v >> KD_NIB_SHIFT(b)) & 7u;
+#else
         const uint32_t ch = kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u);
+#endif
         unsigned char *a = ((b & 1) ? hq : h) + KD_MUL24(ch, rowb) + 4 * (b >> 1);
+#if defined(KD_EXP) && KD_EXP == 1   /* timing experiment: no LDS atomic */
+        asm volatile("" ::"v"(a), "v"((b & 1) ? vq : vp));
+#else
         atomicAdd(reinterpret_cast<uint32_t *>(a), (b & 1) ? vq : vp);
+#endif
     }
 }
 // only bases [blo, bhi) belong to the run
@@ -1138,6 +1160,134 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
     }
 }
 
+// Bases of dword v whose bit is set in m (bit b = base b) are added; the others add 0 to a counter at most
+// 7 sites away from a live one, i.e. inside the row (halo included).  No branches: lanes whose dword is cut
+// by a run end, a clip end or the window edge stay in step with lanes whose dword is whole.
+__device__ __forceinline__ void kd_add8_masked(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t s0, uint32_t m) {
+    const int32_t p = s0 & 1;
+    unsigned char *h = reinterpret_cast<unsigned char *>(hist0 + (s0 >> 1));
+    unsigned char *hq = h + 4 * p;
+    const uint32_t rowb = (uint32_t)Wh * 4u;
+    const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
+    const uint32_t me = m << (16 * p), mo = m << (16 - 16 * p);   // bit b of m moved onto the add value's bit
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const uint32_t ch = kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u);
+        unsigned char *a = ((b & 1) ? hq : h) + KD_MUL24(ch, rowb) + 4 * (b >> 1);
+        atomicAdd(reinterpret_cast<uint32_t *>(a), (b & 1) ? ((mo >> b) & vq) : ((me >> b) & vp));
+    }
+}
+// one 16-byte chunk (query bases xs .. xs+31) against the live query range [lo, hi) of a segment
+__device__ __forceinline__ void kd_add_chunk_masked(uint32_t *hist0, int32_t Wh, const KdChunk &cur, int32_t xs, int32_t lo,
+                                                    int32_t hi, int32_t sx) {
+    const uint32_t dw[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const int32_t x0 = xs + 8 * d;
+        int32_t l = lo - x0, h = hi - x0;
+        if (h <= 0 || l >= 8) continue;
+        l = l < 0 ? 0 : l;
+        h = h > 8 ? 8 : h;
+        kd_add8_masked(hist0, Wh, dw[d], sx + x0, (0xffu >> (8 - h)) & (0xffu << l));
+    }
+}
+
+// SHORT regular reads with clips / indels (at most KD_PREP_MAX_OPS ops, the bulk of the non-plain reads of a
+// short-read batch).  Two phases: (1) decode the CIGAR into at most three SEGMENTS -- runs of query bases that
+// land on consecutive sites of one channel group: an M/=/X run, the leading clip (clip_end_weights), the non-first
+// clip (clip_start_weights) -- each already cut to the window; deletions are tallied on the way; (2) one flat,
+// software-pipelined loop over (segment, 16-byte chunk) steps, every step a branch-free masked add, so that the
+// lanes of a wavefront stay in step whatever their op structure.  Returns false (nothing added) when the read
+// has more than three segments: the caller then takes the general walk.
+__device__ __forceinline__ bool kd_walk_short(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi, int32_t Wh,
+                                              uint32_t *hist0) {
+    const uint32_t nc = rd.n_cig[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    // the first four CIGAR words, all in flight together (a short read rarely has more)
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    if (nc > 0) w0 = cg[0];
+    if (nc > 1) w1 = cg[1];
+    if (nc > 2) w2 = cg[2];
+    if (nc > 3) w3 = cg[3];
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
+    uint32_t n_seg_ops = 0;
+    for (uint32_t k = 0; k < nc; k++) {
+        const uint32_t cw = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : k == 3 ? w3 : cg[k];
+        const uint32_t op = cw & 15u;
+        n_seg_ops += (op == 0 || op == 7 || op == 8 || op == 4) ? 1u : 0u;
+    }
+    if (n_seg_ops > 3) return false;
+    const int32_t Wp = 2 * Wh;   // sites per channel row, halos included
+    const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
+    const int32_t lead = (int32_t)ri.lead;
+    const int32_t foot_end = (int32_t)((uint32_t)(gs + span) - (uint32_t)wlo);  // window-relative end of the footprint
+    int32_t grel = (int32_t)((uint32_t)gs - (uint32_t)wlo);                        // window-relative site, may be negative
+    int32_t q = 0;
+    // segment slots: live query range [a, b) and site offset x (site of query base j is x + j, channel group included)
+    int32_t a0 = 0, b0 = 0, x0 = 0, a1 = 0, b1 = 0, x1 = 0, a2 = 0, b2 = 0, x2 = 0;
+    uint32_t ns = 0;
+    for (uint32_t k = 0; k < nc; k++) {
+        const uint32_t cw = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : k == 3 ? w3 : cg[k];
+        const int32_t len = (int32_t)(cw >> 4);
+        const uint32_t op = cw & 15u;
+        int32_t xa = 0, xb = 0, sx = 0;
+        if (op == 0 || op == 7 || op == 8) {
+            xa = grel < 0 ? q - grel : q;
+            xb = Wi - grel < len ? q + (Wi - grel) : q + len;
+            sx = grel - q;
+            q += len; grel += len;
+        } else if (op == 2) {
+            for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
+                kd_hadd(hist0, Wh, KD_HCH_DEL, grel + j);
+            grel += len;
+        } else if (op == 1) {
+            q += len;
+        } else if (op == 4) {
+            if (k == 0) {   // leading clip, kindel.py:64-73: base j -> site r - len + j, the last `lead` bases are kept
+                const int32_t s_first = grel - len;
+                xa = -s_first > len - lead ? -s_first : len - lead;
+                xb = Wi - s_first < len ? Wi - s_first : len;
+                sx = s_first + (int32_t)KD_HCH_CEW * Wp;
+                q += len;
+            } else {        // non-first clip, kindel.py:74-81: it is the last op that moves r (regular read)
+                const int32_t n_adv = foot_end - grel;
+                xa = grel < 0 ? q - grel : q;
+                xb = Wi - grel < n_adv ? q + (Wi - grel) : q + n_adv;
+                sx = grel - q + (int32_t)KD_HCH_CSW * Wp;
+                k = nc;
+            }
+        }
+        if (xb > xa) {
+            if (ns == 0) { a0 = xa; b0 = xb; x0 = sx; }
+            else if (ns == 1) { a1 = xa; b1 = xb; x1 = sx; }
+            else { a2 = xa; b2 = xb; x2 = sx; }
+            ns++;
+        }
+        if (grel >= Wi) break;   // everything further right is outside the window
+    }
+    if (ns == 0) return true;
+    int32_t c = a0 >> 5, cb = (b0 - 1) >> 5;
+    KdChunk cur = src[c];
+    for (;;) {
+        // the step after this one: next chunk of the segment, or the first chunk of the next segment
+        const bool adv = c + 1 > cb;
+        const bool more = !adv || ns > 1;
+        const int32_t cn = adv ? (a1 >> 5) : c + 1;
+        KdChunk nxt = cur;
+        if (more) nxt = src[cn];
+        kd_add_chunk_masked(hist0, Wh, cur, 32 * c, a0, b0, x0);
+        if (!more) break;
+        if (adv) {
+            a0 = a1; b0 = b1; x0 = x1; a1 = a2; b1 = b2; x1 = x2;
+            ns--;
+            cb = (b0 - 1) >> 5;
+        }
+        c = cn;
+        cur = nxt;
+    }
+    return true;
+}
+
 // A PLAIN read: one M/=/X run covering the whole read, no clips (k_prep: KD_INFO_PLAIN).  Nothing to decode:
 // query base x lands on site grel + x, for x in [0, span).
 __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi,
@@ -1147,7 +1297,15 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
     const int32_t xa = grel < 0 ? -grel : 0;
     const int32_t xb = Wi - grel < len ? Wi - grel : len;
     if (xb <= xa) return;
+#if defined(KD_EXP) && KD_EXP == 6   /* timing experiment: all chunk loads hit the first 4 KB (L1 resident, still one line per lane) */
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + (rd.seq_off[i] & 0xfffu));
+#elif defined(KD_EXP) && KD_EXP == 7 /* timing experiment: all lanes load the same address */
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + (rd.seq_off[i] & 0u));
+#elif defined(KD_EXP) && KD_EXP == 8 /* timing experiment: as 7, and no per-read metadata loads either */
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4);
+#else
     const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
+#endif
     const int32_t ca = xa >> 5, cb = (xb - 1) >> 5;
     // three chunks of prefetch: a 150-base read is 5 chunks, so its loads are (almost) all in flight at once
     KdChunk cur = src[ca], n1 = cur, n2 = cur;
@@ -1184,11 +1342,19 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
     const kd_u64 total = status[KDS_TOTAL_ITEMS];
     const uint32_t nh = (uint32_t)KD_HCH * (uint32_t)Wh;   // histogram dwords
     const int32_t Wi = (int32_t)W;
+#if defined(KD_EXP) && KD_EXP == 20
+    long long c_zero = 0, c_cls = 0, c_plain = 0, c_cplx = 0, c_wait = 0, c_flush = 0, c_deq = 0, c_mark;
+#define KD_MARK(acc) { const long long n_ = clock64(); acc += n_ - c_mark; c_mark = n_; }
+    c_mark = clock64();
+#else
+#define KD_MARK(acc)
+#endif
     for (;;) {
         if (t == 0) s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL);
         __syncthreads();
         const kd_u64 item = s_item;
         if (item >= total) break;
+        KD_MARK(c_deq)
         // window of this item: largest w with item_off[w] <= item
         uint32_t lo = 0, hi = n_win;
         while (hi - lo > 1) {
@@ -1200,9 +1366,11 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
         const kd_u64 first = win_lo[w] + (item - item_off[w]) * slice;
         const kd_u64 last = first + slice < win_hi[w] ? first + slice : win_hi[w];
         for (uint32_t x = t; x < nh; x += KD_BLOCK) hist[x] = 0;
+        KD_MARK(c_zero)
         for (kd_u64 tb = first; tb < last; tb += tile) {
             if (t == 0) { s_np = 0; s_nc = 0; }
             __syncthreads();
+            KD_MARK(c_wait)
             // classify the tile's reads: plain (single aligned run) / complex; drop those outside the window
             for (uint32_t u = 0; u < tile / KD_BLOCK; u++) {
                 const uint32_t rel = u * KD_BLOCK + t;
@@ -1217,6 +1385,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 }
             }
             __syncthreads();
+            KD_MARK(c_cls)
             // homogeneous wavefronts: first the plain reads, then the complex ones.  Lane l of a wavefront takes
             // list entries l*rows + r: neighbours in a wavefront are `rows` reads apart in the sorted batch,
             // which keeps them off the same LDS counters in the same instruction.
@@ -1231,17 +1400,23 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                     }
                 }
             }
+            KD_MARK(c_plain)
             {
                 const uint32_t rows = (ncx + KD_WAVE - 1) / KD_WAVE;
                 for (uint32_t r = wave; r < rows; r += KD_WAVES_PER_BLOCK) {
                     const uint32_t e = lane * rows + r;
                     if (e < ncx) {
                         const kd_u64 j = tb + l_cplx[e], i = order ? (kd_u64)order[j] : j;
-                        kd_walk_complex(rd, i, rinfo[i], ckpt, wlo, Wi, Wh, hist0);
+                        const KdRInfo ri = rinfo[i];
+                        // long CIGARs (checkpointed) and reads with more than three segments: general walk
+                        if (ri.pad || !kd_walk_short(rd, i, ri, wlo, Wi, Wh, hist0))
+                            kd_walk_complex(rd, i, ri, ckpt, wlo, Wi, Wh, hist0);
                     }
                 }
             }
+            KD_MARK(c_cplx)
             __syncthreads();
+            KD_MARK(c_wait)
         }
         // flush: channel-major, consecutive lanes -> consecutive HBM dwords; zeros are skipped.
         // LDS channel -> table channel (KD_CH_*): weights 0-4, deletions 5, csw 6-10, cew 11-15; 0xff = bad slot
@@ -1267,8 +1442,18 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
         }
         // a base outside A,C,G,T,N inside an aligned or clipped segment: k_find_bad_base pins down the read
         if (bad) atomicAdd(&status[KDS_BAD_BASE], 1ULL);
+        KD_MARK(c_flush)
         __syncthreads();
+        KD_MARK(c_wait)
     }
+#if defined(KD_EXP) && KD_EXP == 20
+    if ((t & 63u) == 0) {   // lane 0 of every wavefront
+        atomicAdd(&status[KDS_DBG0], (kd_u64)c_deq); atomicAdd(&status[KDS_DBG1], (kd_u64)c_zero);
+        atomicAdd(&status[KDS_DBG2], (kd_u64)c_cls); atomicAdd(&status[KDS_DBG3], (kd_u64)c_plain);
+        atomicAdd(&status[KDS_DBG4], (kd_u64)c_cplx); atomicAdd(&status[KDS_DBG5], (kd_u64)c_wait);
+        atomicAdd(&status[KDS_DBG6], (kd_u64)c_flush); atomicAdd(&status[KDS_DBG7], 1ULL);
+    }
+#endif
 }
 
 // Rare path: k_window saw a base outside A,C,G,T,N.  One workgroup walks the regular reads of the
