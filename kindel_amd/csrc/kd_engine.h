@@ -271,16 +271,15 @@ struct KdEngine {
                 order = ord;
             }
             if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, d_status)) return hipfail("k_plan_scan");
-            const uint32_t tile = getenv("KD_TILE") ? (uint32_t)atoi(getenv("KD_TILE")) : 1024u;  // multiple of KD_BLOCK, <= KD_TILE_MAX
             uint32_t Wh = (W + 2 * KD_HALO) / 2;   // dwords per channel row
 #if defined(KD_EXP) && (KD_EXP == 4 || KD_EXP == 5)
             Wh = (Wh + 31u) & ~31u;   // timing experiment: row stride a multiple of the 32 LDS banks
 #endif
-            const size_t lds = KD_WINDOW_LDS_BYTES(Wh, tile);
+            const size_t lds = KD_WINDOW_LDS_BYTES(Wh);
             const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
             const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
             if (rt.launch("k_window", k_window, grid, KD_BLOCK, lds, R, (const KdRInfo *)rinfo, order, (const KdCkpt *)b_ckpt.p, T, (const kd_u64 *)wl,
-                          (const kd_u64 *)wh, (const kd_u64 *)io, w0, n_win, W, Wh, slice, tile, d_status))
+                          (const kd_u64 *)wh, (const kd_u64 *)io, w0, n_win, W, Wh, slice, d_status))
                 return hipfail("k_window");
             if (n_cold &&
                 rt.launch("k_cold_lane", k_cold_lane, (unsigned)((n_cold + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, R, T, I,

@@ -1323,20 +1323,20 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
     }
 }
 
-#define KD_TILE_MAX 2048   // reads classified together (runtime `tile`, a multiple of KD_BLOCK)
-#define KD_WINDOW_LDS_BYTES(Wh, tile) ((size_t)KD_HCH * (Wh) * 4 + (size_t)2 * (tile) * 2)   // Wh = dwords per channel row
+#define KD_TILE 1024   // reads classified together (a multiple of KD_BLOCK)
+#define KD_TILE_PER_THREAD (KD_TILE / KD_BLOCK)
+#define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)2 * KD_TILE * 2)   // Wh = dwords per channel row
 
-__global__ void __launch_bounds__(KD_BLOCK)
+__global__ void __launch_bounds__(KD_BLOCK, 5)   // 5 wavefronts per SIMD = the 5 workgroups per CU the LDS footprint allows
 k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *ckpt, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
-         const kd_u64 *item_off, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t Wh_, uint32_t slice, uint32_t tile,
-         kd_u64 *status) {
+         const kd_u64 *item_off, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t Wh_, uint32_t slice, kd_u64 *status) {
     KD_DYN_SHARED(uint32_t, hist);
     const int32_t Wh = (int32_t)Wh_;   // dwords per channel row (two u16 counters each, halos included; >= (W + 2*KD_HALO)/2)
     uint32_t *hist0 = hist + KD_HALO / 2;                 // word of window-relative site 0
     uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * Wh);  // tile-relative read indices
-    uint16_t *l_cplx = l_plain + tile;
+    uint16_t *l_cplx = l_plain + KD_TILE;
     __shared__ kd_u64 s_item;
-    __shared__ uint32_t s_np, s_nc;
+    __shared__ uint32_t s_cnt[2][2];   // [tile parity][plain, complex] list lengths
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
     const kd_u64 total = status[KDS_TOTAL_ITEMS];
@@ -1350,7 +1350,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
 #define KD_MARK(acc)
 #endif
     for (;;) {
-        if (t == 0) s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL);
+        if (t == 0) { s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL); s_cnt[0][0] = 0; s_cnt[0][1] = 0; }
         __syncthreads();
         const kd_u64 item = s_item;
         if (item >= total) break;
@@ -1365,53 +1365,67 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
         const kd_u64 wlo = (kd_u64)(w0 + w) * W, whi = wlo + W;
         const kd_u64 first = win_lo[w] + (item - item_off[w]) * slice;
         const kd_u64 last = first + slice < win_hi[w] ? first + slice : win_hi[w];
+        // The classification keys (start, span | flags, lead) of a tile are fetched ONE TILE AHEAD into registers:
+        // the loads of tile k + 1 are in flight while tile k is walked.  `order`: bucket-sorted permutation.
+        uint32_t p_gs[KD_TILE_PER_THREAD], p_sc[KD_TILE_PER_THREAD], p_ld[KD_TILE_PER_THREAD];
+#pragma unroll
+        for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
+            const kd_u64 j = first + u * KD_BLOCK + t;
+            p_sc[u] = KD_CLS_SKIP; p_gs[u] = 0; p_ld[u] = 0;
+            if (j < last) {
+                const KdRInfo ri = rinfo[order ? (kd_u64)order[j] : j];
+                p_gs[u] = ri.gstart; p_sc[u] = ri.span_cls; p_ld[u] = ri.lead;
+            }
+        }
         for (uint32_t x = t; x < nh; x += KD_BLOCK) hist[x] = 0;
         KD_MARK(c_zero)
-        for (kd_u64 tb = first; tb < last; tb += tile) {
-            if (t == 0) { s_np = 0; s_nc = 0; }
-            __syncthreads();
-            KD_MARK(c_wait)
+        uint32_t par = 0;
+        for (kd_u64 tb = first; tb < last; tb += KD_TILE, par ^= 1u) {
             // classify the tile's reads: plain (single aligned run) / complex; drop those outside the window
-            for (uint32_t u = 0; u < tile / KD_BLOCK; u++) {
-                const uint32_t rel = u * KD_BLOCK + t;
-                if (tb + rel < last) {
-                    const kd_u64 i = order ? (kd_u64)order[tb + rel] : tb + rel;   // `order`: bucket-sorted permutation
-                    const KdRInfo ri = rinfo[i];
-                    const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
-                    if ((ri.span_cls & 3u) == KD_CLS_REG && gs + span > wlo && gs - ri.lead < whi) {
-                        if (ri.span_cls & KD_INFO_PLAIN) l_plain[atomicAdd(&s_np, 1u)] = (uint16_t)rel;
-                        else l_cplx[atomicAdd(&s_nc, 1u)] = (uint16_t)rel;
-                    }
+#pragma unroll
+            for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
+                const kd_u64 gs = p_gs[u], span = p_sc[u] >> KD_SPAN_SHIFT;
+                if ((p_sc[u] & 3u) == KD_CLS_REG && gs + span > wlo && gs - p_ld[u] < whi) {
+                    const uint32_t rel = u * KD_BLOCK + t;
+                    if (p_sc[u] & KD_INFO_PLAIN) l_plain[atomicAdd(&s_cnt[par][0], 1u)] = (uint16_t)rel;
+                    else l_cplx[atomicAdd(&s_cnt[par][1], 1u)] = (uint16_t)rel;
                 }
             }
             __syncthreads();
             KD_MARK(c_cls)
+            const uint32_t np = s_cnt[par][0], ncx = s_cnt[par][1];
+            if (t == 0) { s_cnt[par ^ 1u][0] = 0; s_cnt[par ^ 1u][1] = 0; }   // next tile's counters (idle until its classify)
+#pragma unroll
+            for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
+                const kd_u64 j = tb + KD_TILE + u * KD_BLOCK + t;
+                p_sc[u] = KD_CLS_SKIP;
+                if (j < last) {
+                    const KdRInfo ri = rinfo[order ? (kd_u64)order[j] : j];
+                    p_gs[u] = ri.gstart; p_sc[u] = ri.span_cls; p_ld[u] = ri.lead;
+                }
+            }
             // homogeneous wavefronts: first the plain reads, then the complex ones.  Lane l of a wavefront takes
             // list entries l*rows + r: neighbours in a wavefront are `rows` reads apart in the sorted batch,
             // which keeps them off the same LDS counters in the same instruction.
-            const uint32_t np = s_np, ncx = s_nc;
-            {
-                const uint32_t rows = (np + KD_WAVE - 1) / KD_WAVE;
-                for (uint32_t r = wave; r < rows; r += KD_WAVES_PER_BLOCK) {
-                    const uint32_t e = lane * rows + r;
-                    if (e < np) {
-                        const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
-                        kd_walk_plain(rd, i, rinfo[i], wlo, Wi, Wh, hist0);
-                    }
+            const uint32_t rows_p = (np + KD_WAVE - 1) / KD_WAVE, rows_c = (ncx + KD_WAVE - 1) / KD_WAVE;
+            for (uint32_t r = wave; r < rows_p; r += KD_WAVES_PER_BLOCK) {
+                const uint32_t e = lane * rows_p + r;
+                if (e < np) {
+                    const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
+                    kd_walk_plain(rd, i, rinfo[i], wlo, Wi, Wh, hist0);
                 }
             }
             KD_MARK(c_plain)
-            {
-                const uint32_t rows = (ncx + KD_WAVE - 1) / KD_WAVE;
-                for (uint32_t r = wave; r < rows; r += KD_WAVES_PER_BLOCK) {
-                    const uint32_t e = lane * rows + r;
-                    if (e < ncx) {
-                        const kd_u64 j = tb + l_cplx[e], i = order ? (kd_u64)order[j] : j;
-                        const KdRInfo ri = rinfo[i];
-                        // long CIGARs (checkpointed) and reads with more than three segments: general walk
-                        if (ri.pad || !kd_walk_short(rd, i, ri, wlo, Wi, Wh, hist0))
-                            kd_walk_complex(rd, i, ri, ckpt, wlo, Wi, Wh, hist0);
-                    }
+            // the complex rows start at the wavefront after the one that took the last plain row
+            for (uint32_t r = (wave + KD_WAVES_PER_BLOCK - rows_p % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK; r < rows_c;
+                 r += KD_WAVES_PER_BLOCK) {
+                const uint32_t e = lane * rows_c + r;
+                if (e < ncx) {
+                    const kd_u64 j = tb + l_cplx[e], i = order ? (kd_u64)order[j] : j;
+                    const KdRInfo ri = rinfo[i];
+                    // long CIGARs (checkpointed) and reads with more than three segments: general walk
+                    if (ri.pad || !kd_walk_short(rd, i, ri, wlo, Wi, Wh, hist0))
+                        kd_walk_complex(rd, i, ri, ckpt, wlo, Wi, Wh, hist0);
                 }
             }
             KD_MARK(c_cplx)
@@ -1421,14 +1435,15 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
         // flush: channel-major, consecutive lanes -> consecutive HBM dwords; zeros are skipped.
         // LDS channel -> table channel (KD_CH_*): weights 0-4, deletions 5, csw 6-10, cew 11-15; 0xff = bad slot
         bool bad = false;
-        for (uint32_t x = t; x < nh; x += KD_BLOCK) {
+        uint32_t ch = 0, xw = t;   // word x = ch * Wh + xw, kept without a division
+        for (uint32_t x = t; x < nh; x += KD_BLOCK, xw += KD_BLOCK) {
+            while (xw >= (uint32_t)Wh) { xw -= (uint32_t)Wh; ch++; }
             const uint32_t v = hist[x];
             if (v) {
-                const uint32_t ch = x / (uint32_t)Wh;
                 const uint32_t tch = ch < 5 ? ch : ch == KD_HCH_DEL ? (uint32_t)KDC_DEL
                                    : (ch >= 7 && ch < 12) ? ch - 1 : (ch >= 13 && ch < 18) ? ch - 2 : 0xffu;
                 // the word holds window-relative sites s (low half) and s + 1 (high half); halo sites are dropped
-                const int32_t sw = 2 * (int32_t)(x - ch * (uint32_t)Wh) - KD_HALO;
+                const int32_t sw = 2 * (int32_t)xw - KD_HALO;
                 uint32_t *row = T.tab + (kd_u64)(tch == 0xffu ? 0u : tch) * T.stride;
                 for (int hlf = 0; hlf < 2; hlf++) {
                     const uint32_t cnt = hlf ? v >> 16 : v & 0xffffu;
