@@ -41,7 +41,7 @@ struct KdEngine {
         void *p = nullptr;
         size_t cap = 0;
     };
-    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_ckpt;
+    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_ckpt;
     Buf b_stage[9];
     Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
     uint64_t ev_cap = 0, pool_cap = 0;
@@ -130,7 +130,7 @@ struct KdEngine {
     }
 
     void destroy() {
-        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ckpt, &b_ev_site, &b_ev_len,
+        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_itemwin, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ckpt, &b_ev_site, &b_ev_len,
                       &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_win, &b_cns, &b_changes,
                       &b_tilesum, &b_tileoff, &b_coff, &b_minmax, &b_pstart, &b_pend, &b_poff};
         for (Buf *b : all) release(*b);
@@ -270,7 +270,17 @@ struct KdEngine {
                     return hipfail("k_sort_*");
                 order = ord;
             }
-            if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, d_status)) return hipfail("k_plan_scan");
+            // work item -> window table; an item is (window, slice of its candidate reads): at most one per window
+            // plus one per `slice` (read, window) candidate pairs, and a read is a candidate of the windows its
+            // footprint (<= max span + max lead, both known from k_prep) can touch
+            const uint64_t reach = h_status[KDS_B_MAXSPAN] / W + h_status[KDS_B_MAXLEAD] / W + 4;   // whole-bin ranges of the unsorted path included
+            const uint64_t items_cap = (uint64_t)n_win + (n * reach) / slice + 1;
+            if ((rc = ensure(b_itemwin, items_cap * 4))) return rc;
+            uint32_t *iw = (uint32_t *)b_itemwin.p;
+            if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, d_status) ||
+                rt.launch("k_plan_items", k_plan_items, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, (const kd_u64 *)io, n_win, iw,
+                          (kd_u64)items_cap, d_status))
+                return hipfail("k_plan_scan");
             uint32_t Wh = (W + 2 * KD_HALO) / 2;   // dwords per channel row
 #if defined(KD_EXP) && (KD_EXP == 4 || KD_EXP == 5)
             Wh = (Wh + 31u) & ~31u;   // timing experiment: row stride a multiple of the 32 LDS banks
@@ -279,7 +289,7 @@ struct KdEngine {
             const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
             const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
             if (rt.launch("k_window", k_window, grid, KD_BLOCK, lds, R, (const KdRInfo *)rinfo, order, (const KdCkpt *)b_ckpt.p, T, (const kd_u64 *)wl,
-                          (const kd_u64 *)wh, (const kd_u64 *)io, w0, n_win, W, Wh, slice, d_status))
+                          (const kd_u64 *)wh, (const kd_u64 *)io, (const uint32_t *)iw, (kd_u64)items_cap, w0, W, Wh, slice, d_status))
                 return hipfail("k_window");
             if (n_cold &&
                 rt.launch("k_cold_lane", k_cold_lane, (unsigned)((n_cold + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, R, T, I,

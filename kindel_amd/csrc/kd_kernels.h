@@ -976,6 +976,18 @@ k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
     if (t == 0) { item_off[n_win] = s_carry; status[KDS_TOTAL_ITEMS] = s_carry; status[KDS_NEXT_ITEM] = 0; }
 }
 
+// k_plan_items: work item -> window table (k_window then needs one load, not a binary search over item_off,
+// to find the window of the item it dequeued).
+__global__ void __launch_bounds__(KD_BLOCK)
+k_plan_items(const kd_u64 *item_off, uint32_t n_win, uint32_t *item_win, kd_u64 cap, kd_u64 *status) {
+    const uint32_t w = blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (w >= n_win) return;
+    for (kd_u64 it = item_off[w]; it < item_off[w + 1]; it++) {
+        if (it < cap) item_win[it] = w;
+        else status[KDS_INTERNAL] = 1;
+    }
+}
+
 // k_window: persistent workgroups pull (window, slice) work items.
 //
 // LDS (dynamic): u32 hist[19][W], channel-major, three groups of {A,T,G,C,N, bad}: weights (0-5),
@@ -1329,7 +1341,8 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
 
 __global__ void __launch_bounds__(KD_BLOCK, 5)   // 5 wavefronts per SIMD = the 5 workgroups per CU the LDS footprint allows
 k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *ckpt, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
-         const kd_u64 *item_off, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t Wh_, uint32_t slice, kd_u64 *status) {
+         const kd_u64 *item_off, const uint32_t *item_win, kd_u64 items_cap, uint32_t w0, uint32_t W, uint32_t Wh_, uint32_t slice,
+         kd_u64 *status) {
     KD_DYN_SHARED(uint32_t, hist);
     const int32_t Wh = (int32_t)Wh_;   // dwords per channel row (two u16 counters each, halos included; >= (W + 2*KD_HALO)/2)
     uint32_t *hist0 = hist + KD_HALO / 2;                 // word of window-relative site 0
@@ -1353,15 +1366,9 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
         if (t == 0) { s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL); s_cnt[0][0] = 0; s_cnt[0][1] = 0; }
         __syncthreads();
         const kd_u64 item = s_item;
-        if (item >= total) break;
+        if (item >= total || item >= items_cap) break;   // (>= items_cap: k_plan_items has raised KDS_INTERNAL)
         KD_MARK(c_deq)
-        // window of this item: largest w with item_off[w] <= item
-        uint32_t lo = 0, hi = n_win;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (item_off[mid] <= item) lo = mid; else hi = mid;
-        }
-        const uint32_t w = lo;
+        const uint32_t w = item_win[item];   // k_plan_items: the window with item_off[w] <= item < item_off[w + 1]
         const kd_u64 wlo = (kd_u64)(w0 + w) * W, whi = wlo + W;
         const kd_u64 first = win_lo[w] + (item - item_off[w]) * slice;
         const kd_u64 last = first + slice < win_hi[w] ? first + slice : win_hi[w];
@@ -1377,7 +1384,10 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 p_gs[u] = ri.gstart; p_sc[u] = ri.span_cls; p_ld[u] = ri.lead;
             }
         }
-        for (uint32_t x = t; x < nh; x += KD_BLOCK) hist[x] = 0;
+        {   // Wh is a multiple of 4 (W is a multiple of 64): zero with 16-byte stores
+            uint4 *h4 = reinterpret_cast<uint4 *>(hist);
+            for (uint32_t x = t; x < nh / 4; x += KD_BLOCK) h4[x] = make_uint4(0u, 0u, 0u, 0u);
+        }
         KD_MARK(c_zero)
         uint32_t par = 0;
         for (kd_u64 tb = first; tb < last; tb += KD_TILE, par ^= 1u) {
@@ -1445,6 +1455,13 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 // the word holds window-relative sites s (low half) and s + 1 (high half); halo sites are dropped
                 const int32_t sw = 2 * (int32_t)xw - KD_HALO;
                 uint32_t *row = T.tab + (kd_u64)(tch == 0xffu ? 0u : tch) * T.stride;
+                const kd_u64 g0 = wlo + (kd_u64)sw;   // even: W, the halo and the G-space rows are all even / 8-byte aligned
+                if (tch != 0xffu && sw >= 0 && sw + 1 < Wi && g0 + 1 < T.stride && kd_commit(T, g0) && kd_commit(T, g0 + 1)) {
+                    // both sites of the word live: ONE 64-bit add on the two adjacent u32 counters (the low counter
+                    // cannot carry into the high one: a u32 table counter never wraps)
+                    atomicAdd(reinterpret_cast<kd_u64 *>(row + g0), (kd_u64)(v & 0xffffu) | ((kd_u64)(v >> 16) << 32));
+                    continue;
+                }
                 for (int hlf = 0; hlf < 2; hlf++) {
                     const uint32_t cnt = hlf ? v >> 16 : v & 0xffffu;
                     const int32_t sw2 = sw + hlf;

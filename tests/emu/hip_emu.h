@@ -31,6 +31,7 @@ struct dim3 {
 };
 struct emu_idx { unsigned x = 0, y = 0, z = 0; };
 struct alignas(16) uint4 { uint32_t x, y, z, w; };
+inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 
 inline thread_local emu_idx threadIdx, blockIdx;
 inline thread_local dim3 blockDim, gridDim;
