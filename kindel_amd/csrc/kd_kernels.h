@@ -303,7 +303,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
             const int64_t sl = v_sl[u];
             const uint32_t nc = v_nc[u];
             uint32_t cls, cold = 0, lead = 0;
-            kd_u64 span = 0, al = 0;
+            kd_u64 span = 0, al = 0, n_ins_r = 0, n_insb_r = 0;
             bool has_ins = false;
             if ((v_fl[u] & 4u) || sl <= 1) {
                 cls = KD_CLS_SKIP;
@@ -316,6 +316,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
             } else {
                 KdScan s = kd_scan_cigar(rd.cigar + v_coff[u], nc, pos0, sl, L_cached, v_cw[u]);
                 cls = s.cls; cold = s.cold; span = s.span; lead = s.lead; has_ins = s.n_ins != 0; al = s.aligned;
+                n_ins_r = s.n_ins; n_insb_r = s.ins_bases;
                 a_reads++; a_aligned += s.aligned; a_walked += s.walked; a_ins += s.n_ins; a_insb += s.ins_bases;
             }
             if (span > 0x07ffffffULL) { cls = KD_CLS_IRREG; span = 0; }
@@ -327,7 +328,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
             if (cls == KD_CLS_REG && cold) { n_cold++; m_cold |= 1u << it; }
             if (cls == KD_CLS_IRREG) { n_irreg++; m_irreg |= 1u << it; }
             if (cls == KD_CLS_LONG) { n_long++; m_long |= 1u << it; }
-            if (has_ins) m_ins |= 1u << it;
+            if (has_ins) { m_ins |= 1u << it; read_ev[i] = (uint32_t)n_ins_r; read_pool[i] = n_insb_r; }   // counts, see the last loop
             KdRInfo ri;
             ri.gstart = (uint32_t)gkey;
             // plain: the whole read is ONE aligned run: a single op whose aligned length is the read length
@@ -380,11 +381,11 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
             const int it = __builtin_ctz(todo);
             const kd_u64 i = chunk0 + (kd_u64)it * KD_BLOCK + t;
             const uint32_t bit = 1u << it;
-            if (m_ins & bit) {  // rescan (cached) to hand this read its event / pool slots
-                KdScan s = kd_scan_cigar(rd.cigar + rd.cig_off[i], rd.n_cig[i], rd.pos0[i], rd.seq_len[i],
-                                         (int64_t)T.contig_len[rd.contig[i]]);
+            if (m_ins & bit) {  // the first pass left the read's event / base COUNTS here: turn them into its slots
+                const uint32_t n_ev = read_ev[i];
+                const kd_u64 n_b = read_pool[i];
                 read_ev[i] = (uint32_t)w_ev; read_pool[i] = w_pool;
-                w_ev += s.n_ins; w_pool += s.ins_bases;
+                w_ev += n_ev; w_pool += n_b;
             }
             if (m_cold & bit) cold_list[w_cold++] = (uint32_t)i;
             if (m_irreg & bit) irreg_list[w_irreg++] = (uint32_t)i;
