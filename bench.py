@@ -77,7 +77,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = "cuda:%d" % dev_index
 
-    if os.environ.get("KD_BENCH_LIB"):   # kernel experiments: a differently built library (never the default)
+    if os.environ.get("KD_BENCH_LIB"):   # profiling builds (e.g. hipcc -DKD_PHASE_CLOCKS): a differently built library, never the default
         from kindel_amd import _native as _N
         _N._default = _N.Library(os.environ["KD_BENCH_LIB"])
     cfg = dict(synth.CONFIGS[args.config])

@@ -282,9 +282,6 @@ struct KdEngine {
                           (kd_u64)items_cap, d_status))
                 return hipfail("k_plan_scan");
             uint32_t Wh = (W + 2 * KD_HALO) / 2;   // dwords per channel row
-#if defined(KD_EXP) && (KD_EXP == 4 || KD_EXP == 5)
-            Wh = (Wh + 31u) & ~31u;   // timing experiment: row stride a multiple of the 32 LDS banks
-#endif
             const size_t lds = KD_WINDOW_LDS_BYTES(Wh);
             const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
             const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
@@ -347,7 +344,7 @@ struct KdEngine {
         int rc;
         if ((rc = fetch_status())) return rc;
         if (h_status[KDS_INTERNAL]) return fail(KD_E_INTERNAL, "insertion event buffers overran (internal error)");
-#if defined(KD_EXP) && KD_EXP == 20
+#ifdef KD_PHASE_CLOCKS   // profiling build (hipcc -DKD_PHASE_CLOCKS): where k_window's wavefronts spend their clocks
         {
             const char *nm[8] = {"dequeue", "zero", "classify", "plain", "complex", "barrier-wait", "flush", "waves"};
             double tot = 0;

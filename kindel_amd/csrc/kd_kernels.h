@@ -94,7 +94,7 @@ enum {
     KDS_INS_COLLISION,  // hash verification failed
     KDS_INTERNAL,       // capacity overrun etc.
     KDS_BAD_BASE,       // k_window: windows that saw a base outside A,C,G,T,N
-#if defined(KD_EXP) && KD_EXP == 20
+#ifdef KD_PHASE_CLOCKS
     KDS_DBG0, KDS_DBG1, KDS_DBG2, KDS_DBG3, KDS_DBG4, KDS_DBG5, KDS_DBG6, KDS_DBG7,   // phase clocks (profiling build only)
 #endif
     KDS_COUNT
@@ -1034,15 +1034,6 @@ __device__ __forceinline__ void kd_hadd(uint32_t *hist0, int32_t Wh, uint32_t ch
 // all 8 bases of dword v are added; s0 = window-relative site of its first base.  Even bases go through pointer h
 // with add value vp, odd bases through hq = h + (s0 & 1) with vq: no per-base parity arithmetic.
 __device__ __forceinline__ void kd_add8_full(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t s0) {
-#if defined(KD_EXP) && (KD_EXP == 4 || KD_EXP == 5)   /* timing experiment: lane-determined, bank-conflict-free start sites */
-    {
-        const int32_t ln = (int32_t)(threadIdx.x & 63u);
-        int32_t s1 = (s0 & ~63) | ((ln & 31) << 1) | (ln >> 5);
-        if (s1 > 2 * Wh - 2 * KD_HALO - 80) s1 -= 64;
-        if (s1 < 0) s1 += 64;
-        s0 = s1;
-    }
-#endif
     const int32_t p = s0 & 1;
     // byte addressing: address = row base + ch * (row bytes) + constant, one 24-bit multiply-add per base
     // (v_mad_u32_u24 is full rate; a 32-bit v_mul_lo_u32 is not)
@@ -1052,19 +1043,9 @@ __device__ __forceinline__ void kd_add8_full(uint32_t *hist0, int32_t Wh, uint32
     const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-#if defined(KD_EXP) && KD_EXP == 2   /* timing experiment: no LUT */
-        const uint32_t ch = 0;
-#elif defined(KD_EXP) && (KD_EXP == 3 || KD_EXP == 5) /* timing experiment: row = nibble & 7 */
-        const uint32_t ch = (v >> KD_NIB_SHIFT(b)) & 7u;
-#else
         const uint32_t ch = kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u);
-#endif
         unsigned char *a = ((b & 1) ? hq : h) + KD_MUL24(ch, rowb) + 4 * (b >> 1);
-#if defined(KD_EXP) && KD_EXP == 1   /* timing experiment: no LDS atomic */
-        asm volatile("" ::"v"(a), "v"((b & 1) ? vq : vp));
-#else
         atomicAdd(reinterpret_cast<uint32_t *>(a), (b & 1) ? vq : vp);
-#endif
     }
 }
 // only bases [blo, bhi) belong to the run
@@ -1310,15 +1291,7 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
     const int32_t xa = grel < 0 ? -grel : 0;
     const int32_t xb = Wi - grel < len ? Wi - grel : len;
     if (xb <= xa) return;
-#if defined(KD_EXP) && KD_EXP == 6   /* timing experiment: all chunk loads hit the first 4 KB (L1 resident, still one line per lane) */
-    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + (rd.seq_off[i] & 0xfffu));
-#elif defined(KD_EXP) && KD_EXP == 7 /* timing experiment: all lanes load the same address */
-    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + (rd.seq_off[i] & 0u));
-#elif defined(KD_EXP) && KD_EXP == 8 /* timing experiment: as 7, and no per-read metadata loads either */
-    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4);
-#else
     const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
-#endif
     const int32_t ca = xa >> 5, cb = (xb - 1) >> 5;
     // three chunks of prefetch: a 150-base read is 5 chunks, so its loads are (almost) all in flight at once
     KdChunk cur = src[ca], n1 = cur, n2 = cur;
@@ -1356,7 +1329,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
     const kd_u64 total = status[KDS_TOTAL_ITEMS];
     const uint32_t nh = (uint32_t)KD_HCH * (uint32_t)Wh;   // histogram dwords
     const int32_t Wi = (int32_t)W;
-#if defined(KD_EXP) && KD_EXP == 20
+#ifdef KD_PHASE_CLOCKS
     long long c_zero = 0, c_cls = 0, c_plain = 0, c_cplx = 0, c_wait = 0, c_flush = 0, c_deq = 0, c_mark;
 #define KD_MARK(acc) { const long long n_ = clock64(); acc += n_ - c_mark; c_mark = n_; }
     c_mark = clock64();
@@ -1479,7 +1452,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
         __syncthreads();
         KD_MARK(c_wait)
     }
-#if defined(KD_EXP) && KD_EXP == 20
+#ifdef KD_PHASE_CLOCKS
     if ((t & 63u) == 0) {   // lane 0 of every wavefront
         atomicAdd(&status[KDS_DBG0], (kd_u64)c_deq); atomicAdd(&status[KDS_DBG1], (kd_u64)c_zero);
         atomicAdd(&status[KDS_DBG2], (kd_u64)c_cls); atomicAdd(&status[KDS_DBG3], (kd_u64)c_plain);
