@@ -128,9 +128,9 @@ def main():
     if world > 1:
         eng.set_shard(*interval)
 
-    # pinned host buffers for the consensus bytes: the D2H copy then needs no pageable staging
-    pinned = [torch.empty(int(l) + 4096 + int(l) // 8, dtype=torch.uint8, pin_memory=True) for l in contig_lens]
-    pinned_np = [p.numpy() for p in pinned]
+    # one pinned host buffer for the consensus bytes of all contigs: a single D2H copy, no pageable staging
+    pinned = torch.empty(sum(int(l) + int(l) // 8 for l in contig_lens) + 4096, dtype=torch.uint8, pin_memory=True)
+    pinned_np = pinned.numpy()
 
     state = {}
 
@@ -140,10 +140,8 @@ def main():
         eng.finalize()
         eng.consensus_run(1)
         # this rank's consensus bytes -> pinned host memory (at N = 1 that is the whole FASTA) ...
-        seqs = []
-        for c in range(n_contigs):
-            n = eng.consensus_fetch_into(c, pinned_np[c])
-            seqs.append(pinned_np[c][:n])
+        off = eng.consensus_fetch_all_into(pinned_np)
+        seqs = [pinned_np[int(off[c]): int(off[c + 1])] for c in range(n_contigs)]
         # ... and, at N > 1, the all-gather that leaves the stitched consensus in every GPU's HBM
         if world > 1:
             state["gathered"] = shard.gather(eng, interval, dev)[0]

@@ -170,6 +170,13 @@ int kd_consensus_run(kd_ctx *ctx, uint32_t min_depth, uint32_t n_patches,
 int kd_consensus_fetch(kd_ctx *ctx, uint32_t contig, uint8_t *seq_out, uint64_t cap,
                        uint64_t *len_out, uint8_t *changes, uint32_t *depth_minmax,
                        uint64_t *patch_off);
+/* All contigs in ONE device-to-host copy (multi-contig inputs: kindel.py:515-551 loops over the contigs):
+ * seq_out[cap] receives the concatenated consensus bytes, contig c = seq_out[contig_off[c] .. contig_off[c+1])
+ * with contig_off[n_contigs+1] filled in; changes (may be NULL) receives kd_total_sites() change codes in G-space
+ * (contig c = changes[kd_contig_base(c) ..+len]).  *len_out = total bytes (always set; call with seq_out = NULL
+ * to size the buffer). */
+int kd_consensus_fetch_all(kd_ctx *ctx, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint64_t *contig_off,
+                           uint8_t *changes);
 /* Device-side view of the whole shard's consensus (for the multi-GPU all-gather):
  * *dev_ptr = device pointer to the concatenated bytes, *n_bytes its length. */
 int kd_consensus_device(kd_ctx *ctx, void **dev_ptr, uint64_t *n_bytes);

@@ -26,7 +26,7 @@ KD_MODE_AUTO, KD_MODE_GLOBAL, KD_MODE_WINDOW = 0, 1, 2
 ABI_SYMBOLS = (
     "kd_abi_version kd_create kd_destroy kd_last_error kd_reset kd_set_mode kd_set_tuning kd_contig_base "
     "kd_total_sites kd_set_shard kd_push_batch kd_push_batch_device kd_sync kd_finalize kd_get_stats "
-    "kd_get_batch_info kd_get_tables kd_get_insertions kd_consensus_run kd_consensus_fetch kd_consensus_device kd_changes_device kd_consensus_offsets "
+    "kd_get_batch_info kd_get_tables kd_get_insertions kd_consensus_run kd_consensus_fetch kd_consensus_fetch_all kd_consensus_device kd_changes_device kd_consensus_offsets "
     "kd_profile_enable kd_profile_get kd_profile_reset kd_decode_open kd_decode_batch kd_decode_n_contigs "
     "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error"
 ).split()
@@ -92,6 +92,7 @@ class Library:
         L.kd_consensus_device.argtypes = [p, C.POINTER(p), C.POINTER(u64)]
         L.kd_changes_device.argtypes = [p, C.POINTER(p)]
         L.kd_consensus_offsets.argtypes = [p, p, p]
+        L.kd_consensus_fetch_all.argtypes = [p, p, u64, C.POINTER(u64), p, p]
         L.kd_profile_enable.argtypes = [p, C.c_int]
         L.kd_profile_get.argtypes = [p, C.POINTER(u32), p, p, p]
         L.kd_profile_reset.argtypes = [p]
@@ -299,6 +300,16 @@ class Engine:
                     "kd_consensus_fetch")
         return ln.value
 
+    def consensus_fetch_all_into(self, out, changes=None):
+        """All contigs' consensus bytes in one device-to-host copy into `out` (uint8, ideally pinned);
+        `changes` (uint8[total_sites], G-space) optional.  -> contig_off uint64[n_contigs + 1]."""
+        ln = C.c_uint64(0)
+        off = np.zeros(len(self.contig_lens) + 1, np.uint64)
+        self._check(self.lib.dll.kd_consensus_fetch_all(self._h, _ptr(out), out.size, C.byref(ln), _ptr(off),
+                                                        _ptr(changes) if changes is not None else None),
+                    "kd_consensus_fetch_all")
+        return off
+
     def consensus_fetch(self, contig, want_changes=True):
         """-> (bytes, changes uint8[L] | None, (min_depth, max_depth), patch_off uint64[n_patches])."""
         ln = C.c_uint64(0)
@@ -314,6 +325,16 @@ class Engine:
                     "kd_consensus_fetch")
         return (seq[: ln.value].tobytes(), changes[:L] if want_changes else None, (int(mm[0]), int(mm[1])),
                 poff[: self._n_patches])
+
+    def consensus_meta(self, contig):
+        """Host-side results of the last run for one contig, no device traffic:
+        -> (n_bytes, (min_depth, max_depth), patch_off uint64[n_patches])."""
+        ln = C.c_uint64(0)
+        mm = np.zeros(2, np.uint32)
+        poff = np.zeros(max(self._n_patches, 1), np.uint64)
+        self._check(self.lib.dll.kd_consensus_fetch(self._h, contig, None, 0, C.byref(ln), None, _ptr(mm), _ptr(poff)),
+                    "kd_consensus_fetch")
+        return ln.value, (int(mm[0]), int(mm[1])), poff[: self._n_patches]
 
     def consensus_device(self):
         p, n = C.c_void_p(), C.c_uint64(0)

@@ -99,6 +99,10 @@ int kd_consensus_fetch(kd_ctx *ctx, uint32_t contig, uint8_t *seq_out, uint64_t 
                        uint8_t *changes, uint32_t *depth_minmax, uint64_t *patch_off) {
     return ctx ? ctx->e.consensus_fetch(contig, seq_out, cap, len_out, changes, depth_minmax, patch_off) : KD_E_ARG;
 }
+int kd_consensus_fetch_all(kd_ctx *ctx, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint64_t *contig_off,
+                           uint8_t *changes) {
+    return ctx ? ctx->e.consensus_fetch_all(seq_out, cap, len_out, contig_off, changes) : KD_E_ARG;
+}
 int kd_consensus_device(kd_ctx *ctx, void **dev_ptr, uint64_t *n_bytes) {
     if (!ctx || !dev_ptr || !n_bytes) return KD_E_ARG;
     if (!ctx->e.have_cns) return ctx->e.fail(KD_E_ARG, "kd_consensus_device: call kd_consensus_run first");

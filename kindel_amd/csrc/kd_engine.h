@@ -553,4 +553,18 @@ struct KdEngine {
             }
         return KD_OK;
     }
+
+    int consensus_fetch_all(uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint64_t *contig_off, uint8_t *changes) {
+        if (!have_cns) return fail(KD_E_ARG, "kd_consensus_fetch_all: call kd_consensus_run first");
+        const uint64_t o0 = h_coff[0], o1 = h_coff[n_contigs];
+        if (len_out) *len_out = o1 - o0;
+        if (contig_off)
+            for (uint32_t c = 0; c <= n_contigs; c++) contig_off[c] = h_coff[c] - o0;
+        if (seq_out) {
+            if (o1 - o0 > cap) return fail(KD_E_ARG, "kd_consensus_fetch_all: buffer too small");
+            if (o1 > o0 && rt.d2h(seq_out, (uint8_t *)b_cns.p + o0, o1 - o0)) return hipfail("consensus fetch: d2h");
+        }
+        if (changes && S && rt.d2h(changes, b_changes.p, S)) return hipfail("consensus fetch: d2h changes");
+        return KD_OK;
+    }
 };

@@ -402,6 +402,44 @@ def _device_consensus(pl, cid, cdr_patches, trim_ends, min_depth, uppercase):
     return seq, ch, mm
 
 
+def _device_consensus_all(pl, patches_by_cid, trim_ends, min_depth, uppercase):
+    """All contigs of the input with ONE consensus run and ONE device-to-host copy (the reference loops
+    consensus_sequence over the contigs, kindel.py:515-551) -> {cid: (seq, changes, depth_minmax)}."""
+    eng = pl.engine
+    plans = {cid: _patch_plan(int(pl.lens[cid]), patches_by_cid.get(cid)) for cid in pl.order}
+    flat, owner = [], []
+    for cid in pl.order:
+        base = eng.contig_base(cid)
+        for s, e, _ in plans[cid]:
+            flat.append((base + s, base + e)); owner.append(cid)
+    eng.consensus_run(min_depth, flat)
+    off, _ = eng.consensus_offsets()
+    buf = np.empty(int(off[-1]) + 16, np.uint8)
+    chg = np.empty(max(eng.total_sites(), 1), np.uint8)
+    off = eng.consensus_fetch_all_into(buf, chg)
+    out = {}
+    for cid in pl.order:
+        L = int(pl.lens[cid])
+        base = eng.contig_base(cid)
+        raw = buf[int(off[cid]): int(off[cid + 1])].tobytes()
+        _, mm, poff = eng.consensus_meta(cid)
+        plan = plans[cid]
+        if plan:
+            mine = [o for o, c in zip(poff.tolist(), owner) if c == cid]
+            parts, prev = [], 0
+            for (s, e, text), o in zip(plan, mine):
+                parts.append(raw[prev:o]); parts.append(text.encode()); prev = o
+            parts.append(raw[prev:])
+            raw = b"".join(parts)
+        seq = raw.decode("ascii")
+        if trim_ends:
+            seq = seq.strip("N")        # kindel.py:425-426
+        if uppercase:
+            seq = seq.upper()           # kindel.py:427-428
+        out[cid] = (seq, chg[base: base + L].copy(), mm)
+    return out
+
+
 _CHG = {0: None, ord("D"): "D", ord("N"): "N", ord("I"): "I"}
 
 
@@ -468,17 +506,20 @@ def bam_to_consensus(bam_path, realign=False, min_depth=1, min_overlap=9, clip_d
     """bam_to_consensus of kindel.py:488-555: same arguments, same result tuple."""
     consensuses, refs_changes, refs_reports = [], {}, {}
     pl = pileup_file(bam_path)
+    patches = {}
     for cid in pl.order:
-        ref_id = pl.names[cid]
         if realign:
             aln = pl.alignment(cid)
             cdrps = cdrp_consensuses(aln.weights, aln.deletions, aln.clip_start_weights, aln.clip_end_weights,
                                      aln.clip_start_depth, aln.clip_end_depth, clip_decay_threshold, mask_ends)
-            cdr_patches = merge_cdrps(cdrps, min_overlap)
+            patches[cid] = merge_cdrps(cdrps, min_overlap)
         else:
-            cdr_patches = None
-        seq, ch, mm = _device_consensus(pl, cid, cdr_patches, trim_ends, min_depth, uppercase)
-        report = _report(ref_id, mm, ch, cdr_patches, bam_path, realign, min_depth, min_overlap, clip_decay_threshold,
+            patches[cid] = None
+    done = _device_consensus_all(pl, patches, trim_ends, min_depth, uppercase)
+    for cid in pl.order:
+        ref_id = pl.names[cid]
+        seq, ch, mm = done[cid]
+        report = _report(ref_id, mm, ch, patches[cid], bam_path, realign, min_depth, min_overlap, clip_decay_threshold,
                          trim_ends, uppercase)
         consensuses.append(consensus_seqrecord(seq, ref_id))
         refs_reports[ref_id] = report

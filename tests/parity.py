@@ -179,3 +179,26 @@ def expected_variants(batch, abs_threshold=1, rel_threshold=0.01, only_variants=
 
 def variants_rows(df):
     return [(r.chrom, int(r.pos), r.ref, r.alt, r.type, int(r.count), int(r.depth)) for r in df.itertuples(index=False)]
+
+
+def check_fetch_all(lib, batch, min_depth=1):
+    eng = N.Engine(batch["contig_lens"], lib=lib)
+    try:
+        eng.push(batch)
+        eng.finalize()
+        eng.consensus_run(min_depth)
+        n = len(batch["contig_lens"])
+        off0, _ = eng.consensus_offsets()
+        buf = np.zeros(int(off0[-1]) + 8, np.uint8)
+        chg = np.zeros(eng.total_sites(), np.uint8)
+        off = eng.consensus_fetch_all_into(buf, chg)
+        assert np.array_equal(off, off0 - off0[0])
+        for c in range(n):
+            seq, ch, _, _ = eng.consensus_fetch(c)
+            assert buf[int(off[c]): int(off[c + 1])].tobytes() == seq, c
+            b = eng.contig_base(c)
+            assert np.array_equal(chg[b: b + len(ch)], ch), c
+        with np.testing.assert_raises(Exception):
+            eng.consensus_fetch_all_into(np.zeros(max(int(off[-1]) - 1, 0), np.uint8))
+    finally:
+        eng.close()

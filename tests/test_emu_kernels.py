@@ -114,3 +114,8 @@ def test_virtual_shards_stitch_to_the_unsharded_result(emu_lib):
                 assert np.array_equal(run.tables[c][:, lo:hi], full.tables[c][:, lo:hi])
     for c in full.order:
         assert b"".join(pieces[c]) == full.cns[c][0]
+
+
+def test_fetch_all_equals_per_contig_fetch(emu_lib):
+    """kd_consensus_fetch_all: one copy for every contig == the per-contig kd_consensus_fetch results."""
+    P.check_fetch_all(emu_lib, P.load_fixture("minimap2__1.1.multi"))

@@ -231,3 +231,9 @@ def test_cli_consensus_stdout(hip_lib, tmp_path):
     r = subprocess.run([sys.executable, "-m", "kindel_amd", "consensus", "-r", "-t", "-u", path], cwd=ROOT,
                        capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.split("\n")[1] == g["realign_consensus"].strip("N").upper()
+
+
+def test_fetch_all_equals_per_contig_fetch(hip_lib):
+    P.check_fetch_all(hip_lib, P.load_fixture("minimap2__1.1.multi"))
+    from kindel_amd import synth
+    P.check_fetch_all(hip_lib, synth.to_numpy(synth.make("C4", scale=0.02)))
