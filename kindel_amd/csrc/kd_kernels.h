@@ -1065,6 +1065,16 @@ __device__ __forceinline__ void kd_add_dword(uint32_t *hist0, int32_t Wh, uint32
     else kd_add8_part(hist0, Wh, v, sx + xs, ra - xs, rb - xs);
 }
 
+// CIGAR words k0 .. k0+3 of a read with nc words: one unaligned 16-byte load when all four are the read's own
+// (never touches memory past the batch's CIGAR array), guarded single loads for the read's last group
+__device__ __forceinline__ KdChunk kd_load_cigar4(const uint32_t *cg, uint32_t k0, uint32_t nc) {
+    if (k0 + 4 <= nc) return *reinterpret_cast<const KdChunk *>(cg + k0);
+    KdChunk r;
+    r.x = k0 < nc ? cg[k0] : 0u; r.y = k0 + 1 < nc ? cg[k0 + 1] : 0u;
+    r.z = k0 + 2 < nc ? cg[k0 + 2] : 0u; r.w = 0u;
+    return r;
+}
+
 // General per-lane walk of one regular read against the window (reads with clips, indels, long CIGARs).
 // A state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the current run), not over
 // CIGAR ops, so that lanes keep adding bases together whatever their op structure.  A soft clip is a
@@ -1097,9 +1107,22 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
     // current M run), not over CIGAR ops: lanes whose reads have clips or indels still add
     // bases in the same wavefront instructions as their single-run neighbours.
     int32_t xa = 0, xb = 0, ra = 0, rb = 0, sx = 0, c = 1, cb = 0;   // c > cb: no live run
+    // CIGAR words four at a time (one unaligned 16-byte load, the next four already in flight), and the last
+    // 16-byte chunk of bases kept: a long read's runs are a few bases each, so consecutive runs share a chunk
+    // and one load per op would make the walk a chain of dependent HBM round trips.
+    uint32_t kw = k & ~3u;                     // cw_cur holds words kw .. kw + 3
+    KdChunk cw_cur = kd_load_cigar4(cg, kw, nc), cw_nxt = cw_cur;
+    if (kw + 4 < nc) cw_nxt = kd_load_cigar4(cg, kw + 4, nc);
+    int32_t c_have = -1;
+    KdChunk cur = cw_cur;
     for (;;) {
         while (c > cb && k < nc) {   // advance to the next run with live bases
-            const uint32_t cw = cg[k];
+            if (k >= kw + 4) {
+                kw += 4; cw_cur = cw_nxt;
+                if (kw + 4 < nc) cw_nxt = kd_load_cigar4(cg, kw + 4, nc);
+            }
+            const uint32_t kk = k & 3u;
+            const uint32_t cw = kk == 0 ? cw_cur.x : kk == 1 ? cw_cur.y : kk == 2 ? cw_cur.z : cw_cur.w;
             const int32_t len = (int32_t)(cw >> 4);
             const uint32_t op = cw & 15u;
             k++;
@@ -1144,7 +1167,7 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
             }
         }
         if (c > cb) break;
-        const KdChunk cur = src[c];
+        if (c != c_have) { cur = src[c]; c_have = c; }
         const int32_t xs = 32 * c;
         kd_add_dword(hist0, Wh, cur.x, xs, xa, xb, ra, rb, sx);
         kd_add_dword(hist0, Wh, cur.y, xs + 8, xa, xb, ra, rb, sx);
