@@ -366,7 +366,7 @@ struct KdEngine {
         uint64_t clo, chi;
         shard_cover(clo, chi);
         if ((rc = ensure(b_win, (size_t)S * 4))) return rc;
-        if (rt.memset((uint32_t *)b_win.p + clo, 0xff, (size_t)(chi - clo) * 4)) return hipfail("finalize: memset win");
+        if (rt.memset((uint32_t *)b_win.p + clo, 0, (size_t)(chi - clo) * 4)) return hipfail("finalize: memset win");   // KD_INS_NONE
         const uint64_t n_ev = h_status[KDS_N_EV];
         n_ev_final = n_ev; pool_final = h_status[KDS_POOL];
         if (n_ev) {
@@ -399,8 +399,7 @@ struct KdEngine {
             kd_u64 *best = (kd_u64 *)b_best.p;
             uint32_t *win = (uint32_t *)b_win.p;
             if (rt.launch("k_ins_site_max", k_ins_site_max, gs, KD_BLOCK, 0, I, H, best) ||
-                rt.launch("k_ins_site_tie", k_ins_site_tie, gs, KD_BLOCK, 0, I, H, (const kd_u64 *)best, win) ||
-                rt.launch("k_ins_site_win", k_ins_site_win, gs, KD_BLOCK, 0, I, H, (const kd_u64 *)best, win))
+                rt.launch("k_ins_site_pick", k_ins_site_pick, gs, KD_BLOCK, 0, I, H, (const kd_u64 *)best, win))
                 return hipfail("k_ins_site_*");
         }
         finalized = true; have_cns = false; have_inskeys = false;

@@ -1521,8 +1521,10 @@ k_find_bad_base(KdReads rd, KdTabs T, const KdRInfo *rinfo, kd_u64 *status) {
 // Insertion multiset: insertions[site][string] += 1 (kindel.py:55-58) and
 // consensus(insertions[site]) (kindel.py:420-421) -> per site: unique majority string or tie.
 // ---------------------------------------------------------------------------------------
-#define KD_INS_NONE 0xffffffffu
-#define KD_INS_TIE 0xfffffffeu
+// win[site]: 0 = no insertion string, event index + 1 = the unique majority string, KD_INS_TIE = several strings
+// share the top count.  Ordered so that one atomicMax per hash slot settles it (TIE beats a winner beats NONE).
+#define KD_INS_NONE 0u
+#define KD_INS_TIE 0xffffffffu
 
 struct KdInsTab {
     kd_u64 *key;     // [cap] 0 = empty
@@ -1582,22 +1584,17 @@ k_ins_site_max(KdIns ins, KdInsTab H, kd_u64 *best) {
     if (s >= H.cap || H.key[s] == 0) return;
     atomicMax(&best[ins.ev_site[H.rep[s]]], ((kd_u64)H.cnt[s] << 32) | s);
 }
-// pass 2: another slot of the same site with the same count -> tie (kindel.py:377, :421)
+// pass 2: the best slot of a site nominates its representative event; any OTHER slot of the site with the same
+// count makes it a tie (kindel.py:377, :421)
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_site_tie(KdIns ins, KdInsTab H, const kd_u64 *best, uint32_t *win) {
+k_ins_site_pick(KdIns ins, KdInsTab H, const kd_u64 *best, uint32_t *win) {
     const kd_u64 s = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
     if (s >= H.cap || H.key[s] == 0) return;
-    const uint32_t site = ins.ev_site[H.rep[s]];
+    const uint32_t rep = H.rep[s];
+    const uint32_t site = ins.ev_site[rep];
     const kd_u64 b = best[site];
-    if ((uint32_t)(b >> 32) == H.cnt[s] && (uint32_t)b != (uint32_t)s) win[site] = KD_INS_TIE;
-}
-// pass 3: sites without a tie get the representative event of their best slot
-__global__ void __launch_bounds__(KD_BLOCK)
-k_ins_site_win(KdIns ins, KdInsTab H, const kd_u64 *best, uint32_t *win) {
-    const kd_u64 s = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (s >= H.cap || H.key[s] == 0) return;
-    const uint32_t site = ins.ev_site[H.rep[s]];
-    if ((uint32_t)best[site] == (uint32_t)s && win[site] != KD_INS_TIE) win[site] = H.rep[s];
+    if ((uint32_t)(b >> 32) != H.cnt[s]) return;
+    atomicMax(&win[site], (uint32_t)b == (uint32_t)s ? rep + 1u : KD_INS_TIE);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1609,7 +1606,7 @@ k_ins_site_win(KdIns ins, KdInsTab H, const kd_u64 *best, uint32_t *win) {
 
 struct KdCns {
     const uint32_t *seg_contig;  // [S/64] contig of each 64-site segment
-    const uint32_t *ins_win;     // [S] KD_INS_NONE / KD_INS_TIE / event index of the unique majority
+    const uint32_t *ins_win;     // [S] KD_INS_NONE / KD_INS_TIE / 1 + event index of the unique majority
     uint32_t min_depth;
     uint32_t n_patches;
     const kd_u64 *patch_start, *patch_end;  // skip ranges in G-space (kindel.py:393-401)
@@ -1650,7 +1647,7 @@ __device__ __forceinline__ KdSite kd_site_eval(const KdTabs &T, const KdCns &C, 
         s.change = 'I';
         const uint32_t wv = C.ins_win[g];
         if (wv == KD_INS_TIE || wv == KD_INS_NONE) { s.ins = 2; s.ins_len = 1; }
-        else { s.ins = 1; s.ins_ev = wv; s.ins_len = ins.ev_len[wv]; }
+        else { s.ins = 1; s.ins_ev = wv - 1u; s.ins_len = ins.ev_len[wv - 1u]; }
     }
     // consensus(weight): first max in A,T,G,C,N order, tie -> 'N'  (kindel.py:369-381, :423-424)
     uint32_t best = a; uint8_t bc = 'A';
