@@ -41,7 +41,7 @@ struct KdEngine {
         void *p = nullptr;
         size_t cap = 0;
     };
-    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_ckpt;
+    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_ckpt, b_seginfo;
     Buf b_stage[9];
     Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
     uint64_t ev_cap = 0, pool_cap = 0;
@@ -130,7 +130,7 @@ struct KdEngine {
     }
 
     void destroy() {
-        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_itemwin, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ckpt, &b_ev_site, &b_ev_len,
+        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_itemwin, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ckpt, &b_seginfo, &b_ev_site, &b_ev_len,
                       &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_win, &b_cns, &b_changes,
                       &b_tilesum, &b_tileoff, &b_coff, &b_minmax, &b_pstart, &b_pend, &b_poff};
         for (Buf *b : all) release(*b);
@@ -206,9 +206,12 @@ struct KdEngine {
         if ((rc = fetch_status())) return rc;
         const uint64_t n_long = h_status[KDS_B_N_LONG];
         if (n_long) {
-            if ((rc = ensure(b_ckpt, (size_t)n_long * KD_BLOCK * sizeof(KdCkpt)))) return rc;
+            if ((rc = ensure(b_ckpt, (size_t)n_long * KD_BLOCK * sizeof(KdCkpt))) ||
+                (rc = ensure(b_seginfo, (size_t)n_long * KD_BLOCK * sizeof(KdRInfo))))
+                return rc;
             if (rt.launch("k_prep_long", k_prep_long, (unsigned)n_long, KD_BLOCK, 0, R, T, rinfo,
-                          (const uint32_t *)lng, (KdCkpt *)b_ckpt.p, irreg, (uint32_t *)b_readev.p, (kd_u64 *)b_readpool.p, d_status))
+                          (const uint32_t *)lng, (KdCkpt *)b_ckpt.p, (KdRInfo *)b_seginfo.p, irreg, (uint32_t *)b_readev.p,
+                          (kd_u64 *)b_readpool.p, d_status))
                 return hipfail("k_prep_long");
             if ((rc = fetch_status())) return rc;
         }
@@ -236,58 +239,68 @@ struct KdEngine {
         if (windowed) {
             const uint32_t w0 = (uint32_t)(g_lo / W);   // windows intersecting the shard's commit range only
             const uint32_t n_win = (uint32_t)((std::min<uint64_t>(S, g_hi + 1) + W - 1) / W) - w0;
-            uint32_t slice = slice_cfg;
-            if (!slice) {  // aim for a few thousand work items, slices big enough to amortise the LDS flush
-                uint64_t s = n / 4096;
-                slice = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(256, s));
-            }
-            slice = std::min<uint32_t>(slice, 32768u);   // u16 LDS counters: an item may not tally more reads than that
             if ((rc = ensure(b_winlo, (size_t)n_win * 8)) || (rc = ensure(b_winhi, (size_t)n_win * 8)) ||
                 (rc = ensure(b_itemoff, ((size_t)n_win + 1) * 8)))
                 return rc;
             kd_u64 *wl = (kd_u64 *)b_winlo.p, *wh = (kd_u64 *)b_winhi.p, *io = (kd_u64 *)b_itemoff.p;
-            const uint32_t *order = nullptr;
-            if (sorted_input) {
-                if (rt.launch("k_plan_ranges", k_plan_ranges, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
-                              (const KdRInfo *)rinfo, (kd_u64)n, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status))
-                    return hipfail("k_plan_ranges");
-            } else {
-                // unsorted batch: counting sort of the regular reads by window -> permutation `order`
-                const uint32_t n_bins = (uint32_t)((S + W - 1) / W);
-                if ((rc = ensure(b_order, n * 4)) || (rc = ensure(b_bincnt, ((size_t)n_bins + 1) * 4)) ||
-                    (rc = ensure(b_binoff, ((size_t)n_bins + 1) * 8)))
-                    return rc;
-                uint32_t *ord = (uint32_t *)b_order.p, *bc = (uint32_t *)b_bincnt.p;
-                kd_u64 *bo = (kd_u64 *)b_binoff.p;
-                const unsigned gr = (unsigned)((n + KD_BLOCK - 1) / KD_BLOCK);
-                if (rt.memset(bc, 0, ((size_t)n_bins + 1) * 4) ||
-                    rt.launch("k_sort_count", k_sort_count, gr, KD_BLOCK, 0, (const KdRInfo *)rinfo, (kd_u64)n, W, bc) ||
-                    rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, n_bins) ||
-                    rt.launch("k_sort_scatter", k_sort_scatter, gr, KD_BLOCK, 0, (const KdRInfo *)rinfo, (kd_u64)n, W, bc,
-                              (const kd_u64 *)bo, ord) ||
-                    rt.launch("k_plan_ranges_sorted", k_plan_ranges_sorted, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
-                              (const kd_u64 *)bo, n_bins, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status))
-                    return hipfail("k_sort_*");
-                order = ord;
-            }
-            // work item -> window table; an item is (window, slice of its candidate reads): at most one per window
-            // plus one per `slice` (read, window) candidate pairs, and a read is a candidate of the windows its
-            // footprint (<= max span + max lead, both known from k_prep) can touch
-            const uint64_t reach = h_status[KDS_B_MAXSPAN] / W + h_status[KDS_B_MAXLEAD] / W + 4;   // whole-bin ranges of the unsorted path included
-            const uint64_t items_cap = (uint64_t)n_win + (n * reach) / slice + 1;
-            if ((rc = ensure(b_itemwin, items_cap * 4))) return rc;
-            uint32_t *iw = (uint32_t *)b_itemwin.p;
-            if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, d_status) ||
-                rt.launch("k_plan_items", k_plan_items, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, (const kd_u64 *)io, n_win, iw,
-                          (kd_u64)items_cap, d_status))
-                return hipfail("k_plan_scan");
-            uint32_t Wh = (W + 2 * KD_HALO) / 2;   // dwords per channel row
-            const size_t lds = KD_WINDOW_LDS_BYTES(Wh);
-            const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
-            const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
-            if (rt.launch("k_window", k_window, grid, KD_BLOCK, lds, R, (const KdRInfo *)rinfo, order, (const KdCkpt *)b_ckpt.p, T, (const kd_u64 *)wl,
-                          (const kd_u64 *)wh, (const kd_u64 *)io, (const uint32_t *)iw, (kd_u64)items_cap, w0, W, Wh, slice, d_status))
-                return hipfail("k_window");
+            // One pass of k_window over `ne` entries described by `info`: the batch's reads (seg_read == NULL), then the
+            // SEGMENTS of its long reads (k_prep_long), which are bucket-sorted by window like an unsorted batch.
+            auto window_pass = [&](const KdRInfo *info, uint64_t ne, bool in_order, const uint32_t *seg_read, uint32_t span_slot) -> int {
+                int rc2;
+                uint32_t slice = slice_cfg;
+                if (!slice) {  // aim for a few thousand work items, slices big enough to amortise the LDS flush
+                    uint64_t s = ne / 4096;
+                    slice = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(256, s));
+                }
+                slice = std::min<uint32_t>(slice, 32768u);   // u16 LDS counters: an item may not tally more reads than that
+                const uint32_t *order = nullptr;
+                if (in_order) {
+                    if (rt.launch("k_plan_ranges", k_plan_ranges, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, info, (kd_u64)ne, w0,
+                                  n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status))
+                        return hipfail("k_plan_ranges");
+                } else {
+                    // counting sort of the regular entries by window -> permutation `order`
+                    const uint32_t n_bins = (uint32_t)((S + W - 1) / W);
+                    if ((rc2 = ensure(b_order, ne * 4)) || (rc2 = ensure(b_bincnt, ((size_t)n_bins + 1) * 4)) ||
+                        (rc2 = ensure(b_binoff, ((size_t)n_bins + 1) * 8)))
+                        return rc2;
+                    uint32_t *ord = (uint32_t *)b_order.p, *bc = (uint32_t *)b_bincnt.p;
+                    kd_u64 *bo = (kd_u64 *)b_binoff.p;
+                    const unsigned gr = (unsigned)((ne + KD_BLOCK - 1) / KD_BLOCK);
+                    if (rt.memset(bc, 0, ((size_t)n_bins + 1) * 4) ||
+                        rt.launch("k_sort_count", k_sort_count, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc) ||
+                        rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, n_bins) ||
+                        rt.launch("k_sort_scatter", k_sort_scatter, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, (const kd_u64 *)bo, ord) ||
+                        rt.launch("k_plan_ranges_sorted", k_plan_ranges_sorted, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
+                                  (const kd_u64 *)bo, n_bins, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status, span_slot))
+                        return hipfail("k_sort_*");
+                    order = ord;
+                }
+                // work item -> window table; an item is (window, slice of its candidates): at most one per window plus
+                // one per `slice` (entry, window) candidate pairs, and an entry is a candidate of the windows its
+                // footprint (<= max span + max lead, both known from k_prep / k_prep_long) can touch
+                const uint64_t reach = h_status[span_slot] / W + h_status[KDS_B_MAXLEAD] / W + 4;   // whole-bin ranges included
+                const uint64_t items_cap = (uint64_t)n_win + (ne * reach) / slice + 1;
+                if ((rc2 = ensure(b_itemwin, items_cap * 4))) return rc2;
+                uint32_t *iw = (uint32_t *)b_itemwin.p;
+                if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, d_status) ||
+                    rt.launch("k_plan_items", k_plan_items, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, (const kd_u64 *)io, n_win, iw,
+                              (kd_u64)items_cap, d_status))
+                    return hipfail("k_plan_scan");
+                const uint32_t Wh = (W + 2 * KD_HALO) / 2;   // dwords per channel row
+                const size_t lds = KD_WINDOW_LDS_BYTES(Wh);
+                const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
+                const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
+                if (rt.launch(seg_read ? "k_window_segments" : "k_window", k_window, grid, KD_BLOCK, lds, R, info, order,
+                              (const KdCkpt *)b_ckpt.p, seg_read, T, (const kd_u64 *)wl, (const kd_u64 *)wh, (const kd_u64 *)io,
+                              (const uint32_t *)iw, (kd_u64)items_cap, w0, W, Wh, slice, d_status))
+                    return hipfail("k_window");
+                return KD_OK;
+            };
+            if ((rc = window_pass((const KdRInfo *)rinfo, n, sorted_input, nullptr, (uint32_t)KDS_B_MAXSPAN))) return rc;
+            if (n_long && (rc = window_pass((const KdRInfo *)b_seginfo.p, n_long * KD_BLOCK, false, (const uint32_t *)lng,
+                                            (uint32_t)KDS_B_MAXSEGSPAN)))
+                return rc;
             if (n_cold &&
                 rt.launch("k_cold_lane", k_cold_lane, (unsigned)((n_cold + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, R, T, I,
                           (const uint32_t *)cold, (kd_u64)n_cold, d_status))

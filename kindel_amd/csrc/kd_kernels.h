@@ -84,6 +84,7 @@ enum {
     KDS_B_INS_BASES,    // per batch: insertion bases
     KDS_B_MAXSPAN,      // per batch: max span of regular reads
     KDS_B_MAXLEAD,      // per batch: max leading-clip reach of regular reads
+    KDS_B_MAXSEGSPAN,   // per batch: max span of a long read's SEGMENT (k_prep_long; k_window's second pass)
     KDS_B_UNSORTED,     // per batch: reads not sorted by G-start
     KDS_B_N_COLD,       // per batch: entries in the cold list
     KDS_B_N_IRREG,      // per batch: entries in the irregular list
@@ -399,12 +400,13 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
 // of a contiguous run of ops, an LDS scan turns the sums into start coordinates, and a
 // second sweep applies the same regularity rules as kd_scan_cigar.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdCkpt *ckpt,
+k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdCkpt *ckpt, KdRInfo *seginfo,
             uint32_t *irreg_list, uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
     __shared__ int64_t s_r[KD_BLOCK], s_q[KD_BLOCK];
     __shared__ uint32_t s_ni[KD_BLOCK], s_nb[KD_BLOCK];
     __shared__ kd_u64 s_acc[6];       // aligned, walked, n_ins, ins_bases, bad, cold
     __shared__ uint32_t s_first_nfs, s_last_rel;
+    __shared__ uint32_t s_regular, s_lead, s_gstart, s_nfs_adv, s_maxseg;
     const uint32_t t = threadIdx.x;
     const kd_u64 i = long_list[blockIdx.x];
     const uint32_t c = rd.contig[i];
@@ -416,7 +418,7 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdC
     const uint32_t per = (nc + KD_BLOCK - 1) / KD_BLOCK;
     const uint32_t k0 = t * per < nc ? t * per : nc, k1 = k0 + per < nc ? k0 + per : nc;
     if (t < 6) s_acc[t] = 0;
-    if (t == 0) { s_first_nfs = 0xffffffffu; s_last_rel = 0; }
+    if (t == 0) { s_first_nfs = 0xffffffffu; s_last_rel = 0; s_regular = 0; s_lead = 0; s_gstart = 0; s_nfs_adv = 0; s_maxseg = 0; }
     int64_t dr = 0, dq = 0;
     for (uint32_t k = k0; k < k1; k++) {
         const uint32_t w = cg[k];
@@ -505,18 +507,23 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdC
             if ((cg[0] & 15u) == 4u) { const int64_t l0 = cg[0] >> 4; lead = (uint32_t)(l0 < pos0 ? l0 : pos0); }
             if (s_first_nfs != 0xffffffffu) {  // trailing clip: r at that op is r_end (nothing after it moves r)
                 const int64_t ls = cg[s_first_nfs] >> 4;
-                foot_end += r_end < L ? (ls < L - r_end ? ls : L - r_end) : 0;
+                const int64_t adv = r_end < L ? (ls < L - r_end ? ls : L - r_end) : 0;
+                foot_end += adv;
+                s_nfs_adv = (uint32_t)adv;
             }
         }
         kd_u64 span = foot_end > pos0 ? (kd_u64)(foot_end - pos0) : 0;
         if (span > 0x07ffffffULL) { regular = false; span = 0; }
         const uint32_t coldbit = s_acc[5] ? KD_INFO_COLD : 0u;
         KdRInfo ri = rinfo[i];
+        // a regular long read KEEPS class LONG: k_window's first pass (class REG) leaves it alone, its aligned and
+        // deleted bases are tallied segment by segment in the second pass, its S / I side effects by k_cold_long
         ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | (s_acc[2] ? KD_INFO_INS : 0u) | coldbit |
-                      (regular ? KD_CLS_REG : KD_CLS_IRREG);
+                      (regular ? KD_CLS_LONG : KD_CLS_IRREG);
         ri.lead = regular ? lead : 0u;
         ri.pad = regular ? blockIdx.x + 1u : 0u;
         rinfo[i] = ri;
+        s_regular = regular ? 1u : 0u; s_lead = ri.lead; s_gstart = ri.gstart;
         if (s_acc[2]) {
             read_ev[i] = (uint32_t)atomicAdd(&status[KDS_N_EV], s_acc[2]);
             read_pool[i] = atomicAdd(&status[KDS_POOL], s_acc[3]);
@@ -527,13 +534,35 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdC
         if (s_acc[3]) atomicAdd(&status[KDS_B_INS_BASES], s_acc[3]);
         if (regular) {
             atomicAdd(&status[KDS_B_N_REG], 1ULL);
-            atomicMax(&status[KDS_B_MAXSPAN], span);
             if (lead) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)lead);
             // (its S / I side effects are done by k_cold_long, 256 threads per read)
         } else {
             irreg_list[atomicAdd(&status[KDS_B_N_IRREG], 1ULL)] = (uint32_t)i;
         }
     }
+    __syncthreads();
+    // SEGMENTS: this thread's run of ops [k0, k1) as a work unit of its own -- where it starts on the reference
+    // (checkpoint), how far its M / D / trailing-clip tallies reach.  k_window's second pass treats the segments of all
+    // long reads like a batch of short reads: bucket-sorted by window, one lane per segment, a few ops each,
+    // instead of one lane crawling through the hundreds of ops a long read has inside a window.
+    {
+        KdRInfo v;
+        v.gstart = 0; v.span_cls = KD_CLS_SKIP; v.lead = 0; v.pad = 0;
+        if (s_regular && k0 < k1) {
+            kd_u64 sp = (kd_u64)(r - r_run);                         // M and D advance of the run
+            if (first_nfs != 0xffffffffu) sp += s_nfs_adv;           // the trailing clip's clip_start_weights reach
+            const uint32_t ld = k0 == 0 ? s_lead : 0u;               // the leading clip reaches back from the read's start
+            if (sp > 0 || ld > 0) {
+                v.gstart = s_gstart + (uint32_t)(r_run - pos0);
+                v.span_cls = ((uint32_t)sp << KD_SPAN_SHIFT) | KD_CLS_REG;
+                v.lead = ld; v.pad = blockIdx.x + 1u;
+                atomicMax(&s_maxseg, (uint32_t)sp);
+            }
+        }
+        seginfo[(kd_u64)blockIdx.x * KD_BLOCK + t] = v;
+    }
+    __syncthreads();
+    if (t == 0 && s_maxseg) atomicMax(&status[KDS_B_MAXSEGSPAN], (kd_u64)s_maxseg);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -739,7 +768,7 @@ k_cold_long(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint32_
     const uint32_t t = threadIdx.x;
     const kd_u64 i = long_list[blockIdx.x];
     const uint32_t sc = rinfo[i].span_cls;
-    if ((sc & 3u) != KD_CLS_REG || !(sc & KD_INFO_COLD)) return;
+    if ((sc & 3u) != KD_CLS_LONG || !(sc & KD_INFO_COLD)) return;   // LONG after k_prep_long = regular long read
     const uint32_t nc = rd.n_cig[i];
     const uint32_t per = (nc + KD_BLOCK - 1) / KD_BLOCK;
     const uint32_t k0 = t * per < nc ? t * per : nc, k1 = k0 + per < nc ? k0 + per : nc;
@@ -937,11 +966,11 @@ k_sort_scatter(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t W, uint32_t *bin_f
 // candidate range of window w0 + w in `order`: whole bins covering [wlo - maxspan, whi + maxlead)
 __global__ void __launch_bounds__(KD_BLOCK)
 k_plan_ranges_sorted(const kd_u64 *bin_off, uint32_t n_bins, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t slice,
-                     kd_u64 *win_lo, kd_u64 *win_hi, kd_u64 *item_off, const kd_u64 *status) {
+                     kd_u64 *win_lo, kd_u64 *win_hi, kd_u64 *item_off, const kd_u64 *status, uint32_t span_slot) {
     const uint32_t w = blockIdx.x * KD_BLOCK + threadIdx.x;
     if (w >= n_win) return;
     const kd_u64 wlo = (kd_u64)(w0 + w) * W, whi = wlo + W;
-    const kd_u64 maxspan = status[KDS_B_MAXSPAN], maxlead = status[KDS_B_MAXLEAD];
+    const kd_u64 maxspan = status[span_slot], maxlead = status[KDS_B_MAXLEAD];   // span_slot: KDS_B_MAXSPAN / KDS_B_MAXSEGSPAN
     const kd_u64 blo = (wlo > maxspan ? wlo - maxspan : 0) / W;
     kd_u64 bhi = (whi + maxlead + W - 1) / W;   // exclusive
     if (bhi > n_bins) bhi = n_bins;
@@ -1079,30 +1108,16 @@ __device__ __forceinline__ KdChunk kd_load_cigar4(const uint32_t *cg, uint32_t k
 // A state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the current run), not over
 // CIGAR ops, so that lanes keep adding bases together whatever their op structure.  A soft clip is a
 // run of its own on the clip_start / clip_end channel group.
-__device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, const KdRInfo ri, const KdCkpt *ckpt, kd_u64 wlo,
-                                                int32_t Wi, int32_t Wh, uint32_t *hist0) {
+// Ops [k, k_end) of read i, entered with the reference cursor at window-relative site `grel` and the query cursor
+// at q: the whole CIGAR of a short read with many segments (k = 0, k_end = n_cig), or ONE SEGMENT of a long read
+// (k_prep_long's checkpoint).  `lead` / `foot_end`: reach of the leading clip / window-relative end of the footprint
+// (used by the clip ops, which sit in the first / last segment).
+__device__ __forceinline__ void kd_walk_ops(const KdReads &rd, kd_u64 i, uint32_t k, uint32_t k_end, int32_t grel, int32_t q,
+                                            int32_t lead, int32_t foot_end, int32_t Wi, int32_t Wh, uint32_t *hist0) {
     const int32_t Wp = 2 * Wh;   // sites per channel row, halos included
-    const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
     const uint32_t nc = rd.n_cig[i];
     const uint32_t *cg = rd.cigar + rd.cig_off[i];
-    const int32_t lead = (int32_t)ri.lead;
-    const int32_t foot_end = (int32_t)((uint32_t)(gs + span) - (uint32_t)wlo);  // window-relative end of the footprint
     const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
-    int32_t grel = (int32_t)((uint32_t)gs - (uint32_t)wlo);  // window-relative site, may be negative
-    int32_t q = 0;
-    uint32_t k = 0;
-    if (ri.pad && grel < 0) {
-        // long CIGAR: enter at the last checkpoint whose reference position is still left of the window
-        const KdCkpt *ck = ckpt + (kd_u64)(ri.pad - 1u) * KD_BLOCK;
-        const uint32_t target = (uint32_t)(-grel);
-        uint32_t lo = 0, hi = KD_BLOCK;   // largest t with ck[t].r_rel <= target (ck[0].r_rel == 0)
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (ck[mid].r_rel <= target) lo = mid; else hi = mid;
-        }
-        const uint32_t per = (nc + KD_BLOCK - 1) / KD_BLOCK;
-        if (lo * per < nc) { k = lo * per; grel += (int32_t)ck[lo].r_rel; q = (int32_t)ck[lo].q; }
-    }
     // Per-lane state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the
     // current M run), not over CIGAR ops: lanes whose reads have clips or indels still add
     // bases in the same wavefront instructions as their single-run neighbours.
@@ -1116,7 +1131,7 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
     int32_t c_have = -1;
     KdChunk cur = cw_cur;
     for (;;) {
-        while (c > cb && k < nc) {   // advance to the next run with live bases
+        while (c > cb && k < k_end) {   // advance to the next run with live bases
             if (k >= kw + 4) {
                 kw += 4; cw_cur = cw_nxt;
                 if (kw + 4 < nc) cw_nxt = kd_load_cigar4(cg, kw + 4, nc);
@@ -1134,12 +1149,12 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
                 sx = grel - q;                      // site of query base x is sx + x
                 if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
                 q += len; grel += len;
-                if (grel >= Wi) k = nc;
+                if (grel >= Wi) k = k_end;
             } else if (op == 2) {
                 for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
                     kd_hadd(hist0, Wh, KD_HCH_DEL, grel + j);
                 grel += len;
-                if (grel >= Wi) k = nc;
+                if (grel >= Wi) k = k_end;
             } else if (op == 1) {
                 q += len;
             } else if (op == 4) {
@@ -1162,7 +1177,7 @@ __device__ __forceinline__ void kd_walk_complex(const KdReads &rd, kd_u64 i, con
                     xb = Wi - grel < n_adv ? q + (Wi - grel) : q + n_adv;
                     sx = grel - q + (int32_t)KD_HCH_CSW * Wp;
                     if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
-                    k = nc;
+                    k = k_end;
                 }
             }
         }
@@ -1337,9 +1352,12 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
 #define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)2 * KD_TILE * 2)   // Wh = dwords per channel row
 
 __global__ void __launch_bounds__(KD_BLOCK, 5)   // 5 wavefronts per SIMD = the 5 workgroups per CU the LDS footprint allows
-k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *ckpt, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
-         const kd_u64 *item_off, const uint32_t *item_win, kd_u64 items_cap, uint32_t w0, uint32_t W, uint32_t Wh_, uint32_t slice,
-         kd_u64 *status) {
+k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *ckpt, const uint32_t *seg_read, KdTabs T,
+         const kd_u64 *win_lo, const kd_u64 *win_hi, const kd_u64 *item_off, const uint32_t *item_win, kd_u64 items_cap, uint32_t w0,
+         uint32_t W, uint32_t Wh_, uint32_t slice, kd_u64 *status) {
+    // seg_read == NULL: `rinfo` describes the batch's reads (first pass, class REG = short regular reads).
+    // seg_read != NULL: `rinfo` describes SEGMENTS of long reads (k_prep_long; entry e = 256 * b + t is thread t's
+    // run of ops of the long read seg_read[b], entered through checkpoint ckpt[e]); `order` is then never NULL.
     KD_DYN_SHARED(uint32_t, hist);
     const int32_t Wh = (int32_t)Wh_;   // dwords per channel row (two u16 counters each, halos included; >= (W + 2*KD_HALO)/2)
     uint32_t *hist0 = hist + KD_HALO / 2;                 // word of window-relative site 0
@@ -1430,9 +1448,16 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 if (e < ncx) {
                     const kd_u64 j = tb + l_cplx[e], i = order ? (kd_u64)order[j] : j;
                     const KdRInfo ri = rinfo[i];
-                    // long CIGARs (checkpointed) and reads with more than three segments: general walk
-                    if (ri.pad || !kd_walk_short(rd, i, ri, wlo, Wi, Wh, hist0))
-                        kd_walk_complex(rd, i, ri, ckpt, wlo, Wi, Wh, hist0);
+                    const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);
+                    const int32_t foot_end = grel + (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
+                    if (seg_read) {          // one segment of a long read
+                        const kd_u64 ir = seg_read[i / KD_BLOCK];
+                        const uint32_t nc = rd.n_cig[ir], per = (nc + KD_BLOCK - 1) / KD_BLOCK;
+                        const uint32_t k0 = (uint32_t)(i % KD_BLOCK) * per, k1 = k0 + per < nc ? k0 + per : nc;
+                        kd_walk_ops(rd, ir, k0, k1, grel, (int32_t)ckpt[i].q, (int32_t)ri.lead, foot_end, Wi, Wh, hist0);
+                    } else if (!kd_walk_short(rd, i, ri, wlo, Wi, Wh, hist0)) {   // more than three segments: general walk
+                        kd_walk_ops(rd, i, 0u, rd.n_cig[i], grel, 0, (int32_t)ri.lead, foot_end, Wi, Wh, hist0);
+                    }
                 }
             }
             KD_MARK(c_cplx)
@@ -1491,7 +1516,8 @@ __global__ void __launch_bounds__(KD_BLOCK)
 k_find_bad_base(KdReads rd, KdTabs T, const KdRInfo *rinfo, kd_u64 *status) {
     if (status[KDS_BAD_BASE] == 0) return;
     for (kd_u64 i = threadIdx.x; i < rd.n; i += KD_BLOCK) {
-        if ((rinfo[i].span_cls & 3u) != KD_CLS_REG) continue;
+        const uint32_t cls_i = rinfo[i].span_cls & 3u;
+        if (cls_i != KD_CLS_REG && cls_i != KD_CLS_LONG) continue;   // regular reads, short and long
         if (rd.base_index + i >= status[KDS_ERR_READ]) continue;
         const uint8_t *seq = rd.seq4 + rd.seq_off[i];
         const uint32_t *cg = rd.cigar + rd.cig_off[i];

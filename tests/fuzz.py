@@ -4,16 +4,19 @@ import numpy as np
 OPS = "MIDNSHP=X"
 
 
-def random_batch(rng, n_reads, contig_lens=(37, 90), wild=0.15, sort=False):
+def random_batch(rng, n_reads, contig_lens=(37, 90), wild=0.15, sort=False, long_ops=None):
     """Small contigs so that overhangs / wrap-arounds / slot-L writes happen often.
-    wild: probability that a read is built without any validity constraint."""
+    wild: probability that a read is built without any validity constraint.
+    long_ops=(lo, hi): a tenth of the reads get lo..hi CIGAR ops (long-read path: checkpoints, segments);
+    use with contigs long enough to hold them."""
     contig, pos0, flag, seq_off, seq_len, cig_off, n_cig = [], [], [], [], [], [], []
     seq4, cigar = bytearray(), []
     for _ in range(n_reads):
         c = int(rng.integers(0, len(contig_lens)))
         L = contig_lens[c]
         is_wild = rng.random() < wild
-        n_ops = int(rng.integers(1, 7)) if rng.random() < 0.9 else int(rng.integers(17, 40))
+        lo_ops, hi_ops = long_ops if long_ops else (17, 40)
+        n_ops = int(rng.integers(1, 7)) if rng.random() < 0.9 else int(rng.integers(lo_ops, hi_ops))
         ops = []
         for k in range(n_ops):
             if is_wild:

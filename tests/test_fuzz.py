@@ -29,6 +29,22 @@ def test_fuzz_wild_reads_emulated(emu_lib):
     assert out["raise"] >= 2 and out["ok"] >= 2
 
 
+def _long_campaign(lib, seeds, n_reads):
+    """Reads with hundreds of ops (clips at both ends, indels, N/H/P) on contigs that hold them: the long-read
+    path (k_prep_long checkpoints, k_window's segment pass, k_cold_long), sorted and unsorted, two window sizes."""
+    n_ok = 0
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        batch = fuzz.random_batch(rng, n_reads, contig_lens=(6000, 2500), wild=0.0, sort=bool(seed & 1), long_ops=(17, 700))
+        for mode in MODES:
+            n_ok += fuzz.check_engine(lib, batch, mode, window=[64, 256][seed % 2], slice_reads=[0, 16][(seed >> 1) % 2]) == "ok"
+    return n_ok
+
+
+def test_fuzz_long_cigars_emulated(emu_lib):
+    assert _long_campaign(emu_lib, range(300, 304), n_reads=40) >= 6
+
+
 def test_oracle_fuzz_is_deterministic():
     a = fuzz.random_batch(np.random.default_rng(5), 30)
     b = fuzz.random_batch(np.random.default_rng(5), 30)
@@ -53,3 +69,8 @@ def test_fuzz_large_valid_batch_gpu(hip_lib):
     batch = fuzz.random_batch(rng, 20000, contig_lens=(5000, 3000, 800), wild=0.0, sort=True)
     for mode in MODES:
         assert fuzz.check_engine(hip_lib, batch, mode, window=256) in ("ok", "raise")
+
+
+@pytest.mark.gpu
+def test_fuzz_long_cigars_gpu(hip_lib):
+    assert _long_campaign(hip_lib, range(3000, 3040), n_reads=200) >= 60
