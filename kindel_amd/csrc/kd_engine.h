@@ -266,11 +266,16 @@ struct KdEngine {
                         return rc2;
                     uint32_t *ord = (uint32_t *)b_order.p, *bc = (uint32_t *)b_bincnt.p;
                     kd_u64 *bo = (kd_u64 *)b_binoff.p;
-                    const unsigned gr = (unsigned)((ne + KD_BLOCK - 1) / KD_BLOCK);
+                    const uint64_t run = seg_read ? KD_SORT_RUN : 1;   // segments arrive in reference order: merge runs
+                    const unsigned gr = (unsigned)((ne + (uint64_t)KD_BLOCK * run - 1) / ((uint64_t)KD_BLOCK * run));
                     if (rt.memset(bc, 0, ((size_t)n_bins + 1) * 4) ||
-                        rt.launch("k_sort_count", k_sort_count, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc) ||
+                        (seg_read ? rt.launch("k_sort_count", k_sort_count<KD_SORT_RUN>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc)
+                                  : rt.launch("k_sort_count", k_sort_count<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc)) ||
                         rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, n_bins) ||
-                        rt.launch("k_sort_scatter", k_sort_scatter, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, (const kd_u64 *)bo, ord) ||
+                        (seg_read ? rt.launch("k_sort_scatter", k_sort_scatter<KD_SORT_RUN>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc,
+                                              (const kd_u64 *)bo, ord)
+                                  : rt.launch("k_sort_scatter", k_sort_scatter<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc,
+                                              (const kd_u64 *)bo, ord)) ||
                         rt.launch("k_plan_ranges_sorted", k_plan_ranges_sorted, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
                                   (const kd_u64 *)bo, n_bins, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status, span_slot))
                         return hipfail("k_sort_*");

@@ -919,12 +919,27 @@ k_plan_ranges(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t w0, uint32_t n_win,
 
 // ---- unsorted batches: bucket the regular reads by window (counting sort), so that the candidate reads of
 // a window are again a contiguous range -- of the permutation `order` instead of the batch itself.
+// Each thread takes RUN CONSECUTIVE entries and merges neighbours that fall into the same bin into one atomic.
+// RUN = KD_SORT_RUN for the segments of long reads: they arrive in reference order, thousands per bin, and one
+// atomic per entry would serialise on a handful of addresses.  RUN = 1 for the reads of an unsorted batch
+// (nothing to merge; coalesced one-entry-per-lane access).
+#define KD_SORT_RUN 16
+template <int RUN>
 __global__ void __launch_bounds__(KD_BLOCK)
 k_sort_count(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t W, uint32_t *bin_cnt) {
-    const kd_u64 i = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (i >= n_reads) return;
-    const KdRInfo ri = rinfo[i];
-    if ((ri.span_cls & 3u) == KD_CLS_REG) atomicAdd(&bin_cnt[ri.gstart / W], 1u);
+    const kd_u64 i0 = ((kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x) * RUN;
+    uint32_t cur = 0xffffffffu, run = 0;
+    for (kd_u64 i = i0; i < i0 + RUN && i < n_reads; i++) {
+        const KdRInfo ri = rinfo[i];
+        if ((ri.span_cls & 3u) != KD_CLS_REG) continue;
+        const uint32_t b = ri.gstart / W;
+        if (b != cur) {
+            if (run) atomicAdd(&bin_cnt[cur], run);
+            cur = b; run = 0;
+        }
+        run++;
+    }
+    if (run) atomicAdd(&bin_cnt[cur], run);
 }
 // one workgroup: bin_off = exclusive scan of bin_cnt (n_bins + 1 entries), bin_cnt is reset to 0 (it becomes
 // the fill cursor of k_sort_scatter)
@@ -953,15 +968,32 @@ k_sort_scan(uint32_t *bin_cnt, kd_u64 *bin_off, uint32_t n_bins) {
     }
     if (t == 0) bin_off[n_bins] = s_carry;
 }
+template <int RUN>
 __global__ void __launch_bounds__(KD_BLOCK)
 k_sort_scatter(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t W, uint32_t *bin_fill, const kd_u64 *bin_off,
                uint32_t *order) {
-    const kd_u64 i = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (i >= n_reads) return;
-    const KdRInfo ri = rinfo[i];
-    if ((ri.span_cls & 3u) != KD_CLS_REG) return;
-    const uint32_t b = ri.gstart / W;
-    order[bin_off[b] + atomicAdd(&bin_fill[b], 1u)] = (uint32_t)i;
+    const kd_u64 i0 = ((kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x) * RUN;
+    const kd_u64 i1 = i0 + RUN < n_reads ? i0 + RUN : n_reads;
+    // maximal runs of consecutive regular entries of one bin: one reservation, consecutive slots
+    kd_u64 i = i0;
+    while (i < i1) {
+        const KdRInfo ri = rinfo[i];
+        if ((ri.span_cls & 3u) != KD_CLS_REG) { i++; continue; }
+        const uint32_t b = ri.gstart / W;
+        kd_u64 j = i + 1;
+        uint32_t m = 1;
+        for (; j < i1; j++) {
+            const KdRInfo rj = rinfo[j];
+            if ((rj.span_cls & 3u) != KD_CLS_REG) continue;   // skipped entries do not break a run
+            if (rj.gstart / W != b) break;
+            m++;
+        }
+        kd_u64 at = bin_off[b] + atomicAdd(&bin_fill[b], m);
+        order[at++] = (uint32_t)i;
+        for (kd_u64 x = i + 1; x < j; x++)   // (i, j): entries of bin b and skipped ones
+            if ((rinfo[x].span_cls & 3u) == KD_CLS_REG) order[at++] = (uint32_t)x;
+        i = j;
+    }
 }
 // candidate range of window w0 + w in `order`: whole bins covering [wlo - maxspan, whi + maxlead)
 __global__ void __launch_bounds__(KD_BLOCK)
@@ -1108,90 +1140,6 @@ __device__ __forceinline__ KdChunk kd_load_cigar4(const uint32_t *cg, uint32_t k
 // A state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the current run), not over
 // CIGAR ops, so that lanes keep adding bases together whatever their op structure.  A soft clip is a
 // run of its own on the clip_start / clip_end channel group.
-// Ops [k, k_end) of read i, entered with the reference cursor at window-relative site `grel` and the query cursor
-// at q: the whole CIGAR of a short read with many segments (k = 0, k_end = n_cig), or ONE SEGMENT of a long read
-// (k_prep_long's checkpoint).  `lead` / `foot_end`: reach of the leading clip / window-relative end of the footprint
-// (used by the clip ops, which sit in the first / last segment).
-__device__ __forceinline__ void kd_walk_ops(const KdReads &rd, kd_u64 i, uint32_t k, uint32_t k_end, int32_t grel, int32_t q,
-                                            int32_t lead, int32_t foot_end, int32_t Wi, int32_t Wh, uint32_t *hist0) {
-    const int32_t Wp = 2 * Wh;   // sites per channel row, halos included
-    const uint32_t nc = rd.n_cig[i];
-    const uint32_t *cg = rd.cigar + rd.cig_off[i];
-    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
-    // Per-lane state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the
-    // current M run), not over CIGAR ops: lanes whose reads have clips or indels still add
-    // bases in the same wavefront instructions as their single-run neighbours.
-    int32_t xa = 0, xb = 0, ra = 0, rb = 0, sx = 0, c = 1, cb = 0;   // c > cb: no live run
-    // CIGAR words four at a time (one unaligned 16-byte load, the next four already in flight), and the last
-    // 16-byte chunk of bases kept: a long read's runs are a few bases each, so consecutive runs share a chunk
-    // and one load per op would make the walk a chain of dependent HBM round trips.
-    uint32_t kw = k & ~3u;                     // cw_cur holds words kw .. kw + 3
-    KdChunk cw_cur = kd_load_cigar4(cg, kw, nc), cw_nxt = cw_cur;
-    if (kw + 4 < nc) cw_nxt = kd_load_cigar4(cg, kw + 4, nc);
-    int32_t c_have = -1;
-    KdChunk cur = cw_cur;
-    for (;;) {
-        while (c > cb && k < k_end) {   // advance to the next run with live bases
-            if (k >= kw + 4) {
-                kw += 4; cw_cur = cw_nxt;
-                if (kw + 4 < nc) cw_nxt = kd_load_cigar4(cg, kw + 4, nc);
-            }
-            const uint32_t kk = k & 3u;
-            const uint32_t cw = kk == 0 ? cw_cur.x : kk == 1 ? cw_cur.y : kk == 2 ? cw_cur.z : cw_cur.w;
-            const int32_t len = (int32_t)(cw >> 4);
-            const uint32_t op = cw & 15u;
-            k++;
-            if (op == 0 || op == 7 || op == 8) {
-                // live query range: inside the run and inside the window
-                xa = grel < 0 ? q - grel : q;
-                xb = Wi - grel < len ? q + (Wi - grel) : q + len;
-                ra = q; rb = q + len;
-                sx = grel - q;                      // site of query base x is sx + x
-                if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
-                q += len; grel += len;
-                if (grel >= Wi) k = k_end;
-            } else if (op == 2) {
-                for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
-                    kd_hadd(hist0, Wh, KD_HCH_DEL, grel + j);
-                grel += len;
-                if (grel >= Wi) k = k_end;
-            } else if (op == 1) {
-                q += len;
-            } else if (op == 4) {
-                if (k == 1) {
-                    // leading clip, kindel.py:64-73: base x -> site r - len + x, kept if >= contig start
-                    // (`lead` of the len bases); a run on the clip_end_weights channels
-                    const int32_t s_first = grel - len;           // site of base 0
-                    ra = len - lead; rb = len;
-                    xa = -s_first > ra ? -s_first : ra;
-                    xb = Wi - s_first < len ? Wi - s_first : len;
-                    sx = s_first + (int32_t)KD_HCH_CEW * Wp;
-                    if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
-                    q += len;
-                } else {
-                    // non-first clip, kindel.py:74-81: bases q.. -> sites r.. while r < L; for a regular
-                    // read it is the last op that moves r, so its reach is the end of the footprint
-                    const int32_t n_adv = foot_end - grel;
-                    ra = q; rb = q + n_adv;
-                    xa = grel < 0 ? q - grel : q;
-                    xb = Wi - grel < n_adv ? q + (Wi - grel) : q + n_adv;
-                    sx = grel - q + (int32_t)KD_HCH_CSW * Wp;
-                    if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
-                    k = k_end;
-                }
-            }
-        }
-        if (c > cb) break;
-        if (c != c_have) { cur = src[c]; c_have = c; }
-        const int32_t xs = 32 * c;
-        kd_add_dword(hist0, Wh, cur.x, xs, xa, xb, ra, rb, sx);
-        kd_add_dword(hist0, Wh, cur.y, xs + 8, xa, xb, ra, rb, sx);
-        kd_add_dword(hist0, Wh, cur.z, xs + 16, xa, xb, ra, rb, sx);
-        kd_add_dword(hist0, Wh, cur.w, xs + 24, xa, xb, ra, rb, sx);
-        c++;
-    }
-}
-
 // Bases of dword v whose bit is set in m (bit b = base b) are added; the others add 0 to a counter at most
 // 7 sites away from a live one, i.e. inside the row (halo included).  No branches: lanes whose dword is cut
 // by a run end, a clip end or the window edge stay in step with lanes whose dword is whole.
@@ -1221,6 +1169,84 @@ __device__ __forceinline__ void kd_add_chunk_masked(uint32_t *hist0, int32_t Wh,
         l = l < 0 ? 0 : l;
         h = h > 8 ? 8 : h;
         kd_add8_masked(hist0, Wh, dw[d], sx + x0, (0xffu >> (8 - h)) & (0xffu << l));
+    }
+}
+
+// Ops [k, k_end) of read i, entered with the reference cursor at window-relative site `grel` and the query cursor
+// at q: the whole CIGAR of a short read with many segments (k = 0, k_end = n_cig), or ONE SEGMENT of a long read
+// (k_prep_long's checkpoint).  `lead` / `foot_end`: reach of the leading clip / window-relative end of the footprint
+// (used by the clip ops, which sit in the first / last segment).
+__device__ __forceinline__ void kd_walk_ops(const KdReads &rd, kd_u64 i, uint32_t k, uint32_t k_end, int32_t grel, int32_t q,
+                                            int32_t lead, int32_t foot_end, int32_t Wi, int32_t Wh, uint32_t *hist0) {
+    const int32_t Wp = 2 * Wh;   // sites per channel row, halos included
+    const uint32_t nc = rd.n_cig[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
+    // Per-lane state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the
+    // current M run), not over CIGAR ops: lanes whose reads have clips or indels still add
+    // bases in the same wavefront instructions as their single-run neighbours.
+    int32_t xa = 0, xb = 0, sx = 0, c = 1, cb = 0;   // live query range [xa, xb) of the current run; c > cb: none
+    // CIGAR words four at a time (one unaligned 16-byte load, the next four already in flight), and the last
+    // 16-byte chunk of bases kept: a long read's runs are a few bases each, so consecutive runs share a chunk
+    // and one load per op would make the walk a chain of dependent HBM round trips.
+    uint32_t kw = k & ~3u;                     // cw_cur holds words kw .. kw + 3
+    KdChunk cw_cur = kd_load_cigar4(cg, kw, nc), cw_nxt = cw_cur;
+    if (kw + 4 < nc) cw_nxt = kd_load_cigar4(cg, kw + 4, nc);
+    int32_t c_have = -1;
+    KdChunk cur = cw_cur;
+    for (;;) {
+        while (c > cb && k < k_end) {   // advance to the next run with live bases
+            if (k >= kw + 4) {
+                kw += 4; cw_cur = cw_nxt;
+                if (kw + 4 < nc) cw_nxt = kd_load_cigar4(cg, kw + 4, nc);
+            }
+            const uint32_t kk = k & 3u;
+            const uint32_t cw = kk == 0 ? cw_cur.x : kk == 1 ? cw_cur.y : kk == 2 ? cw_cur.z : cw_cur.w;
+            const int32_t len = (int32_t)(cw >> 4);
+            const uint32_t op = cw & 15u;
+            k++;
+            if (op == 0 || op == 7 || op == 8) {
+                // live query range: inside the run and inside the window
+                xa = grel < 0 ? q - grel : q;
+                xb = Wi - grel < len ? q + (Wi - grel) : q + len;
+                sx = grel - q;                      // site of query base x is sx + x
+                if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                q += len; grel += len;
+                if (grel >= Wi) k = k_end;
+            } else if (op == 2) {
+                for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
+                    kd_hadd(hist0, Wh, KD_HCH_DEL, grel + j);
+                grel += len;
+                if (grel >= Wi) k = k_end;
+            } else if (op == 1) {
+                q += len;
+            } else if (op == 4) {
+                if (k == 1) {
+                    // leading clip, kindel.py:64-73: base x -> site r - len + x, kept if >= contig start
+                    // (`lead` of the len bases); a run on the clip_end_weights channels
+                    const int32_t s_first = grel - len;           // site of base 0
+                    xa = -s_first > len - lead ? -s_first : len - lead;
+                    xb = Wi - s_first < len ? Wi - s_first : len;
+                    sx = s_first + (int32_t)KD_HCH_CEW * Wp;
+                    if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                    q += len;
+                } else {
+                    // non-first clip, kindel.py:74-81: bases q.. -> sites r.. while r < L; for a regular
+                    // read it is the last op that moves r, so its reach is the end of the footprint
+                    const int32_t n_adv = foot_end - grel;
+                    xa = grel < 0 ? q - grel : q;
+                    xb = Wi - grel < n_adv ? q + (Wi - grel) : q + n_adv;
+                    sx = grel - q + (int32_t)KD_HCH_CSW * Wp;
+                    if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                    k = k_end;
+                }
+            }
+        }
+        if (c > cb) break;
+        if (c != c_have) { cur = src[c]; c_have = c; }
+        const int32_t xs = 32 * c;
+        kd_add_chunk_masked(hist0, Wh, cur, xs, xa, xb, sx);   // [xa, xb) lies inside the run: branch-free masked adds
+        c++;
     }
 }
 
