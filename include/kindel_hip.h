@@ -188,7 +188,8 @@ int kd_consensus_offsets(kd_ctx *ctx, uint64_t *contig_off, uint32_t *depth_minm
 
 /* ---- profiling ---------------------------------------------------------------------- */
 
-/* When enabled every kernel launch is bracketed by hipEvents on ctx's stream. */
+/* on = 1: every kernel launch is bracketed by hipEvents on ctx's stream; on = 2: only the launches of the
+ * pileup kernel k_window (what a timed run wants: two events per batch instead of two per launch); 0: off. */
 int kd_profile_enable(kd_ctx *ctx, int on);
 /* Accumulated since enable/reset: number of kernel rows (call with names==NULL), then
  * per row: name (<=63 chars + NUL in names[i*64]), launches, total milliseconds. */

@@ -355,7 +355,7 @@ class Engine:
         return off, mm
 
     # -- profiling --
-    def profile_enable(self, on=True):
+    def profile_enable(self, on=True):   # True / 1: every launch; 2: only k_window's launches; False / 0: off
         self._check(self.lib.dll.kd_profile_enable(self._h, int(on)), "kd_profile_enable")
 
     def profile_reset(self):

@@ -127,7 +127,7 @@ int kd_consensus_offsets(kd_ctx *ctx, uint64_t *contig_off, uint32_t *depth_minm
 
 int kd_profile_enable(kd_ctx *ctx, int on) {
     if (!ctx) return KD_E_ARG;
-    ctx->e.rt.profile_enable(on != 0);
+    ctx->e.rt.profile_enable(on == 2 ? 2 : on != 0);
     return KD_OK;
 }
 int kd_profile_get(kd_ctx *ctx, uint32_t *n_rows, char *names, uint64_t *launches, double *ms) {

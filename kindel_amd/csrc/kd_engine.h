@@ -47,7 +47,7 @@ struct KdEngine {
     uint64_t ev_cap = 0, pool_cap = 0;
     Buf b_hkey, b_hcnt, b_hrep, b_evslot, b_best, b_win;
     uint64_t hash_cap = 0;
-    Buf b_cns, b_changes, b_tilesum, b_tileoff, b_coff, b_minmax, b_pstart, b_pend, b_poff;
+    Buf b_cns, b_changes, b_tilesum, b_tileoff, b_coff;
 
     uint64_t reads_pushed = 0;
     uint64_t last_windowed = 0;
@@ -132,7 +132,7 @@ struct KdEngine {
     void destroy() {
         Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_itemwin, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ckpt, &b_seginfo, &b_ev_site, &b_ev_len,
                       &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_win, &b_cns, &b_changes,
-                      &b_tilesum, &b_tileoff, &b_coff, &b_minmax, &b_pstart, &b_pend, &b_poff};
+                      &b_tilesum, &b_tileoff, &b_coff};
         for (Buf *b : all) release(*b);
         for (Buf &b : b_stage) release(b);
         if (d_tab) rt.free(d_tab);
@@ -505,41 +505,45 @@ struct KdEngine {
         const bool fresh_changes = b_changes.cap < S;
         if ((rc = ensure(b_changes, S))) return rc;
         if (fresh_changes && rt.memset(b_changes.p, 0, S)) return hipfail("consensus: memset changes");  // sites outside the shard stay 0
+        // the small per-run arrays live in ONE device block (one upload, one download per run, not one per array):
+        // u64 contig_off[n_contigs + 1] | u64 patch_off[np1] | u64 patch_start[np1] | u64 patch_end[np1] | u32 minmax[2 n_contigs]
+        const size_t np1 = (size_t)n_patches + 1, nc1 = (size_t)n_contigs + 1;
+        const size_t meta_words = nc1 + 3 * np1 + n_contigs;   // in u64
         if ((rc = ensure(b_cns, cap)) || (rc = ensure(b_tilesum, n_tiles * 8)) ||
-            (rc = ensure(b_tileoff, (n_tiles + 1) * 8)) || (rc = ensure(b_coff, ((size_t)n_contigs + 1) * 8)) ||
-            (rc = ensure(b_minmax, (size_t)n_contigs * 8)) || (rc = ensure(b_pstart, (size_t)(n_patches + 1) * 8)) ||
-            (rc = ensure(b_pend, (size_t)(n_patches + 1) * 8)) || (rc = ensure(b_poff, (size_t)(n_patches + 1) * 8)))
+            (rc = ensure(b_tileoff, (n_tiles + 1) * 8)) || (rc = ensure(b_coff, meta_words * 8)))
             return rc;
-        std::vector<uint32_t> mm(2 * (size_t)n_contigs);
-        for (uint32_t c = 0; c < n_contigs; c++) { mm[2 * c] = 0xffffffffu; mm[2 * c + 1] = 0; }
-        if (rt.h2d(b_minmax.p, mm.data(), mm.size() * 4)) return hipfail("consensus: h2d");
-        if (n_patches && (rt.h2d(b_pstart.p, ps, (size_t)n_patches * 8) || rt.h2d(b_pend.p, pe, (size_t)n_patches * 8)))
-            return hipfail("consensus: h2d patches");
-        if (rt.memset(b_poff.p, 0xff, (size_t)(n_patches + 1) * 8)) return hipfail("consensus: memset");
+        std::vector<uint64_t> meta(meta_words, 0);
+        uint64_t *m_poff = meta.data() + nc1, *m_ps = m_poff + np1, *m_pe = m_ps + np1;
+        uint32_t *m_mm = reinterpret_cast<uint32_t *>(m_pe + np1);
+        for (size_t k = 0; k < np1; k++) m_poff[k] = ~0ULL;
+        for (uint32_t k = 0; k < n_patches; k++) { m_ps[k] = ps[k]; m_pe[k] = pe[k]; }
+        for (uint32_t c = 0; c < n_contigs; c++) { m_mm[2 * c] = 0xffffffffu; m_mm[2 * c + 1] = 0; }
+        if (rt.h2d(b_coff.p, meta.data(), meta_words * 8)) return hipfail("consensus: h2d");
+        kd_u64 *d_coff = (kd_u64 *)b_coff.p, *d_poff = d_coff + nc1, *d_ps = d_poff + np1, *d_pe = d_ps + np1;
+        uint32_t *d_mm = reinterpret_cast<uint32_t *>(d_pe + np1);
         KdTabs T = tabs();
         KdIns I = insdesc();
         KdCns C;
         C.seg_contig = d_seg; C.ins_win = (const uint32_t *)b_win.p; C.min_depth = min_depth; C.n_patches = n_patches;
-        C.patch_start = (const kd_u64 *)b_pstart.p; C.patch_end = (const kd_u64 *)b_pend.p;
+        C.patch_start = d_ps; C.patch_end = d_pe;
         C.g_lo = g_lo; C.g_hi = g_hi;
         if (rt.launch("k_cns_count", k_cns_count, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64)tile_first, (kd_u64 *)b_tilesum.p,
-                      (uint32_t *)b_minmax.p))
+                      d_mm))
             return hipfail("k_cns_count");
         if (rt.launch("k_cns_scan", k_cns_scan, 1u, KD_BLOCK, 0, (const kd_u64 *)b_tilesum.p, (kd_u64 *)b_tileoff.p,
                       (kd_u64)n_tiles))
             return hipfail("k_cns_scan");
         if (rt.launch("k_cns_emit", k_cns_emit, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64)tile_first, (const kd_u64 *)b_tileoff.p,
-                      (uint8_t *)b_cns.p, (uint8_t *)b_changes.p, (kd_u64 *)b_coff.p, n_contigs, (kd_u64 *)b_poff.p))
+                      (uint8_t *)b_cns.p, (uint8_t *)b_changes.p, d_coff, n_contigs, d_poff))
             return hipfail("k_cns_emit");
         h_coff.assign((size_t)n_contigs + 1, 0);
         h_minmax.assign(2 * (size_t)n_contigs, 0);
         h_pstart.assign(ps, ps + n_patches);
         h_poff.assign(n_patches, ~0ULL);
-        if (rt.d2h(h_coff.data(), b_coff.p, (size_t)n_contigs * 8) ||
-            rt.d2h(&h_coff[n_contigs], (kd_u64 *)b_tileoff.p + n_tiles, 8) ||
-            rt.d2h(h_minmax.data(), b_minmax.p, h_minmax.size() * 4) ||
-            (n_patches && rt.d2h(h_poff.data(), b_poff.p, (size_t)n_patches * 8)))
-            return hipfail("consensus: d2h");
+        if (rt.d2h(meta.data(), b_coff.p, meta_words * 8)) return hipfail("consensus: d2h");
+        std::copy(meta.begin(), meta.begin() + nc1, h_coff.begin());
+        std::copy(m_poff, m_poff + n_patches, h_poff.begin());
+        std::copy(m_mm, m_mm + 2 * (size_t)n_contigs, h_minmax.begin());
         if (h_coff[n_contigs] > cap) return fail(KD_E_INTERNAL, "consensus longer than its buffer");
         // contigs whose first site lies outside the processed tiles were not visited by k_cns_emit
         for (uint32_t c = 0; c < n_contigs; c++) {

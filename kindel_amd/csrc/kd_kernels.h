@@ -1801,6 +1801,7 @@ k_cns_emit(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, const kd_u64 *tile_o
     const uint32_t t = threadIdx.x;
     const kd_u64 tile0 = (tile_first + blockIdx.x) * KD_CNS_TILE;
     const kd_u64 g0 = tile0 + (kd_u64)t * KD_CNS_PER_THREAD;
+    if (blockIdx.x == 0 && t == 0) contig_off[n_contigs] = tile_off[gridDim.x];   // total length, next to the per-contig offsets
     KdSite s[KD_CNS_PER_THREAD];
     kd_cns_load_eval(T, C, ins, g0, s);
     uint32_t sum = 0;

@@ -15,7 +15,7 @@ struct HipRt {
     bool own_stream = false;
     int dev = 0, cus = 256;
     std::string e;
-    bool prof = false;
+    int prof = 0;   // 0 off, 1 every launch, 2 only the launches named prof_only
     struct Pending { std::string name; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::map<std::string, std::pair<uint64_t, double>> rows;
@@ -84,13 +84,14 @@ struct HipRt {
             bad(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)))
             return 1;
         Pending p;
-        if (prof) {
+        const bool timed = prof == 1 || (prof == 2 && !strcmp(name, "k_window"));
+        if (timed) {
             if (bad(hipEventCreate(&p.a)) || bad(hipEventCreate(&p.b))) return 1;
             if (bad(hipEventRecord(p.a, stream))) return 1;
         }
         k<<<dim3(grid), dim3(block), shmem, stream>>>(args...);
         if (bad(hipGetLastError())) return 1;
-        if (prof) {
+        if (timed) {
             if (bad(hipEventRecord(p.b, stream))) return 1;
             p.name = name;
             pending.push_back(p);
@@ -98,7 +99,7 @@ struct HipRt {
         return 0;
     }
 
-    void profile_enable(bool on) { prof = on; }
+    void profile_enable(int mode) { prof = mode; }
     int drain() {
         if (pending.empty()) return 0;
         if (bad(hipStreamSynchronize(stream))) return 1;

@@ -33,7 +33,7 @@ struct EmuRt {
         emu::launch(k, dim3(grid), dim3(block), shmem, args...);
         return 0;
     }
-    void profile_enable(bool) {}
+    void profile_enable(int) {}
     int profile_get(uint32_t *n_rows, char *, uint64_t *, double *) { *n_rows = 0; return 0; }
     void profile_reset() {}
 };
