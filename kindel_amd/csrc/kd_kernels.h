@@ -174,6 +174,17 @@ struct __attribute__((packed, aligned(1))) KdChunk { uint32_t x, y, z, w; };
 
 __device__ __forceinline__ bool kd_commit(const KdTabs &T, kd_u64 g) { return g >= T.g_lo && g <= T.g_hi; }
 
+// CIGAR words k0 .. k0+3 of a read with nc words: one unaligned 16-byte load when all four are the read's own
+// (never touches memory past the batch's CIGAR array), guarded single loads for the read's last group
+__device__ __forceinline__ KdChunk kd_load_cigar4(const uint32_t *cg, uint32_t k0, uint32_t nc) {
+    if (k0 + 4 <= nc) return *reinterpret_cast<const KdChunk *>(cg + k0);
+    KdChunk r;
+    r.x = k0 < nc ? cg[k0] : 0u; r.y = k0 + 1 < nc ? cg[k0 + 1] : 0u;
+    r.z = k0 + 2 < nc ? cg[k0 + 2] : 0u; r.w = 0u;
+    return r;
+}
+
+
 __device__ __forceinline__ void kd_flag_error(kd_u64 *status, kd_u64 gidx) { atomicMin(&status[KDS_ERR_READ], gidx); }
 
 // ---------------------------------------------------------------------------------------
@@ -715,16 +726,17 @@ k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list
     uint32_t *tab = T.tab;
     const kd_u64 S = T.stride;
     int64_t r = rd.pos0[i], q = 0;
-    kd_u64 ev_next = 0, pool_next = 0;
-    bool ev_loaded = false;
+    // everything the walk may need is requested up front (first four CIGAR words in one load, the read's event /
+    // pool slots): the kernel is a chain of dependent round trips otherwise
+    const KdChunk pre = kd_load_cigar4(cg, 0u, nc);
+    kd_u64 ev_next = ins.read_ev[i], pool_next = ins.read_pool[i];   // (garbage for a read without insertions: unused)
     for (uint32_t k = 0; k < nc; k++) {
-        const uint32_t w = cg[k];
+        const uint32_t w = k == 0 ? pre.x : k == 1 ? pre.y : k == 2 ? pre.z : k == 3 ? pre.w : cg[k];
         const int64_t len = w >> 4;
         const uint32_t op = w & 15u;
         if (op == 0 || op == 7 || op == 8) { r += len; q += len; }
         else if (op == 2) { r += len; }
         else if (op == 1) {
-            if (!ev_loaded) { ev_next = ins.read_ev[i]; pool_next = ins.read_pool[i]; ev_loaded = true; }
             const int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
             const kd_u64 n = (kd_u64)(q1 - q0);
             const kd_u64 e = ev_next, po = pool_next;
@@ -1124,16 +1136,6 @@ __device__ __forceinline__ void kd_add_dword(uint32_t *hist0, int32_t Wh, uint32
     if (xs + 8 <= xa || xs >= xb) return;
     if (xs >= ra && xs + 8 <= rb) kd_add8_full(hist0, Wh, v, sx + xs);
     else kd_add8_part(hist0, Wh, v, sx + xs, ra - xs, rb - xs);
-}
-
-// CIGAR words k0 .. k0+3 of a read with nc words: one unaligned 16-byte load when all four are the read's own
-// (never touches memory past the batch's CIGAR array), guarded single loads for the read's last group
-__device__ __forceinline__ KdChunk kd_load_cigar4(const uint32_t *cg, uint32_t k0, uint32_t nc) {
-    if (k0 + 4 <= nc) return *reinterpret_cast<const KdChunk *>(cg + k0);
-    KdChunk r;
-    r.x = k0 < nc ? cg[k0] : 0u; r.y = k0 + 1 < nc ? cg[k0 + 1] : 0u;
-    r.z = k0 + 2 < nc ? cg[k0 + 2] : 0u; r.w = 0u;
-    return r;
 }
 
 // General per-lane walk of one regular read against the window (reads with clips, indels, long CIGARs).
