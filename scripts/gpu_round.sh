@@ -6,7 +6,7 @@ echo "== pytest gpu"; timeout 1200 python -m pytest tests -m gpu -q --maxfail=8 
 echo "== bench C3"; timeout 900 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err; echo "bench rc=$?"
 echo "== rocprof stats"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python $R/bench.py --no-cpu-baseline > $O/prof_c3_bench.json 2> $O/prof_c3.err); echo "rc=$?"
 bash scripts/gpu_pmc.sh > $O/pmc_summary.txt 2>&1; grep -E "^[1-4] k_(window|prep|cold)" $O/pmc_summary.txt
-for c in ${CONFIGS:-C2 C4 C5}; do timeout 400 python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_$c.json 2> $O/bench_$c.err; done
+for c in ${CONFIGS:-C2 C4 C5}; do timeout 600 python bench.py --config $c --steps 3 --warmup 1 > $O/bench_$c.json 2> $O/bench_$c.err; done
 python - <<PY
 import json
 for c in ["c3","C2","C4","C5"]:
