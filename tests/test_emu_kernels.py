@@ -119,3 +119,15 @@ def test_virtual_shards_stitch_to_the_unsharded_result(emu_lib):
 def test_fetch_all_equals_per_contig_fetch(emu_lib):
     """kd_consensus_fetch_all: one copy for every contig == the per-contig kd_consensus_fetch results."""
     P.check_fetch_all(emu_lib, P.load_fixture("minimap2__1.1.multi"))
+
+
+def test_multi_tile_items_carry_rows_between_tiles(emu_lib):
+    """Work items of several 1024-read tiles: whole rows in multiples of 4 per tile, the remainder carried into the
+    next tile's lists (plain and complex), the last tile takes everything."""
+    batch = synth.to_numpy(synth.short_reads([700], 1300, seed=9, planted=False))   # ~6000 reads over one window
+    assert len(batch["contig"]) > 5000
+    run = P.Run(emu_lib, batch, window=1024, slice_reads=4096)
+    assert run.info["windowed"] == 1
+    P.assert_matches_oracle(run)
+    run = P.Run(emu_lib, batch, window=256, slice_reads=2500)
+    P.assert_matches_oracle(run)

@@ -237,3 +237,10 @@ def test_fetch_all_equals_per_contig_fetch(hip_lib):
     P.check_fetch_all(hip_lib, P.load_fixture("minimap2__1.1.multi"))
     from kindel_amd import synth
     P.check_fetch_all(hip_lib, synth.to_numpy(synth.make("C4", scale=0.02)))
+
+
+def test_multi_tile_items_carry_rows_between_tiles(hip_lib):
+    from kindel_amd import synth
+    batch = synth.to_numpy(synth.short_reads([2000, 900], 3000, seed=9, planted=False))   # ~58000 reads, 3 windows of 1024
+    for window, slice_reads in ((1024, 32768), (640, 4096), (256, 3000)):
+        P.assert_matches_oracle(P.Run(hip_lib, batch, window=window, slice_reads=slice_reads), what="w%d s%d" % (window, slice_reads))
