@@ -15,7 +15,7 @@ for a in "$@"; do
     c5w) for w in 256 1024; do run c5_w$w --config C5 --window $w; done;;
     c5s) for sl in 64 128; do run c5_s$sl --config C5 --slice $sl; done;;
     shuf) run shuf --shuffle;;
-    half) KD_BENCH_LIB=exp/libkd_half.so run half_plain --synth clip_p=0.0 --synth indel_p=0.0 --synth planted=0; run plain --synth clip_p=0.0 --synth indel_p=0.0 --synth planted=0;;
+    plain) run plain --synth clip_p=0.0 --synth indel_p=0.0 --synth planted=0;;
     phase) KD_BENCH_LIB=exp/libkd_phase.so run phase;;
     phaseplain) KD_BENCH_LIB=exp/libkd_phase.so run phaseplain --synth clip_p=0.0 --synth indel_p=0.0 --synth planted=0;;   # hipcc -DKD_PHASE_CLOCKS build in exp/
     tests) timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3;;
