@@ -403,8 +403,7 @@ struct KdEngine {
             bool ok = false;
             for (int attempt = 0; attempt < 8 && !ok; attempt++) {
                 H.seed = 0x9e3779b97f4a7c15ULL * (uint64_t)(attempt + 1);
-                if (rt.memset(H.key, 0, cap * 8) || rt.memset(H.cnt, 0, cap * 4) || rt.memset(H.rep, 0xff, cap * 4) ||
-                    rt.memset(d_status + KDS_INS_COLLISION, 0, 8))
+                if (rt.memset(H.key, 0, cap * 8) || rt.memset(H.cnt, 0, cap * 4) || rt.memset(d_status + KDS_INS_COLLISION, 0, 8))
                     return hipfail("finalize: memset hash");
                 if (rt.launch("k_ins_insert", k_ins_insert, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev)) return hipfail("k_ins_insert");
                 if (rt.launch("k_ins_verify", k_ins_verify, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev, d_status))

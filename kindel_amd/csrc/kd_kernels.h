@@ -1583,7 +1583,7 @@ k_find_bad_base(KdReads rd, KdTabs T, const KdRInfo *rinfo, kd_u64 *status) {
 struct KdInsTab {
     kd_u64 *key;     // [cap] 0 = empty
     uint32_t *cnt;   // [cap]
-    uint32_t *rep;   // [cap] smallest event index with this key
+    uint32_t *rep;   // [cap] representative event of the key: the one that claimed the slot
     uint32_t *ev_slot;  // [n_ev]
     kd_u64 cap;      // power of two
     kd_u64 seed;
@@ -1607,12 +1607,16 @@ k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev) {
     kd_u64 s = (h >> 1) & (H.cap - 1);
     for (;;) {
         kd_u64 cur = H.key[s];
-        if (cur == 0) cur = atomicCAS(&H.key[s], 0ULL, h);
-        if (cur == 0 || cur == h) break;
+        if (cur == 0) {
+            cur = atomicCAS(&H.key[s], 0ULL, h);
+            // the event that claims the slot is its representative (any member would do: k_ins_verify proves all
+            // members byte-identical); a plain store instead of one more scattered atomic per event
+            if (cur == 0) { H.rep[s] = (uint32_t)e; break; }
+        }
+        if (cur == h) break;
         s = (s + 1) & (H.cap - 1);
     }
     atomicAdd(&H.cnt[s], 1u);
-    atomicMin(&H.rep[s], (uint32_t)e);
     H.ev_slot[e] = (uint32_t)s;
 }
 
