@@ -32,6 +32,11 @@ def first_json_line(path):
 st = glob.glob(os.path.join(O, "prof_c3", "**", "*kernel_stats.csv"), recursive=True)
 if st:
     shutil.copy(st[0], os.path.join(P, "%s_c3_kernel_stats.csv" % tag))
+    rows = list(csv.reader(open(st[0])))   # the same table without the synthetic-input generator's torch kernels
+    with open(os.path.join(P, "%s_c3_kernel_stats_kd_only.csv" % tag), "w", newline="") as fh:
+        w = csv.writer(fh)
+        for r in rows[:1] + [r for r in rows[1:] if r and r[0].startswith("k_")]:
+            w.writerow([r[0].split("(")[0]] + r[1:])
 for src, dst in (("bench_c3.json", "%s_c3_bench.json"), ("prof_c3_bench.json", "%s_c3_bench_under_rocprof.json"),
                  ("bench_C2.json", "%s_C2_bench.json"), ("bench_C4.json", "%s_C4_bench.json"), ("bench_C5.json", "%s_C5_bench.json")):
     p = os.path.join(O, src)
