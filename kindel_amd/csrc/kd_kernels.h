@@ -1682,15 +1682,15 @@ struct KdSite {
     bool live;         // a real site of a contig inside the emit interval
 };
 
-__device__ __forceinline__ KdSite kd_site_eval(const KdTabs &T, const KdCns &C, const KdIns &ins, kd_u64 g,
+// cbase / L: G-space base and length of the contig that owns site g's 64-site segment (looked up once per thread: its
+// 4 consecutive sites share a segment)
+__device__ __forceinline__ KdSite kd_site_eval(const KdTabs &T, const KdCns &C, const KdIns &ins, kd_u64 g, kd_u64 cbase, kd_u64 L,
                                                uint32_t a, uint32_t tt, uint32_t gg, uint32_t cc, uint32_t nn,
                                                uint32_t del, uint32_t ins_total, uint32_t ad_next_raw) {
     KdSite s;
     s.ins_len = 0; s.ins_ev = 0; s.depth = 0; s.ins = 0; s.has_base = 0; s.base = 'N'; s.change = 0; s.live = false;
     if (g >= T.stride || g < C.g_lo || g >= C.g_hi) return s;
-    const uint32_t c = C.seg_contig[g >> 6];
-    const kd_u64 p = g - T.contig_base[c];
-    const kd_u64 L = T.contig_len[c];
+    const kd_u64 p = g - cbase;
     if (p >= L) return s;  // the len-th slot and the padding emit nothing
     s.live = true;
     const kd_u64 ad = (kd_u64)a + cc + gg + tt;  // kindel.py:404 (no N)
@@ -1736,9 +1736,11 @@ __device__ __forceinline__ void kd_cns_load_eval(const KdTabs &T, const KdCns &C
         }
         v[c][KD_CNS_PER_THREAD] = (c < 4 && g0 + KD_CNS_PER_THREAD < S) ? row[g0 + KD_CNS_PER_THREAD] : 0;
     }
+    kd_u64 cbase = 0, L = 0;   // g0 is a multiple of KD_CNS_PER_THREAD = 4: the thread's sites lie in one 64-site segment
+    if (g0 < S) { const uint32_t c = C.seg_contig[g0 >> 6]; cbase = T.contig_base[c]; L = T.contig_len[c]; }
     for (int k = 0; k < KD_CNS_PER_THREAD; k++) {
         const uint32_t adn = v[0][k + 1] + v[1][k + 1] + v[2][k + 1] + v[3][k + 1];
-        out[k] = kd_site_eval(T, C, ins, g0 + k, v[0][k], v[1][k], v[2][k], v[3][k], v[4][k], v[5][k], v[6][k], adn);
+        out[k] = kd_site_eval(T, C, ins, g0 + k, cbase, L, v[0][k], v[1][k], v[2][k], v[3][k], v[4][k], v[5][k], v[6][k], adn);
     }
 }
 
