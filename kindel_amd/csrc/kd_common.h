@@ -1,0 +1,164 @@
+// kd_common.h -- shared by all kernels: status words, table / read / insertion descriptors, small helpers.
+// Part of the device code of kd_kernels.h (included from there, in order; not a stand-alone header).
+#pragma once
+
+#include <stdint.h>
+
+typedef unsigned long long kd_u64;
+
+#ifndef KD_DYN_SHARED
+#define KD_DYN_SHARED(type, name)                                                  \
+    extern __shared__ __attribute__((aligned(16))) unsigned char kd_dyn_smem_[];  \
+    type *name = reinterpret_cast<type *>(kd_dyn_smem_)
+#endif
+
+// 24-bit multiply (operands < 2^24): full-rate on the VALU
+#ifndef KD_MUL24
+#define KD_MUL24(a, b) __umul24((a), (b))
+#endif
+
+#define KD_WAVE 64
+#define KD_BLOCK 256
+#define KD_WAVES_PER_BLOCK (KD_BLOCK / KD_WAVE)
+
+// channel ids (mirrors include/kindel_hip.h)
+#define KDC_A 0
+#define KDC_T 1
+#define KDC_G 2
+#define KDC_C 3
+#define KDC_N 4
+#define KDC_DEL 5
+#define KDC_CSW 6
+#define KDC_CEW 11
+#define KDC_CLIP_STARTS 16
+#define KDC_CLIP_ENDS 17
+#define KDC_INS_TOTAL 18
+#define KDC_NCH 19
+
+// read classes written by k_prep
+#define KD_CLS_SKIP 0u    // flag & 4 or len(seq) <= 1                      kindel.py:43-46
+#define KD_CLS_REG 1u     // no wrap, no overhang, no reference exception possible except a bad base
+#define KD_CLS_IRREG 2u   // everything else: walked with exact Python semantics by k_pileup_wave
+#define KD_CLS_LONG 3u    // transient: CIGAR too long for the per-lane scan, k_prep_long decides
+#define KD_INFO_COLD 4u   // read has S or I ops (soft-clip tables / insertion events)
+#define KD_INFO_INS 8u    // read has I ops: k_prep reserved its insertion-event / pool slots
+#define KD_INFO_PLAIN 16u // regular read that is ONE M/=/X run covering the whole read (no clips, no indels)
+#define KD_SPAN_SHIFT 5
+#define KD_EV_DROPPED 0xffffffffu  // reserved insertion-event slot whose site belongs to another shard
+
+// device status words (kd_u64 each)
+enum {
+    KDS_ERR_READ = 0,   // atomicMin of the global index of the first failing read (init ~0)
+    KDS_ERR_CODE,       // written by k_diagnose
+    KDS_N_EV,           // insertion events used
+    KDS_POOL,           // insertion pool bytes used
+    KDS_ST_READS,       // reads counted
+    KDS_ST_ALIGNED,     // aligned-base events
+    KDS_ST_WALKED,      // walked events
+    KDS_ST_INS,         // insertion ops seen
+    KDS_B_INS_OPS,      // per batch: insertion ops
+    KDS_B_INS_BASES,    // per batch: insertion bases
+    KDS_B_MAXSPAN,      // per batch: max span of regular reads
+    KDS_B_MAXLEAD,      // per batch: max leading-clip reach of regular reads
+    KDS_B_MAXSEGSPAN,   // per batch: max span of a long read's SEGMENT (k_prep_long; k_window's second pass)
+    KDS_B_UNSORTED,     // per batch: reads not sorted by G-start
+    KDS_B_N_COLD,       // per batch: entries in the cold list
+    KDS_B_N_IRREG,      // per batch: entries in the irregular list
+    KDS_B_N_LONG,       // per batch: entries in the long-CIGAR list
+    KDS_B_N_REG,        // per batch: regular reads
+    KDS_NEXT_ITEM,      // window work queue head
+    KDS_TOTAL_ITEMS,    // window work queue length
+    KDS_INS_COLLISION,  // hash verification failed
+    KDS_INTERNAL,       // capacity overrun etc.
+    KDS_BAD_BASE,       // k_window: windows that saw a base outside A,C,G,T,N
+#ifdef KD_PHASE_CLOCKS
+    KDS_DBG0, KDS_DBG1, KDS_DBG2, KDS_DBG3, KDS_DBG4, KDS_DBG5, KDS_DBG6, KDS_DBG7,   // phase clocks (profiling build only)
+#endif
+    KDS_COUNT
+};
+
+struct KdTabs {
+    uint32_t *tab;               // [KDC_NCH][stride]
+    kd_u64 stride;               // S = total G-space sites (multiple of 64)
+    const uint32_t *contig_len;  // [n_contigs]
+    const kd_u64 *contig_base;   // [n_contigs]
+    kd_u64 g_lo, g_hi;           // commit increments with g_lo <= g <= g_hi (g_hi = halo site)
+};
+
+struct KdReads {
+    kd_u64 n;
+    kd_u64 base_index;  // global index of read 0 (over all pushed batches)
+    const uint32_t *contig;
+    const int32_t *pos0;
+    const uint32_t *flag;
+    const kd_u64 *seq_off;
+    const uint32_t *seq_len;
+    const kd_u64 *cig_off;
+    const uint32_t *n_cig;
+    const uint8_t *seq4;
+    const uint32_t *cigar;
+};
+
+struct KdRInfo {
+    uint32_t gstart;    // contig_base + max(pos0, 0)
+    uint32_t span_cls;  // span << KD_SPAN_SHIFT | KD_INFO_INS | KD_INFO_COLD | class; span = sites from
+                        // gstart to the end of the last M / D / trailing-S write
+    uint32_t lead;      // sites before gstart written by a leading soft clip (kindel.py:68-72)
+    uint32_t pad;       // long-CIGAR reads: 1 + index of the read's KdCkpt[256] block; 0 otherwise
+};
+
+// Long-CIGAR reads (k_prep_long): the state at the first op of each of the 256 per-thread op runs.  Lets
+// k_cold_long emit a read's insertion events with 256 threads and lets k_window enter the read near a window
+// instead of walking thousands of ops from the start.
+struct KdCkpt {
+    uint32_t r_rel;   // reference advance (r - pos0) before the run
+    uint32_t q;       // query advance before the run
+    uint32_t ev;      // insertion events of the read before the run
+    uint32_t pool;    // insertion bases of the read before the run
+};
+
+struct KdIns {
+    uint32_t *ev_site;  // [ev_cap] G-space site
+    uint32_t *ev_len;   // [ev_cap] bases
+    kd_u64 *ev_off;     // [ev_cap] offset into pool
+    uint8_t *pool;      // one 4-bit base code per byte
+    kd_u64 ev_cap, pool_cap;
+    uint32_t *read_ev;  // [n reads of the batch] first event slot of the read (valid when KD_INFO_INS)
+    kd_u64 *read_pool;  // [n reads of the batch] first pool byte of the read
+};
+
+// ---------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------
+
+// BAM nibble -> weight channel in the reference's dict order A,T,G,C,N (kindel.py:29);
+// 7 = not a key of that dict (KeyError in the reference).
+__device__ __forceinline__ uint32_t kd_chan(uint32_t nib) {
+    return (uint32_t)((0x4777777177727307ULL >> (nib * 4)) & 7ULL);
+}
+
+__device__ __forceinline__ uint32_t kd_nib(const uint8_t *seq, int64_t q) {
+    uint32_t b = seq[q >> 1];
+    return (q & 1) ? (b & 15u) : (b >> 4);
+}
+
+// 16 packed bases-bytes at ANY byte address: gfx950 global loads are unaligned-capable, hipcc emits one
+// global_load_dwordx4 for this type.  Chunk c of a read holds its query bases 32c .. 32c+31.
+struct __attribute__((packed, aligned(1))) KdChunk { uint32_t x, y, z, w; };
+// bit position of base b (0..7) inside a little-endian dword of BAM nibbles (high nibble first)
+#define KD_NIB_SHIFT(b) (8 * ((b) >> 1) + (((b) & 1) ? 0 : 4))
+
+__device__ __forceinline__ bool kd_commit(const KdTabs &T, kd_u64 g) { return g >= T.g_lo && g <= T.g_hi; }
+
+// CIGAR words k0 .. k0+3 of a read with nc words: one unaligned 16-byte load when all four are the read's own
+// (never touches memory past the batch's CIGAR array), guarded single loads for the read's last group
+__device__ __forceinline__ KdChunk kd_load_cigar4(const uint32_t *cg, uint32_t k0, uint32_t nc) {
+    if (k0 + 4 <= nc) return *reinterpret_cast<const KdChunk *>(cg + k0);
+    KdChunk r;
+    r.x = k0 < nc ? cg[k0] : 0u; r.y = k0 + 1 < nc ? cg[k0 + 1] : 0u;
+    r.z = k0 + 2 < nc ? cg[k0 + 2] : 0u; r.w = 0u;
+    return r;
+}
+
+
+__device__ __forceinline__ void kd_flag_error(kd_u64 *status, kd_u64 gidx) { atomicMin(&status[KDS_ERR_READ], gidx); }

@@ -1,0 +1,167 @@
+// kd_plan.h -- k_plan_*, k_sort_*: windows -> candidate ranges -> work items; bucket sort by window.
+// Part of the device code of kd_kernels.h (included from there, in order; not a stand-alone header).
+#pragma once
+#include "kd_common.h"
+
+// ---------------------------------------------------------------------------------------
+// Windowed path: k_plan + k_window
+// ---------------------------------------------------------------------------------------
+
+// first index in [0,n) with rinfo[idx].gstart >= key
+__device__ __forceinline__ kd_u64 kd_lower_bound(const KdRInfo *rinfo, kd_u64 n, kd_u64 key) {
+    kd_u64 lo = 0, hi = n;
+    while (lo < hi) {
+        const kd_u64 mid = (lo + hi) >> 1;
+        if ((kd_u64)rinfo[mid].gstart < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// k_plan_ranges: one thread per window w of W sites.  The candidate reads are those whose G-start
+// lies in [w*W - maxspan, (w+1)*W) -- a contiguous index range because the batch is sorted -- cut
+// into slices of `slice` reads (one work item each).
+__global__ void __launch_bounds__(KD_BLOCK)
+k_plan_ranges(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t slice,
+              kd_u64 *win_lo, kd_u64 *win_hi, kd_u64 *item_off, const kd_u64 *status) {
+    const uint32_t w = blockIdx.x * KD_BLOCK + threadIdx.x;   // local index; the window is w0 + w (shard-local planning)
+    if (w >= n_win) return;
+    const kd_u64 maxspan = status[KDS_B_MAXSPAN];
+    const kd_u64 wlo = (kd_u64)(w0 + w) * W, whi = wlo + W;
+    const kd_u64 lo = kd_lower_bound(rinfo, n_reads, wlo > maxspan ? wlo - maxspan : 0);
+    const kd_u64 hi = kd_lower_bound(rinfo, n_reads, whi + status[KDS_B_MAXLEAD]);  // leading clips reach back
+    win_lo[w] = lo; win_hi[w] = hi;
+    item_off[w] = (hi - lo + slice - 1) / slice;  // item count; k_plan_scan turns it into an offset
+}
+
+// ---- unsorted batches: bucket the regular reads by window (counting sort), so that the candidate reads of
+// a window are again a contiguous range -- of the permutation `order` instead of the batch itself.
+// Each thread takes RUN CONSECUTIVE entries and merges neighbours that fall into the same bin into one atomic.
+// RUN = KD_SORT_RUN for the segments of long reads: they arrive in reference order, thousands per bin, and one
+// atomic per entry would serialise on a handful of addresses.  RUN = 1 for the reads of an unsorted batch
+// (nothing to merge; coalesced one-entry-per-lane access).
+#define KD_SORT_RUN 16
+template <int RUN>
+__global__ void __launch_bounds__(KD_BLOCK)
+k_sort_count(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t W, uint32_t *bin_cnt) {
+    const kd_u64 i0 = ((kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x) * RUN;
+    uint32_t cur = 0xffffffffu, run = 0;
+    for (kd_u64 i = i0; i < i0 + RUN && i < n_reads; i++) {
+        const KdRInfo ri = rinfo[i];
+        if ((ri.span_cls & 3u) != KD_CLS_REG) continue;
+        const uint32_t b = ri.gstart / W;
+        if (b != cur) {
+            if (run) atomicAdd(&bin_cnt[cur], run);
+            cur = b; run = 0;
+        }
+        run++;
+    }
+    if (run) atomicAdd(&bin_cnt[cur], run);
+}
+// one workgroup: bin_off = exclusive scan of bin_cnt (n_bins + 1 entries), bin_cnt is reset to 0 (it becomes
+// the fill cursor of k_sort_scatter)
+__global__ void __launch_bounds__(KD_BLOCK)
+k_sort_scan(uint32_t *bin_cnt, kd_u64 *bin_off, uint32_t n_bins) {
+    __shared__ kd_u64 s_scan[KD_BLOCK];
+    __shared__ kd_u64 s_carry;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n_bins; b0 += KD_BLOCK) {
+        const uint32_t b = b0 + t;
+        const kd_u64 v = b < n_bins ? bin_cnt[b] : 0;
+        s_scan[t] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
+            kd_u64 a = t >= d ? s_scan[t - d] : 0;
+            __syncthreads();
+            s_scan[t] += a;
+            __syncthreads();
+        }
+        if (b < n_bins) { bin_off[b] = s_carry + s_scan[t] - v; bin_cnt[b] = 0; }
+        __syncthreads();
+        if (t == KD_BLOCK - 1) s_carry += s_scan[t];
+        __syncthreads();
+    }
+    if (t == 0) bin_off[n_bins] = s_carry;
+}
+template <int RUN>
+__global__ void __launch_bounds__(KD_BLOCK)
+k_sort_scatter(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t W, uint32_t *bin_fill, const kd_u64 *bin_off,
+               uint32_t *order) {
+    const kd_u64 i0 = ((kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x) * RUN;
+    const kd_u64 i1 = i0 + RUN < n_reads ? i0 + RUN : n_reads;
+    // maximal runs of consecutive regular entries of one bin: one reservation, consecutive slots
+    kd_u64 i = i0;
+    while (i < i1) {
+        const KdRInfo ri = rinfo[i];
+        if ((ri.span_cls & 3u) != KD_CLS_REG) { i++; continue; }
+        const uint32_t b = ri.gstart / W;
+        kd_u64 j = i + 1;
+        uint32_t m = 1;
+        for (; j < i1; j++) {
+            const KdRInfo rj = rinfo[j];
+            if ((rj.span_cls & 3u) != KD_CLS_REG) continue;   // skipped entries do not break a run
+            if (rj.gstart / W != b) break;
+            m++;
+        }
+        kd_u64 at = bin_off[b] + atomicAdd(&bin_fill[b], m);
+        order[at++] = (uint32_t)i;
+        for (kd_u64 x = i + 1; x < j; x++)   // (i, j): entries of bin b and skipped ones
+            if ((rinfo[x].span_cls & 3u) == KD_CLS_REG) order[at++] = (uint32_t)x;
+        i = j;
+    }
+}
+// candidate range of window w0 + w in `order`: whole bins covering [wlo - maxspan, whi + maxlead)
+__global__ void __launch_bounds__(KD_BLOCK)
+k_plan_ranges_sorted(const kd_u64 *bin_off, uint32_t n_bins, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t slice,
+                     kd_u64 *win_lo, kd_u64 *win_hi, kd_u64 *item_off, const kd_u64 *status, uint32_t span_slot) {
+    const uint32_t w = blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (w >= n_win) return;
+    const kd_u64 wlo = (kd_u64)(w0 + w) * W, whi = wlo + W;
+    const kd_u64 maxspan = status[span_slot], maxlead = status[KDS_B_MAXLEAD];   // span_slot: KDS_B_MAXSPAN / KDS_B_MAXSEGSPAN
+    const kd_u64 blo = (wlo > maxspan ? wlo - maxspan : 0) / W;
+    kd_u64 bhi = (whi + maxlead + W - 1) / W;   // exclusive
+    if (bhi > n_bins) bhi = n_bins;
+    const kd_u64 lo = bin_off[blo < n_bins ? blo : n_bins], hi = bin_off[bhi];
+    win_lo[w] = lo; win_hi[w] = hi;
+    item_off[w] = (hi - lo + slice - 1) / slice;
+}
+
+// k_plan_scan: one workgroup, in-place exclusive scan of the per-window item counts.
+__global__ void __launch_bounds__(KD_BLOCK)
+k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
+    __shared__ kd_u64 s_scan[KD_BLOCK];
+    __shared__ kd_u64 s_carry;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t w0 = 0; w0 < n_win; w0 += KD_BLOCK) {
+        const uint32_t w = w0 + t;
+        const kd_u64 items = w < n_win ? item_off[w] : 0;
+        s_scan[t] = items;
+        __syncthreads();
+        for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
+            kd_u64 a = t >= d ? s_scan[t - d] : 0;
+            __syncthreads();
+            s_scan[t] += a;
+            __syncthreads();
+        }
+        if (w < n_win) item_off[w] = s_carry + s_scan[t] - items;
+        __syncthreads();
+        if (t == KD_BLOCK - 1) s_carry += s_scan[t];
+        __syncthreads();
+    }
+    if (t == 0) { item_off[n_win] = s_carry; status[KDS_TOTAL_ITEMS] = s_carry; status[KDS_NEXT_ITEM] = 0; }
+}
+
+// k_plan_items: work item -> window table (k_window then needs one load, not a binary search over item_off,
+// to find the window of the item it dequeued).
+__global__ void __launch_bounds__(KD_BLOCK)
+k_plan_items(const kd_u64 *item_off, uint32_t n_win, uint32_t *item_win, kd_u64 cap, kd_u64 *status) {
+    const uint32_t w = blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (w >= n_win) return;
+    for (kd_u64 it = item_off[w]; it < item_off[w + 1]; it++) {
+        if (it < cap) item_win[it] = w;
+        else status[KDS_INTERNAL] = 1;
+    }
+}

@@ -1,0 +1,393 @@
+// kd_prep.h -- k_prep, k_prep_long: classify reads, footprints, stats, insertion slots, long-read checkpoints and segments.
+// Part of the device code of kd_kernels.h (included from there, in order; not a stand-alone header).
+#pragma once
+#include "kd_common.h"
+
+// ---------------------------------------------------------------------------------------
+// k_prep: classify reads, compute the reference span of their table writes, count events.
+// One lane per read, KD_PREP_PER_THREAD reads per lane so that the per-block reductions
+// (stats, list reservations) cost one global atomic per 8192 reads.
+// ---------------------------------------------------------------------------------------
+#define KD_PREP_PER_THREAD 32
+#define KD_PREP_CHUNK (KD_BLOCK * KD_PREP_PER_THREAD)
+#define KD_PREP_MAX_OPS 16
+
+// result of scanning one CIGAR
+struct KdScan {
+    uint32_t cls, cold, lead;
+    kd_u64 span, n_ins, ins_bases, aligned, walked;
+};
+
+// Serial scan of ops [0, nc) of a read; shared by k_prep (short CIGARs) and k_diagnose-free
+// paths.  "Regular" means: k_window / the COLD pass can process the read with plain
+// G-space arithmetic and no Python wrap-around or exception can occur (bad bases aside).
+// `pre` = the first 4 CIGAR words, already in registers (loaded together with those of other reads), or NULL
+__device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc, int64_t pos0, int64_t sl, int64_t L,
+                                                const uint32_t *pre = nullptr) {
+    KdScan s;
+    s.cls = KD_CLS_REG; s.cold = 0; s.lead = 0; s.span = 0; s.n_ins = 0; s.ins_bases = 0; s.aligned = 0; s.walked = 0;
+    bool regular = pos0 >= 0;
+    bool seen_nfs = false;  // a non-first S was seen: r is no longer plain prefix arithmetic
+    int64_t r = pos0, q = 0, hot_hi = pos0;
+    for (uint32_t k = 0; k < nc; k++) {
+        const uint32_t c = (pre && k < 4) ? (k == 0 ? pre[0] : k == 1 ? pre[1] : k == 2 ? pre[2] : pre[3]) : cg[k];
+        const int64_t len = c >> 4;
+        const uint32_t op = c & 15u;
+        if (op == 0 || op == 7 || op == 8) {  // M = X
+            if (seen_nfs || r + len > L || q + len > sl) regular = false;
+            r += len; q += len; hot_hi = r;
+            s.aligned += (kd_u64)len; s.walked += (kd_u64)len;
+        } else if (op == 1) {  // I
+            s.cold = KD_INFO_COLD;
+            if (seen_nfs || r > L) regular = false;
+            int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
+            s.n_ins += 1; s.ins_bases += (kd_u64)(q1 - q0);
+            q += len; s.walked += (kd_u64)len;
+        } else if (op == 2) {  // D
+            if (seen_nfs || r + len > L + 1) regular = false;
+            r += len; hot_hi = r;
+            s.walked += (kd_u64)len;
+        } else if (op == 4) {  // S
+            s.cold = KD_INFO_COLD;
+            s.walked += (kd_u64)len;
+            if (k == 0) {
+                if (r > L || len > sl) regular = false;
+                s.lead = (uint32_t)(len < r ? len : (r > 0 ? r : 0));
+                q += len;
+            } else {
+                if (seen_nfs || r - 1 > L) regular = false;   // clip_starts[r - 1] must exist (kindel.py:75)
+                seen_nfs = true;
+                int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
+                if (n_adv > sl - q || (len > n_adv && q + n_adv >= sl)) regular = false;
+                r += n_adv; q += n_adv;
+                hot_hi = r;  // the clip_start_weights writes extend the read's footprint
+            }
+        }
+    }
+    if (!regular) s.cls = KD_CLS_IRREG;
+    s.span = hot_hi > pos0 ? (kd_u64)(hot_hi - pos0) : 0;
+    return s;
+}
+
+__global__ void __launch_bounds__(KD_BLOCK)
+k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irreg_list, uint32_t *long_list,
+       uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
+    __shared__ kd_u64 s_red[8];       // reads, aligned, walked, ins_ops, ins_bases, n_reg, unsorted
+    __shared__ uint32_t s_maxspan, s_maxlead;
+    __shared__ uint32_t s_cnt[3];     // cold, irreg, long (block totals / running offsets)
+    __shared__ kd_u64 s_base[5];
+    __shared__ kd_u64 s_ins[2];       // insertion events / insertion bases of the block's short-CIGAR reads
+    const uint32_t t = threadIdx.x;
+    if (t < 8) s_red[t] = 0;
+    if (t < 3) s_cnt[t] = 0;
+    if (t < 2) s_ins[t] = 0;
+    if (t == 0) { s_maxspan = 0; s_maxlead = 0; }
+    __syncthreads();
+    const kd_u64 chunk0 = (kd_u64)blockIdx.x * KD_PREP_CHUNK;
+    kd_u64 a_reads = 0, a_aligned = 0, a_walked = 0, a_ins = 0, a_insb = 0, a_reg = 0, a_unsorted = 0;
+    uint32_t a_maxspan = 0, a_maxlead = 0, n_cold = 0, n_irreg = 0, n_long = 0;
+    uint32_t m_cold = 0, m_irreg = 0, m_long = 0, m_ins = 0;  // bit `it` = this thread's it-th read is in the list
+    uint32_t c_cached = 0xffffffffu;                             // one-entry cache of the contig table
+    kd_u64 cb_cached = 0;
+    int64_t L_cached = 0;
+    // 4 reads per step: all of their metadata loads are issued before any is consumed
+    for (int it0 = 0; it0 < KD_PREP_PER_THREAD; it0 += 4) {
+        uint32_t v_c[4], v_pc[4], v_nc[4], v_fl[4];
+        int64_t v_pos[4], v_ppos[4], v_sl[4];
+        kd_u64 v_coff[4];
+        bool v_ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const kd_u64 i = chunk0 + (kd_u64)(it0 + u) * KD_BLOCK + t;
+            v_ok[u] = i < rd.n;
+            const kd_u64 j = v_ok[u] ? i : 0, jp = (v_ok[u] && i > 0) ? i - 1 : j;
+            v_c[u] = rd.contig[j]; v_pos[u] = rd.pos0[j];
+            v_pc[u] = rd.contig[jp]; v_ppos[u] = rd.pos0[jp];
+            v_sl[u] = rd.seq_len[j]; v_nc[u] = rd.n_cig[j]; v_fl[u] = rd.flag[j]; v_coff[u] = rd.cig_off[j];
+        }
+        // second level: the first 4 CIGAR words of each of the 4 reads, again all in flight together
+        uint32_t v_cw[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t *cgp = rd.cigar + v_coff[u];
+            const uint32_t ncu = v_ok[u] ? v_nc[u] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v_cw[u][k] = (uint32_t)k < ncu ? cgp[k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!v_ok[u]) continue;
+            const int it = it0 + u;
+            const kd_u64 i = chunk0 + (kd_u64)it * KD_BLOCK + t;
+            const uint32_t c = v_c[u];
+            if (c != c_cached) { c_cached = c; cb_cached = T.contig_base[c]; L_cached = (int64_t)T.contig_len[c]; }
+            const int64_t pos0 = v_pos[u];
+            const kd_u64 gkey = cb_cached + (kd_u64)(pos0 > 0 ? pos0 : 0);
+            {   // sortedness of G-start over ALL reads of the batch (window ranges rely on it)
+                const kd_u64 pcb = v_pc[u] == c ? cb_cached : T.contig_base[v_pc[u]];
+                const kd_u64 pk = pcb + (kd_u64)(v_ppos[u] > 0 ? v_ppos[u] : 0);
+                if (pk > gkey) a_unsorted++;
+            }
+            const int64_t sl = v_sl[u];
+            const uint32_t nc = v_nc[u];
+            uint32_t cls, cold = 0, lead = 0;
+            kd_u64 span = 0, al = 0, n_ins_r = 0, n_insb_r = 0;
+            bool has_ins = false;
+            if ((v_fl[u] & 4u) || sl <= 1) {
+                cls = KD_CLS_SKIP;
+            } else if (nc == 0) {
+                cls = KD_CLS_IRREG;  // CIGAR '*': k_pileup_wave raises KD_E_CIGAR
+                a_reads++;
+            } else if (nc > KD_PREP_MAX_OPS) {
+                cls = KD_CLS_LONG;
+                a_reads++;
+            } else {
+                KdScan s = kd_scan_cigar(rd.cigar + v_coff[u], nc, pos0, sl, L_cached, v_cw[u]);
+                cls = s.cls; cold = s.cold; span = s.span; lead = s.lead; has_ins = s.n_ins != 0; al = s.aligned;
+                n_ins_r = s.n_ins; n_insb_r = s.ins_bases;
+                a_reads++; a_aligned += s.aligned; a_walked += s.walked; a_ins += s.n_ins; a_insb += s.ins_bases;
+            }
+            if (span > 0x07ffffffULL) { cls = KD_CLS_IRREG; span = 0; }
+            if (cls == KD_CLS_REG) {
+                a_reg++;
+                if ((uint32_t)span > a_maxspan) a_maxspan = (uint32_t)span;
+                if (lead > a_maxlead) a_maxlead = lead;
+            }
+            if (cls == KD_CLS_REG && cold) { n_cold++; m_cold |= 1u << it; }
+            if (cls == KD_CLS_IRREG) { n_irreg++; m_irreg |= 1u << it; }
+            if (cls == KD_CLS_LONG) { n_long++; m_long |= 1u << it; }
+            if (has_ins) { m_ins |= 1u << it; read_ev[i] = (uint32_t)n_ins_r; read_pool[i] = n_insb_r; }   // counts, see the last loop
+            KdRInfo ri;
+            ri.gstart = (uint32_t)gkey;
+            // plain: the whole read is ONE aligned run: a single op whose aligned length is the read length
+            const uint32_t plain = (cls == KD_CLS_REG && nc == 1 && !cold && al == (kd_u64)sl && span == al) ? KD_INFO_PLAIN : 0u;
+            ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | plain | (has_ins ? KD_INFO_INS : 0u) | cold | cls;
+            ri.lead = lead; ri.pad = 0;
+            rinfo[i] = ri;
+        }
+    }
+    // block reduction through LDS atomics, then one global atomic per word per block
+    if (a_reads) atomicAdd(&s_red[0], a_reads);
+    if (a_aligned) atomicAdd(&s_red[1], a_aligned);
+    if (a_walked) atomicAdd(&s_red[2], a_walked);
+    if (a_ins) atomicAdd(&s_red[3], a_ins);
+    if (a_insb) atomicAdd(&s_red[4], a_insb);
+    if (a_reg) atomicAdd(&s_red[5], a_reg);
+    if (a_unsorted) atomicAdd(&s_red[6], a_unsorted);
+    if (a_maxspan) atomicMax(&s_maxspan, a_maxspan);
+    if (a_maxlead) atomicMax(&s_maxlead, a_maxlead);
+    // list slots: thread-local offset inside the block
+    uint32_t o_cold = n_cold ? atomicAdd(&s_cnt[0], n_cold) : 0;
+    uint32_t o_irreg = n_irreg ? atomicAdd(&s_cnt[1], n_irreg) : 0;
+    uint32_t o_long = n_long ? atomicAdd(&s_cnt[2], n_long) : 0;
+    // insertion event / pool slots: thread-local offsets inside the block, one global reservation per block
+    // (a global counter bumped per event serialises at ~11 ns per returning atomic on one address)
+    const kd_u64 o_ev = a_ins ? atomicAdd(&s_ins[0], a_ins) : 0;
+    const kd_u64 o_pool = a_ins ? atomicAdd(&s_ins[1], a_insb) : 0;
+    __syncthreads();
+    if (t == 0) {
+        if (s_red[0]) atomicAdd(&status[KDS_ST_READS], s_red[0]);
+        if (s_red[1]) atomicAdd(&status[KDS_ST_ALIGNED], s_red[1]);
+        if (s_red[2]) atomicAdd(&status[KDS_ST_WALKED], s_red[2]);
+        if (s_red[3]) { atomicAdd(&status[KDS_ST_INS], s_red[3]); atomicAdd(&status[KDS_B_INS_OPS], s_red[3]); }
+        if (s_red[4]) atomicAdd(&status[KDS_B_INS_BASES], s_red[4]);
+        s_base[3] = s_ins[0] ? atomicAdd(&status[KDS_N_EV], s_ins[0]) : 0;
+        s_base[4] = s_ins[0] ? atomicAdd(&status[KDS_POOL], s_ins[1]) : 0;
+        if (s_red[5]) atomicAdd(&status[KDS_B_N_REG], s_red[5]);
+        if (s_red[6]) atomicAdd(&status[KDS_B_UNSORTED], s_red[6]);
+        if (s_maxspan) atomicMax(&status[KDS_B_MAXSPAN], (kd_u64)s_maxspan);
+        if (s_maxlead) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)s_maxlead);
+        s_base[0] = s_cnt[0] ? atomicAdd(&status[KDS_B_N_COLD], (kd_u64)s_cnt[0]) : 0;
+        s_base[1] = s_cnt[1] ? atomicAdd(&status[KDS_B_N_IRREG], (kd_u64)s_cnt[1]) : 0;
+        s_base[2] = s_cnt[2] ? atomicAdd(&status[KDS_B_N_LONG], (kd_u64)s_cnt[2]) : 0;
+    }
+    __syncthreads();
+    if (m_cold | m_irreg | m_long | m_ins) {
+        kd_u64 w_cold = s_base[0] + o_cold, w_irreg = s_base[1] + o_irreg, w_long = s_base[2] + o_long;
+        kd_u64 w_ev = s_base[3] + o_ev, w_pool = s_base[4] + o_pool;
+        for (uint32_t todo = m_cold | m_irreg | m_long | m_ins; todo; todo &= todo - 1) {
+            const int it = __builtin_ctz(todo);
+            const kd_u64 i = chunk0 + (kd_u64)it * KD_BLOCK + t;
+            const uint32_t bit = 1u << it;
+            if (m_ins & bit) {  // the first pass left the read's event / base COUNTS here: turn them into its slots
+                const uint32_t n_ev = read_ev[i];
+                const kd_u64 n_b = read_pool[i];
+                read_ev[i] = (uint32_t)w_ev; read_pool[i] = w_pool;
+                w_ev += n_ev; w_pool += n_b;
+            }
+            if (m_cold & bit) cold_list[w_cold++] = (uint32_t)i;
+            if (m_irreg & bit) irreg_list[w_irreg++] = (uint32_t)i;
+            if (m_long & bit) long_list[w_long++] = (uint32_t)i;
+        }
+    }
+}
+
+// k_prep_long: one workgroup per read whose CIGAR has more than KD_PREP_MAX_OPS words
+// (long-read aligners: thousands of ops).  Each thread sums the reference / query advance
+// of a contiguous run of ops, an LDS scan turns the sums into start coordinates, and a
+// second sweep applies the same regularity rules as kd_scan_cigar.
+__global__ void __launch_bounds__(KD_BLOCK)
+k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdCkpt *ckpt, KdRInfo *seginfo,
+            uint32_t *irreg_list, uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
+    __shared__ int64_t s_r[KD_BLOCK], s_q[KD_BLOCK];
+    __shared__ uint32_t s_ni[KD_BLOCK], s_nb[KD_BLOCK];
+    __shared__ kd_u64 s_acc[6];       // aligned, walked, n_ins, ins_bases, bad, cold
+    __shared__ uint32_t s_first_nfs, s_last_rel;
+    __shared__ uint32_t s_regular, s_lead, s_gstart, s_nfs_adv, s_maxseg;
+    const uint32_t t = threadIdx.x;
+    const kd_u64 i = long_list[blockIdx.x];
+    const uint32_t c = rd.contig[i];
+    const int64_t L = T.contig_len[c];
+    const int64_t pos0 = rd.pos0[i];
+    const int64_t sl = rd.seq_len[i];
+    const uint32_t nc = rd.n_cig[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    const uint32_t per = (nc + KD_BLOCK - 1) / KD_BLOCK;
+    const uint32_t k0 = t * per < nc ? t * per : nc, k1 = k0 + per < nc ? k0 + per : nc;
+    if (t < 6) s_acc[t] = 0;
+    if (t == 0) { s_first_nfs = 0xffffffffu; s_last_rel = 0; s_regular = 0; s_lead = 0; s_gstart = 0; s_nfs_adv = 0; s_maxseg = 0; }
+    int64_t dr = 0, dq = 0;
+    for (uint32_t k = k0; k < k1; k++) {
+        const uint32_t w = cg[k];
+        const int64_t len = w >> 4;
+        const uint32_t op = w & 15u;
+        if (op == 0 || op == 7 || op == 8) { dr += len; dq += len; }
+        else if (op == 1) dq += len;
+        else if (op == 2) dr += len;
+        else if (op == 4 && k == 0) dq += len;
+        // a non-first S contributes nothing here: anything after it makes the read irregular,
+        // and if nothing follows its own advance is irrelevant to the span
+    }
+    s_r[t] = dr; s_q[t] = dq;
+    __syncthreads();
+    // inclusive Hillis-Steele scan over the 256 partial sums
+    for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
+        int64_t ar = 0, aq = 0;
+        if (t >= d) { ar = s_r[t - d]; aq = s_q[t - d]; }
+        __syncthreads();
+        s_r[t] += ar; s_q[t] += aq;
+        __syncthreads();
+    }
+    int64_t r = pos0 + (t ? s_r[t - 1] : 0), q = t ? s_q[t - 1] : 0;
+    const int64_t r_end = pos0 + s_r[KD_BLOCK - 1];
+    const int64_t r_run = r, q_run = q;   // checkpoint: state before this thread's run of ops
+    kd_u64 aligned = 0, walked = 0, n_ins = 0, insb = 0, bad = 0, cold = 0;
+    uint32_t first_nfs = 0xffffffffu, last_rel = 0;
+    for (uint32_t k = k0; k < k1; k++) {
+        const uint32_t w = cg[k];
+        const int64_t len = w >> 4;
+        const uint32_t op = w & 15u;
+        if (op == 0 || op == 7 || op == 8) {
+            if (r + len > L || q + len > sl) bad = 1;
+            r += len; q += len; aligned += (kd_u64)len; walked += (kd_u64)len; last_rel = k;
+        } else if (op == 1) {
+            cold = 1;
+            if (r > L) bad = 1;
+            int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
+            n_ins++; insb += (kd_u64)(q1 - q0); q += len; walked += (kd_u64)len; last_rel = k;
+        } else if (op == 2) {
+            if (r + len > L + 1) bad = 1;
+            r += len; walked += (kd_u64)len; last_rel = k;
+        } else if (op == 4) {
+            cold = 1; walked += (kd_u64)len;
+            if (k == 0) { if (r > L || len > sl) bad = 1; q += len; }
+            else {
+                if (k < first_nfs) first_nfs = k;
+                if (r - 1 > L) bad = 1;   // clip_starts[r - 1] must exist (kindel.py:75)
+                int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
+                if (n_adv > sl - q || (len > n_adv && q + n_adv >= sl)) bad = 1;
+                last_rel = k;
+            }
+        }
+    }
+    if (aligned) atomicAdd(&s_acc[0], aligned);
+    if (walked) atomicAdd(&s_acc[1], walked);
+    if (n_ins) atomicAdd(&s_acc[2], n_ins);
+    if (insb) atomicAdd(&s_acc[3], insb);
+    if (bad) atomicAdd(&s_acc[4], bad);
+    if (cold) atomicAdd(&s_acc[5], cold);
+    if (first_nfs != 0xffffffffu) atomicMin(&s_first_nfs, first_nfs);
+    if (last_rel) atomicMax(&s_last_rel, last_rel);
+    // exclusive prefix of the per-run insertion counts -> event / pool offsets inside the read
+    s_ni[t] = (uint32_t)n_ins; s_nb[t] = (uint32_t)insb;
+    __syncthreads();
+    for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
+        uint32_t a = 0, b = 0;
+        if (t >= d) { a = s_ni[t - d]; b = s_nb[t - d]; }
+        __syncthreads();
+        s_ni[t] += a; s_nb[t] += b;
+        __syncthreads();
+    }
+    {
+        KdCkpt ck;
+        ck.r_rel = (uint32_t)(r_run - pos0); ck.q = (uint32_t)q_run;
+        ck.ev = s_ni[t] - (uint32_t)n_ins; ck.pool = s_nb[t] - (uint32_t)insb;
+        ckpt[(kd_u64)blockIdx.x * KD_BLOCK + t] = ck;
+    }
+    if (t == 0) {
+        bool regular = pos0 >= 0 && s_acc[4] == 0;
+        // a non-first S must be the last op that touches r (M, I, D or S)
+        if (s_first_nfs != 0xffffffffu && s_last_rel > s_first_nfs) regular = false;
+        int64_t foot_end = r_end;
+        uint32_t lead = 0;
+        if (regular) {
+            if ((cg[0] & 15u) == 4u) { const int64_t l0 = cg[0] >> 4; lead = (uint32_t)(l0 < pos0 ? l0 : pos0); }
+            if (s_first_nfs != 0xffffffffu) {  // trailing clip: r at that op is r_end (nothing after it moves r)
+                const int64_t ls = cg[s_first_nfs] >> 4;
+                const int64_t adv = r_end < L ? (ls < L - r_end ? ls : L - r_end) : 0;
+                foot_end += adv;
+                s_nfs_adv = (uint32_t)adv;
+            }
+        }
+        kd_u64 span = foot_end > pos0 ? (kd_u64)(foot_end - pos0) : 0;
+        if (span > 0x07ffffffULL) { regular = false; span = 0; }
+        const uint32_t coldbit = s_acc[5] ? KD_INFO_COLD : 0u;
+        KdRInfo ri = rinfo[i];
+        // a regular long read KEEPS class LONG: k_window's first pass (class REG) leaves it alone, its aligned and
+        // deleted bases are tallied segment by segment in the second pass, its S / I side effects by k_cold_long
+        ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | (s_acc[2] ? KD_INFO_INS : 0u) | coldbit |
+                      (regular ? KD_CLS_LONG : KD_CLS_IRREG);
+        ri.lead = regular ? lead : 0u;
+        ri.pad = regular ? blockIdx.x + 1u : 0u;
+        rinfo[i] = ri;
+        s_regular = regular ? 1u : 0u; s_lead = ri.lead; s_gstart = ri.gstart;
+        if (s_acc[2]) {
+            read_ev[i] = (uint32_t)atomicAdd(&status[KDS_N_EV], s_acc[2]);
+            read_pool[i] = atomicAdd(&status[KDS_POOL], s_acc[3]);
+        }
+        atomicAdd(&status[KDS_ST_ALIGNED], s_acc[0]);
+        atomicAdd(&status[KDS_ST_WALKED], s_acc[1]);
+        if (s_acc[2]) { atomicAdd(&status[KDS_ST_INS], s_acc[2]); atomicAdd(&status[KDS_B_INS_OPS], s_acc[2]); }
+        if (s_acc[3]) atomicAdd(&status[KDS_B_INS_BASES], s_acc[3]);
+        if (regular) {
+            atomicAdd(&status[KDS_B_N_REG], 1ULL);
+            if (lead) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)lead);
+            // (its S / I side effects are done by k_cold_long, 256 threads per read)
+        } else {
+            irreg_list[atomicAdd(&status[KDS_B_N_IRREG], 1ULL)] = (uint32_t)i;
+        }
+    }
+    __syncthreads();
+    // SEGMENTS: this thread's run of ops [k0, k1) as a work unit of its own -- where it starts on the reference
+    // (checkpoint), how far its M / D / trailing-clip tallies reach.  k_window's second pass treats the segments of all
+    // long reads like a batch of short reads: bucket-sorted by window, one lane per segment, a few ops each,
+    // instead of one lane crawling through the hundreds of ops a long read has inside a window.
+    {
+        KdRInfo v;
+        v.gstart = 0; v.span_cls = KD_CLS_SKIP; v.lead = 0; v.pad = 0;
+        if (s_regular && k0 < k1) {
+            kd_u64 sp = (kd_u64)(r - r_run);                         // M and D advance of the run
+            if (first_nfs != 0xffffffffu) sp += s_nfs_adv;           // the trailing clip's clip_start_weights reach
+            const uint32_t ld = k0 == 0 ? s_lead : 0u;               // the leading clip reaches back from the read's start
+            if (sp > 0 || ld > 0) {
+                v.gstart = s_gstart + (uint32_t)(r_run - pos0);
+                v.span_cls = ((uint32_t)sp << KD_SPAN_SHIFT) | KD_CLS_REG;
+                v.lead = ld; v.pad = blockIdx.x + 1u;
+                atomicMax(&s_maxseg, (uint32_t)sp);
+            }
+        }
+        seginfo[(kd_u64)blockIdx.x * KD_BLOCK + t] = v;
+    }
+    __syncthreads();
+    if (t == 0 && s_maxseg) atomicMax(&status[KDS_B_MAXSEGSPAN], (kd_u64)s_maxseg);
+}

@@ -1,0 +1,327 @@
+// kd_readwise.h -- k_pileup_wave (exact semantics, wavefront per read), k_cold_lane, k_cold_long, k_diagnose.
+// Part of the device code of kd_kernels.h (included from there, in order; not a stand-alone header).
+#pragma once
+#include "kd_common.h"
+
+// ---------------------------------------------------------------------------------------
+// k_pileup_wave<HOT, COLD>: one wavefront per read, exact reference semantics
+// (kindel.py:40-81 incl. Python negative-index wrap-around), 32-bit atomics into HBM.
+//   HOT : commit M/=/X and D tallies (weights, deletions)
+//   COLD: commit soft-clip tables and emit insertion events
+// <true,true> is what runs: irregular reads, unsorted batches and KD_MODE_GLOBAL.
+// All control flow is wave-uniform (every value steering it comes from uniform loads).
+// ---------------------------------------------------------------------------------------
+template <bool HOT, bool COLD>
+__global__ void __launch_bounds__(KD_BLOCK)
+k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list, const KdRInfo *rinfo,
+              kd_u64 *status) {
+    const uint32_t lane = threadIdx.x & (KD_WAVE - 1);
+    const kd_u64 slot = (kd_u64)blockIdx.x * KD_WAVES_PER_BLOCK + (threadIdx.x / KD_WAVE);
+    if (slot >= n_list) return;
+    const kd_u64 i = list ? (kd_u64)list[slot] : slot;
+    const int64_t sl = rd.seq_len[i];
+    if ((rd.flag[i] & 4u) || sl <= 1) return;  // kindel.py:43-46
+    const kd_u64 gidx = rd.base_index + i;
+    const uint32_t nc = rd.n_cig[i];
+    if (nc == 0) { if (lane == 0) kd_flag_error(status, gidx); return; }  // kindel.py:47
+    const uint32_t c = rd.contig[i];
+    const int64_t L = T.contig_len[c];
+    const kd_u64 cb = T.contig_base[c];
+    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    uint32_t *tab = T.tab;
+    const kd_u64 S = T.stride;
+    int64_t r = rd.pos0[i], q = 0;  // kindel.py:41-42
+    kd_u64 ev_next = 0, pool_next = 0;  // this read's reserved insertion slots (k_prep), loaded at its first I
+    bool ev_loaded = false;
+    for (uint32_t k = 0; k < nc; k++) {
+        const uint32_t w = cg[k];
+        const int64_t len = w >> 4;
+        const uint32_t op = w & 15u;
+        if (op == 0 || op == 7 || op == 8) {  // M = X  kindel.py:49-54
+            if (len > 0 && (q + len > sl || r + len > L || r < -L)) { if (lane == 0) kd_flag_error(status, gidx); return; }
+            if (HOT) {
+                for (int64_t j = lane; j < len; j += KD_WAVE) {
+                    int64_t idx = r + j;
+                    if (idx < 0) idx += L;
+                    const uint32_t ch = kd_chan(kd_nib(seq, q + j));
+                    const kd_u64 g = cb + (kd_u64)idx;
+                    if (ch == 7u) kd_flag_error(status, gidx);
+                    else if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)ch * S + g], 1u);
+                }
+            }
+            r += len; q += len;
+        } else if (op == 1) {  // I  kindel.py:55-58
+            if (r > L || r < -(L + 1)) { if (lane == 0) kd_flag_error(status, gidx); return; }
+            if (COLD) {
+                if (!ev_loaded) { ev_next = ins.read_ev[i]; pool_next = ins.read_pool[i]; ev_loaded = true; }
+                const int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
+                const kd_u64 n = (kd_u64)(q1 - q0);
+                const kd_u64 e = ev_next, po = pool_next;
+                ev_next += 1; pool_next += n;
+                if (lane == 0) {
+                    const int64_t idx = r < 0 ? r + L + 1 : r;
+                    const kd_u64 g = cb + (kd_u64)idx;
+                    if (e >= ins.ev_cap || po + n > ins.pool_cap) {
+                        atomicAdd(&status[KDS_INTERNAL], 1ULL);
+                    } else if (kd_commit(T, g)) {
+                        ins.ev_site[e] = (uint32_t)g; ins.ev_len[e] = (uint32_t)n; ins.ev_off[e] = po;
+                        for (kd_u64 b = 0; b < n; b++) ins.pool[po + b] = (uint8_t)kd_nib(seq, q0 + (int64_t)b);
+                        atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g], 1u);
+                    } else {
+                        ins.ev_site[e] = KD_EV_DROPPED; ins.ev_len[e] = 0; ins.ev_off[e] = po;  // other shard's site
+                    }
+                }
+            }
+            q += len;
+        } else if (op == 2) {  // D  kindel.py:59-62
+            if (len > 0 && (r + len - 1 > L || r < -(L + 1))) { if (lane == 0) kd_flag_error(status, gidx); return; }
+            if (HOT) {
+                for (int64_t j = lane; j < len; j += KD_WAVE) {
+                    int64_t idx = r + j;
+                    if (idx < 0) idx += L + 1;
+                    const kd_u64 g = cb + (kd_u64)idx;
+                    if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_DEL * S + g], 1u);
+                }
+            }
+            r += len;
+        } else if (op == 4) {  // S
+            if (k == 0) {  // kindel.py:64-73
+                if (r > L || r < -(L + 1) || len > sl) { if (lane == 0) kd_flag_error(status, gidx); return; }
+                if (COLD) {
+                    if (lane == 0) {
+                        const kd_u64 g = cb + (kd_u64)(r < 0 ? r + L + 1 : r);
+                        if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g], 1u);
+                    }
+                    for (int64_t j = lane; j < len; j += KD_WAVE) {
+                        const int64_t rel = r - len + j;
+                        if (rel >= 0) {
+                            const uint32_t ch = kd_chan(kd_nib(seq, j));
+                            const kd_u64 g = cb + (kd_u64)rel;
+                            if (ch == 7u) kd_flag_error(status, gidx);
+                            else if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)(KDC_CEW + ch) * S + g], 1u);
+                        }
+                    }
+                }
+                q += len;
+            } else {  // kindel.py:74-81
+                const int64_t x = r - 1;
+                if (x > L || x < -(L + 1)) { if (lane == 0) kd_flag_error(status, gidx); return; }
+                const int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
+                if (n_adv > sl - q || (len > n_adv && q + n_adv >= sl) || (n_adv > 0 && r < -L)) {
+                    if (lane == 0) kd_flag_error(status, gidx);
+                    return;
+                }
+                if (COLD) {
+                    if (lane == 0) {
+                        const kd_u64 g = cb + (kd_u64)(x < 0 ? x + L + 1 : x);
+                        if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
+                    }
+                    for (int64_t j = lane; j < n_adv; j += KD_WAVE) {
+                        int64_t idx = r + j;
+                        if (idx < 0) idx += L;
+                        const uint32_t ch = kd_chan(kd_nib(seq, q + j));
+                        const kd_u64 g = cb + (kd_u64)idx;
+                        if (ch == 7u) kd_flag_error(status, gidx);
+                        else if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)(KDC_CSW + ch) * S + g], 1u);
+                    }
+                }
+                r += n_adv; q += n_adv;
+            }
+        }
+        // H, N, P, anything else: ignored entirely
+    }
+    (void)rinfo;
+}
+
+// k_cold_lane: what is left of the soft-clip / insertion side of REGULAR reads (kindel.py:55-58, :63-81) once
+// k_window has tallied the clipped bases: the clip_ends / clip_starts counters (one 32-bit atomic each) and
+// the insertion events, written into the slots k_prep reserved for the read.  One LANE per read of the cold
+// list.  Regular reads cannot raise and never wrap (k_prep checked), so this is plain G-space arithmetic.
+__global__ void __launch_bounds__(KD_BLOCK)
+k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list, kd_u64 *status) {
+    const kd_u64 slot = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (slot >= n_list) return;
+    const kd_u64 i = list[slot];
+    const int64_t sl = rd.seq_len[i];
+    const uint32_t nc = rd.n_cig[i];
+    const uint32_t c = rd.contig[i];
+    const int64_t L = T.contig_len[c];
+    const kd_u64 cb = T.contig_base[c];
+    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    uint32_t *tab = T.tab;
+    const kd_u64 S = T.stride;
+    int64_t r = rd.pos0[i], q = 0;
+    // everything the walk may need is requested up front (first four CIGAR words in one load, the read's event /
+    // pool slots): the kernel is a chain of dependent round trips otherwise
+    const KdChunk pre = kd_load_cigar4(cg, 0u, nc);
+    kd_u64 ev_next = ins.read_ev[i], pool_next = ins.read_pool[i];   // (garbage for a read without insertions: unused)
+    for (uint32_t k = 0; k < nc; k++) {
+        const uint32_t w = k == 0 ? pre.x : k == 1 ? pre.y : k == 2 ? pre.z : k == 3 ? pre.w : cg[k];
+        const int64_t len = w >> 4;
+        const uint32_t op = w & 15u;
+        if (op == 0 || op == 7 || op == 8) { r += len; q += len; }
+        else if (op == 2) { r += len; }
+        else if (op == 1) {
+            const int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
+            const kd_u64 n = (kd_u64)(q1 - q0);
+            const kd_u64 e = ev_next, po = pool_next;
+            ev_next += 1; pool_next += n;
+            const kd_u64 g = cb + (kd_u64)r;  // 0 <= r <= L for a regular read
+            if (e >= ins.ev_cap || po + n > ins.pool_cap) {
+                atomicAdd(&status[KDS_INTERNAL], 1ULL);
+            } else if (kd_commit(T, g)) {
+                ins.ev_site[e] = (uint32_t)g; ins.ev_len[e] = (uint32_t)n; ins.ev_off[e] = po;
+                for (kd_u64 b = 0; b < n; b++) ins.pool[po + b] = (uint8_t)kd_nib(seq, q0 + (int64_t)b);
+                atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g], 1u);
+            } else {
+                ins.ev_site[e] = KD_EV_DROPPED; ins.ev_len[e] = 0; ins.ev_off[e] = po;
+            }
+            q += len;
+        } else if (op == 4) {
+            if (k == 0) {  // kindel.py:64-73
+                const kd_u64 g = cb + (kd_u64)r;
+                if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g], 1u);
+                // query bases [xa, len) land on sites r - len + x  (those with r - len + x >= 0)
+                // (clip_end_weights of these bases are tallied by k_window)
+                q += len;
+            } else {  // kindel.py:74-81; regular: the last op that touches r
+                const int64_t x = r - 1;
+                const kd_u64 g = cb + (kd_u64)(x < 0 ? x + L + 1 : x);
+                if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
+                const int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
+                // query bases [q, q + n_adv) land on sites r + (x - q)
+                // clip_start_weights are tallied by k_window (LDS)
+                r += n_adv; q += n_adv;
+            }
+        }
+    }
+}
+
+// k_cold_long: k_cold_lane's work for regular long-CIGAR reads, one WORKGROUP per read: thread t starts from
+// checkpoint t (state before its run of ops, incl. how many insertion events / bases precede it).
+__global__ void __launch_bounds__(KD_BLOCK)
+k_cold_long(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint32_t *long_list, const KdCkpt *ckpt,
+            kd_u64 *status) {
+    const uint32_t t = threadIdx.x;
+    const kd_u64 i = long_list[blockIdx.x];
+    const uint32_t sc = rinfo[i].span_cls;
+    if ((sc & 3u) != KD_CLS_LONG || !(sc & KD_INFO_COLD)) return;   // LONG after k_prep_long = regular long read
+    const uint32_t nc = rd.n_cig[i];
+    const uint32_t per = (nc + KD_BLOCK - 1) / KD_BLOCK;
+    const uint32_t k0 = t * per < nc ? t * per : nc, k1 = k0 + per < nc ? k0 + per : nc;
+    if (k0 >= k1) return;
+    const uint32_t c = rd.contig[i];
+    const int64_t L = T.contig_len[c];
+    const kd_u64 cb = T.contig_base[c];
+    const int64_t sl = rd.seq_len[i];
+    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    const KdCkpt ck = ckpt[(kd_u64)blockIdx.x * KD_BLOCK + t];
+    int64_t r = rd.pos0[i] + (int64_t)ck.r_rel, q = ck.q;
+    kd_u64 e = 0, po = 0;
+    if (sc & KD_INFO_INS) { e = (kd_u64)ins.read_ev[i] + ck.ev; po = ins.read_pool[i] + ck.pool; }
+    uint32_t *tab = T.tab;
+    const kd_u64 S = T.stride;
+    for (uint32_t k = k0; k < k1; k++) {
+        const uint32_t w = cg[k];
+        const int64_t len = w >> 4;
+        const uint32_t op = w & 15u;
+        if (op == 0 || op == 7 || op == 8) { r += len; q += len; }
+        else if (op == 2) { r += len; }
+        else if (op == 1) {
+            const int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
+            const kd_u64 n = (kd_u64)(q1 - q0);
+            const kd_u64 g = cb + (kd_u64)r;
+            if (e >= ins.ev_cap || po + n > ins.pool_cap) {
+                atomicAdd(&status[KDS_INTERNAL], 1ULL);
+            } else if (kd_commit(T, g)) {
+                ins.ev_site[e] = (uint32_t)g; ins.ev_len[e] = (uint32_t)n; ins.ev_off[e] = po;
+                for (kd_u64 b = 0; b < n; b++) ins.pool[po + b] = (uint8_t)kd_nib(seq, q0 + (int64_t)b);
+                atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g], 1u);
+            } else {
+                ins.ev_site[e] = KD_EV_DROPPED; ins.ev_len[e] = 0; ins.ev_off[e] = po;
+            }
+            e += 1; po += n; q += len;
+        } else if (op == 4) {
+            if (k == 0) {
+                const kd_u64 g = cb + (kd_u64)r;
+                if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g], 1u);
+                q += len;
+            } else {  // regular: the last op that touches r
+                const int64_t x = r - 1;
+                const kd_u64 g = cb + (kd_u64)(x < 0 ? x + L + 1 : x);
+                if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
+            }
+        }
+    }
+}
+
+// k_diagnose: one thread re-walks the first failing read serially, in the reference's own
+// statement order, to decide WHICH exception the reference raises (KeyError vs IndexError
+// vs RuntimeError).  Error classification only -- it writes no table.
+__global__ void k_diagnose(KdReads rd, KdTabs T, kd_u64 *status) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const kd_u64 gidx = status[KDS_ERR_READ];
+    if (gidx == ~0ULL || gidx < rd.base_index || gidx >= rd.base_index + rd.n) return;
+    const kd_u64 i = gidx - rd.base_index;
+    const int64_t sl = rd.seq_len[i];
+    const uint32_t nc = rd.n_cig[i];
+    const int64_t L = T.contig_len[rd.contig[i]];
+    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    kd_u64 code = 8;  // KD_E_INTERNAL magnitude: flagged but no exception reproduced
+    if (nc == 0) { status[KDS_ERR_CODE] = 3; return; }
+    int64_t r = rd.pos0[i], q = 0;
+    for (uint32_t k = 0; k < nc && code == 8; k++) {
+        const int64_t len = cg[k] >> 4;
+        const uint32_t op = cg[k] & 15u;
+        if (op == 0 || op == 7 || op == 8) {
+            for (int64_t j = 0; j < len; j++) {
+                if (q >= sl) { code = 2; break; }
+                int64_t idx = r < 0 ? r + L : r;
+                if (idx < 0 || idx >= L) { code = 2; break; }
+                if (kd_chan(kd_nib(seq, q)) == 7u) { code = 1; break; }
+                r++; q++;
+            }
+        } else if (op == 1) {
+            int64_t idx = r < 0 ? r + L + 1 : r;
+            if (idx < 0 || idx > L) { code = 2; break; }
+            q += len;
+        } else if (op == 2) {
+            for (int64_t j = 0; j < len; j++) {
+                int64_t idx = r + j < 0 ? r + j + L + 1 : r + j;
+                if (idx < 0 || idx > L) { code = 2; break; }
+            }
+            r += len;
+        } else if (op == 4) {
+            if (k == 0) {
+                int64_t idx = r < 0 ? r + L + 1 : r;
+                if (idx < 0 || idx > L) { code = 2; break; }
+                for (int64_t j = 0; j < len; j++) {
+                    if (j >= sl) { code = 2; break; }
+                    const int64_t rel = r - len + j;
+                    if (rel >= 0) {
+                        if (rel >= L) { code = 2; break; }
+                        if (kd_chan(kd_nib(seq, j)) == 7u) { code = 1; break; }
+                    }
+                }
+                q += len;
+            } else {
+                int64_t idx = r - 1 < 0 ? r - 1 + L + 1 : r - 1;
+                if (idx < 0 || idx > L) { code = 2; break; }
+                for (int64_t j = 0; j < len; j++) {
+                    if (q >= sl) { code = 2; break; }
+                    if (r < L) {
+                        int64_t wi = r < 0 ? r + L : r;
+                        if (wi < 0 || wi >= L) { code = 2; break; }
+                        if (kd_chan(kd_nib(seq, q)) == 7u) { code = 1; break; }
+                        r++; q++;
+                    }
+                }
+            }
+        }
+    }
+    status[KDS_ERR_CODE] = code;
+}

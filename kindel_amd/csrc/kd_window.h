@@ -1,0 +1,514 @@
+// kd_window.h -- k_window: the LDS-histogram pileup (dominant kernel), its walkers, k_find_bad_base.
+// Part of the device code of kd_kernels.h (included from there, in order; not a stand-alone header).
+#pragma once
+#include "kd_common.h"
+
+// k_window: persistent workgroups pull (window, slice) work items (k_plan_*).
+//
+// LDS (dynamic): u16 hist[19][W + 2 * KD_HALO], channel-major, two sites per dword: three groups of
+// {A,T,G,C,N, bad} -- weights (rows 0-5), clip_start_weights (7-12), clip_end_weights (13-18) -- plus deletions (6).
+// "bad" collects bases outside A,C,G,T,N (KeyError in the reference; checked at flush).  38 B per site: W = 640 is
+// 25 KB + 4 KB of read lists, five workgroups (20 wavefronts) per CU.  Soft clips are tallied here too because 4 x 10^7
+// scattered device-scope atomics cost as much as the whole LDS pass (measured: 1.4 ms vs 1.5 ms).
+//
+// One LANE per read.  Per 1024-read tile the threads sort the window's reads into a PLAIN list (one M/=/X run spanning
+// the read: nothing to decode) and a COMPLEX list; wavefronts then take rows of 64 list entries, lane l the entry
+// l * rows + r, so that the lanes of a wavefront sit `rows` reads apart in the coordinate-sorted batch and rarely hit the
+// same counter in the same instruction.
+//   kd_walk_plain   16-byte chunks of packed bases at any byte address, three chunks of prefetch; a dword = 8 bases,
+//                   every base one ds_add_u32: nibble -> bfe, channel -> 64-bit LUT shift, address -> mad24, the base index
+//                   in the instruction's immediate offset (masked variant at the ends of the run / of the window)
+//   kd_walk_short   reads with clips / indels and <= 16 ops: CIGAR -> at most three segments cut to the window, then one
+//                   software-pipelined loop over (segment, chunk) steps of branch-free masked adds
+//   kd_walk_ops     the general op-by-op walk: short reads with more than three segments, and -- in the second launch --
+//                   the SEGMENTS of long reads (k_prep_long), one lane per segment
+// Only regular reads are handled here; their clip_starts / clip_ends counters and insertion events are done by
+// k_cold_lane / k_cold_long, irregular reads by k_pileup_wave.
+#define KD_HCH 19
+#define KD_HCH_DEL 6u
+#define KD_HCH_CSW 7u
+#define KD_HCH_CEW 13u
+
+// BAM nibble -> channel inside a group: A,T,G,C,N -> 0..4, everything else -> 5 (the group's bad slot)
+__device__ __forceinline__ uint32_t kd_hchan(uint32_t nib) {
+    return (uint32_t)((0x4555555155525305ULL >> (nib * 4)) & 7ULL);
+}
+
+// The LDS histogram packs TWO sites per dword (u16 halves): a work item tallies at most `slice` <= 32768 reads
+// and a read adds at most 1 to a counter, so a half cannot overflow into its neighbour.  Every channel has
+// KD_HALO extra sites on both sides of the window: window clipping is done at DWORD granularity (a dword
+// that straddles the window edge is added whole, its outside bases land in the halo and are never flushed),
+// so the masked path below is only needed at the ends of a run -- which are the same step for all lanes of
+// a wavefront of equal-length reads -- and not wherever some lane happens to cross the window edge.
+// Counter of (channel ch, window-relative site s in [-KD_HALO, W + KD_HALO)) = half (s & 1) of word
+// ch*Wh + (s >> 1) of `hist0` = hist + KD_HALO/2, with Wh = (W + 2*KD_HALO) / 2.
+#define KD_HALO 8
+__device__ __forceinline__ void kd_hadd(uint32_t *hist0, int32_t Wh, uint32_t ch, int32_t s) {
+    atomicAdd(&hist0[(int32_t)KD_MUL24(ch, (uint32_t)Wh) + (s >> 1)], 1u << (16 * (s & 1)));
+}
+// all 8 bases of dword v are added; s0 = window-relative site of its first base.  Even bases go through pointer h
+// with add value vp, odd bases through hq = h + (s0 & 1) with vq: no per-base parity arithmetic.
+__device__ __forceinline__ void kd_add8_full(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t s0) {
+    const int32_t p = s0 & 1;
+    // byte addressing: address = row base + ch * (row bytes) + constant, one 24-bit multiply-add per base
+    // (v_mad_u32_u24 is full rate; a 32-bit v_mul_lo_u32 is not)
+    unsigned char *h = reinterpret_cast<unsigned char *>(hist0 + (s0 >> 1));
+    unsigned char *hq = h + 4 * p;
+    const uint32_t rowb = (uint32_t)Wh * 4u;
+    const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const uint32_t ch = kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u);
+        unsigned char *a = ((b & 1) ? hq : h) + KD_MUL24(ch, rowb) + 4 * (b >> 1);
+        atomicAdd(reinterpret_cast<uint32_t *>(a), (b & 1) ? vq : vp);
+    }
+}
+// only bases [blo, bhi) belong to the run
+__device__ __forceinline__ void kd_add8_part(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t s0, int32_t blo, int32_t bhi) {
+#pragma unroll
+    for (int b = 0; b < 8; b++)
+        if (b >= blo && b < bhi) kd_hadd(hist0, Wh, kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u), s0 + b);
+}
+// One memory dword of a run.  xs = query index of the dword's first base; [xa, xb) = the run's query bases that
+// fall inside the window (decides whether the dword is touched at all); [ra, rb) = the run's own query bases
+// (decides which of its 8 bases exist); site of base x is sx + x (for a clip run sx also carries the
+// channel-group offset, an even number of sites).
+__device__ __forceinline__ void kd_add_dword(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t xs, int32_t xa, int32_t xb,
+                                             int32_t ra, int32_t rb, int32_t sx) {
+    if (xs + 8 <= xa || xs >= xb) return;
+    if (xs >= ra && xs + 8 <= rb) kd_add8_full(hist0, Wh, v, sx + xs);
+    else kd_add8_part(hist0, Wh, v, sx + xs, ra - xs, rb - xs);
+}
+
+// General per-lane walk of one regular read against the window (reads with clips, indels, long CIGARs).
+// A state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the current run), not over
+// CIGAR ops, so that lanes keep adding bases together whatever their op structure.  A soft clip is a
+// run of its own on the clip_start / clip_end channel group.
+// Bases of dword v whose bit is set in m (bit b = base b) are added; the others add 0 to a counter at most
+// 7 sites away from a live one, i.e. inside the row (halo included).  No branches: lanes whose dword is cut
+// by a run end, a clip end or the window edge stay in step with lanes whose dword is whole.
+__device__ __forceinline__ void kd_add8_masked(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t s0, uint32_t m) {
+    const int32_t p = s0 & 1;
+    unsigned char *h = reinterpret_cast<unsigned char *>(hist0 + (s0 >> 1));
+    unsigned char *hq = h + 4 * p;
+    const uint32_t rowb = (uint32_t)Wh * 4u;
+    const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
+    const uint32_t me = m << (16 * p), mo = m << (16 - 16 * p);   // bit b of m moved onto the add value's bit
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const uint32_t ch = kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u);
+        unsigned char *a = ((b & 1) ? hq : h) + KD_MUL24(ch, rowb) + 4 * (b >> 1);
+        atomicAdd(reinterpret_cast<uint32_t *>(a), (b & 1) ? ((mo >> b) & vq) : ((me >> b) & vp));
+    }
+}
+// one 16-byte chunk (query bases xs .. xs+31) against the live query range [lo, hi) of a segment
+__device__ __forceinline__ void kd_add_chunk_masked(uint32_t *hist0, int32_t Wh, const KdChunk &cur, int32_t xs, int32_t lo,
+                                                    int32_t hi, int32_t sx) {
+    const uint32_t dw[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const int32_t x0 = xs + 8 * d;
+        int32_t l = lo - x0, h = hi - x0;
+        if (h <= 0 || l >= 8) continue;
+        l = l < 0 ? 0 : l;
+        h = h > 8 ? 8 : h;
+        kd_add8_masked(hist0, Wh, dw[d], sx + x0, (0xffu >> (8 - h)) & (0xffu << l));
+    }
+}
+
+// Ops [k, k_end) of read i, entered with the reference cursor at window-relative site `grel` and the query cursor
+// at q: the whole CIGAR of a short read with many segments (k = 0, k_end = n_cig), or ONE SEGMENT of a long read
+// (k_prep_long's checkpoint).  `lead` / `foot_end`: reach of the leading clip / window-relative end of the footprint
+// (used by the clip ops, which sit in the first / last segment).
+__device__ __forceinline__ void kd_walk_ops(const KdReads &rd, kd_u64 i, uint32_t k, uint32_t k_end, int32_t grel, int32_t q,
+                                            int32_t lead, int32_t foot_end, int32_t Wi, int32_t Wh, uint32_t *hist0) {
+    const int32_t Wp = 2 * Wh;   // sites per channel row, halos included
+    const uint32_t nc = rd.n_cig[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
+    // Per-lane state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the
+    // current M run), not over CIGAR ops: lanes whose reads have clips or indels still add
+    // bases in the same wavefront instructions as their single-run neighbours.
+    int32_t xa = 0, xb = 0, sx = 0, c = 1, cb = 0;   // live query range [xa, xb) of the current run; c > cb: none
+    // CIGAR words four at a time (one unaligned 16-byte load, the next four already in flight), and the last
+    // 16-byte chunk of bases kept: a long read's runs are a few bases each, so consecutive runs share a chunk
+    // and one load per op would make the walk a chain of dependent HBM round trips.
+    uint32_t kw = k & ~3u;                     // cw_cur holds words kw .. kw + 3
+    KdChunk cw_cur = kd_load_cigar4(cg, kw, nc), cw_nxt = cw_cur;
+    if (kw + 4 < nc) cw_nxt = kd_load_cigar4(cg, kw + 4, nc);
+    int32_t c_have = -1;
+    KdChunk cur = cw_cur;
+    for (;;) {
+        while (c > cb && k < k_end) {   // advance to the next run with live bases
+            if (k >= kw + 4) {
+                kw += 4; cw_cur = cw_nxt;
+                if (kw + 4 < nc) cw_nxt = kd_load_cigar4(cg, kw + 4, nc);
+            }
+            const uint32_t kk = k & 3u;
+            const uint32_t cw = kk == 0 ? cw_cur.x : kk == 1 ? cw_cur.y : kk == 2 ? cw_cur.z : cw_cur.w;
+            const int32_t len = (int32_t)(cw >> 4);
+            const uint32_t op = cw & 15u;
+            k++;
+            if (op == 0 || op == 7 || op == 8) {
+                // live query range: inside the run and inside the window
+                xa = grel < 0 ? q - grel : q;
+                xb = Wi - grel < len ? q + (Wi - grel) : q + len;
+                sx = grel - q;                      // site of query base x is sx + x
+                if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                q += len; grel += len;
+                if (grel >= Wi) k = k_end;
+            } else if (op == 2) {
+                for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
+                    kd_hadd(hist0, Wh, KD_HCH_DEL, grel + j);
+                grel += len;
+                if (grel >= Wi) k = k_end;
+            } else if (op == 1) {
+                q += len;
+            } else if (op == 4) {
+                if (k == 1) {
+                    // leading clip, kindel.py:64-73: base x -> site r - len + x, kept if >= contig start
+                    // (`lead` of the len bases); a run on the clip_end_weights channels
+                    const int32_t s_first = grel - len;           // site of base 0
+                    xa = -s_first > len - lead ? -s_first : len - lead;
+                    xb = Wi - s_first < len ? Wi - s_first : len;
+                    sx = s_first + (int32_t)KD_HCH_CEW * Wp;
+                    if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                    q += len;
+                } else {
+                    // non-first clip, kindel.py:74-81: bases q.. -> sites r.. while r < L; for a regular
+                    // read it is the last op that moves r, so its reach is the end of the footprint
+                    const int32_t n_adv = foot_end - grel;
+                    xa = grel < 0 ? q - grel : q;
+                    xb = Wi - grel < n_adv ? q + (Wi - grel) : q + n_adv;
+                    sx = grel - q + (int32_t)KD_HCH_CSW * Wp;
+                    if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
+                    k = k_end;
+                }
+            }
+        }
+        if (c > cb) break;
+        if (c != c_have) { cur = src[c]; c_have = c; }
+        const int32_t xs = 32 * c;
+        kd_add_chunk_masked(hist0, Wh, cur, xs, xa, xb, sx);   // [xa, xb) lies inside the run: branch-free masked adds
+        c++;
+    }
+}
+
+// SHORT regular reads with clips / indels (at most KD_PREP_MAX_OPS ops, the bulk of the non-plain reads of a
+// short-read batch).  Two phases: (1) decode the CIGAR into at most three SEGMENTS -- runs of query bases that
+// land on consecutive sites of one channel group: an M/=/X run, the leading clip (clip_end_weights), the non-first
+// clip (clip_start_weights) -- each already cut to the window; deletions are tallied on the way; (2) one flat,
+// software-pipelined loop over (segment, 16-byte chunk) steps, every step a branch-free masked add, so that the
+// lanes of a wavefront stay in step whatever their op structure.  Returns false (nothing added) when the read
+// has more than three segments: the caller then takes the general walk.
+__device__ __forceinline__ bool kd_walk_short(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi, int32_t Wh,
+                                              uint32_t *hist0) {
+    const uint32_t nc = rd.n_cig[i];
+    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    // the first four CIGAR words, all in flight together (a short read rarely has more)
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    if (nc > 0) w0 = cg[0];
+    if (nc > 1) w1 = cg[1];
+    if (nc > 2) w2 = cg[2];
+    if (nc > 3) w3 = cg[3];
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
+    uint32_t n_seg_ops = 0;
+    for (uint32_t k = 0; k < nc; k++) {
+        const uint32_t cw = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : k == 3 ? w3 : cg[k];
+        const uint32_t op = cw & 15u;
+        n_seg_ops += (op == 0 || op == 7 || op == 8 || op == 4) ? 1u : 0u;
+    }
+    if (n_seg_ops > 3) return false;
+    const int32_t Wp = 2 * Wh;   // sites per channel row, halos included
+    const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
+    const int32_t lead = (int32_t)ri.lead;
+    const int32_t foot_end = (int32_t)((uint32_t)(gs + span) - (uint32_t)wlo);  // window-relative end of the footprint
+    int32_t grel = (int32_t)((uint32_t)gs - (uint32_t)wlo);                        // window-relative site, may be negative
+    int32_t q = 0;
+    // segment slots: live query range [a, b) and site offset x (site of query base j is x + j, channel group included)
+    int32_t a0 = 0, b0 = 0, x0 = 0, a1 = 0, b1 = 0, x1 = 0, a2 = 0, b2 = 0, x2 = 0;
+    uint32_t ns = 0;
+    for (uint32_t k = 0; k < nc; k++) {
+        const uint32_t cw = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : k == 3 ? w3 : cg[k];
+        const int32_t len = (int32_t)(cw >> 4);
+        const uint32_t op = cw & 15u;
+        int32_t xa = 0, xb = 0, sx = 0;
+        if (op == 0 || op == 7 || op == 8) {
+            xa = grel < 0 ? q - grel : q;
+            xb = Wi - grel < len ? q + (Wi - grel) : q + len;
+            sx = grel - q;
+            q += len; grel += len;
+        } else if (op == 2) {
+            for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
+                kd_hadd(hist0, Wh, KD_HCH_DEL, grel + j);
+            grel += len;
+        } else if (op == 1) {
+            q += len;
+        } else if (op == 4) {
+            if (k == 0) {   // leading clip, kindel.py:64-73: base j -> site r - len + j, the last `lead` bases are kept
+                const int32_t s_first = grel - len;
+                xa = -s_first > len - lead ? -s_first : len - lead;
+                xb = Wi - s_first < len ? Wi - s_first : len;
+                sx = s_first + (int32_t)KD_HCH_CEW * Wp;
+                q += len;
+            } else {        // non-first clip, kindel.py:74-81: it is the last op that moves r (regular read)
+                const int32_t n_adv = foot_end - grel;
+                xa = grel < 0 ? q - grel : q;
+                xb = Wi - grel < n_adv ? q + (Wi - grel) : q + n_adv;
+                sx = grel - q + (int32_t)KD_HCH_CSW * Wp;
+                k = nc;
+            }
+        }
+        if (xb > xa) {
+            if (ns == 0) { a0 = xa; b0 = xb; x0 = sx; }
+            else if (ns == 1) { a1 = xa; b1 = xb; x1 = sx; }
+            else { a2 = xa; b2 = xb; x2 = sx; }
+            ns++;
+        }
+        if (grel >= Wi) break;   // everything further right is outside the window
+    }
+    if (ns == 0) return true;
+    int32_t c = a0 >> 5, cb = (b0 - 1) >> 5;
+    KdChunk cur = src[c];
+    for (;;) {
+        // the step after this one: next chunk of the segment, or the first chunk of the next segment
+        const bool adv = c + 1 > cb;
+        const bool more = !adv || ns > 1;
+        const int32_t cn = adv ? (a1 >> 5) : c + 1;
+        KdChunk nxt = cur;
+        if (more) nxt = src[cn];
+        kd_add_chunk_masked(hist0, Wh, cur, 32 * c, a0, b0, x0);
+        if (!more) break;
+        if (adv) {
+            a0 = a1; b0 = b1; x0 = x1; a1 = a2; b1 = b2; x1 = x2;
+            ns--;
+            cb = (b0 - 1) >> 5;
+        }
+        c = cn;
+        cur = nxt;
+    }
+    return true;
+}
+
+// A PLAIN read: one M/=/X run covering the whole read, no clips (k_prep: KD_INFO_PLAIN).  Nothing to decode:
+// query base x lands on site grel + x, for x in [0, span).
+__device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi,
+                                              int32_t Wh, uint32_t *hist0) {
+    const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);
+    const int32_t len = (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
+    const int32_t xa = grel < 0 ? -grel : 0;
+    const int32_t xb = Wi - grel < len ? Wi - grel : len;
+    if (xb <= xa) return;
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
+    const int32_t ca = xa >> 5, cb = (xb - 1) >> 5;
+    // three chunks of prefetch: a 150-base read is 5 chunks, so its loads are (almost) all in flight at once
+    KdChunk cur = src[ca], n1 = cur, n2 = cur;
+    if (ca + 1 <= cb) n1 = src[ca + 1];
+    if (ca + 2 <= cb) n2 = src[ca + 2];
+    for (int32_t c = ca; c <= cb; c++) {
+        KdChunk n3 = n2;
+        if (c + 3 <= cb) n3 = src[c + 3];
+        const int32_t xs = 32 * c;
+        kd_add_dword(hist0, Wh, cur.x, xs, xa, xb, 0, len, grel);
+        kd_add_dword(hist0, Wh, cur.y, xs + 8, xa, xb, 0, len, grel);
+        kd_add_dword(hist0, Wh, cur.z, xs + 16, xa, xb, 0, len, grel);
+        kd_add_dword(hist0, Wh, cur.w, xs + 24, xa, xb, 0, len, grel);
+        cur = n1; n1 = n2; n2 = n3;
+    }
+}
+
+#define KD_TILE 1024   // reads classified together (a multiple of KD_BLOCK)
+#define KD_TILE_PER_THREAD (KD_TILE / KD_BLOCK)
+#define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)2 * KD_TILE * 2)   // Wh = dwords per channel row
+
+__global__ void __launch_bounds__(KD_BLOCK, 5)   // 5 wavefronts per SIMD = the 5 workgroups per CU the LDS footprint allows
+k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *ckpt, const uint32_t *seg_read, KdTabs T,
+         const kd_u64 *win_lo, const kd_u64 *win_hi, const kd_u64 *item_off, const uint32_t *item_win, kd_u64 items_cap, uint32_t w0,
+         uint32_t W, uint32_t Wh_, uint32_t slice, kd_u64 *status) {
+    // seg_read == NULL: `rinfo` describes the batch's reads (first pass, class REG = short regular reads).
+    // seg_read != NULL: `rinfo` describes SEGMENTS of long reads (k_prep_long; entry e = 256 * b + t is thread t's
+    // run of ops of the long read seg_read[b], entered through checkpoint ckpt[e]); `order` is then never NULL.
+    KD_DYN_SHARED(uint32_t, hist);
+    const int32_t Wh = (int32_t)Wh_;   // dwords per channel row (two u16 counters each, halos included; >= (W + 2*KD_HALO)/2)
+    uint32_t *hist0 = hist + KD_HALO / 2;                 // word of window-relative site 0
+    uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * Wh);  // tile-relative read indices
+    uint16_t *l_cplx = l_plain + KD_TILE;
+    __shared__ kd_u64 s_item;
+    __shared__ uint32_t s_cnt[2][2];   // [tile parity][plain, complex] list lengths
+    const uint32_t t = threadIdx.x;
+    const uint32_t lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
+    const kd_u64 total = status[KDS_TOTAL_ITEMS];
+    const uint32_t nh = (uint32_t)KD_HCH * (uint32_t)Wh;   // histogram dwords
+    const int32_t Wi = (int32_t)W;
+#ifdef KD_PHASE_CLOCKS
+    long long c_zero = 0, c_cls = 0, c_plain = 0, c_cplx = 0, c_wait = 0, c_flush = 0, c_deq = 0, c_mark;
+#define KD_MARK(acc) { const long long n_ = clock64(); acc += n_ - c_mark; c_mark = n_; }
+    c_mark = clock64();
+#else
+#define KD_MARK(acc)
+#endif
+    for (;;) {
+        if (t == 0) { s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL); s_cnt[0][0] = 0; s_cnt[0][1] = 0; }
+        __syncthreads();
+        const kd_u64 item = s_item;
+        if (item >= total || item >= items_cap) break;   // (>= items_cap: k_plan_items has raised KDS_INTERNAL)
+        KD_MARK(c_deq)
+        const uint32_t w = item_win[item];   // k_plan_items: the window with item_off[w] <= item < item_off[w + 1]
+        const kd_u64 wlo = (kd_u64)(w0 + w) * W, whi = wlo + W;
+        const kd_u64 first = win_lo[w] + (item - item_off[w]) * slice;
+        const kd_u64 last = first + slice < win_hi[w] ? first + slice : win_hi[w];
+        // The classification keys (start, span | flags, lead) of a tile are fetched ONE TILE AHEAD into registers:
+        // the loads of tile k + 1 are in flight while tile k is walked.  `order`: bucket-sorted permutation.
+        uint32_t p_gs[KD_TILE_PER_THREAD], p_sc[KD_TILE_PER_THREAD], p_ld[KD_TILE_PER_THREAD];
+#pragma unroll
+        for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
+            const kd_u64 j = first + u * KD_BLOCK + t;
+            p_sc[u] = KD_CLS_SKIP; p_gs[u] = 0; p_ld[u] = 0;
+            if (j < last) {
+                const KdRInfo ri = rinfo[order ? (kd_u64)order[j] : j];
+                p_gs[u] = ri.gstart; p_sc[u] = ri.span_cls; p_ld[u] = ri.lead;
+            }
+        }
+        {   // Wh is a multiple of 4 (W is a multiple of 64): zero with 16-byte stores
+            uint4 *h4 = reinterpret_cast<uint4 *>(hist);
+            for (uint32_t x = t; x < nh / 4; x += KD_BLOCK) h4[x] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        KD_MARK(c_zero)
+        uint32_t par = 0;
+        for (kd_u64 tb = first; tb < last; tb += KD_TILE, par ^= 1u) {
+            // classify the tile's reads: plain (single aligned run) / complex; drop those outside the window
+#pragma unroll
+            for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
+                const kd_u64 gs = p_gs[u], span = p_sc[u] >> KD_SPAN_SHIFT;
+                if ((p_sc[u] & 3u) == KD_CLS_REG && gs + span > wlo && gs - p_ld[u] < whi) {
+                    const uint32_t rel = u * KD_BLOCK + t;
+                    if (p_sc[u] & KD_INFO_PLAIN) l_plain[atomicAdd(&s_cnt[par][0], 1u)] = (uint16_t)rel;
+                    else l_cplx[atomicAdd(&s_cnt[par][1], 1u)] = (uint16_t)rel;
+                }
+            }
+            __syncthreads();
+            KD_MARK(c_cls)
+            const uint32_t np = s_cnt[par][0], ncx = s_cnt[par][1];
+            if (t == 0) { s_cnt[par ^ 1u][0] = 0; s_cnt[par ^ 1u][1] = 0; }   // next tile's counters (idle until its classify)
+#pragma unroll
+            for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
+                const kd_u64 j = tb + KD_TILE + u * KD_BLOCK + t;
+                p_sc[u] = KD_CLS_SKIP;
+                if (j < last) {
+                    const KdRInfo ri = rinfo[order ? (kd_u64)order[j] : j];
+                    p_gs[u] = ri.gstart; p_sc[u] = ri.span_cls; p_ld[u] = ri.lead;
+                }
+            }
+            // homogeneous wavefronts: first the plain reads, then the complex ones.  Lane l of a wavefront takes
+            // list entries l*rows + r: neighbours in a wavefront are `rows` reads apart in the sorted batch,
+            // which keeps them off the same LDS counters in the same instruction.
+            const uint32_t rows_p = (np + KD_WAVE - 1) / KD_WAVE, rows_c = (ncx + KD_WAVE - 1) / KD_WAVE;
+            for (uint32_t r = wave; r < rows_p; r += KD_WAVES_PER_BLOCK) {
+                const uint32_t e = lane * rows_p + r;
+                if (e < np) {
+                    const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
+                    kd_walk_plain(rd, i, rinfo[i], wlo, Wi, Wh, hist0);
+                }
+            }
+            KD_MARK(c_plain)
+            // the complex rows start at the wavefront after the one that took the last plain row
+            for (uint32_t r = (wave + KD_WAVES_PER_BLOCK - rows_p % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK; r < rows_c;
+                 r += KD_WAVES_PER_BLOCK) {
+                const uint32_t e = lane * rows_c + r;
+                if (e < ncx) {
+                    const kd_u64 j = tb + l_cplx[e], i = order ? (kd_u64)order[j] : j;
+                    const KdRInfo ri = rinfo[i];
+                    const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);
+                    const int32_t foot_end = grel + (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
+                    if (seg_read) {          // one segment of a long read
+                        const kd_u64 ir = seg_read[i / KD_BLOCK];
+                        const uint32_t nc = rd.n_cig[ir], per = (nc + KD_BLOCK - 1) / KD_BLOCK;
+                        const uint32_t k0 = (uint32_t)(i % KD_BLOCK) * per, k1 = k0 + per < nc ? k0 + per : nc;
+                        kd_walk_ops(rd, ir, k0, k1, grel, (int32_t)ckpt[i].q, (int32_t)ri.lead, foot_end, Wi, Wh, hist0);
+                    } else if (!kd_walk_short(rd, i, ri, wlo, Wi, Wh, hist0)) {   // more than three segments: general walk
+                        kd_walk_ops(rd, i, 0u, rd.n_cig[i], grel, 0, (int32_t)ri.lead, foot_end, Wi, Wh, hist0);
+                    }
+                }
+            }
+            KD_MARK(c_cplx)
+            __syncthreads();
+            KD_MARK(c_wait)
+        }
+        // flush: channel-major, consecutive lanes -> consecutive HBM dwords; zeros are skipped.
+        // LDS channel -> table channel (KD_CH_*): weights 0-4, deletions 5, csw 6-10, cew 11-15; 0xff = bad slot
+        bool bad = false;
+        uint32_t ch = 0, xw = t;   // word x = ch * Wh + xw, kept without a division
+        for (uint32_t x = t; x < nh; x += KD_BLOCK, xw += KD_BLOCK) {
+            while (xw >= (uint32_t)Wh) { xw -= (uint32_t)Wh; ch++; }
+            const uint32_t v = hist[x];
+            if (v) {
+                const uint32_t tch = ch < 5 ? ch : ch == KD_HCH_DEL ? (uint32_t)KDC_DEL
+                                   : (ch >= 7 && ch < 12) ? ch - 1 : (ch >= 13 && ch < 18) ? ch - 2 : 0xffu;
+                // the word holds window-relative sites s (low half) and s + 1 (high half); halo sites are dropped
+                const int32_t sw = 2 * (int32_t)xw - KD_HALO;
+                uint32_t *row = T.tab + (kd_u64)(tch == 0xffu ? 0u : tch) * T.stride;
+                const kd_u64 g0 = wlo + (kd_u64)sw;   // even: W, the halo and the G-space rows are all even / 8-byte aligned
+                if (tch != 0xffu && sw >= 0 && sw + 1 < Wi && g0 + 1 < T.stride && kd_commit(T, g0) && kd_commit(T, g0 + 1)) {
+                    // both sites of the word live: ONE 64-bit add on the two adjacent u32 counters (the low counter
+                    // cannot carry into the high one: a u32 table counter never wraps)
+                    atomicAdd(reinterpret_cast<kd_u64 *>(row + g0), (kd_u64)(v & 0xffffu) | ((kd_u64)(v >> 16) << 32));
+                    continue;
+                }
+                for (int hlf = 0; hlf < 2; hlf++) {
+                    const uint32_t cnt = hlf ? v >> 16 : v & 0xffffu;
+                    const int32_t sw2 = sw + hlf;
+                    if (!cnt || sw2 < 0 || sw2 >= Wi) continue;
+                    const kd_u64 g = wlo + (kd_u64)sw2;
+                    if (tch == 0xffu) bad = true;
+                    else if (g < T.stride && kd_commit(T, g)) atomicAdd(&row[g], cnt);
+                }
+            }
+        }
+        // a base outside A,C,G,T,N inside an aligned or clipped segment: k_find_bad_base pins down the read
+        if (bad) atomicAdd(&status[KDS_BAD_BASE], 1ULL);
+        KD_MARK(c_flush)
+        __syncthreads();
+        KD_MARK(c_wait)
+    }
+#ifdef KD_PHASE_CLOCKS
+    if ((t & 63u) == 0) {   // lane 0 of every wavefront
+        atomicAdd(&status[KDS_DBG0], (kd_u64)c_deq); atomicAdd(&status[KDS_DBG1], (kd_u64)c_zero);
+        atomicAdd(&status[KDS_DBG2], (kd_u64)c_cls); atomicAdd(&status[KDS_DBG3], (kd_u64)c_plain);
+        atomicAdd(&status[KDS_DBG4], (kd_u64)c_cplx); atomicAdd(&status[KDS_DBG5], (kd_u64)c_wait);
+        atomicAdd(&status[KDS_DBG6], (kd_u64)c_flush); atomicAdd(&status[KDS_DBG7], 1ULL);
+    }
+#endif
+}
+
+// Rare path: k_window saw a base outside A,C,G,T,N.  One workgroup walks the regular reads of the
+// batch and records the first offender (atomicMin of the read index), for k_diagnose to classify.
+__global__ void __launch_bounds__(KD_BLOCK)
+k_find_bad_base(KdReads rd, KdTabs T, const KdRInfo *rinfo, kd_u64 *status) {
+    if (status[KDS_BAD_BASE] == 0) return;
+    for (kd_u64 i = threadIdx.x; i < rd.n; i += KD_BLOCK) {
+        const uint32_t cls_i = rinfo[i].span_cls & 3u;
+        if (cls_i != KD_CLS_REG && cls_i != KD_CLS_LONG) continue;   // regular reads, short and long
+        if (rd.base_index + i >= status[KDS_ERR_READ]) continue;
+        const uint8_t *seq = rd.seq4 + rd.seq_off[i];
+        const uint32_t *cg = rd.cigar + rd.cig_off[i];
+        const uint32_t nc = rd.n_cig[i];
+        const int64_t L = T.contig_len[rd.contig[i]];
+        int64_t q = 0, r = rd.pos0[i];
+        bool found = false;
+        for (uint32_t k = 0; k < nc && !found; k++) {
+            const int64_t len = cg[k] >> 4;
+            const uint32_t op = cg[k] & 15u;
+            int64_t x0 = 0, x1 = 0;  // query bases the reference looks up in a weight dict
+            if (op == 0 || op == 7 || op == 8) { x0 = q; x1 = q + len; q += len; r += len; }
+            else if (op == 1) q += len;
+            else if (op == 2) r += len;
+            else if (op == 4) {
+                if (k == 0) { x0 = r < len ? len - r : 0; x1 = len; q += len; }
+                else { const int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0; x0 = q; x1 = q + n_adv; k = nc; }
+            }
+            for (int64_t x = x0; x < x1; x++)
+                if (kd_chan(kd_nib(seq, x)) == 7u) { found = true; break; }
+        }
+        if (found) kd_flag_error(status, rd.base_index + i);
+    }
+}
