@@ -161,4 +161,34 @@ __device__ __forceinline__ KdChunk kd_load_cigar4(const uint32_t *cg, uint32_t k
 }
 
 
+// Inclusive scan of two values per thread over the workgroup in THREE barriers: 16 threads scan 16-element segments
+// serially in LDS, then every thread adds the totals of the segments before its own.  (A Hillis-Steele scan is 8 steps
+// of two barriers each; the kernels that scan are latency chains already.)
+// sa / sb: [KD_BLOCK] scratch, ga / gb: [KD_BLOCK / 16] scratch; returns the inclusive prefixes and the block totals.
+#define KD_SCAN_SEG 16
+template <typename TA, typename TB>
+__device__ __forceinline__ void kd_block_scan2(TA *sa, TB *sb, TA *ga, TB *gb, TA va, TB vb, TA &incl_a, TB &incl_b, TA &tot_a,
+                                               TB &tot_b) {
+    const uint32_t t = threadIdx.x;
+    sa[t] = va; sb[t] = vb;
+    __syncthreads();
+    if (t < KD_BLOCK / KD_SCAN_SEG) {
+        TA a = 0; TB b = 0;
+        for (uint32_t k = 0; k < KD_SCAN_SEG; k++) {
+            a += sa[KD_SCAN_SEG * t + k]; sa[KD_SCAN_SEG * t + k] = a;
+            b += sb[KD_SCAN_SEG * t + k]; sb[KD_SCAN_SEG * t + k] = b;
+        }
+        ga[t] = a; gb[t] = b;
+    }
+    __syncthreads();
+    TA oa = 0, ta = 0; TB ob = 0, tb = 0;
+    for (uint32_t j = 0; j < KD_BLOCK / KD_SCAN_SEG; j++) {
+        const TA xa = ga[j]; const TB xb = gb[j];
+        if (j < t / KD_SCAN_SEG) { oa += xa; ob += xb; }
+        ta += xa; tb += xb;
+    }
+    incl_a = sa[t] + oa; incl_b = sb[t] + ob; tot_a = ta; tot_b = tb;
+    __syncthreads();   // the scratch arrays may be reused by the caller
+}
+
 __device__ __forceinline__ void kd_flag_error(kd_u64 *status, kd_u64 gidx) { atomicMin(&status[KDS_ERR_READ], gidx); }

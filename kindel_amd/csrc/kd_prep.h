@@ -229,8 +229,8 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
 __global__ void __launch_bounds__(KD_BLOCK)
 k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdCkpt *ckpt, KdRInfo *seginfo,
             uint32_t *irreg_list, uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
-    __shared__ int64_t s_r[KD_BLOCK], s_q[KD_BLOCK];
-    __shared__ uint32_t s_ni[KD_BLOCK], s_nb[KD_BLOCK];
+    __shared__ int64_t s_r[KD_BLOCK], s_q[KD_BLOCK], s_gr[KD_BLOCK / KD_SCAN_SEG], s_gq[KD_BLOCK / KD_SCAN_SEG];
+    __shared__ uint32_t s_ni[KD_BLOCK], s_nb[KD_BLOCK], s_gni[KD_BLOCK / KD_SCAN_SEG], s_gnb[KD_BLOCK / KD_SCAN_SEG];
     __shared__ kd_u64 s_acc[6];       // aligned, walked, n_ins, ins_bases, bad, cold
     __shared__ uint32_t s_first_nfs, s_last_rel;
     __shared__ uint32_t s_regular, s_lead, s_gstart, s_nfs_adv, s_maxseg;
@@ -258,18 +258,10 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdC
         // a non-first S contributes nothing here: anything after it makes the read irregular,
         // and if nothing follows its own advance is irrelevant to the span
     }
-    s_r[t] = dr; s_q[t] = dq;
-    __syncthreads();
-    // inclusive Hillis-Steele scan over the 256 partial sums
-    for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
-        int64_t ar = 0, aq = 0;
-        if (t >= d) { ar = s_r[t - d]; aq = s_q[t - d]; }
-        __syncthreads();
-        s_r[t] += ar; s_q[t] += aq;
-        __syncthreads();
-    }
-    int64_t r = pos0 + (t ? s_r[t - 1] : 0), q = t ? s_q[t - 1] : 0;
-    const int64_t r_end = pos0 + s_r[KD_BLOCK - 1];
+    int64_t incl_r, incl_q, tot_r, tot_q;   // prefix sums of the 256 partial advances
+    kd_block_scan2(s_r, s_q, s_gr, s_gq, dr, dq, incl_r, incl_q, tot_r, tot_q);
+    int64_t r = pos0 + incl_r - dr, q = incl_q - dq;
+    const int64_t r_end = pos0 + tot_r;
     const int64_t r_run = r, q_run = q;   // checkpoint: state before this thread's run of ops
     kd_u64 aligned = 0, walked = 0, n_ins = 0, insb = 0, bad = 0, cold = 0;
     uint32_t first_nfs = 0xffffffffu, last_rel = 0;
@@ -309,19 +301,12 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdC
     if (first_nfs != 0xffffffffu) atomicMin(&s_first_nfs, first_nfs);
     if (last_rel) atomicMax(&s_last_rel, last_rel);
     // exclusive prefix of the per-run insertion counts -> event / pool offsets inside the read
-    s_ni[t] = (uint32_t)n_ins; s_nb[t] = (uint32_t)insb;
-    __syncthreads();
-    for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
-        uint32_t a = 0, b = 0;
-        if (t >= d) { a = s_ni[t - d]; b = s_nb[t - d]; }
-        __syncthreads();
-        s_ni[t] += a; s_nb[t] += b;
-        __syncthreads();
-    }
+    uint32_t incl_ni, incl_nb, tot_ni, tot_nb;
+    kd_block_scan2(s_ni, s_nb, s_gni, s_gnb, (uint32_t)n_ins, (uint32_t)insb, incl_ni, incl_nb, tot_ni, tot_nb);
     {
         KdCkpt ck;
         ck.r_rel = (uint32_t)(r_run - pos0); ck.q = (uint32_t)q_run;
-        ck.ev = s_ni[t] - (uint32_t)n_ins; ck.pool = s_nb[t] - (uint32_t)insb;
+        ck.ev = incl_ni - (uint32_t)n_ins; ck.pool = incl_nb - (uint32_t)insb;
         ckpt[(kd_u64)blockIdx.x * KD_BLOCK + t] = ck;
     }
     if (t == 0) {

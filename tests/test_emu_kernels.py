@@ -41,6 +41,8 @@ def test_quirk_case(emu_lib, name, mode):
 ])
 @pytest.mark.parametrize("mode", MODES)
 def test_fixture_subset(emu_lib, key, n0, n1, window, slice_reads, mode):
+    if mode == N.KD_MODE_GLOBAL and "hxb2" in key:
+        n1 = 60   # wavefront-per-read over kilobase reads is slow under the emulator; the GPU suite runs all of them
     batch = P.subset(P.load_fixture(key), n0, n1)
     run = P.Run(emu_lib, batch, mode=mode, window=window, slice_reads=slice_reads)
     P.assert_matches_oracle(run, what=key)
