@@ -29,7 +29,7 @@ def first_json_line(path):
     raise SystemExit("no bench line in " + path)
 
 
-st = glob.glob(os.path.join(O, "prof_c3", "**", "*kernel_stats.csv"), recursive=True)
+st = sorted(glob.glob(os.path.join(O, "prof_c3", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)   # newest run first
 if st:
     shutil.copy(st[0], os.path.join(P, "%s_c3_kernel_stats.csv" % tag))
     rows = list(csv.reader(open(st[0])))   # the same table without the synthetic-input generator's torch kernels
@@ -46,7 +46,8 @@ for src, dst in (("bench_c3.json", "%s_c3_bench.json"), ("prof_c3_bench.json", "
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 ndisp = collections.defaultdict(set)
 for i in (1, 2, 3, 4):
-    for f in glob.glob(os.path.join(O, "pmc_%d" % i, "**", "*counter_collection.csv"), recursive=True):
+    for f in sorted(glob.glob(os.path.join(O, "pmc_%d" % i, "**", "*counter_collection.csv"), recursive=True),
+                    key=os.path.getmtime, reverse=True)[:1]:   # the newest run only (gpurun merges, it does not delete)
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
             k = k.split("<")[0] if k.startswith("void ") is False else k
