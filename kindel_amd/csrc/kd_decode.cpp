@@ -195,55 +195,127 @@ int parse_bam(const Arr<uint8_t> &d, File &f, int n_threads) {
         f.lens.push_back(rd32(d.data() + o + 4 + l_name));
         o += 8 + l_name;
     }
-    // pass 1 (sequential, touches 4 + 20 bytes per record): follow the block_size chain, record where every kept
-    // record starts and the running totals of packed-base bytes / CIGAR words
-    std::vector<uint64_t> rec_at, seq_at, cig_at;
-    size_t seq_bytes = 0, cig_words = 0, p = o;
-    while (p + 4 <= n) {
-        const uint32_t bs = rd32(d.data() + p);
-        if (p + 4 + bs > n || bs < 32) { g_decode_error = "truncated BAM record"; return KD_E_IO; }
-        const uint8_t *r = d.data() + p + 4;
-        const int32_t refid = (int32_t)rd32(r);
-        f.n_records++;
-        if (refid >= 0) {
-            if ((uint32_t)refid >= n_ref) { g_decode_error = "BAM record with refID out of range"; return KD_E_IO; }
-            const uint32_t l_rn = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
-            if (32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 > bs) { g_decode_error = "malformed BAM record"; return KD_E_IO; }
-            rec_at.push_back(p + 4); seq_at.push_back(seq_bytes); cig_at.push_back(cig_words);
-            seq_bytes += ((size_t)l_seq + 1) / 2;
-            cig_words += n_cig;
+    // pass 1 (touches 4 + 20 bytes per record): follow the block_size chain, record where every kept record starts and
+    // the running totals of packed-base bytes / CIGAR words.  The chain is sequential by nature (a record's length
+    // says where the next one begins), and at ~75 ns per record it was most of the decode time, so it is walked IN
+    // PARALLEL over ranges of the stream: the worker of range t looks for its first record speculatively -- the first
+    // offset from which KD_SPEC_CHAIN consecutive records look well-formed -- and walks from there; afterwards the
+    // hand-offs are verified (the walk of range t-1 must END exactly on the start range t guessed), and any range whose
+    // guess was wrong is re-walked from the true position.  The result is identical to the sequential walk.
+    struct Rec { uint64_t at; uint32_t sb, nc; };   // record body offset, packed-base bytes, CIGAR words
+    auto plausible = [&](size_t q) -> size_t {      // 0, or the offset of the record after the one at q
+        if (q + 36 > n) return 0;
+        const uint32_t bs = rd32(d.data() + q);
+        if (bs < 32 || q + 4 + (size_t)bs > n) return 0;
+        const uint8_t *r = d.data() + q + 4;
+        const int32_t refid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
+        const uint32_t l_rn = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
+        if (refid < -1 || (refid >= 0 && (uint32_t)refid >= n_ref) || pos < -1 || l_rn == 0) return 0;
+        if (32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > bs) return 0;
+        if (r[32 + l_rn - 1] != 0) return 0;        // read name is NUL-terminated
+        return q + 4 + bs;
+    };
+    auto walk = [&](size_t p0, size_t p_end, std::vector<Rec> &out, uint64_t &n_rec, size_t &stop, std::string &err) -> bool {
+        size_t q = p0;
+        while (q < p_end && q + 4 <= n) {
+            const uint32_t bs = rd32(d.data() + q);
+            if (q + 4 + (size_t)bs > n || bs < 32) { err = "truncated BAM record"; return false; }
+            const uint8_t *r = d.data() + q + 4;
+            const int32_t refid = (int32_t)rd32(r);
+            n_rec++;
+            if (refid >= 0) {
+                if ((uint32_t)refid >= n_ref) { err = "BAM record with refID out of range"; return false; }
+                const uint32_t l_rn = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
+                if (32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 > bs) { err = "malformed BAM record"; return false; }
+                out.push_back({q + 4, (uint32_t)(((size_t)l_seq + 1) / 2), n_cig});
+            }
+            q += 4 + bs;
         }
-        p += 4 + bs;
+        stop = q;
+        return true;
+    };
+    unsigned nt1 = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+    size_t min_range = 4u << 20;                                      // >= 4 MB of records per range ...
+    if (const char *e = getenv("KD_DECODE_RANGE_BYTES")) min_range = std::max<size_t>(64, strtoull(e, nullptr, 10));   // ... tests: small
+    nt1 = (unsigned)std::max<size_t>(1, std::min<size_t>(nt1, (n - o) / min_range));
+    constexpr int KD_SPEC_CHAIN = 16;
+    std::vector<std::vector<Rec>> part(nt1);
+    std::vector<uint64_t> part_nrec(nt1, 0);
+    std::vector<size_t> guess(nt1, 0), stop(nt1, 0);
+    std::vector<std::string> perr(nt1);
+    std::vector<char> pok(nt1, 1);
+    const size_t span = (n - o + nt1 - 1) / nt1;
+    auto range_end = [&](unsigned t) { return t + 1 == nt1 ? n : std::min(n, o + (size_t)(t + 1) * span); };
+    auto work1 = [&](unsigned t) {
+        size_t q = o + (size_t)t * span;
+        if (t > 0) {   // speculative start: first offset in the range that begins a chain of well-formed records
+            const size_t lim = range_end(t);
+            size_t found = 0;
+            for (; q < lim && !found; q++) {
+                size_t z = q;
+                int ok = 0;
+                while (ok < KD_SPEC_CHAIN) { const size_t nx = plausible(z); if (!nx) break; ok++; z = nx; if (z + 4 > n) break; }
+                if (ok == KD_SPEC_CHAIN || (ok > 0 && z + 4 > n)) found = q;
+            }
+            if (!found) { guess[t] = lim; stop[t] = lim; return; }   // no record starts in this range (one huge record)
+            q = found;
+        }
+        guess[t] = q;
+        pok[t] = walk(q, range_end(t), part[t], part_nrec[t], stop[t], perr[t]) ? 1 : 0;
+    };
+    {
+        std::vector<std::thread> th1;
+        for (unsigned t = 1; t < nt1; t++) th1.emplace_back(work1, t);
+        work1(0);
+        for (auto &x : th1) x.join();
     }
-    const size_t n_keep = rec_at.size();
+    // verify the hand-offs left to right; re-walk what a wrong guess (or an error seen from a wrong start) spoiled
+    size_t p = o;
+    for (unsigned t = 0; t < nt1; t++) {
+        if (guess[t] != p || (t > 0 && !pok[t])) {
+            part[t].clear(); part_nrec[t] = 0; perr[t].clear();
+            pok[t] = p >= range_end(t) ? 1 : (walk(p, range_end(t), part[t], part_nrec[t], stop[t], perr[t]) ? 1 : 0);
+            if (p >= range_end(t)) stop[t] = p;
+        }
+        if (!pok[t]) { g_decode_error = perr[t]; return KD_E_IO; }
+        p = stop[t];
+    }
+    // prefix over the ranges: first record index / packed-base byte / CIGAR word of each
+    std::vector<size_t> k_at(nt1 + 1, 0), sq_at(nt1 + 1, 0), cg_at(nt1 + 1, 0);
+    for (unsigned t = 0; t < nt1; t++) {
+        size_t sb = 0, nc = 0;
+        for (const Rec &rc : part[t]) { sb += rc.sb; nc += rc.nc; }
+        k_at[t + 1] = k_at[t] + part[t].size(); sq_at[t + 1] = sq_at[t] + sb; cg_at[t + 1] = cg_at[t] + nc;
+        f.n_records += part_nrec[t];
+    }
+    const size_t n_keep = k_at[nt1];
     f.contig.resize(n_keep); f.pos0.resize(n_keep); f.flag.resize(n_keep); f.seq_off.resize(n_keep);
     f.seq_len.resize(n_keep); f.cig_off.resize(n_keep); f.n_cig.resize(n_keep);
-    f.seq4.resize(seq_bytes); f.cigar.resize(cig_words);
-    // pass 2 (parallel): every record writes its own slots of the SoA arrays
-    auto fill = [&](size_t k0, size_t k1) {
-        for (size_t k = k0; k < k1; k++) {
-            const uint8_t *r = d.data() + rec_at[k];
+    f.seq4.resize(sq_at[nt1]); f.cigar.resize(cg_at[nt1]);
+    // pass 2 (parallel, one worker per range): every record writes its own slots of the SoA arrays
+    auto fill = [&](unsigned t) {
+        size_t k = k_at[t], so = sq_at[t], co = cg_at[t];
+        for (const Rec &rc : part[t]) {
+            const uint8_t *r = d.data() + rc.at;
             const uint32_t l_rn = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
             f.contig[k] = rd32(r);
             f.pos0[k] = (int32_t)rd32(r + 4);
             f.flag[k] = rd16(r + 14);
             f.seq_len[k] = l_seq;
             f.n_cig[k] = n_cig;
-            f.cig_off[k] = cig_at[k];
-            f.seq_off[k] = seq_at[k];
+            f.cig_off[k] = co;
+            f.seq_off[k] = so;
             const uint8_t *cg = r + 32 + l_rn;
-            for (uint32_t c = 0; c < n_cig; c++) f.cigar[cig_at[k] + c] = rd32(cg + 4 * c);
+            for (uint32_t c = 0; c < n_cig; c++) f.cigar[co + c] = rd32(cg + 4 * c);
             const size_t sb = ((size_t)l_seq + 1) / 2;
-            memcpy(f.seq4.data() + seq_at[k], cg + 4 * (size_t)n_cig, sb);
-            if (l_seq & 1) f.seq4[seq_at[k] + sb - 1] &= 0xf0;
+            memcpy(f.seq4.data() + so, cg + 4 * (size_t)n_cig, sb);
+            if (l_seq & 1) f.seq4[so + sb - 1] &= 0xf0;
+            k++; so += sb; co += n_cig;
         }
     };
-    unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
-    nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, n_keep / 4096));
     std::vector<std::thread> th;
-    const size_t per = (n_keep + nt - 1) / std::max(1u, nt);
-    for (unsigned t = 1; t < nt; t++) th.emplace_back(fill, std::min(n_keep, t * per), std::min(n_keep, (t + 1) * per));
-    fill(0, std::min(n_keep, per));
+    for (unsigned t = 1; t < nt1; t++) th.emplace_back(fill, t);
+    fill(0);
     for (auto &t : th) t.join();
     return KD_OK;
 }

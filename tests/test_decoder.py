@@ -49,6 +49,22 @@ def test_bam_long_reads_roundtrip(tmp_path):
     same_batch(N.decode_file(p), batch)
 
 
+@pytest.mark.parametrize("range_bytes", ["64", "700", "5000"])
+def test_bam_parallel_record_scan(tmp_path, monkeypatch, range_bytes):
+    """Pass 1 of the BAM parser walks the block_size chain in parallel ranges with speculative starts; forcing tiny
+    ranges (smaller than a record / a few records) exercises the speculation, the empty ranges and the hand-off check.
+    A truncated file must report the same error as the sequential walk."""
+    batch = synth.to_numpy(synth.short_reads([3000, 1500], 40, seed=11))
+    lr = synth.to_numpy(synth.long_reads([40000], 5, seed=9))
+    p, q = tmp_path / "x.bam", tmp_path / "l.bam"
+    synth.write_bam(str(p), batch)
+    synth.write_bam(str(q), lr)
+    monkeypatch.setenv("KD_DECODE_RANGE_BYTES", range_bytes)
+    for threads in (0, 3):
+        same_batch(N.decode_file(p, threads=threads), batch)
+        same_batch(N.decode_file(q, threads=threads), lr)
+
+
 def test_unreadable_file(tmp_path):
     with pytest.raises(OSError):
         N.decode_file(tmp_path / "missing.bam")
