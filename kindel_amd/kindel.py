@@ -469,7 +469,7 @@ def consensus_seqrecord(consensus, ref_id):
 def _report(ref_id, depth_minmax, ch, cdr_patches, bam_path, realign, min_depth, min_overlap, clip_decay_threshold,
             trim_ends, uppercase):
     def sites(code):
-        return ", ".join(str(p + 1) for p in np.flatnonzero(ch == ord(code)).tolist())
+        return ", ".join(map(str, (np.flatnonzero(ch == ord(code)) + 1).tolist()))
 
     cdr_patches_fmt = ["{}-{}: {}".format(r.start, r.end, r.seq) for r in cdr_patches] if cdr_patches else ""
     report = "========================= REPORT ===========================\n"
