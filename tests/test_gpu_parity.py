@@ -244,3 +244,25 @@ def test_multi_tile_items_carry_rows_between_tiles(hip_lib):
     batch = synth.to_numpy(synth.short_reads([2000, 900], 3000, seed=9, planted=False))   # ~58000 reads, 3 windows of 1024
     for window, slice_reads in ((1024, 32768), (640, 4096), (256, 3000)):
         P.assert_matches_oracle(P.Run(hip_lib, batch, window=window, slice_reads=slice_reads), what="w%d s%d" % (window, slice_reads))
+
+
+def test_profile_modes(hip_lib):
+    """kd_profile_enable: 1 = hipEvents around every launch, 2 = only around k_window (what bench.py times with)."""
+    from kindel_amd import synth
+    batch = synth.to_numpy(synth.short_reads([20000], 30, seed=4))
+    eng = N.Engine(batch["contig_lens"], lib=hip_lib)
+    try:
+        for mode, check in ((1, lambda rows: {"k_prep", "k_window", "k_cns_emit"} <= set(rows)),
+                            (2, lambda rows: set(rows) == {"k_window"}),
+                            (0, lambda rows: not rows)):
+            eng.reset()
+            eng.profile_enable(mode)
+            eng.profile_reset()
+            eng.push(batch)
+            eng.finalize()
+            eng.consensus_run(1)
+            rows = eng.profile()
+            assert check(rows), (mode, sorted(rows))
+            assert all(n >= 1 and ms > 0 for n, ms in rows.values())
+    finally:
+        eng.close()
