@@ -133,3 +133,26 @@ def test_multi_tile_items_carry_rows_between_tiles(emu_lib):
     P.assert_matches_oracle(run)
     run = P.Run(emu_lib, batch, window=256, slice_reads=2500)
     P.assert_matches_oracle(run)
+
+
+def test_virtual_shards_with_long_reads(emu_lib):
+    """Interval shards + the long-read segment pass: every shard's tables equal the unsharded ones inside its interval."""
+    batch = synth.to_numpy(synth.long_reads([24000], 5, seed=12, median_len=2500, min_len=800, max_len=5000))
+    full = P.Run(emu_lib, batch, window=512)
+    assert full.info["long_cigar"] > 0
+    P.assert_matches_oracle(full)
+    world = 3
+    ivs = shard.partition(batch["contig_lens"], world)
+    base, S = shard.g_layout(batch["contig_lens"])
+    pieces = []
+    for r in range(world):
+        keep = shard.reads_of_rank(batch["contig_lens"], batch["contig"], batch["pos0"], batch["pos0"] + 8000, r, world)
+        sub = dict(batch)
+        for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+            sub[k] = batch[k][keep]
+        run = P.Run(emu_lib, sub, window=512, shard=ivs[r])
+        lo = max(int(base[0]), ivs[r][0]) - int(base[0])
+        hi = min(int(base[0]) + int(batch["contig_lens"][0]), ivs[r][1]) - int(base[0])
+        assert np.array_equal(run.tables[0][:, lo:hi], full.tables[0][:, lo:hi]), r
+        pieces.append(run.cns[0][0])
+    assert b"".join(pieces) == full.cns[0][0]
