@@ -266,3 +266,26 @@ def test_profile_modes(hip_lib):
             assert all(n >= 1 and ms > 0 for n, ms in rows.values())
     finally:
         eng.close()
+
+
+def test_virtual_shards_with_long_reads(hip_lib):
+    """Interval shards + the long-read segment pass (second k_window launch) on the GPU."""
+    batch = synth.to_numpy(synth.long_reads([120_000], 12, seed=12, median_len=6000, min_len=1500, max_len=15000))
+    full = P.Run(hip_lib, batch)
+    assert full.info["long_cigar"] > 0
+    P.assert_matches_oracle(full)
+    world = 4
+    ivs = shard.partition(batch["contig_lens"], world)
+    base, S = shard.g_layout(batch["contig_lens"])
+    pieces = []
+    for r in range(world):
+        keep = shard.reads_of_rank(batch["contig_lens"], batch["contig"], batch["pos0"], batch["pos0"] + 40000, r, world)
+        sub = dict(batch)
+        for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+            sub[k] = batch[k][keep]
+        run = P.Run(hip_lib, sub, shard=ivs[r])
+        lo = max(int(base[0]), ivs[r][0]) - int(base[0])
+        hi = min(int(base[0]) + int(batch["contig_lens"][0]), ivs[r][1]) - int(base[0])
+        assert np.array_equal(run.tables[0][:, lo:hi], full.tables[0][:, lo:hi]), r
+        pieces.append(run.cns[0][0])
+    assert b"".join(pieces) == full.cns[0][0]
