@@ -4,8 +4,10 @@
 // (/root/reference/kindel/kindel.py:136-148): header @SQ -> {name: LN}, record iteration,
 // dropping RNAME '*'.  No arithmetic of the hot path lives here and no GPU is touched.
 // Formats: SAMv1 spec sections 1.3-1.4 (text), 4.1 (BGZF), 4.2 (BAM records).
-// BGZF blocks are independent deflate streams, so they are inflated by a thread pool into
-// their final positions (ISIZE prefix sum) before the records are walked.
+// Everything is parallel over the host cores: BGZF blocks are independent deflate streams and are inflated into their
+// final positions (ISIZE prefix sum); the BAM record chain is walked in ranges from speculative, verified starts; SAM
+// text is parsed in line-aligned ranges; the SoA arrays are filled / merged range by range.
+// (KD_DECODE_RANGE_BYTES shrinks the ranges so that the tests can exercise the range logic on small files.)
 #include <zlib.h>
 
 #include <atomic>
@@ -320,7 +322,17 @@ int parse_bam(const Arr<uint8_t> &d, File &f, int n_threads) {
     return KD_OK;
 }
 
-int parse_sam(const Arr<uint8_t> &raw, File &f) {
+// Records of one range of a SAM file (parallel parse), or of the whole file.
+struct SamPart {
+    Arr<uint32_t> contig, flag, seq_len, n_cig, cigar;
+    Arr<int32_t> pos0;
+    Arr<uint64_t> seq_off, cig_off;   // relative to the part
+    Arr<uint8_t> seq4;
+    uint64_t n_records = 0;
+    std::string err;
+};
+
+int parse_sam(const Arr<uint8_t> &raw, File &f, int n_threads) {
     static int8_t nibtab[256];
     static int8_t optab[256];
     static bool init = false;
@@ -337,80 +349,150 @@ int parse_sam(const Arr<uint8_t> &raw, File &f) {
         init = true;
     }
     std::unordered_map<std::string, uint32_t> ids;
-    const char *p = (const char *)raw.data(), *end = p + raw.size();
-    while (p < end) {
-        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-        const char *le = nl ? nl : end;
-        const char *e = le;
-        if (e > p && e[-1] == '\r') e--;
-        if (e > p) {
-            if (*p == '@') {
-                if (e - p >= 3 && p[1] == 'S' && p[2] == 'Q') {
-                    std::string name;
-                    long ln = -1;
-                    const char *q = p;
-                    while (q < e) {
-                        const char *t = (const char *)memchr(q, '\t', (size_t)(e - q));
-                        const char *fe = t ? t : e;
-                        if (fe - q > 3 && q[0] == 'S' && q[1] == 'N' && q[2] == ':') name.assign(q + 3, fe);
-                        if (fe - q > 3 && q[0] == 'L' && q[1] == 'N' && q[2] == ':') ln = strtol(std::string(q + 3, fe).c_str(), nullptr, 10);
-                        q = t ? t + 1 : e;
-                    }
-                    if (name.empty() || ln < 0) { g_decode_error = "@SQ line without SN/LN"; return KD_E_IO; }
-                    ids[name] = (uint32_t)f.names.size();
-                    f.names.push_back(name);
-                    f.lens.push_back((uint32_t)ln);
-                }
-            } else {
-                const char *fld[11];
-                int nf = 0;
-                const char *q = p;
-                while (nf < 11 && q <= e) {
-                    fld[nf++] = q;
-                    const char *t = (const char *)memchr(q, '\t', (size_t)(e - q));
-                    if (!t) break;
-                    q = t + 1;
-                }
-                if (nf < 10) { g_decode_error = "SAM record with fewer than 10 fields"; return KD_E_IO; }
-                auto flen = [&](int i) { return (size_t)((i + 1 < nf ? fld[i + 1] - 1 : e) - fld[i]); };
-                f.n_records++;
-                std::string rname(fld[2], flen(2));
-                if (rname != "*") {
-                    auto it = ids.find(rname);
-                    if (it == ids.end()) { g_decode_error = "RNAME '" + rname + "' has no @SQ line"; return KD_E_IO; }
-                    f.contig.push_back(it->second);
-                    f.flag.push_back((uint32_t)strtoul(std::string(fld[1], flen(1)).c_str(), nullptr, 10));
-                    f.pos0.push_back((int32_t)(strtol(std::string(fld[3], flen(3)).c_str(), nullptr, 10) - 1));
-                    f.cig_off.push_back(f.cigar.size());
-                    uint32_t nc = 0;
-                    const char *c = fld[5], *ce = c + flen(5);
-                    if (!(ce - c == 1 && *c == '*')) {
-                        uint64_t num = 0;
-                        for (; c < ce; c++) {
-                            if (*c >= '0' && *c <= '9') num = num * 10 + (uint64_t)(*c - '0');
-                            else {
-                                if (num >= (1ULL << 28)) { g_decode_error = "CIGAR length too large"; return KD_E_IO; }
-                                f.cigar.push_back((uint32_t)(num << 4) | (uint32_t)(uint8_t)optab[(uint8_t)*c]);
-                                num = 0; nc++;
-                            }
-                        }
-                    }
-                    f.n_cig.push_back(nc);
-                    const char *s = fld[9];
-                    size_t sl = flen(9);
-                    if (sl == 1 && *s == '*') sl = 0;
-                    f.seq_off.push_back(f.seq4.size());
-                    f.seq_len.push_back((uint32_t)sl);
-                    for (size_t i = 0; i < sl; i += 2) {
-                        const uint8_t hi = (uint8_t)nibtab[(uint8_t)s[i]];
-                        const uint8_t lo = i + 1 < sl ? (uint8_t)nibtab[(uint8_t)s[i + 1]] : 0;
-                        f.seq4.push_back((uint8_t)(hi << 4 | lo));
-                    }
+    const char *base = (const char *)raw.data(), *end = base + raw.size();
+    auto header_line = [&](const char *p, const char *e) -> bool {   // '@' line: only @SQ matters (kindel.py:138-141)
+        if (e - p >= 3 && p[1] == 'S' && p[2] == 'Q') {
+            std::string name;
+            long ln = -1;
+            const char *q = p;
+            while (q < e) {
+                const char *t = (const char *)memchr(q, '\t', (size_t)(e - q));
+                const char *fe = t ? t : e;
+                if (fe - q > 3 && q[0] == 'S' && q[1] == 'N' && q[2] == ':') name.assign(q + 3, fe);
+                if (fe - q > 3 && q[0] == 'L' && q[1] == 'N' && q[2] == ':') ln = strtol(std::string(q + 3, fe).c_str(), nullptr, 10);
+                q = t ? t + 1 : e;
+            }
+            if (name.empty() || ln < 0) { g_decode_error = "@SQ line without SN/LN"; return false; }
+            ids[name] = (uint32_t)f.names.size();
+            f.names.push_back(name);
+            f.lens.push_back((uint32_t)ln);
+        }
+        return true;
+    };
+    // alignment line [p, e) -> one record of `o` (or dropped: RNAME '*', kindel.py:147-148); false = error in o.err
+    auto record_line = [&](const char *p, const char *e, SamPart &o) -> bool {
+        const char *fld[11];
+        int nf = 0;
+        const char *q = p;
+        while (nf < 11 && q <= e) {
+            fld[nf++] = q;
+            const char *t = (const char *)memchr(q, '\t', (size_t)(e - q));
+            if (!t) break;
+            q = t + 1;
+        }
+        if (nf < 10) { o.err = "SAM record with fewer than 10 fields"; return false; }
+        auto flen = [&](int i) { return (size_t)((i + 1 < nf ? fld[i + 1] - 1 : e) - fld[i]); };
+        o.n_records++;
+        std::string rname(fld[2], flen(2));
+        if (rname == "*") return true;
+        auto it = ids.find(rname);
+        if (it == ids.end()) { o.err = "RNAME '" + rname + "' has no @SQ line"; return false; }
+        o.contig.push_back(it->second);
+        o.flag.push_back((uint32_t)strtoul(std::string(fld[1], flen(1)).c_str(), nullptr, 10));
+        o.pos0.push_back((int32_t)(strtol(std::string(fld[3], flen(3)).c_str(), nullptr, 10) - 1));
+        o.cig_off.push_back(o.cigar.size());
+        uint32_t nc = 0;
+        const char *c = fld[5], *ce = c + flen(5);
+        if (!(ce - c == 1 && *c == '*')) {
+            uint64_t num = 0;
+            for (; c < ce; c++) {
+                if (*c >= '0' && *c <= '9') num = num * 10 + (uint64_t)(*c - '0');
+                else {
+                    if (num >= (1ULL << 28)) { o.err = "CIGAR length too large"; return false; }
+                    o.cigar.push_back((uint32_t)(num << 4) | (uint32_t)(uint8_t)optab[(uint8_t)*c]);
+                    num = 0; nc++;
                 }
             }
         }
-        if (!nl) break;
-        p = nl + 1;
+        o.n_cig.push_back(nc);
+        const char *sq = fld[9];
+        size_t sl = flen(9);
+        if (sl == 1 && *sq == '*') sl = 0;
+        o.seq_off.push_back(o.seq4.size());
+        o.seq_len.push_back((uint32_t)sl);
+        for (size_t i = 0; i < sl; i += 2) {
+            const uint8_t hi = (uint8_t)nibtab[(uint8_t)sq[i]];
+            const uint8_t lo = i + 1 < sl ? (uint8_t)nibtab[(uint8_t)sq[i + 1]] : 0;
+            o.seq4.push_back((uint8_t)(hi << 4 | lo));
+        }
+        return true;
+    };
+    // the lines of [p, pe): header lines are only legal while `headers_ok` (the leading block)
+    auto lines = [&](const char *p, const char *pe, bool headers_ok, SamPart &o, const char **first_record) -> bool {
+        while (p < pe) {
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(pe - p));
+            const char *le = nl ? nl : pe;
+            const char *e = le;
+            if (e > p && e[-1] == '\r') e--;
+            if (e > p) {
+                if (*p == '@') {
+                    if (!headers_ok) { o.err = "header line after the first alignment line"; return false; }
+                    if (!header_line(p, e)) { o.err = g_decode_error; return false; }
+                } else {
+                    if (first_record) { *first_record = p; return true; }   // header scan stops at the first record
+                    if (!record_line(p, e, o)) return false;
+                }
+            }
+            if (!nl) break;
+            p = nl + 1;
+        }
+        if (first_record) *first_record = pe;
+        return true;
+    };
+    // 1. the leading header block (sequential), 2. the alignment lines in parallel line-aligned ranges, 3. merge
+    SamPart hdr;
+    const char *rec0 = end;
+    if (!lines(base, end, true, hdr, &rec0)) { g_decode_error = hdr.err; return KD_E_IO; }
+    size_t min_range = 4u << 20;
+    if (const char *ev = getenv("KD_DECODE_RANGE_BYTES")) min_range = std::max<size_t>(64, strtoull(ev, nullptr, 10));
+    unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+    nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, (size_t)(end - rec0) / min_range));
+    std::vector<const char *> cut(nt + 1, end);
+    cut[0] = rec0;
+    for (unsigned t = 1; t < nt; t++) {   // range starts on the line after the proportional split point
+        const char *q = rec0 + (size_t)(end - rec0) / nt * t;
+        if (q < cut[t - 1]) q = cut[t - 1];
+        const char *nl = q < end ? (const char *)memchr(q, '\n', (size_t)(end - q)) : nullptr;
+        cut[t] = nl ? nl + 1 : end;
+    }
+    std::vector<SamPart> part(nt);
+    std::vector<char> ok(nt, 1);
+    {
+        std::vector<std::thread> th;
+        auto work = [&](unsigned t) { ok[t] = lines(cut[t], cut[t + 1], false, part[t], nullptr) ? 1 : 0; };
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    for (unsigned t = 0; t < nt; t++)
+        if (!ok[t]) { g_decode_error = part[t].err; return KD_E_IO; }   // the first failing range = the first failing line
+    std::vector<size_t> k_at(nt + 1, 0), sq_at(nt + 1, 0), cg_at(nt + 1, 0);
+    for (unsigned t = 0; t < nt; t++) {
+        k_at[t + 1] = k_at[t] + part[t].contig.size(); sq_at[t + 1] = sq_at[t] + part[t].seq4.size();
+        cg_at[t + 1] = cg_at[t] + part[t].cigar.size();
+        f.n_records += part[t].n_records;
+    }
+    const size_t n_keep = k_at[nt];
+    f.contig.resize(n_keep); f.pos0.resize(n_keep); f.flag.resize(n_keep); f.seq_off.resize(n_keep);
+    f.seq_len.resize(n_keep); f.cig_off.resize(n_keep); f.n_cig.resize(n_keep);
+    f.seq4.resize(sq_at[nt]); f.cigar.resize(cg_at[nt]);
+    {
+        auto merge = [&](unsigned t) {
+            const SamPart &o = part[t];
+            const size_t k0 = k_at[t], m = o.contig.size();
+            if (m) {
+                memcpy(f.contig.data() + k0, o.contig.data(), m * 4); memcpy(f.flag.data() + k0, o.flag.data(), m * 4);
+                memcpy(f.seq_len.data() + k0, o.seq_len.data(), m * 4); memcpy(f.n_cig.data() + k0, o.n_cig.data(), m * 4);
+                memcpy(f.pos0.data() + k0, o.pos0.data(), m * 4);
+                for (size_t k = 0; k < m; k++) { f.seq_off[k0 + k] = o.seq_off[k] + sq_at[t]; f.cig_off[k0 + k] = o.cig_off[k] + cg_at[t]; }
+            }
+            if (o.seq4.size()) memcpy(f.seq4.data() + sq_at[t], o.seq4.data(), o.seq4.size());
+            if (o.cigar.size()) memcpy(f.cigar.data() + cg_at[t], o.cigar.data(), o.cigar.size() * 4);
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(merge, t);
+        merge(0);
+        for (auto &x : th) x.join();
     }
     return KD_OK;
 }
@@ -435,7 +517,7 @@ int kd_decode_open(kd_file **out, const char *path, int n_threads) {
         if (!decompress(raw, data, n_threads)) { delete h; g_decode_error = "gzip/BGZF inflate failed"; return KD_E_IO; }
         rc = parse_bam(data, h->f, n_threads);
     } else {
-        rc = parse_sam(raw, h->f);
+        rc = parse_sam(raw, h->f, n_threads);
     }
     if (rc) { delete h; return rc; }
     finish_view(h->f);

@@ -65,6 +65,38 @@ def test_bam_parallel_record_scan(tmp_path, monkeypatch, range_bytes):
         same_batch(N.decode_file(q, threads=threads), lr)
 
 
+def test_sam_parallel_line_ranges(tmp_path, monkeypatch):
+    """The SAM text parser splits the alignment lines into line-aligned ranges parsed in parallel: same batch as the
+    pure-Python reader whatever the range size; errors name the first failing line; a header line after the first
+    alignment is rejected."""
+    ref = os.path.join(P.REF_TESTS, "data_ext", "1.issue23.debug.sam")
+    texts = {"many": "@SQ\tSN:c\tLN:500\n" + "".join(
+        "r%d\t0\tc\t%d\t60\t%dM%dI%dM\t*\t0\t0\t%s\t*\n" % (i, 1 + i % 300, 5 + i % 7, 1 + i % 3, 4, "ACGTN"[i % 5] * (10 + i % 7 + i % 3))
+        for i in range(400))}
+    if os.path.exists(ref):
+        texts["issue23"] = open(ref).read()
+    for name, text in texts.items():
+        p = tmp_path / (name + ".sam")
+        p.write_text(text)
+        want = samio_py.load_batch(str(p))
+        for rb in ("64", "1000", "100000000"):
+            monkeypatch.setenv("KD_DECODE_RANGE_BYTES", rb)
+            for threads in (0, 3):
+                same_batch(N.decode_file(p, threads=threads), want)
+    monkeypatch.setenv("KD_DECODE_RANGE_BYTES", "64")
+    bad = tmp_path / "bad.sam"
+    lines = texts["many"].split("\n")
+    lines[200] = "broken\tline"
+    lines[300] = "r\t0\tnope\t1\t60\t5M\t*\t0\t0\tACGTA\t*"
+    bad.write_text("\n".join(lines))
+    with pytest.raises(OSError, match="fewer than 10 fields"):
+        N.decode_file(bad)
+    late = tmp_path / "late.sam"
+    late.write_text(texts["many"] + "@SQ\tSN:d\tLN:5\n")
+    with pytest.raises(OSError, match="header line after"):
+        N.decode_file(late)
+
+
 def test_unreadable_file(tmp_path):
     with pytest.raises(OSError):
         N.decode_file(tmp_path / "missing.bam")
