@@ -17,6 +17,39 @@ typedef unsigned long long kd_u64;
 #define KD_MUL24(a, b) __umul24((a), (b))
 #endif
 
+// Wavefront operations (64 lanes, gfx950).  tests/emu/hip_emu.h supplies functional stand-ins (KD_EMU).
+#ifndef KD_EMU
+// lane-private LDS writes -> cross-lane LDS reads inside ONE wavefront: the LDS queue of a wavefront is in order, so
+// this only has to stop the compiler from moving accesses across it (no s_barrier, no other wavefront involved)
+#define KD_WAVE_SYNC()                                          \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+__device__ __forceinline__ unsigned long long kd_ballot(bool pred) { return __ballot(pred); }
+__device__ __forceinline__ uint32_t kd_lane_id() { return __lane_id(); }
+// number of set bits of `mask` below this lane (v_mbcnt_lo/hi)
+__device__ __forceinline__ uint32_t kd_mbcnt(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ uint32_t kd_shfl(uint32_t v, unsigned src_lane) { return (uint32_t)__shfl((int)v, (int)src_lane, 64); }
+__device__ __forceinline__ unsigned long long kd_shfl64(unsigned long long v, unsigned src_lane) {
+    return ((unsigned long long)kd_shfl((uint32_t)(v >> 32), src_lane) << 32) | kd_shfl((uint32_t)v, src_lane);
+}
+__device__ __forceinline__ uint32_t kd_shfl_up(uint32_t v, unsigned d) { return (uint32_t)__shfl_up((int)v, d, 64); }
+__device__ __forceinline__ uint32_t kd_shfl_xor(uint32_t v, unsigned m) { return (uint32_t)__shfl_xor((int)v, (int)m, 64); }
+__device__ __forceinline__ uint32_t kd_readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long kd_readfirstlane64(unsigned long long v) {
+    return ((unsigned long long)kd_readfirstlane((uint32_t)(v >> 32)) << 32) | kd_readfirstlane((uint32_t)v);
+}
+__device__ __forceinline__ int kd_popcll(unsigned long long m) { return __popcll(m); }
+// v_perm_b32: byte i of the result = byte sel.byte[i] of {hi (bytes 4-7), lo (bytes 0-3)}
+__device__ __forceinline__ uint32_t kd_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// v_alignbyte_b32: ({hi, lo} >> 8 * (sh & 3)) [31:0]
+__device__ __forceinline__ uint32_t kd_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+#endif
+
 #define KD_WAVE 64
 #define KD_BLOCK 256
 #define KD_WAVES_PER_BLOCK (KD_BLOCK / KD_WAVE)
@@ -70,7 +103,9 @@ enum {
     KDS_TOTAL_ITEMS,    // window work queue length
     KDS_INS_COLLISION,  // hash verification failed
     KDS_INTERNAL,       // capacity overrun etc.
-    KDS_BAD_BASE,       // k_window: windows that saw a base outside A,C,G,T,N
+    KDS_BAD_BASE,       // k_window / k_strip: work items that saw a base outside A,C,G,T,N
+    KDS_QUEUE0,         // k_strip: heads of the eight work queues (reset by k_plan_scan)
+    KDS_QUEUE7 = KDS_QUEUE0 + 7,
 #ifdef KD_PHASE_CLOCKS
     KDS_DBG0, KDS_DBG1, KDS_DBG2, KDS_DBG3, KDS_DBG4, KDS_DBG5, KDS_DBG6, KDS_DBG7,   // phase clocks (profiling build only)
 #endif

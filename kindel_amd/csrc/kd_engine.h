@@ -239,8 +239,11 @@ struct KdEngine {
         if (windowed) {
             const uint32_t w0 = (uint32_t)(g_lo / W);   // windows intersecting the shard's commit range only
             const uint32_t n_win = (uint32_t)((std::min<uint64_t>(S, g_hi + 1) + W - 1) / W) - w0;
-            if ((rc = ensure(b_winlo, (size_t)n_win * 8)) || (rc = ensure(b_winhi, (size_t)n_win * 8)) ||
-                (rc = ensure(b_itemoff, ((size_t)n_win + 1) * 8)))
+            // (sized for the strip planning of the first pass as well: the two passes share these arrays)
+            const uint32_t ws0 = (uint32_t)(g_lo / KD_STRIP);
+            const uint32_t ns_win = (uint32_t)((std::min<uint64_t>(S, g_hi + 1) + KD_STRIP - 1) / KD_STRIP) - ws0;
+            const size_t nw_max = std::max<size_t>(n_win, ns_win);
+            if ((rc = ensure(b_winlo, nw_max * 8)) || (rc = ensure(b_winhi, nw_max * 8)) || (rc = ensure(b_itemoff, (nw_max + 1) * 8)))
                 return rc;
             kd_u64 *wl = (kd_u64 *)b_winlo.p, *wh = (kd_u64 *)b_winhi.p, *io = (kd_u64 *)b_itemoff.p;
             // One pass of k_window over `ne` entries described by `info`: the batch's reads (seg_read == NULL), then the
@@ -302,7 +305,59 @@ struct KdEngine {
                     return hipfail("k_window");
                 return KD_OK;
             };
-            if ((rc = window_pass((const KdRInfo *)rinfo, n, sorted_input, nullptr, (uint32_t)KDS_B_MAXSPAN))) return rc;
+            // First pass over the batch's short regular reads.  Default: k_strip, the site-major kernel (wavefront = strip of
+            // 64 sites, counters in registers); KD_MODE_WINDOW keeps the LDS-histogram kernel for it (cross-check, tunings).
+            // Planning is the same machinery with a "window" of one strip.
+            auto strip_pass = [&](const KdRInfo *info, uint64_t ne, bool in_order) -> int {
+                int rc2;
+                const uint32_t Ws = KD_STRIP;
+                kd_u64 *swl = wl, *swh = wh, *sio = io;
+                const uint64_t reach = h_status[KDS_B_MAXSPAN] / Ws + h_status[KDS_B_MAXLEAD] / Ws + 4;
+                uint32_t slice = slice_cfg;
+                if (!slice) {   // enough (strip, slice) items to keep every resident wavefront busy several times over
+                    const uint64_t pairs = ne * (h_status[KDS_B_MAXSPAN] / Ws + 2), want = (uint64_t)rt.n_cus() * 24 * 8;
+                    slice = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(256, (pairs / want + 63) / 64 * 64));
+                }
+                slice = std::min<uint32_t>(slice, 32768u);   // item-relative candidate indices are kept as u16 in LDS
+                const uint32_t *order = nullptr;
+                if (in_order) {
+                    if (rt.launch("k_plan_ranges", k_plan_ranges, (ns_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, info, (kd_u64)ne, ws0,
+                                  ns_win, Ws, slice, swl, swh, sio, (const kd_u64 *)d_status))
+                        return hipfail("k_plan_ranges");
+                } else {
+                    const uint32_t n_bins = (uint32_t)((S + Ws - 1) / Ws);
+                    if ((rc2 = ensure(b_order, ne * 4)) || (rc2 = ensure(b_bincnt, ((size_t)n_bins + 1) * 4)) ||
+                        (rc2 = ensure(b_binoff, ((size_t)n_bins + 1) * 8)))
+                        return rc2;
+                    uint32_t *ord = (uint32_t *)b_order.p, *bc = (uint32_t *)b_bincnt.p;
+                    kd_u64 *bo = (kd_u64 *)b_binoff.p;
+                    const unsigned gr = (unsigned)((ne + KD_BLOCK - 1) / KD_BLOCK);
+                    if (rt.memset(bc, 0, ((size_t)n_bins + 1) * 4) ||
+                        rt.launch("k_sort_count", k_sort_count<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, Ws, bc) ||
+                        rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, n_bins) ||
+                        rt.launch("k_sort_scatter", k_sort_scatter<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, Ws, bc, (const kd_u64 *)bo, ord) ||
+                        rt.launch("k_plan_ranges_sorted", k_plan_ranges_sorted, (ns_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
+                                  (const kd_u64 *)bo, n_bins, ws0, ns_win, Ws, slice, swl, swh, sio, (const kd_u64 *)d_status,
+                                  (uint32_t)KDS_B_MAXSPAN))
+                        return hipfail("k_sort_*");
+                    order = ord;
+                }
+                const uint64_t items_cap = (uint64_t)ns_win + (ne * reach) / slice + 1;
+                if ((rc2 = ensure(b_itemwin, items_cap * 4))) return rc2;
+                uint32_t *siw = (uint32_t *)b_itemwin.p;
+                if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, sio, ns_win, d_status) ||
+                    rt.launch("k_plan_items", k_plan_items, (ns_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, (const kd_u64 *)sio, ns_win, siw,
+                              (kd_u64)items_cap, d_status))
+                    return hipfail("k_plan_scan");
+                const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * 6u);   // 6 workgroups (24 wavefronts) per CU: LDS and registers
+                if (rt.launch("k_strip", k_strip, grid, KD_BLOCK, 0, R, info, order, T, (const kd_u64 *)swl, (const kd_u64 *)swh,
+                              (const kd_u64 *)sio, (const uint32_t *)siw, (kd_u64)items_cap, ws0, slice, d_status))
+                    return hipfail("k_strip");
+                return KD_OK;
+            };
+            if (mode == KD_MODE_WINDOW) rc = window_pass((const KdRInfo *)rinfo, n, sorted_input, nullptr, (uint32_t)KDS_B_MAXSPAN);
+            else rc = strip_pass((const KdRInfo *)rinfo, n, sorted_input);
+            if (rc) return rc;
             if (n_long && (rc = window_pass((const KdRInfo *)b_seginfo.p, n_long * KD_BLOCK, false, (const uint32_t *)lng,
                                             (uint32_t)KDS_B_MAXSEGSPAN)))
                 return rc;

@@ -33,5 +33,6 @@
 #include "kd_readwise.h"
 #include "kd_plan.h"
 #include "kd_window.h"
+#include "kd_strip.h"
 #include "kd_ins.h"
 #include "kd_cns.h"

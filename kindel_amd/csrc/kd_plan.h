@@ -152,6 +152,7 @@ k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
         __syncthreads();
     }
     if (t == 0) { item_off[n_win] = s_carry; status[KDS_TOTAL_ITEMS] = s_carry; status[KDS_NEXT_ITEM] = 0; }
+    if (t < 8) status[KDS_QUEUE0 + t] = 0;   // k_strip's work queues
 }
 
 // k_plan_items: work item -> window table (k_window then needs one load, not a binary search over item_off,

@@ -84,7 +84,7 @@ struct HipRt {
             bad(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)))
             return 1;
         Pending p;
-        const bool timed = prof == 1 || (prof == 2 && !strcmp(name, "k_window"));
+        const bool timed = prof == 1 || (prof == 2 && (!strcmp(name, "k_window") || !strcmp(name, "k_strip")));
         if (timed) {
             if (bad(hipEventCreate(&p.a)) || bad(hipEventCreate(&p.b))) return 1;
             if (bad(hipEventRecord(p.a, stream))) return 1;

@@ -29,7 +29,9 @@ struct EmuRt {
     int d2h_small(void *h, const void *d, size_t n) { ::memcpy(h, d, n); return 0; }
     int sync() { return 0; }
     template <class K, class... A>
-    int launch(const char *, K k, unsigned grid, unsigned block, size_t shmem, A... args) {
+    int launch(const char *name, K k, unsigned grid, unsigned block, size_t shmem, A... args) {
+        static const bool trace = getenv("KD_EMU_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "emu launch %s grid %u block %u\n", name, grid, block);
         emu::launch(k, dim3(grid), dim3(block), shmem, args...);
         return 0;
     }
