@@ -315,7 +315,7 @@ struct KdEngine {
                 const uint64_t reach = h_status[KDS_B_MAXSPAN] / Ws + h_status[KDS_B_MAXLEAD] / Ws + 4;
                 uint32_t slice = slice_cfg;
                 if (!slice) {   // enough (strip, slice) items to keep every resident wavefront busy several times over
-                    const uint64_t pairs = ne * (h_status[KDS_B_MAXSPAN] / Ws + 2), want = (uint64_t)rt.n_cus() * 24 * 8;
+                    const uint64_t pairs = ne * (h_status[KDS_B_MAXSPAN] / Ws + 2), want = (uint64_t)rt.n_cus() * 4 * KD_STRIP_WGS * 8;
                     slice = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(256, (pairs / want + 63) / 64 * 64));
                 }
                 slice = std::min<uint32_t>(slice, 32768u);   // item-relative candidate indices are kept as u16 in LDS
@@ -349,7 +349,7 @@ struct KdEngine {
                     rt.launch("k_plan_items", k_plan_items, (ns_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, (const kd_u64 *)sio, ns_win, siw,
                               (kd_u64)items_cap, d_status))
                     return hipfail("k_plan_scan");
-                const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * 6u);   // 6 workgroups (24 wavefronts) per CU: LDS and registers
+                const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * (unsigned)KD_STRIP_WGS);   // resident workgroups: LDS and registers
                 if (rt.launch("k_strip", k_strip, grid, KD_BLOCK, 0, R, info, order, T, (const kd_u64 *)swl, (const kd_u64 *)swh,
                               (const kd_u64 *)sio, (const uint32_t *)siw, (kd_u64)items_cap, ws0, slice, d_status))
                     return hipfail("k_strip");

@@ -29,7 +29,12 @@
 #define KD_TRASH4 0x1e1e1e1eu  // code 30 x 4
 #define KD_BAD4 0x80808080u    // a code byte with bit 7 set: base outside A,C,G,T,N (KeyError in the reference)
 #define KD_LIST 128u           // ring of pending candidates per class (< 64 pending + <= 64 new)
+#ifndef KD_GRAB
 #define KD_GRAB 2u             // consecutive work items per dequeue
+#endif
+#ifndef KD_STRIP_WGS
+#define KD_STRIP_WGS 6         // workgroups per CU the kernel is built for (24 wavefronts: LDS 6 x 24 KB, <= 80 VGPRs)
+#endif
 #define KD_NQ 8u               // work queues (XCDs)
 
 struct KdStripLds {
@@ -297,7 +302,7 @@ __device__ __forceinline__ void kd_strip_item(const KdReads &rd, const KdRInfo *
     KD_WAVE_SYNC();   // dels / the rings are reused by the next item
 }
 
-__global__ void __launch_bounds__(KD_BLOCK, 6)
+__global__ void __launch_bounds__(KD_BLOCK, KD_STRIP_WGS)
 k_strip(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, const kd_u64 *win_lo, const kd_u64 *win_hi,
         const kd_u64 *item_off, const uint32_t *item_win, kd_u64 items_cap, uint32_t w0, uint32_t slice, kd_u64 *status) {
     __shared__ KdStripLds lds_all[KD_WAVES_PER_BLOCK];
