@@ -44,6 +44,16 @@ __device__ __forceinline__ unsigned long long kd_readfirstlane64(unsigned long l
     return ((unsigned long long)kd_readfirstlane((uint32_t)(v >> 32)) << 32) | kd_readfirstlane((uint32_t)v);
 }
 __device__ __forceinline__ int kd_popcll(unsigned long long m) { return __popcll(m); }
+// OR over the 64 lanes (wave-uniform result): an inclusive DPP scan inside each row of 16 lanes, two cross-row broadcasts, v_readlane 63
+__device__ __forceinline__ uint32_t kd_wave_or(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8: lane 15 of a row = the row's OR
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 // v_perm_b32: byte i of the result = byte sel.byte[i] of {hi (bytes 4-7), lo (bytes 0-3)}
 __device__ __forceinline__ uint32_t kd_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 // v_alignbyte_b32: ({hi, lo} >> 8 * (sh & 3)) [31:0]

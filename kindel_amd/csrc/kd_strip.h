@@ -33,13 +33,17 @@
 #define KD_GRAB 2u             // consecutive work items per dequeue
 #endif
 #ifndef KD_STRIP_WGS
-#define KD_STRIP_WGS 6         // workgroups per CU the kernel is built for (24 wavefronts: LDS 6 x 24 KB, <= 80 VGPRs)
+#define KD_STRIP_WGS 5         // workgroups per CU the kernel is built for (20 wavefronts: LDS 5 x 32 KB, <= 96 VGPRs)
 #endif
 #define KD_NQ 8u               // work queues (XCDs)
 
+// a pending PLAIN read: everything its staging needs (no dependent global loads between the scan and the base loads)
+struct __attribute__((aligned(16))) KdPlainEnt { uint32_t gstart, len; kd_u64 seq_off; };
+
 struct KdStripLds {
+    KdPlainEnt plain[KD_LIST];                // ring of pending plain reads
     uint32_t rows[KD_STRIP * KD_ROW_DW];
-    uint16_t plain[KD_LIST], cplx[KD_LIST];   // item-relative candidate indices
+    uint32_t cplx[KD_LIST];                   // ring of pending reads with clips / indels (read indices)
     uint32_t dels[KD_STRIP];
 };
 
@@ -66,74 +70,71 @@ __device__ __forceinline__ uint32_t kd_mask_bytes(uint32_t value, uint32_t other
     return kd_perm(value, other, ((t >> 5) & 0x04040404u) | 0x03020100u);
 }
 
-// A PLAIN read (one M/=/X run = the whole read): query base x lies on strip-relative site p + x.  All 16 data dwords of
-// the row are written exactly once (bytes outside the read = trash): nine source dwords, two row dwords each.
-__device__ __forceinline__ void kd_stage_plain(uint32_t *row, const uint8_t *seq, int32_t p, int32_t len, uint32_t &bad) {
-    const int32_t lo_b = KD_ROW_BIAS + (p > 0 ? p : 0);
-    const int32_t hi_b = KD_ROW_BIAS + (p + len < (int32_t)KD_STRIP ? p + len : (int32_t)KD_STRIP);
-    const int32_t delta = KD_ROW_BIAS + p;                 // row byte of query base 0
+// ONE RUN per lane into the lane's row: row bytes [b0, b0 + n) <- codes of query bases [q0, q0 + n) of the read at `seq`
+// (KD_ROW_BIAS <= b0, b0 + n <= KD_ROW_BIAS + 64; n == 0: the lane has no run).  The 18 row dwords are produced in nine
+// steps t of two dwords from nine source dwords (8 bases each); the work of a step is decided for the WHOLE wavefront:
+//   no lane needs source dword t   -> nothing is loaded or converted; `first`: the two dwords become trash
+//   every lane covers both dwords  -> convert, realign, store
+//   otherwise                      -> convert, realign, byte-select against trash (`first`) or against the row's content
+// `first`: the rows are being initialised (every data dword is written); else the run is merged into rows that hold
+// earlier runs of the same reads.  `active` = the lane's row is in use (idle lanes neither veto nor report bad bases).
+// Reads of a coordinate-sorted batch start a few sites apart, so most steps are one of the two cheap kinds.
+__device__ __forceinline__ void kd_stage_run(uint32_t *row, const uint8_t *seq, int32_t dmax, int32_t q0, int32_t b0, int32_t n,
+                                             bool first, bool active, uint32_t &bad) {
+    const int32_t hi_b = b0 + n;
+    const int32_t delta = b0 - q0;                         // row byte of query base 0
     const int32_t fd = delta >> 2, adj = (delta & 3) ? 1 : 0;
     const uint32_t e = (4u - ((uint32_t)delta & 3u)) & 3u;
     // row dword K = alignbyte(conv[M + 1], conv[M], e) with M = K - fd - adj; conv[2d], conv[2d + 1] = source dword d
-    const int32_t ds = (2 - fd - adj) >> 1;                // first source dword (floor)
-    int32_t K = 2 * ds - 1 + fd + adj;                     // 0 or 1: the first outputs fall into the slack dwords
-    const int32_t dmax = (len - 1) >> 3;
-    const uint32_t A = (uint32_t)(0x80 - lo_b) * 0x01010101u, B = (uint32_t)(0x80 - hi_b) * 0x01010101u;
-    uint32_t pos = 0x03020100u + (uint32_t)K * 0x04040404u;
+    const int32_t ds = (2 - fd - adj) >> 1;                // source dword of step 0 (floor)
+    const int32_t Kb = 2 * ds - 1 + fd + adj;              // row dword of step 0: 0 or 1 (slack dwords)
+    uint32_t need = 0u, full = active ? 0u : 0x1ffu;
+    if (n > 0) {
+        // steps whose source dword holds run bases (step t produces conv[2(ds+t)-1 .. 2(ds+t)+1] realigned, so its output
+        // may lag its source by a dword), and steps whose two output dwords intersect the run
+        const int32_t sA = (q0 >> 3) - ds, sB = ((q0 + n - 1) >> 3) - ds;
+        const int32_t oA = (b0 - 4 * Kb) >> 3, oB = (hi_b - 1 - 4 * Kb) >> 3;
+        const int32_t tA = sA < oA ? sA : oA, tB = sB > oB ? sB : oB;
+        need = (2u << tB) - (1u << tA);
+        const int32_t f0 = (b0 - 4 * Kb + 7) >> 3, f1 = (hi_b - 4 * Kb - 8) >> 3;   // steps whose two dwords lie inside the run
+        full = f1 >= f0 ? (2u << f1) - (1u << f0) : 0u;
+    }
+    const uint32_t red = kd_wave_or(need | ((~full & 0x1ffu) << 16));
+    const uint32_t NEED = red & 0x1ffu, FULL = ~(red >> 16) & 0x1ffu;
     uint32_t src[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) {
-        const int32_t d = ds + t;
         src[t] = 0u;
-        if (d >= 0 && d <= dmax) src[t] = reinterpret_cast<const KdWord *>(seq + 4 * (int64_t)d)->v;
+        if ((NEED >> t) & 1u) {
+            int32_t d = ds + t;
+            d = d < 0 ? 0 : d > dmax ? dmax : d;           // a clamped dword only feeds bytes outside the run
+            src[t] = reinterpret_cast<const KdWord *>(seq + 4 * (int64_t)d)->v;
+        }
     }
-    uint32_t prev = 0u;
+    const uint32_t A = (uint32_t)(0x80 - b0) * 0x01010101u, B = (uint32_t)(0x80 - hi_b) * 0x01010101u;
+    const uint32_t pos0 = 0x03020100u + (uint32_t)Kb * 0x04040404u;
+    uint32_t prev = 0u, lbad = 0u;
 #pragma unroll
     for (int t = 0; t < 9; t++) {
+        uint32_t *r2 = row + Kb + 2 * t;
+        if (!((NEED >> t) & 1u)) {
+            if (first) { r2[0] = KD_TRASH4; r2[1] = KD_TRASH4; }
+            continue;
+        }
         uint32_t c0, c1;
         kd_conv8(src[t], c0, c1);
-        const uint32_t o0 = kd_mask_bytes(kd_alignbyte(c0, prev, e), KD_TRASH4, pos, A, B);
-        const uint32_t o1 = kd_mask_bytes(kd_alignbyte(c1, c0, e), KD_TRASH4, pos + 0x04040404u, A, B);
+        uint32_t o0 = kd_alignbyte(c0, prev, e), o1 = kd_alignbyte(c1, c0, e);
         prev = c1;
-        bad |= o0 | o1;
-        row[K] = o0; row[K + 1] = o1;
-        K += 2; pos += 0x08080808u;
-    }
-}
-
-// One M/=/X (or soft-clip) run of a read into a row that already holds trash / earlier runs: row bytes [b0, b0 + n) <-
-// codes of query bases [q0, q0 + n).  KD_ROW_BIAS <= b0, b0 + n <= KD_ROW_BIAS + 64, n >= 1.  Interior dwords are
-// stored whole, the two edge dwords are merged with what the row holds.
-__device__ __forceinline__ void kd_put_run(uint32_t *row, const uint8_t *seq, int32_t q0, int32_t b0, int32_t n, int32_t dmax,
-                                           uint32_t &bad) {
-    const int32_t hi_b = b0 + n;
-    const int32_t delta = b0 - q0;
-    const int32_t fd = delta >> 2, adj = (delta & 3) ? 1 : 0;
-    const uint32_t e = (4u - ((uint32_t)delta & 3u)) & 3u;
-    const int32_t Kf = b0 >> 2, Kl = (hi_b - 1) >> 2;
-    const int32_t ds = (Kf - fd - adj) >> 1, de = (Kl - fd - adj + 1) >> 1;
-    int32_t K = 2 * ds - 1 + fd + adj;
-    const uint32_t A = (uint32_t)(0x80 - b0) * 0x01010101u, B = (uint32_t)(0x80 - hi_b) * 0x01010101u;
-    uint32_t pos = 0x03020100u + (uint32_t)K * 0x04040404u;
-    uint32_t prev = 0u;
-    for (int32_t d = ds; d <= de; d++) {
-        uint32_t v = 0u, c0, c1;
-        if (d >= 0 && d <= dmax) v = reinterpret_cast<const KdWord *>(seq + 4 * (int64_t)d)->v;
-        kd_conv8(v, c0, c1);
-        const uint32_t a0 = kd_alignbyte(c0, prev, e), a1 = kd_alignbyte(c1, c0, e);
-        prev = c1;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int32_t Kh = K + h;
-            if (Kh >= Kf && Kh <= Kl) {
-                uint32_t o = h ? a1 : a0;
-                if (Kh == Kf || Kh == Kl) o = kd_mask_bytes(o, row[Kh], pos + (h ? 0x04040404u : 0u), A, B);
-                bad |= o;
-                row[Kh] = o;
-            }
+        if (!((FULL >> t) & 1u)) {
+            const uint32_t pos = pos0 + (uint32_t)t * 0x08080808u;
+            const uint32_t x0 = first ? KD_TRASH4 : r2[0], x1 = first ? KD_TRASH4 : r2[1];
+            o0 = kd_mask_bytes(o0, x0, pos, A, B);
+            o1 = kd_mask_bytes(o1, x1, pos + 0x04040404u, A, B);
         }
-        K += 2; pos += 0x08080808u;
+        lbad |= o0 | o1;
+        r2[0] = o0; r2[1] = o1;
     }
+    if (active) bad |= lbad;
 }
 
 // one group of counters: five 6-bit fields in `acc`, spilled into w[0..4] before a field can reach 64
@@ -167,11 +168,6 @@ __device__ __forceinline__ void kd_accumulate(const uint8_t *col, uint32_t nrows
     }
 }
 
-__device__ __forceinline__ void kd_row_trash(uint32_t *row) {
-#pragma unroll
-    for (int k = 2; k < 18; k++) row[k] = KD_TRASH4;
-}
-
 // One work item: strip [s0, s0 + 64) against the candidates [first, last) of `rinfo` (through `order` if not NULL).
 __device__ __forceinline__ void kd_strip_item(const KdReads &rd, const KdRInfo *rinfo, const uint32_t *order, const KdTabs &T,
                                               KdStripLds &L, uint32_t lane, kd_u64 s0, kd_u64 first, kd_u64 last, uint32_t &bad) {
@@ -183,80 +179,109 @@ __device__ __forceinline__ void kd_strip_item(const KdReads &rd, const KdRInfo *
     uint32_t *const row = &L.rows[lane * KD_ROW_DW];
     const uint8_t *const col = reinterpret_cast<const uint8_t *>(L.rows) + KD_ROW_BIAS + lane;
 
-    // nr plain reads of the ring, from entry d_pl on: stage, accumulate
+    // nr plain reads of the ring, from entry d_pl on: one run each (the whole read, cut to the strip)
     auto plain_batch = [&](uint32_t nr) {
-        if (lane < nr) {
-            const kd_u64 j = first + L.plain[(d_pl + lane) & (KD_LIST - 1u)];
-            const kd_u64 i = order ? (kd_u64)order[j] : j;
-            const KdRInfo ri = rinfo[i];
-            kd_stage_plain(row, rd.seq4 + rd.seq_off[i], (int32_t)(ri.gstart - (uint32_t)s0),
-                           (int32_t)(ri.span_cls >> KD_SPAN_SHIFT), bad);
+        const bool act = lane < nr;
+        const uint8_t *seq = rd.seq4;
+        int32_t dmax = 0, q0 = 0, b0 = KD_ROW_BIAS, n = 0;
+        if (act) {
+            const KdPlainEnt en = L.plain[(d_pl + lane) & (KD_LIST - 1u)];
+            const int32_t p = (int32_t)(en.gstart - (uint32_t)s0), len = (int32_t)en.len;
+            seq = rd.seq4 + en.seq_off;
+            dmax = (len - 1) >> 3;
+            q0 = p < 0 ? -p : 0;
+            b0 = KD_ROW_BIAS + p + q0;
+            n = (p + len < (int32_t)KD_STRIP ? p + len : (int32_t)KD_STRIP) - (p + q0);
         }
+        kd_stage_run(row, seq, dmax, q0, b0, n, true, act, bad);
         KD_WAVE_SYNC();
         kd_accumulate(col, nr, aw);
         KD_WAVE_SYNC();
         d_pl += nr;
     };
-    // nr reads with clips / indels: CIGAR walk, weights rows; then the clip rows in two compacted sub-passes
+    // nr reads with clips / indels: every lane walks its CIGAR from run to run; the wavefront stages one run per lane
+    // and round (a read with one indel has two), then the clip rows in two compacted sub-passes
     auto cplx_batch = [&](uint32_t nr) {
+        const bool act = lane < nr;
         int32_t cew_s = 0, cew_q = 0, cew_n = 0, csw_s = 0, csw_q = 0, csw_n = 0, dmax = 0;
         const uint8_t *seq = rd.seq4;
-        if (lane < nr) {
-            const kd_u64 j = first + L.cplx[(d_cx + lane) & (KD_LIST - 1u)];
-            const kd_u64 i = order ? (kd_u64)order[j] : j;
+        const uint32_t *cg = rd.cigar;
+        KdChunk pre; pre.x = pre.y = pre.z = pre.w = 0u;
+        uint32_t nc = 0, k = 0;
+        int32_t grel = 0, q = 0, foot_end = 0, lead = 0;
+        if (act) {
+            const kd_u64 i = L.cplx[(d_cx + lane) & (KD_LIST - 1u)];
             const KdRInfo ri = rinfo[i];
-            const uint32_t nc = rd.n_cig[i];
-            const uint32_t *cg = rd.cigar + rd.cig_off[i];
-            const KdChunk pre = kd_load_cigar4(cg, 0u, nc);
+            nc = rd.n_cig[i];
+            cg = rd.cigar + rd.cig_off[i];
+            pre = kd_load_cigar4(cg, 0u, nc);
             seq = rd.seq4 + rd.seq_off[i];
             dmax = ((int32_t)rd.seq_len[i] - 1) >> 3;
-            int32_t grel = (int32_t)(ri.gstart - (uint32_t)s0), q = 0;   // strip-relative reference cursor, query cursor
-            const int32_t foot_end = grel + (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
-            const int32_t lead = (int32_t)ri.lead;
-            kd_row_trash(row);
-            for (uint32_t k = 0; k < nc; k++) {
-                const uint32_t cw = k == 0 ? pre.x : k == 1 ? pre.y : k == 2 ? pre.z : k == 3 ? pre.w : cg[k];
-                const int32_t len = (int32_t)(cw >> 4);
-                const uint32_t op = cw & 15u;
-                if (op == 0 || op == 7 || op == 8) {          // kindel.py:49-54
-                    const int32_t i0 = grel < 0 ? -grel : 0, i1 = (int32_t)KD_STRIP - grel < len ? (int32_t)KD_STRIP - grel : len;
-                    if (i1 > i0) kd_put_run(row, seq, q + i0, KD_ROW_BIAS + grel + i0, i1 - i0, dmax, bad);
-                    q += len; grel += len;
-                } else if (op == 2) {                         // kindel.py:59-62
-                    const int32_t a = grel < 0 ? 0 : grel, b = grel + len < (int32_t)KD_STRIP ? grel + len : (int32_t)KD_STRIP;
-                    for (int32_t s = a; s < b; s++) atomicAdd(&L.dels[s], 1u);
-                    grel += len;
-                } else if (op == 1) {
-                    q += len;
-                } else if (op == 4) {
-                    if (k == 0) {   // leading clip, kindel.py:64-73: its last `lead` bases lie on the sites before the read
-                        cew_s = grel - lead; cew_q = len - lead; cew_n = lead;
-                        q += len;
-                    } else {        // non-first clip, kindel.py:74-81: the last op of a regular read that moves r
-                        csw_s = grel; csw_q = q; csw_n = foot_end - grel;
-                        break;
+            grel = (int32_t)(ri.gstart - (uint32_t)s0);          // strip-relative reference cursor
+            foot_end = grel + (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
+            lead = (int32_t)ri.lead;
+        }
+        // phase 0: the weights rows, one M/=/X run per lane and round (a read with one indel has two); phases 1, 2: the
+        // clip_end_weights / clip_start_weights rows of the lanes with a leading / trailing clip, compacted
+#pragma nounroll
+        for (int phase = 0; phase < 3; phase++) {
+            uint32_t nrow = nr;
+            uint32_t *trow = row;
+            bool tact = act;
+            int32_t cq = 0, cb = KD_ROW_BIAS, cn = 0;
+            if (phase > 0) {
+                const int32_t cs = phase == 2 ? csw_s : cew_s, cl = phase == 2 ? csw_n : cew_n;
+                tact = cl > 0 && cs < (int32_t)KD_STRIP && cs + cl > 0;
+                const kd_u64 m = kd_ballot(tact);
+                nrow = (uint32_t)kd_popcll(m);
+                if (!nrow) continue;
+                if (tact) {
+                    const int32_t i0 = cs < 0 ? -cs : 0, i1 = (int32_t)KD_STRIP - cs < cl ? (int32_t)KD_STRIP - cs : cl;
+                    cq = (phase == 2 ? csw_q : cew_q) + i0; cb = KD_ROW_BIAS + cs + i0; cn = i1 - i0;
+                }
+                // the r-th lane with a clip takes row r; idle lanes point at the last row and stay idle in the staging
+                trow = &L.rows[(tact ? kd_mbcnt(m) : KD_STRIP - 1u) * KD_ROW_DW];
+            }
+            for (uint32_t round = 0;; round++) {
+                int32_t rq = 0, rb = KD_ROW_BIAS, rn = 0;
+                if (phase > 0) {
+                    if (round == 0) { rq = cq; rb = cb; rn = cn; }
+                } else {
+                    // advance to the lane's next M/=/X run that reaches into the strip
+                    while (k < nc && rn == 0) {
+                        const uint32_t cw = k == 0 ? pre.x : k == 1 ? pre.y : k == 2 ? pre.z : k == 3 ? pre.w : cg[k];
+                        const int32_t len = (int32_t)(cw >> 4);
+                        const uint32_t op = cw & 15u;
+                        k++;
+                        if (op == 0 || op == 7 || op == 8) {          // kindel.py:49-54
+                            const int32_t i0 = grel < 0 ? -grel : 0, i1 = (int32_t)KD_STRIP - grel < len ? (int32_t)KD_STRIP - grel : len;
+                            if (i1 > i0) { rq = q + i0; rb = KD_ROW_BIAS + grel + i0; rn = i1 - i0; }
+                            q += len; grel += len;
+                        } else if (op == 2) {                         // kindel.py:59-62
+                            const int32_t a = grel < 0 ? 0 : grel, b = grel + len < (int32_t)KD_STRIP ? grel + len : (int32_t)KD_STRIP;
+                            for (int32_t s = a; s < b; s++) atomicAdd(&L.dels[s], 1u);
+                            grel += len;
+                        } else if (op == 1) {
+                            q += len;
+                        } else if (op == 4) {
+                            if (k == 1) {   // leading clip, kindel.py:64-73: its last `lead` bases lie on the sites before the read
+                                cew_s = grel - lead; cew_q = len - lead; cew_n = lead;
+                                q += len;
+                            } else {        // non-first clip, kindel.py:74-81: the last op of a regular read that moves r
+                                csw_s = grel; csw_q = q; csw_n = foot_end - grel;
+                                k = nc;
+                            }
+                        }
+                        if (grel >= (int32_t)KD_STRIP) k = nc;   // everything further right lies outside the strip
                     }
                 }
-                if (grel >= (int32_t)KD_STRIP) break;   // everything further right lies outside the strip
-            }
-        }
-        KD_WAVE_SYNC();
-        kd_accumulate(col, nr, aw);
-        KD_WAVE_SYNC();
-        for (int pass = 0; pass < 2; pass++) {
-            const int32_t cs = pass ? csw_s : cew_s, cq = pass ? csw_q : cew_q, cn = pass ? csw_n : cew_n;
-            const bool has = cn > 0 && cs < (int32_t)KD_STRIP && cs + cn > 0;
-            const kd_u64 m = kd_ballot(has);
-            const uint32_t nrow = (uint32_t)kd_popcll(m);
-            if (!nrow) continue;
-            if (has) {
-                uint32_t *crow = &L.rows[kd_mbcnt(m) * KD_ROW_DW];
-                kd_row_trash(crow);
-                const int32_t i0 = cs < 0 ? -cs : 0, i1 = (int32_t)KD_STRIP - cs < cn ? (int32_t)KD_STRIP - cs : cn;
-                kd_put_run(crow, seq, cq + i0, KD_ROW_BIAS + cs + i0, i1 - i0, dmax, bad);
+                if (round > 0 && kd_ballot(rn > 0) == 0) break;
+                kd_stage_run(trow, seq, dmax, rq, rb, rn, round == 0, tact, bad);
             }
             KD_WAVE_SYNC();
-            kd_accumulate(col, nrow, pass ? as : ae);
+            if (phase == 0) kd_accumulate(col, nrow, aw);
+            else if (phase == 1) kd_accumulate(col, nrow, ae);
+            else kd_accumulate(col, nrow, as);
             KD_WAVE_SYNC();
         }
         d_cx += nr;
@@ -265,17 +290,23 @@ __device__ __forceinline__ void kd_strip_item(const KdReads &rd, const KdRInfo *
     for (kd_u64 tb = first; tb < last; tb += KD_STRIP) {
         const kd_u64 j = tb + lane;
         bool isp = false, isc = false;
+        KdPlainEnt en; en.gstart = 0; en.len = 0; en.seq_off = 0;
+        uint32_t ridx = 0;
         if (j < last) {
-            const KdRInfo ri = rinfo[order ? (kd_u64)order[j] : j];
+            const kd_u64 i = order ? (kd_u64)order[j] : j;
+            const KdRInfo ri = rinfo[i];
+            const kd_u64 so = rd.seq_off[i];
             const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
             if ((ri.span_cls & 3u) == KD_CLS_REG && gs + span > s0 && gs - ri.lead < s1) {
                 isp = (ri.span_cls & KD_INFO_PLAIN) != 0;
                 isc = !isp;
+                en.gstart = ri.gstart; en.len = (uint32_t)span; en.seq_off = so;
+                ridx = (uint32_t)i;
             }
         }
         const kd_u64 mp = kd_ballot(isp), mc = kd_ballot(isc);
-        if (isp) L.plain[(n_pl + kd_mbcnt(mp)) & (KD_LIST - 1u)] = (uint16_t)(j - first);
-        if (isc) L.cplx[(n_cx + kd_mbcnt(mc)) & (KD_LIST - 1u)] = (uint16_t)(j - first);
+        if (isp) L.plain[(n_pl + kd_mbcnt(mp)) & (KD_LIST - 1u)] = en;
+        if (isc) L.cplx[(n_cx + kd_mbcnt(mc)) & (KD_LIST - 1u)] = ridx;
         n_pl += (uint32_t)kd_popcll(mp); n_cx += (uint32_t)kd_popcll(mc);
         KD_WAVE_SYNC();
         if (n_pl - d_pl >= KD_STRIP) plain_batch(KD_STRIP);

@@ -150,6 +150,15 @@ static inline uint32_t kd_shfl_xor(uint32_t v, unsigned m) { return (uint32_t)em
 static inline uint32_t kd_readfirstlane(uint32_t v) { return (uint32_t)emu_exchange(v, 0); }
 static inline unsigned long long kd_readfirstlane64(unsigned long long v) { return emu_exchange(v, 0); }
 static inline int kd_popcll(unsigned long long m) { return __builtin_popcountll(m); }
+static inline uint32_t kd_wave_or(uint32_t v) {
+    unsigned long long *scratch = emu_ctx->wscratch[threadIdx.x / 64];
+    scratch[threadIdx.x & 63u] = v;
+    emu_wave_meet();
+    uint32_t r = 0;
+    for (unsigned l = 0; l < 64; l++) r |= (uint32_t)scratch[l];
+    emu_wave_meet();
+    return r;
+}
 // v_perm_b32: byte i of the result = byte sel.byte[i] of {hi (bytes 4-7), lo (bytes 0-3)} (selectors 0-7 only)
 static inline uint32_t kd_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
     const unsigned long long src = ((unsigned long long)hi << 32) | lo;
