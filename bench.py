@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--synth", action="append", default=[], metavar="KEY=VALUE",
                     help="override a synthetic-generator parameter (sensitivity runs; not the BASELINE workload)")
     ap.add_argument("--scale", type=float, default=1.0, help="depth multiplier (1.0 = the config as specified)")
-    ap.add_argument("--mode", default="auto", choices=["auto", "global", "window"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "global", "window", "strip"])
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--slice", type=int, default=0)
     ap.add_argument("--sweep", default="", help="extra tunings to time on the same batch: mode:window:slice,...")
@@ -117,7 +117,7 @@ def main():
         dist.all_reduce(tot)
     aligned_g, query_g, walked_g, ops_g, reads_g = (int(x) for x in tot.cpu())
 
-    mode = dict(auto=N.KD_MODE_AUTO, window=N.KD_MODE_WINDOW)[args.mode] if args.mode != "global" else N.KD_MODE_GLOBAL
+    mode = {"auto": N.KD_MODE_AUTO, "window": N.KD_MODE_WINDOW, "global": N.KD_MODE_GLOBAL, "strip": N.KD_MODE_STRIP}[args.mode]
     eng = N.Engine(np.asarray(contig_lens, np.uint32), device=dev_index, mode=mode)
     if args.window or args.slice:
         eng.set_tuning(args.window, args.slice)
@@ -233,7 +233,7 @@ def main():
         # tuning sweep on the resident batch: "mode:window:slice,..." -> one JSON line each on stderr
         for spec in args.sweep.split(","):
             m, w, s = (spec.split(":") + ["0", "0"])[:3]
-            eng.set_mode(dict(auto=N.KD_MODE_AUTO, window=N.KD_MODE_WINDOW, **{"global": N.KD_MODE_GLOBAL})[m])
+            eng.set_mode({"auto": N.KD_MODE_AUTO, "window": N.KD_MODE_WINDOW, "global": N.KD_MODE_GLOBAL, "strip": N.KD_MODE_STRIP}[m])
             eng.set_tuning(int(w), int(s))
             step()
             eng.profile_enable(1)

@@ -60,6 +60,8 @@ enum {
 #define KD_MODE_AUTO 0   /* windowed LDS histograms, falling back per read where needed */
 #define KD_MODE_GLOBAL 1 /* one wavefront per read, 32-bit atomics straight into HBM     */
 #define KD_MODE_WINDOW 2 /* force the windowed path                                      */
+#define KD_MODE_STRIP 3  /* windowed planning, first pass by the site-major kernel k_strip (wavefront per 64-site
+                            strip, counters in registers, no LDS atomics): an independent second implementation  */
 
 typedef struct kd_ctx kd_ctx;
 

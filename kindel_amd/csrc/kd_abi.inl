@@ -41,7 +41,7 @@ const char *kd_last_error(const kd_ctx *ctx) { return ctx ? ctx->e.err.c_str() :
 int kd_reset(kd_ctx *ctx) { return ctx ? ctx->e.reset() : KD_E_ARG; }
 
 int kd_set_mode(kd_ctx *ctx, int mode) {
-    if (!ctx || mode < KD_MODE_AUTO || mode > KD_MODE_WINDOW) return KD_E_ARG;
+    if (!ctx || mode < KD_MODE_AUTO || mode > KD_MODE_STRIP) return KD_E_ARG;
     ctx->e.mode = mode;
     return KD_OK;
 }

@@ -305,9 +305,10 @@ struct KdEngine {
                     return hipfail("k_window");
                 return KD_OK;
             };
-            // First pass over the batch's short regular reads.  Default: k_strip, the site-major kernel (wavefront = strip of
-            // 64 sites, counters in registers); KD_MODE_WINDOW keeps the LDS-histogram kernel for it (cross-check, tunings).
-            // Planning is the same machinery with a "window" of one strip.
+            // First pass over the batch's short regular reads.  Default: k_window (LDS histograms).  KD_MODE_STRIP: k_strip, the
+            // site-major kernel (wavefront = strip of 64 sites, counters in registers) -- bit-identical, measured slower on
+            // MI355X, kept as an independent implementation.  Planning is the same machinery with a
+            // "window" of one strip.
             auto strip_pass = [&](const KdRInfo *info, uint64_t ne, bool in_order) -> int {
                 int rc2;
                 const uint32_t Ws = KD_STRIP;
@@ -355,8 +356,8 @@ struct KdEngine {
                     return hipfail("k_strip");
                 return KD_OK;
             };
-            if (mode == KD_MODE_WINDOW) rc = window_pass((const KdRInfo *)rinfo, n, sorted_input, nullptr, (uint32_t)KDS_B_MAXSPAN);
-            else rc = strip_pass((const KdRInfo *)rinfo, n, sorted_input);
+            if (mode == KD_MODE_STRIP) rc = strip_pass((const KdRInfo *)rinfo, n, sorted_input);
+            else rc = window_pass((const KdRInfo *)rinfo, n, sorted_input, nullptr, (uint32_t)KDS_B_MAXSPAN);
             if (rc) return rc;
             if (n_long && (rc = window_pass((const KdRInfo *)b_seginfo.p, n_long * KD_BLOCK, false, (const uint32_t *)lng,
                                             (uint32_t)KDS_B_MAXSEGSPAN)))

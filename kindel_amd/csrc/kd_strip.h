@@ -111,6 +111,9 @@ __device__ __forceinline__ void kd_stage_run(uint32_t *row, const uint8_t *seq, 
             src[t] = reinterpret_cast<const KdWord *>(seq + 4 * (int64_t)d)->v;
         }
     }
+    // the nine steps write dwords Kb .. Kb + 17; a later merge round of the same row may have the other Kb: make sure
+    // the slack dword it would read (and report as "bad base" garbage) is defined
+    if (first) { row[0] = KD_TRASH4; row[18] = KD_TRASH4; }
     const uint32_t A = (uint32_t)(0x80 - b0) * 0x01010101u, B = (uint32_t)(0x80 - hi_b) * 0x01010101u;
     const uint32_t pos0 = 0x03020100u + (uint32_t)Kb * 0x04040404u;
     uint32_t prev = 0u, lbad = 0u;

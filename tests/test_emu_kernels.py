@@ -11,7 +11,7 @@ from oracle import oracle as ko
 from tests import parity as P
 
 QUIRKS = P.golden_quirks()
-MODES = [N.KD_MODE_GLOBAL, N.KD_MODE_AUTO]
+MODES = [N.KD_MODE_GLOBAL, N.KD_MODE_AUTO, N.KD_MODE_STRIP]
 
 
 @pytest.mark.parametrize("mode", MODES)

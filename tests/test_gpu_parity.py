@@ -15,7 +15,7 @@ from tests import parity as P
 pytestmark = pytest.mark.gpu
 QUIRKS = P.golden_quirks()
 GOLD = P.golden_outputs()
-MODES = [N.KD_MODE_GLOBAL, N.KD_MODE_AUTO]
+MODES = [N.KD_MODE_GLOBAL, N.KD_MODE_AUTO, N.KD_MODE_STRIP]
 ROOT = P.ROOT
 
 
