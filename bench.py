@@ -204,7 +204,7 @@ def main():
             launches_per_step = rows[dom][0] / args.steps
             a = B / world / max(launches_per_step, 1) / (rows[dom][1] * 1e-3) / 1e9
             roofline = dict(bound="hbm", kernel=dom, achieved=round(a, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(a / HBM_PEAK_GBS, 5), traffic=_pmc_traffic(dom),
+                            frac=round(a / HBM_PEAK_GBS, 5), traffic=_pmc_traffic(dom), traffic_source=_PMC_SOURCE,
                             avg_launch_ms=round(rows[dom][1], 4),
                             algorithmic_bytes=int(B), bytes_per_event=round(B / max(aligned_g, 1), 4),
                             step_achieved=round(B / (dt / args.steps) / 1e9, 2),
@@ -220,7 +220,7 @@ def main():
                 reads=reads_g, aligned_events=aligned_g, walked_events=walked_g, cigar_ops=ops_g,
                 parallelism="interval-sharded x%d" % world if world > 1 else "single GPU",
                 pileup_path="window-lds" if info["windowed"] else "global-atomics",
-                window_sites=args.window or 2048, work_items=info["work_items"]),
+                window_sites=eng.tuning()[0], work_items=info["work_items"]),
             roofline=roofline,
             kernels={k: dict(launches_per_step=n / args.steps, avg_ms=round(avg, 4)) for k, (n, avg) in sorted(rows.items())},
             kernels_source="hipEvents per launch: %s inside the timed region, the others in an extra untimed pass of the same %d steps" % (
@@ -259,6 +259,11 @@ def main():
         dist.destroy_process_group()
 
 
+_PMC_SOURCE = ("profiles/pmc_traffic.json: STATIC, not measured in this run -- (FETCH_SIZE x k + WRITE_SIZE) x 1024 per launch from "
+               "the committed `rocprofv3 --pmc` passes of the same command (scripts/gpu_pmc.sh), k = the FETCH_SIZE factor "
+               "calibrated on this access pattern (profiles/fetch_calibration.json)")
+
+
 def _pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*pmc*.json), or None."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -271,12 +276,28 @@ def _pmc_traffic(kernel):
 
 
 def cpu_baseline(batch, contig_lens, gpu_seqs, sample, aligned_total):
-    """The C oracle (port of the reference's two loops) on ONE host core, same batch; bounded to
-    ~10-30 s by sub-sampling reads when the batch is large.  With the full batch it is also the
-    full-size bit-exactness check of the GPU consensus."""
+    """Two CPU figures on this box's host cores, both single-threaded (the reference is):
+    `reference_python`: the UNMODIFIED reference (kindel.kindel.parse_records + consensus_sequence) on a bounded sample of
+    the same workload -- measured live when /root/reference exists, else quoted from profiles/reference_python_baseline.json
+    with where / when it was measured;  value/kind "port": the C oracle (oracle/kindel_oracle.c, a statement-by-statement
+    port of those loops) over the same batch, bounded to ~10-30 s by sub-sampling reads when the batch is large -- with the
+    full batch it is also the full-size bit-exactness check of the GPU consensus."""
     from kindel_amd import synth
     from oracle import oracle as ko
     host = synth.to_numpy(batch)
+    refpy = None
+    try:
+        from oracle import refbaseline, refrun
+        if refrun.reference_available():
+            refpy = refbaseline.time_reference(host, 0, 4.0e7)
+            refpy["where"] = "this run, this box (%d host cores)" % os.cpu_count()
+    except Exception as e:   # the reference tree is test infrastructure of the build container only
+        refpy = dict(error=repr(e))
+    if refpy is None:
+        p = os.path.join(ROOT, "profiles", "reference_python_baseline.json")
+        if os.path.exists(p):
+            refpy = json.load(open(p))
+            refpy["note"] = "NOT measured in this run: /root/reference does not exist on this box; figure committed from the build container"
     n = len(host["contig"])
     frac = sample if sample > 0 else min(1.0, 4.0e9 / max(aligned_total, 1))  # the oracle walks ~7e8 events/s
     if int(round(1.0 / frac)) <= 1:
@@ -298,7 +319,8 @@ def cpu_baseline(batch, contig_lens, gpu_seqs, sample, aligned_total):
     return dict(value=ev / dt, unit="events/s", cores=1, kind="port", host_cores=os.cpu_count(),
                 sample="%s of the %d reads (%d aligned-base events), all contigs, pileup + consensus; %.1f s" % (
                     "all" if frac >= 1.0 else "every %d-th" % int(round(1.0 / frac)), n, ev, dt),
-                bit_exact_vs_gpu=(same if frac >= 1.0 else None))
+                bit_exact_vs_gpu=(same if frac >= 1.0 else None),
+                reference_python=refpy)
 
 
 if __name__ == "__main__":

@@ -43,6 +43,7 @@ extern "C" {
 #define KD_E_ARG (-6)    /* bad argument / bad state                                         */
 #define KD_E_IO (-7)     /* decoder: unreadable or malformed SAM/BAM                         */
 #define KD_E_INTERNAL (-8)
+#define KD_E_NOREF (-9)  /* KeyError   : a record names a reference without @SQ line   kindel.py:151 (message = the name) */
 
 /* table channels of kd_get_tables(); order of the reference's dicts is A,T,G,C,N (kindel.py:29) */
 enum {
@@ -104,6 +105,8 @@ int kd_reset(kd_ctx *ctx);
 int kd_set_mode(kd_ctx *ctx, int mode);
 /* window-path tuning (0 = keep default): sites per LDS window, reads per work item */
 int kd_set_tuning(kd_ctx *ctx, uint32_t window_sites, uint32_t slice_reads);
+/* the tuning in effect: out[0] = sites per LDS window, out[1] = reads per work item (0 = chosen per batch) */
+int kd_get_tuning(const kd_ctx *ctx, uint32_t out[2]);
 
 /* G-space geometry */
 uint64_t kd_contig_base(const kd_ctx *ctx, uint32_t contig);

@@ -16,15 +16,15 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libkindel_hip.so")
 
-KD_OK, KD_E_BASE, KD_E_RANGE, KD_E_CIGAR, KD_E_HIP, KD_E_NOMEM, KD_E_ARG, KD_E_IO, KD_E_INTERNAL = (
-    0, -1, -2, -3, -4, -5, -6, -7, -8)
+KD_OK, KD_E_BASE, KD_E_RANGE, KD_E_CIGAR, KD_E_HIP, KD_E_NOMEM, KD_E_ARG, KD_E_IO, KD_E_INTERNAL, KD_E_NOREF = (
+    0, -1, -2, -3, -4, -5, -6, -7, -8, -9)
 KD_MODE_AUTO, KD_MODE_GLOBAL, KD_MODE_WINDOW, KD_MODE_STRIP = 0, 1, 2, 3
 (KD_CH_A, KD_CH_T, KD_CH_G, KD_CH_C, KD_CH_N, KD_CH_DEL, KD_CH_CSW, KD_CH_CEW, KD_CH_CLIP_STARTS,
  KD_CH_CLIP_ENDS, KD_CH_INS_TOTAL, KD_NCH) = (0, 1, 2, 3, 4, 5, 6, 11, 16, 17, 18, 19)
 
 #: every symbol include/kindel_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
-    "kd_abi_version kd_create kd_destroy kd_last_error kd_reset kd_set_mode kd_set_tuning kd_contig_base "
+    "kd_abi_version kd_create kd_destroy kd_last_error kd_reset kd_set_mode kd_set_tuning kd_get_tuning kd_contig_base "
     "kd_total_sites kd_set_shard kd_push_batch kd_push_batch_device kd_sync kd_finalize kd_get_stats "
     "kd_get_batch_info kd_get_tables kd_get_insertions kd_consensus_run kd_consensus_fetch kd_consensus_fetch_all kd_consensus_device kd_changes_device kd_consensus_offsets "
     "kd_profile_enable kd_profile_get kd_profile_reset kd_decode_open kd_decode_batch kd_decode_n_contigs "
@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
 
 #: the reference exception each error code stands for (kindel.py:47,51-52,57,61,67,72,75,79)
 _EXC = {KD_E_BASE: KeyError, KD_E_RANGE: IndexError, KD_E_CIGAR: RuntimeError, KD_E_NOMEM: MemoryError,
-        KD_E_IO: OSError}
+        KD_E_IO: OSError, KD_E_NOREF: KeyError}
 
 
 class KindelNativeError(RuntimeError):
@@ -74,6 +74,7 @@ class Library:
         L.kd_reset.argtypes = [p]
         L.kd_set_mode.argtypes = [p, C.c_int]
         L.kd_set_tuning.argtypes = [p, u32, u32]
+        L.kd_get_tuning.argtypes = [p, C.POINTER(C.c_uint32)]
         L.kd_contig_base.argtypes = [p, u32]
         L.kd_contig_base.restype = u64
         L.kd_total_sites.argtypes = [p]
@@ -151,6 +152,8 @@ def decode_file(path, threads=0, lib=None):
     lib = lib or default_library()
     h = C.c_void_p()
     rc = lib.dll.kd_decode_open(C.byref(h), os.fsencode(str(path)), int(threads))
+    if rc == KD_E_NOREF:   # refs_lens[ref_id] of kindel.py:151: KeyError(<the unknown reference name>)
+        raise KeyError(lib.dll.kd_decode_last_error().decode())
     if rc:
         raise _EXC.get(rc, KindelNativeError)("%s: %s" % (path, lib.dll.kd_decode_last_error().decode()))
     owner = _DecodedFile(lib, h)
@@ -218,6 +221,12 @@ class Engine:
 
     def set_tuning(self, window_sites=0, slice_reads=0):
         self._check(self.lib.dll.kd_set_tuning(self._h, window_sites, slice_reads), "kd_set_tuning")
+
+    def tuning(self):
+        """-> (sites per LDS window, reads per work item or 0 = chosen per batch) in effect"""
+        out = (C.c_uint32 * 2)()
+        self._check(self.lib.dll.kd_get_tuning(self._h, out), "kd_get_tuning")
+        return int(out[0]), int(out[1])
 
     def set_shard(self, g_lo, g_hi):
         self._check(self.lib.dll.kd_set_shard(self._h, g_lo, g_hi), "kd_set_shard")

@@ -56,6 +56,12 @@ int kd_set_tuning(kd_ctx *ctx, uint32_t window_sites, uint32_t slice_reads) {
     return KD_OK;
 }
 
+int kd_get_tuning(const kd_ctx *ctx, uint32_t out[2]) {
+    if (!ctx || !out) return KD_E_ARG;
+    out[0] = ctx->e.W; out[1] = ctx->e.slice_cfg;
+    return KD_OK;
+}
+
 uint64_t kd_contig_base(const kd_ctx *ctx, uint32_t contig) {
     return (ctx && contig < ctx->e.n_contigs) ? ctx->e.cbase[contig] : ~0ULL;
 }

@@ -91,8 +91,9 @@ __device__ __forceinline__ uint32_t kd_alignbyte(uint32_t hi, uint32_t lo, uint3
 
 // device status words (kd_u64 each)
 enum {
-    KDS_ERR_READ = 0,   // atomicMin of the global index of the first failing read (init ~0)
-    KDS_ERR_CODE,       // written by k_diagnose
+    KDS_ERR_READ = 0,   // smallest global index of a failing read (init ~0): "some read failed"; WHICH exception is
+                        // reported is decided per contig (KdTabs::err_first / err_code)
+    KDS_ERR_CODE,       // (unused)
     KDS_N_EV,           // insertion events used
     KDS_POOL,           // insertion pool bytes used
     KDS_ST_READS,       // reads counted
@@ -128,6 +129,11 @@ struct KdTabs {
     const uint32_t *contig_len;  // [n_contigs]
     const kd_u64 *contig_base;   // [n_contigs]
     kd_u64 g_lo, g_hi;           // commit increments with g_lo <= g <= g_hi (g_hi = halo site)
+    // The reference walks the records contig by contig, contigs in order of first appearance (kindel.py:143-151), so the
+    // exception it raises is that of the first failing read of the EARLIEST-APPEARING contig that has one:
+    kd_u64 *first_idx;           // [n_contigs] global index of the contig's first record (k_prep), ~0 = none yet
+    kd_u64 *err_first;           // [n_contigs] global index of the contig's first failing read, ~0 = none
+    uint32_t *err_code;          // [n_contigs] its exception (k_diagnose): 1 KeyError, 2 IndexError, 3 RuntimeError
 };
 
 struct KdReads {
@@ -236,4 +242,7 @@ __device__ __forceinline__ void kd_block_scan2(TA *sa, TB *sb, TA *ga, TB *gb, T
     __syncthreads();   // the scratch arrays may be reused by the caller
 }
 
-__device__ __forceinline__ void kd_flag_error(kd_u64 *status, kd_u64 gidx) { atomicMin(&status[KDS_ERR_READ], gidx); }
+__device__ __forceinline__ void kd_flag_error(const KdTabs &T, kd_u64 *status, uint32_t contig, kd_u64 gidx) {
+    atomicMin(&T.err_first[contig], gidx);
+    atomicMin(&status[KDS_ERR_READ], gidx);
+}

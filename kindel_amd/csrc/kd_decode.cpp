@@ -24,7 +24,7 @@
 
 namespace {
 
-std::string g_decode_error;
+thread_local std::string g_decode_error;   // per thread: concurrent kd_decode_open calls do not share it
 
 // Growable array WITHOUT value-initialisation: resize() of a fresh array does not touch the pages, so the
 // worker threads that fill it take the page faults in parallel (a zero-filling std::vector::resize of a few
@@ -204,7 +204,41 @@ int parse_bam(const Arr<uint8_t> &d, File &f, int n_threads) {
     // offset from which KD_SPEC_CHAIN consecutive records look well-formed -- and walks from there; afterwards the
     // hand-offs are verified (the walk of range t-1 must END exactly on the start range t guessed), and any range whose
     // guess was wrong is re-walked from the true position.  The result is identical to the sequential walk.
-    struct Rec { uint64_t at; uint32_t sb, nc; };   // record body offset, packed-base bytes, CIGAR words
+    // record body offset, packed-base bytes, CIGAR words, and -- for a read with more than 65535 CIGAR operations, which
+    // BAM stores as the placeholder <l_seq>S<ref_len>N with the real CIGAR in the CG:B,I tag (SAMv1 4.2.2) -- the offset
+    // of the tag's array (0 = the in-record CIGAR)
+    struct Rec { uint64_t at; uint32_t sb, nc; uint64_t cg_at; };
+    // the CG:B,I array of the record body r (bs bytes), if its CIGAR is the placeholder: -> element count, *at = offset
+    auto real_cigar = [&](const uint8_t *r, uint32_t bs, uint32_t l_rn, uint32_t n_cig, uint32_t l_seq, uint64_t *at) -> uint32_t {
+        *at = 0;
+        if (n_cig != 2) return n_cig;
+        const uint8_t *cg = r + 32 + l_rn;
+        const uint32_t c0 = rd32(cg), c1 = rd32(cg + 4);
+        if ((c0 & 15u) != 4u || (c0 >> 4) != l_seq || (c1 & 15u) != 3u) return n_cig;
+        size_t a = 32 + (size_t)l_rn + 8 + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+        while (a + 3 <= bs) {
+            const uint8_t t0 = r[a], t1 = r[a + 1], ty = r[a + 2];
+            a += 3;
+            size_t len = 0;
+            if (ty == 'A' || ty == 'c' || ty == 'C') len = 1;
+            else if (ty == 's' || ty == 'S') len = 2;
+            else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
+            else if (ty == 'Z' || ty == 'H') { while (a + len < bs && r[a + len]) len++; len++; }
+            else if (ty == 'B') {
+                if (a + 5 > bs) return n_cig;
+                const uint8_t sub = r[a];
+                const uint32_t cnt = rd32(r + a + 1);
+                const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                if (t0 == 'C' && t1 == 'G' && sub == 'I' && a + 5 + 4 * (size_t)cnt <= bs) {
+                    *at = (uint64_t)(r - d.data()) + a + 5;
+                    return cnt;
+                }
+                len = 5 + es * (size_t)cnt;
+            } else return n_cig;   // unknown type: cannot skip it
+            a += len;
+        }
+        return n_cig;
+    };
     auto plausible = [&](size_t q) -> size_t {      // 0, or the offset of the record after the one at q
         if (q + 36 > n) return 0;
         const uint32_t bs = rd32(d.data() + q);
@@ -229,7 +263,9 @@ int parse_bam(const Arr<uint8_t> &d, File &f, int n_threads) {
                 if ((uint32_t)refid >= n_ref) { err = "BAM record with refID out of range"; return false; }
                 const uint32_t l_rn = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
                 if (32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 > bs) { err = "malformed BAM record"; return false; }
-                out.push_back({q + 4, (uint32_t)(((size_t)l_seq + 1) / 2), n_cig});
+                uint64_t cg_at = 0;
+                const uint32_t nc = real_cigar(r, bs, l_rn, n_cig, l_seq, &cg_at);
+                out.push_back({q + 4, (uint32_t)(((size_t)l_seq + 1) / 2), nc, cg_at});
             }
             q += 4 + bs;
         }
@@ -304,15 +340,16 @@ int parse_bam(const Arr<uint8_t> &d, File &f, int n_threads) {
             f.pos0[k] = (int32_t)rd32(r + 4);
             f.flag[k] = rd16(r + 14);
             f.seq_len[k] = l_seq;
-            f.n_cig[k] = n_cig;
+            f.n_cig[k] = rc.nc;
             f.cig_off[k] = co;
             f.seq_off[k] = so;
             const uint8_t *cg = r + 32 + l_rn;
-            for (uint32_t c = 0; c < n_cig; c++) f.cigar[co + c] = rd32(cg + 4 * c);
+            const uint8_t *cgs = rc.cg_at ? d.data() + rc.cg_at : cg;   // CG:B,I tag or the in-record CIGAR
+            for (uint32_t c = 0; c < rc.nc; c++) f.cigar[co + c] = rd32(cgs + 4 * c);
             const size_t sb = ((size_t)l_seq + 1) / 2;
             memcpy(f.seq4.data() + so, cg + 4 * (size_t)n_cig, sb);
             if (l_seq & 1) f.seq4[so + sb - 1] &= 0xf0;
-            k++; so += sb; co += n_cig;
+            k++; so += sb; co += rc.nc;
         }
     };
     std::vector<std::thread> th;
@@ -330,24 +367,29 @@ struct SamPart {
     Arr<uint8_t> seq4;
     uint64_t n_records = 0;
     std::string err;
+    int err_code = KD_E_IO;
 };
 
 int parse_sam(const Arr<uint8_t> &raw, File &f, int n_threads) {
-    static int8_t nibtab[256];
-    static int8_t optab[256];
-    static bool init = false;
-    if (!init) {
-        memset(nibtab, 0, sizeof nibtab);  // unknown characters -> '=' (0): a KeyError in M / clip context
-        memset(optab, 15, sizeof optab);   // unknown CIGAR letters are ignored by the reference's if/elif chain
-        const char *nibs = "=ACMGRSVTWYHKDBN";
-        for (int i = 0; i < 16; i++) {
-            nibtab[(uint8_t)nibs[i]] = (int8_t)i;
-            nibtab[(uint8_t)tolower(nibs[i])] = (int8_t)i;
+    // character -> BAM base code / CIGAR op code; built once (C++11 static initialisation is thread-safe)
+    struct Tables {
+        int8_t nib[256], op[256];
+        uint8_t known[256];
+        Tables() {
+            memset(nib, 0, sizeof nib);     // characters outside the BAM alphabet -> '=' (0): a KeyError in M / clip context
+            memset(op, 15, sizeof op);      // unknown CIGAR letters are ignored by the reference's if/elif chain
+            memset(known, 0, sizeof known);
+            const char *nibs = "=ACMGRSVTWYHKDBN";
+            for (int i = 0; i < 16; i++) {
+                nib[(uint8_t)nibs[i]] = (int8_t)i; nib[(uint8_t)tolower(nibs[i])] = (int8_t)i;
+                known[(uint8_t)nibs[i]] = 1; known[(uint8_t)tolower(nibs[i])] = 1;
+            }
+            const char *ops = "MIDNSHP=X";
+            for (int i = 0; i < 9; i++) op[(uint8_t)ops[i]] = (int8_t)i;
         }
-        const char *ops = "MIDNSHP=X";
-        for (int i = 0; i < 9; i++) optab[(uint8_t)ops[i]] = (int8_t)i;
-        init = true;
-    }
+    };
+    static const Tables TB;
+    const int8_t *nibtab = TB.nib, *optab = TB.op;
     std::unordered_map<std::string, uint32_t> ids;
     const char *base = (const char *)raw.data(), *end = base + raw.size();
     auto header_line = [&](const char *p, const char *e) -> bool {   // '@' line: only @SQ matters (kindel.py:138-141)
@@ -386,7 +428,7 @@ int parse_sam(const Arr<uint8_t> &raw, File &f, int n_threads) {
         std::string rname(fld[2], flen(2));
         if (rname == "*") return true;
         auto it = ids.find(rname);
-        if (it == ids.end()) { o.err = "RNAME '" + rname + "' has no @SQ line"; return false; }
+        if (it == ids.end()) { o.err = rname; o.err_code = KD_E_NOREF; return false; }   // refs_lens[ref_id], kindel.py:151
         o.contig.push_back(it->second);
         o.flag.push_back((uint32_t)strtoul(std::string(fld[1], flen(1)).c_str(), nullptr, 10));
         o.pos0.push_back((int32_t)(strtol(std::string(fld[3], flen(3)).c_str(), nullptr, 10) - 1));
@@ -410,10 +452,30 @@ int parse_sam(const Arr<uint8_t> &raw, File &f, int n_threads) {
         if (sl == 1 && *sq == '*') sl = 0;
         o.seq_off.push_back(o.seq4.size());
         o.seq_len.push_back((uint32_t)sl);
+        bool all_known = true;
         for (size_t i = 0; i < sl; i += 2) {
             const uint8_t hi = (uint8_t)nibtab[(uint8_t)sq[i]];
             const uint8_t lo = i + 1 < sl ? (uint8_t)nibtab[(uint8_t)sq[i + 1]] : 0;
+            all_known = all_known && TB.known[(uint8_t)sq[i]] && (i + 1 >= sl || TB.known[(uint8_t)sq[i + 1]]);
             o.seq4.push_back((uint8_t)(hi << 4 | lo));
+        }
+        if (!all_known) {
+            // A character outside "=ACMGRSVTWYHKDBN" cannot be stored in 4 bits.  Inside M / clip context it is a KeyError like
+            // any non-ACGTN base (code 0 raises it); inside an INSERTION the reference keeps the text verbatim
+            // (kindel.py:55-58, no alphabet check), which this encoding cannot reproduce: refuse loudly.
+            const uint32_t *cw = o.cigar.data() + o.cig_off[o.cig_off.size() - 1];
+            size_t qpos = 0;
+            for (uint32_t k = 0; k < nc; k++) {
+                const size_t len = cw[k] >> 4;
+                const uint32_t op = cw[k] & 15u;
+                if (op == 1)
+                    for (size_t x = qpos; x < qpos + len && x < sl; x++)
+                        if (!TB.known[(uint8_t)sq[x]]) {
+                            o.err = std::string("insertion contains '") + sq[x] + "', a character outside the BAM base alphabet (=ACMGRSVTWYHKDBN)";
+                            return false;
+                        }
+                if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qpos += len;
+            }
         }
         return true;
     };
@@ -465,7 +527,7 @@ int parse_sam(const Arr<uint8_t> &raw, File &f, int n_threads) {
         for (auto &x : th) x.join();
     }
     for (unsigned t = 0; t < nt; t++)
-        if (!ok[t]) { g_decode_error = part[t].err; return KD_E_IO; }   // the first failing range = the first failing line
+        if (!ok[t]) { g_decode_error = part[t].err; return part[t].err_code; }   // the first failing range = the first failing line
     std::vector<size_t> k_at(nt + 1, 0), sq_at(nt + 1, 0), cg_at(nt + 1, 0);
     for (unsigned t = 0; t < nt; t++) {
         k_at[t + 1] = k_at[t] + part[t].contig.size(); sq_at[t + 1] = sq_at[t] + part[t].seq4.size();

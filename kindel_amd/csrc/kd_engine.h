@@ -34,6 +34,8 @@ struct KdEngine {
 
     uint32_t *d_tab = nullptr, *d_clen = nullptr, *d_seg = nullptr;
     kd_u64 *d_cbase = nullptr, *d_status = nullptr;
+    kd_u64 *d_first_idx = nullptr, *d_err_first = nullptr;   // per contig: first record / first failing read (global indices)
+    uint32_t *d_err_code = nullptr;
     std::vector<kd_u64> h_status = std::vector<kd_u64>(KDS_COUNT, 0);
 
     // grow-only device buffers
@@ -86,6 +88,7 @@ struct KdEngine {
         KdTabs T;
         T.tab = d_tab; T.stride = S; T.contig_len = d_clen; T.contig_base = d_cbase;
         T.g_lo = g_lo; T.g_hi = g_hi;  // commit includes the halo site g_hi
+        T.first_idx = d_first_idx; T.err_first = d_err_first; T.err_code = d_err_code;
         return T;
     }
     KdIns insdesc() const {
@@ -115,7 +118,10 @@ struct KdEngine {
         d_cbase = (kd_u64 *)rt.alloc((size_t)n * 8);
         d_seg = (uint32_t *)rt.alloc((size_t)(S / 64) * 4);
         d_status = (kd_u64 *)rt.alloc(KDS_COUNT * 8);
-        if (!d_tab || !d_clen || !d_cbase || !d_seg || !d_status)
+        d_first_idx = (kd_u64 *)rt.alloc((size_t)n * 8);
+        d_err_first = (kd_u64 *)rt.alloc((size_t)n * 8);
+        d_err_code = (uint32_t *)rt.alloc((size_t)n * 4);
+        if (!d_tab || !d_clen || !d_cbase || !d_seg || !d_status || !d_first_idx || !d_err_first || !d_err_code)
             return fail(KD_E_NOMEM, "kd_create: device allocation failed (" + std::to_string((size_t)KDC_NCH * S * 4) + " table bytes): " + rt.err());
         std::vector<uint32_t> seg(S / 64, n - 1);
         for (uint32_t c = 0; c < n; c++) {
@@ -140,7 +146,10 @@ struct KdEngine {
         if (d_cbase) rt.free(d_cbase);
         if (d_seg) rt.free(d_seg);
         if (d_status) rt.free(d_status);
-        d_tab = d_clen = d_seg = nullptr; d_cbase = d_status = nullptr;
+        if (d_first_idx) rt.free(d_first_idx);
+        if (d_err_first) rt.free(d_err_first);
+        if (d_err_code) rt.free(d_err_code);
+        d_tab = d_clen = d_seg = d_err_code = nullptr; d_cbase = d_status = d_first_idx = d_err_first = nullptr;
         rt.shutdown();
     }
 
@@ -157,6 +166,9 @@ struct KdEngine {
         std::fill(h_status.begin(), h_status.end(), 0);
         h_status[KDS_ERR_READ] = ~0ULL;
         if (rt.h2d(d_status, h_status.data(), KDS_COUNT * 8)) return hipfail("reset: status");
+        if (rt.memset(d_first_idx, 0xff, (size_t)n_contigs * 8) || rt.memset(d_err_first, 0xff, (size_t)n_contigs * 8) ||
+            rt.memset(d_err_code, 0, (size_t)n_contigs * 4))
+            return hipfail("reset: per-contig error state");
         reads_pushed = 0; finalized = false; have_cns = false; have_inskeys = false;
         return KD_OK;
     }
@@ -383,7 +395,8 @@ struct KdEngine {
         }
         if (windowed && rt.launch("k_find_bad_base", k_find_bad_base, 1u, KD_BLOCK, 0, R, T, (const KdRInfo *)rinfo, d_status))
             return hipfail("k_find_bad_base");
-        if (rt.launch("k_diagnose", k_diagnose, 1u, KD_WAVE, 0, R, T, d_status)) return hipfail("k_diagnose");
+        if (rt.launch("k_diagnose", k_diagnose, (n_contigs + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, R, T, n_contigs, d_status))
+            return hipfail("k_diagnose");
         reads_pushed += n;
         finalized = false; have_cns = false; have_inskeys = false;
         return KD_OK;
@@ -429,9 +442,19 @@ struct KdEngine {
         }
 #endif
         if (h_status[KDS_ERR_READ] != ~0ULL) {
-            if (err_read) *err_read = h_status[KDS_ERR_READ];
-            const uint64_t code = h_status[KDS_ERR_CODE];
-            const std::string at = " (read " + std::to_string(h_status[KDS_ERR_READ]) + ")";
+            // the reference raises for the first failing read of the earliest-appearing contig (kindel.py:150-151)
+            std::vector<kd_u64> fi(n_contigs), ef(n_contigs);
+            std::vector<uint32_t> ec(n_contigs);
+            if (rt.d2h(fi.data(), d_first_idx, (size_t)n_contigs * 8) || rt.d2h(ef.data(), d_err_first, (size_t)n_contigs * 8) ||
+                rt.d2h(ec.data(), d_err_code, (size_t)n_contigs * 4))
+                return hipfail("finalize: error state d2h");
+            uint32_t cs = n_contigs;
+            for (uint32_t c = 0; c < n_contigs; c++)
+                if (ef[c] != ~0ULL && (cs == n_contigs || fi[c] < fi[cs])) cs = c;
+            const uint64_t rd_idx = cs < n_contigs ? ef[cs] : h_status[KDS_ERR_READ];
+            const uint64_t code = cs < n_contigs ? ec[cs] : 0;
+            if (err_read) *err_read = rd_idx;
+            const std::string at = " (read " + std::to_string(rd_idx) + ")";
             if (code == 1) return fail(KD_E_BASE, "base outside A,C,G,T,N in an aligned or clipped segment" + at);
             if (code == 2) return fail(KD_E_RANGE, "list index out of range: alignment runs off the reference" + at);
             if (code == 3) return fail(KD_E_CIGAR, "mapped read with CIGAR '*'" + at);

@@ -122,6 +122,9 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
             const uint32_t c = v_c[u];
             if (c != c_cached) { c_cached = c; cb_cached = T.contig_base[c]; L_cached = (int64_t)T.contig_len[c]; }
             const int64_t pos0 = v_pos[u];
+            // first record of its contig in the file (any record with that RNAME counts, kindel.py:143-145): only where
+            // the contig changes from one record to the next can a contig appear for the first time
+            if (i == 0 || v_pc[u] != c) atomicMin(&T.first_idx[c], rd.base_index + i);
             const kd_u64 gkey = cb_cached + (kd_u64)(pos0 > 0 ? pos0 : 0);
             {   // sortedness of G-start over ALL reads of the batch (window ranges rely on it)
                 const kd_u64 pcb = v_pc[u] == c ? cb_cached : T.contig_base[v_pc[u]];

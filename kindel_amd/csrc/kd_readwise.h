@@ -23,8 +23,8 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
     if ((rd.flag[i] & 4u) || sl <= 1) return;  // kindel.py:43-46
     const kd_u64 gidx = rd.base_index + i;
     const uint32_t nc = rd.n_cig[i];
-    if (nc == 0) { if (lane == 0) kd_flag_error(status, gidx); return; }  // kindel.py:47
     const uint32_t c = rd.contig[i];
+    if (nc == 0) { if (lane == 0) kd_flag_error(T, status, c, gidx); return; }  // kindel.py:47
     const int64_t L = T.contig_len[c];
     const kd_u64 cb = T.contig_base[c];
     const uint8_t *seq = rd.seq4 + rd.seq_off[i];
@@ -39,20 +39,20 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
         const int64_t len = w >> 4;
         const uint32_t op = w & 15u;
         if (op == 0 || op == 7 || op == 8) {  // M = X  kindel.py:49-54
-            if (len > 0 && (q + len > sl || r + len > L || r < -L)) { if (lane == 0) kd_flag_error(status, gidx); return; }
+            if (len > 0 && (q + len > sl || r + len > L || r < -L)) { if (lane == 0) kd_flag_error(T, status, c, gidx); return; }
             if (HOT) {
                 for (int64_t j = lane; j < len; j += KD_WAVE) {
                     int64_t idx = r + j;
                     if (idx < 0) idx += L;
                     const uint32_t ch = kd_chan(kd_nib(seq, q + j));
                     const kd_u64 g = cb + (kd_u64)idx;
-                    if (ch == 7u) kd_flag_error(status, gidx);
+                    if (ch == 7u) kd_flag_error(T, status, c, gidx);
                     else if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)ch * S + g], 1u);
                 }
             }
             r += len; q += len;
         } else if (op == 1) {  // I  kindel.py:55-58
-            if (r > L || r < -(L + 1)) { if (lane == 0) kd_flag_error(status, gidx); return; }
+            if (r > L || r < -(L + 1)) { if (lane == 0) kd_flag_error(T, status, c, gidx); return; }
             if (COLD) {
                 if (!ev_loaded) { ev_next = ins.read_ev[i]; pool_next = ins.read_pool[i]; ev_loaded = true; }
                 const int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
@@ -75,7 +75,7 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
             }
             q += len;
         } else if (op == 2) {  // D  kindel.py:59-62
-            if (len > 0 && (r + len - 1 > L || r < -(L + 1))) { if (lane == 0) kd_flag_error(status, gidx); return; }
+            if (len > 0 && (r + len - 1 > L || r < -(L + 1))) { if (lane == 0) kd_flag_error(T, status, c, gidx); return; }
             if (HOT) {
                 for (int64_t j = lane; j < len; j += KD_WAVE) {
                     int64_t idx = r + j;
@@ -87,7 +87,7 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
             r += len;
         } else if (op == 4) {  // S
             if (k == 0) {  // kindel.py:64-73
-                if (r > L || r < -(L + 1) || len > sl) { if (lane == 0) kd_flag_error(status, gidx); return; }
+                if (r > L || r < -(L + 1) || len > sl) { if (lane == 0) kd_flag_error(T, status, c, gidx); return; }
                 if (COLD) {
                     if (lane == 0) {
                         const kd_u64 g = cb + (kd_u64)(r < 0 ? r + L + 1 : r);
@@ -98,7 +98,7 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
                         if (rel >= 0) {
                             const uint32_t ch = kd_chan(kd_nib(seq, j));
                             const kd_u64 g = cb + (kd_u64)rel;
-                            if (ch == 7u) kd_flag_error(status, gidx);
+                            if (ch == 7u) kd_flag_error(T, status, c, gidx);
                             else if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)(KDC_CEW + ch) * S + g], 1u);
                         }
                     }
@@ -106,10 +106,10 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
                 q += len;
             } else {  // kindel.py:74-81
                 const int64_t x = r - 1;
-                if (x > L || x < -(L + 1)) { if (lane == 0) kd_flag_error(status, gidx); return; }
+                if (x > L || x < -(L + 1)) { if (lane == 0) kd_flag_error(T, status, c, gidx); return; }
                 const int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
                 if (n_adv > sl - q || (len > n_adv && q + n_adv >= sl) || (n_adv > 0 && r < -L)) {
-                    if (lane == 0) kd_flag_error(status, gidx);
+                    if (lane == 0) kd_flag_error(T, status, c, gidx);
                     return;
                 }
                 if (COLD) {
@@ -122,7 +122,7 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
                         if (idx < 0) idx += L;
                         const uint32_t ch = kd_chan(kd_nib(seq, q + j));
                         const kd_u64 g = cb + (kd_u64)idx;
-                        if (ch == 7u) kd_flag_error(status, gidx);
+                        if (ch == 7u) kd_flag_error(T, status, c, gidx);
                         else if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)(KDC_CSW + ch) * S + g], 1u);
                     }
                 }
@@ -258,12 +258,16 @@ k_cold_long(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint32_
     }
 }
 
-// k_diagnose: one thread re-walks the first failing read serially, in the reference's own
-// statement order, to decide WHICH exception the reference raises (KeyError vs IndexError
-// vs RuntimeError).  Error classification only -- it writes no table.
-__global__ void k_diagnose(KdReads rd, KdTabs T, kd_u64 *status) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const kd_u64 gidx = status[KDS_ERR_READ];
+// k_diagnose: one thread per contig re-walks the contig's first failing read of this batch serially, in the reference's
+// own statement order, to decide WHICH exception the reference raises (KeyError vs IndexError vs RuntimeError).
+// Error classification only -- it writes no table.  (A contig's first failing read is final once the batch that
+// contains it has been pushed: later batches only hold larger read indices.)
+__global__ void __launch_bounds__(KD_BLOCK)
+k_diagnose(KdReads rd, KdTabs T, uint32_t n_contigs, kd_u64 *status) {
+    if (status[KDS_ERR_READ] == ~0ULL) return;
+    const uint32_t cdx = blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (cdx >= n_contigs) return;
+    const kd_u64 gidx = T.err_first[cdx];
     if (gidx == ~0ULL || gidx < rd.base_index || gidx >= rd.base_index + rd.n) return;
     const kd_u64 i = gidx - rd.base_index;
     const int64_t sl = rd.seq_len[i];
@@ -272,7 +276,7 @@ __global__ void k_diagnose(KdReads rd, KdTabs T, kd_u64 *status) {
     const uint8_t *seq = rd.seq4 + rd.seq_off[i];
     const uint32_t *cg = rd.cigar + rd.cig_off[i];
     kd_u64 code = 8;  // KD_E_INTERNAL magnitude: flagged but no exception reproduced
-    if (nc == 0) { status[KDS_ERR_CODE] = 3; return; }
+    if (nc == 0) { T.err_code[cdx] = 3u; return; }
     int64_t r = rd.pos0[i], q = 0;
     for (uint32_t k = 0; k < nc && code == 8; k++) {
         const int64_t len = cg[k] >> 4;
@@ -323,5 +327,5 @@ __global__ void k_diagnose(KdReads rd, KdTabs T, kd_u64 *status) {
             }
         }
     }
-    status[KDS_ERR_CODE] = code;
+    T.err_code[cdx] = (uint32_t)code;
 }

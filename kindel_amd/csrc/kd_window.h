@@ -491,7 +491,7 @@ k_find_bad_base(KdReads rd, KdTabs T, const KdRInfo *rinfo, kd_u64 *status) {
     for (kd_u64 i = threadIdx.x; i < rd.n; i += KD_BLOCK) {
         const uint32_t cls_i = rinfo[i].span_cls & 3u;
         if (cls_i != KD_CLS_REG && cls_i != KD_CLS_LONG) continue;   // regular reads, short and long
-        if (rd.base_index + i >= status[KDS_ERR_READ]) continue;
+        if (rd.base_index + i >= T.err_first[rd.contig[i]]) continue;   // the contig already has an earlier failing read
         const uint8_t *seq = rd.seq4 + rd.seq_off[i];
         const uint32_t *cg = rd.cigar + rd.cig_off[i];
         const uint32_t nc = rd.n_cig[i];
@@ -512,6 +512,6 @@ k_find_bad_base(KdReads rd, KdTabs T, const KdRInfo *rinfo, kd_u64 *status) {
             for (int64_t x = x0; x < x1; x++)
                 if (kd_chan(kd_nib(seq, x)) == 7u) { found = true; break; }
         }
-        if (found) kd_flag_error(status, rd.base_index + i);
+        if (found) kd_flag_error(T, status, rd.contig[i], rd.base_index + i);
     }
 }

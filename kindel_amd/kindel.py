@@ -162,15 +162,31 @@ def _first_appearance(contig):
 
 
 def pileup_batch(batch, bam_path=None, device=0, lib=None, mode=N.KD_MODE_AUTO):
-    """Run the device record loop over one decoded batch -> Pileup (raises what the reference raises)."""
-    names = [str(x) for x in batch["contig_names"]]
-    lens = np.asarray(batch["contig_lens"], np.uint32)
-    if len(lens) == 0:
-        raise KeyError("no @SQ lines in header")
+    """Run the device record loop over one decoded batch -> Pileup (raises what the reference raises).
+
+    Only the contigs that HAVE records get device tables -- like the reference, which calls parse_records per RNAME
+    seen (kindel.py:143-151) and never allocates for header-only @SQ lines: a human-genome header with reads on chrM
+    costs chrM-sized tables, not 3 Gbp of them.  Contig ids are remapped to the dense ids of that subset (header
+    order); `names` / `lens` / `order` of the Pileup speak the dense ids."""
+    names_all = [str(x) for x in batch["contig_names"]]
+    lens_all = np.asarray(batch["contig_lens"], np.uint32)
+    contig = np.asarray(batch["contig"])
+    if len(contig) == 0:
+        return Pileup(None, [], np.zeros(0, np.uint32), [], bam_path)   # no records: parse_bam returns {} (kindel.py:143-152)
+    used = np.unique(contig)
+    if len(used) == len(lens_all):
+        sub, names, lens = batch, names_all, lens_all
+    else:
+        remap = np.zeros(len(lens_all), np.uint32)
+        remap[used] = np.arange(len(used), dtype=np.uint32)
+        sub = dict(batch)
+        sub["contig"] = remap[contig]
+        names = [names_all[int(i)] for i in used]
+        lens = lens_all[used]
     eng = N.Engine(lens, device=device, lib=lib, mode=mode)
-    eng.push(batch)
+    eng.push(sub)
     eng.finalize()
-    return Pileup(eng, names, lens, _first_appearance(np.asarray(batch["contig"])), bam_path)
+    return Pileup(eng, names, lens, _first_appearance(np.asarray(sub["contig"])), bam_path)
 
 
 def pileup_file(bam_path, device=0, lib=None, threads=0):
@@ -406,6 +422,8 @@ def _device_consensus_all(pl, patches_by_cid, trim_ends, min_depth, uppercase):
     """All contigs of the input with ONE consensus run and ONE device-to-host copy (the reference loops
     consensus_sequence over the contigs, kindel.py:515-551) -> {cid: (seq, changes, depth_minmax)}."""
     eng = pl.engine
+    if not pl.order:
+        return {}
     plans = {cid: _patch_plan(int(pl.lens[cid]), patches_by_cid.get(cid)) for cid in pl.order}
     flat, owner = [], []
     for cid in pl.order:

@@ -348,10 +348,16 @@ def write_bam(path, batch, names=None, sort_order="coordinate"):
         sl, nc = int(batch["seq_len"][i]), int(batch["n_cig"][i])
         so, co = int(batch["seq_off"][i]), int(batch["cig_off"][i])
         name = b"r%d\0" % i
-        rec = struct.pack("<iiBBHHHiiii", int(np.int32(batch["contig"][i])), int(batch["pos0"][i]), len(name), 60, 0, nc,
+        cig = batch["cigar"][co:co + nc].astype("<u4")
+        aux = b""
+        if nc > 65535:   # SAMv1 4.2.2: placeholder <l_seq>S<ref_len>N in the record, the real CIGAR in the CG:B,I tag
+            ref_len = int(sum(int(c) >> 4 for c in cig if (int(c) & 15) in (0, 2, 3, 7, 8)))
+            aux = b"CGBI" + struct.pack("<i", nc) + cig.tobytes()
+            cig = np.asarray([(sl << 4) | 4, (ref_len << 4) | 3], "<u4")
+        rec = struct.pack("<iiBBHHHiiii", int(np.int32(batch["contig"][i])), int(batch["pos0"][i]), len(name), 60, 0, len(cig),
                           int(batch["flag"][i]) & 0xffff, sl, -1, -1, 0)
-        rec += name + batch["cigar"][co:co + nc].astype("<u4").tobytes() + batch["seq4"][so:so + (sl + 1) // 2].tobytes()
-        rec += b"\xff" * sl
+        rec += name + cig.tobytes() + batch["seq4"][so:so + (sl + 1) // 2].tobytes()
+        rec += b"\xff" * sl + aux
         buf += struct.pack("<i", len(rec)) + rec
     with open(path, "wb") as fh:
         for o in range(0, len(buf), 0xff00):

@@ -252,18 +252,59 @@ def do_weights(K):
                 fixture_key(rel), "rel" if relative else "abs")), columns=np.asarray(list(df.columns)), **cols)
 
 
+def do_features(K):
+    """features() (kindel.py:633-664) of the reference on single-contig fixtures (it crashes on multi-contig input)."""
+    for rel in ("data_bwa_mem/1.1.sub_test.bam", "data_ext/3.issue23.bc75.sam", "data_ext/1.issue23.debug.sam"):
+        path = os.path.join(REF_ROOT, "tests", rel)
+        df = K.features(path)
+        cols = {c: df[c].to_numpy() for c in df.columns}
+        cols["chrom"] = cols["chrom"].astype(str)
+        np.savez_compressed(os.path.join(GOLD, "features_%s.npz" % fixture_key(rel)), columns=np.asarray(list(df.columns)), **cols)
+
+
+def do_fasta():
+    """The FASTA files the reference's own tests compare against (tests/test_kindel.py:114-124,143-158,181-238 and the
+    -r variants): record name -> sequence, per file."""
+    out = {}
+    for rel in FIXTURES:
+        for suffix, tag in ((".fa", "default"), (".realign.fa", "realign")):
+            path = os.path.join(REF_ROOT, "tests", rel.rsplit(".", 1)[0] + suffix)
+            if not os.path.exists(path):
+                continue
+            recs, name = {}, None
+            for line in open(path):
+                line = line.rstrip("\n")
+                if line.startswith(">"):
+                    name = line[1:].split()[0]
+                    recs[name] = ""
+                elif name is not None:
+                    recs[name] += line
+            out.setdefault(fixture_key(rel), {})[tag] = recs
+    with open(os.path.join(GOLD, "reference_fasta.json"), "w") as fh:
+        json.dump(out, fh, indent=0, sort_keys=True)
+    print("reference FASTA goldens:", sum(len(v) for v in out.values()), "files")
+
+
 def main():
+    only = set(sys.argv[1:])   # e.g. `python -m oracle.make_golden quirks features fasta` regenerates just those
     K = load_reference()
     os.makedirs(GOLD, exist_ok=True)
-    quirks = do_quirks(K)
-    quirks["__patches__"] = do_patch_cases(K)
-    with open(os.path.join(GOLD, "quirks.json"), "w") as fh:
-        json.dump(quirks, fh, indent=0, sort_keys=True)
-    print("quirk cases:", len(quirks), "raising:", sum("raises" in v for v in quirks.values()))
-    fx = do_fixtures(K)
-    with open(os.path.join(GOLD, "reference_outputs.json"), "w") as fh:
-        json.dump(fx, fh, indent=0, sort_keys=True)
-    do_weights(K)
+    if not only or "quirks" in only:
+        quirks = do_quirks(K)
+        quirks["__patches__"] = do_patch_cases(K)
+        with open(os.path.join(GOLD, "quirks.json"), "w") as fh:
+            json.dump(quirks, fh, indent=0, sort_keys=True)
+        print("quirk cases:", len(quirks), "raising:", sum("raises" in v for v in quirks.values()))
+    if not only or "fixtures" in only:
+        fx = do_fixtures(K)
+        with open(os.path.join(GOLD, "reference_outputs.json"), "w") as fh:
+            json.dump(fx, fh, indent=0, sort_keys=True)
+    if not only or "weights" in only:
+        do_weights(K)
+    if not only or "features" in only:
+        do_features(K)
+    if not only or "fasta" in only:
+        do_fasta()
     print("done")
 
 

@@ -102,6 +102,13 @@ CASES = {
     "nonfirst_S_at_slot_L": _mk(_HDR1, ("a", 0, "c1", 32, "4P0H6S", "ACGTA")),
     "ERR_eq_base_in_M": _mk(_HDR1, ("a", 0, "c1", 2, "4M", "AC=T")),
     "ERR_second_contig_only": _mk(_HDR2, ("a", 0, "c1", 3, "4M", "ACGT"), ("b", 0, "c2", 18, "6M", "ACGTAC")),
+    # several invalid reads: the reference walks contig by contig in order of first appearance (kindel.py:143-151), so
+    # it raises for the first failing read of the earliest-appearing contig, not for the first failing read of the file
+    "ERR_order_first_contig_wins_IndexError": _mk(_HDR2, ("a", 0, "c1", 3, "4M", "ACGT"), ("b", 0, "c2", 3, "4M", "ACRT"),
+                                                  ("c", 0, "c1", 28, "6M", "ACGTAC")),
+    "ERR_order_first_contig_wins_KeyError": _mk(_HDR2, ("a", 0, "c2", 3, "4M", "ACGT"), ("b", 0, "c1", 28, "6M", "ACGTAC"),
+                                                ("c", 0, "c2", 3, "4M", "ACRT")),
+    "ERR_order_within_contig_file_order": _mk(_HDR2, ("a", 0, "c1", 28, "6M", "ACGTAC"), ("b", 0, "c1", 3, "4M", "ACRT")),
 }
 
 #: option sets every non-error case is run with: (min_depth, trim_ends, uppercase)

@@ -76,37 +76,55 @@ SYN = {
 }
 
 
+def _check_device_resident(hip_lib, tb, mode, what):
+    """Device-resident batch through the C-ABI: every table, insertion dict, consensus byte and change code vs the oracle."""
+    host = synth.to_numpy(tb)
+    eng = N.Engine(host["contig_lens"], lib=hip_lib, mode=mode)
+    try:
+        eng.push_device(synth.device_ptrs(tb), tb["contig"].numel(), tb["seq4_bytes"], tb["cigar_words"])
+        eng.finalize()
+        info, stats = eng.batch_info(), eng.stats()
+        assert info["windowed"] == (0 if mode == N.KD_MODE_GLOBAL else 1)
+        reads, aligned, walked = synth.counts(tb)
+        assert stats["aligned"] == aligned and stats["walked"] == walked and stats["reads"] == reads
+        eng.consensus_run(1)
+        tot_w = 0
+        for cid in ko.contig_order(host):
+            oa = ko.parse_records(host, cid)
+            t, L = eng.tables(cid), oa.L
+            assert np.array_equal(t[0:5, :L].T, oa.weights) and np.array_equal(t[5], oa.deletions), what
+            assert np.array_equal(t[6:11, :L].T, oa.clip_start_weights) and np.array_equal(t[11:16, :L].T, oa.clip_end_weights)
+            assert np.array_equal(t[16], oa.clip_starts) and np.array_equal(t[17], oa.clip_ends)
+            assert np.array_equal(t[18], oa.ins_totals)
+            site, count, strings = eng.insertions(cid)
+            assert sorted((int(p), s, int(c)) for p, c, s in zip(site, count, strings)) == sorted(oa.insertions)
+            seq, ch, mm, _ = eng.consensus_fetch(cid)
+            oseq, och = oa.consensus_sequence()
+            assert seq.decode() == oseq and [None if c == 0 else chr(c) for c in ch] == och, what
+            assert mm == oa.depth_minmax()
+            tot_w += int(t[0:5].sum())
+        assert tot_w == aligned   # size-independent property: every aligned base lands in exactly one counter
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("cfg", sorted(SYN))
 def test_synthetic_config_device_resident(hip_lib, cfg, mode):
     """BASELINE.json configs (scaled so the oracle finishes in seconds), inputs resident in HBM."""
-    tb = SYN[cfg]("cuda:0")
-    host = synth.to_numpy(tb)
-    eng = N.Engine(host["contig_lens"], lib=hip_lib, mode=mode)
-    eng.push_device(synth.device_ptrs(tb), tb["contig"].numel(), tb["seq4_bytes"], tb["cigar_words"])
-    eng.finalize()
-    info, stats = eng.batch_info(), eng.stats()
-    assert info["windowed"] == (0 if mode == N.KD_MODE_GLOBAL else 1)
-    reads, aligned, walked = synth.counts(tb)
-    assert stats["aligned"] == aligned and stats["walked"] == walked and stats["reads"] == reads
-    eng.consensus_run(1)
-    tot_w = 0
-    for cid in ko.contig_order(host):
-        oa = ko.parse_records(host, cid)
-        t, L = eng.tables(cid), oa.L
-        assert np.array_equal(t[0:5, :L].T, oa.weights) and np.array_equal(t[5], oa.deletions), cfg
-        assert np.array_equal(t[6:11, :L].T, oa.clip_start_weights) and np.array_equal(t[11:16, :L].T, oa.clip_end_weights)
-        assert np.array_equal(t[16], oa.clip_starts) and np.array_equal(t[17], oa.clip_ends)
-        assert np.array_equal(t[18], oa.ins_totals)
-        site, count, strings = eng.insertions(cid)
-        assert sorted((int(p), s, int(c)) for p, c, s in zip(site, count, strings)) == sorted(oa.insertions)
-        seq, ch, mm, _ = eng.consensus_fetch(cid)
-        oseq, och = oa.consensus_sequence()
-        assert seq.decode() == oseq and [None if c == 0 else chr(c) for c in ch] == och
-        assert mm == oa.depth_minmax()
-        tot_w += int(t[0:5].sum())
-    assert tot_w == aligned   # size-independent property: every aligned base lands in exactly one counter
-    eng.close()
+    _check_device_resident(hip_lib, SYN[cfg]("cuda:0"), mode, cfg)
+
+
+@pytest.mark.parametrize("cfg,mode", [("C2", N.KD_MODE_AUTO), ("C2", N.KD_MODE_STRIP), ("C3", N.KD_MODE_AUTO), ("C3", N.KD_MODE_STRIP),
+                                      ("C4", N.KD_MODE_AUTO), ("C5", N.KD_MODE_AUTO)])
+def test_full_size_config_device_resident(hip_lib, cfg, mode):
+    """BASELINE.json configs 2-5 at FULL size (C2 10 kb x 10^4, C3 5 Mbp x 500, C4 100 x 50 kb x 1000, C5 1 Mbp x 200
+    long reads): every table of every contig, the insertion dicts and the consensus against the oracle, bit for bit."""
+    import torch
+    tb = synth.make(cfg, device="cuda:0")
+    _check_device_resident(hip_lib, tb, mode, cfg + " full size")
+    del tb
+    torch.cuda.empty_cache()
 
 
 def test_host_push_equals_device_push(hip_lib):
@@ -231,6 +249,23 @@ def test_cli_consensus_stdout(hip_lib, tmp_path):
     r = subprocess.run([sys.executable, "-m", "kindel_amd", "consensus", "-r", "-t", "-u", path], cwd=ROOT,
                        capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.split("\n")[1] == g["realign_consensus"].strip("N").upper()
+
+
+@pytest.mark.parametrize("key,tag", __import__("tests.refcheck", fromlist=["x"]).FASTA_CASES)
+def test_reference_fasta(hip_lib, tmp_path, key, tag):
+    """The 21 FASTA files the reference's own CLI tests compare with (tests/golden/reference_fasta.json)."""
+    from kindel_amd import kindel as K
+    from tests import refcheck as RC
+    RC.check_reference_fasta(K, tmp_path, key, tag)
+
+
+def test_features_and_derived_arrays(hip_lib, tmp_path):
+    from kindel_amd import kindel as K
+    from tests import refcheck as RC
+    for key in RC.FEATURE_KEYS:
+        RC.check_features(K, tmp_path, key)
+    for key in ("bwa_mem__2.1.sub_test", "minimap2__1.1.multi", "ext__1.issue23.debug", "segemehl__4.1.sub_test"):
+        RC.check_derived_arrays(K, tmp_path, key, GOLD)
 
 
 def test_fetch_all_equals_per_contig_fetch(hip_lib):
