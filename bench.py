@@ -53,6 +53,11 @@ def main():
     ap.add_argument("--sweep", default="", help="extra tunings to time on the same batch: mode:window:slice,...")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; "
                     "gloo only to exercise the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = N copies of the config's contig set, one per rank (per-GPU work fixed); strong = ONE "
+                         "config-sized input, work-balanced contiguous position intervals (whole contigs where possible), every "
+                         "rank takes its reads from the one shared batch (total work fixed)")
+    ap.add_argument("--one-scaling", action="store_true", help="N > 1: do not also measure the other scaling rule")
     ap.add_argument("--shuffle", action="store_true", help="permute the read order (unsorted input: exercises the device bucket sort)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=0.0, help="fraction of reads for the CPU baseline (0 = auto)")
@@ -80,155 +85,192 @@ def main():
     if os.environ.get("KD_BENCH_LIB"):   # profiling builds (e.g. hipcc -DKD_PHASE_CLOCKS): a differently built library, never the default
         from kindel_amd import _native as _N
         _N._default = _N.Library(os.environ["KD_BENCH_LIB"])
-    cfg = dict(synth.CONFIGS[args.config])
-    for kv in args.synth:            # sensitivity runs only, e.g. --synth clip_p=0 --synth indel_p=0 --synth planted=0
-        k, v = kv.split("=")
-        cfg[k] = float(v) if "." in v else int(v)
-    if world > 1 and cfg["kind"] != "short":
-        raise SystemExit("multi-GPU bench: short-read configs only (C2, C3, C4)")
-    cfg["contig_lens"] = list(cfg["contig_lens"]) * world  # weak scaling: one config-sized interval per rank
-    cfg["depth"] = cfg["depth"] * args.scale
-    contig_lens = cfg["contig_lens"]
-    t0 = time.time()
-    batch = synth.make(cfg, device=dev, shard=(rank, world) if world > 1 else None)
-    torch.cuda.synchronize()
-    t_gen = time.time() - t0
-    n_reads = int(batch["contig"].numel())
-    if args.shuffle:
-        perm = torch.randperm(n_reads, device=dev)
-        for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
-            batch[k] = batch[k][perm].contiguous()
-    # events are credited to the rank that owns the read's start, so every read counts once
-    if world > 1:
-        own = shard.owned_mask(contig_lens, batch["contig"], batch["pos0"], rank, world)
-        cg_owner = torch.repeat_interleave(own, batch["n_cig"].long())
-        cg = batch["cigar"][: batch["cigar_words"]].long()[cg_owner]
-        n_owned = int(own.sum())
-    else:
-        cg = batch["cigar"][: batch["cigar_words"]].long()
-        n_owned = n_reads
-    ln, op = cg >> 4, cg & 15
-    aligned = int(ln[(op == 0) | (op == 7) | (op == 8)].sum())
-    query = aligned + int(ln[(op == 1) | (op == 4)].sum())
-    walked = query + int(ln[op == 2].sum())
-    n_ops = int(cg.numel())
-    tot = torch.tensor([aligned, query, walked, n_ops, n_owned], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(tot)
-    aligned_g, query_g, walked_g, ops_g, reads_g = (int(x) for x in tot.cpu())
-
-    mode = {"auto": N.KD_MODE_AUTO, "window": N.KD_MODE_WINDOW, "global": N.KD_MODE_GLOBAL, "strip": N.KD_MODE_STRIP}[args.mode]
-    eng = N.Engine(np.asarray(contig_lens, np.uint32), device=dev_index, mode=mode)
-    if args.window or args.slice:
-        eng.set_tuning(args.window, args.slice)
-    interval = shard.partition(contig_lens, world)[rank] if world > 1 else (0, eng.total_sites())
-    ptrs = synth.device_ptrs(batch)
-    n_contigs = len(contig_lens)
-
-    if world > 1:
-        eng.set_shard(*interval)
-
-    # one pinned host buffer for the consensus bytes of all contigs: a single D2H copy, no pageable staging
-    pinned = torch.empty(sum(int(l) + int(l) // 8 for l in contig_lens) + 4096, dtype=torch.uint8, pin_memory=True)
-    pinned_np = pinned.numpy()
-
-    state = {}
-
-    def step():
-        eng.reset()
-        eng.push_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"])
-        eng.finalize()
-        eng.consensus_run(1)
-        # this rank's consensus bytes -> pinned host memory (at N = 1 that is the whole FASTA) ...
-        off = eng.consensus_fetch_all_into(pinned_np)
-        seqs = [pinned_np[int(off[c]): int(off[c + 1])] for c in range(n_contigs)]
-        # ... and, at N > 1, the all-gather that leaves the stitched consensus in every GPU's HBM
-        if world > 1:
-            state["gathered"] = shard.gather(eng, interval, dev)[0]
-        return seqs
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        eng.sync()
+    def run(scaling):
+        """One complete measurement (generation, warm-up, K timed steps, per-kernel pass) under one scaling rule."""
+        cfg = dict(synth.CONFIGS[args.config])
+        for kv in args.synth:            # sensitivity runs only, e.g. --synth clip_p=0 --synth indel_p=0 --synth planted=0
+            k, v = kv.split("=")
+            cfg[k] = float(v) if "." in v else int(v)
+        if world > 1 and cfg["kind"] != "short":
+            raise SystemExit("multi-GPU bench: short-read configs only (C2, C3, C4)")
+        strong = world > 1 and scaling == "strong"
+        if not strong:
+            cfg["contig_lens"] = list(cfg["contig_lens"]) * world  # weak scaling: one config-sized interval per rank
+        cfg["depth"] = cfg["depth"] * args.scale
+        contig_lens = cfg["contig_lens"]
+        t0 = time.time()
+        intervals = None
+        if strong:
+            # one shared input (the same seeded batch on every rank, standing in for one decoded file), split by work
+            batch = synth.make(cfg, device=dev)
+            intervals = shard.partition_weighted(contig_lens, batch["contig"], batch["pos0"], batch["seq_len"], world)
+            span_hi = batch["pos0"] + batch["seq_len"].to(batch["pos0"].dtype) + 64    # footprint <= query length + deletions
+            keep = shard.reads_of_rank(contig_lens, batch["contig"], batch["pos0"], span_hi, rank, world, intervals=intervals)
+            full_cigar, full_words = batch["cigar"], batch["cigar_words"]
+            full_ncig = batch["n_cig"]
+            for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+                batch[k] = batch[k][keep].contiguous()     # routed: this rank's reads (bases / CIGAR words stay where they are)
+        else:
+            batch = synth.make(cfg, device=dev, shard=(rank, world) if world > 1 else None)
         torch.cuda.synchronize()
+        t_gen = time.time() - t0
+        n_reads = int(batch["contig"].numel())
+        if args.shuffle:
+            perm = torch.randperm(n_reads, device=dev)
+            for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+                batch[k] = batch[k][perm].contiguous()
+        # events are credited to the rank that owns the read's start, so every read counts once
+        if strong:      # every rank holds the whole CIGAR array: the totals of the ONE input, no reduction needed
+            cg = full_cigar[: full_words].long()
+            n_owned = int(full_ncig.numel())
+        elif world > 1:
+            own = shard.owned_mask(contig_lens, batch["contig"], batch["pos0"], rank, world)
+            cg_owner = torch.repeat_interleave(own, batch["n_cig"].long())
+            cg = batch["cigar"][: batch["cigar_words"]].long()[cg_owner]
+            n_owned = int(own.sum())
+        else:
+            cg = batch["cigar"][: batch["cigar_words"]].long()
+            n_owned = n_reads
+        ln, op = cg >> 4, cg & 15
+        aligned = int(ln[(op == 0) | (op == 7) | (op == 8)].sum())
+        query = aligned + int(ln[(op == 1) | (op == 4)].sum())
+        walked = query + int(ln[op == 2].sum())
+        n_ops = int(cg.numel())
+        tot = torch.tensor([aligned, query, walked, n_ops, n_owned], dtype=torch.int64, device=dev)
+        if world > 1 and not strong:
+            dist.all_reduce(tot)
+        aligned_g, query_g, walked_g, ops_g, reads_g = (int(x) for x in tot.cpu())
 
-    for _ in range(args.warmup):
-        seqs = step()
-    # timed region: hipEvents only around the dominant kernel's launches (mode 2; two events per step, for the
-    # roofline).  Events around EVERY launch cost a few microseconds each, so the per-kernel table comes from an
-    # extra, untimed pass of the same steps afterwards.
-    eng.profile_enable(2)
-    eng.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        seqs = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    prof_dom = eng.profile()
-    eng.profile_enable(1)
-    eng.profile_reset()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    prof = eng.profile()
-    eng.profile_enable(0)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    info = eng.batch_info()
-    stats = eng.stats()
-    if world > 1:   # host assembly of the stitched FASTA, outside the timed region (checksum only)
-        rows = np.ascontiguousarray(state["gathered"].cpu().numpy())
-        seqs, _, _ = shard.assemble(rows, contig_lens, world)
-    seqs = [bytes(memoryview(x)) for x in seqs]
-    fasta_sha = hashlib.sha256(b"\n".join(seqs)).hexdigest()
+        mode = {"auto": N.KD_MODE_AUTO, "window": N.KD_MODE_WINDOW, "global": N.KD_MODE_GLOBAL, "strip": N.KD_MODE_STRIP}[args.mode]
+        eng = N.Engine(np.asarray(contig_lens, np.uint32), device=dev_index, mode=mode)
+        if args.window or args.slice:
+            eng.set_tuning(args.window, args.slice)
+        if world > 1 and intervals is None:
+            intervals = shard.partition(contig_lens, world)
+        interval = intervals[rank] if world > 1 else (0, eng.total_sites())
+        ptrs = synth.device_ptrs(batch)
+        n_contigs = len(contig_lens)
 
-    out = None
-    if rank == 0:
-        ms_step = dt / args.steps * 1e3
-        value = aligned_g / (dt / args.steps)
-        sites = int(sum(contig_lens))
-        B = algorithmic_bytes(reads_g, query_g, ops_g, sites)
-        rows = {k: (n, ms / max(n, 1)) for k, (n, ms) in prof.items()}
-        dom = max(rows.items(), key=lambda kv: kv[1][0] * kv[1][1])[0] if rows else None
-        kernel_ms_per_step = sum(n * avg for n, avg in rows.values()) / args.steps
-        if dom in prof_dom:   # the dominant kernel's duration as measured INSIDE the timed region
-            rows[dom] = (prof_dom[dom][0], prof_dom[dom][1] / max(prof_dom[dom][0], 1))
-        roofline = None
-        if dom:
-            # per-launch algorithmic bytes of the whole path (SURVEY 8d figure x events of one launch; at N > 1
-            # one launch sees 1/N of them) over the dominant kernel's average launch duration
-            launches_per_step = rows[dom][0] / args.steps
-            a = B / world / max(launches_per_step, 1) / (rows[dom][1] * 1e-3) / 1e9
-            roofline = dict(bound="hbm", kernel=dom, achieved=round(a, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(a / HBM_PEAK_GBS, 5), traffic=_pmc_traffic(dom), traffic_source=_PMC_SOURCE,
-                            avg_launch_ms=round(rows[dom][1], 4),
-                            algorithmic_bytes=int(B), bytes_per_event=round(B / max(aligned_g, 1), 4),
-                            step_achieved=round(B / (dt / args.steps) / 1e9, 2),
-                            step_frac=round(B / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5))
-        out = dict(
-            metric="aligned-base events/sec pileup+consensus", value=value, unit="events/s", n_gpus=world,
-            steps=args.steps, warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True,
-            scaling="weak", vs_baseline=None, dtype="u32", data="synthetic",
-            config=dict(workload="%s: synthetic %s, %d contig(s), %d sites, depth %gx%s" % (
-                args.config, "150 bp short reads" if cfg["kind"] == "short" else "ONT-like long reads",
-                n_contigs, sites, cfg["depth"], ("" if args.scale == 1.0 else " (scaled)") +
-                (" [generator overrides: %s]" % ",".join(args.synth) if args.synth else "")),
-                reads=reads_g, aligned_events=aligned_g, walked_events=walked_g, cigar_ops=ops_g,
-                parallelism="interval-sharded x%d" % world if world > 1 else "single GPU",
-                pileup_path="window-lds" if info["windowed"] else "global-atomics",
-                window_sites=eng.tuning()[0], work_items=info["work_items"]),
-            roofline=roofline,
-            kernels={k: dict(launches_per_step=n / args.steps, avg_ms=round(avg, 4)) for k, (n, avg) in sorted(rows.items())},
-            kernels_source="hipEvents per launch: %s inside the timed region, the others in an extra untimed pass of the same %d steps" % (
-                "/".join(sorted(prof_dom)) or "none", args.steps),
-            kernel_ms_per_step=round(kernel_ms_per_step, 4),
-            fasta_sha256=fasta_sha, consensus_len=sum(len(s) for s in seqs), gen_seconds=round(t_gen, 1),
-            engine_stats=stats,
-        )
+        if world > 1:
+            eng.set_shard(*interval)
+
+        # one pinned host buffer for the consensus bytes of all contigs: a single D2H copy, no pageable staging
+        pinned = torch.empty(sum(int(l) + int(l) // 8 for l in contig_lens) + 4096, dtype=torch.uint8, pin_memory=True)
+        pinned_np = pinned.numpy()
+
+        state = {}
+
+        def step():
+            eng.reset()
+            eng.push_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"])
+            eng.finalize()
+            eng.consensus_run(1)
+            # this rank's consensus bytes -> pinned host memory (at N = 1 that is the whole FASTA) ...
+            off = eng.consensus_fetch_all_into(pinned_np)
+            seqs = [pinned_np[int(off[c]): int(off[c + 1])] for c in range(n_contigs)]
+            # ... and, at N > 1, the all-gather that leaves the stitched consensus in every GPU's HBM
+            if world > 1:
+                state["gathered"] = shard.gather(eng, interval, dev)[0]   # one fixed-size all-gather (RCCL over xGMI)
+            return seqs
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            eng.sync()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            seqs = step()
+        # timed region: hipEvents only around the dominant kernel's launches (mode 2; two events per step, for the
+        # roofline).  Events around EVERY launch cost a few microseconds each, so the per-kernel table comes from an
+        # extra, untimed pass of the same steps afterwards.
+        eng.profile_enable(2)
+        eng.profile_reset()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            seqs = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        prof_dom = eng.profile()
+        eng.profile_enable(1)
+        eng.profile_reset()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        prof = eng.profile()
+        eng.profile_enable(0)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        info = eng.batch_info()
+        stats = eng.stats()
+        if world > 1:   # host assembly of the stitched FASTA, outside the timed region (checksum only)
+            rows = np.ascontiguousarray(state["gathered"].cpu().numpy())
+            seqs, _, _ = shard.assemble(rows, contig_lens, world, intervals=intervals)
+        seqs = [bytes(memoryview(x)) for x in seqs]
+        fasta_sha = hashlib.sha256(b"\n".join(seqs)).hexdigest()
+
+        out = None
+        if rank == 0:
+            ms_step = dt / args.steps * 1e3
+            value = aligned_g / (dt / args.steps)
+            sites = int(sum(contig_lens))
+            B = algorithmic_bytes(reads_g, query_g, ops_g, sites)
+            rows = {k: (n, ms / max(n, 1)) for k, (n, ms) in prof.items()}
+            dom = max(rows.items(), key=lambda kv: kv[1][0] * kv[1][1])[0] if rows else None
+            kernel_ms_per_step = sum(n * avg for n, avg in rows.values()) / args.steps
+            if dom in prof_dom:   # the dominant kernel's duration as measured INSIDE the timed region
+                rows[dom] = (prof_dom[dom][0], prof_dom[dom][1] / max(prof_dom[dom][0], 1))
+            roofline = None
+            if dom:
+                # per-launch algorithmic bytes of the whole path (SURVEY 8d figure x events of one launch; at N > 1
+                # one launch sees 1/N of them) over the dominant kernel's average launch duration
+                launches_per_step = rows[dom][0] / args.steps
+                a = B / world / max(launches_per_step, 1) / (rows[dom][1] * 1e-3) / 1e9
+                roofline = dict(bound="hbm", kernel=dom, achieved=round(a, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                                frac=round(a / HBM_PEAK_GBS, 5), traffic=_pmc_traffic(dom), traffic_source=_PMC_SOURCE,
+                                avg_launch_ms=round(rows[dom][1], 4),
+                                algorithmic_bytes=int(B), bytes_per_event=round(B / max(aligned_g, 1), 4),
+                                step_achieved=round(B / (dt / args.steps) / 1e9, 2),
+                                step_frac=round(B / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5))
+            out = dict(
+                metric="aligned-base events/sec pileup+consensus", value=value, unit="events/s", n_gpus=world,
+                steps=args.steps, warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True,
+                scaling=scaling if world > 1 else "weak", vs_baseline=None, dtype="u32", data="synthetic",
+                config=dict(workload="%s: synthetic %s, %d contig(s), %d sites, depth %gx%s" % (
+                    args.config, "150 bp short reads" if cfg["kind"] == "short" else "ONT-like long reads",
+                    n_contigs, sites, cfg["depth"], ("" if args.scale == 1.0 else " (scaled)") +
+                    (" [generator overrides: %s]" % ",".join(args.synth) if args.synth else "")),
+                    reads=reads_g, aligned_events=aligned_g, walked_events=walked_g, cigar_ops=ops_g,
+                    parallelism=("one input, %d work-balanced position intervals (reads routed from the shared batch)" % world if strong
+                                 else "interval-sharded x%d (one config-sized interval per rank)" % world) if world > 1 else "single GPU",
+                    pileup_path="window-lds" if info["windowed"] else "global-atomics",
+                    window_sites=eng.tuning()[0], work_items=info["work_items"]),
+                roofline=roofline,
+                kernels={k: dict(launches_per_step=n / args.steps, avg_ms=round(avg, 4)) for k, (n, avg) in sorted(rows.items())},
+                kernels_source="hipEvents per launch: %s inside the timed region, the others in an extra untimed pass of the same %d steps" % (
+                    "/".join(sorted(prof_dom)) or "none", args.steps),
+                kernel_ms_per_step=round(kernel_ms_per_step, 4),
+                fasta_sha256=fasta_sha, consensus_len=sum(len(s) for s in seqs), gen_seconds=round(t_gen, 1),
+                engine_stats=stats,
+            )
+        return dict(out=out, eng=eng, batch=batch, contig_lens=contig_lens, seqs=seqs, aligned_g=aligned_g, step=step, barrier=barrier)
+
+    res = run(args.scaling)
+    out, eng, batch, contig_lens, seqs, aligned_g, step, barrier = (res[k] for k in ("out", "eng", "batch", "contig_lens", "seqs", "aligned_g", "step", "barrier"))
+    if world > 1 and not args.one_scaling:
+        # the other scaling rule, measured the same way right after (its own generation, warm-up and K timed steps); reported
+        # as a secondary object of the same line -- `value` / `scaling` above stay the contract's figures
+        eng.close()
+        del res, batch
+        torch.cuda.empty_cache()
+        other = run("strong" if args.scaling == "weak" else "weak")
+        eng, batch, contig_lens, seqs, aligned_g, step, barrier = (other[k] for k in ("eng", "batch", "contig_lens", "seqs", "aligned_g", "step", "barrier"))
+        if rank == 0:
+            o = other["out"]
+            out["other_scaling"] = {k: o[k] for k in ("scaling", "value", "unit", "ms_per_step", "config", "roofline", "fasta_sha256")}
     if args.sweep and world == 1:
         # tuning sweep on the resident batch: "mode:window:slice,..." -> one JSON line each on stderr
         for spec in args.sweep.split(","):

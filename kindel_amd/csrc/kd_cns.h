@@ -37,7 +37,7 @@ __device__ __forceinline__ KdSite kd_site_eval(const KdTabs &T, const KdCns &C, 
                                                uint32_t del, uint32_t ins_total, uint32_t ad_next_raw) {
     KdSite s;
     s.ins_len = 0; s.ins_ev = 0; s.depth = 0; s.ins = 0; s.has_base = 0; s.base = 'N'; s.change = 0; s.live = false;
-    if (g >= T.stride || g < C.g_lo || g >= C.g_hi) return s;
+    if (g >= T.sites || g < C.g_lo || g >= C.g_hi) return s;
     const kd_u64 p = g - cbase;
     if (p >= L) return s;  // the len-th slot and the padding emit nothing
     s.live = true;
@@ -72,10 +72,10 @@ __device__ __forceinline__ void kd_cns_load_eval(const KdTabs &T, const KdCns &C
                                                  KdSite out[KD_CNS_PER_THREAD]) {
     uint32_t v[8][KD_CNS_PER_THREAD + 1];
     const int chs[7] = {KDC_A, KDC_T, KDC_G, KDC_C, KDC_N, KDC_DEL, KDC_INS_TOTAL};
-    const kd_u64 S = T.stride;
+    const kd_u64 S = T.sites;
 #pragma unroll
     for (int c = 0; c < 7; c++) {
-        const uint32_t *row = T.tab + (kd_u64)chs[c] * S;
+        const uint32_t *row = T.tab + (kd_u64)chs[c] * T.stride;
         if (g0 + KD_CNS_PER_THREAD <= S) {
             const uint4 x = *reinterpret_cast<const uint4 *>(row + g0);
             v[c][0] = x.x; v[c][1] = x.y; v[c][2] = x.z; v[c][3] = x.w;
@@ -101,7 +101,7 @@ k_cns_count(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, kd_u64 *tile_sum, u
     __syncthreads();
     const kd_u64 tile0 = (tile_first + blockIdx.x) * KD_CNS_TILE;
     const kd_u64 g0 = tile0 + (kd_u64)t * KD_CNS_PER_THREAD;
-    const uint32_t cfirst = tile0 < T.stride ? C.seg_contig[tile0 >> 6] : 0;
+    const uint32_t cfirst = tile0 < T.sites ? C.seg_contig[tile0 >> 6] : 0;
     KdSite s[KD_CNS_PER_THREAD];
     kd_cns_load_eval(T, C, ins, g0, s);
     uint32_t sum = 0, mn = 0xffffffffu, mx = 0;
@@ -174,7 +174,7 @@ k_cns_emit(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, const kd_u64 *tile_o
     const char lower[17] = "=acmgrsvtwyhkdbn";
     for (int k = 0; k < KD_CNS_PER_THREAD; k++) {
         const kd_u64 g = g0 + k;
-        if (g >= T.stride) break;
+        if (g >= T.sites) break;
         changes[g] = s[k].change;
         // contig c starts at G-site contig_base[c]: record the output offset there
         if ((g & 63) == 0) {

@@ -124,8 +124,12 @@ enum {
 };
 
 struct KdTabs {
-    uint32_t *tab;               // [KDC_NCH][stride]
-    kd_u64 stride;               // S = total G-space sites (multiple of 64)
+    uint32_t *tab;               // counter of (channel ch, G-site g) = tab[ch * stride + g].  The allocation only covers the
+                                 // shard's sites [alloc_lo, alloc_hi) (+ slack); `tab` is biased by -alloc_lo so that kernels
+                                 // index with global sites.  Every access is either guarded by kd_commit() or made by the
+                                 // consensus tiles of the shard, which lie inside the allocation.
+    kd_u64 stride;               // dwords between channels (the shard's site count + slack)
+    kd_u64 sites;                // S = total G-space sites (multiple of 1024): bound of valid g
     const uint32_t *contig_len;  // [n_contigs]
     const kd_u64 *contig_base;   // [n_contigs]
     kd_u64 g_lo, g_hi;           // commit increments with g_lo <= g <= g_hi (g_hi = halo site)

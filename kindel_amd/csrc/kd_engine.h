@@ -33,6 +33,10 @@ struct KdEngine {
     uint32_t W = 640, slice_cfg = 0;   // tuned on C3 (profiles/): 19 ch x 640 x 2 B = 24 KB of LDS histogram per workgroup
 
     uint32_t *d_tab = nullptr, *d_clen = nullptr, *d_seg = nullptr;
+    // the tables are allocated for the shard only: sites [alloc_lo, alloc_hi) (tile aligned) + slack, `pitch` dwords per
+    // channel.  Lazily (first push / first read-out), so that kd_create + kd_set_shard never allocate the whole G-space.
+    uint64_t alloc_lo = 0, alloc_hi = 0, pitch = 0;
+    bool tables_ready = false;
     kd_u64 *d_cbase = nullptr, *d_status = nullptr;
     kd_u64 *d_first_idx = nullptr, *d_err_first = nullptr;   // per contig: first record / first failing read (global indices)
     uint32_t *d_err_code = nullptr;
@@ -86,7 +90,7 @@ struct KdEngine {
 
     KdTabs tabs() const {
         KdTabs T;
-        T.tab = d_tab; T.stride = S; T.contig_len = d_clen; T.contig_base = d_cbase;
+        T.tab = d_tab - alloc_lo; T.stride = pitch; T.sites = S; T.contig_len = d_clen; T.contig_base = d_cbase;
         T.g_lo = g_lo; T.g_hi = g_hi;  // commit includes the halo site g_hi
         T.first_idx = d_first_idx; T.err_first = d_err_first; T.err_code = d_err_code;
         return T;
@@ -113,7 +117,6 @@ struct KdEngine {
         S = (g + KD_CNS_TILE - 1) / KD_CNS_TILE * KD_CNS_TILE;
         if (S >= 0xfffffff0ULL) return fail(KD_E_ARG, "kd_create: more than 2^32 reference sites");
         g_lo = 0; g_hi = S;
-        d_tab = (uint32_t *)rt.alloc((size_t)KDC_NCH * S * 4);
         d_clen = (uint32_t *)rt.alloc((size_t)n * 4);
         d_cbase = (kd_u64 *)rt.alloc((size_t)n * 8);
         d_seg = (uint32_t *)rt.alloc((size_t)(S / 64) * 4);
@@ -121,8 +124,8 @@ struct KdEngine {
         d_first_idx = (kd_u64 *)rt.alloc((size_t)n * 8);
         d_err_first = (kd_u64 *)rt.alloc((size_t)n * 8);
         d_err_code = (uint32_t *)rt.alloc((size_t)n * 4);
-        if (!d_tab || !d_clen || !d_cbase || !d_seg || !d_status || !d_first_idx || !d_err_first || !d_err_code)
-            return fail(KD_E_NOMEM, "kd_create: device allocation failed (" + std::to_string((size_t)KDC_NCH * S * 4) + " table bytes): " + rt.err());
+        if (!d_clen || !d_cbase || !d_seg || !d_status || !d_first_idx || !d_err_first || !d_err_code)
+            return fail(KD_E_NOMEM, std::string("kd_create: device allocation failed: ") + rt.err());
         std::vector<uint32_t> seg(S / 64, n - 1);
         for (uint32_t c = 0; c < n; c++) {
             uint64_t e = c + 1 < n ? cbase[c + 1] : S;
@@ -159,10 +162,24 @@ struct KdEngine {
         hi = std::min<uint64_t>(S, (g_hi + 1 + 63) & ~uint64_t(63));
     }
 
+    // (re)allocate the tables for the current shard and zero them
+    int prepare_tables() {
+        const uint64_t lo = g_lo / KD_CNS_TILE * KD_CNS_TILE;
+        const uint64_t hi = std::min<uint64_t>(S, (g_hi + 1 + KD_CNS_TILE - 1) / KD_CNS_TILE * KD_CNS_TILE);
+        if (!d_tab || lo != alloc_lo || hi != alloc_hi) {
+            if (d_tab) { if (rt.sync()) return hipfail("sync"); rt.free(d_tab); d_tab = nullptr; }
+            alloc_lo = lo; alloc_hi = hi; pitch = (hi - lo) + 64;   // slack: the consensus reads one site past its last tile
+            d_tab = (uint32_t *)rt.alloc((size_t)KDC_NCH * pitch * 4);
+            if (!d_tab)
+                return fail(KD_E_NOMEM, "device allocation of the tables failed (" + std::to_string((size_t)KDC_NCH * pitch * 4) + " bytes): " + rt.err());
+        }
+        if (rt.memset(d_tab, 0, (size_t)KDC_NCH * pitch * 4)) return hipfail("memset tables");
+        tables_ready = true;
+        return KD_OK;
+    }
+
     int reset() {
-        uint64_t lo, hi;
-        shard_cover(lo, hi);   // increments outside the shard are never committed, so only this range needs zeroing
-        if (rt.memset2d(d_tab + lo, (size_t)S * 4, 0, (size_t)(hi - lo) * 4, KDC_NCH)) return hipfail("reset: memset tables");
+        tables_ready = false;   // zeroed (and, after kd_set_shard, re-allocated) by the next push or read-out
         std::fill(h_status.begin(), h_status.end(), 0);
         h_status[KDS_ERR_READ] = ~0ULL;
         if (rt.h2d(d_status, h_status.data(), KDS_COUNT * 8)) return hipfail("reset: status");
@@ -176,11 +193,8 @@ struct KdEngine {
     int set_shard(uint64_t lo, uint64_t hi) {
         if (lo > hi || hi > S) return fail(KD_E_ARG, "kd_set_shard: bad interval");
         if (reads_pushed) return fail(KD_E_ARG, "kd_set_shard: call before the first batch (or after kd_reset)");
-        // the tables were zeroed over the old shard range; make sure the new one starts from zero as well
-        g_lo = 0; g_hi = S;
-        int rc = reset();
         g_lo = lo; g_hi = hi;
-        return rc;
+        return reset();
     }
 
     int fetch_status() {
@@ -195,6 +209,7 @@ struct KdEngine {
         if (n >= 0xffffffffULL) return fail(KD_E_ARG, "kd_push_batch: more than 2^32-1 reads in one batch");
         if (reinterpret_cast<uintptr_t>(B.seq4) & 15u) return fail(KD_E_ARG, "kd_push_batch_device: seq4 must be 16-byte aligned");
         int rc;
+        if (!tables_ready && (rc = prepare_tables())) return rc;
         if ((rc = ensure(b_rinfo, n * sizeof(KdRInfo))) || (rc = ensure(b_cold, n * 4)) ||
             (rc = ensure(b_irreg, n * 4)) || (rc = ensure(b_long, n * 4)) || (rc = ensure(b_readev, n * 4)) ||
             (rc = ensure(b_readpool, n * 8)))
@@ -429,6 +444,7 @@ struct KdEngine {
     // ---- finalize: insertion multiset -> per-site winner ----
     int finalize(uint64_t *err_read) {
         int rc;
+        if (!tables_ready && (rc = prepare_tables())) return rc;   // nothing was pushed: all-zero tables
         if ((rc = fetch_status())) return rc;
         if (h_status[KDS_INTERNAL]) return fail(KD_E_INTERNAL, "insertion event buffers overran (internal error)");
 #ifdef KD_PHASE_CLOCKS   // profiling build (hipcc -DKD_PHASE_CLOCKS): where k_window's wavefronts spend their clocks
@@ -513,9 +529,16 @@ struct KdEngine {
     int get_tables(uint32_t contig, uint32_t n_ch, const uint32_t *channels, uint32_t *out) {
         if (contig >= n_contigs) return fail(KD_E_ARG, "kd_get_tables: bad contig");
         const size_t L1 = (size_t)clen[contig] + 1;
+        int rc;
+        if (!tables_ready && (rc = prepare_tables())) return rc;
+        // the part of the contig inside this context's allocation; sites of other shards read as zero
+        const uint64_t c0 = cbase[contig], c1 = c0 + L1;
+        const uint64_t a = std::max(c0, alloc_lo), b = std::min(c1, alloc_hi);
         for (uint32_t k = 0; k < n_ch; k++) {
             if (channels[k] >= KDC_NCH) return fail(KD_E_ARG, "kd_get_tables: bad channel");
-            if (rt.d2h(out + (size_t)k * L1, d_tab + (size_t)channels[k] * S + cbase[contig], L1 * 4))
+            uint32_t *dst = out + (size_t)k * L1;
+            if (a > c0 || b < c1 || a >= b) memset(dst, 0, L1 * 4);
+            if (a < b && rt.d2h(dst + (a - c0), d_tab + (size_t)channels[k] * pitch + (a - alloc_lo), (size_t)(b - a) * 4))
                 return hipfail("kd_get_tables: d2h");
         }
         return KD_OK;

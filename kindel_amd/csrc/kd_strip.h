@@ -322,7 +322,7 @@ __device__ __forceinline__ void kd_strip_item(const KdReads &rd, const KdRInfo *
     kd_acc_spill(aw); kd_acc_spill(ae); kd_acc_spill(as);
     KD_WAVE_SYNC();
     const kd_u64 g = s0 + lane;
-    if (g < T.stride && kd_commit(T, g)) {
+    if (g < T.sites && kd_commit(T, g)) {
         uint32_t *t0 = T.tab + g;
 #pragma unroll
         for (int f = 0; f < 5; f++) {

@@ -448,7 +448,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 const int32_t sw = 2 * (int32_t)xw - KD_HALO;
                 uint32_t *row = T.tab + (kd_u64)(tch == 0xffu ? 0u : tch) * T.stride;
                 const kd_u64 g0 = wlo + (kd_u64)sw;   // even: W, the halo and the G-space rows are all even / 8-byte aligned
-                if (tch != 0xffu && sw >= 0 && sw + 1 < Wi && g0 + 1 < T.stride && kd_commit(T, g0) && kd_commit(T, g0 + 1)) {
+                if (tch != 0xffu && sw >= 0 && sw + 1 < Wi && g0 + 1 < T.sites && kd_commit(T, g0) && kd_commit(T, g0 + 1)) {
                     // both sites of the word live: ONE 64-bit add on the two adjacent u32 counters (the low counter
                     // cannot carry into the high one: a u32 table counter never wraps)
                     atomicAdd(reinterpret_cast<kd_u64 *>(row + g0), (kd_u64)(v & 0xffffu) | ((kd_u64)(v >> 16) << 32));
@@ -460,7 +460,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                     if (!cnt || sw2 < 0 || sw2 >= Wi) continue;
                     const kd_u64 g = wlo + (kd_u64)sw2;
                     if (tch == 0xffu) bad = true;
-                    else if (g < T.stride && kd_commit(T, g)) atomicAdd(&row[g], cnt);
+                    else if (g < T.sites && kd_commit(T, g)) atomicAdd(&row[g], cnt);
                 }
             }
         }

@@ -6,9 +6,9 @@ contiguous interval of "G-space" (all contigs laid back to back, see include/kin
 commits only table increments that land in its interval (+ one halo site for
 aligned_depth_next, kindel.py:405-410).  There is NO collective on the pileup path: a read that
 straddles a boundary is simply given to both owners.  The only exchange is the stitch of the
-per-rank consensus pieces: one tiny all-gather of payload sizes followed by ONE all-gather of the
-padded payload (offsets + depth min/max + change codes + consensus bytes) -- RCCL over xGMI when
-the backend is "nccl", gloo in the CPU tests.  Payload is <= (sites + inserted bases) bytes in
+per-rank consensus pieces: ONE all-gather of fixed-size payloads (header + offsets + depth min/max +
+change codes + consensus bytes; the row size follows from the shard geometry, no size exchange) --
+RCCL over xGMI when the backend is "nccl", gloo in the CPU tests.  Payload is <= (sites + inserted bases) bytes in
 total, i.e. latency bound; sharding by reads instead would need a 76 B/site table all-reduce.
 """
 import ctypes as C
@@ -37,11 +37,48 @@ def partition(contig_lens, world):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def reads_of_rank(contig_lens, contig, pos0, pos_end, rank, world, margin=512):
+def partition_weighted(contig_lens, contig, pos0, weight, world, align=None, snap=0.1):
+    """Split G-space into `world` CONTIGUOUS intervals of (nearly) equal WORK instead of equal sites: `weight` per read
+    (e.g. its aligned length), credited to the bin of `align` sites its start falls in.  This is the balanced assignment of
+    SURVEY 8e for both shapes of input: many contigs (a cut that comes within `snap` x the mean interval of a contig
+    boundary is moved onto it, so whole contigs go to one rank: config 4, "greedy by sum of events") and one long contig
+    (config 3, position intervals).  Deterministic in its inputs: every rank computes the same cuts from the same batch.
+    contig / pos0 / weight: numpy or torch (moved to the host).  -> [(lo, hi)] * world"""
+    def host(a):
+        return a.detach().cpu().numpy() if type(a).__module__.startswith("torch") else np.asarray(a)
+    base, S = g_layout(contig_lens)
+    if world <= 1:
+        return [(0, S)]
+    if align is None:   # bins of 64 .. 2048 sites, a few hundred per rank
+        align = 64
+        while align < 2048 and S // (2 * align) >= world * 256:
+            align *= 2
+    c, p, w = host(contig).astype(np.int64), host(pos0).astype(np.int64), host(weight).astype(np.float64)
+    g0 = base.astype(np.int64)[c] + np.maximum(p, 0)
+    nb = (S + align - 1) // align
+    binw = np.bincount(np.minimum(g0 // align, nb - 1), weights=w, minlength=nb)
+    cum = np.cumsum(binw)
+    total = float(cum[-1]) if len(cum) else 0.0
+    bases = base.astype(np.int64)
+    cuts = [0]
+    for r in range(1, world):
+        if total <= 0:
+            cut = int(round(S * r / world / align)) * align
+        else:
+            cut = int(np.searchsorted(cum, total * r / world, side="left") + 1) * align
+        near = bases[np.argmin(np.abs(bases - cut))] if len(bases) else cut
+        if abs(int(near) - cut) <= snap * S / world:
+            cut = int(near)            # whole contigs on one rank where that costs little balance
+        cuts.append(min(max(cut, cuts[-1]), S))
+    cuts.append(S)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def reads_of_rank(contig_lens, contig, pos0, pos_end, rank, world, margin=512, intervals=None):
     """Boolean mask (same array type as the inputs: numpy or torch) of the reads rank must see:
     every read whose reference footprint [pos0 - margin, pos_end + margin] touches its interval."""
     base, _ = g_layout(contig_lens)
-    lo, hi = partition(contig_lens, world)[rank]
+    lo, hi = (intervals if intervals is not None else partition(contig_lens, world))[rank]
     if type(contig).__module__.startswith("torch"):
         import torch
         b = torch.as_tensor(base.astype(np.int64), device=contig.device)
@@ -54,10 +91,10 @@ def reads_of_rank(contig_lens, contig, pos0, pos_end, rank, world, margin=512):
     return (g1 + margin >= lo) & (g0 - margin <= hi)
 
 
-def owned_mask(contig_lens, contig, pos0, rank, world):
+def owned_mask(contig_lens, contig, pos0, rank, world, intervals=None):
     """Reads whose start lies in rank's interval (each read is owned by exactly one rank)."""
     base, _ = g_layout(contig_lens)
-    lo, hi = partition(contig_lens, world)[rank]
+    lo, hi = (intervals if intervals is not None else partition(contig_lens, world))[rank]
     if type(contig).__module__.startswith("torch"):
         import torch
         b = torch.as_tensor(base.astype(np.int64), device=contig.device)
@@ -84,52 +121,71 @@ def _as_tensor(ptr, n, device):
     return torch.as_tensor(_DevArray(ptr, n), device=device)
 
 
-def gather(engine, interval, device, group=None):
-    """The exchange step: all-gather the per-rank payloads (offsets + depth min/max + change codes +
-    consensus bytes).  Call after engine.consensus_run().  Everything stays on `device`:
-    -> (gathered uint8 tensor [world, pad], world).  One tiny all-gather of sizes, ONE data all-gather."""
+_HDR = 16   # payload header: u64 payload bytes, u64 spare
+
+
+def gather(engine, interval, device, group=None, pad=None):
+    """The exchange step: ONE all-gather of fixed-size payloads -- header (payload bytes) + contig offsets + depth min/max +
+    change codes + consensus bytes; RCCL over xGMI when the backend is "nccl".  The row size `pad` is agreed without
+    communication: every rank derives the same upper bound from the shard geometry (the largest interval, twice: change
+    codes + one byte per site, plus room for inserted bases).  Should a rank's consensus not fit (an insertion-heavy
+    shard), its header says so, every rank reads that in the gathered rows and all of them repeat the gather with the
+    announced size -- a second collective only in that case.  Call after engine.consensus_run(); everything stays on
+    `device`.  -> (gathered uint8 tensor [world, pad], world)."""
     import torch
     import torch.distributed as dist
 
-    lens = engine.contig_lens
     lo, hi = interval
     coff, mm = engine.consensus_offsets()
     cptr, cbytes = engine.consensus_device()
     chptr = engine.changes_device()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     head = np.concatenate([coff.view(np.uint8), mm.reshape(-1).view(np.uint8)])
-    my_size = head.size + (hi - lo) + cbytes
-    sizes = torch.zeros(world, dtype=torch.int64, device=device)
-    if world > 1:
-        dist.all_gather_into_tensor(sizes, torch.tensor([my_size], dtype=torch.int64, device=device), group=group)
-        pad = int(sizes.max().item())
-    else:
-        pad = my_size
-    payload = torch.zeros(pad, dtype=torch.uint8, device=device)
-    payload[: head.size] = torch.from_numpy(head).to(device)
-    payload[head.size: head.size + (hi - lo)] = _as_tensor(chptr + lo, hi - lo, device)
-    payload[head.size + (hi - lo): my_size] = _as_tensor(cptr, cbytes, device)
-    if world > 1:
-        gathered = torch.empty(world * pad, dtype=torch.uint8, device=device)
-        dist.all_gather_into_tensor(gathered, payload, group=group)  # the one data collective
-    else:
-        gathered = payload
-    return gathered.view(world, pad), world
+    my_size = _HDR + head.size + (hi - lo) + cbytes
+    if pad is None:
+        widest = max(1, -(-engine.total_sites() // max(world, 1)) + 4096) if world > 1 else hi - lo
+        pad = _HDR + head.size + 2 * widest + widest // 4 + 65536
+        pad = max(pad, my_size) if world == 1 else pad
+    for _ in range(2):
+        payload = torch.zeros(pad, dtype=torch.uint8, device=device)
+        hdr = np.asarray([my_size, 0], np.uint64).view(np.uint8)
+        payload[:_HDR] = torch.from_numpy(hdr).to(device)
+        if my_size <= pad:
+            o = _HDR
+            payload[o: o + head.size] = torch.from_numpy(head).to(device)
+            o += head.size
+            payload[o: o + (hi - lo)] = _as_tensor(chptr + lo, hi - lo, device)
+            o += hi - lo
+            payload[o: o + cbytes] = _as_tensor(cptr, cbytes, device)
+        if world > 1:
+            gathered = torch.empty(world * pad, dtype=torch.uint8, device=device)
+            dist.all_gather_into_tensor(gathered, payload, group=group)  # the one data collective
+        else:
+            gathered = payload
+        rows = gathered.view(world, pad)
+        need = int(rows[:, :8].contiguous().view(torch.int64).max().item())   # every rank sees the same sizes
+        if need <= pad:
+            return rows, world
+        pad = need
+    raise RuntimeError("shard.gather: payload sizes changed between two gathers")
 
 
-def assemble(rows, contig_lens, world, interval=None):
-    """Host side: per-rank payload rows (uint8 numpy [world, pad]) -> (seqs, changes, minmax) per contig."""
+def assemble(rows, contig_lens, world, interval=None, intervals=None):
+    """Host side: per-rank payload rows (uint8 numpy [world, pad]) -> (seqs, changes, minmax) per contig.
+    intervals: the per-rank G-space intervals (default: partition(contig_lens, world))."""
     lens = np.asarray(contig_lens, np.uint32)
     n = len(lens)
     base, S = g_layout(lens)
-    # every rank lays contigs out identically, so intervals are recomputable locally
-    ivs = partition(lens, world) if world > 1 else [interval if interval is not None else (0, S)]
+    if intervals is not None:
+        ivs = intervals
+    else:   # every rank lays contigs out identically, so the equal-sites intervals are recomputable locally
+        ivs = partition(lens, world) if world > 1 else [interval if interval is not None else (0, S)]
     seq_parts = [[] for _ in range(n)]
     changes_g = np.zeros(S, np.uint8)
     mins = np.full(n, 0xFFFFFFFF, np.uint64)
     maxs = np.zeros(n, np.uint64)
     for r in range(world):
-        row = rows[r]
+        row = rows[r][_HDR:]
         rcoff = row[: (n + 1) * 8].view(np.uint64)
         rmm = row[(n + 1) * 8: (n + 1) * 8 + n * 8].view(np.uint32).reshape(n, 2)
         rlo, rhi = ivs[r]
@@ -147,9 +203,9 @@ def assemble(rows, contig_lens, world, interval=None):
     return seqs, changes, minmax
 
 
-def stitch(engine, interval, device, group=None):
+def stitch(engine, interval, device, group=None, intervals=None, pad=None):
     """gather() + host assembly: -> (seqs, changes, minmax), identical on every rank.
     seqs[c] = bytes of contig c's consensus, changes[c] = uint8[L_c], minmax[c] = (min, max) ACGT depth."""
-    gathered, world = gather(engine, interval, device, group)
+    gathered, world = gather(engine, interval, device, group, pad=pad)
     rows = np.ascontiguousarray(gathered.cpu().numpy())
-    return assemble(rows, engine.contig_lens, world, interval)
+    return assemble(rows, engine.contig_lens, world, interval, intervals=intervals)
