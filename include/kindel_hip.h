@@ -214,6 +214,36 @@ uint64_t kd_decode_n_records(const kd_file *f); /* all records in the file, incl
 void kd_decode_close(kd_file *f);
 const char *kd_decode_last_error(void);
 
+/* ---- tool: write a host batch as a BGZF-compressed BAM (synthetic inputs for end-to-end runs; parallel deflate) ---- */
+int kd_write_bam(const char *path, const kd_batch *host_batch, uint32_t n_contigs, const char *const *names,
+                 const uint32_t *lens, const char *sort_order, int n_threads, int level);
+
+/* ---- streaming ingest: the record iteration of parse_bam (kindel.py:143-145) without holding the whole file -------- */
+
+typedef struct kd_stream kd_stream;
+/* Open a SAM / BAM file for chunked reading: batches of about chunk_bytes uncompressed bytes (0 = 64 MiB), whole records
+ * each, in file order.  The header (@SQ table) is available right after the call. */
+int kd_stream_open(kd_stream **out, const char *path, int n_threads, uint64_t chunk_bytes);
+uint32_t kd_stream_n_contigs(const kd_stream *s);
+const char *kd_stream_contig_name(const kd_stream *s, uint32_t i);
+uint32_t kd_stream_contig_len(const kd_stream *s, uint32_t i);
+/* Next batch, or *batch = NULL at the end of the file.  Two batches are kept: a batch stays valid until the call AFTER the
+ * next one, so one thread can decode batch k+1 while another still reads batch k. */
+int kd_stream_next(kd_stream *s, const kd_batch **batch);
+uint64_t kd_stream_n_records(const kd_stream *s); /* records seen so far, incl. dropped RNAME '*' */
+const char *kd_stream_last_error(const kd_stream *s);
+void kd_stream_close(kd_stream *s);
+
+/* Push every remaining batch of `s` into ctx (kd_create'd over the stream's contig table): a producer thread decodes batch
+ * k+1 while this thread copies batch k to the device and launches its kernels.  stats (may be NULL): [0] batches,
+ * [1] microseconds the decoder was busy, [2] microseconds the pushes took, [3] wall microseconds. */
+int kd_push_stream(kd_ctx *ctx, kd_stream *s, uint64_t stats[4]);
+/* kd_stream_open + kd_push_stream + kd_stream_close for a file whose @SQ table equals ctx's contig table */
+int kd_decode_push_file(kd_ctx *ctx, const char *path, int n_threads, uint64_t chunk_bytes, uint64_t stats[4]);
+/* first_idx[n_contigs]: index (over all pushed records) of each contig's first record, UINT64_MAX = no record: the
+ * contigs parse_bam returns and their order (first appearance, kindel.py:143-151) */
+int kd_get_contig_first(kd_ctx *ctx, uint64_t *first_idx);
+
 #ifdef __cplusplus
 }
 #endif

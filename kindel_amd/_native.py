@@ -28,7 +28,9 @@ ABI_SYMBOLS = (
     "kd_total_sites kd_set_shard kd_push_batch kd_push_batch_device kd_sync kd_finalize kd_get_stats "
     "kd_get_batch_info kd_get_tables kd_get_insertions kd_consensus_run kd_consensus_fetch kd_consensus_fetch_all kd_consensus_device kd_changes_device kd_consensus_offsets "
     "kd_profile_enable kd_profile_get kd_profile_reset kd_decode_open kd_decode_batch kd_decode_n_contigs "
-    "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error"
+    "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error "
+    "kd_stream_open kd_stream_n_contigs kd_stream_contig_name kd_stream_contig_len kd_stream_next kd_stream_n_records "
+    "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_write_bam"
 ).split()
 
 #: the reference exception each error code stands for (kindel.py:47,51-52,57,61,67,72,75,79)
@@ -111,6 +113,24 @@ class Library:
         L.kd_decode_close.argtypes = [p]
         L.kd_decode_close.restype = None
         L.kd_decode_last_error.restype = C.c_char_p
+        L.kd_stream_open.argtypes = [C.POINTER(p), C.c_char_p, C.c_int, u64]
+        L.kd_stream_n_contigs.argtypes = [p]
+        L.kd_stream_n_contigs.restype = u32
+        L.kd_stream_contig_name.argtypes = [p, u32]
+        L.kd_stream_contig_name.restype = C.c_char_p
+        L.kd_stream_contig_len.argtypes = [p, u32]
+        L.kd_stream_contig_len.restype = u32
+        L.kd_stream_next.argtypes = [p, C.POINTER(C.POINTER(kd_batch))]
+        L.kd_stream_n_records.argtypes = [p]
+        L.kd_stream_n_records.restype = u64
+        L.kd_stream_last_error.argtypes = [p]
+        L.kd_stream_last_error.restype = C.c_char_p
+        L.kd_stream_close.argtypes = [p]
+        L.kd_stream_close.restype = None
+        L.kd_push_stream.argtypes = [p, p, C.POINTER(u64)]
+        L.kd_decode_push_file.argtypes = [p, C.c_char_p, C.c_int, u64, C.POINTER(u64)]
+        L.kd_get_contig_first.argtypes = [p, p]
+        L.kd_write_bam.argtypes = [C.c_char_p, C.POINTER(kd_batch), u32, C.POINTER(C.c_char_p), p, C.c_char_p, C.c_int, C.c_int]
         if L.kd_abi_version() != 1:
             raise ImportError("kindel_amd: ABI version mismatch in %s" % path)
 
@@ -140,6 +160,79 @@ class _DecodedFile:
         if self.handle is not None:
             self.lib.dll.kd_decode_close(self.handle)
             self.handle = None
+
+
+class Stream:
+    """A SAM / BAM file read in chunks (kd_stream_*): the header is known at once, the records arrive batch by batch."""
+
+    def __init__(self, path, threads=0, chunk_bytes=0, lib=None):
+        self.lib = lib or default_library()
+        self._h = C.c_void_p()
+        rc = self.lib.dll.kd_stream_open(C.byref(self._h), os.fsencode(str(path)), int(threads), int(chunk_bytes))
+        if rc:
+            self._h = None
+            raise _EXC.get(rc, KindelNativeError)("%s: %s" % (path, self.lib.dll.kd_stream_last_error(None).decode()))
+        n = self.lib.dll.kd_stream_n_contigs(self._h)
+        self.contig_names = [self.lib.dll.kd_stream_contig_name(self._h, i).decode() for i in range(n)]
+        self.contig_lens = np.asarray([self.lib.dll.kd_stream_contig_len(self._h, i) for i in range(n)], np.uint32)
+
+    def _raise(self, rc):
+        msg = self.lib.dll.kd_stream_last_error(self._h).decode()
+        if rc == KD_E_NOREF:
+            raise KeyError(msg)
+        raise _EXC.get(rc, KindelNativeError)(msg)
+
+    def next_batch(self):
+        """-> batch dict of COPIES (numpy), or None at the end of the file"""
+        b = C.POINTER(kd_batch)()
+        rc = self.lib.dll.kd_stream_next(self._h, C.byref(b))
+        if rc:
+            self._raise(rc)
+        if not b:
+            return None
+        b = b.contents
+        n = int(b.n_reads)
+        sizes = dict(contig=n, pos0=n, flag=n, seq_off=n, seq_len=n, cig_off=n, n_cig=n, seq4=int(b.seq4_bytes) + 8,
+                     cigar=int(b.cigar_words) + 2)
+        out = {}
+        for name, dt in _BATCH_FIELDS:
+            m = sizes[name]
+            addr = getattr(b, name)
+            if m and addr:
+                buf = (C.c_char * (m * np.dtype(dt).itemsize)).from_address(addr)
+                out[name] = np.frombuffer(buf, dtype=dt, count=m).copy()
+            else:
+                out[name] = np.zeros(0, dt)
+        out["contig_names"] = np.asarray(self.contig_names)
+        out["contig_lens"] = self.contig_lens
+        return out
+
+    def n_records(self):
+        return int(self.lib.dll.kd_stream_n_records(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.dll.kd_stream_close(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def write_bam(path, batch, names=None, sort_order="coordinate", threads=0, level=1, lib=None):
+    """Host batch (dict of numpy arrays) -> BGZF-compressed BAM through the native writer (parallel deflate)."""
+    lib = lib or default_library()
+    arrs = {name: np.ascontiguousarray(batch[name], dt) for name, dt in _BATCH_FIELDS}
+    b = kd_batch()
+    b.n_reads = len(arrs["contig"])
+    for name, _ in _BATCH_FIELDS:
+        setattr(b, name, arrs[name].ctypes.data)
+    b.seq4_bytes, b.cigar_words = arrs["seq4"].size, arrs["cigar"].size
+    lens = np.ascontiguousarray(batch["contig_lens"], np.uint32)
+    names = [str(x) for x in (names if names is not None else batch.get("contig_names", ["ctg%d" % i for i in range(len(lens))]))]
+    cnames = (C.c_char_p * max(len(names), 1))(*[n.encode() for n in names])
+    rc = lib.dll.kd_write_bam(os.fsencode(str(path)), C.byref(b), len(lens), cnames, _ptr(lens), sort_order.encode(), int(threads), int(level))
+    if rc:
+        raise _EXC.get(rc, KindelNativeError)("%s: %s" % (path, lib.dll.kd_decode_last_error().decode()))
 
 
 def decode_file(path, threads=0, lib=None):
@@ -262,6 +355,22 @@ class Engine:
         b = self._struct(ptrs, n_reads)
         b.seq4_bytes, b.cigar_words = seq4_bytes, cigar_words
         self._check(self.lib.dll.kd_push_batch_device(self._h, C.byref(b)), "kd_push_batch_device")
+
+    def push_stream(self, stream):
+        """Every remaining batch of a Stream: decode of batch k+1 overlapped with copy + kernels of batch k.
+        -> dict(batches, decode_s, push_s, wall_s)"""
+        st = (C.c_uint64 * 4)()
+        rc = self.lib.dll.kd_push_stream(self._h, stream._h, st)
+        if rc == KD_E_NOREF:
+            raise KeyError(self.lib.dll.kd_last_error(self._h).decode())
+        self._check(rc, "kd_push_stream")
+        return dict(batches=int(st[0]), decode_s=st[1] / 1e6, push_s=st[2] / 1e6, wall_s=st[3] / 1e6)
+
+    def contig_first(self):
+        """uint64[n_contigs]: index of each contig's first record over all pushed records, 2^64-1 = none"""
+        out = np.zeros(len(self.contig_lens), np.uint64)
+        self._check(self.lib.dll.kd_get_contig_first(self._h, _ptr(out)), "kd_get_contig_first")
+        return out
 
     def sync(self):
         self._check(self.lib.dll.kd_sync(self._h), "kd_sync")

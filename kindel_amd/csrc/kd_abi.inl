@@ -2,7 +2,11 @@
 // Included once by the translation unit that defines KD_RT (kindel_hip.hip for the product,
 // tests/emu/emu_lib.cpp for the kernel-logic emulator).  Decoder entry points live in
 // kd_decode.cpp.
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
 
 struct kd_ctx {
     KdEngine<KD_RT> e;
@@ -129,6 +133,77 @@ int kd_consensus_offsets(kd_ctx *ctx, uint64_t *contig_off, uint32_t *depth_minm
     if (contig_off) memcpy(contig_off, ctx->e.h_coff.data(), ctx->e.h_coff.size() * 8);
     if (depth_minmax) memcpy(depth_minmax, ctx->e.h_minmax.data(), ctx->e.h_minmax.size() * 4);
     return KD_OK;
+}
+
+int kd_get_contig_first(kd_ctx *ctx, uint64_t *first_idx) {
+    if (!ctx || !first_idx) return KD_E_ARG;
+    if (ctx->e.rt.d2h(first_idx, ctx->e.d_first_idx, (size_t)ctx->e.n_contigs * 8)) return ctx->e.hipfail("kd_get_contig_first");
+    return KD_OK;
+}
+
+int kd_push_stream(kd_ctx *ctx, kd_stream *s, uint64_t stats[4]) {
+    if (!ctx || !s) return KD_E_ARG;
+    typedef std::chrono::steady_clock clk;
+    auto us = [](clk::time_point a, clk::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+    const clk::time_point t_begin = clk::now();
+    // one-slot hand-off: the producer decodes batch k+1 (into the stream's other slot) while the consumer pushes batch k
+    std::mutex mu;
+    std::condition_variable cv;
+    const kd_batch *ready = nullptr;
+    bool have = false, finished = false;
+    int prod_rc = KD_OK;
+    uint64_t decode_us = 0;
+    std::thread producer([&]() {
+        for (;;) {
+            const kd_batch *b = nullptr;
+            const clk::time_point t0 = clk::now();
+            const int rc = kd_stream_next(s, &b);
+            decode_us += us(t0, clk::now());
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !have; });     // the consumer has taken the previous batch (and finished reading the one before)
+            if (rc) { prod_rc = rc; finished = true; cv.notify_all(); return; }
+            if (!b) { finished = true; cv.notify_all(); return; }
+            ready = b; have = true;
+            cv.notify_all();
+        }
+    });
+    uint64_t n_batches = 0, push_us = 0;
+    int rc = KD_OK;
+    for (;;) {
+        const kd_batch *b = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return have || finished; });
+            if (!have) break;
+            b = ready;
+        }
+        const clk::time_point t0 = clk::now();
+        if (rc == KD_OK) rc = ctx->e.push_host(*b);   // after an error the remaining batches are only drained
+        push_us += us(t0, clk::now());
+        n_batches++;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            have = false;                             // the slot may be decoded into again
+        }
+        cv.notify_all();
+    }
+    producer.join();
+    if (rc == KD_OK && prod_rc) rc = ctx->e.fail(prod_rc, kd_stream_last_error(s));
+    if (stats) { stats[0] = n_batches; stats[1] = decode_us; stats[2] = push_us; stats[3] = us(t_begin, clk::now()); }
+    return rc;
+}
+
+int kd_decode_push_file(kd_ctx *ctx, const char *path, int n_threads, uint64_t chunk_bytes, uint64_t stats[4]) {
+    if (!ctx || !path) return KD_E_ARG;
+    kd_stream *s = nullptr;
+    int rc = kd_stream_open(&s, path, n_threads, chunk_bytes);
+    if (rc) return ctx->e.fail(rc, kd_stream_last_error(nullptr));
+    bool same = kd_stream_n_contigs(s) == ctx->e.n_contigs;
+    for (uint32_t c = 0; same && c < ctx->e.n_contigs; c++) same = kd_stream_contig_len(s, c) == ctx->e.clen[c];
+    if (!same) { kd_stream_close(s); return ctx->e.fail(KD_E_ARG, "kd_decode_push_file: the file's @SQ table differs from the context's contig table"); }
+    rc = kd_push_stream(ctx, s, stats);
+    kd_stream_close(s);
+    return rc;
 }
 
 int kd_profile_enable(kd_ctx *ctx, int on) {

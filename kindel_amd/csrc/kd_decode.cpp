@@ -182,21 +182,35 @@ void finish_view(File &f) {
     v.cigar = f.cigar.data(); v.cigar_words = f.cigar.size() - 2;
 }
 
-int parse_bam(const Arr<uint8_t> &d, File &f, int n_threads) {
-    const size_t n = d.size();
-    if (n < 12 || memcmp(d.data(), "BAM\1", 4) != 0) { g_decode_error = "not a BAM stream"; return KD_E_IO; }
-    size_t o = 8 + (size_t)rd32(d.data() + 4);
-    if (o + 4 > n) { g_decode_error = "truncated BAM header"; return KD_E_IO; }
-    const uint32_t n_ref = rd32(d.data() + o);
+// BAM header of the uncompressed stream d[0, n): reference names / lengths -> f, *o = offset of the first record.
+// KD_E_IO + g_decode_error on a malformed header; `need_more` is set when the header is merely cut off at n.
+int parse_bam_header(const uint8_t *d, size_t n, std::vector<std::string> &names, std::vector<uint32_t> &lens, size_t *o_out,
+                     bool *need_more) {
+    *need_more = false;
+    if (n < 12) { *need_more = true; g_decode_error = "truncated BAM header"; return KD_E_IO; }
+    if (memcmp(d, "BAM\1", 4) != 0) { g_decode_error = "not a BAM stream"; return KD_E_IO; }
+    size_t o = 8 + (size_t)rd32(d + 4);
+    if (o + 4 > n) { *need_more = true; g_decode_error = "truncated BAM header"; return KD_E_IO; }
+    const uint32_t n_ref = rd32(d + o);
     o += 4;
     for (uint32_t r = 0; r < n_ref; r++) {
-        if (o + 4 > n) { g_decode_error = "truncated BAM reference list"; return KD_E_IO; }
-        const uint32_t l_name = rd32(d.data() + o);
-        if (o + 8 + l_name > n || !l_name) { g_decode_error = "truncated BAM reference list"; return KD_E_IO; }
-        f.names.emplace_back((const char *)d.data() + o + 4, l_name - 1);
-        f.lens.push_back(rd32(d.data() + o + 4 + l_name));
+        if (o + 4 > n) { *need_more = true; g_decode_error = "truncated BAM reference list"; return KD_E_IO; }
+        const uint32_t l_name = rd32(d + o);
+        if (!l_name) { g_decode_error = "malformed BAM reference list"; return KD_E_IO; }
+        if (o + 8 + l_name > n) { *need_more = true; g_decode_error = "truncated BAM reference list"; return KD_E_IO; }
+        names.emplace_back((const char *)d + o + 4, l_name - 1);
+        lens.push_back(rd32(d + o + 4 + l_name));
         o += 8 + l_name;
     }
+    *o_out = o;
+    return KD_OK;
+}
+
+// The records of d[o, n) -> the SoA arrays of f (replaced, not appended).  final: the stream ends at n, a cut-off record
+// is an error; otherwise the walk stops in front of it and *consumed tells where (the caller carries the rest over into
+// the next chunk).
+int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, int n_threads, bool final, size_t *consumed) {
+    const size_t n = d.size();
     // pass 1 (touches 4 + 20 bytes per record): follow the block_size chain, record where every kept record starts and
     // the running totals of packed-base bytes / CIGAR words.  The chain is sequential by nature (a record's length
     // says where the next one begins), and at ~75 ns per record it was most of the decode time, so it is walked IN
@@ -255,7 +269,11 @@ int parse_bam(const Arr<uint8_t> &d, File &f, int n_threads) {
         size_t q = p0;
         while (q < p_end && q + 4 <= n) {
             const uint32_t bs = rd32(d.data() + q);
-            if (q + 4 + (size_t)bs > n || bs < 32) { err = "truncated BAM record"; return false; }
+            if (bs < 32) { err = "malformed BAM record"; return false; }
+            if (q + 4 + (size_t)bs > n) {
+                if (!final) break;                 // cut off by the chunk boundary: the next chunk starts with it
+                err = "truncated BAM record"; return false;
+            }
             const uint8_t *r = d.data() + q + 4;
             const int32_t refid = (int32_t)rd32(r);
             n_rec++;
@@ -275,7 +293,7 @@ int parse_bam(const Arr<uint8_t> &d, File &f, int n_threads) {
     unsigned nt1 = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
     size_t min_range = 4u << 20;                                      // >= 4 MB of records per range ...
     if (const char *e = getenv("KD_DECODE_RANGE_BYTES")) min_range = std::max<size_t>(64, strtoull(e, nullptr, 10));   // ... tests: small
-    nt1 = (unsigned)std::max<size_t>(1, std::min<size_t>(nt1, (n - o) / min_range));
+    nt1 = (unsigned)std::max<size_t>(1, std::min<size_t>(nt1, (n - std::min(o, n)) / min_range));
     constexpr int KD_SPEC_CHAIN = 16;
     std::vector<std::vector<Rec>> part(nt1);
     std::vector<uint64_t> part_nrec(nt1, 0);
@@ -318,6 +336,8 @@ int parse_bam(const Arr<uint8_t> &d, File &f, int n_threads) {
         if (!pok[t]) { g_decode_error = perr[t]; return KD_E_IO; }
         p = stop[t];
     }
+    if (final && p != n) { g_decode_error = "truncated BAM record"; return KD_E_IO; }
+    *consumed = p;
     // prefix over the ranges: first record index / packed-base byte / CIGAR word of each
     std::vector<size_t> k_at(nt1 + 1, 0), sq_at(nt1 + 1, 0), cg_at(nt1 + 1, 0);
     for (unsigned t = 0; t < nt1; t++) {
@@ -370,141 +390,156 @@ struct SamPart {
     int err_code = KD_E_IO;
 };
 
-int parse_sam(const Arr<uint8_t> &raw, File &f, int n_threads) {
-    // character -> BAM base code / CIGAR op code; built once (C++11 static initialisation is thread-safe)
-    struct Tables {
-        int8_t nib[256], op[256];
-        uint8_t known[256];
-        Tables() {
-            memset(nib, 0, sizeof nib);     // characters outside the BAM alphabet -> '=' (0): a KeyError in M / clip context
-            memset(op, 15, sizeof op);      // unknown CIGAR letters are ignored by the reference's if/elif chain
-            memset(known, 0, sizeof known);
-            const char *nibs = "=ACMGRSVTWYHKDBN";
-            for (int i = 0; i < 16; i++) {
-                nib[(uint8_t)nibs[i]] = (int8_t)i; nib[(uint8_t)tolower(nibs[i])] = (int8_t)i;
-                known[(uint8_t)nibs[i]] = 1; known[(uint8_t)tolower(nibs[i])] = 1;
-            }
-            const char *ops = "MIDNSHP=X";
-            for (int i = 0; i < 9; i++) op[(uint8_t)ops[i]] = (int8_t)i;
+// character -> BAM base code / CIGAR op code; built once (C++11 static initialisation is thread-safe)
+struct SamTables {
+    int8_t nib[256], op[256];
+    uint8_t known[256];
+    SamTables() {
+        memset(nib, 0, sizeof nib);     // characters outside the BAM alphabet -> '=' (0): a KeyError in M / clip context
+        memset(op, 15, sizeof op);      // unknown CIGAR letters are ignored by the reference's if/elif chain
+        memset(known, 0, sizeof known);
+        const char *nibs = "=ACMGRSVTWYHKDBN";
+        for (int i = 0; i < 16; i++) {
+            nib[(uint8_t)nibs[i]] = (int8_t)i; nib[(uint8_t)tolower(nibs[i])] = (int8_t)i;
+            known[(uint8_t)nibs[i]] = 1; known[(uint8_t)tolower(nibs[i])] = 1;
         }
-    };
-    static const Tables TB;
-    const int8_t *nibtab = TB.nib, *optab = TB.op;
-    std::unordered_map<std::string, uint32_t> ids;
-    const char *base = (const char *)raw.data(), *end = base + raw.size();
-    auto header_line = [&](const char *p, const char *e) -> bool {   // '@' line: only @SQ matters (kindel.py:138-141)
-        if (e - p >= 3 && p[1] == 'S' && p[2] == 'Q') {
-            std::string name;
-            long ln = -1;
-            const char *q = p;
-            while (q < e) {
-                const char *t = (const char *)memchr(q, '\t', (size_t)(e - q));
-                const char *fe = t ? t : e;
-                if (fe - q > 3 && q[0] == 'S' && q[1] == 'N' && q[2] == ':') name.assign(q + 3, fe);
-                if (fe - q > 3 && q[0] == 'L' && q[1] == 'N' && q[2] == ':') ln = strtol(std::string(q + 3, fe).c_str(), nullptr, 10);
-                q = t ? t + 1 : e;
-            }
-            if (name.empty() || ln < 0) { g_decode_error = "@SQ line without SN/LN"; return false; }
-            ids[name] = (uint32_t)f.names.size();
-            f.names.push_back(name);
-            f.lens.push_back((uint32_t)ln);
-        }
-        return true;
-    };
-    // alignment line [p, e) -> one record of `o` (or dropped: RNAME '*', kindel.py:147-148); false = error in o.err
-    auto record_line = [&](const char *p, const char *e, SamPart &o) -> bool {
-        const char *fld[11];
-        int nf = 0;
+        const char *ops = "MIDNSHP=X";
+        for (int i = 0; i < 9; i++) op[(uint8_t)ops[i]] = (int8_t)i;
+    }
+};
+const SamTables &sam_tables() { static const SamTables TB; return TB; }
+
+typedef std::unordered_map<std::string, uint32_t> SamIds;
+
+// '@' line: only @SQ matters (kindel.py:138-141)
+bool sam_header_line(const char *p, const char *e, SamIds &ids, std::vector<std::string> &names, std::vector<uint32_t> &lens) {
+    if (e - p >= 3 && p[1] == 'S' && p[2] == 'Q') {
+        std::string name;
+        long ln = -1;
         const char *q = p;
-        while (nf < 11 && q <= e) {
-            fld[nf++] = q;
+        while (q < e) {
             const char *t = (const char *)memchr(q, '\t', (size_t)(e - q));
-            if (!t) break;
-            q = t + 1;
+            const char *fe = t ? t : e;
+            if (fe - q > 3 && q[0] == 'S' && q[1] == 'N' && q[2] == ':') name.assign(q + 3, fe);
+            if (fe - q > 3 && q[0] == 'L' && q[1] == 'N' && q[2] == ':') ln = strtol(std::string(q + 3, fe).c_str(), nullptr, 10);
+            q = t ? t + 1 : e;
         }
-        if (nf < 10) { o.err = "SAM record with fewer than 10 fields"; return false; }
-        auto flen = [&](int i) { return (size_t)((i + 1 < nf ? fld[i + 1] - 1 : e) - fld[i]); };
-        o.n_records++;
-        std::string rname(fld[2], flen(2));
-        if (rname == "*") return true;
-        auto it = ids.find(rname);
-        if (it == ids.end()) { o.err = rname; o.err_code = KD_E_NOREF; return false; }   // refs_lens[ref_id], kindel.py:151
-        o.contig.push_back(it->second);
-        o.flag.push_back((uint32_t)strtoul(std::string(fld[1], flen(1)).c_str(), nullptr, 10));
-        o.pos0.push_back((int32_t)(strtol(std::string(fld[3], flen(3)).c_str(), nullptr, 10) - 1));
-        o.cig_off.push_back(o.cigar.size());
-        uint32_t nc = 0;
-        const char *c = fld[5], *ce = c + flen(5);
-        if (!(ce - c == 1 && *c == '*')) {
-            uint64_t num = 0;
-            for (; c < ce; c++) {
-                if (*c >= '0' && *c <= '9') num = num * 10 + (uint64_t)(*c - '0');
-                else {
-                    if (num >= (1ULL << 28)) { o.err = "CIGAR length too large"; return false; }
-                    o.cigar.push_back((uint32_t)(num << 4) | (uint32_t)(uint8_t)optab[(uint8_t)*c]);
-                    num = 0; nc++;
-                }
+        if (name.empty() || ln < 0) { g_decode_error = "@SQ line without SN/LN"; return false; }
+        ids[name] = (uint32_t)names.size();
+        names.push_back(name);
+        lens.push_back((uint32_t)ln);
+    }
+    return true;
+}
+
+// alignment line [p, e) -> one record of `o` (or dropped: RNAME '*', kindel.py:147-148); false = error in o.err
+bool sam_record_line(const char *p, const char *e, const SamIds &ids, SamPart &o) {
+    const SamTables &TB = sam_tables();
+    const int8_t *nibtab = TB.nib, *optab = TB.op;
+    const char *fld[11];
+    int nf = 0;
+    const char *q = p;
+    while (nf < 11 && q <= e) {
+        fld[nf++] = q;
+        const char *t = (const char *)memchr(q, '\t', (size_t)(e - q));
+        if (!t) break;
+        q = t + 1;
+    }
+    if (nf < 10) { o.err = "SAM record with fewer than 10 fields"; return false; }
+    auto flen = [&](int i) { return (size_t)((i + 1 < nf ? fld[i + 1] - 1 : e) - fld[i]); };
+    o.n_records++;
+    std::string rname(fld[2], flen(2));
+    if (rname == "*") return true;
+    auto it = ids.find(rname);
+    if (it == ids.end()) { o.err = rname; o.err_code = KD_E_NOREF; return false; }   // refs_lens[ref_id], kindel.py:151
+    o.contig.push_back(it->second);
+    o.flag.push_back((uint32_t)strtoul(std::string(fld[1], flen(1)).c_str(), nullptr, 10));
+    o.pos0.push_back((int32_t)(strtol(std::string(fld[3], flen(3)).c_str(), nullptr, 10) - 1));
+    o.cig_off.push_back(o.cigar.size());
+    uint32_t nc = 0;
+    const char *c = fld[5], *ce = c + flen(5);
+    if (!(ce - c == 1 && *c == '*')) {
+        uint64_t num = 0;
+        for (; c < ce; c++) {
+            if (*c >= '0' && *c <= '9') num = num * 10 + (uint64_t)(*c - '0');
+            else {
+                if (num >= (1ULL << 28)) { o.err = "CIGAR length too large"; return false; }
+                o.cigar.push_back((uint32_t)(num << 4) | (uint32_t)(uint8_t)optab[(uint8_t)*c]);
+                num = 0; nc++;
             }
         }
-        o.n_cig.push_back(nc);
-        const char *sq = fld[9];
-        size_t sl = flen(9);
-        if (sl == 1 && *sq == '*') sl = 0;
-        o.seq_off.push_back(o.seq4.size());
-        o.seq_len.push_back((uint32_t)sl);
-        bool all_known = true;
-        for (size_t i = 0; i < sl; i += 2) {
-            const uint8_t hi = (uint8_t)nibtab[(uint8_t)sq[i]];
-            const uint8_t lo = i + 1 < sl ? (uint8_t)nibtab[(uint8_t)sq[i + 1]] : 0;
-            all_known = all_known && TB.known[(uint8_t)sq[i]] && (i + 1 >= sl || TB.known[(uint8_t)sq[i + 1]]);
-            o.seq4.push_back((uint8_t)(hi << 4 | lo));
+    }
+    o.n_cig.push_back(nc);
+    const char *sq = fld[9];
+    size_t sl = flen(9);
+    if (sl == 1 && *sq == '*') sl = 0;
+    o.seq_off.push_back(o.seq4.size());
+    o.seq_len.push_back((uint32_t)sl);
+    bool all_known = true;
+    for (size_t i = 0; i < sl; i += 2) {
+        const uint8_t hi = (uint8_t)nibtab[(uint8_t)sq[i]];
+        const uint8_t lo = i + 1 < sl ? (uint8_t)nibtab[(uint8_t)sq[i + 1]] : 0;
+        all_known = all_known && TB.known[(uint8_t)sq[i]] && (i + 1 >= sl || TB.known[(uint8_t)sq[i + 1]]);
+        o.seq4.push_back((uint8_t)(hi << 4 | lo));
+    }
+    if (!all_known) {
+        // A character outside "=ACMGRSVTWYHKDBN" cannot be stored in 4 bits.  Inside M / clip context it is a KeyError like
+        // any non-ACGTN base (code 0 raises it); inside an INSERTION the reference keeps the text verbatim
+        // (kindel.py:55-58, no alphabet check), which this encoding cannot reproduce: refuse loudly.
+        const uint32_t *cw = o.cigar.data() + o.cig_off[o.cig_off.size() - 1];
+        size_t qpos = 0;
+        for (uint32_t k = 0; k < nc; k++) {
+            const size_t len = cw[k] >> 4;
+            const uint32_t op = cw[k] & 15u;
+            if (op == 1)
+                for (size_t x = qpos; x < qpos + len && x < sl; x++)
+                    if (!TB.known[(uint8_t)sq[x]]) {
+                        o.err = std::string("insertion contains '") + sq[x] + "', a character outside the BAM base alphabet (=ACMGRSVTWYHKDBN)";
+                        return false;
+                    }
+            if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qpos += len;
         }
-        if (!all_known) {
-            // A character outside "=ACMGRSVTWYHKDBN" cannot be stored in 4 bits.  Inside M / clip context it is a KeyError like
-            // any non-ACGTN base (code 0 raises it); inside an INSERTION the reference keeps the text verbatim
-            // (kindel.py:55-58, no alphabet check), which this encoding cannot reproduce: refuse loudly.
-            const uint32_t *cw = o.cigar.data() + o.cig_off[o.cig_off.size() - 1];
-            size_t qpos = 0;
-            for (uint32_t k = 0; k < nc; k++) {
-                const size_t len = cw[k] >> 4;
-                const uint32_t op = cw[k] & 15u;
-                if (op == 1)
-                    for (size_t x = qpos; x < qpos + len && x < sl; x++)
-                        if (!TB.known[(uint8_t)sq[x]]) {
-                            o.err = std::string("insertion contains '") + sq[x] + "', a character outside the BAM base alphabet (=ACMGRSVTWYHKDBN)";
-                            return false;
-                        }
-                if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qpos += len;
-            }
+    }
+    return true;
+}
+
+// The leading header block of SAM text [base, end): fills ids / names / lens, -> the first alignment line (or end)
+int parse_sam_header(const char *base, const char *end, SamIds &ids, std::vector<std::string> &names, std::vector<uint32_t> &lens,
+                     const char **rec0) {
+    const char *p = base;
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        const char *e = le;
+        if (e > p && e[-1] == '\r') e--;
+        if (e > p) {
+            if (*p != '@') break;
+            if (!sam_header_line(p, e, ids, names, lens)) return KD_E_IO;
         }
-        return true;
-    };
-    // the lines of [p, pe): header lines are only legal while `headers_ok` (the leading block)
-    auto lines = [&](const char *p, const char *pe, bool headers_ok, SamPart &o, const char **first_record) -> bool {
+        if (!nl) { p = end; break; }
+        p = nl + 1;
+    }
+    *rec0 = p;
+    return KD_OK;
+}
+
+// The alignment lines of [rec0, end) (whole lines) -> the SoA arrays of f (replaced), parsed in parallel line-aligned ranges
+int parse_sam_records(const char *rec0, const char *end, const SamIds &ids, File &f, int n_threads) {
+    auto lines = [&](const char *p, const char *pe, SamPart &o) -> bool {
         while (p < pe) {
             const char *nl = (const char *)memchr(p, '\n', (size_t)(pe - p));
             const char *le = nl ? nl : pe;
             const char *e = le;
             if (e > p && e[-1] == '\r') e--;
             if (e > p) {
-                if (*p == '@') {
-                    if (!headers_ok) { o.err = "header line after the first alignment line"; return false; }
-                    if (!header_line(p, e)) { o.err = g_decode_error; return false; }
-                } else {
-                    if (first_record) { *first_record = p; return true; }   // header scan stops at the first record
-                    if (!record_line(p, e, o)) return false;
-                }
+                if (*p == '@') { o.err = "header line after the first alignment line"; return false; }
+                if (!sam_record_line(p, e, ids, o)) return false;
             }
             if (!nl) break;
             p = nl + 1;
         }
-        if (first_record) *first_record = pe;
         return true;
     };
-    // 1. the leading header block (sequential), 2. the alignment lines in parallel line-aligned ranges, 3. merge
-    SamPart hdr;
-    const char *rec0 = end;
-    if (!lines(base, end, true, hdr, &rec0)) { g_decode_error = hdr.err; return KD_E_IO; }
     size_t min_range = 4u << 20;
     if (const char *ev = getenv("KD_DECODE_RANGE_BYTES")) min_range = std::max<size_t>(64, strtoull(ev, nullptr, 10));
     unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
@@ -521,7 +556,7 @@ int parse_sam(const Arr<uint8_t> &raw, File &f, int n_threads) {
     std::vector<char> ok(nt, 1);
     {
         std::vector<std::thread> th;
-        auto work = [&](unsigned t) { ok[t] = lines(cut[t], cut[t + 1], false, part[t], nullptr) ? 1 : 0; };
+        auto work = [&](unsigned t) { ok[t] = lines(cut[t], cut[t + 1], part[t]) ? 1 : 0; };
         for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
         work(0);
         for (auto &x : th) x.join();
@@ -559,6 +594,143 @@ int parse_sam(const Arr<uint8_t> &raw, File &f, int n_threads) {
     return KD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Chunked reading: the file as a sequence of batches of about `chunk_bytes` uncompressed bytes each (whole records).
+// BGZF: the blocks of a chunk are inflated in parallel behind the carried-over tail of the previous chunk (the record the
+// chunk boundary cut); SAM text: chunks end on line boundaries; any other gzip stream: one chunk.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Stream {
+    Arr<uint8_t> raw;
+    int n_threads = 0;
+    size_t chunk_bytes = 0;
+    bool is_text = false, bgzf = false, done = false;
+    std::vector<std::string> names;
+    std::vector<uint32_t> lens;
+    uint64_t n_records = 0;
+    // BGZF / BAM
+    std::vector<Block> blocks;
+    size_t next_block = 0;
+    Arr<uint8_t> buf, carry;   // uncompressed bytes of the current chunk (carry + blocks); the cut-off record of the last one
+    uint32_t n_ref = 0;
+    bool header_done = false;
+    Arr<uint8_t> whole;        // non-BGZF gzip: the whole stream
+    // SAM
+    SamIds ids;
+    const char *sam_pos = nullptr, *sam_end = nullptr;
+
+    int open(const char *path, int threads, size_t chunk) {
+        n_threads = threads; chunk_bytes = chunk ? chunk : (size_t)64 << 20;
+        if (!read_all(path, raw)) { g_decode_error = std::string("cannot read ") + path; return KD_E_IO; }
+        if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) {
+            size_t total = 0;
+            bgzf = scan_bgzf(raw, blocks, total);
+            if (!bgzf) {
+                blocks.clear();
+                if (!inflate_generic(raw, whole)) { g_decode_error = "gzip inflate failed"; return KD_E_IO; }
+            }
+            // the header may span several blocks: inflate until it parses
+            return bgzf ? KD_OK : header_from(whole.data(), whole.size(), true);
+        }
+        is_text = true;
+        sam_end = (const char *)raw.data() + raw.size();
+        return parse_sam_header((const char *)raw.data(), sam_end, ids, names, lens, &sam_pos);
+    }
+    size_t hdr_end = 0;
+    int header_from(const uint8_t *d, size_t n, bool final) {
+        bool more = false;
+        names.clear(); lens.clear();
+        int rc = parse_bam_header(d, n, names, lens, &hdr_end, &more);
+        if (rc && more && !final) return 1;   // need more bytes
+        if (rc) return rc;
+        n_ref = (uint32_t)names.size();
+        header_done = true;
+        return KD_OK;
+    }
+    // inflate blocks [b0, b1) behind the first `keep` bytes of buf
+    bool inflate_blocks(size_t b0, size_t b1, size_t keep) {
+        size_t add = 0;
+        for (size_t b = b0; b < b1; b++) add += blocks[b].out_len;
+        if (!buf.resize(keep + add)) return false;
+        std::vector<size_t> at(b1 - b0);
+        size_t o = keep;
+        for (size_t b = b0; b < b1; b++) { at[b - b0] = o; o += blocks[b].out_len; }
+        std::atomic<size_t> next{b0};
+        std::atomic<bool> ok{true};
+        auto work = [&]() {
+            for (;;) {
+                const size_t b = next.fetch_add(1);
+                if (b >= b1) break;
+                if (!inflate_raw(raw.data() + blocks[b].in_off, blocks[b].in_len, buf.data() + at[b - b0], blocks[b].out_len)) ok = false;
+            }
+        };
+        unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+        nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, b1 - b0));
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        return ok;
+    }
+    // next batch into f (arrays replaced); *got = false at the end of the file
+    int next(File &f, bool *got) {
+        *got = false;
+        f.n_records = 0;
+        if (done) return KD_OK;
+        if (is_text) {
+            if (sam_pos >= sam_end) { done = true; return KD_OK; }
+            const char *e = sam_pos + std::min<size_t>(chunk_bytes, (size_t)(sam_end - sam_pos));
+            if (e < sam_end) {
+                const char *nl = (const char *)memchr(e, '\n', (size_t)(sam_end - e));
+                e = nl ? nl + 1 : sam_end;
+            }
+            int rc = parse_sam_records(sam_pos, e, ids, f, n_threads);
+            if (rc) return rc;
+            sam_pos = e;
+            n_records += f.n_records;
+            *got = true;
+            return KD_OK;
+        }
+        if (!bgzf) {   // one chunk
+            if (!header_done) return KD_E_IO;
+            size_t used = 0;
+            int rc = parse_bam_records(whole, hdr_end, n_ref, f, n_threads, true, &used);
+            if (rc) return rc;
+            done = true; n_records += f.n_records; *got = true;
+            return KD_OK;
+        }
+        for (;;) {
+            if (next_block >= blocks.size() && carry.size() == 0 && header_done) { done = true; return KD_OK; }
+            // blocks of this chunk
+            size_t b1 = next_block, add = 0;
+            while (b1 < blocks.size() && (add < chunk_bytes || b1 == next_block)) add += blocks[b1++].out_len;
+            const size_t keep = carry.size();
+            if (!buf.resize(keep)) { g_decode_error = "out of memory"; return KD_E_NOMEM; }
+            if (keep) memcpy(buf.data(), carry.data(), keep);
+            if (!inflate_blocks(next_block, b1, keep)) { g_decode_error = "BGZF inflate failed"; return KD_E_IO; }
+            next_block = b1;
+            const bool final = next_block >= blocks.size();
+            size_t o = 0;
+            if (!header_done) {
+                int rc = header_from(buf.data(), buf.size(), final);
+                if (rc == 1) { carry.resize(buf.size()); memcpy(carry.data(), buf.data(), buf.size()); continue; }   // header not complete yet
+                if (rc) return rc;
+                o = hdr_end;
+            }
+            size_t used = 0;
+            int rc = parse_bam_records(buf, o, n_ref, f, n_threads, final, &used);
+            if (rc) return rc;
+            carry.resize(buf.size() - used);
+            if (carry.size()) memcpy(carry.data(), buf.data() + used, carry.size());
+            n_records += f.n_records;
+            if (f.contig.size() == 0 && !final) continue;   // a chunk smaller than one record: keep reading
+            if (final) { done = true; }
+            *got = f.contig.size() > 0 || final;
+            if (final && f.contig.size() == 0) *got = false;
+            return KD_OK;
+        }
+    }
+};
+
 }  // namespace
 
 struct kd_file {
@@ -570,24 +742,208 @@ extern "C" {
 int kd_decode_open(kd_file **out, const char *path, int n_threads) {
     if (!out || !path) return KD_E_ARG;
     *out = nullptr;
-    Arr<uint8_t> raw;
-    if (!read_all(path, raw)) { g_decode_error = std::string("cannot read ") + path; return KD_E_IO; }
+    Stream st;
+    int rc = st.open(path, n_threads, ~(size_t)0 >> 1);   // one chunk = the whole file
+    if (rc) return rc;
     kd_file *h = new kd_file();
-    int rc;
-    if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) {
-        Arr<uint8_t> data;
-        if (!decompress(raw, data, n_threads)) { delete h; g_decode_error = "gzip/BGZF inflate failed"; return KD_E_IO; }
-        rc = parse_bam(data, h->f, n_threads);
-    } else {
-        rc = parse_sam(raw, h->f, n_threads);
-    }
+    bool got = false;
+    rc = st.next(h->f, &got);
     if (rc) { delete h; return rc; }
+    if (!got) { h->f.contig.resize(0); h->f.pos0.resize(0); h->f.flag.resize(0); h->f.seq_off.resize(0); h->f.seq_len.resize(0);
+                h->f.cig_off.resize(0); h->f.n_cig.resize(0); h->f.seq4.resize(0); h->f.cigar.resize(0); }
+    if (!st.is_text && !st.header_done) { delete h; g_decode_error = "truncated BAM header"; return KD_E_IO; }
+    h->f.names = st.names; h->f.lens = st.lens;
+    h->f.n_records = st.n_records;
     finish_view(h->f);
     *out = h;
     return KD_OK;
 }
 
 const char *kd_decode_last_error(void) { return g_decode_error.c_str(); }
+
+// ---- chunked reading (kd_stream_*) ----
+struct kd_stream {
+    Stream st;
+    File slot[2];
+    int cur = 0;
+    std::string err;
+};
+
+int kd_stream_open(kd_stream **out, const char *path, int n_threads, uint64_t chunk_bytes) {
+    if (!out || !path) return KD_E_ARG;
+    *out = nullptr;
+    kd_stream *h = new kd_stream();
+    int rc = h->st.open(path, n_threads, (size_t)chunk_bytes);
+    if (!rc && !h->st.is_text && !h->st.header_done) {
+        // BGZF: the header sits in the first blocks; read it now so that the contig table is known before the first batch
+        Stream &S = h->st;
+        size_t b1 = 0, add = 0;
+        while (b1 < S.blocks.size() && !S.header_done) {
+            add += S.blocks[b1++].out_len;
+            if (!S.inflate_blocks(0, b1, 0)) { rc = KD_E_IO; g_decode_error = "BGZF inflate failed"; break; }
+            const int hr = S.header_from(S.buf.data(), S.buf.size(), b1 >= S.blocks.size());
+            if (hr != 1 && hr != KD_OK) { rc = hr; break; }
+        }
+        if (!rc && !S.header_done) { rc = KD_E_IO; g_decode_error = "truncated BAM header"; }
+        S.header_done = false;   // next() parses it again from the first chunk (and skips it)
+        std::vector<std::string> nm = S.names; std::vector<uint32_t> ln = S.lens;
+        S.names = nm; S.lens = ln;
+    }
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return KD_OK;
+}
+uint32_t kd_stream_n_contigs(const kd_stream *s) { return s ? (uint32_t)s->st.names.size() : 0; }
+const char *kd_stream_contig_name(const kd_stream *s, uint32_t i) { return (s && i < s->st.names.size()) ? s->st.names[i].c_str() : nullptr; }
+uint32_t kd_stream_contig_len(const kd_stream *s, uint32_t i) { return (s && i < s->st.lens.size()) ? s->st.lens[i] : 0; }
+uint64_t kd_stream_n_records(const kd_stream *s) { return s ? s->st.n_records : 0; }
+int kd_stream_next(kd_stream *s, const kd_batch **batch) {
+    if (!s || !batch) return KD_E_ARG;
+    *batch = nullptr;
+    File &f = s->slot[s->cur];
+    s->cur ^= 1;
+    std::vector<std::string> names = s->st.names;     // the header of a BGZF stream is re-read with the first chunk
+    std::vector<uint32_t> lens = s->st.lens;
+    bool got = false;
+    const int rc = s->st.next(f, &got);
+    if (s->st.names.size() != names.size()) { s->st.names = names; s->st.lens = lens; }
+    if (rc) { s->err = g_decode_error; return rc; }
+    if (!got) return KD_OK;
+    finish_view(f);
+    *batch = &f.view;
+    return KD_OK;
+}
+// ---- BAM writer (tools: synthetic inputs for end-to-end runs; the product path only READS files) ----
+// Records of `b` (host arrays) as a BGZF-compressed BAM: record bodies are laid out and deflated in parallel.
+int kd_write_bam(const char *path, const kd_batch *b, uint32_t n_contigs, const char *const *names, const uint32_t *lens,
+                 const char *sort_order, int n_threads, int level) {
+    if (!path || !b || (n_contigs && (!names || !lens))) return KD_E_ARG;
+    const size_t n = (size_t)b->n_reads;
+    unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+    std::string text = std::string("@HD\tVN:1.6\tSO:") + (sort_order ? sort_order : "unknown") + "\n";
+    for (uint32_t c = 0; c < n_contigs; c++) text += std::string("@SQ\tSN:") + names[c] + "\tLN:" + std::to_string(lens[c]) + "\n";
+    std::string head("BAM\1", 4);
+    auto put32 = [](std::string &o, uint32_t v) { char t[4] = {(char)v, (char)(v >> 8), (char)(v >> 16), (char)(v >> 24)}; o.append(t, 4); };
+    put32(head, (uint32_t)text.size()); head += text; put32(head, n_contigs);
+    for (uint32_t c = 0; c < n_contigs; c++) { const std::string nm = names[c]; put32(head, (uint32_t)nm.size() + 1); head += nm; head.push_back(0); put32(head, lens[c]); }
+    // record sizes -> offsets
+    std::vector<uint64_t> off(n + 1);
+    auto rec_size = [&](size_t i) -> uint64_t {
+        const uint64_t sl = b->seq_len[i], nc = b->n_cig[i];
+        const uint64_t cig = nc > 65535 ? 8 : 4 * nc, aux = nc > 65535 ? 8 + 4 * nc : 0;
+        return 4 + 32 + 2 + cig + (sl + 1) / 2 + sl + aux;
+    };
+    {
+        const size_t per = (n + nt - 1) / std::max(1u, nt);
+        std::vector<uint64_t> part(nt + 1, 0);
+        auto w1 = [&](unsigned t) { uint64_t a = 0; for (size_t i = t * per; i < std::min(n, (t + 1) * per); i++) { off[i] = a; a += rec_size(i); } part[t + 1] = a; };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(w1, t);
+        w1(0);
+        for (auto &x : th) x.join();
+        for (unsigned t = 0; t < nt; t++) part[t + 1] += part[t];
+        auto w2 = [&](unsigned t) { for (size_t i = t * per; i < std::min(n, (t + 1) * per); i++) off[i] += part[t] + head.size(); };
+        std::vector<std::thread> th2;
+        for (unsigned t = 1; t < nt; t++) th2.emplace_back(w2, t);
+        w2(0);
+        for (auto &x : th2) x.join();
+        off[n] = part[nt] + head.size();
+    }
+    Arr<uint8_t> raw;
+    if (!raw.resize((size_t)off[n])) return KD_E_NOMEM;
+    memcpy(raw.data(), head.data(), head.size());
+    {
+        const size_t per = (n + nt - 1) / std::max(1u, nt);
+        auto fill = [&](unsigned t) {
+            for (size_t i = t * per; i < std::min(n, (t + 1) * per); i++) {
+                uint8_t *r = raw.data() + off[i];
+                const uint32_t sl = b->seq_len[i], nc = b->n_cig[i];
+                const uint32_t *cg = b->cigar + b->cig_off[i];
+                auto w32 = [](uint8_t *q, uint32_t v) { q[0] = (uint8_t)v; q[1] = (uint8_t)(v >> 8); q[2] = (uint8_t)(v >> 16); q[3] = (uint8_t)(v >> 24); };
+                w32(r, (uint32_t)(off[i + 1] - off[i] - 4));
+                w32(r + 4, b->contig[i]); w32(r + 8, (uint32_t)b->pos0[i]);
+                r[12] = 2; r[13] = 60; r[14] = 0; r[15] = 0;
+                const uint32_t ncw = nc > 65535 ? 2 : nc;
+                r[16] = (uint8_t)ncw; r[17] = (uint8_t)(ncw >> 8);
+                r[18] = (uint8_t)b->flag[i]; r[19] = (uint8_t)(b->flag[i] >> 8);
+                w32(r + 20, sl); w32(r + 24, 0xffffffffu); w32(r + 28, 0xffffffffu); w32(r + 32, 0);
+                r[36] = 'r'; r[37] = 0;
+                uint8_t *q = r + 38;
+                if (nc > 65535) {   // SAMv1 4.2.2: placeholder CIGAR, the real one in the CG:B,I tag
+                    uint64_t ref_len = 0;
+                    for (uint32_t k = 0; k < nc; k++) { const uint32_t op = cg[k] & 15u; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += cg[k] >> 4; }
+                    w32(q, (sl << 4) | 4u); w32(q + 4, ((uint32_t)ref_len << 4) | 3u); q += 8;
+                } else {
+                    for (uint32_t k = 0; k < nc; k++) w32(q + 4 * k, cg[k]);
+                    q += 4 * (size_t)nc;
+                }
+                memcpy(q, b->seq4 + b->seq_off[i], ((size_t)sl + 1) / 2); q += ((size_t)sl + 1) / 2;
+                memset(q, 0xff, sl); q += sl;
+                if (nc > 65535) {
+                    q[0] = 'C'; q[1] = 'G'; q[2] = 'B'; q[3] = 'I'; w32(q + 4, nc);
+                    for (uint32_t k = 0; k < nc; k++) w32(q + 8 + 4 * (size_t)k, cg[k]);
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(fill, t);
+        fill(0);
+        for (auto &x : th) x.join();
+    }
+    // BGZF blocks of 0xff00 uncompressed bytes, deflated in parallel, written in order
+    const size_t BS = 0xff00, nb = (raw.size() + BS - 1) / BS;
+    std::vector<std::vector<uint8_t>> blk(nb + 1);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> ok{true};
+    auto deflate_block = [&](const uint8_t *src, size_t len, std::vector<uint8_t> &out) -> bool {
+        out.resize(len + len / 8 + 64);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        zs.next_in = const_cast<uint8_t *>(src); zs.avail_in = (uInt)len;
+        zs.next_out = out.data() + 18; zs.avail_out = (uInt)(out.size() - 26);
+        const int rc = deflate(&zs, Z_FINISH);
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END) return false;
+        const size_t bsize = 18 + clen + 8;
+        if (bsize > 65536) return false;
+        static const uint8_t hdr[12] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0};
+        memcpy(out.data(), hdr, 12);
+        out[12] = 'B'; out[13] = 'C'; out[14] = 2; out[15] = 0; out[16] = (uint8_t)(bsize - 1); out[17] = (uint8_t)((bsize - 1) >> 8);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)len);
+        uint8_t *t = out.data() + 18 + clen;
+        t[0] = (uint8_t)crc; t[1] = (uint8_t)(crc >> 8); t[2] = (uint8_t)(crc >> 16); t[3] = (uint8_t)(crc >> 24);
+        t[4] = (uint8_t)len; t[5] = (uint8_t)(len >> 8); t[6] = (uint8_t)(len >> 16); t[7] = (uint8_t)(len >> 24);
+        out.resize(bsize);
+        return true;
+    };
+    auto work = [&]() {
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k > nb) break;
+            const size_t o = k * BS, len = k < nb ? std::min(BS, raw.size() - o) : 0;   // block nb: the empty EOF block
+            if (!deflate_block(raw.data() + std::min(o, raw.size()), len, blk[k])) ok = false;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    }
+    if (!ok) { g_decode_error = "deflate failed"; return KD_E_IO; }
+    FILE *f = fopen(path, "wb");
+    if (!f) { g_decode_error = std::string("cannot write ") + path; return KD_E_IO; }
+    bool wok = true;
+    for (size_t k = 0; k <= nb && wok; k++) wok = fwrite(blk[k].data(), 1, blk[k].size(), f) == blk[k].size();
+    wok = fclose(f) == 0 && wok;
+    if (!wok) { g_decode_error = std::string("write error on ") + path; return KD_E_IO; }
+    return KD_OK;
+}
+
+const char *kd_stream_last_error(const kd_stream *s) { return s ? s->err.c_str() : g_decode_error.c_str(); }
+void kd_stream_close(kd_stream *s) { delete s; }
 const kd_batch *kd_decode_batch(const kd_file *f) { return f ? &f->f.view : nullptr; }
 uint32_t kd_decode_n_contigs(const kd_file *f) { return f ? (uint32_t)f->f.names.size() : 0; }
 const char *kd_decode_contig_name(const kd_file *f, uint32_t i) { return (f && i < f->f.names.size()) ? f->f.names[i].c_str() : nullptr; }

@@ -189,7 +189,35 @@ def pileup_batch(batch, bam_path=None, device=0, lib=None, mode=N.KD_MODE_AUTO):
     return Pileup(eng, names, lens, _first_appearance(np.asarray(sub["contig"])), bam_path)
 
 
-def pileup_file(bam_path, device=0, lib=None, threads=0):
+#: a header whose contigs add up to at most this many sites is laid out whole and the file is STREAMED (decode of batch
+#: k+1 overlapped with copy + kernels of batch k); a larger header (a human genome's) goes through the whole-file decode,
+#: which lays out only the contigs that have records
+STREAM_MAX_SITES = 1 << 28
+
+
+def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=None):
+    """Decode + device record loop of one SAM / BAM file -> Pileup.  stream: True / False forces the path, None decides by
+    the size of the header (see STREAM_MAX_SITES)."""
+    if stream is not False:
+        st = N.Stream(bam_path, threads=threads, chunk_bytes=chunk_bytes, lib=lib)
+        try:
+            total = int(st.contig_lens.astype(np.uint64).sum())
+            if stream or (len(st.contig_lens) and total <= STREAM_MAX_SITES):
+                if len(st.contig_lens) == 0:
+                    if st.next_batch() is not None:
+                        raise KeyError("no @SQ lines in header")
+                    return Pileup(None, [], np.zeros(0, np.uint32), [], bam_path)
+                eng = N.Engine(st.contig_lens, device=device, lib=lib)
+                info = eng.push_stream(st)
+                eng.finalize()
+                first = eng.contig_first()
+                used = np.flatnonzero(first != np.uint64(0xFFFFFFFFFFFFFFFF))
+                order = [int(c) for c in used[np.argsort(first[used], kind="stable")]]   # first appearance, kindel.py:143-151
+                pl = Pileup(eng, list(st.contig_names), st.contig_lens, order, bam_path)
+                pl.ingest = info
+                return pl
+        finally:
+            st.close()
     return pileup_batch(N.decode_file(bam_path, threads=threads, lib=lib), bam_path=bam_path, device=device, lib=lib)
 
 

@@ -1,9 +1,12 @@
 #!/usr/bin/env python
-"""End-to-end leg of SURVEY §8d: BAM path -> FASTA bytes through the public Python API, phase by phase.
+"""End-to-end leg of SURVEY 8d (ii): BAM path -> FASTA bytes, on the GPU box's own host cores.
 
-Not the headline number (bench.py's `value` is the device-resident rate): this shows where a real run
-spends its time -- host BGZF/BAM decode, PCIe, kernels, host report/FASTA -- on the GPU box's own cores.
-Usage: python scripts/e2e_bench.py [--config C3] [--scale 0.1] [--threads 0] [--out profiles/x.json]
+Not the headline number (bench.py's `value` is the device-resident rate): this shows where a real run spends its time.
+Two ingest paths are timed on the same file:
+  whole   kd_decode_open (whole file) -> kd_push_batch (one batch) -> finalize -> consensus
+  stream  kd_stream_open -> kd_push_stream: a decoder thread produces batch k+1 while the pushing thread copies batch k to
+          the device and launches its kernels (what kindel_amd.kindel.bam_to_consensus does) -> finalize -> consensus
+Usage: python scripts/e2e_bench.py [--config C3] [--scale 1.0] [--threads 0] [--chunk-mb 64] [--out profiles/x.json]
 """
 import argparse
 import json
@@ -18,56 +21,76 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kindel_amd import _native as N, kindel as K, synth  # noqa: E402
 
 
+def fasta_of(pl):
+    done = K._device_consensus_all(pl, {c: None for c in pl.order}, False, 1, False)
+    return "".join(">%s_cns\n%s\n" % (pl.names[c], done[c][0]) for c in pl.order).encode()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--scale", type=float, default=0.1)
+    ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--threads", type=int, default=0)
-    ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--chunk-mb", type=int, default=64)
+    ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
 
     t0 = time.time()
-    tb = synth.make(a.config, scale=a.scale)
-    _, ev, _ = synth.counts(tb)                         # flagged/short reads are not in synthetic batches
+    tb = synth.make(a.config, scale=a.scale, device="cuda:0")
+    _, ev, _ = synth.counts(tb)
     batch = synth.to_numpy(tb)
+    del tb
     path = os.path.join(tempfile.gettempdir(), "kd_e2e_%s_%g.bam" % (a.config, a.scale))
-    synth.write_bam(path, batch)
+    t1 = time.time()
+    N.write_bam(path, batch, threads=a.threads)
+    t_write = time.time() - t1
     t_make = time.time() - t0
     size = os.path.getsize(path)
+    n_reads = int(len(batch["contig"]))
+    del batch
 
-    def phases():
+    def whole():
         out = {}
         t = time.perf_counter()
         b = N.decode_file(path, threads=a.threads)
         out["decode_s"] = time.perf_counter() - t
         t = time.perf_counter()
-        pl = K.pileup_batch(b, bam_path=path)           # kd_create + kd_push_batch (H2D) + kd_finalize
+        pl = K.pileup_batch(b, bam_path=path)
         out["pileup_s"] = time.perf_counter() - t
         t = time.perf_counter()
-        recs = []
-        for cid in pl.order:
-            seq, ch, mm = K._device_consensus(pl, cid, None, False, 1, False)
-            recs.append(">%s_cns\n%s\n" % (pl.names[cid], seq))
-        fasta = "".join(recs).encode()
+        fa = fasta_of(pl)
         out["consensus_s"] = time.perf_counter() - t
-        out["fasta_bytes"] = len(fasta)
-        return out
+        out["total_s"] = out["decode_s"] + out["pileup_s"] + out["consensus_s"]
+        pl.engine.close()
+        return out, fa
 
-    runs = [phases() for _ in range(a.repeat)]
-    best = min(runs, key=lambda r: r["decode_s"] + r["pileup_s"] + r["consensus_s"])
-    t = time.perf_counter()
-    res = K.bam_to_consensus(path)                      # the public call, reports included
-    api_s = time.perf_counter() - t
-    total = best["decode_s"] + best["pileup_s"] + best["consensus_s"]
+    def stream():
+        out = {}
+        t = time.perf_counter()
+        pl = K.pileup_file(path, threads=a.threads, chunk_bytes=a.chunk_mb << 20, stream=True)
+        out["ingest_s"] = time.perf_counter() - t
+        out.update({"ingest_" + k: v for k, v in pl.ingest.items()})
+        t = time.perf_counter()
+        fa = fasta_of(pl)
+        out["consensus_s"] = time.perf_counter() - t
+        out["total_s"] = out["ingest_s"] + out["consensus_s"]
+        pl.engine.close()
+        return out, fa
+
+    runs_w = [whole() for _ in range(a.repeat)]
+    runs_s = [stream() for _ in range(a.repeat)]
+    bw = min(runs_w, key=lambda r: r[0]["total_s"])
+    bs = min(runs_s, key=lambda r: r[0]["total_s"])
+    assert bw[1] == bs[1], "streamed and whole-file FASTA differ"
     line = {
-        "what": "end-to-end BAM path -> FASTA bytes (SURVEY 8d ii)", "config": a.config, "scale": a.scale,
-        "reads": int(len(batch["contig"])), "aligned_events": ev, "bam_bytes": size,
-        "host_cores": os.cpu_count(), "decode_threads": a.threads or os.cpu_count(),
-        "best_of": a.repeat, **{k: round(v, 4) if isinstance(v, float) else v for k, v in best.items()},
-        "total_s": round(total, 4), "events_per_s": ev / total, "reads_per_s_decode": len(batch["contig"]) / best["decode_s"],
-        "bam_to_consensus_s": round(api_s, 4), "bam_to_consensus_events_per_s": ev / api_s,
-        "n_consensus_records": len(res.consensuses), "synth_plus_write_s": round(t_make, 1),
+        "what": "end-to-end BAM path -> FASTA bytes (SURVEY 8d ii)", "config": a.config, "scale": a.scale, "reads": n_reads,
+        "aligned_events": ev, "bam_bytes": size, "host_cores": os.cpu_count(), "decode_threads": a.threads or os.cpu_count(),
+        "best_of": a.repeat, "chunk_mb": a.chunk_mb, "fasta_bytes": len(bw[1]), "same_fasta": True,
+        "whole_file": {k: round(v, 4) for k, v in bw[0].items()}, "whole_file_events_per_s": ev / bw[0]["total_s"],
+        "streamed": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in bs[0].items()},
+        "streamed_events_per_s": ev / bs[0]["total_s"],
+        "synth_plus_write_s": round(t_make, 1), "native_bam_write_s": round(t_write, 2),
     }
     s = json.dumps(line)
     print(s)

@@ -115,3 +115,102 @@ def test_reference_fixture_files(rel):
     key = rel.replace("data_", "").replace("/", "__").rsplit(".", 1)[0]
     got = N.decode_file(path)
     same_batch(got, P.load_fixture(key))
+
+
+_NIBS = "=ACMGRSVTWYHKDBN"
+
+
+def _write_sam(path, batch):
+    """batch -> SAM text (what the fixtures were decoded from, minus names / qualities)"""
+    names = [str(x) for x in batch["contig_names"]]
+    with open(path, "w") as fh:
+        fh.write("@HD\tVN:1.6\tSO:unknown\n")
+        for n, l in zip(names, batch["contig_lens"]):
+            fh.write("@SQ\tSN:%s\tLN:%d\n" % (n, int(l)))
+        for i in range(len(batch["contig"])):
+            so, sl, co, nc = int(batch["seq_off"][i]), int(batch["seq_len"][i]), int(batch["cig_off"][i]), int(batch["n_cig"][i])
+            by = batch["seq4"][so: so + (sl + 1) // 2]
+            seq = "".join(_NIBS[b >> 4] + _NIBS[b & 15] for b in by.tolist())[:sl] or "*"
+            cig = "".join("%d%s" % (int(w) >> 4, "MIDNSHP=X"[int(w) & 15]) for w in batch["cigar"][co: co + nc].tolist()) or "*"
+            fh.write("r%d\t%d\t%s\t%d\t60\t%s\t*\t0\t0\t%s\t*\n" % (i, int(batch["flag"][i]), names[int(batch["contig"][i])],
+                                                                     int(batch["pos0"][i]) + 1, cig, seq))
+
+
+def _concat_stream(st):
+    parts = []
+    while True:
+        b = st.next_batch()
+        if b is None:
+            break
+        parts.append(b)
+    keys = ("contig", "pos0", "flag", "seq_len", "n_cig")
+    out = {k: np.concatenate([p[k] for p in parts]) if parts else np.zeros(0) for k in keys}
+    # per-read payloads (offsets are chunk-local)
+    seqs, cigs = [], []
+    for p in parts:
+        for so, sl, co, nc in zip(p["seq_off"].tolist(), p["seq_len"].tolist(), p["cig_off"].tolist(), p["n_cig"].tolist()):
+            seqs.append(p["seq4"][so: so + (sl + 1) // 2].tobytes())
+            cigs.append(p["cigar"][co: co + nc].tobytes())
+    return out, seqs, cigs, len(parts)
+
+
+@pytest.mark.parametrize("key,kind,chunk", [("bwa_mem__1.1.sub_test", "bam", 3000), ("minimap2__1.1.multi", "bam", 700),
+                                            ("minimap2__hxb2-gp120-mutated", "bam", 20000), ("segemehl__3.1.sub_test", "sam", 2500),
+                                            ("ext__2.issue23.bc63", "bam", 1 << 20)])
+def test_stream_chunks_equal_whole_file(emu_lib, tmp_path, key, kind, chunk):
+    """kd_stream_*: batches of ~chunk uncompressed bytes (records cut by a chunk boundary are carried over) == one decode."""
+    batch = P.load_fixture(key)
+    path = str(tmp_path / ("s." + kind))
+    if kind == "bam":
+        synth.write_bam(path, batch, sort_order="unknown")
+    else:
+        _write_sam(path, batch)
+    whole = N.decode_file(path, lib=emu_lib)
+    st = N.Stream(path, chunk_bytes=chunk, lib=emu_lib)
+    assert list(st.contig_names) == [str(x) for x in whole["contig_names"]] and np.array_equal(st.contig_lens, whole["contig_lens"])
+    got, seqs, cigs, n_parts = _concat_stream(st)
+    assert st.n_records() == whole["n_records"]
+    st.close()
+    assert n_parts > (1 if chunk < 100000 else 0)
+    for k in ("contig", "pos0", "flag", "seq_len", "n_cig"):
+        assert np.array_equal(got[k], whole[k]), k
+    for i, (so, sl, co, nc) in enumerate(zip(whole["seq_off"].tolist(), whole["seq_len"].tolist(), whole["cig_off"].tolist(),
+                                             whole["n_cig"].tolist())):
+        assert seqs[i] == whole["seq4"][so: so + (sl + 1) // 2].tobytes(), i
+        assert cigs[i] == whole["cigar"][co: co + nc].tobytes(), i
+
+
+@pytest.mark.parametrize("key,chunk", [("bwa_mem__2.1.sub_test", 5000), ("minimap2__1.1.multi", 900), ("ext__1.issue23.debug", 30000)])
+def test_streamed_pileup_equals_whole_file_pileup(api_on_emu, tmp_path, key, chunk):
+    """kd_push_stream (decode thread + pushing thread, many small batches whose boundaries cut windows) == one batch."""
+    from kindel_amd import kindel as K
+    path = str(tmp_path / "p.bam")
+    synth.write_bam(path, P.load_fixture(key), sort_order="unknown")
+    a = K.pileup_file(path, stream=False)
+    b = K.pileup_file(path, stream=True, chunk_bytes=chunk)
+    assert b.ingest["batches"] > 3
+    assert [a.names[c] for c in a.order] == [b.names[c] for c in b.order]
+    for ca, cb in zip(a.order, b.order):
+        assert np.array_equal(a.tables(ca), b.tables(cb))
+    ra = K.bam_to_consensus(path)
+    assert [c.sequence for c in ra.consensuses] == [g["consensus"] for g in P.golden_outputs()[key]["contigs"]]
+
+
+def test_native_bam_writer_roundtrip(emu_lib, tmp_path):
+    """kd_write_bam (parallel record layout + parallel deflate) -> decoder == the batch; also readable by the pure-Python reader;
+    a read with more than 65535 CIGAR operations goes through the CG tag."""
+    batch = synth.to_numpy(synth.short_reads([3000, 1500], 30, seed=17))
+    p = tmp_path / "n.bam"
+    for threads in (1, 5):
+        N.write_bam(str(p), batch, threads=threads, lib=emu_lib)
+        same_batch(N.decode_file(p, lib=emu_lib), batch)
+    same_batch(samio_py.load_batch(str(p)), batch)
+    lr = synth.to_numpy(synth.long_reads([40000], 5, seed=9))
+    N.write_bam(str(p), lr, lib=emu_lib)
+    same_batch(N.decode_file(p, lib=emu_lib), lr)
+    empty = dict(batch)
+    for k in KEYS:
+        empty[k] = batch[k][:0]
+    N.write_bam(str(p), empty, lib=emu_lib)
+    got = N.decode_file(p, lib=emu_lib)
+    assert len(got["contig"]) == 0 and list(got["contig_lens"]) == [3000, 1500]
