@@ -221,7 +221,7 @@ int kd_write_bam(const char *path, const kd_batch *host_batch, uint32_t n_contig
 /* ---- streaming ingest: the record iteration of parse_bam (kindel.py:143-145) without holding the whole file -------- */
 
 typedef struct kd_stream kd_stream;
-/* Open a SAM / BAM file for chunked reading: batches of about chunk_bytes uncompressed bytes (0 = 64 MiB), whole records
+/* Open a SAM / BAM file for chunked reading: batches of about chunk_bytes uncompressed bytes (0 = 256 MiB), whole records
  * each, in file order.  The header (@SQ table) is available right after the call. */
 int kd_stream_open(kd_stream **out, const char *path, int n_threads, uint64_t chunk_bytes);
 uint32_t kd_stream_n_contigs(const kd_stream *s);

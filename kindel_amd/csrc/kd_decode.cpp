@@ -11,10 +11,14 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -23,6 +27,70 @@
 #include "../../include/kindel_hip.h"
 
 namespace {
+
+// Worker threads kept across calls: a chunk of a streamed file is a few tens of milliseconds of work split three times
+// (inflate, record walk, fill), and starting 255 threads for each of those cost more than the work itself.
+struct Pool {
+    std::vector<std::thread> th;
+    std::mutex mu, run_mu;
+    std::condition_variable cv, done_cv;
+    const std::function<void(unsigned)> *fn = nullptr;
+    unsigned n_tasks = 0, remaining = 0;
+    std::atomic<unsigned> next{0};
+    uint64_t gen = 0;
+    bool stop = false;
+    ~Pool() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : th) t.join();
+    }
+    void drain(const std::function<void(unsigned)> &f, unsigned n) {
+        unsigned done = 0;
+        for (;;) {
+            const unsigned t = next.fetch_add(1);
+            if (t >= n) break;
+            f(t);
+            done++;
+        }
+        if (done) {
+            std::lock_guard<std::mutex> g(mu);
+            remaining -= done;
+            if (!remaining) done_cv.notify_all();
+        }
+    }
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)> *f;
+            unsigned n;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen; f = fn; n = n_tasks;
+            }
+            drain(*f, n);
+        }
+    }
+    // f(0) .. f(n-1), each exactly once, on up to `threads` threads (the caller included); returns when all are done
+    void run(unsigned n, unsigned threads, const std::function<void(unsigned)> &f) {
+        if (n == 0) return;
+        if (n == 1 || threads <= 1) { for (unsigned t = 0; t < n; t++) f(t); return; }
+        std::lock_guard<std::mutex> g(run_mu);
+        const unsigned want = std::min(n, threads) - 1;
+        while (th.size() < want) th.emplace_back([this] { worker(); });
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            fn = &f; n_tasks = n; remaining = n; next = 0; gen++;
+        }
+        cv.notify_all();
+        drain(f, n);
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [&] { return remaining == 0; });
+        fn = nullptr;
+    }
+};
+Pool &pool() { static Pool P; return P; }
 
 thread_local std::string g_decode_error;   // per thread: concurrent kd_decode_open calls do not share it
 
@@ -291,7 +359,7 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
         return true;
     };
     unsigned nt1 = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
-    size_t min_range = 4u << 20;                                      // >= 4 MB of records per range ...
+    size_t min_range = 1u << 20;                                      // >= 1 MB of records per range ...
     if (const char *e = getenv("KD_DECODE_RANGE_BYTES")) min_range = std::max<size_t>(64, strtoull(e, nullptr, 10));   // ... tests: small
     nt1 = (unsigned)std::max<size_t>(1, std::min<size_t>(nt1, (n - std::min(o, n)) / min_range));
     constexpr int KD_SPEC_CHAIN = 16;
@@ -319,12 +387,7 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
         guess[t] = q;
         pok[t] = walk(q, range_end(t), part[t], part_nrec[t], stop[t], perr[t]) ? 1 : 0;
     };
-    {
-        std::vector<std::thread> th1;
-        for (unsigned t = 1; t < nt1; t++) th1.emplace_back(work1, t);
-        work1(0);
-        for (auto &x : th1) x.join();
-    }
+    pool().run(nt1, nt1, work1);
     // verify the hand-offs left to right; re-walk what a wrong guess (or an error seen from a wrong start) spoiled
     size_t p = o;
     for (unsigned t = 0; t < nt1; t++) {
@@ -372,10 +435,7 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
             k++; so += sb; co += rc.nc;
         }
     };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt1; t++) th.emplace_back(fill, t);
-    fill(0);
-    for (auto &t : th) t.join();
+    pool().run(nt1, nt1, fill);
     return KD_OK;
 }
 
@@ -619,7 +679,7 @@ struct Stream {
     const char *sam_pos = nullptr, *sam_end = nullptr;
 
     int open(const char *path, int threads, size_t chunk) {
-        n_threads = threads; chunk_bytes = chunk ? chunk : (size_t)64 << 20;
+        n_threads = threads; chunk_bytes = chunk ? chunk : (size_t)256 << 20;
         if (!read_all(path, raw)) { g_decode_error = std::string("cannot read ") + path; return KD_E_IO; }
         if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) {
             size_t total = 0;
@@ -654,21 +714,12 @@ struct Stream {
         std::vector<size_t> at(b1 - b0);
         size_t o = keep;
         for (size_t b = b0; b < b1; b++) { at[b - b0] = o; o += blocks[b].out_len; }
-        std::atomic<size_t> next{b0};
         std::atomic<bool> ok{true};
-        auto work = [&]() {
-            for (;;) {
-                const size_t b = next.fetch_add(1);
-                if (b >= b1) break;
-                if (!inflate_raw(raw.data() + blocks[b].in_off, blocks[b].in_len, buf.data() + at[b - b0], blocks[b].out_len)) ok = false;
-            }
-        };
         unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
-        nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, b1 - b0));
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
-        work();
-        for (auto &t : th) t.join();
+        pool().run((unsigned)(b1 - b0), nt, [&](unsigned k) {
+            const size_t b = b0 + k;
+            if (!inflate_raw(raw.data() + blocks[b].in_off, blocks[b].in_len, buf.data() + at[k], blocks[b].out_len)) ok = false;
+        });
         return ok;
     }
     // next batch into f (arrays replaced); *got = false at the end of the file
@@ -702,11 +753,15 @@ struct Stream {
             if (next_block >= blocks.size() && carry.size() == 0 && header_done) { done = true; return KD_OK; }
             // blocks of this chunk
             size_t b1 = next_block, add = 0;
+            const size_t b0c = next_block;
             while (b1 < blocks.size() && (add < chunk_bytes || b1 == next_block)) add += blocks[b1++].out_len;
             const size_t keep = carry.size();
+            static const bool trace = getenv("KD_DECODE_TRACE") != nullptr;
+            const auto tt0 = std::chrono::steady_clock::now();
             if (!buf.resize(keep)) { g_decode_error = "out of memory"; return KD_E_NOMEM; }
             if (keep) memcpy(buf.data(), carry.data(), keep);
             if (!inflate_blocks(next_block, b1, keep)) { g_decode_error = "BGZF inflate failed"; return KD_E_IO; }
+            const auto tt1 = std::chrono::steady_clock::now();
             next_block = b1;
             const bool final = next_block >= blocks.size();
             size_t o = 0;
@@ -719,6 +774,11 @@ struct Stream {
             size_t used = 0;
             int rc = parse_bam_records(buf, o, n_ref, f, n_threads, final, &used);
             if (rc) return rc;
+            if (trace) {
+                const auto tt2 = std::chrono::steady_clock::now();
+                fprintf(stderr, "kd_stream chunk: %zu blocks %zu bytes: inflate %.1f ms, parse %.1f ms, %zu records\n", b1 - b0c, buf.size(),
+                        std::chrono::duration<double, std::milli>(tt1 - tt0).count(), std::chrono::duration<double, std::milli>(tt2 - tt1).count(), f.contig.size());
+            }
             carry.resize(buf.size() - used);
             if (carry.size()) memcpy(carry.data(), buf.data() + used, carry.size());
             n_records += f.n_records;
