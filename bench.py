@@ -358,7 +358,8 @@ def cpu_baseline(batch, contig_lens, gpu_seqs, sample, aligned_total):
         if frac >= 1.0:
             same = same and (seq.encode() == gpu_seqs[cid])
     dt = time.perf_counter() - t0
-    return dict(value=ev / dt, unit="events/s", cores=1, kind="port", host_cores=os.cpu_count(),
+    from kindel_amd import _native as _N
+    return dict(value=ev / dt, unit="events/s", cores=1, kind="port", host_cores=os.cpu_count(), host_cores_cgroup_quota=_N.host_threads(),
                 sample="%s of the %d reads (%d aligned-base events), all contigs, pileup + consensus; %.1f s" % (
                     "all" if frac >= 1.0 else "every %d-th" % int(round(1.0 / frac)), n, ev, dt),
                 bit_exact_vs_gpu=(same if frac >= 1.0 else None),

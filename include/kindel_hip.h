@@ -213,6 +213,8 @@ uint32_t kd_decode_contig_len(const kd_file *f, uint32_t i);
 uint64_t kd_decode_n_records(const kd_file *f); /* all records in the file, incl. dropped RNAME '*' */
 void kd_decode_close(kd_file *f);
 const char *kd_decode_last_error(void);
+/* host threads the decoder starts by default (n_threads = 0): the visible cores capped by the cgroup CPU quota */
+uint32_t kd_host_threads(void);
 
 /* ---- tool: write a host batch as a BGZF-compressed BAM (synthetic inputs for end-to-end runs; parallel deflate) ---- */
 int kd_write_bam(const char *path, const kd_batch *host_batch, uint32_t n_contigs, const char *const *names,

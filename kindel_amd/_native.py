@@ -30,7 +30,7 @@ ABI_SYMBOLS = (
     "kd_profile_enable kd_profile_get kd_profile_reset kd_decode_open kd_decode_batch kd_decode_n_contigs "
     "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error "
     "kd_stream_open kd_stream_n_contigs kd_stream_contig_name kd_stream_contig_len kd_stream_next kd_stream_n_records "
-    "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_write_bam"
+    "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_write_bam kd_host_threads"
 ).split()
 
 #: the reference exception each error code stands for (kindel.py:47,51-52,57,61,67,72,75,79)
@@ -233,6 +233,13 @@ def write_bam(path, batch, names=None, sort_order="coordinate", threads=0, level
     rc = lib.dll.kd_write_bam(os.fsencode(str(path)), C.byref(b), len(lens), cnames, _ptr(lens), sort_order.encode(), int(threads), int(level))
     if rc:
         raise _EXC.get(rc, KindelNativeError)("%s: %s" % (path, lib.dll.kd_decode_last_error().decode()))
+
+
+def host_threads(lib=None):
+    """Host threads the native decoder uses by default: visible cores capped by the cgroup CPU quota."""
+    lib = lib or default_library()
+    lib.dll.kd_host_threads.restype = C.c_uint32
+    return int(lib.dll.kd_host_threads())
 
 
 def decode_file(path, threads=0, lib=None):

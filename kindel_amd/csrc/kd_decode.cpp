@@ -28,6 +28,27 @@
 
 namespace {
 
+// Threads worth starting: the visible cores, capped by the cgroup CPU quota (a container that sees 256 cores but may use 16
+// of them per scheduling period is throttled to a standstill by 256 busy threads: measured on the GPU boxes).
+unsigned hw_threads() {
+    static const unsigned n = [] {
+        unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        long long quota = -1, period = 100000;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {             // cgroup v2: "<quota|max> <period>"
+            char q[64] = {0};
+            if (fscanf(f, "%63s %lld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+        }
+        if (quota > 0 && period > 0) hw = (unsigned)std::min<long long>(hw, std::max<long long>(1, (quota + period - 1) / period));
+        return hw;
+    }();
+    return n;
+}
+
 // Worker threads kept across calls: a chunk of a streamed file is a few tens of milliseconds of work split three times
 // (inflate, record walk, fill), and starting 255 threads for each of those cost more than the work itself.
 struct Pool {
@@ -229,7 +250,7 @@ bool decompress(const Arr<uint8_t> &raw, Arr<uint8_t> &out, int n_threads) {
             if (!inflate_raw(raw.data() + B.in_off, B.in_len, out.data() + B.out_off, B.out_len)) ok = false;
         }
     };
-    unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+    unsigned nt = n_threads > 0 ? (unsigned)n_threads : hw_threads();
     nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, blocks.size()));
     std::vector<std::thread> th;
     for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
@@ -358,7 +379,7 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
         stop = q;
         return true;
     };
-    unsigned nt1 = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+    unsigned nt1 = n_threads > 0 ? (unsigned)n_threads : hw_threads();
     size_t min_range = 1u << 20;                                      // >= 1 MB of records per range ...
     if (const char *e = getenv("KD_DECODE_RANGE_BYTES")) min_range = std::max<size_t>(64, strtoull(e, nullptr, 10));   // ... tests: small
     nt1 = (unsigned)std::max<size_t>(1, std::min<size_t>(nt1, (n - std::min(o, n)) / min_range));
@@ -602,7 +623,7 @@ int parse_sam_records(const char *rec0, const char *end, const SamIds &ids, File
     };
     size_t min_range = 4u << 20;
     if (const char *ev = getenv("KD_DECODE_RANGE_BYTES")) min_range = std::max<size_t>(64, strtoull(ev, nullptr, 10));
-    unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+    unsigned nt = n_threads > 0 ? (unsigned)n_threads : hw_threads();
     nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, (size_t)(end - rec0) / min_range));
     std::vector<const char *> cut(nt + 1, end);
     cut[0] = rec0;
@@ -715,7 +736,7 @@ struct Stream {
         size_t o = keep;
         for (size_t b = b0; b < b1; b++) { at[b - b0] = o; o += blocks[b].out_len; }
         std::atomic<bool> ok{true};
-        unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+        unsigned nt = n_threads > 0 ? (unsigned)n_threads : hw_threads();
         pool().run((unsigned)(b1 - b0), nt, [&](unsigned k) {
             const size_t b = b0 + k;
             if (!inflate_raw(raw.data() + blocks[b].in_off, blocks[b].in_len, buf.data() + at[k], blocks[b].out_len)) ok = false;
@@ -820,6 +841,8 @@ int kd_decode_open(kd_file **out, const char *path, int n_threads) {
 }
 
 const char *kd_decode_last_error(void) { return g_decode_error.c_str(); }
+/* host threads the decoder uses by default: visible cores capped by the cgroup CPU quota */
+uint32_t kd_host_threads(void) { return hw_threads(); }
 
 // ---- chunked reading (kd_stream_*) ----
 struct kd_stream {
@@ -879,7 +902,7 @@ int kd_write_bam(const char *path, const kd_batch *b, uint32_t n_contigs, const 
                  const char *sort_order, int n_threads, int level) {
     if (!path || !b || (n_contigs && (!names || !lens))) return KD_E_ARG;
     const size_t n = (size_t)b->n_reads;
-    unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+    unsigned nt = n_threads > 0 ? (unsigned)n_threads : hw_threads();
     std::string text = std::string("@HD\tVN:1.6\tSO:") + (sort_order ? sort_order : "unknown") + "\n";
     for (uint32_t c = 0; c < n_contigs; c++) text += std::string("@SQ\tSN:") + names[c] + "\tLN:" + std::to_string(lens[c]) + "\n";
     std::string head("BAM\1", 4);

@@ -85,7 +85,7 @@ def main():
     assert bw[1] == bs[1], "streamed and whole-file FASTA differ"
     line = {
         "what": "end-to-end BAM path -> FASTA bytes (SURVEY 8d ii)", "config": a.config, "scale": a.scale, "reads": n_reads,
-        "aligned_events": ev, "bam_bytes": size, "host_cores": os.cpu_count(), "decode_threads": a.threads or os.cpu_count(),
+        "aligned_events": ev, "bam_bytes": size, "host_cores_visible": os.cpu_count(), "host_cores_cgroup_quota": N.host_threads(), "decode_threads": a.threads or N.host_threads(),
         "best_of": a.repeat, "chunk_mb": a.chunk_mb, "fasta_bytes": len(bw[1]), "same_fasta": True,
         "whole_file": {k: round(v, 4) for k, v in bw[0].items()}, "whole_file_events_per_s": ev / bw[0]["total_s"],
         "streamed": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in bs[0].items()},
