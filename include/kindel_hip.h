@@ -213,7 +213,7 @@ uint32_t kd_decode_contig_len(const kd_file *f, uint32_t i);
 uint64_t kd_decode_n_records(const kd_file *f); /* all records in the file, incl. dropped RNAME '*' */
 void kd_decode_close(kd_file *f);
 const char *kd_decode_last_error(void);
-/* host threads the decoder starts by default (n_threads = 0): the visible cores capped by the cgroup CPU quota */
+/* host threads the decoder starts by default (n_threads = 0): the visible cores, capped at 1.5 x the cgroup CPU quota */
 uint32_t kd_host_threads(void);
 
 /* ---- tool: write a host batch as a BGZF-compressed BAM (synthetic inputs for end-to-end runs; parallel deflate) ---- */
@@ -223,7 +223,7 @@ int kd_write_bam(const char *path, const kd_batch *host_batch, uint32_t n_contig
 /* ---- streaming ingest: the record iteration of parse_bam (kindel.py:143-145) without holding the whole file -------- */
 
 typedef struct kd_stream kd_stream;
-/* Open a SAM / BAM file for chunked reading: batches of about chunk_bytes uncompressed bytes (0 = 256 MiB), whole records
+/* Open a SAM / BAM file for chunked reading: batches of about chunk_bytes uncompressed bytes (0 = 64 MiB), whole records
  * each, in file order.  The header (@SQ table) is available right after the call. */
 int kd_stream_open(kd_stream **out, const char *path, int n_threads, uint64_t chunk_bytes);
 uint32_t kd_stream_n_contigs(const kd_stream *s);

@@ -43,7 +43,9 @@ unsigned hw_threads() {
             fclose(g);
             if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
         }
-        if (quota > 0 && period > 0) hw = (unsigned)std::min<long long>(hw, std::max<long long>(1, (quota + period - 1) / period));
+        // 1.5 x the quota: the workers also wait (hand-offs, page faults), and on the MI355X boxes (quota 16 of 256 cores)
+        // 24 threads decoded a 4.4 GB BAM in 0.33 s, 16 in 1.08 s, 48 in 0.62 s, 256 in 1.6 s (profiles/r02_e2e_*.json)
+        if (quota > 0 && period > 0) hw = (unsigned)std::min<long long>(hw, std::max<long long>(1, (3 * quota + 2 * period - 1) / (2 * period)));
         return hw;
     }();
     return n;
@@ -700,7 +702,7 @@ struct Stream {
     const char *sam_pos = nullptr, *sam_end = nullptr;
 
     int open(const char *path, int threads, size_t chunk) {
-        n_threads = threads; chunk_bytes = chunk ? chunk : (size_t)256 << 20;
+        n_threads = threads; chunk_bytes = chunk ? chunk : (size_t)64 << 20;
         if (!read_all(path, raw)) { g_decode_error = std::string("cannot read ") + path; return KD_E_IO; }
         if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) {
             size_t total = 0;
