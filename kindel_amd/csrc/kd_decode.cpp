@@ -58,7 +58,7 @@ struct Pool {
     std::mutex mu, run_mu;
     std::condition_variable cv, done_cv;
     const std::function<void(unsigned)> *fn = nullptr;
-    unsigned n_tasks = 0, remaining = 0;
+    unsigned n_tasks = 0, remaining = 0, active = 0;   // active: workers inside drain() for the current generation
     std::atomic<unsigned> next{0};
     uint64_t gen = 0;
     bool stop = false;
@@ -91,8 +91,14 @@ struct Pool {
                 cv.wait(lk, [&] { return stop || gen != seen; });
                 if (stop) return;
                 seen = gen; f = fn; n = n_tasks;
+                if (!f) continue;          // woke up after its generation was over
+                active++;
             }
             drain(*f, n);
+            {
+                std::lock_guard<std::mutex> g(mu);
+                if (--active == 0) done_cv.notify_all();
+            }
         }
     }
     // f(0) .. f(n-1), each exactly once, on up to `threads` threads (the caller included); returns when all are done
@@ -109,7 +115,8 @@ struct Pool {
         cv.notify_all();
         drain(f, n);
         std::unique_lock<std::mutex> lk(mu);
-        done_cv.wait(lk, [&] { return remaining == 0; });
+        // no worker may still be inside drain() when `f` goes out of scope or `next` is reset for the next generation
+        done_cv.wait(lk, [&] { return remaining == 0 && active == 0; });
         fn = nullptr;
     }
 };
