@@ -92,13 +92,16 @@ __device__ __forceinline__ void kd_cns_load_eval(const KdTabs &T, const KdCns &C
     }
 }
 
-// pass 1: bytes emitted per 1024-site tile + per-contig min/max depth
+// pass 1: bytes emitted per 1024-site tile + the tile's min / max A+C+G+T depth.
+// The per-contig depth range is NOT reduced here with atomics: 4883 tiles x 2 device-scope atomics on the two words of one
+// contig serialise at ~12 ns each (0.12 of this kernel's 0.14 ms on C3, measured); the tile writes (contig of its first
+// site, min, max) and k_cns_scan folds those.  Sites of a second contig inside the tile (contig boundaries) go the atomic way.
+struct KdTileMM { uint32_t contig, mn, mx, pad; };
+
 __global__ void __launch_bounds__(KD_BLOCK)
-k_cns_count(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, kd_u64 *tile_sum, uint32_t *depth_minmax) {
-    __shared__ uint32_t s_sum, s_min, s_max;
-    const uint32_t t = threadIdx.x;
-    if (t == 0) { s_sum = 0; s_min = 0xffffffffu; s_max = 0; }
-    __syncthreads();
+k_cns_count(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, kd_u64 *tile_sum, KdTileMM *tile_mm, uint32_t *depth_minmax) {
+    __shared__ uint32_t s_w[3][KD_WAVES_PER_BLOCK];
+    const uint32_t t = threadIdx.x, lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
     const kd_u64 tile0 = (tile_first + blockIdx.x) * KD_CNS_TILE;
     const kd_u64 g0 = tile0 + (kd_u64)t * KD_CNS_PER_THREAD;
     const uint32_t cfirst = tile0 < T.sites ? C.seg_contig[tile0 >> 6] : 0;
@@ -113,47 +116,53 @@ k_cns_count(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, kd_u64 *tile_sum, u
             else { atomicMin(&depth_minmax[2 * c], s[k].depth); atomicMax(&depth_minmax[2 * c + 1], s[k].depth); }
         }
     }
-    if (sum) atomicAdd(&s_sum, sum);
-    if (mn != 0xffffffffu) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
+    // wavefront reductions by shuffles, then the four wavefronts through LDS
+    sum = kd_wave_sum(sum); mn = kd_wave_min(mn); mx = kd_wave_max(mx);
+    if (lane == 0) { s_w[0][wave] = sum; s_w[1][wave] = mn; s_w[2][wave] = mx; }
     __syncthreads();
     if (t == 0) {
-        tile_sum[blockIdx.x] = s_sum;
-        if (s_min != 0xffffffffu) { atomicMin(&depth_minmax[2 * cfirst], s_min); atomicMax(&depth_minmax[2 * cfirst + 1], s_max); }
+        uint32_t a = 0, b = 0xffffffffu, c = 0;
+        for (uint32_t w = 0; w < KD_WAVES_PER_BLOCK; w++) { a += s_w[0][w]; b = s_w[1][w] < b ? s_w[1][w] : b; c = s_w[2][w] > c ? s_w[2][w] : c; }
+        tile_sum[blockIdx.x] = a;
+        KdTileMM m; m.contig = cfirst; m.mn = b; m.mx = c; m.pad = 0;
+        tile_mm[blockIdx.x] = m;
     }
 }
 
-// pass 2: exclusive scan of the tile sums (one workgroup), tile_off[n_tiles] = total
+// pass 2 (one workgroup): exclusive scan of the tile sums, tile_off[n_tiles] = total; fold the tiles' depth ranges into the
+// per-contig ranges (a thread merges its consecutive tiles of one contig before touching the contig's words)
 __global__ void __launch_bounds__(KD_BLOCK)
-k_cns_scan(const kd_u64 *tile_sum, kd_u64 *tile_off, kd_u64 n_tiles) {
-    __shared__ kd_u64 s_scan[KD_BLOCK];
-    __shared__ kd_u64 s_carry;
+k_cns_scan(const kd_u64 *tile_sum, kd_u64 *tile_off, kd_u64 n_tiles, const KdTileMM *tile_mm, uint32_t *depth_minmax) {
+    __shared__ kd_u64 s_wave[KD_WAVES_PER_BLOCK];
     const uint32_t t = threadIdx.x;
-    if (t == 0) s_carry = 0;
-    __syncthreads();
-    for (kd_u64 b0 = 0; b0 < n_tiles; b0 += KD_BLOCK) {
-        const kd_u64 b = b0 + t;
-        const kd_u64 v = b < n_tiles ? tile_sum[b] : 0;
-        s_scan[t] = v;
-        __syncthreads();
-        for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
-            kd_u64 a = t >= d ? s_scan[t - d] : 0;
-            __syncthreads();
-            s_scan[t] += a;
-            __syncthreads();
-        }
-        if (b < n_tiles) tile_off[b] = s_carry + s_scan[t] - v;
-        __syncthreads();
-        if (t == KD_BLOCK - 1) s_carry += s_scan[t];
-        __syncthreads();
+    kd_u64 carry = 0;
+    // each thread owns a contiguous run of tiles (contiguous -> few contig changes per thread)
+    const kd_u64 per = (n_tiles + KD_BLOCK - 1) / KD_BLOCK;
+    const kd_u64 b0 = (kd_u64)t * per, b1 = b0 + per < n_tiles ? b0 + per : n_tiles;
+    kd_u64 mine = 0;
+    uint32_t cur = 0xffffffffu, mn = 0xffffffffu, mx = 0;
+    for (kd_u64 b = b0; b < b1; b++) {
+        mine += tile_sum[b];
+        const KdTileMM m = tile_mm[b];
+        if (m.mn == 0xffffffffu) continue;        // no live site of its first contig
+        if (m.contig != cur) {
+            if (cur != 0xffffffffu) { atomicMin(&depth_minmax[2 * cur], mn); atomicMax(&depth_minmax[2 * cur + 1], mx); }
+            cur = m.contig; mn = m.mn; mx = m.mx;
+        } else { mn = m.mn < mn ? m.mn : mn; mx = m.mx > mx ? m.mx : mx; }
     }
-    if (t == 0) tile_off[n_tiles] = s_carry;
+    if (cur != 0xffffffffu) { atomicMin(&depth_minmax[2 * cur], mn); atomicMax(&depth_minmax[2 * cur + 1], mx); }
+    kd_u64 total;
+    const kd_u64 incl = kd_block_scan_incl(mine, s_wave, total);
+    kd_u64 o = carry + incl - mine;
+    for (kd_u64 b = b0; b < b1; b++) { tile_off[b] = o; o += tile_sum[b]; }
+    if (t == 0) tile_off[n_tiles] = total;
 }
 
 // pass 3: recompute, scan inside the tile, write bytes / changes / per-contig start offsets
 __global__ void __launch_bounds__(KD_BLOCK)
 k_cns_emit(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, const kd_u64 *tile_off, uint8_t *out, uint8_t *changes,
            kd_u64 *contig_off, uint32_t n_contigs, kd_u64 *patch_off) {
-    __shared__ uint32_t s_scan[KD_BLOCK];
+    __shared__ kd_u64 s_wave[KD_WAVES_PER_BLOCK];
     const uint32_t t = threadIdx.x;
     const kd_u64 tile0 = (tile_first + blockIdx.x) * KD_CNS_TILE;
     const kd_u64 g0 = tile0 + (kd_u64)t * KD_CNS_PER_THREAD;
@@ -162,15 +171,9 @@ k_cns_emit(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, const kd_u64 *tile_o
     kd_cns_load_eval(T, C, ins, g0, s);
     uint32_t sum = 0;
     for (int k = 0; k < KD_CNS_PER_THREAD; k++) sum += s[k].ins_len + s[k].has_base;
-    s_scan[t] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
-        uint32_t a = t >= d ? s_scan[t - d] : 0;
-        __syncthreads();
-        s_scan[t] += a;
-        __syncthreads();
-    }
-    kd_u64 o = tile_off[blockIdx.x] + s_scan[t] - sum;
+    kd_u64 tile_total;
+    const kd_u64 incl = kd_block_scan_incl((kd_u64)sum, s_wave, tile_total);   // __shfl_up scans, two barriers
+    kd_u64 o = tile_off[blockIdx.x] + incl - sum;
     const char lower[17] = "=acmgrsvtwyhkdbn";
     for (int k = 0; k < KD_CNS_PER_THREAD; k++) {
         const kd_u64 g = g0 + k;

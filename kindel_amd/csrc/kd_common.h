@@ -38,6 +38,9 @@ __device__ __forceinline__ unsigned long long kd_shfl64(unsigned long long v, un
     return ((unsigned long long)kd_shfl((uint32_t)(v >> 32), src_lane) << 32) | kd_shfl((uint32_t)v, src_lane);
 }
 __device__ __forceinline__ uint32_t kd_shfl_up(uint32_t v, unsigned d) { return (uint32_t)__shfl_up((int)v, d, 64); }
+__device__ __forceinline__ unsigned long long kd_shfl_up64(unsigned long long v, unsigned d) {
+    return ((unsigned long long)kd_shfl_up((uint32_t)(v >> 32), d) << 32) | kd_shfl_up((uint32_t)v, d);
+}
 __device__ __forceinline__ uint32_t kd_shfl_xor(uint32_t v, unsigned m) { return (uint32_t)__shfl_xor((int)v, (int)m, 64); }
 __device__ __forceinline__ uint32_t kd_readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ unsigned long long kd_readfirstlane64(unsigned long long v) {
@@ -244,6 +247,42 @@ __device__ __forceinline__ void kd_block_scan2(TA *sa, TB *sb, TA *ga, TB *gb, T
     }
     incl_a = sa[t] + oa; incl_b = sb[t] + ob; tot_a = ta; tot_b = tb;
     __syncthreads();   // the scratch arrays may be reused by the caller
+}
+
+// Inclusive scan of one 64-bit value per thread over the 256-thread workgroup: six __shfl_up steps inside each wavefront,
+// the four wavefront totals through LDS (two barriers instead of the sixteen of a Hillis-Steele scan in LDS).
+// s_wave: [KD_WAVES_PER_BLOCK] scratch.  Returns the inclusive prefix; total = sum over the workgroup.
+__device__ __forceinline__ kd_u64 kd_block_scan_incl(kd_u64 v, kd_u64 *s_wave, kd_u64 &total) {
+    const uint32_t lane = threadIdx.x & (KD_WAVE - 1), wave = threadIdx.x / KD_WAVE;
+#pragma unroll
+    for (uint32_t d = 1; d < KD_WAVE; d <<= 1) {
+        const kd_u64 t = kd_shfl_up64(v, d);
+        if (lane >= d) v += t;
+    }
+    if (lane == KD_WAVE - 1) s_wave[wave] = v;
+    __syncthreads();
+    kd_u64 off = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < KD_WAVES_PER_BLOCK; w++) { const kd_u64 x = s_wave[w]; if (w < wave) off += x; tot += x; }
+    total = tot;
+    __syncthreads();   // s_wave may be reused by the caller
+    return v + off;
+}
+// min / max / sum over the 64 lanes by butterfly shuffles (every lane gets the result)
+__device__ __forceinline__ uint32_t kd_wave_min(uint32_t v) {
+#pragma unroll
+    for (uint32_t m = 1; m < KD_WAVE; m <<= 1) { const uint32_t t = kd_shfl_xor(v, m); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t kd_wave_max(uint32_t v) {
+#pragma unroll
+    for (uint32_t m = 1; m < KD_WAVE; m <<= 1) { const uint32_t t = kd_shfl_xor(v, m); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t kd_wave_sum(uint32_t v) {
+#pragma unroll
+    for (uint32_t m = 1; m < KD_WAVE; m <<= 1) v += kd_shfl_xor(v, m);
+    return v;
 }
 
 __device__ __forceinline__ void kd_flag_error(const KdTabs &T, kd_u64 *status, uint32_t contig, kd_u64 gidx) {

@@ -53,7 +53,10 @@ struct KdEngine {
     uint64_t ev_cap = 0, pool_cap = 0;
     Buf b_hkey, b_hcnt, b_hrep, b_evslot, b_best, b_win;
     uint64_t hash_cap = 0;
-    Buf b_cns, b_changes, b_tilesum, b_tileoff, b_coff;
+    // what the last insertion reduction left behind (k_ins_cleanup undoes it before the event buffers are reused)
+    uint64_t ins_dirty_ev = 0;
+    KdInsTab ins_dirty_tab;
+    Buf b_cns, b_changes, b_tilesum, b_tilemm, b_tileoff, b_coff;
 
     uint64_t reads_pushed = 0;
     uint64_t last_windowed = 0;
@@ -141,7 +144,7 @@ struct KdEngine {
     void destroy() {
         Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_itemwin, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ckpt, &b_seginfo, &b_ev_site, &b_ev_len,
                       &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_win, &b_cns, &b_changes,
-                      &b_tilesum, &b_tileoff, &b_coff};
+                      &b_tilesum, &b_tilemm, &b_tileoff, &b_coff};
         for (Buf *b : all) release(*b);
         for (Buf &b : b_stage) release(b);
         if (d_tab) rt.free(d_tab);
@@ -179,6 +182,8 @@ struct KdEngine {
     }
 
     int reset() {
+        int rcc;
+        if ((rcc = ins_cleanup())) return rcc;    // before the event buffers are overwritten
         tables_ready = false;   // zeroed (and, after kd_set_shard, re-allocated) by the next push or read-out
         std::fill(h_status.begin(), h_status.end(), 0);
         h_status[KDS_ERR_READ] = ~0ULL;
@@ -197,6 +202,17 @@ struct KdEngine {
         return reset();
     }
 
+    // hash table, best[] and win[] back to all-zero: one thread per event of the last reduction
+    int ins_cleanup() {
+        if (!ins_dirty_ev) return KD_OK;
+        KdIns I = insdesc();
+        if (rt.launch("k_ins_cleanup", k_ins_cleanup, (unsigned)((ins_dirty_ev + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, I, ins_dirty_tab,
+                      (kd_u64)ins_dirty_ev, (kd_u64 *)b_best.p, (uint32_t *)b_win.p))
+            return hipfail("k_ins_cleanup");
+        ins_dirty_ev = 0;
+        return KD_OK;
+    }
+
     int fetch_status() {
         if (rt.d2h_small(h_status.data(), d_status, KDS_COUNT * 8)) return hipfail("status d2h");
         return KD_OK;
@@ -210,6 +226,7 @@ struct KdEngine {
         if (reinterpret_cast<uintptr_t>(B.seq4) & 15u) return fail(KD_E_ARG, "kd_push_batch_device: seq4 must be 16-byte aligned");
         int rc;
         if (!tables_ready && (rc = prepare_tables())) return rc;
+        if ((rc = ins_cleanup())) return rc;      // the last reduction's events are about to be joined by new ones
         if ((rc = ensure(b_rinfo, n * sizeof(KdRInfo))) || (rc = ensure(b_cold, n * 4)) ||
             (rc = ensure(b_irreg, n * 4)) || (rc = ensure(b_long, n * 4)) || (rc = ensure(b_readev, n * 4)) ||
             (rc = ensure(b_readpool, n * 8)))
@@ -445,6 +462,43 @@ struct KdEngine {
     int finalize(uint64_t *err_read) {
         int rc;
         if (!tables_ready && (rc = prepare_tables())) return rc;   // nothing was pushed: all-zero tables
+        if ((rc = ins_cleanup())) return rc;
+        // best[] / win[] are site-indexed and all-zero between reductions (k_ins_cleanup): zeroed once, when allocated
+        if (b_win.cap < (size_t)S * 4) {
+            if ((rc = ensure(b_win, (size_t)S * 4)) || (rc = ensure(b_best, (size_t)S * 8))) return rc;
+            if (rt.memset(b_win.p, 0, (size_t)S * 4) || rt.memset(b_best.p, 0, (size_t)S * 8)) return hipfail("finalize: memset win");
+        }
+        // the event counts are exact as of the last push (k_prep reserves the slots, push_device reads them back)
+        const uint64_t n_ev = h_status[KDS_N_EV];
+        bool launched = false;
+        KdInsTab H;
+        KdIns I = insdesc();
+        auto reduce = [&](int attempt) -> int {
+            H.seed = 0x9e3779b97f4a7c15ULL * (uint64_t)(attempt + 1);
+            const unsigned ge = (unsigned)((n_ev + KD_BLOCK - 1) / KD_BLOCK);
+            if (rt.memset(d_status + KDS_INS_COLLISION, 0, 8)) return hipfail("finalize: memset status");
+            if (rt.launch("k_ins_insert", k_ins_insert, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev)) return hipfail("k_ins_insert");
+            if (rt.launch("k_ins_verify_max", k_ins_verify_max, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev, (kd_u64 *)b_best.p, d_status))
+                return hipfail("k_ins_verify_max");
+            ins_dirty_ev = n_ev; ins_dirty_tab = H;
+            return KD_OK;
+        };
+        if (n_ev) {
+            uint64_t cap = 1024;
+            while (cap < 2 * n_ev) cap <<= 1;
+            if (cap >= 0xfffffff0ULL) return fail(KD_E_NOMEM, "too many insertion events");
+            if (cap * 8 > b_hkey.cap) {   // a new (larger) table: zero it once
+                if ((rc = ensure(b_hkey, cap * 8)) || (rc = ensure(b_hcnt, cap * 4)) || (rc = ensure(b_hrep, cap * 4))) return rc;
+                if (rt.memset(b_hkey.p, 0, b_hkey.cap) || rt.memset(b_hcnt.p, 0, b_hcnt.cap)) return hipfail("finalize: memset hash");
+            }
+            if ((rc = ensure(b_evslot, n_ev * 4))) return rc;
+            hash_cap = cap;
+            H.key = (kd_u64 *)b_hkey.p; H.cnt = (uint32_t *)b_hcnt.p; H.rep = (uint32_t *)b_hrep.p;
+            H.ev_slot = (uint32_t *)b_evslot.p; H.cap = cap; H.sites = S;
+            if ((rc = reduce(0))) return rc;
+            launched = true;
+        }
+        // ONE status read-back: deferred reference exceptions, buffer overruns and the hash verification
         if ((rc = fetch_status())) return rc;
         if (h_status[KDS_INTERNAL]) return fail(KD_E_INTERNAL, "insertion event buffers overran (internal error)");
 #ifdef KD_PHASE_CLOCKS   // profiling build (hipcc -DKD_PHASE_CLOCKS): where k_window's wavefronts spend their clocks
@@ -476,43 +530,15 @@ struct KdEngine {
             if (code == 3) return fail(KD_E_CIGAR, "mapped read with CIGAR '*'" + at);
             return fail(KD_E_INTERNAL, "read flagged by a kernel but no reference exception reproduced" + at);
         }
-        uint64_t clo, chi;
-        shard_cover(clo, chi);
-        if ((rc = ensure(b_win, (size_t)S * 4))) return rc;
-        if (rt.memset((uint32_t *)b_win.p + clo, 0, (size_t)(chi - clo) * 4)) return hipfail("finalize: memset win");   // KD_INS_NONE
-        const uint64_t n_ev = h_status[KDS_N_EV];
         n_ev_final = n_ev; pool_final = h_status[KDS_POOL];
-        if (n_ev) {
-            uint64_t cap = 1024;
-            while (cap < 2 * n_ev) cap <<= 1;
-            if (cap >= 0xfffffff0ULL) return fail(KD_E_NOMEM, "too many insertion events");
-            hash_cap = cap;
-            if ((rc = ensure(b_hkey, cap * 8)) || (rc = ensure(b_hcnt, cap * 4)) || (rc = ensure(b_hrep, cap * 4)) ||
-                (rc = ensure(b_evslot, n_ev * 4)) || (rc = ensure(b_best, (size_t)S * 8)))
-                return rc;
-            KdIns I = insdesc();
-            KdInsTab H;
-            H.key = (kd_u64 *)b_hkey.p; H.cnt = (uint32_t *)b_hcnt.p; H.rep = (uint32_t *)b_hrep.p;
-            H.ev_slot = (uint32_t *)b_evslot.p; H.cap = cap;
-            const unsigned ge = (unsigned)((n_ev + KD_BLOCK - 1) / KD_BLOCK), gs = (unsigned)((cap + KD_BLOCK - 1) / KD_BLOCK);
-            bool ok = false;
-            for (int attempt = 0; attempt < 8 && !ok; attempt++) {
-                H.seed = 0x9e3779b97f4a7c15ULL * (uint64_t)(attempt + 1);
-                if (rt.memset(H.key, 0, cap * 8) || rt.memset(H.cnt, 0, cap * 4) || rt.memset(d_status + KDS_INS_COLLISION, 0, 8))
-                    return hipfail("finalize: memset hash");
-                if (rt.launch("k_ins_insert", k_ins_insert, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev)) return hipfail("k_ins_insert");
-                if (rt.launch("k_ins_verify", k_ins_verify, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev, d_status))
-                    return hipfail("k_ins_verify");
-                if ((rc = fetch_status())) return rc;
-                ok = h_status[KDS_INS_COLLISION] == 0;
+        if (launched) {
+            for (int attempt = 1; h_status[KDS_INS_COLLISION] != 0; attempt++) {   // a 64-bit hash collision (never seen): re-seed
+                if (attempt >= 8) return fail(KD_E_INTERNAL, "insertion hash: repeated 64-bit collisions");
+                if ((rc = ins_cleanup()) || (rc = reduce(attempt)) || (rc = fetch_status())) return rc;
             }
-            if (!ok) return fail(KD_E_INTERNAL, "insertion hash: repeated 64-bit collisions");
-            if (rt.memset((kd_u64 *)b_best.p + clo, 0, (size_t)(chi - clo) * 8)) return hipfail("finalize: memset best");
-            kd_u64 *best = (kd_u64 *)b_best.p;
-            uint32_t *win = (uint32_t *)b_win.p;
-            if (rt.launch("k_ins_site_max", k_ins_site_max, gs, KD_BLOCK, 0, I, H, best) ||
-                rt.launch("k_ins_site_pick", k_ins_site_pick, gs, KD_BLOCK, 0, I, H, (const kd_u64 *)best, win))
-                return hipfail("k_ins_site_*");
+            const unsigned ge = (unsigned)((n_ev + KD_BLOCK - 1) / KD_BLOCK);
+            if (rt.launch("k_ins_pick", k_ins_pick, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev, (const kd_u64 *)b_best.p, (uint32_t *)b_win.p))
+                return hipfail("k_ins_pick");
         }
         finalized = true; have_cns = false; have_inskeys = false;
         return KD_OK;
@@ -610,7 +636,7 @@ struct KdEngine {
         // u64 contig_off[n_contigs + 1] | u64 patch_off[np1] | u64 patch_start[np1] | u64 patch_end[np1] | u32 minmax[2 n_contigs]
         const size_t np1 = (size_t)n_patches + 1, nc1 = (size_t)n_contigs + 1;
         const size_t meta_words = nc1 + 3 * np1 + n_contigs;   // in u64
-        if ((rc = ensure(b_cns, cap)) || (rc = ensure(b_tilesum, n_tiles * 8)) ||
+        if ((rc = ensure(b_cns, cap)) || (rc = ensure(b_tilesum, n_tiles * 8)) || (rc = ensure(b_tilemm, n_tiles * sizeof(KdTileMM))) ||
             (rc = ensure(b_tileoff, (n_tiles + 1) * 8)) || (rc = ensure(b_coff, meta_words * 8)))
             return rc;
         std::vector<uint64_t> meta(meta_words, 0);
@@ -629,10 +655,10 @@ struct KdEngine {
         C.patch_start = d_ps; C.patch_end = d_pe;
         C.g_lo = g_lo; C.g_hi = g_hi;
         if (rt.launch("k_cns_count", k_cns_count, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64)tile_first, (kd_u64 *)b_tilesum.p,
-                      d_mm))
+                      (KdTileMM *)b_tilemm.p, d_mm))
             return hipfail("k_cns_count");
         if (rt.launch("k_cns_scan", k_cns_scan, 1u, KD_BLOCK, 0, (const kd_u64 *)b_tilesum.p, (kd_u64 *)b_tileoff.p,
-                      (kd_u64)n_tiles))
+                      (kd_u64)n_tiles, (const KdTileMM *)b_tilemm.p, d_mm))
             return hipfail("k_cns_scan");
         if (rt.launch("k_cns_emit", k_cns_emit, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64)tile_first, (const kd_u64 *)b_tileoff.p,
                       (uint8_t *)b_cns.p, (uint8_t *)b_changes.p, d_coff, n_contigs, d_poff))

@@ -19,6 +19,7 @@ struct KdInsTab {
     uint32_t *ev_slot;  // [n_ev]
     kd_u64 cap;      // power of two
     kd_u64 seed;
+    kd_u64 sites;    // G-space sites (bound of a valid event site)
 };
 
 __device__ __forceinline__ kd_u64 kd_mix64(kd_u64 x) {
@@ -31,7 +32,9 @@ k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev) {
     const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
     if (e >= n_ev) return;
     const uint32_t site = ins.ev_site[e], len = ins.ev_len[e];
-    if (site == KD_EV_DROPPED) { H.ev_slot[e] = KD_EV_DROPPED; return; }
+    // a reserved slot that was never written (its read raised a reference exception half way: the batch is rejected by
+    // kd_finalize anyway) holds stale data: keep it out of the table unless it is at least in bounds
+    if (site == KD_EV_DROPPED || site >= H.sites || ins.ev_off[e] + len > ins.pool_cap) { H.ev_slot[e] = KD_EV_DROPPED; return; }
     const uint8_t *p = ins.pool + ins.ev_off[e];
     kd_u64 h = kd_mix64(H.seed ^ ((kd_u64)site << 32 | len));
     for (uint32_t b = 0; b < len; b++) h = (h ^ p[b]) * 0x100000001b3ULL;
@@ -52,13 +55,20 @@ k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev) {
     H.ev_slot[e] = (uint32_t)s;
 }
 
-// exactness: every event must be byte-identical to the representative of its slot
+// exactness: every event must be byte-identical to the representative of its slot (k_ins_insert has finished: the counts
+// are final).  The representative itself nominates its slot for its site: best[site] = max over the site's slots of
+// (count << 32 | slot).  One thread per EVENT: nothing here is proportional to the table capacity or to the sites.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_verify(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *status) {
+k_ins_verify_max(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, kd_u64 *status) {
     const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (e >= n_ev || H.ev_slot[e] == KD_EV_DROPPED) return;
-    const uint32_t r = H.rep[H.ev_slot[e]];
-    if (r == (uint32_t)e) return;
+    if (e >= n_ev) return;
+    const uint32_t s = H.ev_slot[e];
+    if (s == KD_EV_DROPPED) return;
+    const uint32_t r = H.rep[s];
+    if (r == (uint32_t)e) {
+        atomicMax(&best[ins.ev_site[e]], ((kd_u64)H.cnt[s] << 32) | s);
+        return;
+    }
     bool same = ins.ev_site[e] == ins.ev_site[r] && ins.ev_len[e] == ins.ev_len[r];
     if (same) {
         const uint8_t *a = ins.pool + ins.ev_off[e], *b = ins.pool + ins.ev_off[r];
@@ -66,23 +76,28 @@ k_ins_verify(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *status) {
     }
     if (!same) atomicAdd(&status[KDS_INS_COLLISION], 1ULL);
 }
-
-// pass 1: best[site] = max over slots of (count << 32 | slot)
+// the best slot of a site nominates its representative event; any OTHER slot of the site with the same count makes it
+// a tie (kindel.py:377, :421).  One thread per event, only representatives act.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_site_max(KdIns ins, KdInsTab H, kd_u64 *best) {
-    const kd_u64 s = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (s >= H.cap || H.key[s] == 0) return;
-    atomicMax(&best[ins.ev_site[H.rep[s]]], ((kd_u64)H.cnt[s] << 32) | s);
-}
-// pass 2: the best slot of a site nominates its representative event; any OTHER slot of the site with the same
-// count makes it a tie (kindel.py:377, :421)
-__global__ void __launch_bounds__(KD_BLOCK)
-k_ins_site_pick(KdIns ins, KdInsTab H, const kd_u64 *best, uint32_t *win) {
-    const kd_u64 s = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (s >= H.cap || H.key[s] == 0) return;
-    const uint32_t rep = H.rep[s];
-    const uint32_t site = ins.ev_site[rep];
+k_ins_pick(KdIns ins, KdInsTab H, kd_u64 n_ev, const kd_u64 *best, uint32_t *win) {
+    const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (e >= n_ev) return;
+    const uint32_t s = H.ev_slot[e];
+    if (s == KD_EV_DROPPED || H.rep[s] != (uint32_t)e) return;
+    const uint32_t site = ins.ev_site[e];
     const kd_u64 b = best[site];
     if ((uint32_t)(b >> 32) != H.cnt[s]) return;
-    atomicMax(&win[site], (uint32_t)b == (uint32_t)s ? rep + 1u : KD_INS_TIE);
+    atomicMax(&win[site], (uint32_t)b == s ? (uint32_t)e + 1u : KD_INS_TIE);
+}
+// undo what the events of the last reduction left in the hash table and in best[] / win[] (all of them are zero between
+// reductions: no capacity- or site-proportional memset per kd_finalize)
+__global__ void __launch_bounds__(KD_BLOCK)
+k_ins_cleanup(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, uint32_t *win) {
+    const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (e >= n_ev) return;
+    const uint32_t s = H.ev_slot[e];
+    if (s == KD_EV_DROPPED) return;
+    H.key[s] = 0ULL; H.cnt[s] = 0u;
+    const uint32_t site = ins.ev_site[e];
+    best[site] = 0ULL; win[site] = KD_INS_NONE;
 }

@@ -58,31 +58,20 @@ k_sort_count(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t W, uint32_t *bin_cnt
     if (run) atomicAdd(&bin_cnt[cur], run);
 }
 // one workgroup: bin_off = exclusive scan of bin_cnt (n_bins + 1 entries), bin_cnt is reset to 0 (it becomes
-// the fill cursor of k_sort_scatter)
+// the fill cursor of k_sort_scatter).  Every thread scans a contiguous run of bins, the run totals are scanned over the
+// workgroup with __shfl_up (kd_block_scan_incl): two barriers whatever n_bins is.
 __global__ void __launch_bounds__(KD_BLOCK)
 k_sort_scan(uint32_t *bin_cnt, kd_u64 *bin_off, uint32_t n_bins) {
-    __shared__ kd_u64 s_scan[KD_BLOCK];
-    __shared__ kd_u64 s_carry;
+    __shared__ kd_u64 s_wave[KD_WAVES_PER_BLOCK];
     const uint32_t t = threadIdx.x;
-    if (t == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t b0 = 0; b0 < n_bins; b0 += KD_BLOCK) {
-        const uint32_t b = b0 + t;
-        const kd_u64 v = b < n_bins ? bin_cnt[b] : 0;
-        s_scan[t] = v;
-        __syncthreads();
-        for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
-            kd_u64 a = t >= d ? s_scan[t - d] : 0;
-            __syncthreads();
-            s_scan[t] += a;
-            __syncthreads();
-        }
-        if (b < n_bins) { bin_off[b] = s_carry + s_scan[t] - v; bin_cnt[b] = 0; }
-        __syncthreads();
-        if (t == KD_BLOCK - 1) s_carry += s_scan[t];
-        __syncthreads();
-    }
-    if (t == 0) bin_off[n_bins] = s_carry;
+    const uint32_t per = (n_bins + KD_BLOCK - 1) / KD_BLOCK;
+    const uint32_t b0 = t * per < n_bins ? t * per : n_bins, b1 = b0 + per < n_bins ? b0 + per : n_bins;
+    kd_u64 mine = 0;
+    for (uint32_t b = b0; b < b1; b++) mine += bin_cnt[b];
+    kd_u64 total;
+    kd_u64 o = kd_block_scan_incl(mine, s_wave, total) - mine;
+    for (uint32_t b = b0; b < b1; b++) { const kd_u64 v = bin_cnt[b]; bin_off[b] = o; bin_cnt[b] = 0; o += v; }
+    if (t == 0) bin_off[n_bins] = total;
 }
 template <int RUN>
 __global__ void __launch_bounds__(KD_BLOCK)
@@ -127,31 +116,20 @@ k_plan_ranges_sorted(const kd_u64 *bin_off, uint32_t n_bins, uint32_t w0, uint32
     item_off[w] = (hi - lo + slice - 1) / slice;
 }
 
-// k_plan_scan: one workgroup, in-place exclusive scan of the per-window item counts.
+// k_plan_scan: one workgroup, in-place exclusive scan of the per-window item counts (contiguous run per thread, run totals
+// scanned with __shfl_up).
 __global__ void __launch_bounds__(KD_BLOCK)
 k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
-    __shared__ kd_u64 s_scan[KD_BLOCK];
-    __shared__ kd_u64 s_carry;
+    __shared__ kd_u64 s_wave[KD_WAVES_PER_BLOCK];
     const uint32_t t = threadIdx.x;
-    if (t == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t w0 = 0; w0 < n_win; w0 += KD_BLOCK) {
-        const uint32_t w = w0 + t;
-        const kd_u64 items = w < n_win ? item_off[w] : 0;
-        s_scan[t] = items;
-        __syncthreads();
-        for (uint32_t d = 1; d < KD_BLOCK; d <<= 1) {
-            kd_u64 a = t >= d ? s_scan[t - d] : 0;
-            __syncthreads();
-            s_scan[t] += a;
-            __syncthreads();
-        }
-        if (w < n_win) item_off[w] = s_carry + s_scan[t] - items;
-        __syncthreads();
-        if (t == KD_BLOCK - 1) s_carry += s_scan[t];
-        __syncthreads();
-    }
-    if (t == 0) { item_off[n_win] = s_carry; status[KDS_TOTAL_ITEMS] = s_carry; status[KDS_NEXT_ITEM] = 0; }
+    const uint32_t per = (n_win + KD_BLOCK - 1) / KD_BLOCK;
+    const uint32_t w0 = t * per < n_win ? t * per : n_win, w1 = w0 + per < n_win ? w0 + per : n_win;
+    kd_u64 mine = 0;
+    for (uint32_t w = w0; w < w1; w++) mine += item_off[w];
+    kd_u64 total;
+    kd_u64 o = kd_block_scan_incl(mine, s_wave, total) - mine;
+    for (uint32_t w = w0; w < w1; w++) { const kd_u64 v = item_off[w]; item_off[w] = o; o += v; }
+    if (t == 0) { item_off[n_win] = total; status[KDS_TOTAL_ITEMS] = total; status[KDS_NEXT_ITEM] = 0; }
     if (t < 8) status[KDS_QUEUE0 + t] = 0;   // k_strip's work queues
 }
 

@@ -9,7 +9,8 @@ run() { tag=$1; n=$2; shift 2
   python - <<PY
 import json
 try:
-    d=json.load(open("gpurun_out/multirank_$tag.json")); o=d.get("other_scaling") or {}
+    d=json.loads([l for l in open("gpurun_out/multirank_$tag.json") if l.startswith("{")][-1]); o=d.get("other_scaling") or {}
+    json.dump(d, open("gpurun_out/multirank_$tag.clean.json", "w"))
     print("  ", d["scaling"], "%.3g ev/s"%d["value"], "%.2f ms"%d["ms_per_step"], d["fasta_sha256"][:12], "| other:", o.get("scaling"), o.get("value") and "%.3g"%o["value"], (o.get("fasta_sha256") or "")[:12])
 except Exception as e: print("   failed", e)
 PY

@@ -146,6 +146,10 @@ static inline uint32_t kd_shfl_up(uint32_t v, unsigned d) {   // lanes below d k
     const unsigned l = threadIdx.x & 63u;
     return (uint32_t)emu_exchange(v, l >= d ? l - d : l);
 }
+static inline unsigned long long kd_shfl_up64(unsigned long long v, unsigned d) {
+    const unsigned l = threadIdx.x & 63u;
+    return emu_exchange(v, l >= d ? l - d : l);
+}
 static inline uint32_t kd_shfl_xor(uint32_t v, unsigned m) { return (uint32_t)emu_exchange(v, (threadIdx.x & 63u) ^ m); }
 static inline uint32_t kd_readfirstlane(uint32_t v) { return (uint32_t)emu_exchange(v, 0); }
 static inline unsigned long long kd_readfirstlane64(unsigned long long v) { return emu_exchange(v, 0); }
