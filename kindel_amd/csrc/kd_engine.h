@@ -206,7 +206,7 @@ struct KdEngine {
     int ins_cleanup() {
         if (!ins_dirty_ev) return KD_OK;
         KdIns I = insdesc();
-        if (rt.launch("k_ins_cleanup", k_ins_cleanup, (unsigned)((ins_dirty_ev + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, I, ins_dirty_tab,
+        if (rt.launch("k_ins_cleanup", k_ins_cleanup, (unsigned)((ins_dirty_ev + KD_INS_CHUNK - 1) / KD_INS_CHUNK), KD_BLOCK, 0, I, ins_dirty_tab,
                       (kd_u64)ins_dirty_ev, (kd_u64 *)b_best.p, (uint32_t *)b_win.p))
             return hipfail("k_ins_cleanup");
         ins_dirty_ev = 0;
@@ -478,7 +478,8 @@ struct KdEngine {
             const unsigned ge = (unsigned)((n_ev + KD_BLOCK - 1) / KD_BLOCK);
             if (rt.memset(d_status + KDS_INS_COLLISION, 0, 8)) return hipfail("finalize: memset status");
             if (rt.launch("k_ins_insert", k_ins_insert, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev)) return hipfail("k_ins_insert");
-            if (rt.launch("k_ins_verify_max", k_ins_verify_max, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev, (kd_u64 *)b_best.p, d_status))
+            const unsigned g4 = (unsigned)((n_ev + KD_INS_CHUNK - 1) / KD_INS_CHUNK);
+            if (rt.launch("k_ins_verify_max", k_ins_verify_max, g4, KD_BLOCK, 0, I, H, (kd_u64)n_ev, (kd_u64 *)b_best.p, d_status))
                 return hipfail("k_ins_verify_max");
             ins_dirty_ev = n_ev; ins_dirty_tab = H;
             return KD_OK;
@@ -536,7 +537,7 @@ struct KdEngine {
                 if (attempt >= 8) return fail(KD_E_INTERNAL, "insertion hash: repeated 64-bit collisions");
                 if ((rc = ins_cleanup()) || (rc = reduce(attempt)) || (rc = fetch_status())) return rc;
             }
-            const unsigned ge = (unsigned)((n_ev + KD_BLOCK - 1) / KD_BLOCK);
+            const unsigned ge = (unsigned)((n_ev + KD_INS_CHUNK - 1) / KD_INS_CHUNK);
             if (rt.launch("k_ins_pick", k_ins_pick, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev, (const kd_u64 *)b_best.p, (uint32_t *)b_win.p))
                 return hipfail("k_ins_pick");
         }

@@ -55,49 +55,84 @@ k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev) {
     H.ev_slot[e] = (uint32_t)s;
 }
 
+// The three kernels below are chains of dependent scattered loads (event -> slot -> representative -> site -> counter):
+// every thread handles KD_INS_PER_THREAD events and issues each level of the chain for all of them before using any.
+#define KD_INS_PER_THREAD 4
+#define KD_INS_CHUNK (KD_BLOCK * KD_INS_PER_THREAD)
+
 // exactness: every event must be byte-identical to the representative of its slot (k_ins_insert has finished: the counts
 // are final).  The representative itself nominates its slot for its site: best[site] = max over the site's slots of
-// (count << 32 | slot).  One thread per EVENT: nothing here is proportional to the table capacity or to the sites.
+// (count << 32 | slot).  Per EVENT: nothing here is proportional to the table capacity or to the sites.
 __global__ void __launch_bounds__(KD_BLOCK)
 k_ins_verify_max(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, kd_u64 *status) {
-    const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (e >= n_ev) return;
-    const uint32_t s = H.ev_slot[e];
-    if (s == KD_EV_DROPPED) return;
-    const uint32_t r = H.rep[s];
-    if (r == (uint32_t)e) {
-        atomicMax(&best[ins.ev_site[e]], ((kd_u64)H.cnt[s] << 32) | s);
-        return;
+    const kd_u64 e0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x;
+    uint32_t s[KD_INS_PER_THREAD], r[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD], cnt[KD_INS_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) { const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK; s[k] = e < n_ev ? H.ev_slot[e] : KD_EV_DROPPED; }
+#pragma unroll
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) {
+        const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK;
+        r[k] = 0; site[k] = 0; cnt[k] = 0;
+        if (s[k] != KD_EV_DROPPED) { r[k] = H.rep[s[k]]; site[k] = ins.ev_site[e]; cnt[k] = H.cnt[s[k]]; }
     }
-    bool same = ins.ev_site[e] == ins.ev_site[r] && ins.ev_len[e] == ins.ev_len[r];
-    if (same) {
-        const uint8_t *a = ins.pool + ins.ev_off[e], *b = ins.pool + ins.ev_off[r];
-        for (uint32_t k = 0; k < ins.ev_len[e]; k++) if (a[k] != b[k]) { same = false; break; }
+#pragma unroll
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) {
+        const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK;
+        if (s[k] == KD_EV_DROPPED) continue;
+        if (r[k] == (uint32_t)e) { atomicMax(&best[site[k]], ((kd_u64)cnt[k] << 32) | s[k]); continue; }
+        const uint32_t rr = r[k];
+        bool same = site[k] == ins.ev_site[rr] && ins.ev_len[e] == ins.ev_len[rr];
+        if (same) {
+            const uint8_t *a = ins.pool + ins.ev_off[e], *b = ins.pool + ins.ev_off[rr];
+            for (uint32_t j = 0; j < ins.ev_len[e]; j++) if (a[j] != b[j]) { same = false; break; }
+        }
+        if (!same) atomicAdd(&status[KDS_INS_COLLISION], 1ULL);
     }
-    if (!same) atomicAdd(&status[KDS_INS_COLLISION], 1ULL);
 }
 // the best slot of a site nominates its representative event; any OTHER slot of the site with the same count makes it
-// a tie (kindel.py:377, :421).  One thread per event, only representatives act.
+// a tie (kindel.py:377, :421).  Only representatives act.
 __global__ void __launch_bounds__(KD_BLOCK)
 k_ins_pick(KdIns ins, KdInsTab H, kd_u64 n_ev, const kd_u64 *best, uint32_t *win) {
-    const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (e >= n_ev) return;
-    const uint32_t s = H.ev_slot[e];
-    if (s == KD_EV_DROPPED || H.rep[s] != (uint32_t)e) return;
-    const uint32_t site = ins.ev_site[e];
-    const kd_u64 b = best[site];
-    if ((uint32_t)(b >> 32) != H.cnt[s]) return;
-    atomicMax(&win[site], (uint32_t)b == s ? (uint32_t)e + 1u : KD_INS_TIE);
+    const kd_u64 e0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x;
+    uint32_t s[KD_INS_PER_THREAD], r[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD], cnt[KD_INS_PER_THREAD];
+    kd_u64 b[KD_INS_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) { const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK; s[k] = e < n_ev ? H.ev_slot[e] : KD_EV_DROPPED; }
+#pragma unroll
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) {
+        const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK;
+        r[k] = 0xffffffffu; site[k] = 0; cnt[k] = 0;
+        if (s[k] != KD_EV_DROPPED) { r[k] = H.rep[s[k]]; site[k] = ins.ev_site[e]; cnt[k] = H.cnt[s[k]]; }
+    }
+#pragma unroll
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) {
+        const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK;
+        b[k] = (s[k] != KD_EV_DROPPED && r[k] == (uint32_t)e) ? best[site[k]] : 0ULL;
+    }
+#pragma unroll
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) {
+        const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK;
+        if (s[k] == KD_EV_DROPPED || r[k] != (uint32_t)e) continue;
+        if ((uint32_t)(b[k] >> 32) != cnt[k]) continue;
+        atomicMax(&win[site[k]], (uint32_t)b[k] == s[k] ? (uint32_t)e + 1u : KD_INS_TIE);
+    }
 }
 // undo what the events of the last reduction left in the hash table and in best[] / win[] (all of them are zero between
 // reductions: no capacity- or site-proportional memset per kd_finalize)
 __global__ void __launch_bounds__(KD_BLOCK)
 k_ins_cleanup(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, uint32_t *win) {
-    const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (e >= n_ev) return;
-    const uint32_t s = H.ev_slot[e];
-    if (s == KD_EV_DROPPED) return;
-    H.key[s] = 0ULL; H.cnt[s] = 0u;
-    const uint32_t site = ins.ev_site[e];
-    best[site] = 0ULL; win[site] = KD_INS_NONE;
+    const kd_u64 e0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x;
+    uint32_t s[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) {
+        const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK;
+        s[k] = e < n_ev ? H.ev_slot[e] : KD_EV_DROPPED;
+        site[k] = e < n_ev ? ins.ev_site[e] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) {
+        if (s[k] == KD_EV_DROPPED) continue;
+        H.key[s[k]] = 0ULL; H.cnt[s[k]] = 0u;
+        best[site[k]] = 0ULL; win[site[k]] = KD_INS_NONE;
+    }
 }
