@@ -15,6 +15,7 @@ typedef unsigned long long kd_u64;
 // 24-bit multiply (operands < 2^24): full-rate on the VALU
 #ifndef KD_MUL24
 #define KD_MUL24(a, b) __umul24((a), (b))
+#define KD_MUL24S(a, b) __mul24((a), (b))   // signed (|operands| < 2^23)
 #endif
 
 // Wavefront operations (64 lanes, gfx950).  tests/emu/hip_emu.h supplies functional stand-ins (KD_EMU).

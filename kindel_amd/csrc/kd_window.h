@@ -5,8 +5,8 @@
 
 // k_window: persistent workgroups pull (window, slice) work items (k_plan_*).
 //
-// LDS (dynamic): u16 hist[19][W + 2 * KD_HALO], channel-major, two sites per dword: three groups of
-// {A,T,G,C,N, bad} -- weights (rows 0-5), clip_start_weights (7-12), clip_end_weights (13-18) -- plus deletions (6).
+// LDS (dynamic): u16 counters, site-pair major: hist[(W + 2 * KD_HALO) / 2 pairs][19 channels] dwords, two sites per dword:
+// three groups of {A,T,G,C,N, bad} -- weights (0-5), clip_start_weights (7-12), clip_end_weights (13-18) -- plus deletions (6).
 // "bad" collects bases outside A,C,G,T,N (KeyError in the reference; checked at flush).  38 B per site: W = 640 is
 // 25 KB + 4 KB of read lists, five workgroups (20 wavefronts) per CU.  Soft clips are tallied here too because 4 x 10^7
 // scattered device-scope atomics cost as much as the whole LDS pass (measured: 1.4 ms vs 1.5 ms).
@@ -15,9 +15,9 @@
 // the read: nothing to decode) and a COMPLEX list; wavefronts then take rows of 64 list entries, lane l the entry
 // l * rows + r, so that the lanes of a wavefront sit `rows` reads apart in the coordinate-sorted batch and rarely hit the
 // same counter in the same instruction.
-//   kd_walk_plain   16-byte chunks of packed bases at any byte address, three chunks of prefetch; a dword = 8 bases,
-//                   every base one ds_add_u32: nibble -> bfe, channel -> 64-bit LUT shift, address -> mad24, the base index
-//                   in the instruction's immediate offset (masked variant at the ends of the run / of the window)
+//   kd_walk_plain   16-byte chunks of packed bases at any byte address, three chunks of prefetch; a dword = 8 bases: their
+//                   channel offsets by three v_perm_b32 look-ups, then per base ONE byte add (pointer + offset) and one
+//                   ds_add_u32 with the site pair in the immediate offset (masked variant at the ends of the run / window)
 //   kd_walk_short   reads with clips / indels and <= 16 ops: CIGAR -> at most three segments cut to the window, then one
 //                   software-pipelined loop over (segment, chunk) steps of branch-free masked adds
 //   kd_walk_ops     the general op-by-op walk: short reads with more than three segments, and -- in the second launch --
@@ -29,81 +29,94 @@
 #define KD_HCH_CSW 7u
 #define KD_HCH_CEW 13u
 
-// BAM nibble -> channel inside a group: A,T,G,C,N -> 0..4, everything else -> 5 (the group's bad slot)
-__device__ __forceinline__ uint32_t kd_hchan(uint32_t nib) {
-    return (uint32_t)((0x4555555155525305ULL >> (nib * 4)) & 7ULL);
+// The LDS histogram is SITE-PAIR major: hist[pair P][channel] with KD_HPITCH = 19 dwords per pair of sites, the dword of
+// (P, ch) holding the u16 counters of sites 2P (low half) and 2P + 1 (high half): a work item tallies at most `slice`
+// <= 32768 reads and a read adds at most 1 to a counter, so a half cannot overflow into its neighbour.  The 19 channels
+// of a pair: weights A,T,G,C,N,bad (0-5), deletions (6), clip_start_weights (7-12), clip_end_weights (13-18).
+// With the channel as the FAST index the per-base address is  pointer + 4 * channel  -- a byte add of the looked-up code,
+// no multiply -- and the 8 bases of a packed dword get their codes from three v_perm_b32 table look-ups (kd_codes8)
+// instead of one 64-bit LUT shift per base.  19 is odd: both the walk (lanes on different pairs) and the flush (lane =
+// pair, fixed channel, stride 19 dwords) spread over the 32 banks.
+// KD_HALO extra sites on both sides of the window: window clipping is done at DWORD granularity of the packed bases (a
+// dword that straddles the window edge is added whole, its outside bases land in the halo and are never flushed), so the
+// masked path below is only needed at the ends of a run.
+// Counter of (channel ch, window-relative site s in [-KD_HALO, W + KD_HALO)) = half (s & 1) of hist0[(s >> 1) * 19 + ch],
+// hist0 = hist + (KD_HALO / 2) * 19; Wh = (W + 2 * KD_HALO) / 2 pairs.
+#define KD_HALO 8
+#define KD_HPITCH 19
+#define KD_HPITCHB (4 * KD_HPITCH)
+
+// 8 packed bases -> byte offsets of their channels inside a pair (4 * {A,T,G,C,N = 0..4; anything else = 5, the group's
+// bad slot}): rh = bases 0,2,4,6, rl = bases 1,3,5,7 (byte k = base 2k / 2k + 1).  Two 8-entry tables (bit 3 of the nibble
+// clear / set) looked up with v_perm_b32, a third v_perm selects per byte.
+__device__ __forceinline__ void kd_codes8(uint32_t v, uint32_t &rh, uint32_t &rl) {
+    const uint32_t TL_LO = 0x140c0014u, TL_HI = 0x14141408u;   // nibbles 0-7:  '=',A,C,M,G,R,S,V
+    const uint32_t TH_LO = 0x14141404u, TH_HI = 0x10141414u;   // nibbles 8-15: T,W,Y,H,K,D,B,N
+    const uint32_t tl = v & 0x07070707u, th = (v >> 4) & 0x07070707u;
+    const uint32_t sl = ((v >> 1) & 0x04040404u) | 0x03020100u, sh = ((v >> 5) & 0x04040404u) | 0x03020100u;
+    rl = kd_perm(kd_perm(TH_HI, TH_LO, tl), kd_perm(TL_HI, TL_LO, tl), sl);
+    rh = kd_perm(kd_perm(TH_HI, TH_LO, th), kd_perm(TL_HI, TL_LO, th), sh);
 }
 
-// The LDS histogram packs TWO sites per dword (u16 halves): a work item tallies at most `slice` <= 32768 reads
-// and a read adds at most 1 to a counter, so a half cannot overflow into its neighbour.  Every channel has
-// KD_HALO extra sites on both sides of the window: window clipping is done at DWORD granularity (a dword
-// that straddles the window edge is added whole, its outside bases land in the halo and are never flushed),
-// so the masked path below is only needed at the ends of a run -- which are the same step for all lanes of
-// a wavefront of equal-length reads -- and not wherever some lane happens to cross the window edge.
-// Counter of (channel ch, window-relative site s in [-KD_HALO, W + KD_HALO)) = half (s & 1) of word
-// ch*Wh + (s >> 1) of `hist0` = hist + KD_HALO/2, with Wh = (W + 2*KD_HALO) / 2.
-#define KD_HALO 8
-__device__ __forceinline__ void kd_hadd(uint32_t *hist0, int32_t Wh, uint32_t ch, int32_t s) {
-    atomicAdd(&hist0[(int32_t)KD_MUL24(ch, (uint32_t)Wh) + (s >> 1)], 1u << (16 * (s & 1)));
+__device__ __forceinline__ void kd_hadd(uint32_t *hist0, uint32_t ch, int32_t s) {
+    atomicAdd(&hist0[KD_MUL24S(s >> 1, KD_HPITCH) + (int32_t)ch], 1u << (16 * (s & 1)));
 }
-// all 8 bases of dword v are added; s0 = window-relative site of its first base.  Even bases go through pointer h
-// with add value vp, odd bases through hq = h + (s0 & 1) with vq: no per-base parity arithmetic.
-__device__ __forceinline__ void kd_add8_full(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t s0) {
+// all 8 bases of dword v are added; s0 = window-relative site of its first base, gb = byte offset of the channel group
+// (0 weights, 28 clip_start_weights, 52 clip_end_weights).  Even bases go through pointer h with add value vp, odd bases
+// through hq = h + (s0 & 1) pairs with vq: no per-base parity arithmetic; the pair of base b is an immediate offset.
+__device__ __forceinline__ void kd_add8_full(uint32_t *hist0, uint32_t v, int32_t s0, uint32_t gb) {
     const int32_t p = s0 & 1;
-    // byte addressing: address = row base + ch * (row bytes) + constant, one 24-bit multiply-add per base
-    // (v_mad_u32_u24 is full rate; a 32-bit v_mul_lo_u32 is not)
-    unsigned char *h = reinterpret_cast<unsigned char *>(hist0 + (s0 >> 1));
-    unsigned char *hq = h + 4 * p;
-    const uint32_t rowb = (uint32_t)Wh * 4u;
+    unsigned char *h = reinterpret_cast<unsigned char *>(hist0) + KD_MUL24S(s0 >> 1, KD_HPITCHB) + gb;
+    unsigned char *hq = h + KD_HPITCHB * p;
     const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
+    uint32_t rh, rl;
+    kd_codes8(v, rh, rl);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-        const uint32_t ch = kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u);
-        unsigned char *a = ((b & 1) ? hq : h) + KD_MUL24(ch, rowb) + 4 * (b >> 1);
+        const uint32_t code = (((b & 1) ? rl : rh) >> (8 * (b >> 1))) & 0xffu;
+        unsigned char *a = ((b & 1) ? hq : h) + code + KD_HPITCHB * (b >> 1);
         atomicAdd(reinterpret_cast<uint32_t *>(a), (b & 1) ? vq : vp);
     }
 }
 // only bases [blo, bhi) belong to the run
-__device__ __forceinline__ void kd_add8_part(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t s0, int32_t blo, int32_t bhi) {
+__device__ __forceinline__ void kd_add8_part(uint32_t *hist0, uint32_t v, int32_t s0, int32_t blo, int32_t bhi, uint32_t gb) {
+    uint32_t rh, rl;
+    kd_codes8(v, rh, rl);
 #pragma unroll
     for (int b = 0; b < 8; b++)
-        if (b >= blo && b < bhi) kd_hadd(hist0, Wh, kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u), s0 + b);
+        if (b >= blo && b < bhi) kd_hadd(hist0, (gb >> 2) + (((((b & 1) ? rl : rh) >> (8 * (b >> 1))) & 0xffu) >> 2), s0 + b);
 }
 // One memory dword of a run.  xs = query index of the dword's first base; [xa, xb) = the run's query bases that
 // fall inside the window (decides whether the dword is touched at all); [ra, rb) = the run's own query bases
-// (decides which of its 8 bases exist); site of base x is sx + x (for a clip run sx also carries the
-// channel-group offset, an even number of sites).
-__device__ __forceinline__ void kd_add_dword(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t xs, int32_t xa, int32_t xb,
-                                             int32_t ra, int32_t rb, int32_t sx) {
+// (decides which of its 8 bases exist); site of base x is sx + x.
+__device__ __forceinline__ void kd_add_dword(uint32_t *hist0, uint32_t v, int32_t xs, int32_t xa, int32_t xb,
+                                             int32_t ra, int32_t rb, int32_t sx, uint32_t gb) {
     if (xs + 8 <= xa || xs >= xb) return;
-    if (xs >= ra && xs + 8 <= rb) kd_add8_full(hist0, Wh, v, sx + xs);
-    else kd_add8_part(hist0, Wh, v, sx + xs, ra - xs, rb - xs);
+    if (xs >= ra && xs + 8 <= rb) kd_add8_full(hist0, v, sx + xs, gb);
+    else kd_add8_part(hist0, v, sx + xs, ra - xs, rb - xs, gb);
 }
 
-// General per-lane walk of one regular read against the window (reads with clips, indels, long CIGARs).
-// A state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the current run), not over
-// CIGAR ops, so that lanes keep adding bases together whatever their op structure.  A soft clip is a
-// run of its own on the clip_start / clip_end channel group.
 // Bases of dword v whose bit is set in m (bit b = base b) are added; the others add 0 to a counter at most
-// 7 sites away from a live one, i.e. inside the row (halo included).  No branches: lanes whose dword is cut
-// by a run end, a clip end or the window edge stay in step with lanes whose dword is whole.
-__device__ __forceinline__ void kd_add8_masked(uint32_t *hist0, int32_t Wh, uint32_t v, int32_t s0, uint32_t m) {
+// 7 sites away from a live one, i.e. inside the halo.  No branches: lanes whose dword is cut by a run end, a clip end or
+// the window edge stay in step with lanes whose dword is whole.
+__device__ __forceinline__ void kd_add8_masked(uint32_t *hist0, uint32_t v, int32_t s0, uint32_t m, uint32_t gb) {
     const int32_t p = s0 & 1;
-    unsigned char *h = reinterpret_cast<unsigned char *>(hist0 + (s0 >> 1));
-    unsigned char *hq = h + 4 * p;
-    const uint32_t rowb = (uint32_t)Wh * 4u;
+    unsigned char *h = reinterpret_cast<unsigned char *>(hist0) + KD_MUL24S(s0 >> 1, KD_HPITCHB) + gb;
+    unsigned char *hq = h + KD_HPITCHB * p;
     const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
     const uint32_t me = m << (16 * p), mo = m << (16 - 16 * p);   // bit b of m moved onto the add value's bit
+    uint32_t rh, rl;
+    kd_codes8(v, rh, rl);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-        const uint32_t ch = kd_hchan((v >> KD_NIB_SHIFT(b)) & 15u);
-        unsigned char *a = ((b & 1) ? hq : h) + KD_MUL24(ch, rowb) + 4 * (b >> 1);
+        const uint32_t code = (((b & 1) ? rl : rh) >> (8 * (b >> 1))) & 0xffu;
+        unsigned char *a = ((b & 1) ? hq : h) + code + KD_HPITCHB * (b >> 1);
         atomicAdd(reinterpret_cast<uint32_t *>(a), (b & 1) ? ((mo >> b) & vq) : ((me >> b) & vp));
     }
 }
 // one 16-byte chunk (query bases xs .. xs+31) against the live query range [lo, hi) of a segment
-__device__ __forceinline__ void kd_add_chunk_masked(uint32_t *hist0, int32_t Wh, const KdChunk &cur, int32_t xs, int32_t lo,
-                                                    int32_t hi, int32_t sx) {
+__device__ __forceinline__ void kd_add_chunk_masked(uint32_t *hist0, const KdChunk &cur, int32_t xs, int32_t lo,
+                                                    int32_t hi, int32_t sx, uint32_t gb) {
     const uint32_t dw[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
     for (int d = 0; d < 4; d++) {
@@ -112,20 +125,24 @@ __device__ __forceinline__ void kd_add_chunk_masked(uint32_t *hist0, int32_t Wh,
         if (h <= 0 || l >= 8) continue;
         l = l < 0 ? 0 : l;
         h = h > 8 ? 8 : h;
-        kd_add8_masked(hist0, Wh, dw[d], sx + x0, (0xffu >> (8 - h)) & (0xffu << l));
+        kd_add8_masked(hist0, dw[d], sx + x0, (0xffu >> (8 - h)) & (0xffu << l), gb);
     }
 }
 
+// General per-lane walk of one regular read against the window (reads with clips, indels, long CIGARs).
+// A state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the current run), not over
+// CIGAR ops, so that lanes keep adding bases together whatever their op structure.  A soft clip is a
+// run of its own on the clip_start / clip_end channel group.
 // Ops [k, k_end) of read i, entered with the reference cursor at window-relative site `grel` and the query cursor
 // at q: the whole CIGAR of a short read with many segments (k = 0, k_end = n_cig), or ONE SEGMENT of a long read
 // (k_prep_long's checkpoint).  `lead` / `foot_end`: reach of the leading clip / window-relative end of the footprint
 // (used by the clip ops, which sit in the first / last segment).
 __device__ __forceinline__ void kd_walk_ops(const KdReads &rd, kd_u64 i, uint32_t k, uint32_t k_end, int32_t grel, int32_t q,
                                             int32_t lead, int32_t foot_end, int32_t Wi, int32_t Wh, uint32_t *hist0) {
-    const int32_t Wp = 2 * Wh;   // sites per channel row, halos included
     const uint32_t nc = rd.n_cig[i];
     const uint32_t *cg = rd.cigar + rd.cig_off[i];
     const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
+    uint32_t sg = 0;   // byte offset of the current run's channel group inside a pair
     // Per-lane state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the
     // current M run), not over CIGAR ops: lanes whose reads have clips or indels still add
     // bases in the same wavefront instructions as their single-run neighbours.
@@ -154,12 +171,13 @@ __device__ __forceinline__ void kd_walk_ops(const KdReads &rd, kd_u64 i, uint32_
                 xa = grel < 0 ? q - grel : q;
                 xb = Wi - grel < len ? q + (Wi - grel) : q + len;
                 sx = grel - q;                      // site of query base x is sx + x
+                sg = 0;
                 if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
                 q += len; grel += len;
                 if (grel >= Wi) k = k_end;
             } else if (op == 2) {
                 for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
-                    kd_hadd(hist0, Wh, KD_HCH_DEL, grel + j);
+                    kd_hadd(hist0, KD_HCH_DEL, grel + j);
                 grel += len;
                 if (grel >= Wi) k = k_end;
             } else if (op == 1) {
@@ -171,7 +189,7 @@ __device__ __forceinline__ void kd_walk_ops(const KdReads &rd, kd_u64 i, uint32_
                     const int32_t s_first = grel - len;           // site of base 0
                     xa = -s_first > len - lead ? -s_first : len - lead;
                     xb = Wi - s_first < len ? Wi - s_first : len;
-                    sx = s_first + (int32_t)KD_HCH_CEW * Wp;
+                    sx = s_first; sg = 4u * KD_HCH_CEW;
                     if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
                     q += len;
                 } else {
@@ -180,7 +198,7 @@ __device__ __forceinline__ void kd_walk_ops(const KdReads &rd, kd_u64 i, uint32_
                     const int32_t n_adv = foot_end - grel;
                     xa = grel < 0 ? q - grel : q;
                     xb = Wi - grel < n_adv ? q + (Wi - grel) : q + n_adv;
-                    sx = grel - q + (int32_t)KD_HCH_CSW * Wp;
+                    sx = grel - q; sg = 4u * KD_HCH_CSW;
                     if (xb > xa) { c = xa >> 5; cb = (xb - 1) >> 5; }
                     k = k_end;
                 }
@@ -189,7 +207,7 @@ __device__ __forceinline__ void kd_walk_ops(const KdReads &rd, kd_u64 i, uint32_
         if (c > cb) break;
         if (c != c_have) { cur = src[c]; c_have = c; }
         const int32_t xs = 32 * c;
-        kd_add_chunk_masked(hist0, Wh, cur, xs, xa, xb, sx);   // [xa, xb) lies inside the run: branch-free masked adds
+        kd_add_chunk_masked(hist0, cur, xs, xa, xb, sx, sg);   // [xa, xb) lies inside the run: branch-free masked adds
         c++;
     }
 }
@@ -219,20 +237,21 @@ __device__ __forceinline__ bool kd_walk_short(const KdReads &rd, kd_u64 i, const
         n_seg_ops += (op == 0 || op == 7 || op == 8 || op == 4) ? 1u : 0u;
     }
     if (n_seg_ops > 3) return false;
-    const int32_t Wp = 2 * Wh;   // sites per channel row, halos included
     const kd_u64 gs = ri.gstart, span = ri.span_cls >> KD_SPAN_SHIFT;
     const int32_t lead = (int32_t)ri.lead;
     const int32_t foot_end = (int32_t)((uint32_t)(gs + span) - (uint32_t)wlo);  // window-relative end of the footprint
     int32_t grel = (int32_t)((uint32_t)gs - (uint32_t)wlo);                        // window-relative site, may be negative
     int32_t q = 0;
-    // segment slots: live query range [a, b) and site offset x (site of query base j is x + j, channel group included)
+    // segment slots: live query range [a, b), site offset x (site of query base j is x + j), channel-group byte offset g
     int32_t a0 = 0, b0 = 0, x0 = 0, a1 = 0, b1 = 0, x1 = 0, a2 = 0, b2 = 0, x2 = 0;
+    uint32_t g0 = 0, g1 = 0, g2 = 0;
     uint32_t ns = 0;
     for (uint32_t k = 0; k < nc; k++) {
         const uint32_t cw = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : k == 3 ? w3 : cg[k];
         const int32_t len = (int32_t)(cw >> 4);
         const uint32_t op = cw & 15u;
         int32_t xa = 0, xb = 0, sx = 0;
+        uint32_t sg = 0;
         if (op == 0 || op == 7 || op == 8) {
             xa = grel < 0 ? q - grel : q;
             xb = Wi - grel < len ? q + (Wi - grel) : q + len;
@@ -240,7 +259,7 @@ __device__ __forceinline__ bool kd_walk_short(const KdReads &rd, kd_u64 i, const
             q += len; grel += len;
         } else if (op == 2) {
             for (int32_t j = grel < 0 ? -grel : 0; j < len && grel + j < Wi; j++)
-                kd_hadd(hist0, Wh, KD_HCH_DEL, grel + j);
+                kd_hadd(hist0, KD_HCH_DEL, grel + j);
             grel += len;
         } else if (op == 1) {
             q += len;
@@ -249,20 +268,20 @@ __device__ __forceinline__ bool kd_walk_short(const KdReads &rd, kd_u64 i, const
                 const int32_t s_first = grel - len;
                 xa = -s_first > len - lead ? -s_first : len - lead;
                 xb = Wi - s_first < len ? Wi - s_first : len;
-                sx = s_first + (int32_t)KD_HCH_CEW * Wp;
+                sx = s_first; sg = 4u * KD_HCH_CEW;
                 q += len;
             } else {        // non-first clip, kindel.py:74-81: it is the last op that moves r (regular read)
                 const int32_t n_adv = foot_end - grel;
                 xa = grel < 0 ? q - grel : q;
                 xb = Wi - grel < n_adv ? q + (Wi - grel) : q + n_adv;
-                sx = grel - q + (int32_t)KD_HCH_CSW * Wp;
+                sx = grel - q; sg = 4u * KD_HCH_CSW;
                 k = nc;
             }
         }
         if (xb > xa) {
-            if (ns == 0) { a0 = xa; b0 = xb; x0 = sx; }
-            else if (ns == 1) { a1 = xa; b1 = xb; x1 = sx; }
-            else { a2 = xa; b2 = xb; x2 = sx; }
+            if (ns == 0) { a0 = xa; b0 = xb; x0 = sx; g0 = sg; }
+            else if (ns == 1) { a1 = xa; b1 = xb; x1 = sx; g1 = sg; }
+            else { a2 = xa; b2 = xb; x2 = sx; g2 = sg; }
             ns++;
         }
         if (grel >= Wi) break;   // everything further right is outside the window
@@ -277,10 +296,10 @@ __device__ __forceinline__ bool kd_walk_short(const KdReads &rd, kd_u64 i, const
         const int32_t cn = adv ? (a1 >> 5) : c + 1;
         KdChunk nxt = cur;
         if (more) nxt = src[cn];
-        kd_add_chunk_masked(hist0, Wh, cur, 32 * c, a0, b0, x0);
+        kd_add_chunk_masked(hist0, cur, 32 * c, a0, b0, x0, g0);
         if (!more) break;
         if (adv) {
-            a0 = a1; b0 = b1; x0 = x1; a1 = a2; b1 = b2; x1 = x2;
+            a0 = a1; b0 = b1; x0 = x1; g0 = g1; a1 = a2; b1 = b2; x1 = x2; g1 = g2;
             ns--;
             cb = (b0 - 1) >> 5;
         }
@@ -309,17 +328,17 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
         KdChunk n3 = n2;
         if (c + 3 <= cb) n3 = src[c + 3];
         const int32_t xs = 32 * c;
-        kd_add_dword(hist0, Wh, cur.x, xs, xa, xb, 0, len, grel);
-        kd_add_dword(hist0, Wh, cur.y, xs + 8, xa, xb, 0, len, grel);
-        kd_add_dword(hist0, Wh, cur.z, xs + 16, xa, xb, 0, len, grel);
-        kd_add_dword(hist0, Wh, cur.w, xs + 24, xa, xb, 0, len, grel);
+        kd_add_dword(hist0, cur.x, xs, xa, xb, 0, len, grel, 0u);
+        kd_add_dword(hist0, cur.y, xs + 8, xa, xb, 0, len, grel, 0u);
+        kd_add_dword(hist0, cur.z, xs + 16, xa, xb, 0, len, grel, 0u);
+        kd_add_dword(hist0, cur.w, xs + 24, xa, xb, 0, len, grel, 0u);
         cur = n1; n1 = n2; n2 = n3;
     }
 }
 
 #define KD_TILE 1024   // reads classified together (a multiple of KD_BLOCK)
 #define KD_TILE_PER_THREAD (KD_TILE / KD_BLOCK)
-#define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)2 * KD_TILE * 2)   // Wh = dwords per channel row
+#define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)2 * KD_TILE * 2)   // Wh = site pairs, halos included
 
 __global__ void __launch_bounds__(KD_BLOCK, 5)   // 5 wavefronts per SIMD = the 5 workgroups per CU the LDS footprint allows
 k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *ckpt, const uint32_t *seg_read, KdTabs T,
@@ -330,7 +349,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
     // run of ops of the long read seg_read[b], entered through checkpoint ckpt[e]); `order` is then never NULL.
     KD_DYN_SHARED(uint32_t, hist);
     const int32_t Wh = (int32_t)Wh_;   // dwords per channel row (two u16 counters each, halos included; >= (W + 2*KD_HALO)/2)
-    uint32_t *hist0 = hist + KD_HALO / 2;                 // word of window-relative site 0
+    uint32_t *hist0 = hist + (KD_HALO / 2) * KD_HPITCH;   // pair of window-relative site 0
     uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * Wh);  // tile-relative read indices
     uint16_t *l_cplx = l_plain + KD_TILE;
     __shared__ kd_u64 s_item;
@@ -434,19 +453,19 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
             __syncthreads();
             KD_MARK(c_wait)
         }
-        // flush: channel-major, consecutive lanes -> consecutive HBM dwords; zeros are skipped.
+        // flush: channel by channel, lane = site pair: consecutive lanes -> consecutive dwords of one HBM channel row (the LDS
+        // reads are 19 dwords apart: conflict free); zeros are skipped.
         // LDS channel -> table channel (KD_CH_*): weights 0-4, deletions 5, csw 6-10, cew 11-15; 0xff = bad slot
         bool bad = false;
-        uint32_t ch = 0, xw = t;   // word x = ch * Wh + xw, kept without a division
-        for (uint32_t x = t; x < nh; x += KD_BLOCK, xw += KD_BLOCK) {
-            while (xw >= (uint32_t)Wh) { xw -= (uint32_t)Wh; ch++; }
-            const uint32_t v = hist[x];
-            if (v) {
-                const uint32_t tch = ch < 5 ? ch : ch == KD_HCH_DEL ? (uint32_t)KDC_DEL
-                                   : (ch >= 7 && ch < 12) ? ch - 1 : (ch >= 13 && ch < 18) ? ch - 2 : 0xffu;
+        for (uint32_t ch = 0; ch < KD_HCH; ch++) {
+            const uint32_t tch = ch < 5 ? ch : ch == KD_HCH_DEL ? (uint32_t)KDC_DEL
+                               : (ch >= 7 && ch < 12) ? ch - 1 : (ch >= 13 && ch < 18) ? ch - 2 : 0xffu;
+            uint32_t *row = T.tab + (kd_u64)(tch == 0xffu ? 0u : tch) * T.stride;
+            for (uint32_t xw = t; xw < (uint32_t)Wh; xw += KD_BLOCK) {
+                const uint32_t v = hist[xw * KD_HPITCH + ch];
+                if (!v) continue;
                 // the word holds window-relative sites s (low half) and s + 1 (high half); halo sites are dropped
                 const int32_t sw = 2 * (int32_t)xw - KD_HALO;
-                uint32_t *row = T.tab + (kd_u64)(tch == 0xffu ? 0u : tch) * T.stride;
                 const kd_u64 g0 = wlo + (kd_u64)sw;   // even: W, the halo and the G-space rows are all even / 8-byte aligned
                 if (tch != 0xffu && sw >= 0 && sw + 1 < Wi && g0 + 1 < T.sites && kd_commit(T, g0) && kd_commit(T, g0 + 1)) {
                     // both sites of the word live: ONE 64-bit add on the two adjacent u32 counters (the low counter

@@ -110,6 +110,7 @@ static inline void emu_wave_meet() {
 #define __shared__ static thread_local
 #define __launch_bounds__(...)
 #define KD_MUL24(a, b) ((uint32_t)(a) * (uint32_t)(b))
+#define KD_MUL24S(a, b) ((int32_t)(a) * (int32_t)(b))
 #define KD_DYN_SHARED(type, name) type *name = reinterpret_cast<type *>(emu_dyn_shared_ptr)
 
 static inline void __syncthreads() {
