@@ -8,7 +8,9 @@
 // One lane per read, KD_PREP_PER_THREAD reads per lane so that the per-block reductions
 // (stats, list reservations) cost one global atomic per 8192 reads.
 // ---------------------------------------------------------------------------------------
+#ifndef KD_PREP_PER_THREAD
 #define KD_PREP_PER_THREAD 32
+#endif
 #define KD_PREP_CHUNK (KD_BLOCK * KD_PREP_PER_THREAD)
 #define KD_PREP_MAX_OPS 16
 
@@ -188,22 +190,22 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
     const kd_u64 o_ev = a_ins ? atomicAdd(&s_ins[0], a_ins) : 0;
     const kd_u64 o_pool = a_ins ? atomicAdd(&s_ins[1], a_insb) : 0;
     __syncthreads();
-    if (t == 0) {
-        if (s_red[0]) atomicAdd(&status[KDS_ST_READS], s_red[0]);
-        if (s_red[1]) atomicAdd(&status[KDS_ST_ALIGNED], s_red[1]);
-        if (s_red[2]) atomicAdd(&status[KDS_ST_WALKED], s_red[2]);
-        if (s_red[3]) { atomicAdd(&status[KDS_ST_INS], s_red[3]); atomicAdd(&status[KDS_B_INS_OPS], s_red[3]); }
-        if (s_red[4]) atomicAdd(&status[KDS_B_INS_BASES], s_red[4]);
-        s_base[3] = s_ins[0] ? atomicAdd(&status[KDS_N_EV], s_ins[0]) : 0;
-        s_base[4] = s_ins[0] ? atomicAdd(&status[KDS_POOL], s_ins[1]) : 0;
-        if (s_red[5]) atomicAdd(&status[KDS_B_N_REG], s_red[5]);
-        if (s_red[6]) atomicAdd(&status[KDS_B_UNSORTED], s_red[6]);
-        if (s_maxspan) atomicMax(&status[KDS_B_MAXSPAN], (kd_u64)s_maxspan);
-        if (s_maxlead) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)s_maxlead);
-        s_base[0] = s_cnt[0] ? atomicAdd(&status[KDS_B_N_COLD], (kd_u64)s_cnt[0]) : 0;
-        s_base[1] = s_cnt[1] ? atomicAdd(&status[KDS_B_N_IRREG], (kd_u64)s_cnt[1]) : 0;
-        s_base[2] = s_cnt[2] ? atomicAdd(&status[KDS_B_N_LONG], (kd_u64)s_cnt[2]) : 0;
-    }
+    // one global atomic per word and block, issued by DIFFERENT threads (a dozen returning atomics in a row from one
+    // thread are a dozen round trips the other 255 threads wait for)
+    if (t == 0 && s_red[0]) atomicAdd(&status[KDS_ST_READS], s_red[0]);
+    if (t == 1 && s_red[1]) atomicAdd(&status[KDS_ST_ALIGNED], s_red[1]);
+    if (t == 2 && s_red[2]) atomicAdd(&status[KDS_ST_WALKED], s_red[2]);
+    if (t == 3 && s_red[3]) { atomicAdd(&status[KDS_ST_INS], s_red[3]); atomicAdd(&status[KDS_B_INS_OPS], s_red[3]); }
+    if (t == 4 && s_red[4]) atomicAdd(&status[KDS_B_INS_BASES], s_red[4]);
+    if (t == 5) s_base[3] = s_ins[0] ? atomicAdd(&status[KDS_N_EV], s_ins[0]) : 0;
+    if (t == 6) s_base[4] = s_ins[0] ? atomicAdd(&status[KDS_POOL], s_ins[1]) : 0;
+    if (t == 7 && s_red[5]) atomicAdd(&status[KDS_B_N_REG], s_red[5]);
+    if (t == 8 && s_red[6]) atomicAdd(&status[KDS_B_UNSORTED], s_red[6]);
+    if (t == 9 && s_maxspan) atomicMax(&status[KDS_B_MAXSPAN], (kd_u64)s_maxspan);
+    if (t == 10 && s_maxlead) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)s_maxlead);
+    if (t == 64) s_base[0] = s_cnt[0] ? atomicAdd(&status[KDS_B_N_COLD], (kd_u64)s_cnt[0]) : 0;
+    if (t == 65) s_base[1] = s_cnt[1] ? atomicAdd(&status[KDS_B_N_IRREG], (kd_u64)s_cnt[1]) : 0;
+    if (t == 66) s_base[2] = s_cnt[2] ? atomicAdd(&status[KDS_B_N_LONG], (kd_u64)s_cnt[2]) : 0;
     __syncthreads();
     if (m_cold | m_irreg | m_long | m_ins) {
         kd_u64 w_cold = s_base[0] + o_cold, w_irreg = s_base[1] + o_irreg, w_long = s_base[2] + o_long;

@@ -336,6 +336,9 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
     }
 }
 
+#ifndef KD_LANE_GROUP
+#define KD_LANE_GROUP 1   // 1, 2, 4, .. 64 (a divisor of the wavefront size)
+#endif
 #define KD_TILE 1024   // reads classified together (a multiple of KD_BLOCK)
 #define KD_TILE_PER_THREAD (KD_TILE / KD_BLOCK)
 #define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)2 * KD_TILE * 2)   // Wh = site pairs, halos included
@@ -421,9 +424,14 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
             // homogeneous wavefronts: first the plain reads, then the complex ones.  Lane l of a wavefront takes
             // list entries l*rows + r: neighbours in a wavefront are `rows` reads apart in the sorted batch,
             // which keeps them off the same LDS counters in the same instruction.
-            const uint32_t rows_p = (np + KD_WAVE - 1) / KD_WAVE, rows_c = (ncx + KD_WAVE - 1) / KD_WAVE;
+            // lanes take the list in GROUPS of KD_LANE_GROUP neighbouring entries (neighbours in the sorted batch: their
+            // rinfo / seq_off / packed bases share cache lines, one fetch serves the group), the groups of a wavefront
+            // lie rows apart (different sites: fewer same-counter collisions in one LDS instruction)
+            const uint32_t ngp = (np + KD_LANE_GROUP - 1) / KD_LANE_GROUP, ngc = (ncx + KD_LANE_GROUP - 1) / KD_LANE_GROUP;
+            const uint32_t rows_p = (ngp + KD_WAVE / KD_LANE_GROUP - 1) / (KD_WAVE / KD_LANE_GROUP);
+            const uint32_t rows_c = (ngc + KD_WAVE / KD_LANE_GROUP - 1) / (KD_WAVE / KD_LANE_GROUP);
             for (uint32_t r = wave; r < rows_p; r += KD_WAVES_PER_BLOCK) {
-                const uint32_t e = lane * rows_p + r;
+                const uint32_t e = ((lane / KD_LANE_GROUP) * rows_p + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
                 if (e < np) {
                     const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
                     kd_walk_plain(rd, i, rinfo[i], wlo, Wi, Wh, hist0);
@@ -433,7 +441,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
             // the complex rows start at the wavefront after the one that took the last plain row
             for (uint32_t r = (wave + KD_WAVES_PER_BLOCK - rows_p % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK; r < rows_c;
                  r += KD_WAVES_PER_BLOCK) {
-                const uint32_t e = lane * rows_c + r;
+                const uint32_t e = ((lane / KD_LANE_GROUP) * rows_c + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
                 if (e < ncx) {
                     const kd_u64 j = tb + l_cplx[e], i = order ? (kd_u64)order[j] : j;
                     const KdRInfo ri = rinfo[i];
