@@ -20,7 +20,55 @@ struct KdInsTab {
     kd_u64 cap;      // power of two
     kd_u64 seed;
     kd_u64 sites;    // G-space sites (bound of a valid event site)
+    const uint32_t *sel;   // the events that take part: those on sites where an insertion can be emitted (k_ins_filter)
+    const kd_u64 *n_sel;   // their number (device word: the host never reads it, grids are sized by the upper bound n_ev)
 };
+
+// An insertion is emitted at a site only if 2 * ins_total > min(aligned_depth, aligned_depth_next) (kindel.py:411-412, :419);
+// the deletion / min_depth tests before it can only remove sites.  On sequencing data that is a handful of sites, while
+// EVERY read with an I op contributes an event: flag the sites first, reduce only the events on flagged sites.
+// One thread per 4 sites (16-byte loads per channel), flag[g] = 1 / 0.
+__global__ void __launch_bounds__(KD_BLOCK)
+k_ins_flag(KdTabs T, kd_u64 g_first, kd_u64 g_end, uint8_t *flag) {
+    const kd_u64 g0 = g_first + ((kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x) * 4;
+    if (g0 >= g_end) return;
+    uint32_t v[5][5];
+    const int chs[5] = {KDC_A, KDC_T, KDC_G, KDC_C, KDC_INS_TOTAL};
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const uint32_t *row = T.tab + (kd_u64)chs[c] * T.stride;
+        const uint4 x = *reinterpret_cast<const uint4 *>(row + g0);     // the allocation covers whole 1024-site tiles + slack
+        v[c][0] = x.x; v[c][1] = x.y; v[c][2] = x.z; v[c][3] = x.w;
+        v[c][4] = (c < 4 && g0 + 4 < T.sites) ? row[g0 + 4] : 0u;
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const kd_u64 ad = (kd_u64)v[0][k] + v[1][k] + v[2][k] + v[3][k];
+        const kd_u64 adn = (kd_u64)v[0][k + 1] + v[1][k + 1] + v[2][k + 1] + v[3][k + 1];   // 0 behind a contig's last site
+        const kd_u64 m = ad < adn ? ad : adn;
+        if (v[4][k] && 2ULL * v[4][k] > m) out |= 1u << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(flag + g0) = out;
+}
+// events on flagged sites -> sel[0 .. n_sel): one atomic per wavefront (ballot + popcount + prefix by v_mbcnt)
+__global__ void __launch_bounds__(KD_BLOCK)
+k_ins_filter(KdIns ins, kd_u64 n_ev, const uint8_t *flag, kd_u64 sites, uint32_t *sel, kd_u64 *n_sel, uint32_t *ev_slot) {
+    const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    bool take = false;
+    if (e < n_ev) {
+        const uint32_t site = ins.ev_site[e];
+        // a reserved slot that was never written (its read raised a reference exception half way: the batch is rejected by
+        // kd_finalize anyway) holds stale data: keep it out unless it is at least in bounds
+        take = site != KD_EV_DROPPED && site < sites && ins.ev_off[e] + ins.ev_len[e] <= ins.pool_cap && flag[site];
+        if (!take) ev_slot[e] = KD_EV_DROPPED;
+    }
+    const kd_u64 m = kd_ballot(take);
+    kd_u64 base = 0;
+    if (m && kd_lane_id() == 0) base = atomicAdd(n_sel, (kd_u64)kd_popcll(m));
+    base = kd_readfirstlane64(base);
+    if (take) sel[base + kd_mbcnt(m)] = (uint32_t)e;
+}
 
 __device__ __forceinline__ kd_u64 kd_mix64(kd_u64 x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -28,13 +76,11 @@ __device__ __forceinline__ kd_u64 kd_mix64(kd_u64 x) {
 }
 
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev) {
-    const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (e >= n_ev) return;
+k_ins_insert(KdIns ins, KdInsTab H) {
+    const kd_u64 k = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (k >= *H.n_sel) return;
+    const kd_u64 e = H.sel[k];
     const uint32_t site = ins.ev_site[e], len = ins.ev_len[e];
-    // a reserved slot that was never written (its read raised a reference exception half way: the batch is rejected by
-    // kd_finalize anyway) holds stale data: keep it out of the table unless it is at least in bounds
-    if (site == KD_EV_DROPPED || site >= H.sites || ins.ev_off[e] + len > ins.pool_cap) { H.ev_slot[e] = KD_EV_DROPPED; return; }
     const uint8_t *p = ins.pool + ins.ev_off[e];
     kd_u64 h = kd_mix64(H.seed ^ ((kd_u64)site << 32 | len));
     for (uint32_t b = 0; b < len; b++) h = (h ^ p[b]) * 0x100000001b3ULL;
@@ -64,20 +110,22 @@ k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev) {
 // are final).  The representative itself nominates its slot for its site: best[site] = max over the site's slots of
 // (count << 32 | slot).  Per EVENT: nothing here is proportional to the table capacity or to the sites.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_verify_max(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, kd_u64 *status) {
-    const kd_u64 e0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x;
-    uint32_t s[KD_INS_PER_THREAD], r[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD], cnt[KD_INS_PER_THREAD];
+k_ins_verify_max(KdIns ins, KdInsTab H, kd_u64 *best, kd_u64 *status) {
+    const kd_u64 k0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x, n_ev = *H.n_sel;
+    uint32_t ev[KD_INS_PER_THREAD], s[KD_INS_PER_THREAD], r[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD], cnt[KD_INS_PER_THREAD];
 #pragma unroll
-    for (int k = 0; k < KD_INS_PER_THREAD; k++) { const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK; s[k] = e < n_ev ? H.ev_slot[e] : KD_EV_DROPPED; }
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) { const kd_u64 j = k0 + (kd_u64)k * KD_BLOCK; ev[k] = j < n_ev ? H.sel[j] : 0xffffffffu; }
+#pragma unroll
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) s[k] = ev[k] != 0xffffffffu ? H.ev_slot[ev[k]] : KD_EV_DROPPED;
 #pragma unroll
     for (int k = 0; k < KD_INS_PER_THREAD; k++) {
-        const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK;
+        const kd_u64 e = ev[k];
         r[k] = 0; site[k] = 0; cnt[k] = 0;
         if (s[k] != KD_EV_DROPPED) { r[k] = H.rep[s[k]]; site[k] = ins.ev_site[e]; cnt[k] = H.cnt[s[k]]; }
     }
 #pragma unroll
     for (int k = 0; k < KD_INS_PER_THREAD; k++) {
-        const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK;
+        const kd_u64 e = ev[k];
         if (s[k] == KD_EV_DROPPED) continue;
         if (r[k] == (uint32_t)e) { atomicMax(&best[site[k]], ((kd_u64)cnt[k] << 32) | s[k]); continue; }
         const uint32_t rr = r[k];
@@ -92,26 +140,28 @@ k_ins_verify_max(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, kd_u64 *statu
 // the best slot of a site nominates its representative event; any OTHER slot of the site with the same count makes it
 // a tie (kindel.py:377, :421).  Only representatives act.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_pick(KdIns ins, KdInsTab H, kd_u64 n_ev, const kd_u64 *best, uint32_t *win) {
-    const kd_u64 e0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x;
-    uint32_t s[KD_INS_PER_THREAD], r[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD], cnt[KD_INS_PER_THREAD];
+k_ins_pick(KdIns ins, KdInsTab H, const kd_u64 *best, uint32_t *win) {
+    const kd_u64 k0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x, n_ev = *H.n_sel;
+    uint32_t ev[KD_INS_PER_THREAD], s[KD_INS_PER_THREAD], r[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD], cnt[KD_INS_PER_THREAD];
     kd_u64 b[KD_INS_PER_THREAD];
 #pragma unroll
-    for (int k = 0; k < KD_INS_PER_THREAD; k++) { const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK; s[k] = e < n_ev ? H.ev_slot[e] : KD_EV_DROPPED; }
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) { const kd_u64 j = k0 + (kd_u64)k * KD_BLOCK; ev[k] = j < n_ev ? H.sel[j] : 0xffffffffu; }
+#pragma unroll
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) s[k] = ev[k] != 0xffffffffu ? H.ev_slot[ev[k]] : KD_EV_DROPPED;
 #pragma unroll
     for (int k = 0; k < KD_INS_PER_THREAD; k++) {
-        const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK;
+        const kd_u64 e = ev[k];
         r[k] = 0xffffffffu; site[k] = 0; cnt[k] = 0;
         if (s[k] != KD_EV_DROPPED) { r[k] = H.rep[s[k]]; site[k] = ins.ev_site[e]; cnt[k] = H.cnt[s[k]]; }
     }
 #pragma unroll
     for (int k = 0; k < KD_INS_PER_THREAD; k++) {
-        const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK;
+        const kd_u64 e = ev[k];
         b[k] = (s[k] != KD_EV_DROPPED && r[k] == (uint32_t)e) ? best[site[k]] : 0ULL;
     }
 #pragma unroll
     for (int k = 0; k < KD_INS_PER_THREAD; k++) {
-        const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK;
+        const kd_u64 e = ev[k];
         if (s[k] == KD_EV_DROPPED || r[k] != (uint32_t)e) continue;
         if ((uint32_t)(b[k] >> 32) != cnt[k]) continue;
         atomicMax(&win[site[k]], (uint32_t)b[k] == s[k] ? (uint32_t)e + 1u : KD_INS_TIE);
@@ -120,14 +170,15 @@ k_ins_pick(KdIns ins, KdInsTab H, kd_u64 n_ev, const kd_u64 *best, uint32_t *win
 // undo what the events of the last reduction left in the hash table and in best[] / win[] (all of them are zero between
 // reductions: no capacity- or site-proportional memset per kd_finalize)
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_cleanup(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, uint32_t *win) {
-    const kd_u64 e0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x;
+k_ins_cleanup(KdIns ins, KdInsTab H, kd_u64 *best, uint32_t *win) {
+    const kd_u64 k0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x, n_ev = *H.n_sel;
     uint32_t s[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < KD_INS_PER_THREAD; k++) {
-        const kd_u64 e = e0 + (kd_u64)k * KD_BLOCK;
-        s[k] = e < n_ev ? H.ev_slot[e] : KD_EV_DROPPED;
-        site[k] = e < n_ev ? ins.ev_site[e] : 0u;
+        const kd_u64 j = k0 + (kd_u64)k * KD_BLOCK;
+        const uint32_t e = j < n_ev ? H.sel[j] : 0xffffffffu;
+        s[k] = e != 0xffffffffu ? H.ev_slot[e] : KD_EV_DROPPED;
+        site[k] = e != 0xffffffffu ? ins.ev_site[e] : 0u;
     }
 #pragma unroll
     for (int k = 0; k < KD_INS_PER_THREAD; k++) {
