@@ -121,7 +121,6 @@ enum {
     KDS_BAD_BASE,       // k_window / k_strip: work items that saw a base outside A,C,G,T,N
     KDS_QUEUE0,         // k_strip: heads of the eight work queues (reset by k_plan_scan)
     KDS_QUEUE7 = KDS_QUEUE0 + 7,
-    KDS_N_SEL,          // insertion events on sites where an insertion can be emitted (k_ins_filter)
 #ifdef KD_PHASE_CLOCKS
     KDS_DBG0, KDS_DBG1, KDS_DBG2, KDS_DBG3, KDS_DBG4, KDS_DBG5, KDS_DBG6, KDS_DBG7,   // phase clocks (profiling build only)
 #endif

@@ -51,7 +51,7 @@ struct KdEngine {
     Buf b_stage[9];
     Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
     uint64_t ev_cap = 0, pool_cap = 0;
-    Buf b_hkey, b_hcnt, b_hrep, b_evslot, b_best, b_win, b_flag, b_sel;
+    Buf b_hkey, b_hcnt, b_hrep, b_evslot, b_best, b_win, b_flag;
     uint64_t hash_cap = 0;
     // what the last insertion reduction left behind (k_ins_cleanup undoes it before the event buffers are reused)
     uint64_t ins_dirty_ev = 0;
@@ -143,7 +143,7 @@ struct KdEngine {
 
     void destroy() {
         Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_itemwin, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ckpt, &b_seginfo, &b_ev_site, &b_ev_len,
-                      &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_win, &b_flag, &b_sel, &b_cns, &b_changes,
+                      &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_win, &b_flag, &b_cns, &b_changes,
                       &b_tilesum, &b_tilemm, &b_tileoff, &b_coff};
         for (Buf *b : all) release(*b);
         for (Buf &b : b_stage) release(b);
@@ -207,7 +207,7 @@ struct KdEngine {
         if (!ins_dirty_ev) return KD_OK;
         KdIns I = insdesc();
         if (rt.launch("k_ins_cleanup", k_ins_cleanup, (unsigned)((ins_dirty_ev + KD_INS_CHUNK - 1) / KD_INS_CHUNK), KD_BLOCK, 0, I, ins_dirty_tab,
-                      (kd_u64 *)b_best.p, (uint32_t *)b_win.p))
+                      (kd_u64)ins_dirty_ev, (kd_u64 *)b_best.p, (uint32_t *)b_win.p))
             return hipfail("k_ins_cleanup");
         ins_dirty_ev = 0;
         return KD_OK;
@@ -478,8 +478,8 @@ struct KdEngine {
             // grids are sized by the upper bound n_ev; the kernels stop at the device-side count of selected events
             const unsigned ge = (unsigned)((n_ev + KD_BLOCK - 1) / KD_BLOCK), g4 = (unsigned)((n_ev + KD_INS_CHUNK - 1) / KD_INS_CHUNK);
             if (rt.memset(d_status + KDS_INS_COLLISION, 0, 8)) return hipfail("finalize: memset status");
-            if (rt.launch("k_ins_insert", k_ins_insert, ge, KD_BLOCK, 0, I, H)) return hipfail("k_ins_insert");
-            if (rt.launch("k_ins_verify_max", k_ins_verify_max, g4, KD_BLOCK, 0, I, H, (kd_u64 *)b_best.p, d_status))
+            if (rt.launch("k_ins_insert", k_ins_insert, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev)) return hipfail("k_ins_insert");
+            if (rt.launch("k_ins_verify_max", k_ins_verify_max, g4, KD_BLOCK, 0, I, H, (kd_u64)n_ev, (kd_u64 *)b_best.p, d_status))
                 return hipfail("k_ins_verify_max");
             ins_dirty_ev = n_ev; ins_dirty_tab = H;
             return KD_OK;
@@ -492,18 +492,16 @@ struct KdEngine {
                 if ((rc = ensure(b_hkey, cap * 8)) || (rc = ensure(b_hcnt, cap * 4)) || (rc = ensure(b_hrep, cap * 4))) return rc;
                 if (rt.memset(b_hkey.p, 0, b_hkey.cap) || rt.memset(b_hcnt.p, 0, b_hcnt.cap)) return hipfail("finalize: memset hash");
             }
-            if ((rc = ensure(b_evslot, n_ev * 4)) || (rc = ensure(b_sel, n_ev * 4)) || (rc = ensure(b_flag, (size_t)S + 64))) return rc;
+            if ((rc = ensure(b_evslot, n_ev * 4)) || (rc = ensure(b_flag, (size_t)S + 64))) return rc;
             hash_cap = cap;
             H.key = (kd_u64 *)b_hkey.p; H.cnt = (uint32_t *)b_hcnt.p; H.rep = (uint32_t *)b_hrep.p;
             H.ev_slot = (uint32_t *)b_evslot.p; H.cap = cap; H.sites = S;
-            H.sel = (const uint32_t *)b_sel.p; H.n_sel = d_status + KDS_N_SEL;
             // sites where an insertion can be emitted at all, then the events on those sites
             KdTabs T = tabs();
-            if (rt.memset(d_status + KDS_N_SEL, 0, 8)) return hipfail("finalize: memset status");
             if (rt.launch("k_ins_flag", k_ins_flag, (unsigned)(((alloc_hi - alloc_lo) / 4 + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, T,
                           (kd_u64)alloc_lo, (kd_u64)alloc_hi, (uint8_t *)b_flag.p) ||
                 rt.launch("k_ins_filter", k_ins_filter, (unsigned)((n_ev + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, I, (kd_u64)n_ev,
-                          (const uint8_t *)b_flag.p, (kd_u64)S, (uint32_t *)b_sel.p, d_status + KDS_N_SEL, (uint32_t *)b_evslot.p))
+                          (const uint8_t *)b_flag.p, (kd_u64)S, (uint32_t *)b_evslot.p))
                 return hipfail("k_ins_flag / k_ins_filter");
             if ((rc = reduce(0))) return rc;
             launched = true;
@@ -547,7 +545,7 @@ struct KdEngine {
                 if ((rc = ins_cleanup()) || (rc = reduce(attempt)) || (rc = fetch_status())) return rc;
             }
             const unsigned ge = (unsigned)((n_ev + KD_INS_CHUNK - 1) / KD_INS_CHUNK);
-            if (rt.launch("k_ins_pick", k_ins_pick, ge, KD_BLOCK, 0, I, H, (const kd_u64 *)b_best.p, (uint32_t *)b_win.p))
+            if (rt.launch("k_ins_pick", k_ins_pick, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev, (const kd_u64 *)b_best.p, (uint32_t *)b_win.p))
                 return hipfail("k_ins_pick");
         }
         finalized = true; have_cns = false; have_inskeys = false;

@@ -20,9 +20,9 @@ struct KdInsTab {
     kd_u64 cap;      // power of two
     kd_u64 seed;
     kd_u64 sites;    // G-space sites (bound of a valid event site)
-    const uint32_t *sel;   // the events that take part: those on sites where an insertion can be emitted (k_ins_filter)
-    const kd_u64 *n_sel;   // their number (device word: the host never reads it, grids are sized by the upper bound n_ev)
 };
+// ev_slot[e] before k_ins_insert: KD_EV_TAKE = the event takes part (its site is flagged), KD_EV_DROPPED = it does not
+#define KD_EV_TAKE 0xfffffffeu
 
 // An insertion is emitted at a site only if 2 * ins_total > min(aligned_depth, aligned_depth_next) (kindel.py:411-412, :419);
 // the deletion / min_depth tests before it can only remove sites.  On sequencing data that is a handful of sites, while
@@ -51,23 +51,17 @@ k_ins_flag(KdTabs T, kd_u64 g_first, kd_u64 g_end, uint8_t *flag) {
     }
     *reinterpret_cast<uint32_t *>(flag + g0) = out;
 }
-// events on flagged sites -> sel[0 .. n_sel): one atomic per wavefront (ballot + popcount + prefix by v_mbcnt)
+// events on flagged sites are marked to take part (no compaction: the kernels below run over all events and the others
+// leave after one coalesced 4-byte load; a compacted list needed one atomic per wavefront on one counter, 0.5 ms on C4)
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_filter(KdIns ins, kd_u64 n_ev, const uint8_t *flag, kd_u64 sites, uint32_t *sel, kd_u64 *n_sel, uint32_t *ev_slot) {
+k_ins_filter(KdIns ins, kd_u64 n_ev, const uint8_t *flag, kd_u64 sites, uint32_t *ev_slot) {
     const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    bool take = false;
-    if (e < n_ev) {
-        const uint32_t site = ins.ev_site[e];
-        // a reserved slot that was never written (its read raised a reference exception half way: the batch is rejected by
-        // kd_finalize anyway) holds stale data: keep it out unless it is at least in bounds
-        take = site != KD_EV_DROPPED && site < sites && ins.ev_off[e] + ins.ev_len[e] <= ins.pool_cap && flag[site];
-        if (!take) ev_slot[e] = KD_EV_DROPPED;
-    }
-    const kd_u64 m = kd_ballot(take);
-    kd_u64 base = 0;
-    if (m && kd_lane_id() == 0) base = atomicAdd(n_sel, (kd_u64)kd_popcll(m));
-    base = kd_readfirstlane64(base);
-    if (take) sel[base + kd_mbcnt(m)] = (uint32_t)e;
+    if (e >= n_ev) return;
+    const uint32_t site = ins.ev_site[e];
+    // a reserved slot that was never written (its read raised a reference exception half way: the batch is rejected by
+    // kd_finalize anyway) holds stale data: keep it out unless it is at least in bounds
+    const bool take = site != KD_EV_DROPPED && site < sites && ins.ev_off[e] + ins.ev_len[e] <= ins.pool_cap && flag[site];
+    ev_slot[e] = take ? KD_EV_TAKE : KD_EV_DROPPED;
 }
 
 __device__ __forceinline__ kd_u64 kd_mix64(kd_u64 x) {
@@ -76,10 +70,9 @@ __device__ __forceinline__ kd_u64 kd_mix64(kd_u64 x) {
 }
 
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_insert(KdIns ins, KdInsTab H) {
-    const kd_u64 k = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (k >= *H.n_sel) return;
-    const kd_u64 e = H.sel[k];
+k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev) {
+    const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (e >= n_ev || H.ev_slot[e] != KD_EV_TAKE) return;
     const uint32_t site = ins.ev_site[e], len = ins.ev_len[e];
     const uint8_t *p = ins.pool + ins.ev_off[e];
     kd_u64 h = kd_mix64(H.seed ^ ((kd_u64)site << 32 | len));
@@ -110,11 +103,11 @@ k_ins_insert(KdIns ins, KdInsTab H) {
 // are final).  The representative itself nominates its slot for its site: best[site] = max over the site's slots of
 // (count << 32 | slot).  Per EVENT: nothing here is proportional to the table capacity or to the sites.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_verify_max(KdIns ins, KdInsTab H, kd_u64 *best, kd_u64 *status) {
-    const kd_u64 k0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x, n_ev = *H.n_sel;
+k_ins_verify_max(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, kd_u64 *status) {
+    const kd_u64 k0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x;
     uint32_t ev[KD_INS_PER_THREAD], s[KD_INS_PER_THREAD], r[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD], cnt[KD_INS_PER_THREAD];
 #pragma unroll
-    for (int k = 0; k < KD_INS_PER_THREAD; k++) { const kd_u64 j = k0 + (kd_u64)k * KD_BLOCK; ev[k] = j < n_ev ? H.sel[j] : 0xffffffffu; }
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) { const kd_u64 j = k0 + (kd_u64)k * KD_BLOCK; ev[k] = j < n_ev ? (uint32_t)j : 0xffffffffu; }
 #pragma unroll
     for (int k = 0; k < KD_INS_PER_THREAD; k++) s[k] = ev[k] != 0xffffffffu ? H.ev_slot[ev[k]] : KD_EV_DROPPED;
 #pragma unroll
@@ -140,12 +133,12 @@ k_ins_verify_max(KdIns ins, KdInsTab H, kd_u64 *best, kd_u64 *status) {
 // the best slot of a site nominates its representative event; any OTHER slot of the site with the same count makes it
 // a tie (kindel.py:377, :421).  Only representatives act.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_pick(KdIns ins, KdInsTab H, const kd_u64 *best, uint32_t *win) {
-    const kd_u64 k0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x, n_ev = *H.n_sel;
+k_ins_pick(KdIns ins, KdInsTab H, kd_u64 n_ev, const kd_u64 *best, uint32_t *win) {
+    const kd_u64 k0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x;
     uint32_t ev[KD_INS_PER_THREAD], s[KD_INS_PER_THREAD], r[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD], cnt[KD_INS_PER_THREAD];
     kd_u64 b[KD_INS_PER_THREAD];
 #pragma unroll
-    for (int k = 0; k < KD_INS_PER_THREAD; k++) { const kd_u64 j = k0 + (kd_u64)k * KD_BLOCK; ev[k] = j < n_ev ? H.sel[j] : 0xffffffffu; }
+    for (int k = 0; k < KD_INS_PER_THREAD; k++) { const kd_u64 j = k0 + (kd_u64)k * KD_BLOCK; ev[k] = j < n_ev ? (uint32_t)j : 0xffffffffu; }
 #pragma unroll
     for (int k = 0; k < KD_INS_PER_THREAD; k++) s[k] = ev[k] != 0xffffffffu ? H.ev_slot[ev[k]] : KD_EV_DROPPED;
 #pragma unroll
@@ -170,13 +163,13 @@ k_ins_pick(KdIns ins, KdInsTab H, const kd_u64 *best, uint32_t *win) {
 // undo what the events of the last reduction left in the hash table and in best[] / win[] (all of them are zero between
 // reductions: no capacity- or site-proportional memset per kd_finalize)
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_cleanup(KdIns ins, KdInsTab H, kd_u64 *best, uint32_t *win) {
-    const kd_u64 k0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x, n_ev = *H.n_sel;
+k_ins_cleanup(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, uint32_t *win) {
+    const kd_u64 k0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x;
     uint32_t s[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < KD_INS_PER_THREAD; k++) {
         const kd_u64 j = k0 + (kd_u64)k * KD_BLOCK;
-        const uint32_t e = j < n_ev ? H.sel[j] : 0xffffffffu;
+        const uint32_t e = j < n_ev ? (uint32_t)j : 0xffffffffu;
         s[k] = e != 0xffffffffu ? H.ev_slot[e] : KD_EV_DROPPED;
         site[k] = e != 0xffffffffu ? ins.ev_site[e] : 0u;
     }
