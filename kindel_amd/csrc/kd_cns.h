@@ -107,13 +107,25 @@ k_cns_count(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, kd_u64 *tile_sum, K
     const uint32_t cfirst = tile0 < T.sites ? C.seg_contig[tile0 >> 6] : 0;
     KdSite s[KD_CNS_PER_THREAD];
     kd_cns_load_eval(T, C, ins, g0, s);
+    // a thread's 4 sites lie in one 64-site segment = one contig; 16 consecutive lanes share the segment
     uint32_t sum = 0, mn = 0xffffffffu, mx = 0;
     for (int k = 0; k < KD_CNS_PER_THREAD; k++) {
         sum += s[k].ins_len + s[k].has_base;
-        if (s[k].live) {
-            const uint32_t c = C.seg_contig[(g0 + k) >> 6];
-            if (c == cfirst) { mn = s[k].depth < mn ? s[k].depth : mn; mx = s[k].depth > mx ? s[k].depth : mx; }
-            else { atomicMin(&depth_minmax[2 * c], s[k].depth); atomicMax(&depth_minmax[2 * c + 1], s[k].depth); }
+        if (s[k].live) { mn = s[k].depth < mn ? s[k].depth : mn; mx = s[k].depth > mx ? s[k].depth : mx; }
+    }
+    const uint32_t cseg = g0 < T.sites ? C.seg_contig[g0 >> 6] : cfirst;
+    if (kd_ballot(cseg != cfirst) != 0) {
+        // the tile crosses into other contigs: their segments are reduced over their 16 lanes and go to the contig's words
+        // directly (a few atomics per contig boundary); the lanes of the tile's first contig continue below
+        uint32_t smn = mn, smx = mx;
+#pragma unroll
+        for (uint32_t m = 1; m < 16; m <<= 1) {
+            const uint32_t a = kd_shfl_xor(smn, m), b = kd_shfl_xor(smx, m);
+            smn = a < smn ? a : smn; smx = b > smx ? b : smx;
+        }
+        if (cseg != cfirst) {
+            if ((lane & 15u) == 0 && smn != 0xffffffffu) { atomicMin(&depth_minmax[2 * cseg], smn); atomicMax(&depth_minmax[2 * cseg + 1], smx); }
+            mn = 0xffffffffu; mx = 0;
         }
     }
     // wavefront reductions by shuffles, then the four wavefronts through LDS

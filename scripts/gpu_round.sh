@@ -6,6 +6,10 @@ echo "== pytest gpu"; timeout 1200 python -m pytest tests -m gpu -q --maxfail=8 
 echo "== bench C3"; timeout 900 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err; echo "bench rc=$?"
 echo "== rocprof stats"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python $R/bench.py --no-cpu-baseline > $O/prof_c3_bench.json 2> $O/prof_c3.err); echo "rc=$?"
 bash scripts/gpu_pmc.sh > $O/pmc_summary.txt 2>&1; grep -E "^[1-4] k_(window|prep|cold)" $O/pmc_summary.txt
+echo "== strip mode / shuffled"; bash scripts/gpu_r2.sh lib:none > /dev/null 2>&1; for m in strip; do timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --mode $m > $O/exp_$m.json 2> $O/exp_$m.err; done; timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --shuffle > $O/exp_shuf.json 2> $O/exp_shuf.err
+echo "== e2e full C3"; timeout 900 python scripts/e2e_bench.py --scale 1.0 --repeat 3 --out $O/e2e_c3_full.json > /dev/null 2> $O/e2e.err; tail -c 600 $O/e2e_c3_full.json
+echo "== multirank (gloo, one GPU)"; bash scripts/gpu_multirank.sh 2>&1 | tail -12
+echo "== FETCH_SIZE calibration"; bash scripts/gpu_calib.sh 2>&1 | tail -6
 for c in ${CONFIGS:-C2 C4 C5}; do timeout 600 python bench.py --config $c --steps 3 --warmup 1 > $O/bench_$c.json 2> $O/bench_$c.err; done
 python - <<PY
 import json

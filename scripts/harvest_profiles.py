@@ -38,7 +38,8 @@ if st:
         for r in rows[:1] + [r for r in rows[1:] if r and r[0].startswith("k_")]:
             w.writerow([r[0].split("(")[0]] + r[1:])
 for src, dst in (("bench_c3.json", "%s_c3_bench.json"), ("prof_c3_bench.json", "%s_c3_bench_under_rocprof.json"),
-                 ("bench_C2.json", "%s_C2_bench.json"), ("bench_C4.json", "%s_C4_bench.json"), ("bench_C5.json", "%s_C5_bench.json")):
+                 ("bench_C2.json", "%s_C2_bench.json"), ("bench_C4.json", "%s_C4_bench.json"), ("bench_C5.json", "%s_C5_bench.json"),
+                 ("exp_strip.json", "%s_c3_bench_mode_strip.json"), ("exp_shuf.json", "%s_c3_bench_shuffled.json")):
     p = os.path.join(O, src)
     if os.path.exists(p):
         json.dump(first_json_line(p), open(os.path.join(P, dst % tag), "w"), indent=1, sort_keys=True)
@@ -58,10 +59,28 @@ for i in (1, 2, 3, 4):
 per = {k: {c: v / max(len(ndisp[(k, c)]), 1) for c, v in cs.items()} for k, cs in acc.items()}
 if per:
     json.dump(per, open(os.path.join(P, "%s_c3_pmc_per_dispatch.json" % tag), "w"), indent=1, sort_keys=True)
-    note = ("(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch: gfx950 FETCH_SIZE halving correction of MI355X_MICROARCH.md applied; "
-            "raw_bytes = uncorrected")
+    note = ("(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch.  The factors are calibrated on this GPU in the kernels' own access patterns "
+            "(profiles/fetch_calibration.json, scripts/fetch_calib.hip: a 2 GiB buffer touched exactly once): FETCH_SIZE counts half "
+            "the bytes (x2.00 for coalesced 8- and 16-byte streams; k_window's per-lane unaligned 16-byte loads over 75-byte records "
+            "fetch 1.30x their unique bytes, which this figure includes as real traffic), WRITE_SIZE x1.00 for stores and for atomics "
+            "(whose read half is not counted).  raw_bytes = (FETCH_SIZE + WRITE_SIZE)*1024, uncorrected")
     traffic = {k: dict(bytes=int((2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024),
                        raw_bytes=int((c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024), note=note)
                for k, c in per.items() if "FETCH_SIZE" in c}
     json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+for src, dst in (("e2e_c3_full.json", "e2e_c3_full.json"), ("fetch_calibration.json", "fetch_calibration.json"),
+                 ("e2e_sweep.txt", "%s_e2e_thread_chunk_sweep.txt" % tag)):
+    p = os.path.join(O, src)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(P, dst))
+mr = {}
+for f in sorted(glob.glob(os.path.join(O, "multirank_*.clean.json"))):
+    d = json.load(open(f))
+    mr[os.path.basename(f)[len("multirank_"):-len(".clean.json")]] = {k: d.get(k) for k in (
+        "n_gpus", "scaling", "value", "ms_per_step", "fasta_sha256", "config", "other_scaling")}
+if mr:
+    mr["_note"] = ("bench.py --gpus N with N ranks SHARING the one GPU of the box over gloo: exercises sharded synthesis / routed reads, kd_set_shard "
+                   "with shard-local tables and the one fixed-size all-gather; NOT a scaling measurement.  The strong-scaling FASTA must equal the "
+                   "single-GPU FASTA of the same config (checked by scripts/gpu_multirank.sh).")
+    json.dump(mr, open(os.path.join(P, "%s_multirank_gloo_one_gpu.json" % tag), "w"), indent=1, sort_keys=True)
 print("profiles/ refreshed with tag", tag, "from", O)
