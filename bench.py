@@ -301,7 +301,7 @@ def main():
                 d = json.loads(open(e2e).read().strip().splitlines()[-1])
                 out["e2e"] = dict(source="profiles/e2e_c3_full.json: STATIC, measured by scripts/e2e_bench.py on an MI355X box, not in this run",
                                   events_per_s=d["streamed_events_per_s"], seconds=d["streamed"]["total_s"], bam_bytes=d["bam_bytes"],
-                                  decode_threads=d["decode_threads"], host_cores_cgroup_quota=d.get("host_cores_cgroup_quota"),
+                                  decode_threads=d["decode_threads"], host_cpu_quota=d.get("host_cpu_quota"),
                                   whole_file_events_per_s=d["whole_file_events_per_s"])
             except Exception:
                 pass
@@ -314,6 +314,15 @@ def main():
 _PMC_SOURCE = ("profiles/pmc_traffic.json: STATIC, not measured in this run -- (FETCH_SIZE x k + WRITE_SIZE) x 1024 per launch from "
                "the committed `rocprofv3 --pmc` passes of the same command (scripts/gpu_pmc.sh), k = the FETCH_SIZE factor "
                "calibrated on this access pattern (profiles/fetch_calibration.json)")
+
+
+def _cpu_quota():
+    """CPUs the cgroup grants per scheduling period (None = no limit): the GPU boxes show 256 cores and grant 16."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except Exception:
+        return None
 
 
 def _pmc_traffic(kernel):
@@ -369,7 +378,7 @@ def cpu_baseline(batch, contig_lens, gpu_seqs, sample, aligned_total):
             same = same and (seq.encode() == gpu_seqs[cid])
     dt = time.perf_counter() - t0
     from kindel_amd import _native as _N
-    return dict(value=ev / dt, unit="events/s", cores=1, kind="port", host_cores=os.cpu_count(), host_cores_cgroup_quota=_N.host_threads(),
+    return dict(value=ev / dt, unit="events/s", cores=1, kind="port", host_cores=os.cpu_count(), host_cpu_quota=_cpu_quota(), decoder_threads_default=_N.host_threads(),
                 sample="%s of the %d reads (%d aligned-base events), all contigs, pileup + consensus; %.1f s" % (
                     "all" if frac >= 1.0 else "every %d-th" % int(round(1.0 / frac)), n, ev, dt),
                 bit_exact_vs_gpu=(same if frac >= 1.0 else None),

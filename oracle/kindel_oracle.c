@@ -11,9 +11,11 @@
  * sequential CIGAR loop, one increment per base) -- including Python's negative-index
  * wrap-around on lists and the exception the reference would raise -- so that it can act
  * as the checker for the HIP kernels at sizes where the Python reference is too slow.
- * PARITY IS PINNED: tests/test_oracle_vs_reference.py runs this file and the unmodified
- * reference side by side on every reference fixture (in the build container) and
- * tests/golden/ holds digests of the reference's own outputs for the GPU box.
+ * PARITY IS PINNED: oracle/make_golden.py runs this file and the UNMODIFIED reference side by side (in the
+ * build container) on every reference fixture and on the quirk cases of oracle/quirk_cases.py and asserts
+ * equality of every table, insertion dict, consensus string and exception type; tests/golden/ holds the
+ * reference's own outputs (tests/test_oracle_golden.py re-checks this file against them on any box), and
+ * oracle/refbaseline.py compares the consensus again on the sample it times the reference on.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  */

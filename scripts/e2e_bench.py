@@ -21,6 +21,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kindel_amd import _native as N, kindel as K, synth  # noqa: E402
 
 
+def _quota():
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except Exception:
+        return None
+
+
 def fasta_of(pl):
     done = K._device_consensus_all(pl, {c: None for c in pl.order}, False, 1, False)
     return "".join(">%s_cns\n%s\n" % (pl.names[c], done[c][0]) for c in pl.order).encode()
@@ -85,7 +93,7 @@ def main():
     assert bw[1] == bs[1], "streamed and whole-file FASTA differ"
     line = {
         "what": "end-to-end BAM path -> FASTA bytes (SURVEY 8d ii)", "config": a.config, "scale": a.scale, "reads": n_reads,
-        "aligned_events": ev, "bam_bytes": size, "host_cores_visible": os.cpu_count(), "host_cores_cgroup_quota": N.host_threads(), "decode_threads": a.threads or N.host_threads(),
+        "aligned_events": ev, "bam_bytes": size, "host_cores_visible": os.cpu_count(), "host_cpu_quota": _quota(), "decode_threads": a.threads or N.host_threads(),
         "best_of": a.repeat, "chunk_mb": a.chunk_mb, "fasta_bytes": len(bw[1]), "same_fasta": True,
         "whole_file": {k: round(v, 4) for k, v in bw[0].items()}, "whole_file_events_per_s": ev / bw[0]["total_s"],
         "streamed": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in bs[0].items()},
