@@ -176,6 +176,16 @@ struct KdCkpt {
     uint32_t pool;    // insertion bases of the read before the run
 };
 
+// What k_prep_long learned about one long read (one workgroup each): summed into the status words and turned into event /
+// pool / irregular-list slots by ONE small kernel (k_long_reduce) instead of ten same-address atomics per workgroup.
+struct KdLongAcc {
+    kd_u64 aligned, walked, insb;
+    uint32_t n_ins;
+    uint32_t lead;      // leading-clip reach of a regular read
+    uint32_t maxseg;    // longest segment span
+    uint32_t regular;   // 1: stays class LONG, 0: irregular (goes to irreg_list)
+};
+
 struct KdIns {
     uint32_t *ev_site;  // [ev_cap] G-space site
     uint32_t *ev_len;   // [ev_cap] bases
@@ -250,6 +260,25 @@ __device__ __forceinline__ void kd_block_scan2(TA *sa, TB *sb, TA *ga, TB *gb, T
     __syncthreads();   // the scratch arrays may be reused by the caller
 }
 
+// Runs of neighbouring lanes aiming at the SAME key (reads sorted by position meeting at one deep site: ten thousand
+// atomics on one address take 0.1 ms however idle the rest of the GPU is).  The first lane of each run acts for all of
+// them: returns the number of lanes in this lane's run if it is the run's head, 0 otherwise; head_lane = the lane that
+// acts for this lane.  Every lane of the wavefront must call (wave-level exchange inside).
+__device__ __forceinline__ uint32_t kd_run_heads(bool valid, kd_u64 key, uint32_t &head_lane) {
+    const uint32_t lane = kd_lane_id();
+    const kd_u64 amask = kd_ballot(valid);
+    const kd_u64 below = amask & ((1ULL << lane) - 1ULL);
+    const uint32_t prev = below ? 63u - (uint32_t)__builtin_clzll(below) : lane;
+    const kd_u64 kp = kd_shfl64(key, prev);
+    const bool head = valid && (!below || kp != key);
+    const kd_u64 hmask = kd_ballot(head);
+    const kd_u64 upto = hmask & ((2ULL << lane) - 1ULL);       // heads at or below this lane
+    head_lane = upto ? 63u - (uint32_t)__builtin_clzll(upto) : lane;
+    if (!head) return 0;
+    const kd_u64 above = hmask & ~((2ULL << lane) - 1ULL);     // the next run's head, if any
+    const kd_u64 range = above ? (1ULL << __builtin_ctzll(above)) - 1ULL : ~0ULL;
+    return (uint32_t)kd_popcll(amask & range & ~((1ULL << lane) - 1ULL));
+}
 // Inclusive scan of one 64-bit value per thread over the 256-thread workgroup: six __shfl_up steps inside each wavefront,
 // the four wavefront totals through LDS (two barriers instead of the sixteen of a Hillis-Steele scan in LDS).
 // s_wave: [KD_WAVES_PER_BLOCK] scratch.  Returns the inclusive prefix; total = sum over the workgroup.

@@ -47,7 +47,7 @@ struct KdEngine {
         void *p = nullptr;
         size_t cap = 0;
     };
-    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_ckpt, b_seginfo;
+    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_ckpt, b_seginfo, b_longacc;
     Buf b_stage[9];
     Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
     uint64_t ev_cap = 0, pool_cap = 0;
@@ -142,7 +142,7 @@ struct KdEngine {
     }
 
     void destroy() {
-        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_itemwin, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ckpt, &b_seginfo, &b_ev_site, &b_ev_len,
+        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_itemwin, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ckpt, &b_seginfo, &b_longacc, &b_ev_site, &b_ev_len,
                       &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_win, &b_flag, &b_cns, &b_changes,
                       &b_tilesum, &b_tilemm, &b_tileoff, &b_coff};
         for (Buf *b : all) release(*b);
@@ -253,10 +253,13 @@ struct KdEngine {
             if ((rc = ensure(b_ckpt, (size_t)n_long * KD_BLOCK * sizeof(KdCkpt))) ||
                 (rc = ensure(b_seginfo, (size_t)n_long * KD_BLOCK * sizeof(KdRInfo))))
                 return rc;
+            if ((rc = ensure(b_longacc, (size_t)n_long * sizeof(KdLongAcc)))) return rc;
             if (rt.launch("k_prep_long", k_prep_long, (unsigned)n_long, KD_BLOCK, 0, R, T, rinfo,
-                          (const uint32_t *)lng, (KdCkpt *)b_ckpt.p, (KdRInfo *)b_seginfo.p, irreg, (uint32_t *)b_readev.p,
-                          (kd_u64 *)b_readpool.p, d_status))
+                          (const uint32_t *)lng, (KdCkpt *)b_ckpt.p, (KdRInfo *)b_seginfo.p, (KdLongAcc *)b_longacc.p))
                 return hipfail("k_prep_long");
+            if (rt.launch("k_long_reduce", k_long_reduce, (unsigned)((n_long + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, (const KdLongAcc *)b_longacc.p,
+                          (const uint32_t *)lng, (uint32_t)n_long, irreg, (uint32_t *)b_readev.p, (kd_u64 *)b_readpool.p, d_status))
+                return hipfail("k_long_reduce");
             if ((rc = fetch_status())) return rc;
         }
         // size the insertion event buffers from the exact counts of this batch

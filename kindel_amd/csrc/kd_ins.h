@@ -69,29 +69,40 @@ __device__ __forceinline__ kd_u64 kd_mix64(kd_u64 x) {
     return x;
 }
 
+// (events of one deep site sit next to each other in event order and carry the same insertion: neighbouring lanes with
+//  the same 64-bit key probe once and add their number, kd_run_heads)
 __global__ void __launch_bounds__(KD_BLOCK)
 k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev) {
     const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (e >= n_ev || H.ev_slot[e] != KD_EV_TAKE) return;
-    const uint32_t site = ins.ev_site[e], len = ins.ev_len[e];
-    const uint8_t *p = ins.pool + ins.ev_off[e];
-    kd_u64 h = kd_mix64(H.seed ^ ((kd_u64)site << 32 | len));
-    for (uint32_t b = 0; b < len; b++) h = (h ^ p[b]) * 0x100000001b3ULL;
-    h = kd_mix64(h) | 1ULL;
-    kd_u64 s = (h >> 1) & (H.cap - 1);
-    for (;;) {
-        kd_u64 cur = H.key[s];
-        if (cur == 0) {
-            cur = atomicCAS(&H.key[s], 0ULL, h);
-            // the event that claims the slot is its representative (any member would do: k_ins_verify proves all
-            // members byte-identical); a plain store instead of one more scattered atomic per event
-            if (cur == 0) { H.rep[s] = (uint32_t)e; break; }
-        }
-        if (cur == h) break;
-        s = (s + 1) & (H.cap - 1);
+    const bool take = e < n_ev && H.ev_slot[e] == KD_EV_TAKE;
+    kd_u64 h = 0;
+    if (take) {
+        const uint32_t site = ins.ev_site[e], len = ins.ev_len[e];
+        const uint8_t *p = ins.pool + ins.ev_off[e];
+        h = kd_mix64(H.seed ^ ((kd_u64)site << 32 | len));
+        for (uint32_t b = 0; b < len; b++) h = (h ^ p[b]) * 0x100000001b3ULL;
+        h = kd_mix64(h) | 1ULL;
     }
-    atomicAdd(&H.cnt[s], 1u);
-    H.ev_slot[e] = (uint32_t)s;
+    uint32_t head_lane;
+    const uint32_t run = kd_run_heads(take, h, head_lane);
+    kd_u64 s = 0;
+    if (run) {
+        s = (h >> 1) & (H.cap - 1);
+        for (;;) {
+            kd_u64 cur = H.key[s];
+            if (cur == 0) {
+                cur = atomicCAS(&H.key[s], 0ULL, h);
+                // the event that claims the slot is its representative (any member would do: k_ins_verify proves all
+                // members byte-identical); a plain store instead of one more scattered atomic per event
+                if (cur == 0) { H.rep[s] = (uint32_t)e; break; }
+            }
+            if (cur == h) break;
+            s = (s + 1) & (H.cap - 1);
+        }
+        atomicAdd(&H.cnt[s], run);
+    }
+    s = kd_shfl64(s, head_lane);
+    if (take) H.ev_slot[e] = (uint32_t)s;
 }
 
 // The three kernels below are chains of dependent scattered loads (event -> slot -> representative -> site -> counter):

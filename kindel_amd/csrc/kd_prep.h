@@ -12,6 +12,9 @@
 #define KD_PREP_PER_THREAD 32
 #endif
 #define KD_PREP_CHUNK (KD_BLOCK * KD_PREP_PER_THREAD)
+#ifndef KD_PREP_UNROLL
+#define KD_PREP_UNROLL 4   // reads whose loads are issued together (a divisor of KD_PREP_PER_THREAD)
+#endif
 #define KD_PREP_MAX_OPS 16
 
 // result of scanning one CIGAR
@@ -93,13 +96,13 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
     kd_u64 cb_cached = 0;
     int64_t L_cached = 0;
     // 4 reads per step: all of their metadata loads are issued before any is consumed
-    for (int it0 = 0; it0 < KD_PREP_PER_THREAD; it0 += 4) {
-        uint32_t v_c[4], v_pc[4], v_nc[4], v_fl[4];
-        int64_t v_pos[4], v_ppos[4], v_sl[4];
-        kd_u64 v_coff[4];
-        bool v_ok[4];
+    for (int it0 = 0; it0 < KD_PREP_PER_THREAD; it0 += KD_PREP_UNROLL) {
+        uint32_t v_c[KD_PREP_UNROLL], v_pc[KD_PREP_UNROLL], v_nc[KD_PREP_UNROLL], v_fl[KD_PREP_UNROLL];
+        int64_t v_pos[KD_PREP_UNROLL], v_ppos[KD_PREP_UNROLL], v_sl[KD_PREP_UNROLL];
+        kd_u64 v_coff[KD_PREP_UNROLL];
+        bool v_ok[KD_PREP_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < KD_PREP_UNROLL; u++) {
             const kd_u64 i = chunk0 + (kd_u64)(it0 + u) * KD_BLOCK + t;
             v_ok[u] = i < rd.n;
             const kd_u64 j = v_ok[u] ? i : 0, jp = (v_ok[u] && i > 0) ? i - 1 : j;
@@ -108,16 +111,16 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
             v_sl[u] = rd.seq_len[j]; v_nc[u] = rd.n_cig[j]; v_fl[u] = rd.flag[j]; v_coff[u] = rd.cig_off[j];
         }
         // second level: the first 4 CIGAR words of each of the 4 reads, again all in flight together
-        uint32_t v_cw[4][4];
+        uint32_t v_cw[KD_PREP_UNROLL][4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < KD_PREP_UNROLL; u++) {
             const uint32_t *cgp = rd.cigar + v_coff[u];
             const uint32_t ncu = v_ok[u] ? v_nc[u] : 0u;
 #pragma unroll
             for (int k = 0; k < 4; k++) v_cw[u][k] = (uint32_t)k < ncu ? cgp[k] : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < KD_PREP_UNROLL; u++) {
             if (!v_ok[u]) continue;
             const int it = it0 + u;
             const kd_u64 i = chunk0 + (kd_u64)it * KD_BLOCK + t;
@@ -233,7 +236,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
 // second sweep applies the same regularity rules as kd_scan_cigar.
 __global__ void __launch_bounds__(KD_BLOCK)
 k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdCkpt *ckpt, KdRInfo *seginfo,
-            uint32_t *irreg_list, uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
+            KdLongAcc *long_acc) {
     __shared__ int64_t s_r[KD_BLOCK], s_q[KD_BLOCK], s_gr[KD_BLOCK / KD_SCAN_SEG], s_gq[KD_BLOCK / KD_SCAN_SEG];
     __shared__ uint32_t s_ni[KD_BLOCK], s_nb[KD_BLOCK], s_gni[KD_BLOCK / KD_SCAN_SEG], s_gnb[KD_BLOCK / KD_SCAN_SEG];
     __shared__ kd_u64 s_acc[6];       // aligned, walked, n_ins, ins_bases, bad, cold
@@ -341,21 +344,8 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdC
         ri.pad = regular ? blockIdx.x + 1u : 0u;
         rinfo[i] = ri;
         s_regular = regular ? 1u : 0u; s_lead = ri.lead; s_gstart = ri.gstart;
-        if (s_acc[2]) {
-            read_ev[i] = (uint32_t)atomicAdd(&status[KDS_N_EV], s_acc[2]);
-            read_pool[i] = atomicAdd(&status[KDS_POOL], s_acc[3]);
-        }
-        atomicAdd(&status[KDS_ST_ALIGNED], s_acc[0]);
-        atomicAdd(&status[KDS_ST_WALKED], s_acc[1]);
-        if (s_acc[2]) { atomicAdd(&status[KDS_ST_INS], s_acc[2]); atomicAdd(&status[KDS_B_INS_OPS], s_acc[2]); }
-        if (s_acc[3]) atomicAdd(&status[KDS_B_INS_BASES], s_acc[3]);
-        if (regular) {
-            atomicAdd(&status[KDS_B_N_REG], 1ULL);
-            if (lead) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)lead);
-            // (its S / I side effects are done by k_cold_long, 256 threads per read)
-        } else {
-            irreg_list[atomicAdd(&status[KDS_B_N_IRREG], 1ULL)] = (uint32_t)i;
-        }
+        // (its S / I side effects are done by k_cold_long, 256 threads per read; its statistics and its event / pool /
+        //  irregular-list slots by k_long_reduce)
     }
     __syncthreads();
     // SEGMENTS: this thread's run of ops [k0, k1) as a work unit of its own -- where it starts on the reference
@@ -379,5 +369,55 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdC
         seginfo[(kd_u64)blockIdx.x * KD_BLOCK + t] = v;
     }
     __syncthreads();
-    if (t == 0 && s_maxseg) atomicMax(&status[KDS_B_MAXSEGSPAN], (kd_u64)s_maxseg);
+    if (t == 0) {
+        KdLongAcc a;
+        a.aligned = s_acc[0]; a.walked = s_acc[1]; a.insb = s_acc[3]; a.n_ins = (uint32_t)s_acc[2];
+        a.lead = s_lead; a.maxseg = s_maxseg; a.regular = s_regular;
+        long_acc[blockIdx.x] = a;
+    }
+}
+
+// k_long_reduce: one thread per long read.  Sums k_prep_long's per-read records into the status words and hands every long
+// read its insertion-event slots, its pool range and (irregular ones) its place in irreg_list: three block scans give the
+// offsets inside the workgroup, three returning atomics per WORKGROUP reserve its ranges (slot order is free).
+__global__ void __launch_bounds__(KD_BLOCK)
+k_long_reduce(const KdLongAcc *long_acc, const uint32_t *long_list, uint32_t n_long, uint32_t *irreg_list,
+              uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
+    __shared__ kd_u64 s_wave[KD_WAVES_PER_BLOCK], s_base[3], s_sum[3];
+    __shared__ uint32_t s_mx[2];
+    const uint32_t t = threadIdx.x;
+    const uint32_t b = blockIdx.x * KD_BLOCK + t;
+    if (t < 3) s_sum[t] = 0;
+    if (t < 2) s_mx[t] = 0;
+    __syncthreads();
+    KdLongAcc a;
+    a.aligned = a.walked = a.insb = 0; a.n_ins = a.lead = a.maxseg = 0; a.regular = 1;
+    const bool live = b < n_long;
+    if (live) a = long_acc[b];
+    const kd_u64 n_irreg = live && !a.regular ? 1 : 0;
+    kd_u64 tot_ev, tot_pool, tot_irreg;
+    const kd_u64 o_ev = kd_block_scan_incl(a.n_ins, s_wave, tot_ev) - a.n_ins;
+    const kd_u64 o_pool = kd_block_scan_incl(a.insb, s_wave, tot_pool) - a.insb;
+    const kd_u64 o_irreg = kd_block_scan_incl(n_irreg, s_wave, tot_irreg) - n_irreg;
+    if (a.aligned) atomicAdd(&s_sum[0], a.aligned);
+    if (a.walked) atomicAdd(&s_sum[1], a.walked);
+    if (live && a.regular) { atomicAdd(&s_sum[2], 1ULL); if (a.lead) atomicMax(&s_mx[0], a.lead); }
+    if (a.maxseg) atomicMax(&s_mx[1], a.maxseg);
+    __syncthreads();
+    if (t == 0) s_base[0] = tot_ev ? atomicAdd(&status[KDS_N_EV], tot_ev) : 0;
+    if (t == 1) s_base[1] = tot_pool ? atomicAdd(&status[KDS_POOL], tot_pool) : 0;
+    if (t == 2) s_base[2] = tot_irreg ? atomicAdd(&status[KDS_B_N_IRREG], tot_irreg) : 0;
+    if (t == 3 && s_sum[0]) atomicAdd(&status[KDS_ST_ALIGNED], s_sum[0]);
+    if (t == 4 && s_sum[1]) atomicAdd(&status[KDS_ST_WALKED], s_sum[1]);
+    if (t == 5 && tot_ev) { atomicAdd(&status[KDS_ST_INS], tot_ev); atomicAdd(&status[KDS_B_INS_OPS], tot_ev); }
+    if (t == 6 && tot_pool) atomicAdd(&status[KDS_B_INS_BASES], tot_pool);
+    if (t == 7 && s_sum[2]) atomicAdd(&status[KDS_B_N_REG], s_sum[2]);
+    if (t == 8 && s_mx[0]) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)s_mx[0]);
+    if (t == 9 && s_mx[1]) atomicMax(&status[KDS_B_MAXSEGSPAN], (kd_u64)s_mx[1]);
+    __syncthreads();
+    if (live) {
+        const uint32_t i = long_list[b];
+        if (a.n_ins) { read_ev[i] = (uint32_t)(s_base[0] + o_ev); read_pool[i] = s_base[1] + o_pool; }
+        if (!a.regular) irreg_list[s_base[2] + o_irreg] = i;
+    }
 }

@@ -141,10 +141,10 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
 __global__ void __launch_bounds__(KD_BLOCK)
 k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list, kd_u64 *status) {
     const kd_u64 slot = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (slot >= n_list) return;
-    const kd_u64 i = list[slot];
+    const bool live = slot < n_list;              // (no early exit: the wavefront meets again behind the walk)
+    const kd_u64 i = list[live ? slot : 0];
     const int64_t sl = rd.seq_len[i];
-    const uint32_t nc = rd.n_cig[i];
+    const uint32_t nc = live ? rd.n_cig[i] : 0u;
     const uint32_t c = rd.contig[i];
     const int64_t L = T.contig_len[c];
     const kd_u64 cb = T.contig_base[c];
@@ -157,6 +157,10 @@ k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list
     // pool slots): the kernel is a chain of dependent round trips otherwise
     const KdChunk pre = kd_load_cigar4(cg, 0u, nc);
     kd_u64 ev_next = ins.read_ev[i], pool_next = ins.read_pool[i];   // (garbage for a read without insertions: unused)
+    // the counters this read bumps -- its clip_ends site, its clip_starts site, the site of its first insertion -- are
+    // committed behind the walk, where neighbouring lanes (reads sorted by position) aiming at the same site add once
+    const kd_u64 NONE = ~0ULL;
+    kd_u64 g_ce = NONE, g_cs = NONE, g_in = NONE;
     for (uint32_t k = 0; k < nc; k++) {
         const uint32_t w = k == 0 ? pre.x : k == 1 ? pre.y : k == 2 ? pre.z : k == 3 ? pre.w : cg[k];
         const int64_t len = w >> 4;
@@ -174,7 +178,8 @@ k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list
             } else if (kd_commit(T, g)) {
                 ins.ev_site[e] = (uint32_t)g; ins.ev_len[e] = (uint32_t)n; ins.ev_off[e] = po;
                 for (kd_u64 b = 0; b < n; b++) ins.pool[po + b] = (uint8_t)kd_nib(seq, q0 + (int64_t)b);
-                atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g], 1u);
+                if (g_in == NONE) g_in = g;
+                else atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g], 1u);
             } else {
                 ins.ev_site[e] = KD_EV_DROPPED; ins.ev_len[e] = 0; ins.ev_off[e] = po;
             }
@@ -182,14 +187,17 @@ k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list
         } else if (op == 4) {
             if (k == 0) {  // kindel.py:64-73
                 const kd_u64 g = cb + (kd_u64)r;
-                if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g], 1u);
+                if (kd_commit(T, g)) g_ce = g;
                 // query bases [xa, len) land on sites r - len + x  (those with r - len + x >= 0)
                 // (clip_end_weights of these bases are tallied by k_window)
                 q += len;
             } else {  // kindel.py:74-81; regular: the last op that touches r
                 const int64_t x = r - 1;
                 const kd_u64 g = cb + (kd_u64)(x < 0 ? x + L + 1 : x);
-                if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
+                if (kd_commit(T, g)) {              // (a regular read has one such clip)
+                    if (g_cs == NONE) g_cs = g;
+                    else atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
+                }
                 const int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
                 // query bases [q, q + n_adv) land on sites r + (x - q)
                 // clip_start_weights are tallied by k_window (LDS)
@@ -197,6 +205,10 @@ k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list
             }
         }
     }
+    uint32_t hl, n;
+    if ((n = kd_run_heads(g_ce != NONE, g_ce, hl))) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g_ce], n);
+    if ((n = kd_run_heads(g_cs != NONE, g_cs, hl))) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g_cs], n);
+    if ((n = kd_run_heads(g_in != NONE, g_in, hl))) atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g_in], n);
 }
 
 // k_cold_long: k_cold_lane's work for regular long-CIGAR reads, one WORKGROUP per read: thread t starts from
