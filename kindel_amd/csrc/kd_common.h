@@ -176,6 +176,21 @@ struct KdCkpt {
     uint32_t pool;    // insertion bases of the read before the run
 };
 
+// A regular short-CIGAR read with a soft clip or an insertion, as k_cold_lane needs it.  k_prep has all of this in
+// registers when it classifies the read; k_cold_lane, one lane per such read (one read in nine), would gather it again
+// through six arrays behind an index list: a chain of dependent scattered loads.  k_prep stages the records in LDS and
+// writes them out as one coalesced run per workgroup.
+struct alignas(16) KdColdRec {
+    kd_u64 cig_off;
+    uint32_t read;      // index of the read in the batch
+    uint32_t pos0;      // >= 0 for a regular read
+    uint32_t contig, seq_len;
+    uint32_t n_cig;     // | KD_COLD_HAS_INS
+    uint32_t pad;
+};
+#define KD_COLD_HAS_INS 0x80000000u
+#define KD_COLD_STAGE 1024      // records staged in LDS per k_prep workgroup (4096 reads); the rest take the slow way
+
 // What k_prep_long learned about one long read (one workgroup each): summed into the status words and turned into event /
 // pool / irregular-list slots by ONE small kernel (k_long_reduce) instead of ten same-address atomics per workgroup.
 struct KdLongAcc {

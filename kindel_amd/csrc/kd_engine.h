@@ -227,7 +227,7 @@ struct KdEngine {
         int rc;
         if (!tables_ready && (rc = prepare_tables())) return rc;
         if ((rc = ins_cleanup())) return rc;      // the last reduction's events are about to be joined by new ones
-        if ((rc = ensure(b_rinfo, n * sizeof(KdRInfo))) || (rc = ensure(b_cold, n * 4)) ||
+        if ((rc = ensure(b_rinfo, n * sizeof(KdRInfo))) || (rc = ensure(b_cold, n * sizeof(KdColdRec))) ||
             (rc = ensure(b_irreg, n * 4)) || (rc = ensure(b_long, n * 4)) || (rc = ensure(b_readev, n * 4)) ||
             (rc = ensure(b_readpool, n * 8)))
             return rc;
@@ -238,7 +238,7 @@ struct KdEngine {
         R.cigar = B.cigar;
         KdTabs T = tabs();
         KdRInfo *rinfo = (KdRInfo *)b_rinfo.p;
-        uint32_t *cold = (uint32_t *)b_cold.p, *irreg = (uint32_t *)b_irreg.p, *lng = (uint32_t *)b_long.p;
+        KdColdRec *cold = (KdColdRec *)b_cold.p; uint32_t *irreg = (uint32_t *)b_irreg.p, *lng = (uint32_t *)b_long.p;
         // per-batch status words are contiguous: KDS_B_INS_OPS .. KDS_TOTAL_ITEMS
         if (rt.memset(d_status + KDS_B_INS_OPS, 0, (size_t)(KDS_TOTAL_ITEMS - KDS_B_INS_OPS + 1) * 8))
             return hipfail("push: memset status");
@@ -411,7 +411,7 @@ struct KdEngine {
                 return rc;
             if (n_cold &&
                 rt.launch("k_cold_lane", k_cold_lane, (unsigned)((n_cold + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, R, T, I,
-                          (const uint32_t *)cold, (kd_u64)n_cold, d_status))
+                          (const KdColdRec *)cold, (kd_u64)n_cold, d_status))
                 return hipfail("k_cold_lane");
             if (n_long &&
                 rt.launch("k_cold_long", k_cold_long, (unsigned)n_long, KD_BLOCK, 0, R, T, I, (const KdRInfo *)rinfo,

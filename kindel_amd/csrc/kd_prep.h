@@ -75,18 +75,20 @@ __device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc,
 }
 
 __global__ void __launch_bounds__(KD_BLOCK)
-k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irreg_list, uint32_t *long_list,
+k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *irreg_list, uint32_t *long_list,
        uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
     __shared__ kd_u64 s_red[8];       // reads, aligned, walked, ins_ops, ins_bases, n_reg, unsorted
     __shared__ uint32_t s_maxspan, s_maxlead;
     __shared__ uint32_t s_cnt[3];     // cold, irreg, long (block totals / running offsets)
     __shared__ kd_u64 s_base[5];
     __shared__ kd_u64 s_ins[2];       // insertion events / insertion bases of the block's short-CIGAR reads
+    __shared__ KdColdRec s_stage[KD_COLD_STAGE];
+    __shared__ uint32_t s_nstage;
     const uint32_t t = threadIdx.x;
     if (t < 8) s_red[t] = 0;
     if (t < 3) s_cnt[t] = 0;
     if (t < 2) s_ins[t] = 0;
-    if (t == 0) { s_maxspan = 0; s_maxlead = 0; }
+    if (t == 0) { s_maxspan = 0; s_maxlead = 0; s_nstage = 0; }
     __syncthreads();
     const kd_u64 chunk0 = (kd_u64)blockIdx.x * KD_PREP_CHUNK;
     kd_u64 a_reads = 0, a_aligned = 0, a_walked = 0, a_ins = 0, a_insb = 0, a_reg = 0, a_unsorted = 0;
@@ -161,7 +163,15 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
                 if ((uint32_t)span > a_maxspan) a_maxspan = (uint32_t)span;
                 if (lead > a_maxlead) a_maxlead = lead;
             }
-            if (cls == KD_CLS_REG && cold) { n_cold++; m_cold |= 1u << it; }
+            if (cls == KD_CLS_REG && cold) {
+                const uint32_t st = atomicAdd(&s_nstage, 1u);
+                if (st < KD_COLD_STAGE) {
+                    KdColdRec cr;
+                    cr.cig_off = v_coff[u]; cr.read = (uint32_t)i; cr.pos0 = (uint32_t)pos0; cr.contig = c;
+                    cr.seq_len = (uint32_t)sl; cr.n_cig = nc | (has_ins ? KD_COLD_HAS_INS : 0u); cr.pad = 0;
+                    s_stage[st] = cr;
+                } else { n_cold++; m_cold |= 1u << it; }   // staging area full: written from the last loop
+            }
             if (cls == KD_CLS_IRREG) { n_irreg++; m_irreg |= 1u << it; }
             if (cls == KD_CLS_LONG) { n_long++; m_long |= 1u << it; }
             if (has_ins) { m_ins |= 1u << it; read_ev[i] = (uint32_t)n_ins_r; read_pool[i] = n_insb_r; }   // counts, see the last loop
@@ -206,12 +216,14 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
     if (t == 8 && s_red[6]) atomicAdd(&status[KDS_B_UNSORTED], s_red[6]);
     if (t == 9 && s_maxspan) atomicMax(&status[KDS_B_MAXSPAN], (kd_u64)s_maxspan);
     if (t == 10 && s_maxlead) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)s_maxlead);
-    if (t == 64) s_base[0] = s_cnt[0] ? atomicAdd(&status[KDS_B_N_COLD], (kd_u64)s_cnt[0]) : 0;
+    const uint32_t n_staged = s_nstage < KD_COLD_STAGE ? s_nstage : KD_COLD_STAGE;
+    if (t == 64) s_base[0] = (n_staged + s_cnt[0]) ? atomicAdd(&status[KDS_B_N_COLD], (kd_u64)(n_staged + s_cnt[0])) : 0;
     if (t == 65) s_base[1] = s_cnt[1] ? atomicAdd(&status[KDS_B_N_IRREG], (kd_u64)s_cnt[1]) : 0;
     if (t == 66) s_base[2] = s_cnt[2] ? atomicAdd(&status[KDS_B_N_LONG], (kd_u64)s_cnt[2]) : 0;
     __syncthreads();
+    for (uint32_t k = t; k < n_staged; k += KD_BLOCK) cold_rec[s_base[0] + k] = s_stage[k];   // one coalesced run
     if (m_cold | m_irreg | m_long | m_ins) {
-        kd_u64 w_cold = s_base[0] + o_cold, w_irreg = s_base[1] + o_irreg, w_long = s_base[2] + o_long;
+        kd_u64 w_cold = s_base[0] + n_staged + o_cold, w_irreg = s_base[1] + o_irreg, w_long = s_base[2] + o_long;
         kd_u64 w_ev = s_base[3] + o_ev, w_pool = s_base[4] + o_pool;
         for (uint32_t todo = m_cold | m_irreg | m_long | m_ins; todo; todo &= todo - 1) {
             const int it = __builtin_ctz(todo);
@@ -223,7 +235,12 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, uint32_t *cold_list, uint32_t *irre
                 read_ev[i] = (uint32_t)w_ev; read_pool[i] = w_pool;
                 w_ev += n_ev; w_pool += n_b;
             }
-            if (m_cold & bit) cold_list[w_cold++] = (uint32_t)i;
+            if (m_cold & bit) {  // (rare: the metadata is read again)
+                KdColdRec cr;
+                cr.cig_off = rd.cig_off[i]; cr.read = (uint32_t)i; cr.pos0 = (uint32_t)rd.pos0[i]; cr.contig = rd.contig[i];
+                cr.seq_len = (uint32_t)rd.seq_len[i]; cr.n_cig = rd.n_cig[i] | ((m_ins & bit) ? KD_COLD_HAS_INS : 0u); cr.pad = 0;
+                cold_rec[w_cold++] = cr;
+            }
             if (m_irreg & bit) irreg_list[w_irreg++] = (uint32_t)i;
             if (m_long & bit) long_list[w_long++] = (uint32_t)i;
         }

@@ -139,24 +139,26 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
 // the insertion events, written into the slots k_prep reserved for the read.  One LANE per read of the cold
 // list.  Regular reads cannot raise and never wrap (k_prep checked), so this is plain G-space arithmetic.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_list, kd_u64 *status) {
+k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const KdColdRec *rec, kd_u64 n_list, kd_u64 *status) {
     const kd_u64 slot = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
     const bool live = slot < n_list;              // (no early exit: the wavefront meets again behind the walk)
-    const kd_u64 i = list[live ? slot : 0];
-    const int64_t sl = rd.seq_len[i];
-    const uint32_t nc = live ? rd.n_cig[i] : 0u;
-    const uint32_t c = rd.contig[i];
-    const int64_t L = T.contig_len[c];
-    const kd_u64 cb = T.contig_base[c];
-    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
-    const uint32_t *cg = rd.cigar + rd.cig_off[i];
-    uint32_t *tab = T.tab;
-    const kd_u64 S = T.stride;
-    int64_t r = rd.pos0[i], q = 0;
+    const KdColdRec cr = rec[live ? slot : 0];    // k_prep's record of the read: two coalesced 16-byte loads
+    const kd_u64 i = cr.read;
+    const int64_t sl = cr.seq_len;
+    const uint32_t nc = live ? (cr.n_cig & ~KD_COLD_HAS_INS) : 0u;
+    const uint32_t c = cr.contig;
     // everything the walk may need is requested up front (first four CIGAR words in one load, the read's event /
     // pool slots): the kernel is a chain of dependent round trips otherwise
+    const uint32_t *cg = rd.cigar + cr.cig_off;
     const KdChunk pre = kd_load_cigar4(cg, 0u, nc);
-    kd_u64 ev_next = ins.read_ev[i], pool_next = ins.read_pool[i];   // (garbage for a read without insertions: unused)
+    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
+    const bool has_ins = (cr.n_cig & KD_COLD_HAS_INS) != 0;
+    kd_u64 ev_next = has_ins ? ins.read_ev[i] : 0, pool_next = has_ins ? ins.read_pool[i] : 0;
+    const int64_t L = T.contig_len[c];
+    const kd_u64 cb = T.contig_base[c];
+    uint32_t *tab = T.tab;
+    const kd_u64 S = T.stride;
+    int64_t r = cr.pos0, q = 0;
     // the counters this read bumps -- its clip_ends site, its clip_starts site, the site of its first insertion -- are
     // committed behind the walk, where neighbouring lanes (reads sorted by position) aiming at the same site add once
     const kd_u64 NONE = ~0ULL;

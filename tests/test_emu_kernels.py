@@ -86,6 +86,16 @@ def test_synthetic_short_reads_with_planted_features(emu_lib, mode):
     assert any(chr(c).islower() for c in seqs)
 
 
+def test_more_clipped_reads_than_the_prep_staging_area_holds(emu_lib):
+    # k_prep stages the records of a workgroup's (4096 reads) clipped / inserted reads in LDS, KD_COLD_STAGE = 1024 of them:
+    # here most reads are clipped, so every workgroup overflows into the slow path
+    batch = synth.to_numpy(synth.short_reads([9000], 150, seed=11, clip_p=0.6, indel_p=0.3))
+    assert len(batch["contig"]) > 8192
+    run = P.Run(emu_lib, batch, window=1024)
+    assert run.info["windowed"] == 1
+    P.assert_matches_oracle(run)
+
+
 def test_synthetic_long_reads(emu_lib):
     batch = synth.to_numpy(synth.long_reads([30000], 4, seed=6, median_len=3000, min_len=1000, max_len=6000))
     run = P.Run(emu_lib, batch, window=1024)
