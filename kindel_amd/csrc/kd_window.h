@@ -42,6 +42,15 @@
 // masked path below is only needed at the ends of a run.
 // Counter of (channel ch, window-relative site s in [-KD_HALO, W + KD_HALO)) = half (s & 1) of hist0[(s >> 1) * 19 + ch],
 // hist0 = hist + (KD_HALO / 2) * 19; Wh = (W + 2 * KD_HALO) / 2 pairs.
+// MEASUREMENT-ONLY builds (exp/, never the product: their results are wrong on purpose), used to attribute k_window's HBM
+// traffic to its sources under `rocprofv3 --pmc FETCH_SIZE` (scripts/gpu_attrib.sh):
+//   -DKD_EXP_NOSEQ    every read takes its packed bases from the first 4 KiB of the batch (cache hits)
+//   -DKD_EXP_NOFLUSH  the LDS histogram is built but never added to the tables
+#ifdef KD_EXP_NOSEQ
+#define KD_SEQ_AT(rd, i) ((rd).seq4 + ((rd).seq_off[i] & 0xff0u))
+#else
+#define KD_SEQ_AT(rd, i) ((rd).seq4 + (rd).seq_off[i])
+#endif
 #define KD_HALO 8
 #define KD_HPITCH 19
 #define KD_HPITCHB (4 * KD_HPITCH)
@@ -141,7 +150,7 @@ __device__ __forceinline__ void kd_walk_ops(const KdReads &rd, kd_u64 i, uint32_
                                             int32_t lead, int32_t foot_end, int32_t Wi, int32_t Wh, uint32_t *hist0) {
     const uint32_t nc = rd.n_cig[i];
     const uint32_t *cg = rd.cigar + rd.cig_off[i];
-    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(KD_SEQ_AT(rd, i));
     uint32_t sg = 0;   // byte offset of the current run's channel group inside a pair
     // Per-lane state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the
     // current M run), not over CIGAR ops: lanes whose reads have clips or indels still add
@@ -229,7 +238,7 @@ __device__ __forceinline__ bool kd_walk_short(const KdReads &rd, kd_u64 i, const
     if (nc > 1) w1 = cg[1];
     if (nc > 2) w2 = cg[2];
     if (nc > 3) w3 = cg[3];
-    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(KD_SEQ_AT(rd, i));
     uint32_t n_seg_ops = 0;
     for (uint32_t k = 0; k < nc; k++) {
         const uint32_t cw = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : k == 3 ? w3 : cg[k];
@@ -318,7 +327,7 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
     const int32_t xa = grel < 0 ? -grel : 0;
     const int32_t xb = Wi - grel < len ? Wi - grel : len;
     if (xb <= xa) return;
-    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + rd.seq_off[i]);
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(KD_SEQ_AT(rd, i));
     const int32_t ca = xa >> 5, cb = (xb - 1) >> 5;
     // three chunks of prefetch: a 150-base read is 5 chunks, so its loads are (almost) all in flight at once
     KdChunk cur = src[ca], n1 = cur, n2 = cur;
@@ -471,6 +480,9 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
             uint32_t *row = T.tab + (kd_u64)(tch == 0xffu ? 0u : tch) * T.stride;
             for (uint32_t xw = t; xw < (uint32_t)Wh; xw += KD_BLOCK) {
                 const uint32_t v = hist[xw * KD_HPITCH + ch];
+#ifdef KD_EXP_NOFLUSH
+                if (v != 0x7fff7fffu) continue;
+#endif
                 if (!v) continue;
                 // the word holds window-relative sites s (low half) and s + 1 (high half); halo sites are dropped
                 const int32_t sw = 2 * (int32_t)xw - KD_HALO;
