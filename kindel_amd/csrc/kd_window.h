@@ -46,6 +46,10 @@
 // traffic to its sources under `rocprofv3 --pmc FETCH_SIZE` (scripts/gpu_attrib.sh):
 //   -DKD_EXP_NOSEQ    every read takes its packed bases from the first 4 KiB of the batch (cache hits)
 //   -DKD_EXP_NOFLUSH  the LDS histogram is built but never added to the tables
+//   -DKD_EXP_PAIRADD  cost model of a joint (two-base) histogram: a whole dword of a run issues 4 LDS atomics, each with the
+//                     address / half-word arithmetic a 16-bit joint counter needs, instead of 8 (same LDS footprint:
+//                     an optimistic bound, the real thing needs 36 counters per site pair)
+//   -DKD_WINDOW_OCC=7 __launch_bounds__ for 7 workgroups per CU (<= 72 VGPRs); run with a window of <= 448 sites
 #ifdef KD_EXP_NOSEQ
 #define KD_SEQ_AT(rd, i) ((rd).seq4 + ((rd).seq_off[i] & 0xff0u))
 #else
@@ -80,12 +84,22 @@ __device__ __forceinline__ void kd_add8_full(uint32_t *hist0, uint32_t v, int32_
     const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
     uint32_t rh, rl;
     kd_codes8(v, rh, rl);
+#ifdef KD_EXP_PAIRADD
+    const uint32_t jj = rh + rl;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t jb = (jj >> (8 * k)) & 0xffu;
+        unsigned char *a = (p ? hq : h) + (jb & 0xfcu) + KD_HPITCHB * k;
+        atomicAdd(reinterpret_cast<uint32_t *>(a), (vp | vq) << ((jb & 2u) << 3));
+    }
+#else
 #pragma unroll
     for (int b = 0; b < 8; b++) {
         const uint32_t code = (((b & 1) ? rl : rh) >> (8 * (b >> 1))) & 0xffu;
         unsigned char *a = ((b & 1) ? hq : h) + code + KD_HPITCHB * (b >> 1);
         atomicAdd(reinterpret_cast<uint32_t *>(a), (b & 1) ? vq : vp);
     }
+#endif
 }
 // only bases [blo, bhi) belong to the run
 __device__ __forceinline__ void kd_add8_part(uint32_t *hist0, uint32_t v, int32_t s0, int32_t blo, int32_t bhi, uint32_t gb) {
@@ -345,6 +359,57 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
     }
 }
 
+// The 8 bases of dword v through precomputed pointers (h: pair of the dword's first base + channel group, hq = h + one pair if
+// that base sits on an odd site) and add values: what kd_add8_full does after its address arithmetic.
+__device__ __forceinline__ void kd_add8_ptr(unsigned char *h, unsigned char *hq, uint32_t v, uint32_t vp, uint32_t vq) {
+    uint32_t rh, rl;
+    kd_codes8(v, rh, rl);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const uint32_t code = (((b & 1) ? rl : rh) >> (8 * (b >> 1))) & 0xffu;
+        unsigned char *a = ((b & 1) ? hq : h) + code + KD_HPITCHB * (b >> 1);
+        atomicAdd(reinterpret_cast<uint32_t *>(a), (b & 1) ? vq : vp);
+    }
+}
+// A plain read that lies INSIDE the window (k_window's first list): no window clipping, and for a read of up to 160 bases no
+// loop either -- its (up to) five chunks are requested together, every chunk before the last is four whole dwords whose
+// counters sit at compile-time offsets from one pointer computed per read.
+__device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi,
+                                              int32_t Wh, uint32_t *hist0) {
+    const int32_t len = (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
+    const int32_t cb = (len - 1) >> 5;
+    if (cb > 4) { kd_walk_plain(rd, i, ri, wlo, Wi, Wh, hist0); return; }
+    const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);   // 0 <= grel, grel + len <= W
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(KD_SEQ_AT(rd, i));
+    KdChunk k0 = src[0], k1 = k0, k2 = k0, k3 = k0, k4 = k0;
+    if (cb >= 1) k1 = src[1];
+    if (cb >= 2) k2 = src[2];
+    if (cb >= 3) k3 = src[3];
+    if (cb >= 4) k4 = src[4];
+    const int32_t p = grel & 1;
+    unsigned char *h = reinterpret_cast<unsigned char *>(hist0) + KD_MUL24S(grel >> 1, KD_HPITCHB);
+    unsigned char *hq = h + KD_HPITCHB * p;
+    const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
+#define KD_INNER_STAGE(kc, c)                                                                            \
+    if ((c) < cb) {                                                                                      \
+        kd_add8_ptr(h + 16 * (c) * KD_HPITCHB, hq + 16 * (c) * KD_HPITCHB, kc.x, vp, vq);               \
+        kd_add8_ptr(h + (16 * (c) + 4) * KD_HPITCHB, hq + (16 * (c) + 4) * KD_HPITCHB, kc.y, vp, vq);   \
+        kd_add8_ptr(h + (16 * (c) + 8) * KD_HPITCHB, hq + (16 * (c) + 8) * KD_HPITCHB, kc.z, vp, vq);   \
+        kd_add8_ptr(h + (16 * (c) + 12) * KD_HPITCHB, hq + (16 * (c) + 12) * KD_HPITCHB, kc.w, vp, vq); \
+    } else if ((c) == cb) {                                                                              \
+        kd_add_dword(hist0, kc.x, 32 * (c), 0, len, 0, len, grel, 0u);                                   \
+        kd_add_dword(hist0, kc.y, 32 * (c) + 8, 0, len, 0, len, grel, 0u);                               \
+        kd_add_dword(hist0, kc.z, 32 * (c) + 16, 0, len, 0, len, grel, 0u);                              \
+        kd_add_dword(hist0, kc.w, 32 * (c) + 24, 0, len, 0, len, grel, 0u);                              \
+    }
+    KD_INNER_STAGE(k0, 0)
+    KD_INNER_STAGE(k1, 1)
+    KD_INNER_STAGE(k2, 2)
+    KD_INNER_STAGE(k3, 3)
+    KD_INNER_STAGE(k4, 4)
+#undef KD_INNER_STAGE
+}
+
 #ifndef KD_LANE_GROUP
 #define KD_LANE_GROUP 1   // 1, 2, 4, .. 64 (a divisor of the wavefront size)
 #endif
@@ -352,7 +417,10 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
 #define KD_TILE_PER_THREAD (KD_TILE / KD_BLOCK)
 #define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)2 * KD_TILE * 2)   // Wh = site pairs, halos included
 
-__global__ void __launch_bounds__(KD_BLOCK, 5)   // 5 wavefronts per SIMD = the 5 workgroups per CU the LDS footprint allows
+#ifndef KD_WINDOW_OCC
+#define KD_WINDOW_OCC 5
+#endif
+__global__ void __launch_bounds__(KD_BLOCK, KD_WINDOW_OCC)   // 5 wavefronts per SIMD = the 5 workgroups per CU the LDS footprint allows
 k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *ckpt, const uint32_t *seg_read, KdTabs T,
          const kd_u64 *win_lo, const kd_u64 *win_hi, const kd_u64 *item_off, const uint32_t *item_win, kd_u64 items_cap, uint32_t w0,
          uint32_t W, uint32_t Wh_, uint32_t slice, kd_u64 *status) {
@@ -365,7 +433,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
     uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * Wh);  // tile-relative read indices
     uint16_t *l_cplx = l_plain + KD_TILE;
     __shared__ kd_u64 s_item;
-    __shared__ uint32_t s_cnt[2][2];   // [tile parity][plain, complex] list lengths
+    __shared__ uint32_t s_cnt[2][3];   // [tile parity][plain inside the window, plain across an edge, complex] list lengths
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
     const kd_u64 total = status[KDS_TOTAL_ITEMS];
@@ -379,7 +447,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
 #define KD_MARK(acc)
 #endif
     for (;;) {
-        if (t == 0) { s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL); s_cnt[0][0] = 0; s_cnt[0][1] = 0; }
+        if (t == 0) { s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL); s_cnt[0][0] = 0; s_cnt[0][1] = 0; s_cnt[0][2] = 0; }
         __syncthreads();
         const kd_u64 item = s_item;
         if (item >= total || item >= items_cap) break;   // (>= items_cap: k_plan_items has raised KDS_INTERNAL)
@@ -413,14 +481,16 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 const kd_u64 gs = p_gs[u], span = p_sc[u] >> KD_SPAN_SHIFT;
                 if ((p_sc[u] & 3u) == KD_CLS_REG && gs + span > wlo && gs - p_ld[u] < whi) {
                     const uint32_t rel = u * KD_BLOCK + t;
-                    if (p_sc[u] & KD_INFO_PLAIN) l_plain[atomicAdd(&s_cnt[par][0], 1u)] = (uint16_t)rel;
-                    else l_cplx[atomicAdd(&s_cnt[par][1], 1u)] = (uint16_t)rel;
+                    // plain reads: those inside the window fill l_plain from the front, those across an edge from the back
+                    if (!(p_sc[u] & KD_INFO_PLAIN)) l_cplx[atomicAdd(&s_cnt[par][2], 1u)] = (uint16_t)rel;
+                    else if (gs >= wlo && gs + span <= whi) l_plain[atomicAdd(&s_cnt[par][0], 1u)] = (uint16_t)rel;
+                    else l_plain[KD_TILE - 1u - atomicAdd(&s_cnt[par][1], 1u)] = (uint16_t)rel;
                 }
             }
             __syncthreads();
             KD_MARK(c_cls)
-            const uint32_t np = s_cnt[par][0], ncx = s_cnt[par][1];
-            if (t == 0) { s_cnt[par ^ 1u][0] = 0; s_cnt[par ^ 1u][1] = 0; }   // next tile's counters (idle until its classify)
+            const uint32_t ni = s_cnt[par][0], np = s_cnt[par][1], ncx = s_cnt[par][2];
+            if (t == 0) { s_cnt[par ^ 1u][0] = 0; s_cnt[par ^ 1u][1] = 0; s_cnt[par ^ 1u][2] = 0; }   // next tile's counters (idle until its classify)
 #pragma unroll
             for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
                 const kd_u64 j = tb + KD_TILE + u * KD_BLOCK + t;
@@ -436,19 +506,30 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
             // lanes take the list in GROUPS of KD_LANE_GROUP neighbouring entries (neighbours in the sorted batch: their
             // rinfo / seq_off / packed bases share cache lines, one fetch serves the group), the groups of a wavefront
             // lie rows apart (different sites: fewer same-counter collisions in one LDS instruction)
-            const uint32_t ngp = (np + KD_LANE_GROUP - 1) / KD_LANE_GROUP, ngc = (ncx + KD_LANE_GROUP - 1) / KD_LANE_GROUP;
+            const uint32_t ngi = (ni + KD_LANE_GROUP - 1) / KD_LANE_GROUP, ngp = (np + KD_LANE_GROUP - 1) / KD_LANE_GROUP,
+                           ngc = (ncx + KD_LANE_GROUP - 1) / KD_LANE_GROUP;
+            const uint32_t rows_i = (ngi + KD_WAVE / KD_LANE_GROUP - 1) / (KD_WAVE / KD_LANE_GROUP);
             const uint32_t rows_p = (ngp + KD_WAVE / KD_LANE_GROUP - 1) / (KD_WAVE / KD_LANE_GROUP);
             const uint32_t rows_c = (ngc + KD_WAVE / KD_LANE_GROUP - 1) / (KD_WAVE / KD_LANE_GROUP);
-            for (uint32_t r = wave; r < rows_p; r += KD_WAVES_PER_BLOCK) {
+            for (uint32_t r = wave; r < rows_i; r += KD_WAVES_PER_BLOCK) {
+                const uint32_t e = ((lane / KD_LANE_GROUP) * rows_i + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
+                if (e < ni) {
+                    const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
+                    kd_walk_inner(rd, i, rinfo[i], wlo, Wi, Wh, hist0);
+                }
+            }
+            // (each list's rows start at the wavefront after the one that took the last row of the list before)
+            for (uint32_t r = (wave + KD_WAVES_PER_BLOCK - rows_i % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK; r < rows_p;
+                 r += KD_WAVES_PER_BLOCK) {
                 const uint32_t e = ((lane / KD_LANE_GROUP) * rows_p + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
                 if (e < np) {
-                    const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
+                    const kd_u64 j = tb + l_plain[KD_TILE - 1u - e], i = order ? (kd_u64)order[j] : j;
                     kd_walk_plain(rd, i, rinfo[i], wlo, Wi, Wh, hist0);
                 }
             }
             KD_MARK(c_plain)
             // the complex rows start at the wavefront after the one that took the last plain row
-            for (uint32_t r = (wave + KD_WAVES_PER_BLOCK - rows_p % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK; r < rows_c;
+            for (uint32_t r = (wave + 2 * KD_WAVES_PER_BLOCK - (rows_i + rows_p) % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK; r < rows_c;
                  r += KD_WAVES_PER_BLOCK) {
                 const uint32_t e = ((lane / KD_LANE_GROUP) * rows_c + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
                 if (e < ncx) {
