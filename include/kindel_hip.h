@@ -215,6 +215,10 @@ void kd_decode_close(kd_file *f);
 const char *kd_decode_last_error(void);
 /* host threads the decoder starts by default (n_threads = 0): the visible cores, capped at 1.5 x the cgroup CPU quota */
 uint32_t kd_host_threads(void);
+/* The BGZF reader's block decoder on its own (kd_inflate.h): the raw DEFLATE stream in[0, in_len) must decode to exactly
+   out_len bytes; KD_OK or KD_E_IO (malformed / truncated stream, other size).  Never writes outside out[0, out_len).
+   Replaces what pysam / htslib's bgzf_read do under kindel.py:131-134. */
+int kd_host_inflate(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_len);
 
 /* ---- tool: write a host batch as a BGZF-compressed BAM (synthetic inputs for end-to-end runs; parallel deflate) ---- */
 int kd_write_bam(const char *path, const kd_batch *host_batch, uint32_t n_contigs, const char *const *names,

@@ -30,7 +30,7 @@ ABI_SYMBOLS = (
     "kd_profile_enable kd_profile_get kd_profile_reset kd_decode_open kd_decode_batch kd_decode_n_contigs "
     "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error "
     "kd_stream_open kd_stream_n_contigs kd_stream_contig_name kd_stream_contig_len kd_stream_next kd_stream_n_records "
-    "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_write_bam kd_host_threads"
+    "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_write_bam kd_host_threads kd_host_inflate"
 ).split()
 
 #: the reference exception each error code stands for (kindel.py:47,51-52,57,61,67,72,75,79)
@@ -240,6 +240,23 @@ def host_threads(lib=None):
     lib = lib or default_library()
     lib.dll.kd_host_threads.restype = C.c_uint32
     return int(lib.dll.kd_host_threads())
+
+
+def host_inflate(data, out_len, lib=None):
+    """Raw DEFLATE -> bytes of exactly `out_len` (the BGZF reader's block decoder, kd_host_inflate); ValueError if malformed."""
+    lib = lib or default_library()
+    src = np.frombuffer(bytes(data), dtype=np.uint8) if len(data) else np.zeros(0, np.uint8)
+    out = np.empty(int(out_len) + 64, np.uint8)
+    out[int(out_len):] = 0xA5          # canary: the decoder never writes past out_len
+    f = lib.dll.kd_host_inflate
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    rc = f(src.ctypes.data if len(src) else None, len(src), out.ctypes.data, int(out_len))
+    if not (out[int(out_len):] == 0xA5).all():
+        raise AssertionError("kd_host_inflate wrote past the end of its output")
+    if rc != 0:
+        raise ValueError("kd_host_inflate: malformed DEFLATE stream (rc %d)" % rc)
+    return out[:int(out_len)].tobytes()
 
 
 def decode_file(path, threads=0, lib=None):

@@ -189,7 +189,9 @@ struct alignas(16) KdColdRec {
     uint32_t pad;
 };
 #define KD_COLD_HAS_INS 0x80000000u
+#ifndef KD_COLD_STAGE
 #define KD_COLD_STAGE 1024      // records staged in LDS per k_prep workgroup (4096 reads); the rest take the slow way
+#endif
 
 // What k_prep_long learned about one long read (one workgroup each): summed into the status words and turned into event /
 // pool / irregular-list slots by ONE small kernel (k_long_reduce) instead of ten same-address atomics per workgroup.

@@ -74,7 +74,10 @@ __device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc,
     return s;
 }
 
-__global__ void __launch_bounds__(KD_BLOCK)
+#ifndef KD_PREP_OCC
+#define KD_PREP_OCC 4     // workgroups per CU the register budget is set for (5: measured slower)
+#endif
+__global__ void __launch_bounds__(KD_BLOCK, KD_PREP_OCC)
 k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *irreg_list, uint32_t *long_list,
        uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
     __shared__ kd_u64 s_red[8];       // reads, aligned, walked, ins_ops, ins_bases, n_reg, unsorted
