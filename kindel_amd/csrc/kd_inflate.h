@@ -20,8 +20,7 @@ namespace kdz {
 //   bits 4..7   extra bits of a length / distance symbol (0..13); K_SUB: index bits of the second-level table
 //   bits 8..12  kind
 //   bits 16..31 literal value / length base / distance base / K_SUB: offset of the second-level table
-//               K_LIT | K_LIT2: TWO literals whose codes fit the primary index together (first in bits 16..23, second in 24..31)
-enum : uint32_t { K_LIT = 0x0100u, K_LEN = 0x0200u, K_EOB = 0x0400u, K_SUB = 0x0800u, K_BAD = 0x1000u, K_LIT2 = 0x2000u };
+enum : uint32_t { K_LIT = 0x0100u, K_LEN = 0x0200u, K_EOB = 0x0400u, K_SUB = 0x0800u, K_BAD = 0x1000u };
 static inline uint32_t mk(uint32_t kind, uint32_t nbits, uint32_t extra, uint32_t value) {
     return (value << 16) | kind | (extra << 4) | nbits;
 }
@@ -34,10 +33,14 @@ static const uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 
 static const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 static const uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 
+// the low `len` (<= 15) bits of code, reversed
 static inline uint32_t rev_bits(uint32_t code, int len) {
-    uint32_t r = 0;
-    for (int i = 0; i < len; i++) { r = (r << 1) | (code & 1u); code >>= 1; }
-    return r;
+    uint32_t x = code;
+    x = ((x & 0x5555u) << 1) | ((x >> 1) & 0x5555u);
+    x = ((x & 0x3333u) << 2) | ((x >> 2) & 0x3333u);
+    x = ((x & 0x0f0fu) << 4) | ((x >> 4) & 0x0f0fu);
+    x = ((x & 0x00ffu) << 8) | ((x >> 8) & 0x00ffu);
+    return x >> (16 - len);
 }
 
 // Canonical Huffman code of `n` symbols with lengths lens[] (0 = unused) -> look-up table indexed by the next bits of the
@@ -54,29 +57,38 @@ static bool build_table(const uint8_t *lens, int n, int primary_bits, uint32_t *
     uint32_t next_code[16];
     { uint32_t code = 0; for (int l = 1; l <= 15; l++) { code = (code + (uint32_t)count[l - 1]) << 1; next_code[l] = code; } }
     const int psize = 1 << primary_bits;
-    for (int i = 0; i < psize; i++) table[i] = K_BAD | 1u;
-    // second-level tables: the longest code under each primary prefix decides the table's width
-    uint8_t sub_bits[1 << LIT_BITS];
-    memset(sub_bits, 0, (size_t)psize);
+    int maxlen = 15;
+    while (maxlen > 0 && !count[maxlen]) maxlen--;
+    // a complete code whose longest word fits the primary index overwrites every primary entry: nothing to prepare
+    const bool simple = left == 0 && maxlen <= primary_bits;
     uint32_t codes[288];
     for (int s = 0; s < n; s++) {
         const int l = lens[s];
-        if (!l) continue;
-        const uint32_t r = rev_bits(next_code[l]++, l);
-        codes[s] = r;
-        if (l > primary_bits) {
-            const uint32_t p = r & (uint32_t)(psize - 1);
-            if (l - primary_bits > sub_bits[p]) sub_bits[p] = (uint8_t)(l - primary_bits);
-        }
+        if (l) codes[s] = rev_bits(next_code[l]++, l);
     }
-    int used = psize;
-    for (int p = 0; p < psize; p++) {
-        if (!sub_bits[p]) continue;
-        const int sz = 1 << sub_bits[p];
-        if (used + sz > table_cap) return false;
-        table[p] = mk(K_SUB, (uint32_t)primary_bits, sub_bits[p], (uint32_t)used);
-        for (int i = 0; i < sz; i++) table[used + i] = K_BAD | 1u;
-        used += sz;
+    uint8_t sub_bits[1 << LIT_BITS];
+    if (!simple) {
+        for (int i = 0; i < psize; i++) table[i] = K_BAD | 1u;
+        if (maxlen > primary_bits) {
+            // second-level tables: the longest code under each primary prefix decides the table's width
+            memset(sub_bits, 0, (size_t)psize);
+            for (int s = 0; s < n; s++) {
+                const int l = lens[s];
+                if (l > primary_bits) {
+                    const uint32_t p = codes[s] & (uint32_t)(psize - 1);
+                    if (l - primary_bits > sub_bits[p]) sub_bits[p] = (uint8_t)(l - primary_bits);
+                }
+            }
+            int used = psize;
+            for (int p = 0; p < psize; p++) {
+                if (!sub_bits[p]) continue;
+                const int sz = 1 << sub_bits[p];
+                if (used + sz > table_cap) return false;
+                table[p] = mk(K_SUB, (uint32_t)primary_bits, sub_bits[p], (uint32_t)used);
+                for (int i = 0; i < sz; i++) table[used + i] = K_BAD | 1u;
+                used += sz;
+            }
+        }
     }
     for (int s = 0; s < n; s++) {
         const int l = lens[s];
@@ -93,22 +105,6 @@ static bool build_table(const uint8_t *lens, int n, int primary_bits, uint32_t *
         }
     }
     return true;
-}
-
-// Primary entries whose literal leaves enough index bits for a complete second literal code become two-literal entries
-// (packed bases and qualities are a few dozen byte values with 3- to 6-bit codes: most look-ups then yield two bytes).
-// Descending order: the entry consulted for the second symbol (index i >> l1 < i) is still the original one.
-static void pair_literals(uint32_t *table, int primary_bits) {
-    for (int i = (1 << primary_bits) - 1; i >= 0; i--) {
-        const uint32_t e1 = table[i];
-        if ((e1 & (K_LIT | K_LIT2)) != K_LIT) continue;
-        const uint32_t l1 = e1 & 15u;
-        const uint32_t e2 = table[(uint32_t)i >> l1];
-        if ((e2 & (K_LIT | K_LIT2)) != K_LIT) continue;
-        const uint32_t l2 = e2 & 15u;
-        if (l1 + l2 > (uint32_t)primary_bits) continue;
-        table[i] = mk(K_LIT | K_LIT2, l1 + l2, 0, (e1 >> 16) | ((e2 >> 16) << 8));
-    }
 }
 
 static inline uint32_t litlen_entry(int s) {
@@ -197,7 +193,6 @@ struct Decoder {
         }
         if (overrun() || lens[256] == 0) return false;
         if (!build_table(lens, hlit, LIT_BITS, lit, LIT_TABLE, litlen_entry)) return false;
-        pair_literals(lit, LIT_BITS);
         return build_table(lens + hlit, hdist, DIST_BITS, dist, DIST_TABLE, dist_entry);
     }
 
@@ -209,7 +204,6 @@ struct Decoder {
         for (int i = 280; i < 288; i++) lens[i] = 8;
         for (int i = 0; i < 32; i++) lens[288 + i] = 5;
         build_table(lens, 288, LIT_BITS, lit, LIT_TABLE, litlen_entry);
-        pair_literals(lit, LIT_BITS);
         build_table(lens + 288, 32, DIST_BITS, dist, DIST_TABLE, dist_entry);
     }
 
@@ -233,23 +227,34 @@ struct Decoder {
     // one compressed block's symbols; FAST: both buffers have slack for a whole step (checked by the caller's loop)
     bool block() {
         for (;;) {
-            // fast steps: >= 16 input bytes for the refills, >= 6 literals + 258 + 8 bytes of output slack
-            while (in_end - in >= 16 && out_end - out >= 6 + 258 + 8 + 1) {
+            // fast steps: >= 16 input bytes for the refills, >= 3 literals + 258 + 8 bytes of output slack
+            while (in_end - in >= 16 && out_end - out >= 3 + 258 + 8) {
                 refill();
-                uint32_t e = lookup_lit();
-                if (e & K_LIT) {   // up to three look-ups = up to six literals per refill (each writes 2 bytes, keeps 1 or 2)
+                // up to three literals per refill; the test for a second-level table stays off the literal path (a literal
+                // with a long code just takes the slow exit below)
+                uint32_t e = lit[bb & ((1u << LIT_BITS) - 1)];
+                if (e & K_LIT) {
                     bb >>= (e & 15u); bc -= (int)(e & 15u);
-                    { const uint16_t v = (uint16_t)(e >> 16); memcpy(out, &v, 2); out += 1 + ((e >> 13) & 1u); }
-                    e = lookup_lit();
+                    *out++ = (uint8_t)(e >> 16);
+                    e = lit[bb & ((1u << LIT_BITS) - 1)];
                     if (e & K_LIT) {
                         bb >>= (e & 15u); bc -= (int)(e & 15u);
-                        { const uint16_t v = (uint16_t)(e >> 16); memcpy(out, &v, 2); out += 1 + ((e >> 13) & 1u); }
-                        e = lookup_lit();
+                        *out++ = (uint8_t)(e >> 16);
+                        e = lit[bb & ((1u << LIT_BITS) - 1)];
                         if (e & K_LIT) {
                             bb >>= (e & 15u); bc -= (int)(e & 15u);
-                            { const uint16_t v = (uint16_t)(e >> 16); memcpy(out, &v, 2); out += 1 + ((e >> 13) & 1u); }
+                            *out++ = (uint8_t)(e >> 16);
                             continue;
                         }
+                    }
+                }
+                if (e & K_SUB) {
+                    bb >>= LIT_BITS; bc -= LIT_BITS;
+                    e = lit[(e >> 16) + (uint32_t)(bb & ((1u << ((e >> 4) & 15u)) - 1))];
+                    if (e & K_LIT) {
+                        bb >>= (e & 15u); bc -= (int)(e & 15u);
+                        *out++ = (uint8_t)(e >> 16);
+                        continue;
                     }
                 }
                 bb >>= (e & 15u); bc -= (int)(e & 15u);
@@ -284,11 +289,8 @@ struct Decoder {
             bb >>= (e & 15u); bc -= (int)(e & 15u);
             if (overrun()) return false;
             if (e & K_LIT) {
-                const size_t nl = 1 + ((e >> 13) & 1u);
-                if ((size_t)(out_end - out) < nl) return false;
-                out[0] = (uint8_t)(e >> 16);
-                if (nl == 2) out[1] = (uint8_t)(e >> 24);
-                out += nl;
+                if (out >= out_end) return false;
+                *out++ = (uint8_t)(e >> 16);
                 continue;
             }
             if (!(e & K_LEN)) return (e & K_EOB) != 0;
