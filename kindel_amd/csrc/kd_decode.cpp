@@ -355,8 +355,10 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
         if (r[32 + l_rn - 1] != 0) return 0;        // read name is NUL-terminated
         return q + 4 + bs;
     };
-    auto walk = [&](size_t p0, size_t p_end, std::vector<Rec> &out, uint64_t &n_rec, size_t &stop, std::string &err) -> bool {
+    // (sums[0] / sums[1]: packed-base bytes / CIGAR words of the kept records, for the prefix over the ranges)
+    auto walk = [&](size_t p0, size_t p_end, std::vector<Rec> &out, uint64_t &n_rec, size_t &stop, std::string &err, size_t *sums) -> bool {
         size_t q = p0;
+        sums[0] = 0; sums[1] = 0;
         while (q < p_end && q + 4 <= n) {
             const uint32_t bs = rd32(d.data() + q);
             if (bs < 32) { err = "malformed BAM record"; return false; }
@@ -374,6 +376,7 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
                 uint64_t cg_at = 0;
                 const uint32_t nc = real_cigar(r, bs, l_rn, n_cig, l_seq, &cg_at);
                 out.push_back({q + 4, (uint32_t)(((size_t)l_seq + 1) / 2), nc, cg_at});
+                sums[0] += ((size_t)l_seq + 1) / 2; sums[1] += nc;
             }
             q += 4 + bs;
         }
@@ -385,8 +388,14 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
     if (const char *e = getenv("KD_DECODE_RANGE_BYTES")) min_range = std::max<size_t>(64, strtoull(e, nullptr, 10));   // ... tests: small
     nt1 = (unsigned)std::max<size_t>(1, std::min<size_t>(nt1, (n - std::min(o, n)) / min_range));
     constexpr int KD_SPEC_CHAIN = 16;
-    std::vector<std::vector<Rec>> part(nt1);
+    // (kept across calls by the calling thread: a stream parses ~70 chunks, and fresh vectors of this size come from mmap --
+    //  page faults and munmap for every chunk)
+    static thread_local std::vector<std::vector<Rec>> part_of_this_thread;
+    std::vector<std::vector<Rec>> &part = part_of_this_thread;   // (the workers must see the CALLER's instance: captured by reference)
+    if (part.size() < nt1) part.resize(nt1);
+    for (unsigned t = 0; t < nt1; t++) part[t].clear();
     std::vector<uint64_t> part_nrec(nt1, 0);
+    std::vector<size_t> part_sums(2 * (size_t)nt1, 0);
     std::vector<size_t> guess(nt1, 0), stop(nt1, 0);
     std::vector<std::string> perr(nt1);
     std::vector<char> pok(nt1, 1);
@@ -407,15 +416,15 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
             q = found;
         }
         guess[t] = q;
-        pok[t] = walk(q, range_end(t), part[t], part_nrec[t], stop[t], perr[t]) ? 1 : 0;
+        pok[t] = walk(q, range_end(t), part[t], part_nrec[t], stop[t], perr[t], &part_sums[2 * t]) ? 1 : 0;
     };
     pool().run(nt1, nt1, work1);
     // verify the hand-offs left to right; re-walk what a wrong guess (or an error seen from a wrong start) spoiled
     size_t p = o;
     for (unsigned t = 0; t < nt1; t++) {
         if (guess[t] != p || (t > 0 && !pok[t])) {
-            part[t].clear(); part_nrec[t] = 0; perr[t].clear();
-            pok[t] = p >= range_end(t) ? 1 : (walk(p, range_end(t), part[t], part_nrec[t], stop[t], perr[t]) ? 1 : 0);
+            part[t].clear(); part_nrec[t] = 0; perr[t].clear(); part_sums[2 * t] = part_sums[2 * t + 1] = 0;
+            pok[t] = p >= range_end(t) ? 1 : (walk(p, range_end(t), part[t], part_nrec[t], stop[t], perr[t], &part_sums[2 * t]) ? 1 : 0);
             if (p >= range_end(t)) stop[t] = p;
         }
         if (!pok[t]) { g_decode_error = perr[t]; return KD_E_IO; }
@@ -426,9 +435,7 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
     // prefix over the ranges: first record index / packed-base byte / CIGAR word of each
     std::vector<size_t> k_at(nt1 + 1, 0), sq_at(nt1 + 1, 0), cg_at(nt1 + 1, 0);
     for (unsigned t = 0; t < nt1; t++) {
-        size_t sb = 0, nc = 0;
-        for (const Rec &rc : part[t]) { sb += rc.sb; nc += rc.nc; }
-        k_at[t + 1] = k_at[t] + part[t].size(); sq_at[t + 1] = sq_at[t] + sb; cg_at[t + 1] = cg_at[t] + nc;
+        k_at[t + 1] = k_at[t] + part[t].size(); sq_at[t + 1] = sq_at[t] + part_sums[2 * t]; cg_at[t + 1] = cg_at[t] + part_sums[2 * t + 1];
         f.n_records += part_nrec[t];
     }
     const size_t n_keep = k_at[nt1];

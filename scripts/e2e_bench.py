@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--chunk-mb", type=int, default=64)
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--out", default="")
+    ap.add_argument("--sweep", default="", help="streamed ingest only, for each THREADSxCHUNK_MB of a comma-separated list (e.g. 16x64,24x128)")
     a = ap.parse_args()
 
     t0 = time.time()
@@ -86,6 +87,16 @@ def main():
         pl.engine.close()
         return out, fa
 
+    if a.sweep:
+        for spec in a.sweep.split(","):
+            th, mb = (int(x) for x in spec.split("x"))
+            a.threads, a.chunk_mb = th, mb
+            rs = [stream()[0] for _ in range(a.repeat)]
+            b = min(rs, key=lambda r: r["total_s"])
+            print("sweep threads %d chunk %d MB: stream %.3f s (decode %.3f, push %.3f) %.3g events/s   [all: %s]" % (
+                th, mb, b["total_s"], b["ingest_decode_s"], b["ingest_push_s"], ev / b["total_s"], " ".join("%.3f" % r["total_s"] for r in rs)))
+        os.unlink(path)
+        return
     runs_w = [whole() for _ in range(a.repeat)]
     runs_s = [stream() for _ in range(a.repeat)]
     bw = min(runs_w, key=lambda r: r[0]["total_s"])
