@@ -36,6 +36,7 @@ struct KdEngine {
     // the tables are allocated for the shard only: sites [alloc_lo, alloc_hi) (tile aligned) + slack, `pitch` dwords per
     // channel.  Lazily (first push / first read-out), so that kd_create + kd_set_shard never allocate the whole G-space.
     uint64_t alloc_lo = 0, alloc_hi = 0, pitch = 0;
+    bool batch_status_clean = false;   // the per-batch status words are all zero (k_reset ran, no batch since)
     bool tables_ready = false;
     kd_u64 *d_cbase = nullptr, *d_status = nullptr;
     kd_u64 *d_first_idx = nullptr, *d_err_first = nullptr;   // per contig: first record / first failing read (global indices)
@@ -187,10 +188,11 @@ struct KdEngine {
         tables_ready = false;   // zeroed (and, after kd_set_shard, re-allocated) by the next push or read-out
         std::fill(h_status.begin(), h_status.end(), 0);
         h_status[KDS_ERR_READ] = ~0ULL;
-        if (rt.h2d(d_status, h_status.data(), KDS_COUNT * 8)) return hipfail("reset: status");
-        if (rt.memset(d_first_idx, 0xff, (size_t)n_contigs * 8) || rt.memset(d_err_first, 0xff, (size_t)n_contigs * 8) ||
-            rt.memset(d_err_code, 0, (size_t)n_contigs * 4))
-            return hipfail("reset: per-contig error state");
+        // status words and the per-contig first-record / first-error state in ONE launch (it was a copy and three memsets)
+        if (rt.launch("k_reset", k_reset, (unsigned)((std::max<uint64_t>(n_contigs, KDS_COUNT) + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0,
+                      d_status, d_first_idx, d_err_first, d_err_code, n_contigs))
+            return hipfail("k_reset");
+        batch_status_clean = true;
         reads_pushed = 0; finalized = false; have_cns = false; have_inskeys = false;
         return KD_OK;
     }
@@ -240,8 +242,9 @@ struct KdEngine {
         KdRInfo *rinfo = (KdRInfo *)b_rinfo.p;
         KdColdRec *cold = (KdColdRec *)b_cold.p; uint32_t *irreg = (uint32_t *)b_irreg.p, *lng = (uint32_t *)b_long.p;
         // per-batch status words are contiguous: KDS_B_INS_OPS .. KDS_TOTAL_ITEMS
-        if (rt.memset(d_status + KDS_B_INS_OPS, 0, (size_t)(KDS_TOTAL_ITEMS - KDS_B_INS_OPS + 1) * 8))
-            return hipfail("push: memset status");
+        if (!batch_status_clean && rt.memset(d_status + KDS_B_INS_OPS, 0, (size_t)(KDS_TOTAL_ITEMS - KDS_B_INS_OPS + 1) * 8))
+            return hipfail("push: memset status");      // (the first batch after kd_reset finds them zeroed by k_reset)
+        batch_status_clean = false;
         const unsigned prep_grid = (unsigned)((n + KD_PREP_CHUNK - 1) / KD_PREP_CHUNK);
         const uint64_t ev_before = h_status[KDS_N_EV], pool_before = h_status[KDS_POOL];  // as of the last fetch
         if (rt.launch("k_prep", k_prep, prep_grid, KD_BLOCK, 0, R, T, rinfo, cold, irreg, lng, (uint32_t *)b_readev.p,
@@ -338,9 +341,7 @@ struct KdEngine {
                 const uint64_t items_cap = (uint64_t)n_win + (ne * reach) / slice + 1;
                 if ((rc2 = ensure(b_itemwin, items_cap * 4))) return rc2;
                 uint32_t *iw = (uint32_t *)b_itemwin.p;
-                if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, d_status) ||
-                    rt.launch("k_plan_items", k_plan_items, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, (const kd_u64 *)io, n_win, iw,
-                              (kd_u64)items_cap, d_status))
+                if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, iw, (kd_u64)items_cap, d_status))
                     return hipfail("k_plan_scan");
                 const uint32_t Wh = (W + 2 * KD_HALO) / 2;   // dwords per channel row
                 const size_t lds = KD_WINDOW_LDS_BYTES(Wh);
@@ -393,9 +394,7 @@ struct KdEngine {
                 const uint64_t items_cap = (uint64_t)ns_win + (ne * reach) / slice + 1;
                 if ((rc2 = ensure(b_itemwin, items_cap * 4))) return rc2;
                 uint32_t *siw = (uint32_t *)b_itemwin.p;
-                if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, sio, ns_win, d_status) ||
-                    rt.launch("k_plan_items", k_plan_items, (ns_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, (const kd_u64 *)sio, ns_win, siw,
-                              (kd_u64)items_cap, d_status))
+                if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, sio, ns_win, siw, (kd_u64)items_cap, d_status))
                     return hipfail("k_plan_scan");
                 const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * (unsigned)KD_STRIP_WGS);   // resident workgroups: LDS and registers
                 if (rt.launch("k_strip", k_strip, grid, KD_BLOCK, 0, R, info, order, T, (const kd_u64 *)swl, (const kd_u64 *)swh,

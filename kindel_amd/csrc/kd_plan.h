@@ -117,9 +117,10 @@ k_plan_ranges_sorted(const kd_u64 *bin_off, uint32_t n_bins, uint32_t w0, uint32
 }
 
 // k_plan_scan: one workgroup, in-place exclusive scan of the per-window item counts (contiguous run per thread, run totals
-// scanned with __shfl_up).
+// scanned with __shfl_up), and the work item -> window table on the way (k_window then needs one load, not a binary search
+// over item_off, to find the window of the item it dequeued).
 __global__ void __launch_bounds__(KD_BLOCK)
-k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
+k_plan_scan(kd_u64 *item_off, uint32_t n_win, uint32_t *item_win, kd_u64 cap, kd_u64 *status) {
     __shared__ kd_u64 s_wave[KD_WAVES_PER_BLOCK];
     const uint32_t t = threadIdx.x;
     const uint32_t per = (n_win + KD_BLOCK - 1) / KD_BLOCK;
@@ -128,19 +129,23 @@ k_plan_scan(kd_u64 *item_off, uint32_t n_win, kd_u64 *status) {
     for (uint32_t w = w0; w < w1; w++) mine += item_off[w];
     kd_u64 total;
     kd_u64 o = kd_block_scan_incl(mine, s_wave, total) - mine;
-    for (uint32_t w = w0; w < w1; w++) { const kd_u64 v = item_off[w]; item_off[w] = o; o += v; }
+    for (uint32_t w = w0; w < w1; w++) {
+        const kd_u64 v = item_off[w];
+        item_off[w] = o;
+        for (kd_u64 it = o; it < o + v; it++) {
+            if (it < cap) item_win[it] = w;
+            else status[KDS_INTERNAL] = 1;
+        }
+        o += v;
+    }
     if (t == 0) { item_off[n_win] = total; status[KDS_TOTAL_ITEMS] = total; status[KDS_NEXT_ITEM] = 0; }
     if (t < 8) status[KDS_QUEUE0 + t] = 0;   // k_strip's work queues
 }
 
-// k_plan_items: work item -> window table (k_window then needs one load, not a binary search over item_off,
-// to find the window of the item it dequeued).
+// k_reset (kd_reset): the status words and the per-contig first-record / first-error state in one launch.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_plan_items(const kd_u64 *item_off, uint32_t n_win, uint32_t *item_win, kd_u64 cap, kd_u64 *status) {
-    const uint32_t w = blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (w >= n_win) return;
-    for (kd_u64 it = item_off[w]; it < item_off[w + 1]; it++) {
-        if (it < cap) item_win[it] = w;
-        else status[KDS_INTERNAL] = 1;
-    }
+k_reset(kd_u64 *status, kd_u64 *first_idx, kd_u64 *err_first, uint32_t *err_code, uint32_t n_contigs) {
+    const uint32_t i = blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (i < KDS_COUNT) status[i] = i == KDS_ERR_READ ? ~0ULL : 0ULL;
+    if (i < n_contigs) { first_idx[i] = ~0ULL; err_first[i] = ~0ULL; err_code[i] = 0u; }
 }
