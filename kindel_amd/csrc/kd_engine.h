@@ -341,7 +341,11 @@ struct KdEngine {
                 const uint64_t items_cap = (uint64_t)n_win + (ne * reach) / slice + 1;
                 if ((rc2 = ensure(b_itemwin, items_cap * 4))) return rc2;
                 uint32_t *iw = (uint32_t *)b_itemwin.p;
-                if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, iw, (kd_u64)items_cap, d_status))
+                // (up to 2^16 windows the scan's workgroup also writes the item -> window table; beyond, a kernel of its own)
+                const bool fused_items = n_win <= 65536u;
+                if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, fused_items ? iw : (uint32_t *)nullptr, (kd_u64)items_cap, d_status) ||
+                    (!fused_items && rt.launch("k_plan_items", k_plan_items, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, (const kd_u64 *)io,
+                                               n_win, iw, (kd_u64)items_cap, d_status)))
                     return hipfail("k_plan_scan");
                 const uint32_t Wh = (W + 2 * KD_HALO) / 2;   // dwords per channel row
                 const size_t lds = KD_WINDOW_LDS_BYTES(Wh);
@@ -394,7 +398,9 @@ struct KdEngine {
                 const uint64_t items_cap = (uint64_t)ns_win + (ne * reach) / slice + 1;
                 if ((rc2 = ensure(b_itemwin, items_cap * 4))) return rc2;
                 uint32_t *siw = (uint32_t *)b_itemwin.p;
-                if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, sio, ns_win, siw, (kd_u64)items_cap, d_status))
+                if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, sio, ns_win, (uint32_t *)nullptr, (kd_u64)items_cap, d_status) ||
+                    rt.launch("k_plan_items", k_plan_items, (ns_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, (const kd_u64 *)sio, ns_win, siw,
+                              (kd_u64)items_cap, d_status))
                     return hipfail("k_plan_scan");
                 const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * (unsigned)KD_STRIP_WGS);   // resident workgroups: LDS and registers
                 if (rt.launch("k_strip", k_strip, grid, KD_BLOCK, 0, R, info, order, T, (const kd_u64 *)swl, (const kd_u64 *)swh,

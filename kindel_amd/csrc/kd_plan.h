@@ -132,14 +132,27 @@ k_plan_scan(kd_u64 *item_off, uint32_t n_win, uint32_t *item_win, kd_u64 cap, kd
     for (uint32_t w = w0; w < w1; w++) {
         const kd_u64 v = item_off[w];
         item_off[w] = o;
-        for (kd_u64 it = o; it < o + v; it++) {
-            if (it < cap) item_win[it] = w;
-            else status[KDS_INTERNAL] = 1;
+        if (item_win) {   // (NULL: many more windows than one workgroup should serve -- k_plan_items does it, k_strip's planning)
+            for (kd_u64 it = o; it < o + v; it++) {
+                if (it < cap) item_win[it] = w;
+                else status[KDS_INTERNAL] = 1;
+            }
         }
         o += v;
     }
     if (t == 0) { item_off[n_win] = total; status[KDS_TOTAL_ITEMS] = total; status[KDS_NEXT_ITEM] = 0; }
     if (t < 8) status[KDS_QUEUE0 + t] = 0;   // k_strip's work queues
+}
+
+// k_plan_items: work item -> window table with one thread per window (after a k_plan_scan that was given no table to fill)
+__global__ void __launch_bounds__(KD_BLOCK)
+k_plan_items(const kd_u64 *item_off, uint32_t n_win, uint32_t *item_win, kd_u64 cap, kd_u64 *status) {
+    const uint32_t w = blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (w >= n_win) return;
+    for (kd_u64 it = item_off[w]; it < item_off[w + 1]; it++) {
+        if (it < cap) item_win[it] = w;
+        else status[KDS_INTERNAL] = 1;
+    }
 }
 
 // k_reset (kd_reset): the status words and the per-contig first-record / first-error state in one launch.
