@@ -281,6 +281,17 @@ def test_multi_tile_items_carry_rows_between_tiles(hip_lib):
         P.assert_matches_oracle(P.Run(hip_lib, batch, window=window, slice_reads=slice_reads), what="w%d s%d" % (window, slice_reads))
 
 
+def test_clipped_reads_beyond_the_prep_staging_area_and_deep_sites(hip_lib):
+    """k_prep stages 1024 compact records of clipped / inserted reads per 8192-read block in LDS (the excess takes a slower
+    path); k_cold_lane / k_ins_insert let neighbouring lanes that aim at one site add once.  Deep, clip-heavy input
+    exercises both: most reads clipped, thousands of reads over every site."""
+    from kindel_amd import synth
+    batch = synth.to_numpy(synth.short_reads([2500, 1200], 2500, seed=13, clip_p=0.6, indel_p=0.3))
+    assert len(batch["contig"]) > 3 * 8192
+    for mode in (N.KD_MODE_AUTO, N.KD_MODE_STRIP):
+        P.assert_matches_oracle(P.Run(hip_lib, batch, mode=mode), what="mode %d" % mode)
+
+
 def test_profile_modes(hip_lib):
     """kd_profile_enable: 1 = hipEvents around every launch, 2 = only around k_window (what bench.py times with)."""
     from kindel_amd import synth
