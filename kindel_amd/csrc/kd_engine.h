@@ -227,7 +227,6 @@ struct KdEngine {
         if (n >= 0xffffffffULL) return fail(KD_E_ARG, "kd_push_batch: more than 2^32-1 reads in one batch");
         if (reinterpret_cast<uintptr_t>(B.seq4) & 15u) return fail(KD_E_ARG, "kd_push_batch_device: seq4 must be 16-byte aligned");
         int rc;
-        if (!tables_ready && (rc = prepare_tables())) return rc;
         if ((rc = ins_cleanup())) return rc;      // the last reduction's events are about to be joined by new ones
         if ((rc = ensure(b_rinfo, n * sizeof(KdRInfo))) || (rc = ensure(b_cold, n * sizeof(KdColdRec))) ||
             (rc = ensure(b_irreg, n * 4)) || (rc = ensure(b_long, n * 4)) || (rc = ensure(b_readev, n * 4)) ||
@@ -250,7 +249,14 @@ struct KdEngine {
         if (rt.launch("k_prep", k_prep, prep_grid, KD_BLOCK, 0, R, T, rinfo, cold, irreg, lng, (uint32_t *)b_readev.p,
                       (kd_u64 *)b_readpool.p, d_status))
             return hipfail("k_prep");
-        if ((rc = fetch_status())) return rc;
+        // k_prep touches no table: the first batch's table zeroing is queued BEHIND it and behind the status copy, so that
+        // the host's wait for the copy (a round trip of ~30 us) passes while the memset runs
+        if (rt.d2h_small_begin(d_status, KDS_COUNT * 8)) return hipfail("status d2h");
+        if (!tables_ready) {
+            if ((rc = prepare_tables())) return rc;
+            T = tabs();      // (the tables may just have been allocated: k_prep only used the contig geometry of T)
+        }
+        if (rt.d2h_small_end(h_status.data(), KDS_COUNT * 8)) return hipfail("status d2h");
         const uint64_t n_long = h_status[KDS_B_N_LONG];
         if (n_long) {
             if ((rc = ensure(b_ckpt, (size_t)n_long * KD_BLOCK * sizeof(KdCkpt))) ||
@@ -483,6 +489,10 @@ struct KdEngine {
         KdIns I = insdesc();
         auto reduce = [&](int attempt) -> int {
             H.seed = 0x9e3779b97f4a7c15ULL * (uint64_t)(attempt + 1);
+            // KD_TEST_INS_COLLIDE=1 (tests): two possible keys in the first attempt, so that different insertions share a key, the
+            // byte-for-byte verification fails and the re-seeded second attempt has to put everything right
+            const bool collide = getenv("KD_TEST_INS_COLLIDE") != nullptr;
+            H.key_mask = (collide && attempt == 0) ? 0x2ULL : ~0ULL;
             // grids are sized by the upper bound n_ev; the kernels stop at the device-side count of selected events
             const unsigned ge = (unsigned)((n_ev + KD_BLOCK - 1) / KD_BLOCK), g4 = (unsigned)((n_ev + KD_INS_CHUNK - 1) / KD_INS_CHUNK);
             if (rt.memset(d_status + KDS_INS_COLLISION, 0, 8)) return hipfail("finalize: memset status");
@@ -490,6 +500,12 @@ struct KdEngine {
             if (rt.launch("k_ins_verify_max", k_ins_verify_max, g4, KD_BLOCK, 0, I, H, (kd_u64)n_ev, (kd_u64 *)b_best.p, d_status))
                 return hipfail("k_ins_verify_max");
             ins_dirty_ev = n_ev; ins_dirty_tab = H;
+            return KD_OK;
+        };
+        auto pick = [&]() -> int {
+            const unsigned ge = (unsigned)((n_ev + KD_INS_CHUNK - 1) / KD_INS_CHUNK);
+            if (rt.launch("k_ins_pick", k_ins_pick, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev, (const kd_u64 *)b_best.p, (uint32_t *)b_win.p))
+                return hipfail("k_ins_pick");
             return KD_OK;
         };
         if (n_ev) {
@@ -513,6 +529,9 @@ struct KdEngine {
                 return hipfail("k_ins_flag / k_ins_filter");
             if ((rc = reduce(0))) return rc;
             launched = true;
+            // the winners are picked BEFORE the verification result is known to the host (one round trip less on the critical
+            // path); should the verification have failed -- a 64-bit hash collision, never seen -- everything is redone below
+            if ((rc = pick())) return rc;
         }
         // ONE status read-back: deferred reference exceptions, buffer overruns and the hash verification
         if ((rc = fetch_status())) return rc;
@@ -550,11 +569,8 @@ struct KdEngine {
         if (launched) {
             for (int attempt = 1; h_status[KDS_INS_COLLISION] != 0; attempt++) {   // a 64-bit hash collision (never seen): re-seed
                 if (attempt >= 8) return fail(KD_E_INTERNAL, "insertion hash: repeated 64-bit collisions");
-                if ((rc = ins_cleanup()) || (rc = reduce(attempt)) || (rc = fetch_status())) return rc;
+                if ((rc = ins_cleanup()) || (rc = reduce(attempt)) || (rc = pick()) || (rc = fetch_status())) return rc;
             }
-            const unsigned ge = (unsigned)((n_ev + KD_INS_CHUNK - 1) / KD_INS_CHUNK);
-            if (rt.launch("k_ins_pick", k_ins_pick, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev, (const kd_u64 *)b_best.p, (uint32_t *)b_win.p))
-                return hipfail("k_ins_pick");
         }
         finalized = true; have_cns = false; have_inskeys = false;
         return KD_OK;

@@ -19,6 +19,7 @@ struct KdInsTab {
     uint32_t *ev_slot;  // [n_ev]
     kd_u64 cap;      // power of two
     kd_u64 seed;
+    kd_u64 key_mask; // ~0; the tests narrow the key for the first attempt so that the collision / re-seed path runs
     kd_u64 sites;    // G-space sites (bound of a valid event site)
 };
 // ev_slot[e] before k_ins_insert: KD_EV_TAKE = the event takes part (its site is flagged), KD_EV_DROPPED = it does not
@@ -81,7 +82,7 @@ k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev) {
         const uint8_t *p = ins.pool + ins.ev_off[e];
         h = kd_mix64(H.seed ^ ((kd_u64)site << 32 | len));
         for (uint32_t b = 0; b < len; b++) h = (h ^ p[b]) * 0x100000001b3ULL;
-        h = kd_mix64(h) | 1ULL;
+        h = (kd_mix64(h) & H.key_mask) | 1ULL;
     }
     uint32_t head_lane;
     const uint32_t run = kd_run_heads(take, h, head_lane);
@@ -176,18 +177,21 @@ k_ins_pick(KdIns ins, KdInsTab H, kd_u64 n_ev, const kd_u64 *best, uint32_t *win
 __global__ void __launch_bounds__(KD_BLOCK)
 k_ins_cleanup(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, uint32_t *win) {
     const kd_u64 k0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x;
-    uint32_t s[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD];
+    uint32_t ev[KD_INS_PER_THREAD], s[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < KD_INS_PER_THREAD; k++) {
         const kd_u64 j = k0 + (kd_u64)k * KD_BLOCK;
-        const uint32_t e = j < n_ev ? (uint32_t)j : 0xffffffffu;
-        s[k] = e != 0xffffffffu ? H.ev_slot[e] : KD_EV_DROPPED;
-        site[k] = e != 0xffffffffu ? ins.ev_site[e] : 0u;
+        ev[k] = j < n_ev ? (uint32_t)j : 0xffffffffu;
+        s[k] = ev[k] != 0xffffffffu ? H.ev_slot[ev[k]] : KD_EV_DROPPED;
+        site[k] = ev[k] != 0xffffffffu ? ins.ev_site[ev[k]] : 0u;
     }
 #pragma unroll
     for (int k = 0; k < KD_INS_PER_THREAD; k++) {
-        if (s[k] == KD_EV_DROPPED) continue;
+        if (s[k] >= KD_EV_TAKE) continue;   // dropped, or marked but never inserted
         H.key[s[k]] = 0ULL; H.cnt[s[k]] = 0u;
         best[site[k]] = 0ULL; win[site[k]] = KD_INS_NONE;
+        // the event takes part again should the reduction be repeated (re-seeded after a hash collision); a later
+        // kd_finalize marks all events afresh (k_ins_filter)
+        H.ev_slot[ev[k]] = KD_EV_TAKE;
     }
 }

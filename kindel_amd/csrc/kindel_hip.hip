@@ -44,6 +44,7 @@ struct HipRt {
     void shutdown() {
         profile_reset();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; }
+        if (ev_copy) { (void)hipEventDestroy(ev_copy); ev_copy = nullptr; }
         if (own_stream && stream) { (void)hipSetDevice(dev); (void)hipStreamDestroy(stream); }
         stream = nullptr;
     }
@@ -73,6 +74,20 @@ struct HipRt {
         if (n > 4096) return d2h(h, d, n);
         if (bad(hipMemcpyAsync(pin, d, n, hipMemcpyDeviceToHost, stream))) return 1;
         if (bad(hipStreamSynchronize(stream))) return 1;
+        memcpy(h, pin, n);
+        return 0;
+    }
+
+    // the same read-back in two halves: work queued between begin and end runs while the host waits for the copy
+    hipEvent_t ev_copy = nullptr;
+    int d2h_small_begin(const void *d, size_t n) {
+        if (n > 4096) return 1;
+        if (!pin && bad(hipHostMalloc(&pin, 4096, hipHostMallocDefault))) return 1;
+        if (!ev_copy && bad(hipEventCreateWithFlags(&ev_copy, hipEventDisableTiming))) return 1;
+        return bad(hipMemcpyAsync(pin, d, n, hipMemcpyDeviceToHost, stream)) || bad(hipEventRecord(ev_copy, stream));
+    }
+    int d2h_small_end(void *h, size_t n) {
+        if (bad(hipEventSynchronize(ev_copy))) return 1;
         memcpy(h, pin, n);
         return 0;
     }

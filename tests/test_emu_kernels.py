@@ -96,6 +96,17 @@ def test_more_clipped_reads_than_the_prep_staging_area_holds(emu_lib):
     P.assert_matches_oracle(run)
 
 
+def test_insertion_hash_collision_is_detected_and_reseeded(emu_lib, monkeypatch):
+    # KD_TEST_INS_COLLIDE: two possible keys in the first attempt -> different insertions share a slot, the byte-for-byte verification
+    # fails, kd_finalize cleans up, re-seeds and reduces again (the winners of the first attempt were picked speculatively)
+    batch = synth.to_numpy(synth.short_reads([6000], 40, seed=21, indel_p=0.5))
+    plain = P.Run(emu_lib, batch, window=512)
+    monkeypatch.setenv("KD_TEST_INS_COLLIDE", "1")
+    forced = P.Run(emu_lib, batch, window=512)
+    P.assert_matches_oracle(forced)
+    assert [forced.cns[c][0] for c in forced.order] == [plain.cns[c][0] for c in plain.order]
+
+
 def test_synthetic_long_reads(emu_lib):
     batch = synth.to_numpy(synth.long_reads([30000], 4, seed=6, median_len=3000, min_len=1000, max_len=6000))
     run = P.Run(emu_lib, batch, window=1024)

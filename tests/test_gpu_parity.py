@@ -292,6 +292,15 @@ def test_clipped_reads_beyond_the_prep_staging_area_and_deep_sites(hip_lib):
         P.assert_matches_oracle(P.Run(hip_lib, batch, mode=mode), what="mode %d" % mode)
 
 
+def test_insertion_hash_collision_is_detected_and_reseeded(hip_lib, monkeypatch):
+    """KD_TEST_INS_COLLIDE leaves two possible insertion keys in the first attempt: the verification must notice, kd_finalize
+    must clean up, re-seed and redo the reduction (incl. the speculatively picked winners)."""
+    from kindel_amd import synth
+    batch = synth.to_numpy(synth.short_reads([20000], 60, seed=21, indel_p=0.5))
+    monkeypatch.setenv("KD_TEST_INS_COLLIDE", "1")
+    P.assert_matches_oracle(P.Run(hip_lib, batch))
+
+
 def test_profile_modes(hip_lib):
     """kd_profile_enable: 1 = hipEvents around every launch, 2 = only around k_window (what bench.py times with)."""
     from kindel_amd import synth
