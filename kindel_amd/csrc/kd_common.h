@@ -177,9 +177,9 @@ struct KdCkpt {
 };
 
 // A regular short-CIGAR read with a soft clip or an insertion, as k_cold_lane needs it.  k_prep has all of this in
-// registers when it classifies the read; k_cold_lane, one lane per such read (one read in nine), would gather it again
-// through six arrays behind an index list: a chain of dependent scattered loads.  k_prep stages the records in LDS and
-// writes them out as one coalesced run per workgroup.
+// registers when it classifies the read; k_cold_lane, one lane per such read (one read in nine on C3), would gather it again
+// through six arrays behind an index list: a chain of dependent scattered loads.  Every wavefront of k_prep owns a region
+// of the record array; the lanes whose read qualifies take consecutive slots of it (ballot + mbcnt) and store.
 struct alignas(16) KdColdRec {
     kd_u64 cig_off;
     uint32_t read;      // index of the read in the batch
@@ -189,9 +189,6 @@ struct alignas(16) KdColdRec {
     uint32_t pad;
 };
 #define KD_COLD_HAS_INS 0x80000000u
-#ifndef KD_COLD_STAGE
-#define KD_COLD_STAGE 1024      // records staged in LDS per k_prep workgroup (4096 reads); the rest take the slow way
-#endif
 
 // What k_prep_long learned about one long read (one workgroup each): summed into the status words and turned into event /
 // pool / irregular-list slots by ONE small kernel (k_long_reduce) instead of ten same-address atomics per workgroup.

@@ -12,6 +12,7 @@
 #define KD_PREP_PER_THREAD 32
 #endif
 #define KD_PREP_CHUNK (KD_BLOCK * KD_PREP_PER_THREAD)
+#define KD_COLD_REGION (KD_WAVE * KD_PREP_PER_THREAD)   // record slots per wavefront of k_prep (one per read it classifies)
 #ifndef KD_PREP_UNROLL
 #define KD_PREP_UNROLL 4   // reads whose loads are issued together (a divisor of KD_PREP_PER_THREAD)
 #endif
@@ -78,25 +79,30 @@ __device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc,
 #define KD_PREP_OCC 4     // workgroups per CU the register budget is set for (5: measured slower)
 #endif
 __global__ void __launch_bounds__(KD_BLOCK, KD_PREP_OCC)
-k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *irreg_list, uint32_t *long_list,
+k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold_cnt, uint32_t *irreg_list, uint32_t *long_list,
        uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
     __shared__ kd_u64 s_red[8];       // reads, aligned, walked, ins_ops, ins_bases, n_reg, unsorted
     __shared__ uint32_t s_maxspan, s_maxlead;
     __shared__ uint32_t s_cnt[3];     // cold, irreg, long (block totals / running offsets)
     __shared__ kd_u64 s_base[5];
     __shared__ kd_u64 s_ins[2];       // insertion events / insertion bases of the block's short-CIGAR reads
-    __shared__ KdColdRec s_stage[KD_COLD_STAGE];
-    __shared__ uint32_t s_nstage;
     const uint32_t t = threadIdx.x;
     if (t < 8) s_red[t] = 0;
     if (t < 3) s_cnt[t] = 0;
     if (t < 2) s_ins[t] = 0;
-    if (t == 0) { s_maxspan = 0; s_maxlead = 0; s_nstage = 0; }
+    if (t == 0) { s_maxspan = 0; s_maxlead = 0; }
     __syncthreads();
     const kd_u64 chunk0 = (kd_u64)blockIdx.x * KD_PREP_CHUNK;
     kd_u64 a_reads = 0, a_aligned = 0, a_walked = 0, a_ins = 0, a_insb = 0, a_reg = 0, a_unsorted = 0;
-    uint32_t a_maxspan = 0, a_maxlead = 0, n_cold = 0, n_irreg = 0, n_long = 0;
-    uint32_t m_cold = 0, m_irreg = 0, m_long = 0, m_ins = 0;  // bit `it` = this thread's it-th read is in the list
+    uint32_t a_maxspan = 0, a_maxlead = 0, n_irreg = 0, n_long = 0;
+    uint32_t m_irreg = 0, m_long = 0, m_ins = 0;  // bit `it` = this thread's it-th read is in the list
+    // Compact records of the clipped / inserted reads (for k_cold_lane): every WAVEFRONT owns a region of the record array
+    // (one slot per read it classifies), the lanes whose read qualifies take consecutive slots (__ballot + mbcnt) and store
+    // straight to HBM: neighbouring records from neighbouring lanes, no atomics, no staging, no limit on how many reads
+    // are clipped.  cold_cnt[region] = records written.
+    const kd_u64 wave_region = (kd_u64)blockIdx.x * KD_WAVES_PER_BLOCK + t / KD_WAVE;
+    KdColdRec *wave_rec = cold_rec + wave_region * KD_COLD_REGION;
+    uint32_t wcount = 0;
     uint32_t c_cached = 0xffffffffu;                             // one-entry cache of the contig table
     kd_u64 cb_cached = 0;
     int64_t L_cached = 0;
@@ -126,7 +132,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *irre
         }
 #pragma unroll
         for (int u = 0; u < KD_PREP_UNROLL; u++) {
-            if (!v_ok[u]) continue;
+            const bool ok = v_ok[u];   // (no early exit for a lane past the end of the batch: the wavefront votes below)
             const int it = it0 + u;
             const kd_u64 i = chunk0 + (kd_u64)it * KD_BLOCK + t;
             const uint32_t c = v_c[u];
@@ -134,19 +140,19 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *irre
             const int64_t pos0 = v_pos[u];
             // first record of its contig in the file (any record with that RNAME counts, kindel.py:143-145): only where
             // the contig changes from one record to the next can a contig appear for the first time
-            if (i == 0 || v_pc[u] != c) atomicMin(&T.first_idx[c], rd.base_index + i);
+            if (ok && (i == 0 || v_pc[u] != c)) atomicMin(&T.first_idx[c], rd.base_index + i);
             const kd_u64 gkey = cb_cached + (kd_u64)(pos0 > 0 ? pos0 : 0);
             {   // sortedness of G-start over ALL reads of the batch (window ranges rely on it)
                 const kd_u64 pcb = v_pc[u] == c ? cb_cached : T.contig_base[v_pc[u]];
                 const kd_u64 pk = pcb + (kd_u64)(v_ppos[u] > 0 ? v_ppos[u] : 0);
-                if (pk > gkey) a_unsorted++;
+                if (ok && pk > gkey) a_unsorted++;
             }
             const int64_t sl = v_sl[u];
             const uint32_t nc = v_nc[u];
             uint32_t cls, cold = 0, lead = 0;
             kd_u64 span = 0, al = 0, n_ins_r = 0, n_insb_r = 0;
             bool has_ins = false;
-            if ((v_fl[u] & 4u) || sl <= 1) {
+            if (!ok || (v_fl[u] & 4u) || sl <= 1) {
                 cls = KD_CLS_SKIP;
             } else if (nc == 0) {
                 cls = KD_CLS_IRREG;  // CIGAR '*': k_pileup_wave raises KD_E_CIGAR
@@ -166,14 +172,16 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *irre
                 if ((uint32_t)span > a_maxspan) a_maxspan = (uint32_t)span;
                 if (lead > a_maxlead) a_maxlead = lead;
             }
-            if (cls == KD_CLS_REG && cold) {
-                const uint32_t st = atomicAdd(&s_nstage, 1u);
-                if (st < KD_COLD_STAGE) {
+            {
+                const bool is_cold = cls == KD_CLS_REG && cold != 0;
+                const unsigned long long cm = kd_ballot(is_cold);
+                if (is_cold) {
                     KdColdRec cr;
                     cr.cig_off = v_coff[u]; cr.read = (uint32_t)i; cr.pos0 = (uint32_t)pos0; cr.contig = c;
                     cr.seq_len = (uint32_t)sl; cr.n_cig = nc | (has_ins ? KD_COLD_HAS_INS : 0u); cr.pad = 0;
-                    s_stage[st] = cr;
-                } else { n_cold++; m_cold |= 1u << it; }   // staging area full: written from the last loop
+                    wave_rec[wcount + kd_mbcnt(cm)] = cr;
+                }
+                wcount += (uint32_t)kd_popcll(cm);
             }
             if (cls == KD_CLS_IRREG) { n_irreg++; m_irreg |= 1u << it; }
             if (cls == KD_CLS_LONG) { n_long++; m_long |= 1u << it; }
@@ -184,8 +192,12 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *irre
             const uint32_t plain = (cls == KD_CLS_REG && nc == 1 && !cold && al == (kd_u64)sl && span == al) ? KD_INFO_PLAIN : 0u;
             ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | plain | (has_ins ? KD_INFO_INS : 0u) | cold | cls;
             ri.lead = lead; ri.pad = 0;
-            rinfo[i] = ri;
+            if (ok) rinfo[i] = ri;
         }
+    }
+    if ((t & (KD_WAVE - 1)) == 0) {
+        cold_cnt[wave_region] = wcount;
+        if (wcount) atomicAdd(&s_cnt[0], wcount);
     }
     // block reduction through LDS atomics, then one global atomic per word per block
     if (a_reads) atomicAdd(&s_red[0], a_reads);
@@ -198,7 +210,6 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *irre
     if (a_maxspan) atomicMax(&s_maxspan, a_maxspan);
     if (a_maxlead) atomicMax(&s_maxlead, a_maxlead);
     // list slots: thread-local offset inside the block
-    uint32_t o_cold = n_cold ? atomicAdd(&s_cnt[0], n_cold) : 0;
     uint32_t o_irreg = n_irreg ? atomicAdd(&s_cnt[1], n_irreg) : 0;
     uint32_t o_long = n_long ? atomicAdd(&s_cnt[2], n_long) : 0;
     // insertion event / pool slots: thread-local offsets inside the block, one global reservation per block
@@ -219,16 +230,14 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *irre
     if (t == 8 && s_red[6]) atomicAdd(&status[KDS_B_UNSORTED], s_red[6]);
     if (t == 9 && s_maxspan) atomicMax(&status[KDS_B_MAXSPAN], (kd_u64)s_maxspan);
     if (t == 10 && s_maxlead) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)s_maxlead);
-    const uint32_t n_staged = s_nstage < KD_COLD_STAGE ? s_nstage : KD_COLD_STAGE;
-    if (t == 64) s_base[0] = (n_staged + s_cnt[0]) ? atomicAdd(&status[KDS_B_N_COLD], (kd_u64)(n_staged + s_cnt[0])) : 0;
+    if (t == 64 && s_cnt[0]) atomicAdd(&status[KDS_B_N_COLD], (kd_u64)s_cnt[0]);
     if (t == 65) s_base[1] = s_cnt[1] ? atomicAdd(&status[KDS_B_N_IRREG], (kd_u64)s_cnt[1]) : 0;
     if (t == 66) s_base[2] = s_cnt[2] ? atomicAdd(&status[KDS_B_N_LONG], (kd_u64)s_cnt[2]) : 0;
     __syncthreads();
-    for (uint32_t k = t; k < n_staged; k += KD_BLOCK) cold_rec[s_base[0] + k] = s_stage[k];   // one coalesced run
-    if (m_cold | m_irreg | m_long | m_ins) {
-        kd_u64 w_cold = s_base[0] + n_staged + o_cold, w_irreg = s_base[1] + o_irreg, w_long = s_base[2] + o_long;
+    if (m_irreg | m_long | m_ins) {
+        kd_u64 w_irreg = s_base[1] + o_irreg, w_long = s_base[2] + o_long;
         kd_u64 w_ev = s_base[3] + o_ev, w_pool = s_base[4] + o_pool;
-        for (uint32_t todo = m_cold | m_irreg | m_long | m_ins; todo; todo &= todo - 1) {
+        for (uint32_t todo = m_irreg | m_long | m_ins; todo; todo &= todo - 1) {
             const int it = __builtin_ctz(todo);
             const kd_u64 i = chunk0 + (kd_u64)it * KD_BLOCK + t;
             const uint32_t bit = 1u << it;
@@ -237,12 +246,6 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *irre
                 const kd_u64 n_b = read_pool[i];
                 read_ev[i] = (uint32_t)w_ev; read_pool[i] = w_pool;
                 w_ev += n_ev; w_pool += n_b;
-            }
-            if (m_cold & bit) {  // (rare: the metadata is read again)
-                KdColdRec cr;
-                cr.cig_off = rd.cig_off[i]; cr.read = (uint32_t)i; cr.pos0 = (uint32_t)rd.pos0[i]; cr.contig = rd.contig[i];
-                cr.seq_len = (uint32_t)rd.seq_len[i]; cr.n_cig = rd.n_cig[i] | ((m_ins & bit) ? KD_COLD_HAS_INS : 0u); cr.pad = 0;
-                cold_rec[w_cold++] = cr;
             }
             if (m_irreg & bit) irreg_list[w_irreg++] = (uint32_t)i;
             if (m_long & bit) long_list[w_long++] = (uint32_t)i;

@@ -139,10 +139,14 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
 // the insertion events, written into the slots k_prep reserved for the read.  One LANE per read of the cold
 // list.  Regular reads cannot raise and never wrap (k_prep checked), so this is plain G-space arithmetic.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const KdColdRec *rec, kd_u64 n_list, kd_u64 *status) {
-    const kd_u64 slot = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    const bool live = slot < n_list;              // (no early exit: the wavefront meets again behind the walk)
-    const KdColdRec cr = rec[live ? slot : 0];    // k_prep's record of the read: two coalesced 16-byte loads
+k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const KdColdRec *rec, const uint32_t *cold_cnt, uint32_t region_slots, kd_u64 *status) {
+    // one workgroup per record region (= per wavefront of k_prep): cnt records, usually fewer than 256
+    const uint32_t cnt = cold_cnt[blockIdx.x];
+    const KdColdRec *reg = rec + (kd_u64)blockIdx.x * region_slots;
+  for (uint32_t k0 = 0; k0 < cnt; k0 += KD_BLOCK) {     // (uniform trip count: the wavefront meets again behind each walk)
+    const uint32_t slot = k0 + threadIdx.x;
+    const bool live = slot < cnt;
+    const KdColdRec cr = reg[live ? slot : 0];    // k_prep's record of the read: two coalesced 16-byte loads
     const kd_u64 i = cr.read;
     const int64_t sl = cr.seq_len;
     const uint32_t nc = live ? (cr.n_cig & ~KD_COLD_HAS_INS) : 0u;
@@ -211,6 +215,7 @@ k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const KdColdRec *rec, kd_u64 n_list
     if ((n = kd_run_heads(g_ce != NONE, g_ce, hl))) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g_ce], n);
     if ((n = kd_run_heads(g_cs != NONE, g_cs, hl))) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g_cs], n);
     if ((n = kd_run_heads(g_in != NONE, g_in, hl))) atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g_in], n);
+  }
 }
 
 // k_cold_long: k_cold_lane's work for regular long-CIGAR reads, one WORKGROUP per read: thread t starts from

@@ -86,9 +86,9 @@ def test_synthetic_short_reads_with_planted_features(emu_lib, mode):
     assert any(chr(c).islower() for c in seqs)
 
 
-def test_more_clipped_reads_than_the_prep_staging_area_holds(emu_lib):
-    # k_prep stages the records of a workgroup's (4096 reads) clipped / inserted reads in LDS, KD_COLD_STAGE = 1024 of them:
-    # here most reads are clipped, so every workgroup overflows into the slow path
+def test_mostly_clipped_reads(emu_lib):
+    # k_prep writes a compact record for every clipped / inserted read (ballot-compacted per wavefront) and k_cold_lane walks
+    # them region by region: here most reads are clipped, regions hold several hundred records
     batch = synth.to_numpy(synth.short_reads([9000], 150, seed=11, clip_p=0.6, indel_p=0.3))
     assert len(batch["contig"]) > 8192
     run = P.Run(emu_lib, batch, window=1024)

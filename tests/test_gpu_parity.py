@@ -281,10 +281,10 @@ def test_multi_tile_items_carry_rows_between_tiles(hip_lib):
         P.assert_matches_oracle(P.Run(hip_lib, batch, window=window, slice_reads=slice_reads), what="w%d s%d" % (window, slice_reads))
 
 
-def test_clipped_reads_beyond_the_prep_staging_area_and_deep_sites(hip_lib):
-    """k_prep stages 1024 compact records of clipped / inserted reads per 8192-read block in LDS (the excess takes a slower
-    path); k_cold_lane / k_ins_insert let neighbouring lanes that aim at one site add once.  Deep, clip-heavy input
-    exercises both: most reads clipped, thousands of reads over every site."""
+def test_mostly_clipped_reads_and_deep_sites(hip_lib):
+    """k_prep writes a compact record for every clipped / inserted read (ballot-compacted per wavefront, one region of the
+    record array per wavefront), k_cold_lane walks the regions (more than one round of 256 where most reads are clipped) and
+    lets neighbouring lanes that aim at one site add once (as does k_ins_insert).  Deep, clip-heavy input exercises all of it."""
     from kindel_amd import synth
     batch = synth.to_numpy(synth.short_reads([2500, 1200], 2500, seed=13, clip_p=0.6, indel_p=0.3))
     assert len(batch["contig"]) > 3 * 8192
