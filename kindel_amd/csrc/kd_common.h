@@ -184,11 +184,13 @@ struct alignas(16) KdColdRec {
     kd_u64 cig_off;
     uint32_t read;      // index of the read in the batch
     uint32_t pos0;      // >= 0 for a regular read
-    uint32_t contig, seq_len;
-    uint32_t n_cig;     // | KD_COLD_HAS_INS
-    uint32_t pad;
+    uint32_t contig;
+    uint32_t len_ops;   // seq_len (< 2^20: longer short-CIGAR reads take the general path) | n_cig << 20 | KD_COLD_HAS_INS
+    uint32_t ev_rel;    // reads with insertions: first event slot / first pool byte, relative to the region's base
+    uint32_t pool_rel;  //   (ev_base[region], pool_base[region]: written by k_prep once the block has reserved its range)
 };
 #define KD_COLD_HAS_INS 0x80000000u
+#define KD_COLD_MAX_SEQ (1u << 20)
 
 // What k_prep_long learned about one long read (one workgroup each): summed into the status words and turned into event /
 // pool / irregular-list slots by ONE small kernel (k_long_reduce) instead of ten same-address atomics per workgroup.

@@ -48,7 +48,7 @@ struct KdEngine {
         void *p = nullptr;
         size_t cap = 0;
     };
-    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_ckpt, b_seginfo, b_longacc, b_coldcnt;
+    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_ckpt, b_seginfo, b_longacc, b_coldcnt, b_coldev, b_coldpool;
     Buf b_stage[9];
     Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
     uint64_t ev_cap = 0, pool_cap = 0;
@@ -143,7 +143,7 @@ struct KdEngine {
     }
 
     void destroy() {
-        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_itemwin, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ckpt, &b_seginfo, &b_longacc, &b_coldcnt, &b_ev_site, &b_ev_len,
+        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_itemwin, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ckpt, &b_seginfo, &b_longacc, &b_coldcnt, &b_coldev, &b_coldpool, &b_ev_site, &b_ev_len,
                       &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_win, &b_flag, &b_cns, &b_changes,
                       &b_tilesum, &b_tilemm, &b_tileoff, &b_coff};
         for (Buf *b : all) release(*b);
@@ -231,6 +231,7 @@ struct KdEngine {
         const unsigned prep_regions = prep_grid * KD_WAVES_PER_BLOCK;     // one region of compact cold-read records per wavefront of k_prep
         if ((rc = ins_cleanup())) return rc;      // the last reduction's events are about to be joined by new ones
         if ((rc = ensure(b_rinfo, n * sizeof(KdRInfo))) || (rc = ensure(b_cold, (size_t)prep_regions * KD_COLD_REGION * sizeof(KdColdRec))) || (rc = ensure(b_coldcnt, (size_t)prep_regions * 4)) ||
+            (rc = ensure(b_coldev, (size_t)prep_regions * 8)) || (rc = ensure(b_coldpool, (size_t)prep_regions * 8)) ||
             (rc = ensure(b_irreg, n * 4)) || (rc = ensure(b_long, n * 4)) || (rc = ensure(b_readev, n * 4)) ||
             (rc = ensure(b_readpool, n * 8)))
             return rc;
@@ -247,7 +248,7 @@ struct KdEngine {
             return hipfail("push: memset status");      // (the first batch after kd_reset finds them zeroed by k_reset)
         batch_status_clean = false;
         const uint64_t ev_before = h_status[KDS_N_EV], pool_before = h_status[KDS_POOL];  // as of the last fetch
-        if (rt.launch("k_prep", k_prep, prep_grid, KD_BLOCK, 0, R, T, rinfo, cold, (uint32_t *)b_coldcnt.p, irreg, lng, (uint32_t *)b_readev.p,
+        if (rt.launch("k_prep", k_prep, prep_grid, KD_BLOCK, 0, R, T, rinfo, cold, (uint32_t *)b_coldcnt.p, (kd_u64 *)b_coldev.p, (kd_u64 *)b_coldpool.p, irreg, lng, (uint32_t *)b_readev.p,
                       (kd_u64 *)b_readpool.p, d_status))
             return hipfail("k_prep");
         // k_prep touches no table: the first batch's table zeroing is queued BEHIND it and behind the status copy, so that
@@ -423,7 +424,7 @@ struct KdEngine {
                 return rc;
             if (n_cold &&
                 rt.launch("k_cold_lane", k_cold_lane, prep_regions, KD_BLOCK, 0, R, T, I, (const KdColdRec *)cold,
-                          (const uint32_t *)b_coldcnt.p, (uint32_t)KD_COLD_REGION, d_status))
+                          (const uint32_t *)b_coldcnt.p, (const kd_u64 *)b_coldev.p, (const kd_u64 *)b_coldpool.p, (uint32_t)KD_COLD_REGION, d_status))
                 return hipfail("k_cold_lane");
             if (n_long &&
                 rt.launch("k_cold_long", k_cold_long, (unsigned)n_long, KD_BLOCK, 0, R, T, I, (const KdRInfo *)rinfo,
@@ -435,6 +436,11 @@ struct KdEngine {
                           (const uint32_t *)irreg, (kd_u64)n_irreg, (const KdRInfo *)rinfo, d_status))
                 return hipfail("k_pileup_wave_irreg");
         } else {
+            // (k_pileup_wave looks a read's insertion slots up by read index: spell the regular reads' out)
+            if (n_cold && rt.launch("k_cold_slots", k_cold_slots, prep_regions, KD_BLOCK, 0, (const KdColdRec *)cold, (const uint32_t *)b_coldcnt.p,
+                                    (const kd_u64 *)b_coldev.p, (const kd_u64 *)b_coldpool.p, (uint32_t)KD_COLD_REGION, (uint32_t *)b_readev.p,
+                                    (kd_u64 *)b_readpool.p))
+                return hipfail("k_cold_slots");
             if (rt.launch("k_pileup_wave_all", k_pileup_wave<true, true>,
                           (unsigned)((n + KD_WAVES_PER_BLOCK - 1) / KD_WAVES_PER_BLOCK), KD_BLOCK, 0, R, T, I,
                           (const uint32_t *)nullptr, (kd_u64)n, (const KdRInfo *)rinfo, d_status))

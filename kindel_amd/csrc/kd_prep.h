@@ -79,7 +79,8 @@ __device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc,
 #define KD_PREP_OCC 4     // workgroups per CU the register budget is set for (5: measured slower)
 #endif
 __global__ void __launch_bounds__(KD_BLOCK, KD_PREP_OCC)
-k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold_cnt, uint32_t *irreg_list, uint32_t *long_list,
+k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold_cnt, kd_u64 *cold_evbase, kd_u64 *cold_poolbase,
+       uint32_t *irreg_list, uint32_t *long_list,
        uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
     __shared__ kd_u64 s_red[8];       // reads, aligned, walked, ins_ops, ins_bases, n_reg, unsorted
     __shared__ uint32_t s_maxspan, s_maxlead;
@@ -94,6 +95,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
     __syncthreads();
     const kd_u64 chunk0 = (kd_u64)blockIdx.x * KD_PREP_CHUNK;
     kd_u64 a_reads = 0, a_aligned = 0, a_walked = 0, a_ins = 0, a_insb = 0, a_reg = 0, a_unsorted = 0;
+    kd_u64 a_ins_tail = 0, a_insb_tail = 0;
     uint32_t a_maxspan = 0, a_maxlead = 0, n_irreg = 0, n_long = 0;
     uint32_t m_irreg = 0, m_long = 0, m_ins = 0;  // bit `it` = this thread's it-th read is in the list
     // Compact records of the clipped / inserted reads (for k_cold_lane): every WAVEFRONT owns a region of the record array
@@ -103,6 +105,11 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
     const kd_u64 wave_region = (kd_u64)blockIdx.x * KD_WAVES_PER_BLOCK + t / KD_WAVE;
     KdColdRec *wave_rec = cold_rec + wave_region * KD_COLD_REGION;
     uint32_t wcount = 0;
+    // The insertion-event slots and pool bytes of these reads are handed out here too: a wavefront-wide prefix sum per read
+    // gives every read its offset in the wavefront's range, the range's base follows when the block has reserved its share
+    // (one returning atomic per block, as before).  Only irregular reads with insertions (rare) still go through the last loop.
+    uint32_t w_ev_total = 0;
+    kd_u64 w_pool_total = 0;
     uint32_t c_cached = 0xffffffffu;                             // one-entry cache of the contig table
     kd_u64 cb_cached = 0;
     int64_t L_cached = 0;
@@ -151,7 +158,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
             const uint32_t nc = v_nc[u];
             uint32_t cls, cold = 0, lead = 0;
             kd_u64 span = 0, al = 0, n_ins_r = 0, n_insb_r = 0;
-            bool has_ins = false;
+            bool has_ins = false, has_ins_tail = true;   // has_ins_tail: the read's slots come from the last loop
             if (!ok || (v_fl[u] & 4u) || sl <= 1) {
                 cls = KD_CLS_SKIP;
             } else if (nc == 0) {
@@ -166,7 +173,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
                 n_ins_r = s.n_ins; n_insb_r = s.ins_bases;
                 a_reads++; a_aligned += s.aligned; a_walked += s.walked; a_ins += s.n_ins; a_insb += s.ins_bases;
             }
-            if (span > 0x07ffffffULL) { cls = KD_CLS_IRREG; span = 0; }
+            if (span > 0x07ffffffULL || (cls == KD_CLS_REG && sl >= (int64_t)KD_COLD_MAX_SEQ)) { cls = KD_CLS_IRREG; span = 0; }
             if (cls == KD_CLS_REG) {
                 a_reg++;
                 if ((uint32_t)span > a_maxspan) a_maxspan = (uint32_t)span;
@@ -175,17 +182,38 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
             {
                 const bool is_cold = cls == KD_CLS_REG && cold != 0;
                 const unsigned long long cm = kd_ballot(is_cold);
+                const bool reg_ins = is_cold && has_ins;
+                uint32_t ev_rel = 0, pool_rel = 0;
+                if (kd_ballot(reg_ins)) {   // (wave-uniform) inclusive scan of (pool bytes << 16 | events): <= 16 events per read
+                    const kd_u64 v = reg_ins ? ((kd_u64)n_insb_r << 16) | n_ins_r : 0ULL;
+                    kd_u64 incl = v;
+#pragma unroll
+                    for (uint32_t d = 1; d < KD_WAVE; d <<= 1) {
+                        const kd_u64 up = kd_shfl_up64(incl, d);
+                        if ((t & (KD_WAVE - 1)) >= d) incl += up;
+                    }
+                    const kd_u64 tot = kd_shfl64(incl, KD_WAVE - 1);
+                    ev_rel = w_ev_total + (uint32_t)((incl - v) & 0xffffu);
+                    pool_rel = (uint32_t)(w_pool_total + ((incl - v) >> 16));
+                    w_ev_total += (uint32_t)(tot & 0xffffu);
+                    w_pool_total += tot >> 16;
+                }
                 if (is_cold) {
                     KdColdRec cr;
                     cr.cig_off = v_coff[u]; cr.read = (uint32_t)i; cr.pos0 = (uint32_t)pos0; cr.contig = c;
-                    cr.seq_len = (uint32_t)sl; cr.n_cig = nc | (has_ins ? KD_COLD_HAS_INS : 0u); cr.pad = 0;
+                    cr.len_ops = (uint32_t)sl | (nc << 20) | (has_ins ? KD_COLD_HAS_INS : 0u);
+                    cr.ev_rel = ev_rel; cr.pool_rel = pool_rel;
                     wave_rec[wcount + kd_mbcnt(cm)] = cr;
                 }
                 wcount += (uint32_t)kd_popcll(cm);
+                if (reg_ins) has_ins_tail = false;
             }
             if (cls == KD_CLS_IRREG) { n_irreg++; m_irreg |= 1u << it; }
             if (cls == KD_CLS_LONG) { n_long++; m_long |= 1u << it; }
-            if (has_ins) { m_ins |= 1u << it; read_ev[i] = (uint32_t)n_ins_r; read_pool[i] = n_insb_r; }   // counts, see the last loop
+            if (has_ins && has_ins_tail) {   // (an irregular read with insertions) counts, see the last loop
+                m_ins |= 1u << it; read_ev[i] = (uint32_t)n_ins_r; read_pool[i] = n_insb_r;
+                a_ins_tail += n_ins_r; a_insb_tail += n_insb_r;
+            }
             KdRInfo ri;
             ri.gstart = (uint32_t)gkey;
             // plain: the whole read is ONE aligned run: a single op whose aligned length is the read length
@@ -195,9 +223,11 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
             if (ok) rinfo[i] = ri;
         }
     }
+    kd_u64 wave_off_ev = 0, wave_off_pool = 0;     // the wavefront's range inside the block's reservation (lane 0)
     if ((t & (KD_WAVE - 1)) == 0) {
         cold_cnt[wave_region] = wcount;
         if (wcount) atomicAdd(&s_cnt[0], wcount);
+        if (w_ev_total) { wave_off_ev = atomicAdd(&s_ins[0], (kd_u64)w_ev_total); wave_off_pool = atomicAdd(&s_ins[1], w_pool_total); }
     }
     // block reduction through LDS atomics, then one global atomic per word per block
     if (a_reads) atomicAdd(&s_red[0], a_reads);
@@ -214,8 +244,8 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
     uint32_t o_long = n_long ? atomicAdd(&s_cnt[2], n_long) : 0;
     // insertion event / pool slots: thread-local offsets inside the block, one global reservation per block
     // (a global counter bumped per event serialises at ~11 ns per returning atomic on one address)
-    const kd_u64 o_ev = a_ins ? atomicAdd(&s_ins[0], a_ins) : 0;
-    const kd_u64 o_pool = a_ins ? atomicAdd(&s_ins[1], a_insb) : 0;
+    const kd_u64 o_ev = a_ins_tail ? atomicAdd(&s_ins[0], a_ins_tail) : 0;
+    const kd_u64 o_pool = a_ins_tail ? atomicAdd(&s_ins[1], a_insb_tail) : 0;
     __syncthreads();
     // one global atomic per word and block, issued by DIFFERENT threads (a dozen returning atomics in a row from one
     // thread are a dozen round trips the other 255 threads wait for)
@@ -234,6 +264,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
     if (t == 65) s_base[1] = s_cnt[1] ? atomicAdd(&status[KDS_B_N_IRREG], (kd_u64)s_cnt[1]) : 0;
     if (t == 66) s_base[2] = s_cnt[2] ? atomicAdd(&status[KDS_B_N_LONG], (kd_u64)s_cnt[2]) : 0;
     __syncthreads();
+    if ((t & (KD_WAVE - 1)) == 0) { cold_evbase[wave_region] = s_base[3] + wave_off_ev; cold_poolbase[wave_region] = s_base[4] + wave_off_pool; }
     if (m_irreg | m_long | m_ins) {
         kd_u64 w_irreg = s_base[1] + o_irreg, w_long = s_base[2] + o_long;
         kd_u64 w_ev = s_base[3] + o_ev, w_pool = s_base[4] + o_pool;

@@ -139,25 +139,26 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
 // the insertion events, written into the slots k_prep reserved for the read.  One LANE per read of the cold
 // list.  Regular reads cannot raise and never wrap (k_prep checked), so this is plain G-space arithmetic.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const KdColdRec *rec, const uint32_t *cold_cnt, uint32_t region_slots, kd_u64 *status) {
+k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const KdColdRec *rec, const uint32_t *cold_cnt, const kd_u64 *cold_evbase,
+            const kd_u64 *cold_poolbase, uint32_t region_slots, kd_u64 *status) {
     // one workgroup per record region (= per wavefront of k_prep): cnt records, usually fewer than 256
     const uint32_t cnt = cold_cnt[blockIdx.x];
     const KdColdRec *reg = rec + (kd_u64)blockIdx.x * region_slots;
+    const kd_u64 ev_base = cold_evbase[blockIdx.x], pool_base = cold_poolbase[blockIdx.x];   // the region's insertion slots
   for (uint32_t k0 = 0; k0 < cnt; k0 += KD_BLOCK) {     // (uniform trip count: the wavefront meets again behind each walk)
     const uint32_t slot = k0 + threadIdx.x;
     const bool live = slot < cnt;
     const KdColdRec cr = reg[live ? slot : 0];    // k_prep's record of the read: two coalesced 16-byte loads
     const kd_u64 i = cr.read;
-    const int64_t sl = cr.seq_len;
-    const uint32_t nc = live ? (cr.n_cig & ~KD_COLD_HAS_INS) : 0u;
+    const int64_t sl = cr.len_ops & (KD_COLD_MAX_SEQ - 1u);
+    const uint32_t nc = live ? ((cr.len_ops >> 20) & 31u) : 0u;
     const uint32_t c = cr.contig;
-    // everything the walk may need is requested up front (first four CIGAR words in one load, the read's event /
-    // pool slots): the kernel is a chain of dependent round trips otherwise
+    // everything the walk may need is requested up front (first four CIGAR words in one load, the read's packed bases'
+    // offset): the kernel is a chain of dependent round trips otherwise
     const uint32_t *cg = rd.cigar + cr.cig_off;
     const KdChunk pre = kd_load_cigar4(cg, 0u, nc);
     const uint8_t *seq = rd.seq4 + rd.seq_off[i];
-    const bool has_ins = (cr.n_cig & KD_COLD_HAS_INS) != 0;
-    kd_u64 ev_next = has_ins ? ins.read_ev[i] : 0, pool_next = has_ins ? ins.read_pool[i] : 0;
+    kd_u64 ev_next = ev_base + cr.ev_rel, pool_next = pool_base + cr.pool_rel;   // (unused by a read without insertions)
     const int64_t L = T.contig_len[c];
     const kd_u64 cb = T.contig_base[c];
     uint32_t *tab = T.tab;
@@ -216,6 +217,21 @@ k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const KdColdRec *rec, const uint32_
     if ((n = kd_run_heads(g_cs != NONE, g_cs, hl))) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g_cs], n);
     if ((n = kd_run_heads(g_in != NONE, g_in, hl))) atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g_in], n);
   }
+}
+
+// k_cold_slots: the same records -> read_ev[] / read_pool[] of the reads with insertions.  Only for the paths that walk regular
+// reads through k_pileup_wave (KD_MODE_GLOBAL, a batch without window work), which looks a read's slots up by read index.
+__global__ void __launch_bounds__(KD_BLOCK)
+k_cold_slots(const KdColdRec *rec, const uint32_t *cold_cnt, const kd_u64 *cold_evbase, const kd_u64 *cold_poolbase,
+             uint32_t region_slots, uint32_t *read_ev, kd_u64 *read_pool) {
+    const uint32_t cnt = cold_cnt[blockIdx.x];
+    const KdColdRec *reg = rec + (kd_u64)blockIdx.x * region_slots;
+    for (uint32_t k = threadIdx.x; k < cnt; k += KD_BLOCK) {
+        const KdColdRec cr = reg[k];
+        if (!(cr.len_ops & KD_COLD_HAS_INS)) continue;
+        read_ev[cr.read] = (uint32_t)(cold_evbase[blockIdx.x] + cr.ev_rel);
+        read_pool[cr.read] = cold_poolbase[blockIdx.x] + cr.pool_rel;
+    }
 }
 
 // k_cold_long: k_cold_lane's work for regular long-CIGAR reads, one WORKGROUP per read: thread t starts from

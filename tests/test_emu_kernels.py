@@ -107,6 +107,24 @@ def test_insertion_hash_collision_is_detected_and_reseeded(emu_lib, monkeypatch)
     assert [forced.cns[c][0] for c in forced.order] == [plain.cns[c][0] for c in plain.order]
 
 
+def test_megabase_read_with_a_short_cigar_takes_the_general_path(emu_lib):
+    # a read of >= 2^20 bases with a handful of CIGAR ops (an assembly contig aligned to its reference) is not a "short read":
+    # its insertion offsets would not fit k_prep's compact records, so it is walked by k_pileup_wave like an irregular read
+    import random
+    rng = random.Random(4)
+    L = (1 << 20) + 5000
+    seq = "".join(rng.choice("ACGT") for _ in range(L + 3))
+    sam = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:big\tLN:%d\n" % (L + 100)
+    sam += "asm\t0\tbig\t11\t60\t600000M3I%dM\t*\t0\t0\t%s\t*\n" % (L - 600000, seq)
+    for k in range(40):     # ordinary reads over the insertion site
+        p = 600000 - 60 + k
+        sam += "r%d\t0\tbig\t%d\t60\t100M\t*\t0\t0\t%s\t*\n" % (k, p + 11, seq[p: p + 100])
+    batch = P.sam_to_batch(sam)
+    run = P.Run(emu_lib, batch)
+    assert run.info["irregular"] >= 1
+    P.assert_matches_oracle(run)
+
+
 def test_synthetic_long_reads(emu_lib):
     batch = synth.to_numpy(synth.long_reads([30000], 4, seed=6, median_len=3000, min_len=1000, max_len=6000))
     run = P.Run(emu_lib, batch, window=1024)
