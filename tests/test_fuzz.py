@@ -29,6 +29,16 @@ def test_fuzz_wild_reads_emulated(emu_lib):
     assert out["raise"] >= 2 and out["ok"] >= 2
 
 
+@pytest.mark.parametrize("n_reads", [64, 65, 2049, 8192, 8193, 17000])
+def test_fuzz_batch_sizes_around_the_prep_block_emulated(emu_lib, n_reads):
+    """k_prep classifies 8192 reads per workgroup, 2048 per wavefront, and hands out record slots / insertion slots with
+    wavefront-wide votes and prefix sums in which lanes past the end of the batch take part: sizes around those boundaries."""
+    rng = np.random.default_rng(7000 + n_reads)
+    batch = fuzz.random_batch(rng, n_reads, contig_lens=(5000, 3000, 800), wild=0.0 if n_reads % 3 else 0.02, sort=bool(n_reads & 1))
+    for mode in (N.KD_MODE_GLOBAL, N.KD_MODE_AUTO):
+        assert fuzz.check_engine(emu_lib, batch, mode, window=[64, 256, 640][n_reads % 3], slice_reads=[0, 16][n_reads % 2]) in ("ok", "raise")
+
+
 def _long_campaign(lib, seeds, n_reads):
     """Reads with hundreds of ops (clips at both ends, indels, N/H/P) on contigs that hold them: the long-read
     path (k_prep_long checkpoints, k_window's segment pass, k_cold_long), sorted and unsorted, two window sizes."""
