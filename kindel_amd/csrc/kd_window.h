@@ -137,18 +137,35 @@ __device__ __forceinline__ void kd_add8_masked(uint32_t *hist0, uint32_t v, int3
         atomicAdd(reinterpret_cast<uint32_t *>(a), (b & 1) ? ((mo >> b) & vq) : ((me >> b) & vp));
     }
 }
-// one 16-byte chunk (query bases xs .. xs+31) against the live query range [lo, hi) of a segment
+// one 16-byte chunk (query bases xs .. xs+31) against the live query range [lo, hi) of a segment: the live bases as ONE
+// 32-bit mask, one pointer pair for the chunk (its dwords' counters sit at compile-time offsets: 4 site pairs per dword,
+// and the parity of the first site is the same for all four), dwords without a live base skipped
 __device__ __forceinline__ void kd_add_chunk_masked(uint32_t *hist0, const KdChunk &cur, int32_t xs, int32_t lo,
                                                     int32_t hi, int32_t sx, uint32_t gb) {
+    int32_t l = lo - xs, h = hi - xs;
+    l = l < 0 ? 0 : l;
+    h = h > 32 ? 32 : h;
+    if (h <= l) return;
+    const uint32_t live = (0xffffffffu >> (32 - h)) & (0xffffffffu << l);   // 0 <= l < h <= 32
+    const int32_t s0 = sx + xs;
+    const int32_t p = s0 & 1;
+    unsigned char *hb = reinterpret_cast<unsigned char *>(hist0) + KD_MUL24S(s0 >> 1, KD_HPITCHB) + gb;
+    unsigned char *hq = hb + KD_HPITCHB * p;
+    const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
     const uint32_t dw[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-        const int32_t x0 = xs + 8 * d;
-        int32_t l = lo - x0, h = hi - x0;
-        if (h <= 0 || l >= 8) continue;
-        l = l < 0 ? 0 : l;
-        h = h > 8 ? 8 : h;
-        kd_add8_masked(hist0, dw[d], sx + x0, (0xffu >> (8 - h)) & (0xffu << l), gb);
+        const uint32_t m = (live >> (8 * d)) & 0xffu;
+        if (!m) continue;
+        const uint32_t me = m << (16 * p), mo = m << (16 - 16 * p);   // bit b of m moved onto the add value's bit
+        uint32_t rh, rl;
+        kd_codes8(dw[d], rh, rl);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint32_t code = (((b & 1) ? rl : rh) >> (8 * (b >> 1))) & 0xffu;
+            unsigned char *a = ((b & 1) ? hq : hb) + code + KD_HPITCHB * (4 * d + (b >> 1));
+            atomicAdd(reinterpret_cast<uint32_t *>(a), (b & 1) ? ((mo >> b) & vq) : ((me >> b) & vp));
+        }
     }
 }
 
