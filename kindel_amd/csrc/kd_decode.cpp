@@ -367,6 +367,10 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
                 err = "truncated BAM record"; return false;
             }
             const uint8_t *r = d.data() + q + 4;
+            // the chain of block_size fields is a pointer chase through freshly inflated memory: ask for the lines a few
+            // records ahead (the records are back to back, so "ahead in bytes" is "ahead in the chain")
+            __builtin_prefetch(r + 1024);
+            __builtin_prefetch(r + 1088);
             const int32_t refid = (int32_t)rd32(r);
             n_rec++;
             if (refid >= 0) {
@@ -418,7 +422,10 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
         guess[t] = q;
         pok[t] = walk(q, range_end(t), part[t], part_nrec[t], stop[t], perr[t], &part_sums[2 * t]) ? 1 : 0;
     };
+    static const bool trace_parse = getenv("KD_DECODE_TRACE") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
     pool().run(nt1, nt1, work1);
+    const auto tp1 = std::chrono::steady_clock::now();
     // verify the hand-offs left to right; re-walk what a wrong guess (or an error seen from a wrong start) spoiled
     size_t p = o;
     for (unsigned t = 0; t < nt1; t++) {
@@ -445,8 +452,11 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
     // pass 2 (parallel, one worker per range): every record writes its own slots of the SoA arrays
     auto fill = [&](unsigned t) {
         size_t k = k_at[t], so = sq_at[t], co = cg_at[t];
-        for (const Rec &rc : part[t]) {
+        const std::vector<Rec> &pt = part[t];
+        for (size_t ri = 0; ri < pt.size(); ri++) {
+            const Rec &rc = pt[ri];
             const uint8_t *r = d.data() + rc.at;
+            if (ri + 6 < pt.size()) { const uint8_t *nx = d.data() + pt[ri + 6].at; __builtin_prefetch(nx); __builtin_prefetch(nx + 64); }
             const uint32_t l_rn = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
             f.contig[k] = rd32(r);
             f.pos0[k] = (int32_t)rd32(r + 4);
@@ -464,7 +474,14 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
             k++; so += sb; co += rc.nc;
         }
     };
+    const auto tp2 = std::chrono::steady_clock::now();
     pool().run(nt1, nt1, fill);
+    if (trace_parse) {
+        const auto tp3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "kd parse: %u ranges: walk %.2f ms, hand-offs + prefix + resize %.2f ms, fill %.2f ms\n", nt1, ms(tp0, tp1), ms(tp1, tp2),
+                ms(tp2, tp3));
+    }
     return KD_OK;
 }
 
