@@ -299,7 +299,16 @@ int parse_bam_header(const uint8_t *d, size_t n, std::vector<std::string> &names
 // The records of d[o, n) -> the SoA arrays of f (replaced, not appended).  final: the stream ends at n, a cut-off record
 // is an error; otherwise the walk stops in front of it and *consumed tells where (the caller carries the rest over into
 // the next chunk).
-int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, int n_threads, bool final, size_t *consumed) {
+// Ranges of the record stream that are PRODUCED by the worker that then walks them (kd_stream: a range = a run of whole BGZF
+// blocks, inflated by the worker itself, so that the block_size chain is followed through memory the same core just wrote --
+// walking ranges other cores had inflated cost 240 ns per record on the GPU boxes' hosts, more CPU time than the inflate).
+struct RangePlan {
+    std::vector<size_t> bound;               // range t = bytes [bound[t], bound[t + 1]) of d; bound[0] = first record, bound.back() = d.size()
+    std::function<bool(unsigned)> make;      // make(t): bring the bytes of range t into d; false = failed
+};
+
+int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, int n_threads, bool final, size_t *consumed,
+                      const RangePlan *plan = nullptr) {
     const size_t n = d.size();
     // pass 1 (touches 4 + 20 bytes per record): follow the block_size chain, record where every kept record starts and
     // the running totals of packed-base bytes / CIGAR words.  The chain is sequential by nature (a record's length
@@ -343,7 +352,11 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
         }
         return n_cig;
     };
-    auto plausible = [&](size_t q) -> size_t {      // 0, or the offset of the record after the one at q
+    // While a worker walks its own range the bytes behind the range's end may not exist yet (lim < n): a record that starts
+    // within KD_EDGE bytes of lim is left to the hand-off pass below, which runs when everything is there.
+    constexpr size_t KD_EDGE = 4 + 32 + 255 + 8, KD_UNKNOWN = ~(size_t)0;
+    auto plausible = [&](size_t q, size_t lim) -> size_t {      // 0, KD_UNKNOWN, or the offset of the record after the one at q
+        if (lim < n && q + KD_EDGE > lim) return KD_UNKNOWN;
         if (q + 36 > n) return 0;
         const uint32_t bs = rd32(d.data() + q);
         if (bs < 32 || q + 4 + (size_t)bs > n) return 0;
@@ -356,10 +369,11 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
         return q + 4 + bs;
     };
     // (sums[0] / sums[1]: packed-base bytes / CIGAR words of the kept records, for the prefix over the ranges)
-    auto walk = [&](size_t p0, size_t p_end, std::vector<Rec> &out, uint64_t &n_rec, size_t &stop, std::string &err, size_t *sums) -> bool {
+    auto walk = [&](size_t p0, size_t p_end, size_t lim, std::vector<Rec> &out, uint64_t &n_rec, size_t &stop, std::string &err, size_t *sums) -> bool {
         size_t q = p0;
         sums[0] = 0; sums[1] = 0;
         while (q < p_end && q + 4 <= n) {
+            if (lim < n && q + KD_EDGE > lim) break;         // header / name / CIGAR words may lie behind what exists: later
             const uint32_t bs = rd32(d.data() + q);
             if (bs < 32) { err = "malformed BAM record"; return false; }
             if (q + 4 + (size_t)bs > n) {
@@ -377,6 +391,7 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
                 if ((uint32_t)refid >= n_ref) { err = "BAM record with refID out of range"; return false; }
                 const uint32_t l_rn = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
                 if (32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 > bs) { err = "malformed BAM record"; return false; }
+                if (lim < n && n_cig == 2 && q + 4 + (size_t)bs > lim) { n_rec--; break; }   // (a placeholder CIGAR reads the whole record)
                 uint64_t cg_at = 0;
                 const uint32_t nc = real_cigar(r, bs, l_rn, n_cig, l_seq, &cg_at);
                 out.push_back({q + 4, (uint32_t)(((size_t)l_seq + 1) / 2), nc, cg_at});
@@ -391,6 +406,7 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
     size_t min_range = 1u << 20;                                      // >= 1 MB of records per range ...
     if (const char *e = getenv("KD_DECODE_RANGE_BYTES")) min_range = std::max<size_t>(64, strtoull(e, nullptr, 10));   // ... tests: small
     nt1 = (unsigned)std::max<size_t>(1, std::min<size_t>(nt1, (n - std::min(o, n)) / min_range));
+    if (plan) nt1 = (unsigned)(plan->bound.size() - 1);
     constexpr int KD_SPEC_CHAIN = 16;
     // (kept across calls by the calling thread: a stream parses ~70 chunks, and fresh vectors of this size come from mmap --
     //  page faults and munmap for every chunk)
@@ -404,23 +420,34 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
     std::vector<std::string> perr(nt1);
     std::vector<char> pok(nt1, 1);
     const size_t span = (n - o + nt1 - 1) / nt1;
-    auto range_end = [&](unsigned t) { return t + 1 == nt1 ? n : std::min(n, o + (size_t)(t + 1) * span); };
+    auto range_begin = [&](unsigned t) { return plan ? plan->bound[t] : o + (size_t)t * span; };
+    auto range_end = [&](unsigned t) { return plan ? plan->bound[t + 1] : (t + 1 == nt1 ? n : std::min(n, o + (size_t)(t + 1) * span)); };
     auto work1 = [&](unsigned t) {
-        size_t q = o + (size_t)t * span;
+        const size_t lim = plan ? range_end(t) : n;       // bytes that exist while this worker runs
+        if (plan && !plan->make(t)) { pok[t] = 0; perr[t] = "BGZF inflate failed"; guess[t] = stop[t] = range_end(t); return; }
+        size_t q = range_begin(t);
         if (t > 0) {   // speculative start: first offset in the range that begins a chain of well-formed records
-            const size_t lim = range_end(t);
-            size_t found = 0;
-            for (; q < lim && !found; q++) {
+            const size_t rend = range_end(t);
+            size_t found = ~(size_t)0;
+            for (; q < rend && found == ~(size_t)0; q++) {
                 size_t z = q;
                 int ok = 0;
-                while (ok < KD_SPEC_CHAIN) { const size_t nx = plausible(z); if (!nx) break; ok++; z = nx; if (z + 4 > n) break; }
-                if (ok == KD_SPEC_CHAIN || (ok > 0 && z + 4 > n)) found = q;
+                bool ran_out = false;      // the chain reached the end of what exists
+                while (ok < KD_SPEC_CHAIN) {
+                    const size_t nx = plausible(z, lim);
+                    if (nx == KD_UNKNOWN) { ran_out = true; break; }
+                    if (!nx) break;
+                    ok++; z = nx;
+                    if (z + 4 > n) { ran_out = true; break; }
+                }
+                if (ok == KD_SPEC_CHAIN || (ok > 0 && ran_out)) found = q;
+                else if (ran_out) break;   // too close to the end to judge: the hand-off pass walks the rest of this range
             }
-            if (!found) { guess[t] = lim; stop[t] = lim; return; }   // no record starts in this range (one huge record)
+            if (found == ~(size_t)0) { guess[t] = rend; stop[t] = rend; return; }   // no (judgeable) record start in this range
             q = found;
         }
         guess[t] = q;
-        pok[t] = walk(q, range_end(t), part[t], part_nrec[t], stop[t], perr[t], &part_sums[2 * t]) ? 1 : 0;
+        pok[t] = walk(q, range_end(t), lim, part[t], part_nrec[t], stop[t], perr[t], &part_sums[2 * t]) ? 1 : 0;
     };
     static const bool trace_parse = getenv("KD_DECODE_TRACE") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
@@ -429,13 +456,28 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
     // verify the hand-offs left to right; re-walk what a wrong guess (or an error seen from a wrong start) spoiled
     size_t p = o;
     for (unsigned t = 0; t < nt1; t++) {
+        if (plan && !pok[t] && perr[t] == "BGZF inflate failed") { g_decode_error = perr[t]; return KD_E_IO; }
+        if (t > 0 && p < guess[t]) {   // the records a worker left at the end of its range (everything exists now): they belong to range t - 1
+            size_t gs[2] = {0, 0}, gstop = p;
+            std::string gerr;
+            if (!walk(p, guess[t], n, part[t - 1], part_nrec[t - 1], gstop, gerr, gs)) { g_decode_error = gerr; return KD_E_IO; }
+            part_sums[2 * (t - 1)] += gs[0]; part_sums[2 * (t - 1) + 1] += gs[1];
+            p = gstop;
+        }
         if (guess[t] != p || (t > 0 && !pok[t])) {
             part[t].clear(); part_nrec[t] = 0; perr[t].clear(); part_sums[2 * t] = part_sums[2 * t + 1] = 0;
-            pok[t] = p >= range_end(t) ? 1 : (walk(p, range_end(t), part[t], part_nrec[t], stop[t], perr[t], &part_sums[2 * t]) ? 1 : 0);
+            pok[t] = p >= range_end(t) ? 1 : (walk(p, range_end(t), n, part[t], part_nrec[t], stop[t], perr[t], &part_sums[2 * t]) ? 1 : 0);
             if (p >= range_end(t)) stop[t] = p;
         }
         if (!pok[t]) { g_decode_error = perr[t]; return KD_E_IO; }
         p = stop[t];
+    }
+    if (plan && p < n) {   // (only when the LAST range had no judgeable start: its records are still to be walked)
+        size_t gs[2] = {0, 0}, gstop = p;
+        std::string gerr;
+        if (!walk(p, n, n, part[nt1 - 1], part_nrec[nt1 - 1], gstop, gerr, gs)) { g_decode_error = gerr; return KD_E_IO; }
+        part_sums[2 * (nt1 - 1)] += gs[0]; part_sums[2 * (nt1 - 1) + 1] += gs[1];
+        p = gstop;
     }
     if (final && p != n) { g_decode_error = "truncated BAM record"; return KD_E_IO; }
     *consumed = p;
@@ -479,8 +521,8 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
     if (trace_parse) {
         const auto tp3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "kd parse: %u ranges: walk %.2f ms, hand-offs + prefix + resize %.2f ms, fill %.2f ms\n", nt1, ms(tp0, tp1), ms(tp1, tp2),
-                ms(tp2, tp3));
+        fprintf(stderr, "kd parse: %u ranges: %s %.2f ms, hand-offs + prefix + resize %.2f ms, fill %.2f ms\n", nt1,
+                plan ? "inflate + walk" : "walk", ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3));
     }
     return KD_OK;
 }
@@ -804,22 +846,55 @@ struct Stream {
             const size_t keep = carry.size();
             static const bool trace = getenv("KD_DECODE_TRACE") != nullptr;
             const auto tt0 = std::chrono::steady_clock::now();
-            if (!buf.resize(keep)) { g_decode_error = "out of memory"; return KD_E_NOMEM; }
-            if (keep) memcpy(buf.data(), carry.data(), keep);
-            if (!inflate_blocks(next_block, b1, keep)) { g_decode_error = "BGZF inflate failed"; return KD_E_IO; }
-            const auto tt1 = std::chrono::steady_clock::now();
-            next_block = b1;
-            const bool final = next_block >= blocks.size();
-            size_t o = 0;
-            if (!header_done) {
-                int rc = header_from(buf.data(), buf.size(), final);
-                if (rc == 1) { carry.resize(buf.size()); memcpy(carry.data(), buf.data(), buf.size()); continue; }   // header not complete yet
-                if (rc) return rc;
-                o = hdr_end;
-            }
             size_t used = 0;
-            int rc = parse_bam_records(buf, o, n_ref, f, n_threads, final, &used);
-            if (rc) return rc;
+            auto tt1 = tt0;
+            bool final;
+            const bool unfused = getenv("KD_DECODE_UNFUSED") != nullptr;   // (tests / measurements: the two-phase path)
+            if (header_done && !unfused) {
+                // Records only: every worker inflates a run of whole blocks and walks the records in them straight away
+                // (RangePlan); what a worker cannot judge at the end of its run is walked by the hand-off pass.
+                if (!buf.resize(keep + add)) { g_decode_error = "out of memory"; return KD_E_NOMEM; }
+                if (keep) memcpy(buf.data(), carry.data(), keep);
+                const size_t nb = b1 - next_block;
+                std::vector<size_t> at(nb + 1);
+                at[0] = keep;
+                for (size_t k = 0; k < nb; k++) at[k + 1] = at[k] + blocks[next_block + k].out_len;
+                unsigned nt = n_threads > 0 ? (unsigned)n_threads : hw_threads();
+                size_t min_range = 1u << 20;
+                if (const char *e = getenv("KD_DECODE_RANGE_BYTES")) min_range = std::max<size_t>(64, strtoull(e, nullptr, 10));
+                const size_t nr = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(2 * (size_t)nt, nb), add / min_range));
+                RangePlan plan;
+                plan.bound.resize(nr + 1);
+                std::vector<size_t> first(nr + 1);
+                for (size_t t = 0; t <= nr; t++) { first[t] = nb * t / nr; plan.bound[t] = at[first[t]]; }
+                plan.bound[0] = 0;                      // the carried-over bytes belong to the first range
+                const size_t b0 = next_block;
+                plan.make = [&, b0](unsigned t) -> bool {
+                    for (size_t k = first[t]; k < first[t + 1]; k++)
+                        if (!inflate_raw(raw.data() + blocks[b0 + k].in_off, blocks[b0 + k].in_len, buf.data() + at[k], blocks[b0 + k].out_len)) return false;
+                    return true;
+                };
+                next_block = b1;
+                final = next_block >= blocks.size();
+                int rc = parse_bam_records(buf, 0, n_ref, f, n_threads, final, &used, &plan);
+                if (rc) return rc;
+            } else {
+                if (!buf.resize(keep)) { g_decode_error = "out of memory"; return KD_E_NOMEM; }
+                if (keep) memcpy(buf.data(), carry.data(), keep);
+                if (!inflate_blocks(next_block, b1, keep)) { g_decode_error = "BGZF inflate failed"; return KD_E_IO; }
+                tt1 = std::chrono::steady_clock::now();
+                next_block = b1;
+                final = next_block >= blocks.size();
+                size_t o = 0;
+                if (!header_done) {
+                    int rc = header_from(buf.data(), buf.size(), final);
+                    if (rc == 1) { carry.resize(buf.size()); memcpy(carry.data(), buf.data(), buf.size()); continue; }   // header not complete yet
+                    if (rc) return rc;
+                    o = hdr_end;
+                }
+                int rc = parse_bam_records(buf, o, n_ref, f, n_threads, final, &used);
+                if (rc) return rc;
+            }
             if (trace) {
                 const auto tt2 = std::chrono::steady_clock::now();
                 fprintf(stderr, "kd_stream chunk: %zu blocks %zu bytes: inflate %.1f ms, parse %.1f ms, %zu records\n", b1 - b0c, buf.size(),

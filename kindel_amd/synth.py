@@ -335,8 +335,8 @@ def _bgzf_block(data):
             struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
 
 
-def write_bam(path, batch, names=None, sort_order="coordinate"):
-    """Write a numpy batch (see to_numpy) as a BAM file."""
+def write_bam(path, batch, names=None, sort_order="coordinate", block_bytes=0xff00):
+    """Write a numpy batch (see to_numpy) as a BAM file (block_bytes: uncompressed bytes per BGZF block; tests use small ones)."""
     lens = [int(x) for x in batch["contig_lens"]]
     names = [str(x) for x in (names if names is not None else batch.get("contig_names", ["ctg%d" % i for i in range(len(lens))]))]
     text = "@HD\tVN:1.6\tSO:%s\n" % sort_order + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in zip(names, lens))
@@ -360,6 +360,6 @@ def write_bam(path, batch, names=None, sort_order="coordinate"):
         rec += b"\xff" * sl + aux
         buf += struct.pack("<i", len(rec)) + rec
     with open(path, "wb") as fh:
-        for o in range(0, len(buf), 0xff00):
-            fh.write(_bgzf_block(bytes(buf[o:o + 0xff00])))
+        for o in range(0, len(buf), block_bytes):
+            fh.write(_bgzf_block(bytes(buf[o:o + block_bytes])))
         fh.write(_bgzf_block(b""))

@@ -180,6 +180,35 @@ def test_stream_chunks_equal_whole_file(emu_lib, tmp_path, key, kind, chunk):
         assert cigs[i] == whole["cigar"][co: co + nc].tobytes(), i
 
 
+@pytest.mark.parametrize("block_bytes,range_bytes,chunk", [(61, 64, 4000), (200, 64, 1500), (333, 700, 20000), (1000, 3000, 1 << 20),
+                                                           (4096, 5000, 50000), (97, 300, 997)])
+def test_stream_workers_inflate_and_walk_their_own_ranges(emu_lib, tmp_path, monkeypatch, block_bytes, range_bytes, chunk):
+    """kd_stream: every worker inflates a run of whole BGZF blocks and walks the records in it; records it cannot judge at
+    the end of its run (header behind what exists yet) are left to the hand-off pass.  Tiny blocks and tiny ranges put a
+    range boundary inside almost every record; the result must equal the two-phase path and the whole-file decode."""
+    batch = P.load_fixture("minimap2__1.1.multi")
+    path = str(tmp_path / "t.bam")
+    synth.write_bam(path, batch, sort_order="unknown", block_bytes=block_bytes)
+    monkeypatch.setenv("KD_DECODE_RANGE_BYTES", str(range_bytes))
+    whole = N.decode_file(path, lib=emu_lib)
+    same_batch(whole, batch)
+    outs = []
+    for unfused in (False, True):
+        if unfused:
+            monkeypatch.setenv("KD_DECODE_UNFUSED", "1")
+        st = N.Stream(path, chunk_bytes=chunk, threads=5, lib=emu_lib)
+        got, seqs, cigs, n_parts = _concat_stream(st)
+        assert st.n_records() == whole["n_records"]
+        st.close()
+        outs.append((got, seqs, cigs))
+    for k in ("contig", "pos0", "flag", "seq_len", "n_cig"):
+        assert np.array_equal(outs[0][0][k], whole[k]), k
+        assert np.array_equal(outs[1][0][k], whole[k]), k
+    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+    for i, (so, sl) in enumerate(zip(whole["seq_off"].tolist(), whole["seq_len"].tolist())):
+        assert outs[0][1][i] == whole["seq4"][so: so + (sl + 1) // 2].tobytes(), i
+
+
 @pytest.mark.parametrize("key,chunk", [("bwa_mem__2.1.sub_test", 5000), ("minimap2__1.1.multi", 900), ("ext__1.issue23.debug", 30000)])
 def test_streamed_pileup_equals_whole_file_pileup(api_on_emu, tmp_path, key, chunk):
     """kd_push_stream (decode thread + pushing thread, many small batches whose boundaries cut windows) == one batch."""
