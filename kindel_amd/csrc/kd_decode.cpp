@@ -862,7 +862,9 @@ struct Stream {
                 unsigned nt = n_threads > 0 ? (unsigned)n_threads : hw_threads();
                 size_t min_range = 1u << 20;
                 if (const char *e = getenv("KD_DECODE_RANGE_BYTES")) min_range = std::max<size_t>(64, strtoull(e, nullptr, 10));
-                const size_t nr = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(2 * (size_t)nt, nb), add / min_range));
+                size_t per_thread = 2;          // ranges per worker: finer = better balance when the cores are shared, more hand-offs
+                if (const char *e = getenv("KD_DECODE_RANGES_PER_THREAD")) per_thread = std::max<size_t>(1, strtoull(e, nullptr, 10));
+                const size_t nr = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(per_thread * (size_t)nt, nb), add / min_range));
                 RangePlan plan;
                 plan.bound.resize(nr + 1);
                 std::vector<size_t> first(nr + 1);
