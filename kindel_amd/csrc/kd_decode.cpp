@@ -60,6 +60,7 @@ struct Pool {
     std::condition_variable cv, done_cv;
     const std::function<void(unsigned)> *fn = nullptr;
     unsigned n_tasks = 0, remaining = 0, active = 0;   // active: workers inside drain() for the current generation
+    unsigned limit = 0;                                 // workers 0 .. limit-1 take part in the current generation
     std::atomic<unsigned> next{0};
     uint64_t gen = 0;
     bool stop = false;
@@ -82,7 +83,7 @@ struct Pool {
             if (!remaining) done_cv.notify_all();
         }
     }
-    void worker() {
+    void worker(unsigned idx) {
         uint64_t seen = 0;
         for (;;) {
             const std::function<void(unsigned)> *f;
@@ -92,7 +93,7 @@ struct Pool {
                 cv.wait(lk, [&] { return stop || gen != seen; });
                 if (stop) return;
                 seen = gen; f = fn; n = n_tasks;
-                if (!f) continue;          // woke up after its generation was over
+                if (!f || idx >= limit) continue;   // woke up after its generation was over / not wanted for this one
                 active++;
             }
             drain(*f, n);
@@ -108,10 +109,10 @@ struct Pool {
         if (n == 1 || threads <= 1) { for (unsigned t = 0; t < n; t++) f(t); return; }
         std::lock_guard<std::mutex> g(run_mu);
         const unsigned want = std::min(n, threads) - 1;
-        while (th.size() < want) th.emplace_back([this] { worker(); });
+        while (th.size() < want) { const unsigned idx = (unsigned)th.size(); th.emplace_back([this, idx] { worker(idx); }); }
         {
             std::lock_guard<std::mutex> lk(mu);
-            fn = &f; n_tasks = n; remaining = n; next = 0; gen++;
+            fn = &f; n_tasks = n; remaining = n; next = 0; limit = want; gen++;
         }
         cv.notify_all();
         drain(f, n);
@@ -451,7 +452,8 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
     };
     static const bool trace_parse = getenv("KD_DECODE_TRACE") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
-    pool().run(nt1, nt1, work1);
+    const unsigned nt_thr = n_threads > 0 ? (unsigned)n_threads : hw_threads();   // (ranges may outnumber the workers)
+    pool().run(nt1, nt_thr, work1);
     const auto tp1 = std::chrono::steady_clock::now();
     // verify the hand-offs left to right; re-walk what a wrong guess (or an error seen from a wrong start) spoiled
     size_t p = o;
@@ -517,7 +519,7 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
         }
     };
     const auto tp2 = std::chrono::steady_clock::now();
-    pool().run(nt1, nt1, fill);
+    pool().run(nt1, nt_thr, fill);
     if (trace_parse) {
         const auto tp3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
