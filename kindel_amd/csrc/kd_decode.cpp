@@ -8,6 +8,10 @@
 // final positions (ISIZE prefix sum); the BAM record chain is walked in ranges from speculative, verified starts; SAM
 // text is parsed in line-aligned ranges; the SoA arrays are filled / merged range by range.
 // (KD_DECODE_RANGE_BYTES shrinks the ranges so that the tests can exercise the range logic on small files.)
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 #include "kd_inflate.h"
 
@@ -204,6 +208,30 @@ bool scan_bgzf(const Arr<uint8_t> &raw, std::vector<Block> &blocks, size_t &tota
         o += bsize;
     }
     return o == raw.size();
+}
+
+// The same, a stretch at a time (kd_stream: the file is mapped, not read, and scanned as the chunks are taken: touching one
+// header per 64 KiB block of a 300 MB file up front is tens of thousands of page faults before the first record is decoded).
+// Appends blocks from offset *o until at least `want_out` more uncompressed bytes are covered or the file ends; false = malformed.
+bool scan_bgzf_some(const uint8_t *raw, size_t n, size_t *o, std::vector<Block> &blocks, size_t *total, size_t want_out) {
+    const size_t stop_at = *total + want_out;
+    while (*o + 18 <= n && *total < stop_at) {
+        const uint8_t *p = raw + *o;
+        if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return false;
+        const size_t xlen = rd16(p + 10);
+        size_t x = 12, bsize = 0;
+        while (x + 4 <= 12 + xlen) {
+            const size_t slen = rd16(p + x + 2);
+            if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2) bsize = (size_t)rd16(p + x + 4) + 1;
+            x += 4 + slen;
+        }
+        if (!bsize || *o + bsize > n || bsize < 12 + xlen + 8) return false;
+        const size_t isize = rd32(p + bsize - 4);
+        blocks.push_back({*o + 12 + xlen, bsize - (12 + xlen) - 8, *total, isize});
+        *total += isize;
+        *o += bsize;
+    }
+    return *o + 18 <= n || *o == n;     // stopped early, or consumed the file exactly
 }
 
 // one BGZF block: kd_inflate.h (whole-buffer raw DEFLATE decoder; zlib's streaming inflate was 79 % of the decoder's CPU time)
@@ -749,8 +777,37 @@ int parse_sam_records(const char *rec0, const char *end, const SamIds &ids, File
 // BGZF: the blocks of a chunk are inflated in parallel behind the carried-over tail of the previous chunk (the record the
 // chunk boundary cut); SAM text: chunks end on line boundaries; any other gzip stream: one chunk.
 // ---------------------------------------------------------------------------------------------------------------------
+struct RawView {   // the compressed file: mapped read-only (the workers fault its pages in as they inflate), or read as a fallback
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+    void *map = nullptr;
+    Arr<uint8_t> own;
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    uint8_t operator[](size_t i) const { return p[i]; }
+    bool open(const char *path) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                (void)madvise(m, (size_t)st.st_size, MADV_WILLNEED);
+                map = m; p = (const uint8_t *)m; n = (size_t)st.st_size;
+                ::close(fd);
+                return true;
+            }
+        }
+        ::close(fd);
+        if (!read_all(path, own)) return false;
+        p = own.data(); n = own.size();
+        return true;
+    }
+    ~RawView() { if (map) munmap(map, n); }
+};
+
 struct Stream {
-    Arr<uint8_t> raw;
+    RawView raw;
     int n_threads = 0;
     size_t chunk_bytes = 0;
     bool is_text = false, bgzf = false, done = false;
@@ -758,7 +815,9 @@ struct Stream {
     std::vector<uint32_t> lens;
     uint64_t n_records = 0;
     // BGZF / BAM
-    std::vector<Block> blocks;
+    std::vector<Block> blocks;          // scanned so far
+    size_t scan_off = 0, scan_total = 0;
+    bool scan_done = false;
     size_t next_block = 0;
     Arr<uint8_t> buf, carry;   // uncompressed bytes of the current chunk (carry + blocks); the cut-off record of the last one
     uint32_t n_ref = 0;
@@ -768,15 +827,33 @@ struct Stream {
     SamIds ids;
     const char *sam_pos = nullptr, *sam_end = nullptr;
 
+    // blocks covering at least `want` uncompressed bytes behind next_block, or up to the end of the file
+    bool scan_ahead(size_t want) {
+        size_t have = 0;
+        for (size_t b = next_block; b < blocks.size(); b++) have += blocks[b].out_len;
+        while (!scan_done && have < want) {
+            const size_t before = scan_total;
+            if (!scan_bgzf_some(raw.data(), raw.size(), &scan_off, blocks, &scan_total, want - have + 1)) return false;
+            have += scan_total - before;
+            if (scan_off == raw.size()) scan_done = true;
+            else if (scan_total == before && scan_off + 18 > raw.size()) return false;   // trailing garbage shorter than a block header
+        }
+        return true;
+    }
+
     int open(const char *path, int threads, size_t chunk) {
         n_threads = threads; chunk_bytes = chunk ? chunk : (size_t)64 << 20;
-        if (!read_all(path, raw)) { g_decode_error = std::string("cannot read ") + path; return KD_E_IO; }
+        if (!raw.open(path)) { g_decode_error = std::string("cannot read ") + path; return KD_E_IO; }
         if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) {
-            size_t total = 0;
-            bgzf = scan_bgzf(raw, blocks, total);
+            // BGZF if the first block says so (a later block that does not parse is then a corrupt file, not another format)
+            std::vector<Block> probe;
+            size_t po = 0, pt = 0;
+            bgzf = scan_bgzf_some(raw.data(), raw.size(), &po, probe, &pt, 1) && !probe.empty();
             if (!bgzf) {
-                blocks.clear();
-                if (!inflate_generic(raw, whole)) { g_decode_error = "gzip inflate failed"; return KD_E_IO; }
+                Arr<uint8_t> all;     // (inflate_generic wants the bytes in an Arr)
+                if (!all.resize(raw.size())) { g_decode_error = "out of memory"; return KD_E_NOMEM; }
+                memcpy(all.data(), raw.data(), raw.size());
+                if (!inflate_generic(all, whole)) { g_decode_error = "gzip inflate failed"; return KD_E_IO; }
             }
             // the header may span several blocks: inflate until it parses
             return bgzf ? KD_OK : header_from(whole.data(), whole.size(), true);
@@ -840,7 +917,8 @@ struct Stream {
             return KD_OK;
         }
         for (;;) {
-            if (next_block >= blocks.size() && carry.size() == 0 && header_done) { done = true; return KD_OK; }
+            if (!scan_ahead(chunk_bytes)) { g_decode_error = "corrupt BGZF block header"; return KD_E_IO; }
+            if (next_block >= blocks.size() && scan_done && carry.size() == 0 && header_done) { done = true; return KD_OK; }
             // blocks of this chunk
             size_t b1 = next_block, add = 0;
             const size_t b0c = next_block;
@@ -879,7 +957,7 @@ struct Stream {
                     return true;
                 };
                 next_block = b1;
-                final = next_block >= blocks.size();
+                final = scan_done && next_block >= blocks.size();
                 int rc = parse_bam_records(buf, 0, n_ref, f, n_threads, final, &used, &plan);
                 if (rc) return rc;
             } else {
@@ -888,7 +966,7 @@ struct Stream {
                 if (!inflate_blocks(next_block, b1, keep)) { g_decode_error = "BGZF inflate failed"; return KD_E_IO; }
                 tt1 = std::chrono::steady_clock::now();
                 next_block = b1;
-                final = next_block >= blocks.size();
+                final = scan_done && next_block >= blocks.size();
                 size_t o = 0;
                 if (!header_done) {
                     int rc = header_from(buf.data(), buf.size(), final);
@@ -967,11 +1045,13 @@ int kd_stream_open(kd_stream **out, const char *path, int n_threads, uint64_t ch
     if (!rc && !h->st.is_text && !h->st.header_done) {
         // BGZF: the header sits in the first blocks; read it now so that the contig table is known before the first batch
         Stream &S = h->st;
-        size_t b1 = 0, add = 0;
-        while (b1 < S.blocks.size() && !S.header_done) {
-            add += S.blocks[b1++].out_len;
+        size_t b1 = 0, want = 1;
+        while (!S.header_done) {
+            if (!S.scan_ahead(want)) { rc = KD_E_IO; g_decode_error = "corrupt BGZF block header"; break; }   // (the blocks are scanned as needed)
+            if (b1 >= S.blocks.size()) break;
+            want += S.blocks[b1++].out_len + 1;
             if (!S.inflate_blocks(0, b1, 0)) { rc = KD_E_IO; g_decode_error = "BGZF inflate failed"; break; }
-            const int hr = S.header_from(S.buf.data(), S.buf.size(), b1 >= S.blocks.size());
+            const int hr = S.header_from(S.buf.data(), S.buf.size(), S.scan_done && b1 >= S.blocks.size());
             if (hr != 1 && hr != KD_OK) { rc = hr; break; }
         }
         if (!rc && !S.header_done) { rc = KD_E_IO; g_decode_error = "truncated BAM header"; }

@@ -225,6 +225,25 @@ def test_streamed_pileup_equals_whole_file_pileup(api_on_emu, tmp_path, key, chu
     assert [c.sequence for c in ra.consensuses] == [g["consensus"] for g in P.golden_outputs()[key]["contigs"]]
 
 
+@pytest.mark.parametrize("cut", [0.999, 0.9, 0.5, 0.1])
+def test_truncated_bgzf_file_is_an_error_not_a_crash(emu_lib, tmp_path, cut):
+    """The stream maps the file and scans its blocks as it goes: a file cut inside a block (or inside the header) must end in
+    OSError from kd_stream_open / kd_stream_next, as it does from the whole-file decoder."""
+    batch = P.load_fixture("bwa_mem__1.1.sub_test")
+    full = str(tmp_path / "f.bam")
+    synth.write_bam(full, batch, sort_order="unknown", block_bytes=700)
+    data = open(full, "rb").read()
+    path = str(tmp_path / "t.bam")
+    with open(path, "wb") as fh:
+        fh.write(data[: int(len(data) * cut)])
+    with pytest.raises(OSError):
+        N.decode_file(path, lib=emu_lib)
+    with pytest.raises(OSError):
+        st = N.Stream(path, chunk_bytes=5000, lib=emu_lib)
+        while st.next_batch() is not None:
+            pass
+
+
 def test_native_bam_writer_roundtrip(emu_lib, tmp_path):
     """kd_write_bam (parallel record layout + parallel deflate) -> decoder == the batch; also readable by the pure-Python reader;
     a read with more than 65535 CIGAR operations goes through the CG tag."""
