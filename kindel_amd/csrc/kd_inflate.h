@@ -230,10 +230,13 @@ struct Decoder {
             // fast steps: >= 16 input bytes for the refills, >= 3 literals + 258 + 8 bytes of output slack
             while (in_end - in >= 16 && out_end - out >= 3 + 258 + 8) {
                 refill();
-                // up to three literals per refill; the test for a second-level table stays off the literal path (a literal
-                // with a long code just takes the slow exit below)
+                // A match as the FIRST symbol behind a refill needs no second refill (length code 15 + 5 extra bits, distance
+                // code 15 + 13: 48 of the 56 bits); behind up to two literals it does.  Up to three literals per refill; the
+                // test for a second-level table stays off the literal path.
                 uint32_t e = lit[bb & ((1u << LIT_BITS) - 1)];
+                bool fresh = true;
                 if (e & K_LIT) {
+                    fresh = false;
                     bb >>= (e & 15u); bc -= (int)(e & 15u);
                     *out++ = (uint8_t)(e >> 16);
                     e = lit[bb & ((1u << LIT_BITS) - 1)];
@@ -256,15 +259,16 @@ struct Decoder {
                         *out++ = (uint8_t)(e >> 16);
                         continue;
                     }
+                    fresh = false;     // (a long length code: be generous with the bits)
                 }
                 bb >>= (e & 15u); bc -= (int)(e & 15u);
                 if (!(e & K_LEN)) {
                     if (e & K_EOB) return true;
                     return false;
                 }
-                uint32_t len = (e >> 16) + (uint32_t)(bb & ((1u << ((e >> 4) & 15u)) - 1));
+                const uint32_t len = (e >> 16) + (uint32_t)(bb & ((1u << ((e >> 4) & 15u)) - 1));
                 { const int x = (int)((e >> 4) & 15u); bb >>= x; bc -= x; }
-                refill();      // (unconditional: cheaper than a branch that goes either way)
+                if (!fresh) refill();
                 uint32_t d = lookup_dist();
                 bb >>= (d & 15u); bc -= (int)(d & 15u);
                 if (!(d & K_LEN)) return false;
@@ -274,11 +278,12 @@ struct Decoder {
                 const uint8_t *src = out - dd;
                 uint8_t *dst = out;
                 out += len;
+                // (the copies may write up to 7 bytes past out: inside the slack the loop condition guarantees)
                 if (dd >= 8) {
-                    // (may write up to 7 bytes past out: inside the slack the loop condition guarantees)
                     do { uint64_t w; memcpy(&w, src, 8); memcpy(dst, &w, 8); src += 8; dst += 8; } while (dst < out);
                 } else if (dd == 1) {
-                    memset(dst, *src, len);
+                    const uint64_t w = 0x0101010101010101ull * (uint64_t)*src;
+                    do { memcpy(dst, &w, 8); dst += 8; } while (dst < out);
                 } else {
                     do { *dst++ = *src++; } while (dst < out);
                 }
