@@ -862,6 +862,24 @@ struct Stream {
         sam_end = (const char *)raw.data() + raw.size();
         return parse_sam_header((const char *)raw.data(), sam_end, ids, names, lens, &sam_pos);
     }
+    // BGZF: the header sits in the first blocks; read it at open so that the contig table is known before the first batch
+    // (next() parses it again from the first chunk, and skips it)
+    int preload_header() {
+        if (is_text || header_done) return KD_OK;
+        int rc = KD_OK;
+        size_t b1 = 0, want = 1;
+        while (!header_done) {
+            if (!scan_ahead(want)) { rc = KD_E_IO; g_decode_error = "corrupt BGZF block header"; break; }   // (the blocks are scanned as needed)
+            if (b1 >= blocks.size()) break;
+            want += blocks[b1++].out_len + 1;
+            if (!inflate_blocks(0, b1, 0)) { rc = KD_E_IO; g_decode_error = "BGZF inflate failed"; break; }
+            const int hr = header_from(buf.data(), buf.size(), scan_done && b1 >= blocks.size());
+            if (hr != 1 && hr != KD_OK) { rc = hr; break; }
+        }
+        if (!rc && !header_done) { rc = KD_E_IO; g_decode_error = "truncated BAM header"; }
+        header_done = false;
+        return rc;
+    }
     size_t hdr_end = 0;
     int header_from(const uint8_t *d, size_t n, bool final) {
         bool more = false;
@@ -1002,22 +1020,55 @@ struct kd_file {
 
 extern "C" {
 
+// The whole file as ONE batch: the stream's chunks (64 MiB of records each, workers inflating and walking their own runs of
+// blocks) appended to one another -- no 4 GB buffer of inflated records in between.  KD_DECODE_ONE_CHUNK=1: the old way (tests).
 int kd_decode_open(kd_file **out, const char *path, int n_threads) {
     if (!out || !path) return KD_E_ARG;
     *out = nullptr;
+    const bool one_chunk = getenv("KD_DECODE_ONE_CHUNK") != nullptr;
     Stream st;
-    int rc = st.open(path, n_threads, ~(size_t)0 >> 1);   // one chunk = the whole file
+    size_t chunk = (size_t)64 << 20;
+    if (const char *e = getenv("KD_DECODE_CHUNK_BYTES")) chunk = std::max<size_t>(1, strtoull(e, nullptr, 10));   // (tests: many chunks)
+    int rc = st.open(path, n_threads, one_chunk ? ~(size_t)0 >> 1 : chunk);
     if (rc) return rc;
+    std::vector<std::string> names; std::vector<uint32_t> lens;
+    if (!one_chunk) {
+        if ((rc = st.preload_header())) return rc;
+        names = st.names; lens = st.lens;
+    }
     kd_file *h = new kd_file();
-    bool got = false;
-    rc = st.next(h->f, &got);
-    if (rc) { delete h; return rc; }
-    if (!got) { h->f.contig.resize(0); h->f.pos0.resize(0); h->f.flag.resize(0); h->f.seq_off.resize(0); h->f.seq_len.resize(0);
-                h->f.cig_off.resize(0); h->f.n_cig.resize(0); h->f.seq4.resize(0); h->f.cigar.resize(0); }
+    File &F = h->f;
+    F.contig.resize(0); F.pos0.resize(0); F.flag.resize(0); F.seq_off.resize(0); F.seq_len.resize(0);
+    F.cig_off.resize(0); F.n_cig.resize(0); F.seq4.resize(0); F.cigar.resize(0);
+    File tmp;
+    bool first = true;
+    for (;;) {
+        bool got = false;
+        File &dst = first ? F : tmp;       // the first chunk lands in place
+        rc = st.next(dst, &got);
+        if (rc) { delete h; return rc; }
+        if (!got) { if (first) { F.contig.resize(0); F.pos0.resize(0); F.flag.resize(0); F.seq_off.resize(0); F.seq_len.resize(0);
+                                 F.cig_off.resize(0); F.n_cig.resize(0); F.seq4.resize(0); F.cigar.resize(0); } break; }
+        if (!first) {
+            const size_t k0 = F.contig.size(), k1 = tmp.contig.size(), s0 = F.seq4.size(), c0 = F.cigar.size();
+            bool ok = F.contig.resize(k0 + k1) && F.pos0.resize(k0 + k1) && F.flag.resize(k0 + k1) && F.seq_off.resize(k0 + k1) &&
+                      F.seq_len.resize(k0 + k1) && F.cig_off.resize(k0 + k1) && F.n_cig.resize(k0 + k1) &&
+                      F.seq4.resize(s0 + tmp.seq4.size()) && F.cigar.resize(c0 + tmp.cigar.size());
+            if (!ok) { delete h; g_decode_error = "out of memory"; return KD_E_NOMEM; }
+            memcpy(F.contig.data() + k0, tmp.contig.data(), k1 * 4); memcpy(F.pos0.data() + k0, tmp.pos0.data(), k1 * 4);
+            memcpy(F.flag.data() + k0, tmp.flag.data(), k1 * 4); memcpy(F.seq_len.data() + k0, tmp.seq_len.data(), k1 * 4);
+            memcpy(F.n_cig.data() + k0, tmp.n_cig.data(), k1 * 4);
+            for (size_t k = 0; k < k1; k++) { F.seq_off[k0 + k] = tmp.seq_off[k] + s0; F.cig_off[k0 + k] = tmp.cig_off[k] + c0; }
+            if (tmp.seq4.size()) memcpy(F.seq4.data() + s0, tmp.seq4.data(), tmp.seq4.size());
+            if (tmp.cigar.size()) memcpy(F.cigar.data() + c0, tmp.cigar.data(), tmp.cigar.size() * 4);
+        }
+        first = false;
+        if (st.done) break;
+    }
     if (!st.is_text && !st.header_done) { delete h; g_decode_error = "truncated BAM header"; return KD_E_IO; }
-    h->f.names = st.names; h->f.lens = st.lens;
-    h->f.n_records = st.n_records;
-    finish_view(h->f);
+    F.names = one_chunk || st.is_text || names.empty() ? st.names : names; F.lens = one_chunk || st.is_text || lens.empty() ? st.lens : lens;
+    F.n_records = st.n_records;
+    finish_view(F);
     *out = h;
     return KD_OK;
 }
@@ -1042,23 +1093,7 @@ int kd_stream_open(kd_stream **out, const char *path, int n_threads, uint64_t ch
     *out = nullptr;
     kd_stream *h = new kd_stream();
     int rc = h->st.open(path, n_threads, (size_t)chunk_bytes);
-    if (!rc && !h->st.is_text && !h->st.header_done) {
-        // BGZF: the header sits in the first blocks; read it now so that the contig table is known before the first batch
-        Stream &S = h->st;
-        size_t b1 = 0, want = 1;
-        while (!S.header_done) {
-            if (!S.scan_ahead(want)) { rc = KD_E_IO; g_decode_error = "corrupt BGZF block header"; break; }   // (the blocks are scanned as needed)
-            if (b1 >= S.blocks.size()) break;
-            want += S.blocks[b1++].out_len + 1;
-            if (!S.inflate_blocks(0, b1, 0)) { rc = KD_E_IO; g_decode_error = "BGZF inflate failed"; break; }
-            const int hr = S.header_from(S.buf.data(), S.buf.size(), S.scan_done && b1 >= S.blocks.size());
-            if (hr != 1 && hr != KD_OK) { rc = hr; break; }
-        }
-        if (!rc && !S.header_done) { rc = KD_E_IO; g_decode_error = "truncated BAM header"; }
-        S.header_done = false;   // next() parses it again from the first chunk (and skips it)
-        std::vector<std::string> nm = S.names; std::vector<uint32_t> ln = S.lens;
-        S.names = nm; S.lens = ln;
-    }
+    if (!rc) rc = h->st.preload_header();
     if (rc) { delete h; return rc; }
     *out = h;
     return KD_OK;

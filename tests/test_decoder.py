@@ -225,6 +225,28 @@ def test_streamed_pileup_equals_whole_file_pileup(api_on_emu, tmp_path, key, chu
     assert [c.sequence for c in ra.consensuses] == [g["consensus"] for g in P.golden_outputs()[key]["contigs"]]
 
 
+@pytest.mark.parametrize("key,kind", [("bwa_mem__1.1.sub_test", "bam"), ("minimap2__1.1.multi", "bam"), ("segemehl__3.1.sub_test", "sam"),
+                                      ("minimap2__hxb2-gp120-mutated", "bam")])
+def test_whole_file_decode_is_the_streams_chunks_appended(emu_lib, tmp_path, monkeypatch, key, kind):
+    """kd_decode_open reads the file through the stream (64 MiB chunks appended to one another); with tiny chunks the result
+    must equal the one-chunk decode (KD_DECODE_ONE_CHUNK) and the fixture."""
+    batch = P.load_fixture(key)
+    path = str(tmp_path / ("w." + kind))
+    if kind == "bam":
+        synth.write_bam(path, batch, sort_order="unknown", block_bytes=900)
+    else:
+        _write_sam(path, batch)
+    monkeypatch.setenv("KD_DECODE_ONE_CHUNK", "1")
+    one = N.decode_file(path, lib=emu_lib)
+    monkeypatch.delenv("KD_DECODE_ONE_CHUNK")
+    for chunk in (1500, 40000):
+        monkeypatch.setenv("KD_DECODE_CHUNK_BYTES", str(chunk))
+        got = N.decode_file(path, threads=3, lib=emu_lib)
+        same_batch(got, one)
+        same_batch(got, batch)
+        assert got["n_records"] == one["n_records"] and list(got["contig_names"]) == list(one["contig_names"])
+
+
 @pytest.mark.parametrize("cut", [0.999, 0.9, 0.5, 0.1])
 def test_truncated_bgzf_file_is_an_error_not_a_crash(emu_lib, tmp_path, cut):
     """The stream maps the file and scans its blocks as it goes: a file cut inside a block (or inside the header) must end in
