@@ -167,6 +167,7 @@ struct File {
     Arr<uint64_t> seq_off, cig_off;
     Arr<uint8_t> seq4;
     uint64_t n_records = 0;
+    bool append = false;       // parse_bam_records adds its records BEHIND what the arrays hold (kd_decode_open: chunk after chunk)
     kd_batch view;
 };
 
@@ -513,6 +514,7 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
     *consumed = p;
     // prefix over the ranges: first record index / packed-base byte / CIGAR word of each
     std::vector<size_t> k_at(nt1 + 1, 0), sq_at(nt1 + 1, 0), cg_at(nt1 + 1, 0);
+    if (f.append) { k_at[0] = f.contig.size(); sq_at[0] = f.seq4.size(); cg_at[0] = f.cigar.size(); }
     for (unsigned t = 0; t < nt1; t++) {
         k_at[t + 1] = k_at[t] + part[t].size(); sq_at[t + 1] = sq_at[t] + part_sums[2 * t]; cg_at[t + 1] = cg_at[t] + part_sums[2 * t + 1];
         f.n_records += part_nrec[t];
@@ -910,7 +912,7 @@ struct Stream {
     // next batch into f (arrays replaced); *got = false at the end of the file
     int next(File &f, bool *got) {
         *got = false;
-        f.n_records = 0;
+        if (!f.append) f.n_records = 0;
         if (done) return KD_OK;
         if (is_text) {
             if (sam_pos >= sam_end) { done = true; return KD_OK; }
@@ -935,6 +937,8 @@ struct Stream {
             return KD_OK;
         }
         for (;;) {
+            const size_t kept_before = f.append ? f.contig.size() : 0;
+            const uint64_t recs_before = f.append ? f.n_records : 0;
             if (!scan_ahead(chunk_bytes)) { g_decode_error = "corrupt BGZF block header"; return KD_E_IO; }
             if (next_block >= blocks.size() && scan_done && carry.size() == 0 && header_done) { done = true; return KD_OK; }
             // blocks of this chunk
@@ -1002,11 +1006,11 @@ struct Stream {
             }
             carry.resize(buf.size() - used);
             if (carry.size()) memcpy(carry.data(), buf.data() + used, carry.size());
-            n_records += f.n_records;
-            if (f.contig.size() == 0 && !final) continue;   // a chunk smaller than one record: keep reading
+            n_records += f.append ? f.n_records - recs_before : f.n_records;
+            const size_t kept_now = f.contig.size() - kept_before;
+            if (kept_now == 0 && !final) continue;   // a chunk smaller than one record: keep reading
             if (final) { done = true; }
-            *got = f.contig.size() > 0 || final;
-            if (final && f.contig.size() == 0) *got = false;
+            *got = kept_now > 0;
             return KD_OK;
         }
     }
@@ -1040,31 +1044,15 @@ int kd_decode_open(kd_file **out, const char *path, int n_threads) {
     File &F = h->f;
     F.contig.resize(0); F.pos0.resize(0); F.flag.resize(0); F.seq_off.resize(0); F.seq_len.resize(0);
     F.cig_off.resize(0); F.n_cig.resize(0); F.seq4.resize(0); F.cigar.resize(0);
-    File tmp;
-    bool first = true;
+    if (st.is_text || !st.bgzf) st.chunk_bytes = ~(size_t)0 >> 1;   // SAM text / plain gzip: one chunk (their parsers replace the arrays)
+    else F.append = !one_chunk;                                     // BGZF: every chunk's records land behind the previous ones, in place
     for (;;) {
         bool got = false;
-        File &dst = first ? F : tmp;       // the first chunk lands in place
-        rc = st.next(dst, &got);
+        rc = st.next(F, &got);
         if (rc) { delete h; return rc; }
-        if (!got) { if (first) { F.contig.resize(0); F.pos0.resize(0); F.flag.resize(0); F.seq_off.resize(0); F.seq_len.resize(0);
-                                 F.cig_off.resize(0); F.n_cig.resize(0); F.seq4.resize(0); F.cigar.resize(0); } break; }
-        if (!first) {
-            const size_t k0 = F.contig.size(), k1 = tmp.contig.size(), s0 = F.seq4.size(), c0 = F.cigar.size();
-            bool ok = F.contig.resize(k0 + k1) && F.pos0.resize(k0 + k1) && F.flag.resize(k0 + k1) && F.seq_off.resize(k0 + k1) &&
-                      F.seq_len.resize(k0 + k1) && F.cig_off.resize(k0 + k1) && F.n_cig.resize(k0 + k1) &&
-                      F.seq4.resize(s0 + tmp.seq4.size()) && F.cigar.resize(c0 + tmp.cigar.size());
-            if (!ok) { delete h; g_decode_error = "out of memory"; return KD_E_NOMEM; }
-            memcpy(F.contig.data() + k0, tmp.contig.data(), k1 * 4); memcpy(F.pos0.data() + k0, tmp.pos0.data(), k1 * 4);
-            memcpy(F.flag.data() + k0, tmp.flag.data(), k1 * 4); memcpy(F.seq_len.data() + k0, tmp.seq_len.data(), k1 * 4);
-            memcpy(F.n_cig.data() + k0, tmp.n_cig.data(), k1 * 4);
-            for (size_t k = 0; k < k1; k++) { F.seq_off[k0 + k] = tmp.seq_off[k] + s0; F.cig_off[k0 + k] = tmp.cig_off[k] + c0; }
-            if (tmp.seq4.size()) memcpy(F.seq4.data() + s0, tmp.seq4.data(), tmp.seq4.size());
-            if (tmp.cigar.size()) memcpy(F.cigar.data() + c0, tmp.cigar.data(), tmp.cigar.size() * 4);
-        }
-        first = false;
-        if (st.done) break;
+        if (!got || st.done || !F.append) break;
     }
+    F.append = false;
     if (!st.is_text && !st.header_done) { delete h; g_decode_error = "truncated BAM header"; return KD_E_IO; }
     F.names = one_chunk || st.is_text || names.empty() ? st.names : names; F.lens = one_chunk || st.is_text || lens.empty() ? st.lens : lens;
     F.n_records = st.n_records;
