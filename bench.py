@@ -64,6 +64,10 @@ def main():
     args = ap.parse_args()
 
     import torch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (no torchrun): spawn the N ranks ourselves, one process per GPU, and hand their
+        # output / exit status through -- never fall through to one rank that reports a 1-GPU number under an N-GPU request
+        sys.exit(_spawn_ranks(args, torch))
     import torch.distributed as dist
     from kindel_amd import _native as N
     from kindel_amd import shard, synth
@@ -78,7 +82,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch as `python bench.py --gpus N` (spawns its own ranks) or under "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
+    if args.backend == "nccl" and torch.cuda.device_count() < (world if world > 1 else 1):
+        raise SystemExit("bench.py: %d rank(s) over RCCL need %d visible GPU(s), found %d" % (world, world, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
     dev = "cuda:%d" % dev_index
 
@@ -104,8 +112,9 @@ def main():
             # one shared input (the same seeded batch on every rank, standing in for one decoded file), split by work
             batch = synth.make(cfg, device=dev)
             intervals = shard.partition_weighted(contig_lens, batch["contig"], batch["pos0"], batch["seq_len"], world)
-            span_hi = batch["pos0"] + batch["seq_len"].to(batch["pos0"].dtype) + 64    # footprint <= query length + deletions
-            keep = shard.reads_of_rank(contig_lens, batch["contig"], batch["pos0"], span_hi, rank, world, intervals=intervals)
+            g_lo, g_hi = shard.footprints(contig_lens, batch)      # exact reach of every read, from its CIGAR (deletions included)
+            keep = shard.reads_of_rank(contig_lens, g_lo, g_hi, rank, world, intervals=intervals)
+            del g_lo, g_hi
             full_cigar, full_words = batch["cigar"], batch["cigar_words"]
             full_ncig = batch["n_cig"]
             for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
@@ -170,7 +179,7 @@ def main():
             seqs = [pinned_np[int(off[c]): int(off[c + 1])] for c in range(n_contigs)]
             # ... and, at N > 1, the all-gather that leaves the stitched consensus in every GPU's HBM
             if world > 1:
-                state["gathered"] = shard.gather(eng, interval, dev)[0]   # one fixed-size all-gather (RCCL over xGMI)
+                state["gathered"] = shard.gather(eng, interval, dev, intervals=intervals)[0]   # one fixed-size all-gather (RCCL over xGMI)
             return seqs
 
         def barrier():
@@ -309,6 +318,27 @@ def main():
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def _spawn_ranks(args, torch):
+    """`python bench.py --gpus N` without a launcher: re-execute this command under torch.distributed.run with N ranks on
+    127.0.0.1 (one process per GPU, RCCL).  Refuses when fewer than N GPUs are visible (unless --backend gloo asks for ranks
+    that share GPUs, which is a functional test of the N-rank path, not a scaling measurement)."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and n_dev < args.gpus:
+        print("bench.py: --gpus %d requested but only %d GPU(s) visible; refusing to report a %d-GPU number from fewer devices"
+              % (args.gpus, n_dev, args.gpus), file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 _PMC_SOURCE = ("profiles/pmc_traffic.json: STATIC, not measured in this run -- (FETCH_SIZE x k + WRITE_SIZE) x 1024 per launch from "

@@ -74,9 +74,66 @@ def partition_weighted(contig_lens, contig, pos0, weight, world, align=None, sna
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def reads_of_rank(contig_lens, contig, pos0, pos_end, rank, world, margin=512, intervals=None):
-    """Boolean mask (same array type as the inputs: numpy or torch) of the reads rank must see:
-    every read whose reference footprint [pos0 - margin, pos_end + margin] touches its interval."""
+def footprints(contig_lens, batch):
+    """Exact reference footprint of every read of a batch, from its CIGAR: -> (g_lo, g_hi) int64 arrays (numpy or torch,
+    like the batch), G-space, g_hi EXCLUSIVE -- every table slot the record loop can touch for the read lies in
+    [g_lo, g_hi).  Follows parse_records (/root/reference/kindel/kindel.py:40-81): M/=/X and D advance r (:49-54, :59-62),
+    a non-first S advances r while r < L (:74-81), a leading S writes the `len` sites in front of pos (:63-73), I / clip
+    counters touch the slot AT r (:55-58, :66, :75; hence +1), H / N / P move nothing.  A read placed at pos 0 (r = -1: Python's
+    negative indices wrap, :42) may touch any slot of its contig and gets the whole contig.  This is the routing key of the
+    multi-GPU layer -- the same footprint k_prep derives on the device (KdRInfo.gstart / span / lead) -- not a guess from
+    the query length: a read with a 2 kb deletion reaches 2 kb further than its bases."""
+    tor = type(batch["contig"]).__module__.startswith("torch")
+    base, _ = g_layout(contig_lens)
+    if tor:
+        import torch
+        dev = batch["contig"].device
+        I64 = torch.int64
+        lens = torch.as_tensor(np.asarray(contig_lens, np.int64), device=dev)
+        b = torch.as_tensor(base.astype(np.int64), device=dev)
+        c = batch["contig"].to(I64); pos = batch["pos0"].to(I64); nc = batch["n_cig"].to(I64); co = batch["cig_off"].to(I64)
+        n = int(c.numel())
+        rid = torch.repeat_interleave(torch.arange(n, device=dev), nc)
+        first = torch.cumsum(nc, 0) - nc                      # index of each read's first op in the gathered op list
+        k = torch.arange(int(rid.numel()), device=dev) - first[rid]
+        w = batch["cigar"].to(I64)[co[rid] + k]
+        ln, op = w >> 4, w & 15
+        adv = torch.where((op == 0) | (op == 2) | (op == 7) | (op == 8) | ((op == 4) & (k > 0)), ln, torch.zeros_like(ln))
+        span = torch.zeros(n, dtype=I64, device=dev).index_add_(0, rid, adv)
+        lead = torch.zeros(n, dtype=I64, device=dev).index_add_(0, rid, torch.where((op == 4) & (k == 0), ln, torch.zeros_like(ln)))
+        L = lens[c]
+        lo = torch.clamp(pos - lead, min=0)
+        hi = torch.minimum(torch.clamp(pos, min=0) + span + 1, L + 1)
+        wrap = pos < 0
+        lo = torch.where(wrap, torch.zeros_like(lo), lo)
+        hi = torch.where(wrap, L + 1, hi)
+        return b[c] + lo, b[c] + hi
+    lens = np.asarray(contig_lens, np.int64)
+    b = base.astype(np.int64)
+    c = np.asarray(batch["contig"], np.int64); pos = np.asarray(batch["pos0"], np.int64)
+    nc = np.asarray(batch["n_cig"], np.int64); co = np.asarray(batch["cig_off"], np.int64)
+    n = len(c)
+    rid = np.repeat(np.arange(n), nc)
+    first = np.cumsum(nc) - nc
+    k = np.arange(len(rid)) - first[rid]
+    w = np.asarray(batch["cigar"]).astype(np.int64)[co[rid] + k] if len(rid) else np.zeros(0, np.int64)
+    ln, op = w >> 4, w & 15
+    adv = np.where((op == 0) | (op == 2) | (op == 7) | (op == 8) | ((op == 4) & (k > 0)), ln, 0)
+    span = np.bincount(rid, weights=adv, minlength=n).astype(np.int64) if n else np.zeros(0, np.int64)
+    lead = np.bincount(rid, weights=np.where((op == 4) & (k == 0), ln, 0), minlength=n).astype(np.int64) if n else np.zeros(0, np.int64)
+    L = lens[c]
+    lo = np.maximum(pos - lead, 0)
+    hi = np.minimum(np.maximum(pos, 0) + span + 1, L + 1)
+    wrap = pos < 0
+    lo = np.where(wrap, 0, lo)
+    hi = np.where(wrap, L + 1, hi)
+    return b[c] + lo, b[c] + hi
+
+
+def reads_touching(contig_lens, contig, pos0, pos_end, rank, world, margin=512, intervals=None):
+    """Mask of the reads whose CALLER-SUPPLIED bounds [pos0 - margin, pos_end + margin] touch rank's interval.  Only for
+    producers that know their own reads' reach (the synthetic generator, which draws the deletion lengths itself); routing of
+    decoded input goes through footprints() + reads_of_rank()."""
     base, _ = g_layout(contig_lens)
     lo, hi = (intervals if intervals is not None else partition(contig_lens, world))[rank]
     if type(contig).__module__.startswith("torch"):
@@ -89,6 +146,13 @@ def reads_of_rank(contig_lens, contig, pos0, pos_end, rank, world, margin=512, i
         g0 = b[np.asarray(contig, np.int64)] + np.asarray(pos0, np.int64)
         g1 = b[np.asarray(contig, np.int64)] + np.asarray(pos_end, np.int64)
     return (g1 + margin >= lo) & (g0 - margin <= hi)
+
+
+def reads_of_rank(contig_lens, g_lo, g_hi, rank, world, intervals=None):
+    """Boolean mask (numpy or torch, like the inputs) of the reads `rank` must see: those whose footprint [g_lo, g_hi)
+    (footprints()) touches its commit range [lo, hi] (hi = the halo site for aligned_depth_next, kindel.py:405-410)."""
+    lo, hi = (intervals if intervals is not None else partition(contig_lens, world))[rank]
+    return (g_hi > lo) & (g_lo <= hi)
 
 
 def owned_mask(contig_lens, contig, pos0, rank, world, intervals=None):
@@ -124,11 +188,11 @@ def _as_tensor(ptr, n, device):
 _HDR = 16   # payload header: u64 payload bytes, u64 spare
 
 
-def gather(engine, interval, device, group=None, pad=None):
+def gather(engine, interval, device, group=None, pad=None, intervals=None):
     """The exchange step: ONE all-gather of fixed-size payloads -- header (payload bytes) + contig offsets + depth min/max +
     change codes + consensus bytes; RCCL over xGMI when the backend is "nccl".  The row size `pad` is agreed without
-    communication: every rank derives the same upper bound from the shard geometry (the largest interval, twice: change
-    codes + one byte per site, plus room for inserted bases).  Should a rank's consensus not fit (an insertion-heavy
+    communication: every rank derives the same upper bound from the shard geometry (the largest interval of `intervals`,
+    or of the equal-sites split when none are given, twice: change codes + one byte per site, plus room for inserted bases).  Should a rank's consensus not fit (an insertion-heavy
     shard), its header says so, every rank reads that in the gathered rows and all of them repeat the gather with the
     announced size -- a second collective only in that case.  Call after engine.consensus_run(); everything stays on
     `device`.  -> (gathered uint8 tensor [world, pad], world)."""
@@ -143,7 +207,10 @@ def gather(engine, interval, device, group=None, pad=None):
     head = np.concatenate([coff.view(np.uint8), mm.reshape(-1).view(np.uint8)])
     my_size = _HDR + head.size + (hi - lo) + cbytes
     if pad is None:
-        widest = max(1, -(-engine.total_sites() // max(world, 1)) + 4096) if world > 1 else hi - lo
+        if intervals is not None:      # every rank holds the same list: the widest interval bounds every rank's payload
+            widest = max(1, max(b - a for a, b in intervals))
+        else:
+            widest = max(1, -(-engine.total_sites() // max(world, 1)) + 4096) if world > 1 else hi - lo
         pad = _HDR + head.size + 2 * widest + widest // 4 + 65536
         pad = max(pad, my_size) if world == 1 else pad
     for _ in range(2):
@@ -206,6 +273,6 @@ def assemble(rows, contig_lens, world, interval=None, intervals=None):
 def stitch(engine, interval, device, group=None, intervals=None, pad=None):
     """gather() + host assembly: -> (seqs, changes, minmax), identical on every rank.
     seqs[c] = bytes of contig c's consensus, changes[c] = uint8[L_c], minmax[c] = (min, max) ACGT depth."""
-    gathered, world = gather(engine, interval, device, group, pad=pad)
+    gathered, world = gather(engine, interval, device, group, pad=pad, intervals=intervals)
     rows = np.ascontiguousarray(gathered.cpu().numpy())
     return assemble(rows, engine.contig_lens, world, interval, intervals=intervals)

@@ -154,7 +154,7 @@ def short_reads(contig_lens, depth, read_len=150, seed=0, device="cpu", planted=
             out["pos0"].append(cr["pos0"]); out["ops"].append(cr["ops"]); out["seq"].append(cr["seq"])
     contig = torch.cat(out["contig"]); pos0 = torch.cat(out["pos0"]); ops = torch.cat(out["ops"]); seq = torch.cat(out["seq"])
     if shard is not None:
-        keep = _sh.reads_of_rank(contig_lens, contig, pos0, pos0 + rl + 64, shard[0], shard[1])
+        keep = _sh.reads_touching(contig_lens, contig, pos0, pos0 + rl + 64, shard[0], shard[1])
         contig, pos0, ops, seq = contig[keep], pos0[keep], ops[keep], seq[keep]
     key = contig.to(torch.int64) * (1 << 40) + pos0.to(torch.int64)
     order = torch.argsort(key, stable=True)
@@ -231,7 +231,7 @@ def long_reads(contig_lens, depth, seed=0, device="cpu", median_len=10_000, min_
     start = (torch.rand(n, generator=g, device=dev, dtype=torch.float64) * (L - rspan - 1).clamp(min=1)).to(torch.int64)
     if shard is not None:
         from . import shard as _sh
-        keep = _sh.reads_of_rank(contig_lens, torch.zeros(n, dtype=torch.int32, device=dev), start, start + rspan,
+        keep = _sh.reads_touching(contig_lens, torch.zeros(n, dtype=torch.int32, device=dev), start, start + rspan,
                                  shard[0], shard[1])
     else:
         keep = torch.ones(n, dtype=torch.bool, device=dev)

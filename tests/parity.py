@@ -202,3 +202,73 @@ def check_fetch_all(lib, batch, min_depth=1):
             eng.consensus_fetch_all_into(np.zeros(max(int(off[-1]) - 1, 0), np.uint8))
     finally:
         eng.close()
+
+
+def check_as_shards(lib, host, world, dev="cpu", tb=None, window=0):
+    """The multi-GPU decomposition on ONE device: `world` work-balanced contiguous intervals (partition_weighted), the
+    shards run one after another -- each with its own shard-local context and the reads routed to it by their CIGAR
+    footprints -- every shard's payload goes through gather() / assemble() exactly as the ranks' rows do, and the stitched
+    consensus, change codes and depth ranges as well as every shard's tables inside its interval (and at its halo site)
+    must equal the oracle's, bit for bit.  tb: the device-resident batch (torch) to push instead of the host arrays.
+    -> the intervals."""
+    from kindel_amd import shard, synth
+    src = tb if tb is not None else host
+    lens = host["contig_lens"]
+    base, S = shard.g_layout(lens)
+    ivs = shard.partition_weighted(lens, src["contig"], src["pos0"], src["seq_len"], world)
+    assert ivs[0][0] == 0 and ivs[-1][1] == S and all(a[1] == b[0] for a, b in zip(ivs, ivs[1:]))
+    g_lo, g_hi = shard.footprints(lens, src)
+    n_reads = len(host["contig"])
+    stitched = {cid: np.zeros((N.KD_NCH, int(lens[cid]) + 1), np.uint32) for cid in range(len(lens))}
+    halo, rows, seen = [], [], 0
+    for r in range(world):
+        keep = shard.reads_of_rank(lens, g_lo, g_hi, r, world, intervals=ivs)
+        seen += int(keep.sum())
+        sub = dict(src)
+        for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+            sub[k] = src[k][keep].contiguous() if tb is not None else src[k][keep]
+        eng = N.Engine(lens, lib=lib)
+        try:
+            if window:
+                eng.set_tuning(window, 0)
+            eng.set_shard(*ivs[r])
+            if tb is not None:
+                eng.push_device(synth.device_ptrs(sub), int(sub["contig"].numel()), tb["seq4_bytes"], tb["cigar_words"])
+            else:
+                eng.push(sub)
+            eng.finalize()
+            eng.consensus_run(1)
+            lo, hi = ivs[r]
+            for cid in range(len(lens)):
+                c0, c1 = int(base[cid]), int(base[cid]) + int(lens[cid]) + 1
+                a, b = max(c0, lo), min(c1, hi)
+                if a >= b:
+                    continue
+                t = eng.tables(cid)
+                stitched[cid][:, a - c0: b - c0] = t[:, a - c0: b - c0]
+                if b < c1 and r + 1 < world:      # the halo site of this shard lies in the same contig: committed here as well
+                    halo.append((cid, b - c0, t[:, b - c0].copy()))
+            payload, _ = shard.gather(eng, ivs[r], dev)     # world 1: this rank's row, as the all-gather would carry it
+            rows.append(np.ascontiguousarray(payload.cpu().numpy()[0]))
+        finally:
+            eng.close()
+    assert seen <= 1.05 * n_reads + world * 4096      # a read is seen by the shards it touches: boundary reads twice, no more
+    seqs, changes, minmax = shard.assemble(rows, lens, world, intervals=ivs)
+    tot_w = 0
+    for cid in ko.contig_order(host):
+        oa = ko.parse_records(host, cid)
+        t, L = stitched[cid], oa.L
+        assert np.array_equal(t[0:5, :L].T, oa.weights) and np.array_equal(t[5], oa.deletions), cid
+        assert np.array_equal(t[6:11, :L].T, oa.clip_start_weights) and np.array_equal(t[11:16, :L].T, oa.clip_end_weights)
+        assert np.array_equal(t[16], oa.clip_starts) and np.array_equal(t[17], oa.clip_ends)
+        assert np.array_equal(t[18], oa.ins_totals)
+        oseq, och = oa.consensus_sequence()
+        assert seqs[cid].decode() == oseq, cid
+        assert [None if c == 0 else chr(c) for c in changes[cid]] == och
+        assert minmax[cid] == oa.depth_minmax()
+        for hc, site, col in halo:
+            if hc == cid and site < L:
+                assert np.array_equal(col[0:5], oa.weights[site]) and col[5] == oa.deletions[site], ("halo", cid, site)
+        tot_w += int(t[0:5].sum())
+    assert tot_w > 0
+    return ivs

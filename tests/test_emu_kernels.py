@@ -141,7 +141,7 @@ def test_virtual_shards_stitch_to_the_unsharded_result(emu_lib):
     base, S = shard.g_layout(batch["contig_lens"])
     pieces = {c: [] for c in full.order}
     for r in range(world):
-        keep = shard.reads_of_rank(batch["contig_lens"], batch["contig"], batch["pos0"], batch["pos0"] + 300, r, world)
+        keep = shard.reads_of_rank(batch["contig_lens"], *shard.footprints(batch["contig_lens"], batch), r, world)
         sub = dict(batch)
         for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
             sub[k] = batch[k][keep]
@@ -185,7 +185,7 @@ def test_virtual_shards_with_long_reads(emu_lib):
     base, S = shard.g_layout(batch["contig_lens"])
     pieces = []
     for r in range(world):
-        keep = shard.reads_of_rank(batch["contig_lens"], batch["contig"], batch["pos0"], batch["pos0"] + 8000, r, world)
+        keep = shard.reads_of_rank(batch["contig_lens"], *shard.footprints(batch["contig_lens"], batch), r, world)
         sub = dict(batch)
         for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
             sub[k] = batch[k][keep]
@@ -195,3 +195,97 @@ def test_virtual_shards_with_long_reads(emu_lib):
         assert np.array_equal(run.tables[0][:, lo:hi], full.tables[0][:, lo:hi]), r
         pieces.append(run.cns[0][0])
     assert b"".join(pieces) == full.cns[0][0]
+
+
+def _brute_footprint(batch, i):
+    """Per-read restatement of the slots parse_records can touch (kindel.py:40-81), contig coordinates, hi exclusive."""
+    L = int(batch["contig_lens"][int(batch["contig"][i])])
+    r = int(batch["pos0"][i])
+    if r < 0:
+        return 0, L + 1
+    lo, hi = r, r + 1
+    co, nc = int(batch["cig_off"][i]), int(batch["n_cig"][i])
+    for k in range(nc):
+        w = int(batch["cigar"][co + k])
+        ln, op = w >> 4, w & 15
+        if op in (0, 2, 7, 8) or (op == 4 and k > 0):
+            r += ln
+            hi = max(hi, r + 1)
+        elif op == 4:
+            lo = max(0, r - ln)
+    return lo, min(hi, L + 1)
+
+
+def test_footprints_follow_the_cigar():
+    """shard.footprints == the brute-force reach of every read (numpy and torch agree), on reads with clips, long
+    deletions, N / H / P ops and a read at POS 0."""
+    import torch
+    sam = "@SQ\tSN:c1\tLN:9000\n@SQ\tSN:c2\tLN:700\n"
+    seq = "ACGT" * 100
+    rows = [("c1", 101, "100M"), ("c1", 201, "10S90M"), ("c1", 301, "50M2000D50M"), ("c1", 5, "20S80M"), ("c1", 401, "60M5I35M12S"),
+            ("c1", 501, "5H30M100N30M4P36M"), ("c2", 1, "100M"), ("c2", 0, "100M"), ("c2", 601, "90M10S"), ("c1", 8000, "3S40M700D57M")]
+    for k, (c, p, cg) in enumerate(rows):
+        sam += "r%d\t0\t%s\t%d\t60\t%s\t*\t0\t0\t%s\t*\n" % (k, c, p, cg, seq[:sum(int(x) for x in __import__("re").findall(r"(\d+)[MIS=X]", cg))])
+    batch = P.sam_to_batch(sam)
+    lens = batch["contig_lens"]
+    base, _ = shard.g_layout(lens)
+    g_lo, g_hi = shard.footprints(lens, batch)
+    for i in range(len(batch["contig"])):
+        lo, hi = _brute_footprint(batch, i)
+        b = int(base[int(batch["contig"][i])])
+        assert (int(g_lo[i]), int(g_hi[i])) == (b + lo, b + hi), (i, rows[i])
+    tb = {k: torch.from_numpy(np.ascontiguousarray(v).astype(np.int64)) for k, v in batch.items() if k in ("contig", "pos0", "n_cig", "cig_off", "cigar")}
+    t_lo, t_hi = shard.footprints(lens, tb)
+    assert np.array_equal(t_lo.numpy(), g_lo) and np.array_equal(t_hi.numpy(), g_hi)
+
+
+def test_read_with_a_long_deletion_across_a_cut_reaches_its_far_shard(emu_lib):
+    """A read whose 2 kb deletion carries it over an interval boundary must be given to the far interval's owner too:
+    routing by the CIGAR's footprint, not by query length (a `pos + len(seq) + margin` rule drops it)."""
+    rng = np.random.default_rng(5)
+    L = 8192
+    ref = "".join("ACGT"[i] for i in rng.integers(0, 4, L))
+    sam = "@SQ\tSN:big\tLN:%d\n" % L
+    n = 0
+    for p in range(1, L - 160, 37):                       # a thin even coverage
+        sam += "r%d\t0\tbig\t%d\t60\t150M\t*\t0\t0\t%s\t*\n" % (n, p, ref[p - 1: p + 149]); n += 1
+    jump = []
+    for k in range(6):                                    # six reads that start well before site 4096 and land 2 kb behind it
+        p = 3200 + 7 * k
+        s = ref[p - 1: p + 59] + ref[p + 2059: p + 2149]
+        jump.append(n)
+        sam += "j%d\t0\tbig\t%d\t60\t60M2000D90M\t*\t0\t0\t%s\t*\n" % (k, p, s); n += 1
+    batch = P.sam_to_batch(sam)
+    order = np.argsort(batch["pos0"], kind="stable")
+    for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+        batch[k] = batch[k][order]
+    full = P.Run(emu_lib, batch, window=256)
+    P.assert_matches_oracle(full)
+    world = 2
+    ivs = [(0, 4096), (4096, shard.g_layout(batch["contig_lens"])[1])]
+    g_lo, g_hi = shard.footprints(batch["contig_lens"], batch)
+    is_jump = batch["n_cig"] == 3
+    assert is_jump.sum() == 6
+    pieces = []
+    for r in range(world):
+        keep = shard.reads_of_rank(batch["contig_lens"], g_lo, g_hi, r, world, intervals=ivs)
+        assert keep[is_jump].all(), "both owners need the reads that jump the cut"
+        naive = shard.reads_touching(batch["contig_lens"], batch["contig"], batch["pos0"], batch["pos0"] + batch["seq_len"].astype(np.int64) + 64,
+                                     r, world, margin=512, intervals=ivs)
+        if r == 1:
+            assert not naive[is_jump].any()               # what the query-length rule would have done
+        sub = dict(batch)
+        for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+            sub[k] = batch[k][keep]
+        run = P.Run(emu_lib, sub, window=256, shard=ivs[r])
+        lo, hi = ivs[r][0], min(ivs[r][1], L + 1)
+        assert np.array_equal(run.tables[0][:, lo:hi], full.tables[0][:, lo:hi]), r
+        pieces.append(run.cns[0][0])
+    assert b"".join(pieces) == full.cns[0][0]
+
+
+@pytest.mark.parametrize("lens,depth,world", [([3000] * 16, 12, 8), ([60000], 8, 8), ([5000, 300, 7000], 10, 3)])
+def test_config_as_virtual_shards_through_gather_and_assemble(emu_lib, lens, depth, world):
+    """Config 4 / config 3 in miniature as `world` virtual shards through the rows of the all-gather (the GPU suite runs the
+    same check at full size: tests/test_gpu_parity.py::test_full_size_config_as_eight_shards)."""
+    P.check_as_shards(emu_lib, synth.to_numpy(synth.short_reads(lens, depth, seed=17)), world, window=256)

@@ -150,7 +150,7 @@ def test_virtual_shards_and_stitch(hip_lib):
     ivs = shard.partition(batch["contig_lens"], world)
     pieces = {c: [] for c in full.order}
     for r in range(world):
-        keep = shard.reads_of_rank(batch["contig_lens"], batch["contig"], batch["pos0"], batch["pos0"] + 300, r, world)
+        keep = shard.reads_of_rank(batch["contig_lens"], *shard.footprints(batch["contig_lens"], batch), r, world)
         sub = dict(batch)
         for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
             sub[k] = batch[k][keep]
@@ -334,7 +334,7 @@ def test_virtual_shards_with_long_reads(hip_lib):
     base, S = shard.g_layout(batch["contig_lens"])
     pieces = []
     for r in range(world):
-        keep = shard.reads_of_rank(batch["contig_lens"], batch["contig"], batch["pos0"], batch["pos0"] + 40000, r, world)
+        keep = shard.reads_of_rank(batch["contig_lens"], *shard.footprints(batch["contig_lens"], batch), r, world)
         sub = dict(batch)
         for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
             sub[k] = batch[k][keep]
@@ -344,3 +344,17 @@ def test_virtual_shards_with_long_reads(hip_lib):
         assert np.array_equal(run.tables[0][:, lo:hi], full.tables[0][:, lo:hi]), r
         pieces.append(run.cns[0][0])
     assert b"".join(pieces) == full.cns[0][0]
+
+
+@pytest.mark.parametrize("cfg", ["C4", "C3"])
+def test_full_size_config_as_eight_shards(hip_lib, cfg):
+    """north_star's multi-GPU decomposition at FULL size on ONE GPU: config 4 (100 contigs x 50 kb x 1000x) -> 8 work-balanced
+    shards of whole contigs, config 3 (5 Mbp x 500x) -> 8 position intervals (tests/parity.py: check_as_shards)."""
+    import torch
+    tb = synth.make(cfg, device="cuda:0")
+    ivs = P.check_as_shards(hip_lib, synth.to_numpy(tb), 8, dev="cuda:0", tb=tb)
+    if cfg == "C4":   # 100 equal contigs: the cuts snap onto contig boundaries, 12 - 13 whole contigs per shard
+        base, _ = shard.g_layout(tb["contig_lens"])
+        assert all(iv[0] in set(int(b) for b in base) for iv in ivs)
+    del tb
+    torch.cuda.empty_cache()

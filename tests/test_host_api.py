@@ -10,6 +10,8 @@ import pytest
 from kindel_amd import synth
 from tests import parity as P
 
+ROOT = P.ROOT
+
 GOLD = P.golden_outputs()
 QUIRKS = P.golden_quirks()
 
@@ -170,3 +172,16 @@ def test_cli_in_process(api_on_emu, tmp_path):
     a = cli.build_parser().parse_args(["consensus", "x.bam"])
     assert (a.realign, a.min_depth, a.min_overlap, a.clip_decay_threshold, a.mask_ends, a.trim_ends, a.uppercase) == \
         (False, 1, 7, 0.1, 50, False, False)   # cli.py:11-18 defaults
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` without a launcher spawns its own ranks -- and refuses (non-zero, nothing on stdout) when
+    fewer than N GPUs are visible instead of silently benchmarking one."""
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count() + 1 if torch.cuda.is_available() else 2
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(max(n, 2)), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0 and p.stdout.strip() == "" and "GPU(s) visible" in p.stderr

@@ -58,7 +58,7 @@ def _worker_routed(rank, world, port, emu_path, lens, depth, seed, pad, q):
     lib = N.Library(emu_path)
     full = synth.to_numpy(synth.short_reads(lens, depth, seed=seed))
     ivs = shard.partition_weighted(lens, full["contig"], full["pos0"], full["seq_len"], world)
-    keep = shard.reads_of_rank(lens, full["contig"], full["pos0"], full["pos0"] + 400, rank, world, intervals=ivs)
+    keep = shard.reads_of_rank(lens, *shard.footprints(lens, full), rank, world, intervals=ivs)
     sub = dict(full)
     for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
         sub[k] = full[k][keep]
