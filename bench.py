@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--synth", action="append", default=[], metavar="KEY=VALUE",
                     help="override a synthetic-generator parameter (sensitivity runs; not the BASELINE workload)")
     ap.add_argument("--scale", type=float, default=1.0, help="depth multiplier (1.0 = the config as specified)")
-    ap.add_argument("--mode", default="auto", choices=["auto", "global", "window", "strip"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "global", "window", "strip", "coop"])
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--slice", type=int, default=0)
     ap.add_argument("--sweep", default="", help="extra tunings to time on the same batch: mode:window:slice,...")
@@ -150,7 +150,7 @@ def main():
             dist.all_reduce(tot)
         aligned_g, query_g, walked_g, ops_g, reads_g = (int(x) for x in tot.cpu())
 
-        mode = {"auto": N.KD_MODE_AUTO, "window": N.KD_MODE_WINDOW, "global": N.KD_MODE_GLOBAL, "strip": N.KD_MODE_STRIP}[args.mode]
+        mode = {"auto": N.KD_MODE_AUTO, "window": N.KD_MODE_WINDOW, "global": N.KD_MODE_GLOBAL, "strip": N.KD_MODE_STRIP, "coop": N.KD_MODE_COOP}[args.mode]
         eng = N.Engine(np.asarray(contig_lens, np.uint32), device=dev_index, mode=mode)
         if args.window or args.slice:
             eng.set_tuning(args.window, args.slice)
@@ -284,7 +284,7 @@ def main():
         # tuning sweep on the resident batch: "mode:window:slice,..." -> one JSON line each on stderr
         for spec in args.sweep.split(","):
             m, w, s = (spec.split(":") + ["0", "0"])[:3]
-            eng.set_mode({"auto": N.KD_MODE_AUTO, "window": N.KD_MODE_WINDOW, "global": N.KD_MODE_GLOBAL, "strip": N.KD_MODE_STRIP}[m])
+            eng.set_mode({"auto": N.KD_MODE_AUTO, "window": N.KD_MODE_WINDOW, "global": N.KD_MODE_GLOBAL, "strip": N.KD_MODE_STRIP, "coop": N.KD_MODE_COOP}[m])
             eng.set_tuning(int(w), int(s))
             step()
             eng.profile_enable(1)
@@ -369,8 +369,9 @@ def _pmc_traffic(kernel):
 def cpu_baseline(batch, contig_lens, gpu_seqs, sample, aligned_total):
     """Two CPU figures on this box's host cores, both single-threaded (the reference is):
     `reference_python`: the UNMODIFIED reference (kindel.kindel.parse_records + consensus_sequence) on a bounded sample of
-    the same workload -- measured live when /root/reference exists, else quoted from profiles/reference_python_baseline.json
-    with where / when it was measured;  value/kind "port": the C oracle (oracle/kindel_oracle.c, a statement-by-statement
+    the same workload -- measured live, in this run: from /root/reference where that exists (the build container), from the
+    bytecode oracle/make_ref.py compiled out of it into oracle/_ref/ elsewhere (the GPU box); only if neither is there is the
+    committed figure of profiles/reference_python_baseline.json quoted, labelled as such;  value/kind "port": the C oracle (oracle/kindel_oracle.c, a statement-by-statement
     port of those loops) over the same batch, bounded to ~10-30 s by sub-sampling reads when the batch is large -- with the
     full batch it is also the full-size bit-exactness check of the GPU consensus."""
     from kindel_amd import synth
@@ -381,7 +382,9 @@ def cpu_baseline(batch, contig_lens, gpu_seqs, sample, aligned_total):
         from oracle import refbaseline, refrun
         if refrun.reference_available():
             refpy = refbaseline.time_reference(host, 0, 4.0e7)
-            refpy["where"] = "this run, this box (%d host cores)" % os.cpu_count()
+            refpy["where"] = "this run, this box (%d host cores, cgroup quota %s)" % (os.cpu_count(), _cpu_quota())
+            refpy["origin"] = ("unmodified reference, imported from /root/reference" if refrun.origin() == "source" else
+                               "unmodified reference, sourceless bytecode oracle/_ref/ compiled from /root/reference by oracle/make_ref.py")
     except Exception as e:   # the reference tree is test infrastructure of the build container only
         refpy = dict(error=repr(e))
     if refpy is None:

@@ -58,11 +58,14 @@ enum {
 };
 
 /* pileup kernel selection for kd_set_mode() */
-#define KD_MODE_AUTO 0   /* windowed LDS histograms, falling back per read where needed */
+#define KD_MODE_AUTO 0   /* windowed LDS histograms (first pass: k_window), falling back per read where needed */
 #define KD_MODE_GLOBAL 1 /* one wavefront per read, 32-bit atomics straight into HBM     */
-#define KD_MODE_WINDOW 2 /* force the windowed path                                      */
+#define KD_MODE_WINDOW 2 /* force the windowed path (first pass by k_window, one lane per read)                     */
 #define KD_MODE_STRIP 3  /* windowed planning, first pass by the site-major kernel k_strip (wavefront per 64-site
                             strip, counters in registers, no LDS atomics): an independent second implementation  */
+#define KD_MODE_COOP 4   /* windowed path, first pass by k_window_coop (loads one lane per read, tile staged in LDS, walk with
+                            16 lanes per read on conflict-free LDS rows): bit-identical, measured slower on MI355X
+                            (DESIGN.md section 3), kept as an independent implementation                               */
 
 typedef struct kd_ctx kd_ctx;
 

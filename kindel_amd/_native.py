@@ -18,7 +18,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libkindel_hip.so")
 
 KD_OK, KD_E_BASE, KD_E_RANGE, KD_E_CIGAR, KD_E_HIP, KD_E_NOMEM, KD_E_ARG, KD_E_IO, KD_E_INTERNAL, KD_E_NOREF = (
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9)
-KD_MODE_AUTO, KD_MODE_GLOBAL, KD_MODE_WINDOW, KD_MODE_STRIP = 0, 1, 2, 3
+KD_MODE_AUTO, KD_MODE_GLOBAL, KD_MODE_WINDOW, KD_MODE_STRIP, KD_MODE_COOP = 0, 1, 2, 3, 4
 (KD_CH_A, KD_CH_T, KD_CH_G, KD_CH_C, KD_CH_N, KD_CH_DEL, KD_CH_CSW, KD_CH_CEW, KD_CH_CLIP_STARTS,
  KD_CH_CLIP_ENDS, KD_CH_INS_TOTAL, KD_NCH) = (0, 1, 2, 3, 4, 5, 6, 11, 16, 17, 18, 19)
 

@@ -45,7 +45,7 @@ const char *kd_last_error(const kd_ctx *ctx) { return ctx ? ctx->e.err.c_str() :
 int kd_reset(kd_ctx *ctx) { return ctx ? ctx->e.reset() : KD_E_ARG; }
 
 int kd_set_mode(kd_ctx *ctx, int mode) {
-    if (!ctx || mode < KD_MODE_AUTO || mode > KD_MODE_STRIP) return KD_E_ARG;
+    if (!ctx || mode < KD_MODE_AUTO || mode > KD_MODE_COOP) return KD_E_ARG;
     ctx->e.mode = mode;
     return KD_OK;
 }
@@ -62,7 +62,7 @@ int kd_set_tuning(kd_ctx *ctx, uint32_t window_sites, uint32_t slice_reads) {
 
 int kd_get_tuning(const kd_ctx *ctx, uint32_t out[2]) {
     if (!ctx || !out) return KD_E_ARG;
-    out[0] = ctx->e.W; out[1] = ctx->e.slice_cfg;
+    out[0] = ctx->e.window_sites(ctx->e.coop_mode()); out[1] = ctx->e.slice_cfg;
     return KD_OK;
 }
 

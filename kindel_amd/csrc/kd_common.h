@@ -163,7 +163,8 @@ struct KdRInfo {
     uint32_t span_cls;  // span << KD_SPAN_SHIFT | KD_INFO_INS | KD_INFO_COLD | class; span = sites from
                         // gstart to the end of the last M / D / trailing-S write
     uint32_t lead;      // sites before gstart written by a leading soft clip (kindel.py:68-72)
-    uint32_t pad;       // long-CIGAR reads: 1 + index of the read's KdCkpt[256] block; 0 otherwise
+    uint32_t pad;       // long-CIGAR reads: 1 + index of the read's KdCkpt[256] block; regular short-CIGAR reads: query length
+                        // (< 2^20) | CIGAR words << 24; 0 otherwise
 };
 
 // Long-CIGAR reads (k_prep_long): the state at the first op of each of the 256 per-thread op runs.  Lets

@@ -188,6 +188,26 @@ bool read_all(const char *path, Arr<uint8_t> &out) {
 
 struct Block { size_t in_off, in_len, out_off, out_len; };
 
+// The gzip member at p (avail >= 18 bytes left in the file, magic / FEXTRA already checked): the length of its extra field
+// and its total size from the BC subfield (SAMv1 4.1).  Everything the header promises must lie inside the file BEFORE it is
+// read: the file is memory-mapped, an xlen that points past its end is a SIGSEGV, not a short read.
+inline bool bgzf_block_size(const uint8_t *p, size_t avail, size_t *xlen_out, size_t *bsize_out) {
+    const size_t xlen = rd16(p + 10);
+    if (12 + xlen + 8 > avail) return false;            // extra field + the 8-byte trailer do not fit
+    size_t x = 12, bsize = 0;
+    while (x + 4 <= 12 + xlen) {
+        const size_t slen = rd16(p + x + 2);
+        if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2) {
+            if (x + 6 > 12 + xlen) return false;         // the BC payload would lie behind the extra field
+            bsize = (size_t)rd16(p + x + 4) + 1;
+        }
+        x += 4 + slen;
+    }
+    if (!bsize || bsize > avail || bsize < 12 + xlen + 8) return false;
+    *xlen_out = xlen; *bsize_out = bsize;
+    return true;
+}
+
 // Split a BGZF file into its blocks using the BC extra subfield (SAMv1 4.1).
 bool scan_bgzf(const Arr<uint8_t> &raw, std::vector<Block> &blocks, size_t &total) {
     size_t o = 0;
@@ -195,14 +215,8 @@ bool scan_bgzf(const Arr<uint8_t> &raw, std::vector<Block> &blocks, size_t &tota
     while (o + 18 <= raw.size()) {
         const uint8_t *p = raw.data() + o;
         if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return false;
-        const size_t xlen = rd16(p + 10);
-        size_t x = 12, bsize = 0;
-        while (x + 4 <= 12 + xlen) {
-            const size_t slen = rd16(p + x + 2);
-            if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2) bsize = (size_t)rd16(p + x + 4) + 1;
-            x += 4 + slen;
-        }
-        if (!bsize || o + bsize > raw.size() || bsize < 12 + xlen + 8) return false;
+        size_t xlen = 0, bsize = 0;
+        if (!bgzf_block_size(p, raw.size() - o, &xlen, &bsize)) return false;
         const size_t isize = rd32(p + bsize - 4);
         blocks.push_back({o + 12 + xlen, bsize - (12 + xlen) - 8, total, isize});
         total += isize;
@@ -219,14 +233,8 @@ bool scan_bgzf_some(const uint8_t *raw, size_t n, size_t *o, std::vector<Block> 
     while (*o + 18 <= n && *total < stop_at) {
         const uint8_t *p = raw + *o;
         if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return false;
-        const size_t xlen = rd16(p + 10);
-        size_t x = 12, bsize = 0;
-        while (x + 4 <= 12 + xlen) {
-            const size_t slen = rd16(p + x + 2);
-            if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2) bsize = (size_t)rd16(p + x + 4) + 1;
-            x += 4 + slen;
-        }
-        if (!bsize || *o + bsize > n || bsize < 12 + xlen + 8) return false;
+        size_t xlen = 0, bsize = 0;
+        if (!bgzf_block_size(p, n - *o, &xlen, &bsize)) return false;
         const size_t isize = rd32(p + bsize - 4);
         blocks.push_back({*o + 12 + xlen, bsize - (12 + xlen) - 8, *total, isize});
         *total += isize;

@@ -30,7 +30,11 @@ struct KdEngine {
     uint64_t S = 0;  // G-space sites, multiple of 1024 (consensus tile)
     uint64_t g_lo = 0, g_hi = 0;  // emit interval [g_lo, g_hi)
     int mode = KD_MODE_AUTO;
-    uint32_t W = 640, slice_cfg = 0;   // tuned on C3 (profiles/): 19 ch x 640 x 2 B = 24 KB of LDS histogram per workgroup
+    uint32_t W = 0, slice_cfg = 0;     // sites per LDS window; 0 = the kernel's own default (kd_set_tuning overrides both kernels)
+    static constexpr uint32_t W_LANE = 640;   // k_window (lane per read): 19 ch x 640 x 2 B = 24 KB of LDS histogram per workgroup
+    static constexpr uint32_t W_COOP = 640;   // k_window_coop (16 lanes per read): 33 rows x (320 + 32) dwords = 46 KB + 29 KB of staged tile, two workgroups per CU
+    bool coop_mode() const { return mode == KD_MODE_COOP; }   // (measured slower than k_window: DESIGN.md section 3; never the default)
+    uint32_t window_sites(bool coop) const { return W ? W : coop ? W_COOP : W_LANE; }
 
     uint32_t *d_tab = nullptr, *d_clen = nullptr, *d_seg = nullptr;
     // the tables are allocated for the shard only: sites [alloc_lo, alloc_hi) (tile aligned) + slack, `pitch` dwords per
@@ -295,19 +299,25 @@ struct KdEngine {
         const bool sorted_input = h_status[KDS_B_UNSORTED] == 0;
         last_windowed = windowed ? 1 : 0;
         if (windowed) {
-            const uint32_t w0 = (uint32_t)(g_lo / W);   // windows intersecting the shard's commit range only
-            const uint32_t n_win = (uint32_t)((std::min<uint64_t>(S, g_hi + 1) + W - 1) / W) - w0;
-            // (sized for the strip planning of the first pass as well: the two passes share these arrays)
-            const uint32_t ws0 = (uint32_t)(g_lo / KD_STRIP);
-            const uint32_t ns_win = (uint32_t)((std::min<uint64_t>(S, g_hi + 1) + KD_STRIP - 1) / KD_STRIP) - ws0;
-            const size_t nw_max = std::max<size_t>(n_win, ns_win);
+            // windows intersecting the shard's commit range only; the planning arrays are shared by the passes (first pass by
+            // k_window_coop / k_window / k_strip, long-read segments by k_window), each with its own window size
+            const uint64_t g_end = std::min<uint64_t>(S, g_hi + 1);
+            auto windows_of = [&](uint32_t Wx, uint32_t &first) { first = (uint32_t)(g_lo / Wx); return (uint32_t)((g_end + Wx - 1) / Wx) - first; };
+            const bool coop = coop_mode();
+            const uint32_t W_first = window_sites(coop), W_seg = window_sites(false);
+            uint32_t ws0, dummy0;
+            const uint32_t ns_win = windows_of(KD_STRIP, ws0);
+            const size_t nw_max = std::max<size_t>(std::max(windows_of(W_first, dummy0), windows_of(W_seg, dummy0)), ns_win);
             if ((rc = ensure(b_winlo, nw_max * 8)) || (rc = ensure(b_winhi, nw_max * 8)) || (rc = ensure(b_itemoff, (nw_max + 1) * 8)))
                 return rc;
             kd_u64 *wl = (kd_u64 *)b_winlo.p, *wh = (kd_u64 *)b_winhi.p, *io = (kd_u64 *)b_itemoff.p;
-            // One pass of k_window over `ne` entries described by `info`: the batch's reads (seg_read == NULL), then the
-            // SEGMENTS of its long reads (k_prep_long), which are bucket-sorted by window like an unsorted batch.
-            auto window_pass = [&](const KdRInfo *info, uint64_t ne, bool in_order, const uint32_t *seg_read, uint32_t span_slot) -> int {
+            // One pass over `ne` entries described by `info`: the batch's reads (seg_read == NULL; k_window_coop when `use_coop`),
+            // then the SEGMENTS of its long reads (k_prep_long), which are bucket-sorted by window like an unsorted batch.
+            auto window_pass = [&](const KdRInfo *info, uint64_t ne, bool in_order, const uint32_t *seg_read, uint32_t span_slot,
+                                   uint32_t W, bool use_coop) -> int {
                 int rc2;
+                uint32_t w0;
+                const uint32_t n_win = windows_of(W, w0);
                 uint32_t slice = slice_cfg;
                 if (!slice) {  // aim for a few thousand work items, slices big enough to amortise the LDS flush
                     uint64_t s = ne / 4096;
@@ -355,6 +365,17 @@ struct KdEngine {
                     (!fused_items && rt.launch("k_plan_items", k_plan_items, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, (const kd_u64 *)io,
                                                n_win, iw, (kd_u64)items_cap, d_status)))
                     return hipfail("k_plan_scan");
+                // 16 lanes per read, row-major histogram (kd_coop.h) -- unless a hand-picked window is too wide for its 33 rows
+                if (use_coop && KD_COOP_LDS_BYTES(KD_COOP_PITCH(W)) <= (size_t)160 * 1024 - 1024) {
+                    const uint32_t P = KD_COOP_PITCH(W);
+                    const size_t lds = KD_COOP_LDS_BYTES(P);
+                    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
+                    const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
+                    if (rt.launch("k_window", k_window_coop, grid, KD_BLOCK, lds, R, info, order, T, (const kd_u64 *)wl, (const kd_u64 *)wh,
+                                  (const kd_u64 *)io, (const uint32_t *)iw, (kd_u64)items_cap, w0, W, P, slice, d_status))
+                        return hipfail("k_window_coop");
+                    return KD_OK;
+                }
                 const uint32_t Wh = (W + 2 * KD_HALO) / 2;   // dwords per channel row
                 const size_t lds = KD_WINDOW_LDS_BYTES(Wh);
                 const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
@@ -417,10 +438,10 @@ struct KdEngine {
                 return KD_OK;
             };
             if (mode == KD_MODE_STRIP) rc = strip_pass((const KdRInfo *)rinfo, n, sorted_input);
-            else rc = window_pass((const KdRInfo *)rinfo, n, sorted_input, nullptr, (uint32_t)KDS_B_MAXSPAN);
+            else rc = window_pass((const KdRInfo *)rinfo, n, sorted_input, nullptr, (uint32_t)KDS_B_MAXSPAN, W_first, coop);
             if (rc) return rc;
             if (n_long && (rc = window_pass((const KdRInfo *)b_seginfo.p, n_long * KD_BLOCK, false, (const uint32_t *)lng,
-                                            (uint32_t)KDS_B_MAXSEGSPAN)))
+                                            (uint32_t)KDS_B_MAXSEGSPAN, W_seg, false)))
                 return rc;
             if (n_cold &&
                 rt.launch("k_cold_lane", k_cold_lane, prep_regions, KD_BLOCK, 0, R, T, I, (const KdColdRec *)cold,

@@ -33,6 +33,7 @@
 #include "kd_readwise.h"
 #include "kd_plan.h"
 #include "kd_window.h"
+#include "kd_coop.h"
 #include "kd_strip.h"
 #include "kd_ins.h"
 #include "kd_cns.h"

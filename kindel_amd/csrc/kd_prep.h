@@ -219,7 +219,9 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
             // plain: the whole read is ONE aligned run: a single op whose aligned length is the read length
             const uint32_t plain = (cls == KD_CLS_REG && nc == 1 && !cold && al == (kd_u64)sl && span == al) ? KD_INFO_PLAIN : 0u;
             ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | plain | (has_ins ? KD_INFO_INS : 0u) | cold | cls;
-            ri.lead = lead; ri.pad = 0;
+            // pad of a REGULAR short-CIGAR read: query length | CIGAR words << 24 (k_window_coop routes on them without touching
+            // seq_len / n_cig again; a regular read is shorter than KD_COLD_MAX_SEQ = 2^20 bases and has <= 16 words)
+            ri.lead = lead; ri.pad = cls == KD_CLS_REG ? ((uint32_t)sl | (nc << 24)) : 0u;
             if (ok) rinfo[i] = ri;
         }
     }

@@ -161,20 +161,22 @@ def _first_appearance(contig):
     return [int(contig[i]) for i in np.sort(first)]
 
 
-def pileup_batch(batch, bam_path=None, device=0, lib=None, mode=N.KD_MODE_AUTO):
+def pileup_batch(batch, bam_path=None, device=0, lib=None, mode=N.KD_MODE_AUTO, all_contigs=False):
     """Run the device record loop over one decoded batch -> Pileup (raises what the reference raises).
 
     Only the contigs that HAVE records get device tables -- like the reference, which calls parse_records per RNAME
     seen (kindel.py:143-151) and never allocates for header-only @SQ lines: a human-genome header with reads on chrM
     costs chrM-sized tables, not 3 Gbp of them.  Contig ids are remapped to the dense ids of that subset (header
-    order); `names` / `lens` / `order` of the Pileup speak the dense ids."""
+    order); `names` / `lens` / `order` of the Pileup speak the dense ids.  all_contigs: every contig of `contig_lens` gets
+    tables whether or not a record names it -- parse_records(ref_id, ref_len, records) allocates ref_len sites before it looks
+    at a record (kindel.py:29-39) and returns an all-zero alignment for an empty or all-unmapped record list."""
     names_all = [str(x) for x in batch["contig_names"]]
     lens_all = np.asarray(batch["contig_lens"], np.uint32)
     contig = np.asarray(batch["contig"])
-    if len(contig) == 0:
+    if len(contig) == 0 and not all_contigs:
         return Pileup(None, [], np.zeros(0, np.uint32), [], bam_path)   # no records: parse_bam returns {} (kindel.py:143-152)
     used = np.unique(contig)
-    if len(used) == len(lens_all):
+    if all_contigs or len(used) == len(lens_all):
         sub, names, lens = batch, names_all, lens_all
     else:
         remap = np.zeros(len(lens_all), np.uint32)
@@ -254,7 +256,7 @@ def parse_records(ref_id, ref_len, records):
                  cig_off=np.asarray(cig_off, np.uint64), n_cig=np.asarray(n_cig, np.uint32),
                  seq4=np.frombuffer(bytes(seq4) + b"\0", np.uint8), cigar=np.asarray(cigar + [0], np.uint32),
                  contig_names=np.asarray([ref_id]), contig_lens=np.asarray([ref_len], np.uint32))
-    return pileup_batch(batch).alignment(0)
+    return pileup_batch(batch, all_contigs=True).alignment(0)
 
 
 # --------------------------------------------------------------------------------------

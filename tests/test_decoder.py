@@ -266,6 +266,43 @@ def test_truncated_bgzf_file_is_an_error_not_a_crash(emu_lib, tmp_path, cut):
             pass
 
 
+def _run_in_child(code):
+    """The failure mode under test is a SIGSEGV of the process: run the decoder in a child and look at how it ended."""
+    import subprocess
+    import sys
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=P.ROOT)
+
+
+@pytest.mark.parametrize("where", ["alone", "after_a_valid_block"])
+def test_gzip_header_whose_extra_field_points_past_the_file_end(emu_lib, tmp_path, where):
+    """A gzip member header with FEXTRA and xlen = 0xffff in the last bytes of a (memory-mapped) file: the subfield walk must
+    not leave the mapping.  OSError, not a crash -- from the whole-file decoder and from the stream."""
+    evil = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 0xff, 0xff]) + b"BC\x02\x00\x10\x00"      # 18 bytes, xlen 65535
+    head = b""
+    if where == "after_a_valid_block":
+        full = str(tmp_path / "f.bam")
+        synth.write_bam(full, P.load_fixture("minimap2__1.1.multi"), sort_order="unknown", block_bytes=700)
+        data = open(full, "rb").read()
+        head = data[:-28]                      # everything but the BGZF end-of-file marker
+    path = str(tmp_path / "evil.bam")
+    with open(path, "wb") as fh:
+        fh.write(head + evil)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from kindel_amd import _native as N\n"
+            "lib = N.Library(%r)\n"
+            "for how in ('file', 'stream'):\n"
+            "    try:\n"
+            "        if how == 'file': N.decode_file(%r, lib=lib)\n"
+            "        else:\n"
+            "            st = N.Stream(%r, chunk_bytes=4096, lib=lib)\n"
+            "            while st.next_batch() is not None: pass\n"
+            "        print(how, 'no error')\n"
+            "    except OSError as e: print(how, 'OSError')\n") % (P.ROOT, emu_lib.path, path, path)
+    r = _run_in_child(code)
+    assert r.returncode == 0, "decoder crashed (rc %d): %s" % (r.returncode, r.stderr[-400:])
+    assert r.stdout.split() == ["file", "OSError", "stream", "OSError"], r.stdout
+
+
 def test_native_bam_writer_roundtrip(emu_lib, tmp_path):
     """kd_write_bam (parallel record layout + parallel deflate) -> decoder == the batch; also readable by the pure-Python reader;
     a read with more than 65535 CIGAR operations goes through the CG tag."""

@@ -11,7 +11,7 @@ from oracle import oracle as ko
 from tests import parity as P
 
 QUIRKS = P.golden_quirks()
-MODES = [N.KD_MODE_GLOBAL, N.KD_MODE_AUTO, N.KD_MODE_STRIP]
+MODES = [N.KD_MODE_GLOBAL, N.KD_MODE_AUTO, N.KD_MODE_COOP, N.KD_MODE_STRIP]   # AUTO = k_window (lane per read), COOP = k_window_coop
 
 
 @pytest.mark.parametrize("mode", MODES)

@@ -6,7 +6,7 @@ import pytest
 from kindel_amd import _native as N
 from tests import fuzz
 
-MODES = [N.KD_MODE_GLOBAL, N.KD_MODE_AUTO, N.KD_MODE_STRIP]
+MODES = [N.KD_MODE_GLOBAL, N.KD_MODE_AUTO, N.KD_MODE_COOP, N.KD_MODE_STRIP]   # AUTO = k_window (lane per read), COOP = k_window_coop
 
 
 def _campaign(lib, seeds, n_reads, wild):

@@ -15,7 +15,7 @@ from tests import parity as P
 pytestmark = pytest.mark.gpu
 QUIRKS = P.golden_quirks()
 GOLD = P.golden_outputs()
-MODES = [N.KD_MODE_GLOBAL, N.KD_MODE_AUTO, N.KD_MODE_STRIP]
+MODES = [N.KD_MODE_GLOBAL, N.KD_MODE_AUTO, N.KD_MODE_COOP, N.KD_MODE_STRIP]   # AUTO = k_window (lane per read), COOP = k_window_coop
 ROOT = P.ROOT
 
 
@@ -115,7 +115,7 @@ def test_synthetic_config_device_resident(hip_lib, cfg, mode):
     _check_device_resident(hip_lib, SYN[cfg]("cuda:0"), mode, cfg)
 
 
-@pytest.mark.parametrize("cfg,mode", [("C2", N.KD_MODE_AUTO), ("C2", N.KD_MODE_STRIP), ("C3", N.KD_MODE_AUTO), ("C3", N.KD_MODE_STRIP),
+@pytest.mark.parametrize("cfg,mode", [("C2", N.KD_MODE_AUTO), ("C2", N.KD_MODE_STRIP), ("C3", N.KD_MODE_AUTO), ("C3", N.KD_MODE_COOP), ("C3", N.KD_MODE_STRIP),
                                       ("C4", N.KD_MODE_AUTO), ("C5", N.KD_MODE_AUTO)])
 def test_full_size_config_device_resident(hip_lib, cfg, mode):
     """BASELINE.json configs 2-5 at FULL size (C2 10 kb x 10^4, C3 5 Mbp x 500, C4 100 x 50 kb x 1000, C5 1 Mbp x 200
@@ -288,7 +288,7 @@ def test_mostly_clipped_reads_and_deep_sites(hip_lib):
     from kindel_amd import synth
     batch = synth.to_numpy(synth.short_reads([2500, 1200], 2500, seed=13, clip_p=0.6, indel_p=0.3))
     assert len(batch["contig"]) > 3 * 8192
-    for mode in (N.KD_MODE_AUTO, N.KD_MODE_STRIP):
+    for mode in (N.KD_MODE_AUTO, N.KD_MODE_COOP, N.KD_MODE_STRIP):
         P.assert_matches_oracle(P.Run(hip_lib, batch, mode=mode), what="mode %d" % mode)
 
 

@@ -185,3 +185,23 @@ def test_bench_refuses_more_ranks_than_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(max(n, 2)), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode != 0 and p.stdout.strip() == "" and "GPU(s) visible" in p.stderr
+
+
+def test_parse_records_without_countable_records(api_on_emu):
+    """parse_records('ref', 10, []) and an all-unmapped record list: the reference returns an all-zero alignment of ref_len
+    sites (kindel.py:29-39, :43-46), not an error."""
+    from kindel_amd import kindel as K
+
+    class Rec:
+        def __init__(self, pos, mapped, seq, cigars):
+            self.pos, self.mapped, self.seq, self.cigars = pos, mapped, seq, cigars
+
+    for recs in ([], [Rec(3, False, "ACGT", ((4, "M"),)), Rec(1, False, "*", ())]):
+        aln = K.parse_records("ref", 10, recs)
+        assert aln.ref_id == "ref" and len(aln.weights) == 10
+        assert all(sum(w.values()) == 0 for w in aln.weights)
+        assert aln.deletions == [0] * 11 and aln.clip_starts == [0] * 11 and aln.clip_ends == [0] * 11
+        assert len(aln.insertions) == 11 and all(d == {} for d in aln.insertions)
+        assert aln.clip_depth == [0] * 10 and list(aln.consensus_depth) == [0] * 10
+        seq, changes = K.consensus_sequence(aln.weights, aln.insertions, aln.deletions, None, False, 1, False)
+        assert seq == "N" * 10 and changes == ["N"] * 10
