@@ -209,6 +209,16 @@ int kd_profile_reset(kd_ctx *ctx);
 typedef struct kd_file kd_file;
 /* Decode a SAM text or BAM (BGZF) file into one kd_batch held by the handle.  No GPU use. */
 int kd_decode_open(kd_file **out, const char *path, int n_threads);
+/* Multi-GPU ingest (every rank opens the file and decodes only its share; kindel.py:143-151 distributed over the ranks):
+ * kd_bgzf_index -- number of BGZF blocks and, if in_off != NULL, the compressed file offset of each (to cut the file into byte
+ * shares); KD_E_IO when the file is not BGZF.
+ * kd_decode_open_span -- the records that begin in blocks [block_lo, block_hi): from the first offset at or behind the start
+ * of block_lo where 16 consecutive well-formed records begin (block 0: the first record) up to the offset found the same way
+ * for block_hi (or the end of the file).  The boundaries are a function of the file alone -- all ranks agree on them -- and
+ * the record chain that starts on one must end exactly on the next, else KD_E_IO (the caller then reads the whole file).
+ * info[4]: absolute uncompressed offsets of the span's start / end, records walked, 1 if the span reaches the end of file. */
+int kd_bgzf_index(const char *path, uint64_t *n_blocks, uint64_t *in_off, uint64_t cap);
+int kd_decode_open_span(kd_file **out, const char *path, int n_threads, uint64_t block_lo, uint64_t block_hi, uint64_t *info);
 const kd_batch *kd_decode_batch(const kd_file *f);
 uint32_t kd_decode_n_contigs(const kd_file *f);
 const char *kd_decode_contig_name(const kd_file *f, uint32_t i);

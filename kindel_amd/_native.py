@@ -30,7 +30,8 @@ ABI_SYMBOLS = (
     "kd_profile_enable kd_profile_get kd_profile_reset kd_decode_open kd_decode_batch kd_decode_n_contigs "
     "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error "
     "kd_stream_open kd_stream_n_contigs kd_stream_contig_name kd_stream_contig_len kd_stream_next kd_stream_n_records "
-    "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_write_bam kd_host_threads kd_host_inflate"
+    "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_write_bam kd_host_threads kd_host_inflate "
+    "kd_bgzf_index kd_decode_open_span"
 ).split()
 
 #: the reference exception each error code stands for (kindel.py:47,51-52,57,61,67,72,75,79)
@@ -100,6 +101,8 @@ class Library:
         L.kd_profile_get.argtypes = [p, C.POINTER(u32), p, p, p]
         L.kd_profile_reset.argtypes = [p]
         L.kd_decode_open.argtypes = [C.POINTER(p), C.c_char_p, C.c_int]
+        L.kd_bgzf_index.argtypes = [C.c_char_p, C.POINTER(u64), p, u64]
+        L.kd_decode_open_span.argtypes = [C.POINTER(p), C.c_char_p, C.c_int, u64, u64, p]
         L.kd_decode_batch.argtypes = [p]
         L.kd_decode_batch.restype = C.POINTER(kd_batch)
         L.kd_decode_n_contigs.argtypes = [p]
@@ -257,6 +260,62 @@ def host_inflate(data, out_len, lib=None):
     if rc != 0:
         raise ValueError("kd_host_inflate: malformed DEFLATE stream (rc %d)" % rc)
     return out[:int(out_len)].tobytes()
+
+
+def bgzf_index(path, lib=None):
+    """-> uint64[n_blocks]: compressed file offset of every BGZF block's data (kd_bgzf_index); OSError if the file is not BGZF"""
+    lib = lib or default_library()
+    n = C.c_uint64(0)
+    rc = lib.dll.kd_bgzf_index(os.fsencode(str(path)), C.byref(n), None, 0)
+    if rc:
+        raise _EXC.get(rc, KindelNativeError)("%s: %s" % (path, lib.dll.kd_decode_last_error().decode()))
+    off = np.zeros(n.value, np.uint64)
+    rc = lib.dll.kd_bgzf_index(os.fsencode(str(path)), C.byref(n), _ptr(off), off.size)
+    if rc:
+        raise _EXC.get(rc, KindelNativeError)("%s: %s" % (path, lib.dll.kd_decode_last_error().decode()))
+    return off
+
+
+def _batch_of_handle(lib, h):
+    owner = _DecodedFile(lib, h)
+    b = lib.dll.kd_decode_batch(h).contents
+    n = int(b.n_reads)
+    sizes = dict(contig=n, pos0=n, flag=n, seq_off=n, seq_len=n, cig_off=n, n_cig=n,
+                 seq4=int(b.seq4_bytes), cigar=int(b.cigar_words))
+    out = {}
+    for name, dt in _BATCH_FIELDS:
+        cnt = sizes[name]
+        addr = getattr(b, name)
+        if cnt and addr:
+            buf = (C.c_char * (cnt * np.dtype(dt).itemsize)).from_address(addr)
+            buf._kd_owner = owner                      # array -> .base (buf) -> owner -> kd_decode_close
+            a = np.frombuffer(buf, dtype=dt, count=cnt)
+            a.flags.writeable = False
+            out[name] = a
+        else:
+            out[name] = np.zeros(0, dt)
+    nc = lib.dll.kd_decode_n_contigs(h)
+    out["contig_names"] = np.asarray([lib.dll.kd_decode_contig_name(h, i).decode() for i in range(nc)])
+    out["contig_lens"] = np.asarray([lib.dll.kd_decode_contig_len(h, i) for i in range(nc)], np.uint32)
+    out["n_records"] = int(lib.dll.kd_decode_n_records(h))
+    return out
+
+
+def decode_span(path, block_lo, block_hi, threads=0, lib=None):
+    """The records that begin in BGZF blocks [block_lo, block_hi) of a BAM file (kd_decode_open_span) -> batch dict as
+    decode_file() plus span = (start offset, end offset, records, reaches_eof).  OSError when the record chain of the span does
+    not end on the next span's start (the caller falls back to the whole file)."""
+    lib = lib or default_library()
+    h = C.c_void_p()
+    info = np.zeros(4, np.uint64)
+    rc = lib.dll.kd_decode_open_span(C.byref(h), os.fsencode(str(path)), int(threads), int(block_lo), int(block_hi), _ptr(info))
+    if rc == KD_E_NOREF:
+        raise KeyError(lib.dll.kd_decode_last_error().decode())
+    if rc:
+        raise _EXC.get(rc, KindelNativeError)("%s: %s" % (path, lib.dll.kd_decode_last_error().decode()))
+    out = _batch_of_handle(lib, h)
+    out["span"] = tuple(int(x) for x in info)
+    return out
 
 
 def decode_file(path, threads=0, lib=None):

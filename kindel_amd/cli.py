@@ -9,10 +9,59 @@ import sys
 from . import __version__
 
 
+def _spawn_ranks(n, argv):
+    """`kindel consensus --gpus N` without a launcher: re-run this command as N ranks (one process per GPU) under
+    torch.distributed.run on 127.0.0.1; rank 0 prints.  Refuses when fewer than N GPUs are visible."""
+    import os
+    import socket
+    import subprocess
+    import torch
+    if os.environ.get("KINDEL_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < n:
+        print("kindel: --gpus %d requested but only %d GPU(s) visible" % (n, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "kindel_amd"] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def consensus(args):
+    import os
     from . import kindel
-    result = kindel.bam_to_consensus(args.bam_path, args.realign, args.min_depth, args.min_overlap,
-                                     args.clip_decay_threshold, args.mask_ends, args.trim_ends, args.uppercase)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        sys.exit(_spawn_ranks(args.gpus, args.argv))
+    if world > 1:
+        # one process per GPU: every rank decodes its share of the file, piles up its interval, one all-gather stitches
+        import torch
+        import torch.distributed as dist
+        rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+        backend = os.environ.get("KINDEL_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            device, dev_index = "cuda:%d" % local, local
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            dev_index = local % max(1, torch.cuda.device_count()) if torch.cuda.is_available() else 0
+            device = "cpu"
+        try:
+            result = kindel.bam_to_consensus_sharded(args.bam_path, rank, world, device=device, dev_index=dev_index, realign=args.realign,
+                                                     min_depth=args.min_depth, min_overlap=args.min_overlap,
+                                                     clip_decay_threshold=args.clip_decay_threshold, mask_ends=args.mask_ends,
+                                                     trim_ends=args.trim_ends, uppercase=args.uppercase)
+        finally:
+            dist.destroy_process_group()
+        if rank != 0:
+            return
+    else:
+        result = kindel.bam_to_consensus(args.bam_path, args.realign, args.min_depth, args.min_overlap,
+                                         args.clip_decay_threshold, args.mask_ends, args.trim_ends, args.uppercase)
     print("\n".join([r for r in result.refs_reports.values()]), file=sys.stderr)
     for consensus_record in result.consensuses:
         print(f">{consensus_record.name}")
@@ -60,6 +109,8 @@ def build_parser():
     c.add_argument("-t", "--trim-ends", action="store_true", default=False,
                    help="trim ambiguous nucleotides (Ns) from sequence ends")
     c.add_argument("-u", "--uppercase", action="store_true", default=False, help="close gaps using uppercase alphabet")
+    c.add_argument("--gpus", type=int, default=1, help="(kindel_amd) GPUs of this node to spread the reference positions over: "
+                   "one process per GPU, every rank decodes its share of the file, one all-gather stitches the FASTA")
     c.set_defaults(func=consensus)
     w = sub.add_parser("weights", help="Returns table of per-site nucleotide frequencies and coverage")
     w.add_argument("bam_path", help="path to SAM/BAM file")
@@ -90,6 +141,7 @@ def build_parser():
 def main(argv=None):
     parser = build_parser()
     args = parser.parse_args(argv)
+    args.argv = list(sys.argv[1:] if argv is None else argv)
     if not getattr(args, "func", None):
         parser.print_help()
         return 1

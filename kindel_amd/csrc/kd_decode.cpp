@@ -345,9 +345,28 @@ struct RangePlan {
     std::function<bool(unsigned)> make;      // make(t): bring the bytes of range t into d; false = failed
 };
 
+// Does d[q, n) begin with a well-formed BAM record (block_size, refID, pos, l_read_name, the lengths adding up, the read name
+// NUL-terminated)?  -> the offset of the record behind it, 0 if not, or KD_REC_UNKNOWN when too little of the record lies in front of n
+// to tell.  The speculative record starts of the parallel walk (below) and of a span of a file (kd_decode_open_span) use it.
+constexpr size_t KD_REC_EDGE = 4 + 32 + 255 + 8, KD_REC_UNKNOWN = ~(size_t)0;
+constexpr int KD_SPEC_CHAIN = 16;
+inline size_t bam_record_plausible(const uint8_t *d, size_t n, size_t q, uint32_t n_ref) {
+    if (q + 36 > n) return KD_REC_UNKNOWN;
+    const uint32_t bs = rd32(d + q);
+    if (bs < 32) return 0;
+    const uint8_t *r = d + q + 4;
+    const int32_t refid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
+    const uint32_t l_rn = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
+    if (refid < -1 || (refid >= 0 && (uint32_t)refid >= n_ref) || pos < -1 || l_rn == 0) return 0;
+    if (32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > bs) return 0;
+    if (q + 4 + 32 + (size_t)l_rn > n) return KD_REC_UNKNOWN;
+    if (r[32 + l_rn - 1] != 0) return 0;        // read name is NUL-terminated
+    return q + 4 + bs;
+}
+
 int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, int n_threads, bool final, size_t *consumed,
-                      const RangePlan *plan = nullptr) {
-    const size_t n = d.size();
+                      const RangePlan *plan = nullptr, size_t n_limit = 0) {
+    const size_t n = n_limit ? n_limit : d.size();   // (n_limit: the stream of records ends inside the buffer -- a span of a file)
     // pass 1 (touches 4 + 20 bytes per record): follow the block_size chain, record where every kept record starts and
     // the running totals of packed-base bytes / CIGAR words.  The chain is sequential by nature (a record's length
     // says where the next one begins), and at ~75 ns per record it was most of the decode time, so it is walked IN
@@ -445,7 +464,6 @@ int parse_bam_records(const Arr<uint8_t> &d, size_t o, uint32_t n_ref, File &f, 
     if (const char *e = getenv("KD_DECODE_RANGE_BYTES")) min_range = std::max<size_t>(64, strtoull(e, nullptr, 10));   // ... tests: small
     nt1 = (unsigned)std::max<size_t>(1, std::min<size_t>(nt1, (n - std::min(o, n)) / min_range));
     if (plan) nt1 = (unsigned)(plan->bound.size() - 1);
-    constexpr int KD_SPEC_CHAIN = 16;
     // (kept across calls by the calling thread: a stream parses ~70 chunks, and fresh vectors of this size come from mmap --
     //  page faults and munmap for every chunk)
     static thread_local std::vector<std::vector<Rec>> part_of_this_thread;
@@ -832,6 +850,9 @@ struct Stream {
     Arr<uint8_t> buf, carry;   // uncompressed bytes of the current chunk (carry + blocks); the cut-off record of the last one
     uint32_t n_ref = 0;
     bool header_done = false;
+    // a SPAN of the file (kd_decode_open_span): records from absolute uncompressed offset span_begin (inside block next_block)
+    // up to span_end; blocks from span_blk_end on are not touched.  Defaults: the whole file.
+    size_t span_skip = 0, span_end = ~(size_t)0, span_blk_end = ~(size_t)0;
     Arr<uint8_t> whole;        // non-BGZF gzip: the whole stream
     // SAM
     SamIds ids;
@@ -948,11 +969,13 @@ struct Stream {
             const size_t kept_before = f.append ? f.contig.size() : 0;
             const uint64_t recs_before = f.append ? f.n_records : 0;
             if (!scan_ahead(chunk_bytes)) { g_decode_error = "corrupt BGZF block header"; return KD_E_IO; }
-            if (next_block >= blocks.size() && scan_done && carry.size() == 0 && header_done) { done = true; return KD_OK; }
+            const size_t blk_end = std::min(blocks.size(), span_blk_end);   // (a span stops in front of span_blk_end)
+            const bool all_scanned = scan_done || span_blk_end <= blocks.size();
+            if (next_block >= blk_end && all_scanned && carry.size() == 0 && header_done) { done = true; return KD_OK; }
             // blocks of this chunk
             size_t b1 = next_block, add = 0;
             const size_t b0c = next_block;
-            while (b1 < blocks.size() && (add < chunk_bytes || b1 == next_block)) add += blocks[b1++].out_len;
+            while (b1 < blk_end && (add < chunk_bytes || b1 == next_block)) add += blocks[b1++].out_len;
             const size_t keep = carry.size();
             static const bool trace = getenv("KD_DECODE_TRACE") != nullptr;
             const auto tt0 = std::chrono::steady_clock::now();
@@ -980,6 +1003,9 @@ struct Stream {
                 std::vector<size_t> first(nr + 1);
                 for (size_t t = 0; t <= nr; t++) { first[t] = nb * t / nr; plan.bound[t] = at[first[t]]; }
                 plan.bound[0] = 0;                      // the carried-over bytes belong to the first range
+                for (size_t t = 0; t <= nr; t++) plan.bound[t] = std::max(plan.bound[t], span_skip);   // (a span begins inside its first block)
+                plan.bound[nr] = at[nb];
+                span_skip = 0;
                 const size_t b0 = next_block;
                 plan.make = [&, b0](unsigned t) -> bool {
                     for (size_t k = first[t]; k < first[t + 1]; k++)
@@ -987,16 +1013,24 @@ struct Stream {
                     return true;
                 };
                 next_block = b1;
-                final = scan_done && next_block >= blocks.size();
-                int rc = parse_bam_records(buf, 0, n_ref, f, n_threads, final, &used, &plan);
+                final = all_scanned && next_block >= blk_end;
+                // the last chunk of a span ends at span_end, which lies inside its last block: the walk must land exactly there
+                size_t limit = 0;
+                if (final && span_end != ~(size_t)0 && nb) {
+                    limit = keep + (span_end - blocks[b0].out_off);
+                    if (limit > buf.size()) limit = buf.size();
+                    for (size_t t = 0; t <= nr; t++) plan.bound[t] = std::min(plan.bound[t], limit);
+                }
+                int rc = parse_bam_records(buf, plan.bound[0], n_ref, f, n_threads, final, &used, &plan, limit);
                 if (rc) return rc;
+                if (limit) used = buf.size();           // (what lies behind the span's end belongs to the next span)
             } else {
                 if (!buf.resize(keep)) { g_decode_error = "out of memory"; return KD_E_NOMEM; }
                 if (keep) memcpy(buf.data(), carry.data(), keep);
                 if (!inflate_blocks(next_block, b1, keep)) { g_decode_error = "BGZF inflate failed"; return KD_E_IO; }
                 tt1 = std::chrono::steady_clock::now();
                 next_block = b1;
-                final = scan_done && next_block >= blocks.size();
+                final = all_scanned && next_block >= blk_end;
                 size_t o = 0;
                 if (!header_done) {
                     int rc = header_from(buf.data(), buf.size(), final);
@@ -1065,6 +1099,118 @@ int kd_decode_open(kd_file **out, const char *path, int n_threads) {
     F.names = one_chunk || st.is_text || names.empty() ? st.names : names; F.lens = one_chunk || st.is_text || lens.empty() ? st.lens : lens;
     F.n_records = st.n_records;
     finish_view(F);
+    *out = h;
+    return KD_OK;
+}
+
+// ---- a span of a BGZF / BAM file: the unit of work of one rank in the multi-GPU ingest ---------------------------------
+// kd_bgzf_index: the compressed offsets of the file's BGZF blocks (to cut it into byte shares).
+int kd_bgzf_index(const char *path, uint64_t *n_blocks, uint64_t *in_off, uint64_t cap) {
+    if (!path || !n_blocks) return KD_E_ARG;
+    RawView raw;
+    if (!raw.open(path)) { g_decode_error = std::string("cannot read ") + path; return KD_E_IO; }
+    std::vector<Block> blocks;
+    size_t o = 0, total = 0;
+    if (raw.size() < 18 || raw[0] != 0x1f || raw[1] != 0x8b || !scan_bgzf_some(raw.data(), raw.size(), &o, blocks, &total, ~(size_t)0 >> 1) ||
+        o != raw.size() || blocks.empty()) {
+        g_decode_error = "not a BGZF file";
+        return KD_E_IO;
+    }
+    *n_blocks = blocks.size();
+    if (in_off)
+        for (size_t b = 0; b < blocks.size() && b < cap; b++) in_off[b] = blocks[b].in_off;   // (offset of the block's DEFLATE data)
+    return KD_OK;
+}
+
+// The records that BEGIN in blocks [block_lo, block_hi) of a BAM file -- precisely: from the first offset at or behind the
+// start of block block_lo at which KD_SPEC_CHAIN consecutive well-formed records begin (block 0: the first record behind the
+// header) up to the offset found in the same way for block block_hi (the end of the file if there is no such block).  The
+// rule is a function of the file alone, so every rank that asks for a boundary gets the same one, and a walk that starts on
+// a true record start follows the record chain: it must END exactly on the next boundary -- if a boundary were a fake (sixteen
+// plausible records in a row that are not records) the walk would run over it and this call fails with KD_E_IO; the caller
+// then falls back to reading the whole file.  info: [0] / [1] absolute uncompressed offsets of the span's first byte / end,
+// [2] records walked (incl. RNAME '*'), [3] 1 if the span reaches the end of the file.
+int kd_decode_open_span(kd_file **out, const char *path, int n_threads, uint64_t block_lo, uint64_t block_hi, uint64_t *info) {
+    if (!out || !path) return KD_E_ARG;
+    *out = nullptr;
+    Stream st;
+    int rc = st.open(path, n_threads, (size_t)64 << 20);
+    if (rc) return rc;
+    if (!st.bgzf) { g_decode_error = "kd_decode_open_span: not a BGZF-compressed BAM file"; return KD_E_IO; }
+    if ((rc = st.preload_header())) return rc;
+    const std::vector<std::string> names = st.names;
+    const std::vector<uint32_t> lens = st.lens;
+    const size_t hdr_end = st.hdr_end;
+    if (!st.scan_ahead(~(size_t)0 >> 1) || !st.scan_done) { g_decode_error = "corrupt BGZF block header"; return KD_E_IO; }
+    const size_t nb = st.blocks.size();
+    const size_t total = nb ? st.blocks[nb - 1].out_off + st.blocks[nb - 1].out_len : 0;
+    const uint32_t n_ref = (uint32_t)names.size();
+    // first chain start at or behind the start of block b (absolute uncompressed offset), total if there is none
+    auto boundary = [&](size_t b, size_t *at) -> int {
+        if (b == 0) { *at = hdr_end; return KD_OK; }
+        if (b >= nb) { *at = total; return KD_OK; }
+        Arr<uint8_t> tmp;
+        size_t b1 = b, have = 0, want = (size_t)1 << 18;
+        for (;;) {
+            while (b1 < nb && have < want) {
+                if (!tmp.resize(have + st.blocks[b1].out_len)) { g_decode_error = "out of memory"; return KD_E_NOMEM; }
+                if (!inflate_raw(st.raw.data() + st.blocks[b1].in_off, st.blocks[b1].in_len, tmp.data() + have, st.blocks[b1].out_len)) {
+                    g_decode_error = "BGZF inflate failed"; return KD_E_IO;
+                }
+                have += st.blocks[b1].out_len; b1++;
+            }
+            const bool at_eof = b1 >= nb;
+            bool need_more = false;
+            for (size_t q = 0; q < have; q++) {
+                size_t z = q;
+                int ok = 0;
+                bool ran_out = false;
+                while (ok < KD_SPEC_CHAIN) {
+                    if (z == have && at_eof) break;                       // the chain ends with the file
+                    const size_t nx = bam_record_plausible(tmp.data(), have, z, n_ref);
+                    if (nx == KD_REC_UNKNOWN || (nx && nx > have)) { ran_out = true; break; }
+                    if (!nx) break;
+                    ok++; z = nx;
+                }
+                if (ok == KD_SPEC_CHAIN || (ok > 0 && z == have && at_eof)) { *at = st.blocks[b].out_off + q; return KD_OK; }
+                if (ran_out) {
+                    if (at_eof) continue;        // a record that claims to run past the end of the file: not a record start
+                    need_more = true; break;     // cannot judge q with what is inflated: inflate more and start over
+                }
+            }
+            if (!need_more) { *at = total; return KD_OK; }
+            want *= 4;
+        }
+    };
+    size_t S = 0, E = 0;
+    if ((rc = boundary((size_t)std::min<uint64_t>(block_lo, nb), &S)) || (rc = boundary((size_t)std::min<uint64_t>(block_hi, nb), &E))) return rc;
+    kd_file *h = new kd_file();
+    File &F = h->f;
+    F.contig.resize(0); F.pos0.resize(0); F.flag.resize(0); F.seq_off.resize(0); F.seq_len.resize(0);
+    F.cig_off.resize(0); F.n_cig.resize(0); F.seq4.resize(0); F.cigar.resize(0);
+    F.names = names; F.lens = lens;
+    uint64_t n_rec = 0;
+    if (S < E) {
+        size_t bs = 0;
+        while (bs + 1 < nb && st.blocks[bs + 1].out_off <= S) bs++;     // the block S lies in
+        size_t be = bs;
+        while (be < nb && st.blocks[be].out_off < E) be++;              // first block that begins at or behind E
+        st.next_block = bs; st.span_skip = S - st.blocks[bs].out_off; st.span_end = E; st.span_blk_end = be;
+        st.header_done = true; st.n_ref = n_ref; st.names = names; st.lens = lens;
+        st.carry.resize(0); st.done = false; st.n_records = 0;
+        F.append = true;
+        for (;;) {
+            bool got = false;
+            rc = st.next(F, &got);
+            if (rc) { delete h; return rc; }
+            if (st.done || (!got && st.next_block >= be)) break;
+        }
+        F.append = false;
+        n_rec = st.n_records;
+    }
+    F.n_records = n_rec;
+    finish_view(F);
+    if (info) { info[0] = S; info[1] = E; info[2] = n_rec; info[3] = E >= total ? 1 : 0; }
     *out = h;
     return KD_OK;
 }

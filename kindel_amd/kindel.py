@@ -576,6 +576,35 @@ def bam_to_consensus(bam_path, realign=False, min_depth=1, min_overlap=9, clip_d
     return result(consensuses, refs_changes, refs_reports)
 
 
+def bam_to_consensus_sharded(bam_path, rank, world, device="cpu", dev_index=0, group=None, realign=False, min_depth=1, min_overlap=9,
+                             clip_decay_threshold=0.1, mask_ends=50, trim_ends=False, uppercase=False, threads=0, lib=None):
+    """bam_to_consensus (kindel.py:488-555) with the per-contig loop (:143-151, :501-551) spread over `world` ranks, one GPU
+    each (kindel_amd/shard.py: sharded ingest, shard-local pileup, one all-gather).  Call on every rank of an initialised
+    torch.distributed group; every rank returns the same result tuple.  --realign needs whole-contig clip tables on one host
+    and is not distributed: use one GPU for it."""
+    from . import shard
+    if realign:
+        raise NotImplementedError("kindel_amd: realign=True is a single-GPU path (clip-dominant regions are found on whole-contig "
+                                  "tables); run without --gpus")
+    out = shard.pileup_consensus_sharded(bam_path, rank, world, device=device, dev_index=dev_index, group=group, min_depth=min_depth,
+                                         threads=threads, lib=lib)
+    consensuses, refs_changes, refs_reports = [], {}, {}
+    for cid in out["order"]:
+        ref_id = out["names"][cid]
+        seq = out["seqs"][cid].decode("ascii")
+        if trim_ends:
+            seq = seq.strip("N")        # kindel.py:425-426
+        if uppercase:
+            seq = seq.upper()           # kindel.py:427-428
+        ch = out["changes"][cid]
+        consensuses.append(consensus_seqrecord(seq, ref_id))
+        refs_reports[ref_id] = _report(ref_id, out["minmax"][cid], ch, None, bam_path, realign, min_depth, min_overlap,
+                                       clip_decay_threshold, trim_ends, uppercase)
+        refs_changes[ref_id] = _changes_list(ch)
+    result = namedtuple("result", ["consensuses", "refs_changes", "refs_reports"])
+    return result(consensuses, refs_changes, refs_reports)
+
+
 # --------------------------------------------------------------------------------------
 # tables as DataFrames (kindel.py:558-664): integer columns from the device, floats on host
 # --------------------------------------------------------------------------------------

@@ -276,3 +276,202 @@ def stitch(engine, interval, device, group=None, intervals=None, pad=None):
     gathered, world = gather(engine, interval, device, group, pad=pad, intervals=intervals)
     rows = np.ascontiguousarray(gathered.cpu().numpy())
     return assemble(rows, engine.contig_lens, world, interval, intervals=intervals)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Product entry: ONE file, N ranks (north_star: "reference positions shard by contig/interval across the 8 GPUs of one node
+# with a single RCCL all-gather to stitch the final FASTA").  Ingest is sharded too -- end to end the host decode is the
+# long pole, so N GPUs only help if every rank decodes 1/N of the file:
+#   * rank r decodes the records that begin in its byte share of the BGZF blocks (kd_decode_open_span; boundaries are a
+#     function of the file alone, verified through the record chain);
+#   * ONE small all-gather of per-rank facts (first / last start key, sortedness, longest footprint, span offsets): in a
+#     coordinate-sorted file the shares are ordered by position, so rank r OWNS the sites from its first read's start to
+#     the next rank's -- work-balanced by construction (equal bytes = equal reads);
+#   * reads that reach into the interval from the neighbouring shares (at most the longest footprint before it, the longest
+#     leading clip behind it) are decoded by the rank itself from the few blocks either side -- no read exchange;
+#   * pileup + consensus of the interval (kd_set_shard: shard-local tables, no collective), then the ONE all-gather of
+#     stitch().
+# Anything that breaks the premises (not BGZF, not sorted, a span whose chain does not close) is agreed on in that first
+# all-gather and every rank reads the whole file instead -- same results, no ingest speed-up.  This is what
+# parse_bam's loop over the records (/root/reference/kindel/kindel.py:143-151) becomes across ranks.
+# ---------------------------------------------------------------------------------------------------------------------
+_REC_FIELDS = ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig")
+
+
+def concat_batches(parts):
+    """Host batches (dicts of numpy arrays over the same contig table) -> one batch, offsets rebased, order kept."""
+    parts = [p for p in parts if len(p["contig"])]
+    if not parts:
+        return None
+    if len(parts) == 1:
+        return parts[0]
+    out = {k: np.concatenate([np.asarray(p[k]) for p in parts]) for k in ("contig", "pos0", "flag", "seq_len", "n_cig")}
+    so, co, sq, cg = [], [], [], []
+    s_at = c_at = 0
+    for p in parts:
+        so.append(np.asarray(p["seq_off"], np.uint64) + np.uint64(s_at))
+        co.append(np.asarray(p["cig_off"], np.uint64) + np.uint64(c_at))
+        sq.append(np.asarray(p["seq4"])); cg.append(np.asarray(p["cigar"]))
+        s_at += len(p["seq4"]); c_at += len(p["cigar"])
+    out["seq_off"], out["cig_off"] = np.concatenate(so), np.concatenate(co)
+    out["seq4"], out["cigar"] = np.concatenate(sq), np.concatenate(cg)
+    out["contig_names"], out["contig_lens"] = parts[0]["contig_names"], parts[0]["contig_lens"]
+    return out
+
+
+def _subset(batch, keep):
+    out = dict(batch)
+    for k in _REC_FIELDS:
+        out[k] = np.asarray(batch[k])[keep]
+    return out
+
+
+def _start_keys(base, batch):
+    return base.astype(np.int64)[np.asarray(batch["contig"], np.int64)] + np.maximum(np.asarray(batch["pos0"], np.int64), 0)
+
+
+def ingest_sharded(path, rank, world, device="cpu", group=None, threads=0, lib=None):
+    """This rank's reads of `path` and its G-space interval.
+    -> dict(batch (host, may be None), interval, intervals, names, lens, order (contig ids, first appearance), mode, stats)"""
+    import torch
+    import torch.distributed as dist
+    from . import _native as N
+
+    def gather_rows(vals):
+        t = torch.tensor(vals, dtype=torch.int64, device=device)
+        if world == 1:
+            return t.cpu().numpy().reshape(1, -1)
+        out = torch.empty(world * t.numel(), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(out, t, group=group)
+        return out.cpu().numpy().reshape(world, -1)
+
+    def gather_obj(o):
+        if world == 1:
+            return [o]
+        out = [None] * world
+        dist.all_gather_object(out, o, group=group)
+        return out
+
+    own, ok, blocks = None, 1, None
+    try:
+        off = N.bgzf_index(path, lib=lib)
+        size = __import__("os").path.getsize(path)
+        blocks = [0] + [int(np.searchsorted(off, size * p // world)) for p in range(1, world)] + [len(off)]
+        own = N.decode_span(path, blocks[rank], blocks[rank + 1], threads=threads, lib=lib)
+    except OSError:
+        ok = 0          # not BGZF (SAM text, plain gzip) or a span that does not close
+    n = len(own["contig"]) if own is not None else 0
+    first = last = -1
+    is_sorted, reach, lead, s0, s1 = 1, 0, 0, 0, 0
+    if own is not None:
+        lens = own["contig_lens"]
+        base, S = g_layout(lens)
+        s0, s1 = own["span"][0], own["span"][1]
+        if n:
+            g0 = _start_keys(base, own)
+            g_lo, g_hi = footprints(lens, own)
+            first, last = int(g0[0]), int(g0[-1])
+            is_sorted = int(bool(np.all(g0[1:] >= g0[:-1])) and bool(np.all(np.asarray(own["pos0"]) >= 0)))
+            reach, lead = int((g_hi - g0).max()), int((g0 - g_lo).max())
+    rows = gather_rows([ok, n, first, last, is_sorted, reach, lead, s0, s1])       # collective 1 of 2 (72 bytes per rank)
+    good = bool(rows[:, 0].all() and rows[:, 4].all())
+    if good:
+        good = all(rows[r, 8] == rows[r + 1, 7] for r in range(world - 1))        # every span ends where the next begins
+        filled = [r for r in range(world) if rows[r, 1] > 0]
+        good = good and all(rows[a, 3] <= rows[b, 2] for a, b in zip(filled, filled[1:]))   # shares ordered by position
+    if not good:
+        # premises broken: every rank reads the whole file and takes its share of an equal-work partition (same results)
+        full = N.decode_file(path, threads=threads, lib=lib)
+        lens = full["contig_lens"]
+        ivs = partition_weighted(lens, full["contig"], full["pos0"], full["seq_len"], world) if len(full["contig"]) else partition(lens, world)
+        batch = None
+        if len(full["contig"]):
+            g_lo, g_hi = footprints(lens, full)
+            batch = _subset(full, reads_of_rank(lens, g_lo, g_hi, rank, world, intervals=ivs))
+        c = np.asarray(full["contig"])
+        _, fi = np.unique(c, return_index=True)
+        order = [int(c[i]) for i in np.sort(fi)]
+        return dict(batch=batch, interval=ivs[rank], intervals=ivs, names=[str(x) for x in full["contig_names"]], lens=lens, order=order,
+                    mode="whole-file", stats=dict(decoded_records=len(c)))
+    lens = own["contig_lens"]
+    base, S = g_layout(lens)
+    # rank r owns [cut_r, cut_{r+1}): from its first read's start to the next non-empty share's
+    cuts = [0] * (world + 1)
+    cuts[world] = S
+    nxt = S
+    for r in range(world - 1, 0, -1):
+        if rows[r, 1] > 0:
+            nxt = int(rows[r, 2])
+        cuts[r] = nxt
+    ivs = [(cuts[r], cuts[r + 1]) for r in range(world)]
+    lo, hi = ivs[rank]
+    M, Lmax = int(rows[:, 5].max()), int(rows[:, 6].max())
+    pieces, extra = [own], 0
+    if hi > lo:
+        # reads of EARLIER shares that reach into [lo, ...): they start after lo - M
+        if rank > 0 and lo > 0:
+            b_hi, step, back = blocks[rank], 1, []
+            while b_hi > 0:
+                b_lo = max(0, b_hi - step)
+                sp = N.decode_span(path, b_lo, b_hi, threads=threads, lib=lib)
+                back.insert(0, sp)
+                b_hi, step = b_lo, step * 2
+                if len(sp["contig"]) and int(_start_keys(base, sp)[0]) + M <= lo:
+                    break
+            pieces = back + pieces
+            extra += sum(len(b["contig"]) for b in back)
+        # reads of LATER shares that touch the halo site hi (or reach back over it with a leading clip): they start by hi + Lmax
+        if rank + 1 < world and hi < S:
+            b_lo, step, fwd = blocks[rank + 1], 1, []
+            nblk = blocks[world]
+            while b_lo < nblk:
+                b_hi = min(nblk, b_lo + step)
+                sp = N.decode_span(path, b_lo, b_hi, threads=threads, lib=lib)
+                fwd.append(sp)
+                b_lo, step = b_hi, step * 2
+                if len(sp["contig"]) and int(_start_keys(base, sp)[-1]) > hi + Lmax:
+                    break
+            pieces = pieces + fwd
+            extra += sum(len(b["contig"]) for b in fwd)
+    batch = concat_batches(pieces) if hi > lo else None
+    if batch is not None:
+        g_lo, g_hi = footprints(lens, batch)
+        batch = _subset(batch, (g_hi > lo) & (g_lo <= hi))
+    used = gather_obj(np.unique(np.asarray(own["contig"])).tolist())              # (a handful of ints per rank; same collective round)
+    order = sorted(set(c for u in used for c in u))      # coordinate-sorted file: first appearance = ascending contig id
+    return dict(batch=batch, interval=(lo, hi), intervals=ivs, names=[str(x) for x in own["contig_names"]], lens=lens, order=order,
+                mode="sharded", stats=dict(decoded_records=n, neighbour_records=extra, blocks=(blocks[rank], blocks[rank + 1])))
+
+
+def pileup_consensus_sharded(path, rank, world, device="cpu", dev_index=0, group=None, min_depth=1, threads=0, lib=None):
+    """ingest_sharded + shard-local pileup + consensus + stitch.  -> dict(seqs, changes, minmax, names, lens, order, mode, stats),
+    identical on every rank.  A reference exception raised by any rank's reads (KeyError / IndexError / RuntimeError,
+    kindel.py:47-81) is agreed on by all ranks and raised everywhere."""
+    import torch
+    import torch.distributed as dist
+    from . import _native as N
+    ing = ingest_sharded(path, rank, world, device=device, group=group, threads=threads, lib=lib)
+    eng = N.Engine(ing["lens"], device=dev_index, lib=lib)
+    err = None
+    try:
+        eng.set_shard(*ing["interval"])
+        if ing["batch"] is not None and len(ing["batch"]["contig"]):
+            eng.push(ing["batch"])
+        try:
+            eng.finalize()
+        except (KeyError, IndexError, RuntimeError) as e:
+            err = (type(e).__name__, str(e))
+        if world > 1:
+            errs = [None] * world
+            dist.all_gather_object(errs, err, group=group)
+        else:
+            errs = [err]
+        first_err = next((e for e in errs if e), None)
+        if first_err:     # (the lowest rank's = the earliest position's, for a sorted file the reference's own choice)
+            raise {"KeyError": KeyError, "IndexError": IndexError, "RuntimeError": RuntimeError}[first_err[0]](first_err[1])
+        eng.consensus_run(min_depth)
+        seqs, changes, minmax = stitch(eng, ing["interval"], device, group, intervals=ing["intervals"])
+    finally:
+        eng.close()
+    return dict(seqs=seqs, changes=changes, minmax=minmax, names=ing["names"], lens=ing["lens"], order=ing["order"], mode=ing["mode"],
+                stats=ing["stats"])

@@ -321,3 +321,54 @@ def test_native_bam_writer_roundtrip(emu_lib, tmp_path):
     N.write_bam(str(p), empty, lib=emu_lib)
     got = N.decode_file(p, lib=emu_lib)
     assert len(got["contig"]) == 0 and list(got["contig_lens"]) == [3000, 1500]
+
+
+@pytest.mark.parametrize("key,block_bytes,parts", [("bwa_mem__1.1.sub_test", 700, 5), ("minimap2__1.1.multi", 300, 8),
+                                                    ("ext__1.issue23.debug", 4000, 3), ("bwa_mem__3.1.sub_test", 65280, 4)])
+def test_spans_of_a_bam_file_tile_it_exactly(emu_lib, tmp_path, key, block_bytes, parts, monkeypatch):
+    """kd_decode_open_span: cutting the file's BGZF blocks into `parts` byte shares, the spans' records concatenated are the
+    file's records in order -- every record exactly once, whichever block a cut falls into (records straddle blocks) -- and the
+    end offset of each span is the start offset of the next (what the ranks verify with one small all-gather)."""
+    monkeypatch.setenv("KD_DECODE_RANGE_BYTES", "2000")      # several worker ranges per chunk even on these small files
+    batch = P.load_fixture(key)
+    path = str(tmp_path / "s.bam")
+    synth.write_bam(path, batch, sort_order="unknown", block_bytes=block_bytes)
+    whole = N.decode_file(path, lib=emu_lib)
+    off = N.bgzf_index(path, lib=emu_lib)
+    size = os.path.getsize(path)
+    cuts = [0] + [int(np.searchsorted(off, size * p // parts)) for p in range(1, parts)] + [len(off)]
+    got = {k: [] for k in ("contig", "pos0", "flag", "seq_len", "n_cig")}
+    seqs, cigs, spans, n_rec = [], [], [], 0
+    for p in range(parts):
+        sp = N.decode_span(path, cuts[p], cuts[p + 1], threads=3, lib=emu_lib)
+        spans.append(sp["span"])
+        n_rec += sp["span"][2]
+        for k in got:
+            got[k].append(np.asarray(sp[k]).copy())
+        for so, sl in zip(sp["seq_off"].tolist(), sp["seq_len"].tolist()):
+            seqs.append(sp["seq4"][so: so + (sl + 1) // 2].tobytes())
+        for co, nc in zip(sp["cig_off"].tolist(), sp["n_cig"].tolist()):
+            cigs.append(sp["cigar"][co: co + nc].tobytes())
+        assert list(sp["contig_names"]) == list(whole["contig_names"])
+    for a, b in zip(spans, spans[1:]):
+        assert a[1] == b[0]
+    assert spans[-1][3] == 1 and n_rec == whole["n_records"]
+    for k in got:
+        assert np.array_equal(np.concatenate(got[k]), whole[k]), k
+    for i, (so, sl) in enumerate(zip(whole["seq_off"].tolist(), whole["seq_len"].tolist())):
+        assert seqs[i] == whole["seq4"][so: so + (sl + 1) // 2].tobytes(), i
+    for i, (co, nc) in enumerate(zip(whole["cig_off"].tolist(), whole["n_cig"].tolist())):
+        assert cigs[i] == whole["cigar"][co: co + nc].tobytes(), i
+    # single-block spans and an empty one
+    one = N.decode_span(path, 3, 4, lib=emu_lib)
+    assert one["span"][0] <= one["span"][1]
+    assert N.decode_span(path, len(off), len(off) + 5, lib=emu_lib)["span"][2] == 0
+
+
+def test_span_decoder_refuses_what_is_not_bgzf(emu_lib, tmp_path):
+    p = tmp_path / "x.sam"
+    p.write_text("@SQ\tSN:c\tLN:10\nr\t0\tc\t1\t60\t4M\t*\t0\t0\tACGT\t*\n")
+    with pytest.raises(OSError):
+        N.bgzf_index(str(p), lib=emu_lib)
+    with pytest.raises(OSError):
+        N.decode_span(str(p), 0, 1, lib=emu_lib)

@@ -358,3 +358,40 @@ def test_full_size_config_as_eight_shards(hip_lib, cfg):
         assert all(iv[0] in set(int(b) for b in base) for iv in ivs)
     del tb
     torch.cuda.empty_cache()
+
+
+def test_cli_two_ranks_on_one_gpu(hip_lib, tmp_path):
+    """`python -m kindel_amd consensus --gpus 2 x.bam` end to end on the real library: two processes (here sharing the one GPU,
+    gloo instead of RCCL), each decoding its share of the file, rank 0 prints -- stdout equals the single-process run and the
+    reference's golden FASTA."""
+    key = "bwa_mem__3.1.sub_test"
+    path = str(tmp_path / "x.bam")
+    synth.write_bam(path, P.load_fixture(key), sort_order="unknown", block_bytes=3000)
+    env = dict(os.environ, KINDEL_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, "-m", "kindel_amd", "consensus", path], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    two = subprocess.run([sys.executable, "-m", "kindel_amd", "consensus", "--gpus", "2", path], capture_output=True, text=True, timeout=900,
+                         env=env, cwd=ROOT)
+    assert one.returncode == 0 and two.returncode == 0, two.stderr[-2000:]
+    assert two.stdout == one.stdout
+    g = GOLD[key]["contigs"][0]
+    assert two.stdout == ">%s_cns\n%s\n" % (g["name"], g["consensus"])
+    assert g["report"].replace("{bam_path}", path) in two.stderr
+
+
+@pytest.mark.parametrize("key,chunk", [("bwa_mem__2.1.sub_test", 5000), ("minimap2__1.1.multi", 900), ("ext__1.issue23.debug", 30000)])
+def test_streamed_ingest_many_small_batches(hip_lib, tmp_path, key, chunk):
+    """kd_push_stream on the GPU with chunks small enough that batch boundaries cut windows (decode thread + pushing thread,
+    dozens of batches into the same tables) == one whole-file batch == the reference's golden consensus."""
+    from kindel_amd import kindel as K
+    path = str(tmp_path / "p.bam")
+    synth.write_bam(path, P.load_fixture(key), sort_order="unknown")
+    a = K.pileup_file(path, stream=False)
+    b = K.pileup_file(path, stream=True, chunk_bytes=chunk)
+    assert b.ingest["batches"] > 3
+    assert [a.names[c] for c in a.order] == [b.names[c] for c in b.order]
+    for ca, cb in zip(a.order, b.order):
+        assert np.array_equal(a.tables(ca), b.tables(cb))
+    ra = K.bam_to_consensus(path)
+    assert [c.sequence for c in ra.consensuses] == [g["consensus"] for g in GOLD[key]["contigs"]]

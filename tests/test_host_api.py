@@ -205,3 +205,15 @@ def test_parse_records_without_countable_records(api_on_emu):
         assert aln.clip_depth == [0] * 10 and list(aln.consensus_depth) == [0] * 10
         seq, changes = K.consensus_sequence(aln.weights, aln.insertions, aln.deletions, None, False, 1, False)
         assert seq == "N" * 10 and changes == ["N"] * 10
+
+
+def test_cli_refuses_more_ranks_than_gpus(tmp_path):
+    """`kindel consensus --gpus N` spawns one process per GPU -- and refuses when there are fewer GPUs than ranks."""
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count() + 1 if torch.cuda.is_available() else 2
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KINDEL_DIST_BACKEND")}
+    p = subprocess.run([sys.executable, "-m", "kindel_amd", "consensus", "--gpus", str(max(n, 2)), str(tmp_path / "x.bam")],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 2 and p.stdout == "" and "GPU(s) visible" in p.stderr

@@ -139,3 +139,136 @@ def test_two_rank_stitch_matches_oracle(emu_lib):
             assert seqs[cid].decode() == oseq, (rank, cid)
             assert [None if c == 0 else chr(c) for c in changes[cid]] == och
             assert minmax[cid] == oa.depth_minmax()
+
+
+def _worker_file(rank, world, port, emu_path, path, q):
+    """The product's multi-GPU entry on CPU: every rank decodes its share of ONE file (gloo, emulated kernels)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kindel_amd import _native as N
+    from kindel_amd import kindel as K
+    from kindel_amd import shard
+    lib = N.Library(emu_path)
+    N._default = lib
+    out = shard.pileup_consensus_sharded(path, rank, world, device="cpu", lib=lib)
+    try:
+        res = K.bam_to_consensus_sharded(path, rank, world, device="cpu", lib=lib)
+        res = ([(c.name, c.sequence) for c in res.consensuses], res.refs_reports, {k: "".join("." if c is None else c for c in v) for k, v in res.refs_changes.items()})
+    except Exception as e:       # noqa: BLE001 -- handed to the parent
+        res = repr(e)
+    q.put((rank, out["mode"], out["stats"], [out["names"][c] for c in out["order"]], res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_file_ranks(emu_lib, path, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_file, args=(r, world, port, emu_lib.path, path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+@pytest.mark.parametrize("key,world,block_bytes,expect_mode", [
+    ("bwa_mem__1.1.sub_test", 2, 900, "sharded"),        # the reference's own HCV fixture, coordinate sorted
+    ("bwa_mem__4.1.sub_test", 3, 2000, "sharded"),
+    ("segemehl__2.1.sub_test", 4, 1500, "sharded"),      # indel-heavy
+    ("minimap2__hxb2-gp120-mutated", 2, 1200, "whole-file"),   # SO:unsorted in the reference: every rank reads the whole file
+])
+def test_one_file_across_ranks_matches_the_reference_golden(emu_lib, tmp_path, key, world, block_bytes, expect_mode):
+    """`kindel consensus --gpus N x.bam` underneath: every rank opens the file and decodes only the BGZF blocks of its share
+    (+ the neighbouring reads that reach into its interval), one all-gather stitches -- consensus, report and change codes equal
+    what the unmodified reference produced for the fixture (tests/golden), on every rank."""
+    from kindel_amd import synth
+    from tests import parity as P
+    gold = P.golden_outputs()[key]["contigs"]
+    path = str(tmp_path / (key + ".bam"))
+    synth.write_bam(path, P.load_fixture(key), sort_order="unknown", block_bytes=block_bytes)
+    results = _run_file_ranks(emu_lib, path, world)
+    assert [r[1] for r in results] == [expect_mode] * world, results[0][1:3]
+    if expect_mode == "sharded":
+        total = len(P.load_fixture(key)["contig"])
+        assert sum(r[2]["decoded_records"] for r in results) == total          # every record decoded by exactly one rank
+        assert max(r[2]["decoded_records"] for r in results) < 1.5 * total / world + 50
+        assert all(r[2]["neighbour_records"] < 0.2 * total + 200 for r in results)
+    for rank, mode, stats, order, res in results:
+        assert not isinstance(res, str), res
+        recs, reports, changes = res
+        assert order == [g["name"] for g in gold]
+        assert recs == [(g["name"] + "_cns", g["consensus"]) for g in gold], rank
+        for g in gold:
+            assert reports[g["name"]] == g["report"].replace("{bam_path}", path)
+            assert changes[g["name"]] == g["changes"]
+
+
+def test_one_file_across_ranks_synthetic_multi_contig(emu_lib, tmp_path):
+    """Many contigs, more ranks than some shares deserve (empty intervals), reads with leading clips across the cuts: vs the oracle."""
+    from kindel_amd import synth
+    from oracle import oracle as ko
+    batch = synth.to_numpy(synth.short_reads([4000, 2500, 300, 5000], 12, seed=41, clip_p=0.3))
+    path = str(tmp_path / "m.bam")
+    synth.write_bam(path, batch, sort_order="coordinate", block_bytes=1100)
+    results = _run_file_ranks(emu_lib, path, 5)
+    assert all(r[1] == "sharded" for r in results)
+    for rank, mode, stats, order, res in results:
+        assert not isinstance(res, str), res
+        recs, reports, changes = res
+        assert [n for n, _ in recs] == ["ctg%d_cns" % c for c in ko.contig_order(batch)] or len(recs) == 4
+        for (name, seq), cid in zip(recs, ko.contig_order(batch)):
+            oa = ko.parse_records(batch, cid)
+            oseq, och = oa.consensus_sequence()
+            assert seq == oseq, (rank, cid)
+            assert changes[name[:-4]] == "".join("." if c is None else c for c in och)
+
+
+def test_a_reference_exception_reaches_every_rank(emu_lib, tmp_path):
+    """A base outside A,C,G,T,N in one rank's share: KeyError on every rank (kindel.py:51-52), not a hang."""
+    from kindel_amd import synth
+    batch = synth.to_numpy(synth.short_reads([6000], 10, seed=43))
+    seq4 = batch["seq4"].copy()
+    i = len(batch["contig"]) // 4                     # a read in the first rank's share
+    seq4[int(batch["seq_off"][i]) + 3] = 0x3C         # 'M' (an IUPAC code) inside an aligned segment
+    batch["seq4"] = seq4
+    path = str(tmp_path / "bad.bam")
+    synth.write_bam(path, batch, sort_order="coordinate", block_bytes=1500)
+    results = _run_file_ranks_expect_error(emu_lib, path, 3)
+    assert all("KeyError" in r for r in results), results
+
+
+def _worker_file_err(rank, world, port, emu_path, path, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kindel_amd import _native as N
+    from kindel_amd import kindel as K
+    lib = N.Library(emu_path)
+    try:
+        K.bam_to_consensus_sharded(path, rank, world, device="cpu", lib=lib)
+        q.put("no error")
+    except Exception as e:       # noqa: BLE001
+        q.put(type(e).__name__ + ": " + str(e))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_file_ranks_expect_error(emu_lib, path, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_file_err, args=(r, world, port, emu_lib.path, path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
