@@ -1299,6 +1299,8 @@ int kd_write_bam(const char *path, const kd_batch *b, uint32_t n_contigs, const 
     Arr<uint8_t> raw;
     if (!raw.resize((size_t)off[n])) return KD_E_NOMEM;
     memcpy(raw.data(), head.data(), head.size());
+    const char *qual_mode = getenv("KD_WRITE_BAM_QUAL");
+    const bool phred = qual_mode && !strcmp(qual_mode, "phred");
     {
         const size_t per = (n + nt - 1) / std::max(1u, nt);
         auto fill = [&](unsigned t) {
@@ -1325,7 +1327,16 @@ int kd_write_bam(const char *path, const kd_batch *b, uint32_t n_contigs, const 
                     q += 4 * (size_t)nc;
                 }
                 memcpy(q, b->seq4 + b->seq_off[i], ((size_t)sl + 1) / 2); q += ((size_t)sl + 1) / 2;
-                memset(q, 0xff, sl); q += sl;
+                if (!phred) memset(q, 0xff, sl);     // qualities absent (SAM '*'): compresses to nothing
+                else {                                // KD_WRITE_BAM_QUAL=phred: a skewed spread over Phred 2 .. 41, deterministic per (read, base) --
+                    for (uint32_t j = 0; j < sl; j++) {   // a file that compresses like sequencer output (3 - 4 x), not 15 x
+                        uint32_t hsh = (uint32_t)i * 0x9e3779b1u + j * 0x85ebca6bu;
+                        hsh ^= hsh >> 15; hsh *= 0x2c1b3c6du; hsh ^= hsh >> 12; hsh *= 0x297a2d39u; hsh ^= hsh >> 15;
+                        const uint32_t a = hsh & 63u, c2 = (hsh >> 6) & 63u;
+                        q[j] = (uint8_t)(41u - (a * c2) / 104u);      // most bases near 41, a tail down to ~3
+                    }
+                }
+                q += sl;
                 if (nc > 65535) {
                     q[0] = 'C'; q[1] = 'G'; q[2] = 'B'; q[3] = 'I'; w32(q + 4, nc);
                     for (uint32_t k = 0; k < nc; k++) w32(q + 8 + 4 * (size_t)k, cg[k]);

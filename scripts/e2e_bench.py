@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--chunk-mb", type=int, default=64)
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--out", default="")
+    ap.add_argument("--qual", default="absent", choices=["absent", "phred"], help="base qualities of the written BAM: absent (0xff, compresses "
+                    "~15x) or a Phred-like spread (compresses 3-4x like sequencer output: what the inflater really has to do)")
+    ap.add_argument("--check", action="store_true", help="compare the FASTA with the oracle's consensus of the same batch (full-size bit-exactness)")
     ap.add_argument("--sweep", default="", help="streamed ingest only, for each THREADSxCHUNK_MB of a comma-separated list (e.g. 16x64,24x128)")
     a = ap.parse_args()
 
@@ -52,7 +55,15 @@ def main():
     del tb
     path = os.path.join(tempfile.gettempdir(), "kd_e2e_%s_%g.bam" % (a.config, a.scale))
     t1 = time.time()
+    if a.qual == "phred":
+        os.environ["KD_WRITE_BAM_QUAL"] = "phred"
     N.write_bam(path, batch, threads=a.threads)
+    os.environ.pop("KD_WRITE_BAM_QUAL", None)
+    want_fasta = None
+    if a.check:     # the oracle's consensus of the batch that was written (TEST INFRASTRUCTURE, outside every timed region)
+        from oracle import oracle as ko
+        names = ["ctg%d" % i for i in range(len(batch["contig_lens"]))]
+        want_fasta = "".join(">%s_cns\n%s\n" % (names[c], ko.parse_records(batch, c).consensus_sequence()[0]) for c in ko.contig_order(batch)).encode()
     t_write = time.time() - t1
     t_make = time.time() - t0
     size = os.path.getsize(path)
@@ -102,10 +113,15 @@ def main():
     bw = min(runs_w, key=lambda r: r[0]["total_s"])
     bs = min(runs_s, key=lambda r: r[0]["total_s"])
     assert bw[1] == bs[1], "streamed and whole-file FASTA differ"
+    if want_fasta is not None:
+        assert bs[1] == want_fasta, "end-to-end FASTA differs from the oracle's"
+    import hashlib
     line = {
         "what": "end-to-end BAM path -> FASTA bytes (SURVEY 8d ii)", "config": a.config, "scale": a.scale, "reads": n_reads,
         "aligned_events": ev, "bam_bytes": size, "host_cores_visible": os.cpu_count(), "host_cpu_quota": _quota(), "decode_threads": a.threads or N.host_threads(),
-        "best_of": a.repeat, "chunk_mb": a.chunk_mb, "fasta_bytes": len(bw[1]), "same_fasta": True,
+        "best_of": a.repeat, "chunk_mb": a.chunk_mb, "fasta_bytes": len(bw[1]), "same_fasta": True, "qualities": a.qual,
+        "bit_exact_vs_oracle": (True if want_fasta is not None else None),
+        "consensus_sha256": hashlib.sha256(b"\n".join(l for l in bw[1].split(b"\n") if l and not l.startswith(b">"))).hexdigest(),
         "whole_file": {k: round(v, 4) for k, v in bw[0].items()}, "whole_file_events_per_s": ev / bw[0]["total_s"],
         "streamed": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in bs[0].items()},
         "streamed_events_per_s": ev / bs[0]["total_s"],
