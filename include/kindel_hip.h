@@ -188,7 +188,8 @@ int kd_consensus_fetch_all(kd_ctx *ctx, uint8_t *seq_out, uint64_t cap, uint64_t
 /* Device-side view of the whole shard's consensus (for the multi-GPU all-gather):
  * *dev_ptr = device pointer to the concatenated bytes, *n_bytes its length. */
 int kd_consensus_device(kd_ctx *ctx, void **dev_ptr, uint64_t *n_bytes);
-/* Same for the per-site change codes: *dev_ptr = device pointer to changes[kd_total_sites] (G-space). */
+/* Same for the per-site change codes: *dev_ptr + g = the change code of G-space site g, valid for the sites of the context's
+ * interval [g_lo, g_hi) only (the array is shard-local like the tables; the pointer is biased to G-space indexing). */
 int kd_changes_device(kd_ctx *ctx, void **dev_ptr);
 /* Host-side metadata of the last run: contig_off[n_contigs+1] = byte offset of each contig in the
  * concatenated consensus (last entry = total), depth_minmax[2*n_contigs]. Either may be NULL. */

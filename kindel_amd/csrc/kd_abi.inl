@@ -124,7 +124,8 @@ int kd_consensus_device(kd_ctx *ctx, void **dev_ptr, uint64_t *n_bytes) {
 int kd_changes_device(kd_ctx *ctx, void **dev_ptr) {
     if (!ctx || !dev_ptr) return KD_E_ARG;
     if (!ctx->e.have_cns) return ctx->e.fail(KD_E_ARG, "kd_changes_device: call kd_consensus_run first");
-    *dev_ptr = ctx->e.b_changes.p;
+    // (the array is shard-local; the pointer is biased so that  pointer + g  is the change code of G-space site g of the shard)
+    *dev_ptr = (uint8_t *)ctx->e.b_changes.p - ctx->e.alloc_lo;
     return KD_OK;
 }
 int kd_consensus_offsets(kd_ctx *ctx, uint64_t *contig_off, uint32_t *depth_minmax) {

@@ -59,7 +59,7 @@ struct KdEngine {
     Buf b_hkey, b_hcnt, b_hrep, b_evslot, b_best, b_win, b_flag;
     uint64_t hash_cap = 0;
     // what the last insertion reduction left behind (k_ins_cleanup undoes it before the event buffers are reused)
-    uint64_t ins_dirty_ev = 0;
+    uint64_t ins_dirty_ev = 0, ins_dirty_bias = 0;   // (bias: alloc_lo when the reduction ran -- best[] / win[] are shard-local)
     KdInsTab ins_dirty_tab;
     Buf b_cns, b_changes, b_tilesum, b_tilemm, b_tileoff, b_coff;
 
@@ -213,7 +213,7 @@ struct KdEngine {
         if (!ins_dirty_ev) return KD_OK;
         KdIns I = insdesc();
         if (rt.launch("k_ins_cleanup", k_ins_cleanup, (unsigned)((ins_dirty_ev + KD_INS_CHUNK - 1) / KD_INS_CHUNK), KD_BLOCK, 0, I, ins_dirty_tab,
-                      (kd_u64)ins_dirty_ev, (kd_u64 *)b_best.p, (uint32_t *)b_win.p))
+                      (kd_u64)ins_dirty_ev, (kd_u64 *)b_best.p - ins_dirty_bias, (uint32_t *)b_win.p - ins_dirty_bias))
             return hipfail("k_ins_cleanup");
         ins_dirty_ev = 0;
         return KD_OK;
@@ -505,11 +505,17 @@ struct KdEngine {
         int rc;
         if (!tables_ready && (rc = prepare_tables())) return rc;   // nothing was pushed: all-zero tables
         if ((rc = ins_cleanup())) return rc;
-        // best[] / win[] are site-indexed and all-zero between reductions (k_ins_cleanup): zeroed once, when allocated
-        if (b_win.cap < (size_t)S * 4) {
-            if ((rc = ensure(b_win, (size_t)S * 4)) || (rc = ensure(b_best, (size_t)S * 8))) return rc;
-            if (rt.memset(b_win.p, 0, (size_t)S * 4) || rt.memset(b_best.p, 0, (size_t)S * 8)) return hipfail("finalize: memset win");
+        // best[] / win[] / flag[] (and changes[], kd_consensus_run) are site-indexed and SHARD-LOCAL like the tables: allocated for
+        // the sites [alloc_lo, alloc_hi) only, the pointers handed to the kernels biased by -alloc_lo so that they keep indexing
+        // with global sites (8 ranks x one C3-sized interval each: 14 B/site x 5 M sites per rank, not x 40 M).
+        // best[] / win[] are all-zero between reductions (k_ins_cleanup): zeroed once, when (re)allocated.
+        const size_t n_local = (size_t)(alloc_hi - alloc_lo) + 64;
+        if (b_win.cap < n_local * 4 || b_best.cap < n_local * 8) {
+            if ((rc = ensure(b_win, n_local * 4)) || (rc = ensure(b_best, n_local * 8))) return rc;
+            if (rt.memset(b_win.p, 0, b_win.cap) || rt.memset(b_best.p, 0, b_best.cap)) return hipfail("finalize: memset win");
         }
+        kd_u64 *best_g = (kd_u64 *)b_best.p - alloc_lo;
+        uint32_t *win_g = (uint32_t *)b_win.p - alloc_lo;
         // the event counts are exact as of the last push (k_prep reserves the slots, push_device reads them back)
         const uint64_t n_ev = h_status[KDS_N_EV];
         bool launched = false;
@@ -525,14 +531,14 @@ struct KdEngine {
             const unsigned ge = (unsigned)((n_ev + KD_BLOCK - 1) / KD_BLOCK), g4 = (unsigned)((n_ev + KD_INS_CHUNK - 1) / KD_INS_CHUNK);
             if (rt.memset(d_status + KDS_INS_COLLISION, 0, 8)) return hipfail("finalize: memset status");
             if (rt.launch("k_ins_insert", k_ins_insert, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev)) return hipfail("k_ins_insert");
-            if (rt.launch("k_ins_verify_max", k_ins_verify_max, g4, KD_BLOCK, 0, I, H, (kd_u64)n_ev, (kd_u64 *)b_best.p, d_status))
+            if (rt.launch("k_ins_verify_max", k_ins_verify_max, g4, KD_BLOCK, 0, I, H, (kd_u64)n_ev, best_g, d_status))
                 return hipfail("k_ins_verify_max");
-            ins_dirty_ev = n_ev; ins_dirty_tab = H;
+            ins_dirty_ev = n_ev; ins_dirty_tab = H; ins_dirty_bias = alloc_lo;
             return KD_OK;
         };
         auto pick = [&]() -> int {
             const unsigned ge = (unsigned)((n_ev + KD_INS_CHUNK - 1) / KD_INS_CHUNK);
-            if (rt.launch("k_ins_pick", k_ins_pick, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev, (const kd_u64 *)b_best.p, (uint32_t *)b_win.p))
+            if (rt.launch("k_ins_pick", k_ins_pick, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev, (const kd_u64 *)best_g, win_g))
                 return hipfail("k_ins_pick");
             return KD_OK;
         };
@@ -544,16 +550,16 @@ struct KdEngine {
                 if ((rc = ensure(b_hkey, cap * 8)) || (rc = ensure(b_hcnt, cap * 4)) || (rc = ensure(b_hrep, cap * 4))) return rc;
                 if (rt.memset(b_hkey.p, 0, b_hkey.cap) || rt.memset(b_hcnt.p, 0, b_hcnt.cap)) return hipfail("finalize: memset hash");
             }
-            if ((rc = ensure(b_evslot, n_ev * 4)) || (rc = ensure(b_flag, (size_t)S + 64))) return rc;
+            if ((rc = ensure(b_evslot, n_ev * 4)) || (rc = ensure(b_flag, n_local))) return rc;
             hash_cap = cap;
             H.key = (kd_u64 *)b_hkey.p; H.cnt = (uint32_t *)b_hcnt.p; H.rep = (uint32_t *)b_hrep.p;
             H.ev_slot = (uint32_t *)b_evslot.p; H.cap = cap; H.sites = S;
             // sites where an insertion can be emitted at all, then the events on those sites
             KdTabs T = tabs();
             if (rt.launch("k_ins_flag", k_ins_flag, (unsigned)(((alloc_hi - alloc_lo) / 4 + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, T,
-                          (kd_u64)alloc_lo, (kd_u64)alloc_hi, (uint8_t *)b_flag.p) ||
+                          (kd_u64)alloc_lo, (kd_u64)alloc_hi, (uint8_t *)b_flag.p - alloc_lo) ||
                 rt.launch("k_ins_filter", k_ins_filter, (unsigned)((n_ev + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, I, (kd_u64)n_ev,
-                          (const uint8_t *)b_flag.p, (kd_u64)S, (uint32_t *)b_evslot.p))
+                          (const uint8_t *)b_flag.p - alloc_lo, (kd_u64)S, (uint32_t *)b_evslot.p))
                 return hipfail("k_ins_flag / k_ins_filter");
             if ((rc = reduce(0))) return rc;
             launched = true;
@@ -711,9 +717,7 @@ struct KdEngine {
         const uint64_t tile_first = g_lo / KD_CNS_TILE;
         const uint64_t n_tiles = std::max<uint64_t>(1, (std::min<uint64_t>(S, g_hi) + KD_CNS_TILE - 1) / KD_CNS_TILE - tile_first);
         const uint64_t cap = n_tiles * KD_CNS_TILE + pool_final + 64;
-        const bool fresh_changes = b_changes.cap < S;
-        if ((rc = ensure(b_changes, S))) return rc;
-        if (fresh_changes && rt.memset(b_changes.p, 0, S)) return hipfail("consensus: memset changes");  // sites outside the shard stay 0
+        if ((rc = ensure(b_changes, (size_t)(alloc_hi - alloc_lo) + 64))) return rc;   // shard-local (read back through copy_changes)
         // the small per-run arrays live in ONE device block (one upload, one download per run, not one per array):
         // u64 contig_off[n_contigs + 1] | u64 patch_off[np1] | u64 patch_start[np1] | u64 patch_end[np1] | u32 minmax[2 n_contigs]
         const size_t np1 = (size_t)n_patches + 1, nc1 = (size_t)n_contigs + 1;
@@ -733,7 +737,7 @@ struct KdEngine {
         KdTabs T = tabs();
         KdIns I = insdesc();
         KdCns C;
-        C.seg_contig = d_seg; C.ins_win = (const uint32_t *)b_win.p; C.min_depth = min_depth; C.n_patches = n_patches;
+        C.seg_contig = d_seg; C.ins_win = (const uint32_t *)b_win.p - alloc_lo; C.min_depth = min_depth; C.n_patches = n_patches;
         C.patch_start = d_ps; C.patch_end = d_pe;
         C.g_lo = g_lo; C.g_hi = g_hi;
         if (rt.launch("k_cns_count", k_cns_count, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64)tile_first, (kd_u64 *)b_tilesum.p,
@@ -743,7 +747,7 @@ struct KdEngine {
                       (kd_u64)n_tiles, (const KdTileMM *)b_tilemm.p, d_mm))
             return hipfail("k_cns_scan");
         if (rt.launch("k_cns_emit", k_cns_emit, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64)tile_first, (const kd_u64 *)b_tileoff.p,
-                      (uint8_t *)b_cns.p, (uint8_t *)b_changes.p, d_coff, n_contigs, d_poff))
+                      (uint8_t *)b_cns.p, (uint8_t *)b_changes.p - alloc_lo, d_coff, n_contigs, d_poff))
             return hipfail("k_cns_emit");
         h_coff.assign((size_t)n_contigs + 1, 0);
         h_minmax.assign(2 * (size_t)n_contigs, 0);
@@ -763,6 +767,15 @@ struct KdEngine {
         return KD_OK;
     }
 
+    // change codes of G-space sites [g0, g0 + n) into dst: the part inside this context's emit interval from the (shard-local)
+    // device array, zero elsewhere
+    int copy_changes(uint8_t *dst, uint64_t g0, uint64_t n) {
+        memset(dst, 0, (size_t)n);
+        const uint64_t a = std::max(g0, g_lo), b = std::min(g0 + n, std::min<uint64_t>(g_hi, S));
+        if (a < b && rt.d2h(dst + (a - g0), (uint8_t *)b_changes.p + (a - alloc_lo), (size_t)(b - a))) return 1;
+        return 0;
+    }
+
     int consensus_fetch(uint32_t contig, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint8_t *changes,
                         uint32_t *depth_minmax, uint64_t *patch_off) {
         if (!have_cns) return fail(KD_E_ARG, "kd_consensus_fetch: call kd_consensus_run first");
@@ -773,8 +786,7 @@ struct KdEngine {
             if (o1 - o0 > cap) return fail(KD_E_ARG, "kd_consensus_fetch: buffer too small");
             if (o1 > o0 && rt.d2h(seq_out, (uint8_t *)b_cns.p + o0, o1 - o0)) return hipfail("consensus fetch: d2h");
         }
-        if (changes && clen[contig] && rt.d2h(changes, (uint8_t *)b_changes.p + cbase[contig], clen[contig]))
-            return hipfail("consensus fetch: d2h changes");
+        if (changes && clen[contig] && copy_changes(changes, cbase[contig], clen[contig])) return hipfail("consensus fetch: d2h changes");
         if (depth_minmax) { depth_minmax[0] = h_minmax[2 * contig]; depth_minmax[1] = h_minmax[2 * contig + 1]; }
         if (patch_off)
             for (size_t k = 0; k < h_pstart.size(); k++) {
@@ -794,7 +806,7 @@ struct KdEngine {
             if (o1 - o0 > cap) return fail(KD_E_ARG, "kd_consensus_fetch_all: buffer too small");
             if (o1 > o0 && rt.d2h(seq_out, (uint8_t *)b_cns.p + o0, o1 - o0)) return hipfail("consensus fetch: d2h");
         }
-        if (changes && S && rt.d2h(changes, b_changes.p, S)) return hipfail("consensus fetch: d2h changes");
+        if (changes && S && copy_changes(changes, 0, S)) return hipfail("consensus fetch: d2h changes");
         return KD_OK;
     }
 };

@@ -194,7 +194,7 @@ def pileup_batch(batch, bam_path=None, device=0, lib=None, mode=N.KD_MODE_AUTO, 
 #: a header whose contigs add up to at most this many sites is laid out whole and the file is STREAMED (decode of batch
 #: k+1 overlapped with copy + kernels of batch k); a larger header (a human genome's) goes through the whole-file decode,
 #: which lays out only the contigs that have records
-STREAM_MAX_SITES = 1 << 28
+STREAM_MAX_SITES = 1 << 26      # 67 M sites = 5 GB of tables at 76 B/site (the streamed path lays out every @SQ contig)
 
 
 def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=None):

@@ -36,9 +36,11 @@ def load_reference():
         raise RuntimeError("reference not present: neither %s nor %s (python -m oracle.make_ref)" % (REF_ROOT, _REF_BUILT))
     root = REF_ROOT if _source_available() else _REF_BUILT
     repo = os.path.dirname(_HERE)
-    for p in (os.path.join(_HERE, "ref_shims"), root, repo):
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    for p in (os.path.join(_HERE, "ref_shims"), root):     # BEHIND everything else: the reference tree has a `tests` package too
         if p not in sys.path:
-            sys.path.insert(0, p)
+            sys.path.append(p)
     os.environ.setdefault("TQDM_DISABLE", "1")
     mod = importlib.import_module("kindel.kindel")
     assert os.path.abspath(mod.__file__).startswith(root), mod.__file__
