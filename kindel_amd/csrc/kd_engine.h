@@ -31,7 +31,7 @@ struct KdEngine {
     uint64_t g_lo = 0, g_hi = 0;  // emit interval [g_lo, g_hi)
     int mode = KD_MODE_AUTO;
     uint32_t W = 0, slice_cfg = 0;     // sites per LDS window; 0 = the kernel's own default (kd_set_tuning overrides both kernels)
-    static constexpr uint32_t W_LANE = 640;   // k_window (lane per read): 19 ch x 640 x 2 B = 24 KB of LDS histogram per workgroup
+    static constexpr uint32_t W_LANE = 448;   // k_window (lane per read): 19 ch x (448 + 192 reach + 16 halo) x 2 B = 25 KB of LDS histogram per workgroup
     static constexpr uint32_t W_COOP = 640;   // k_window_coop (16 lanes per read): 33 rows x (320 + 32) dwords = 46 KB + 29 KB of staged tile, two workgroups per CU
     bool coop_mode() const { return mode == KD_MODE_COOP; }   // (measured slower than k_window: DESIGN.md section 3; never the default)
     uint32_t window_sites(bool coop) const { return W ? W : coop ? W_COOP : W_LANE; }
@@ -325,9 +325,13 @@ struct KdEngine {
                 }
                 slice = std::min<uint32_t>(slice, 32768u);   // u16 LDS counters: an item may not tally more reads than that
                 const uint32_t *order = nullptr;
+                // the histogram reaches H sites past the window: an entry is tallied whole by the window it starts in (kd_window.h:
+                // OWNERSHIP); H = the longest footprint of this pass's entries, up to 256 sites (longer ones leave a remainder)
+                uint32_t H = use_coop ? 0u : (uint32_t)std::min<uint64_t>(256, (h_status[span_slot] + 63) & ~uint64_t(63));
+                while (H && KD_WINDOW_LDS_BYTES((W + H + 2 * KD_HALO) / 2) > (size_t)160 * 1024 - 1024) H -= 64;   // (a hand-picked window near the LDS limit)
                 if (in_order) {
                     if (rt.launch("k_plan_ranges", k_plan_ranges, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, info, (kd_u64)ne, w0,
-                                  n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status))
+                                  n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status, span_slot == (uint32_t)KDS_B_MAXSPAN ? H : 0u))
                         return hipfail("k_plan_ranges");
                 } else {
                     // counting sort of the regular entries by window -> permutation `order`
@@ -376,13 +380,13 @@ struct KdEngine {
                         return hipfail("k_window_coop");
                     return KD_OK;
                 }
-                const uint32_t Wh = (W + 2 * KD_HALO) / 2;   // dwords per channel row
+                const uint32_t Wh = (W + H + 2 * KD_HALO) / 2;   // dwords per channel row
                 const size_t lds = KD_WINDOW_LDS_BYTES(Wh);
                 const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
                 const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
                 if (rt.launch(seg_read ? "k_window_segments" : "k_window", k_window, grid, KD_BLOCK, lds, R, info, order,
                               (const KdCkpt *)b_ckpt.p, seg_read, T, (const kd_u64 *)wl, (const kd_u64 *)wh, (const kd_u64 *)io,
-                              (const uint32_t *)iw, (kd_u64)items_cap, w0, W, Wh, slice, d_status))
+                              (const uint32_t *)iw, (kd_u64)items_cap, w0, W, H, Wh, slice, d_status))
                     return hipfail("k_window");
                 return KD_OK;
             };
@@ -404,7 +408,7 @@ struct KdEngine {
                 const uint32_t *order = nullptr;
                 if (in_order) {
                     if (rt.launch("k_plan_ranges", k_plan_ranges, (ns_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, info, (kd_u64)ne, ws0,
-                                  ns_win, Ws, slice, swl, swh, sio, (const kd_u64 *)d_status))
+                                  ns_win, Ws, slice, swl, swh, sio, (const kd_u64 *)d_status, 0u))
                         return hipfail("k_plan_ranges");
                 } else {
                     const uint32_t n_bins = (uint32_t)((S + Ws - 1) / Ws);

@@ -22,10 +22,13 @@ __device__ __forceinline__ kd_u64 kd_lower_bound(const KdRInfo *rinfo, kd_u64 n,
 // into slices of `slice` reads (one work item each).
 __global__ void __launch_bounds__(KD_BLOCK)
 k_plan_ranges(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t slice,
-              kd_u64 *win_lo, kd_u64 *win_hi, kd_u64 *item_off, const kd_u64 *status) {
+              kd_u64 *win_lo, kd_u64 *win_hi, kd_u64 *item_off, const kd_u64 *status, uint32_t H) {
     const uint32_t w = blockIdx.x * KD_BLOCK + threadIdx.x;   // local index; the window is w0 + w (shard-local planning)
     if (w >= n_win) return;
-    const kd_u64 maxspan = status[KDS_B_MAXSPAN];
+    // H (k_window: OWNERSHIP): an entry that starts in front of the window has something left for it only if it is longer than
+    // H -- except for the first window of the plan, which takes such entries from its first site
+    kd_u64 maxspan = status[KDS_B_MAXSPAN];
+    if (w) maxspan = maxspan > H ? maxspan - H : 0;
     const kd_u64 wlo = (kd_u64)(w0 + w) * W, whi = wlo + W;
     const kd_u64 lo = kd_lower_bound(rinfo, n_reads, wlo > maxspan ? wlo - maxspan : 0);
     const kd_u64 hi = kd_lower_bound(rinfo, n_reads, whi + status[KDS_B_MAXLEAD]);  // leading clips reach back

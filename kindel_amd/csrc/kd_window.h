@@ -440,7 +440,16 @@ __device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const
 __global__ void __launch_bounds__(KD_BLOCK, KD_WINDOW_OCC)   // 5 wavefronts per SIMD = the 5 workgroups per CU the LDS footprint allows
 k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *ckpt, const uint32_t *seg_read, KdTabs T,
          const kd_u64 *win_lo, const kd_u64 *win_hi, const kd_u64 *item_off, const uint32_t *item_win, kd_u64 items_cap, uint32_t w0,
-         uint32_t W, uint32_t Wh_, uint32_t slice, kd_u64 *status) {
+         uint32_t W, uint32_t H, uint32_t Wh_, uint32_t slice, kd_u64 *status) {
+    // OWNERSHIP (round 3).  The histogram of window w covers the sites [wlo, whi + H): H sites more than the window.  An entry
+    // is tallied by the window its START lies in, over [start, min(end, whi + H)) -- with H >= the longest footprint of the
+    // batch that is the whole read, once, on the loop-free walk, whatever window edge it crosses (before, every read that
+    // crossed an edge was walked twice, both times on the clipped path: 1.23 visits per read on the bench workload, the
+    // crossing ones with the worst lane occupancy).  What a longer entry leaves over is tallied by the windows behind:
+    // window w > s takes [max(start, wlo + H), min(end, whi + H)) ("early" entries: a shifted origin, the general walk), and
+    // the reach of a leading clip back into the windows in FRONT of its read's start window is tallied there over
+    // [wlo, whi) ("late" entries).  The flush adds the H extra sites to the tables like the others: table counters are
+    // sums of work items anyway.
     // seg_read == NULL: `rinfo` describes the batch's reads (first pass, class REG = short regular reads).
     // seg_read != NULL: `rinfo` describes SEGMENTS of long reads (k_prep_long; entry e = 256 * b + t is thread t's
     // run of ops of the long read seg_read[b], entered through checkpoint ckpt[e]); `order` is then never NULL.
@@ -450,12 +459,15 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
     uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * Wh);  // tile-relative read indices
     uint16_t *l_cplx = l_plain + KD_TILE;
     __shared__ kd_u64 s_item;
-    __shared__ uint32_t s_cnt[2][3];   // [tile parity][plain inside the window, plain across an edge, complex] list lengths
+    // [tile parity][list]: 0 own plain entries that end inside the histogram (l_plain from the front), 1 own plain entries cut by
+    // its end (l_plain from the back), 2 own complex entries (l_cplx from the front), 3 early / late entries (l_cplx from the back)
+    __shared__ uint32_t s_cnt[2][4];
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
     const kd_u64 total = status[KDS_TOTAL_ITEMS];
     const uint32_t nh = (uint32_t)KD_HCH * (uint32_t)Wh;   // histogram dwords
-    const int32_t Wi = (int32_t)W;
+    const int32_t Wi = (int32_t)W, We = (int32_t)(W + H);     // the window / the histogram's reach, in sites
+    uint32_t *hist_early = hist0 + (H / 2) * KD_HPITCH;       // pair of site wlo + H: origin of the early entries' walk (H is even)
 #ifdef KD_PHASE_CLOCKS
     long long c_zero = 0, c_cls = 0, c_plain = 0, c_cplx = 0, c_wait = 0, c_flush = 0, c_deq = 0, c_mark;
 #define KD_MARK(acc) { const long long n_ = clock64(); acc += n_ - c_mark; c_mark = n_; }
@@ -464,7 +476,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
 #define KD_MARK(acc)
 #endif
     for (;;) {
-        if (t == 0) { s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL); s_cnt[0][0] = 0; s_cnt[0][1] = 0; s_cnt[0][2] = 0; }
+        if (t == 0) { s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL); s_cnt[0][0] = 0; s_cnt[0][1] = 0; s_cnt[0][2] = 0; s_cnt[0][3] = 0; }
         __syncthreads();
         const kd_u64 item = s_item;
         if (item >= total || item >= items_cap) break;   // (>= items_cap: k_plan_items has raised KDS_INTERNAL)
@@ -496,18 +508,24 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
 #pragma unroll
             for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
                 const kd_u64 gs = p_gs[u], span = p_sc[u] >> KD_SPAN_SHIFT;
-                if ((p_sc[u] & 3u) == KD_CLS_REG && gs + span > wlo && gs - p_ld[u] < whi) {
+                if ((p_sc[u] & 3u) == KD_CLS_REG) {
                     const uint32_t rel = u * KD_BLOCK + t;
-                    // plain reads: those inside the window fill l_plain from the front, those across an edge from the back
-                    if (!(p_sc[u] & KD_INFO_PLAIN)) l_cplx[atomicAdd(&s_cnt[par][2], 1u)] = (uint16_t)rel;
-                    else if (gs >= wlo && gs + span <= whi) l_plain[atomicAdd(&s_cnt[par][0], 1u)] = (uint16_t)rel;
-                    else l_plain[KD_TILE - 1u - atomicAdd(&s_cnt[par][1], 1u)] = (uint16_t)rel;
+                    if (gs >= wlo && gs < whi) {             // starts here: this window's own
+                        if (!(p_sc[u] & KD_INFO_PLAIN)) l_cplx[atomicAdd(&s_cnt[par][2], 1u)] = (uint16_t)rel;
+                        else if (gs + span <= whi + H) l_plain[atomicAdd(&s_cnt[par][0], 1u)] = (uint16_t)rel;
+                        else l_plain[KD_TILE - 1u - atomicAdd(&s_cnt[par][1], 1u)] = (uint16_t)rel;
+                    } else if (gs < wlo) {                   // starts in a window in front: what its owner(s) left of it for this one
+                        // (the FIRST window of a shard's plan has no window in front: it takes such entries from its own first site)
+                        if (gs + span > wlo + (w ? H : 0u)) l_cplx[KD_TILE - 1u - atomicAdd(&s_cnt[par][3], 1u)] = (uint16_t)(rel | 0x8000u);
+                    } else if (gs - p_ld[u] < whi) {         // starts behind: its leading clip reaches back into this window
+                        l_cplx[KD_TILE - 1u - atomicAdd(&s_cnt[par][3], 1u)] = (uint16_t)(rel | 0x4000u);
+                    }
                 }
             }
             __syncthreads();
             KD_MARK(c_cls)
-            const uint32_t ni = s_cnt[par][0], np = s_cnt[par][1], ncx = s_cnt[par][2];
-            if (t == 0) { s_cnt[par ^ 1u][0] = 0; s_cnt[par ^ 1u][1] = 0; s_cnt[par ^ 1u][2] = 0; }   // next tile's counters (idle until its classify)
+            const uint32_t ni = s_cnt[par][0], np = s_cnt[par][1], ncx = s_cnt[par][2], nx = s_cnt[par][3];
+            if (t == 0) { s_cnt[par ^ 1u][0] = 0; s_cnt[par ^ 1u][1] = 0; s_cnt[par ^ 1u][2] = 0; s_cnt[par ^ 1u][3] = 0; }   // next tile's counters (idle until its classify)
 #pragma unroll
             for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
                 const kd_u64 j = tb + KD_TILE + u * KD_BLOCK + t;
@@ -532,7 +550,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 const uint32_t e = ((lane / KD_LANE_GROUP) * rows_i + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
                 if (e < ni) {
                     const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
-                    kd_walk_inner(rd, i, rinfo[i], wlo, Wi, Wh, hist0);
+                    kd_walk_inner(rd, i, rinfo[i], wlo, We, Wh, hist0);
                 }
             }
             // (each list's rows start at the wavefront after the one that took the last row of the list before)
@@ -541,7 +559,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 const uint32_t e = ((lane / KD_LANE_GROUP) * rows_p + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
                 if (e < np) {
                     const kd_u64 j = tb + l_plain[KD_TILE - 1u - e], i = order ? (kd_u64)order[j] : j;
-                    kd_walk_plain(rd, i, rinfo[i], wlo, Wi, Wh, hist0);
+                    kd_walk_plain(rd, i, rinfo[i], wlo, We, Wh, hist0);
                 }
             }
             KD_MARK(c_plain)
@@ -558,9 +576,35 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                         const kd_u64 ir = seg_read[i / KD_BLOCK];
                         const uint32_t nc = rd.n_cig[ir], per = (nc + KD_BLOCK - 1) / KD_BLOCK;
                         const uint32_t k0 = (uint32_t)(i % KD_BLOCK) * per, k1 = k0 + per < nc ? k0 + per : nc;
-                        kd_walk_ops(rd, ir, k0, k1, grel, (int32_t)ckpt[i].q, (int32_t)ri.lead, foot_end, Wi, Wh, hist0);
-                    } else if (!kd_walk_short(rd, i, ri, wlo, Wi, Wh, hist0)) {   // more than three segments: general walk
-                        kd_walk_ops(rd, i, 0u, rd.n_cig[i], grel, 0, (int32_t)ri.lead, foot_end, Wi, Wh, hist0);
+                        kd_walk_ops(rd, ir, k0, k1, grel, (int32_t)ckpt[i].q, (int32_t)ri.lead, foot_end, We, Wh, hist0);
+                    } else if (!kd_walk_short(rd, i, ri, wlo, We, Wh, hist0)) {   // more than three segments: general walk
+                        kd_walk_ops(rd, i, 0u, rd.n_cig[i], grel, 0, (int32_t)ri.lead, foot_end, We, Wh, hist0);
+                    }
+                }
+            }
+            // early / late entries (rare: an entry longer than the histogram's reach, a leading clip across the window's left
+            // edge): the general walk, early ones against the origin wlo + H over W sites, late ones against [wlo, whi)
+            for (uint32_t r = (wave + 3 * KD_WAVES_PER_BLOCK - (rows_i + rows_p + rows_c) % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK;
+                 r * KD_WAVE < nx; r += KD_WAVES_PER_BLOCK) {
+                const uint32_t e = r * KD_WAVE + lane;
+                if (e < nx) {
+                    const uint32_t code = l_cplx[KD_TILE - 1u - e];
+                    const bool early = (code & 0x8000u) != 0;
+                    const kd_u64 j = tb + (code & 0x3fffu), i = order ? (kd_u64)order[j] : j;
+                    const KdRInfo ri = rinfo[i];
+                    const bool shifted = early && w != 0;          // early entry of a window that has windows in front
+                    const kd_u64 org = shifted ? wlo + H : wlo;
+                    uint32_t *h0 = shifted ? hist_early : hist0;
+                    const int32_t Wx = (early && !shifted) ? We : Wi;
+                    const int32_t grel = (int32_t)(ri.gstart - (uint32_t)org);
+                    const int32_t foot_end = grel + (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
+                    if (seg_read) {
+                        const kd_u64 ir = seg_read[i / KD_BLOCK];
+                        const uint32_t nc = rd.n_cig[ir], per = (nc + KD_BLOCK - 1) / KD_BLOCK;
+                        const uint32_t k0 = (uint32_t)(i % KD_BLOCK) * per, k1 = k0 + per < nc ? k0 + per : nc;
+                        kd_walk_ops(rd, ir, k0, k1, grel, (int32_t)ckpt[i].q, (int32_t)ri.lead, foot_end, Wx, Wh, h0);
+                    } else {
+                        kd_walk_ops(rd, i, 0u, rd.n_cig[i], grel, 0, (int32_t)ri.lead, foot_end, Wx, Wh, h0);
                     }
                 }
             }
@@ -585,7 +629,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 // the word holds window-relative sites s (low half) and s + 1 (high half); halo sites are dropped
                 const int32_t sw = 2 * (int32_t)xw - KD_HALO;
                 const kd_u64 g0 = wlo + (kd_u64)sw;   // even: W, the halo and the G-space rows are all even / 8-byte aligned
-                if (tch != 0xffu && sw >= 0 && sw + 1 < Wi && g0 + 1 < T.sites && kd_commit(T, g0) && kd_commit(T, g0 + 1)) {
+                if (tch != 0xffu && sw >= 0 && sw + 1 < We && g0 + 1 < T.sites && kd_commit(T, g0) && kd_commit(T, g0 + 1)) {
                     // both sites of the word live: ONE 64-bit add on the two adjacent u32 counters (the low counter
                     // cannot carry into the high one: a u32 table counter never wraps)
                     atomicAdd(reinterpret_cast<kd_u64 *>(row + g0), (kd_u64)(v & 0xffffu) | ((kd_u64)(v >> 16) << 32));
@@ -594,7 +638,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 for (int hlf = 0; hlf < 2; hlf++) {
                     const uint32_t cnt = hlf ? v >> 16 : v & 0xffffu;
                     const int32_t sw2 = sw + hlf;
-                    if (!cnt || sw2 < 0 || sw2 >= Wi) continue;
+                    if (!cnt || sw2 < 0 || sw2 >= We) continue;
                     const kd_u64 g = wlo + (kd_u64)sw2;
                     if (tch == 0xffu) bad = true;
                     else if (g < T.sites && kd_commit(T, g)) atomicAdd(&row[g], cnt);
