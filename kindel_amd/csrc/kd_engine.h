@@ -231,10 +231,15 @@ struct KdEngine {
         if (n >= 0xffffffffULL) return fail(KD_E_ARG, "kd_push_batch: more than 2^32-1 reads in one batch");
         if (reinterpret_cast<uintptr_t>(B.seq4) & 15u) return fail(KD_E_ARG, "kd_push_batch_device: seq4 must be 16-byte aligned");
         int rc;
-        const unsigned prep_grid = (unsigned)((n + KD_PREP_CHUNK - 1) / KD_PREP_CHUNK);
+        // reads per lane of k_prep: 32 amortise its per-block reductions best, but a small batch (a shard of a strong-scaling run, a
+        // deep small genome) then launches fewer workgroups than the chip has slots: halve until ~3 workgroups per CU are there
+        uint32_t prep_per = KD_PREP_PER_THREAD;
+        while (prep_per > KD_PREP_UNROLL && n / ((uint64_t)KD_BLOCK * prep_per) < (uint64_t)3 * rt.n_cus()) prep_per /= 2;
+        const uint32_t prep_chunk = KD_BLOCK * prep_per, cold_region = KD_WAVE * prep_per;
+        const unsigned prep_grid = (unsigned)((n + prep_chunk - 1) / prep_chunk);
         const unsigned prep_regions = prep_grid * KD_WAVES_PER_BLOCK;     // one region of compact cold-read records per wavefront of k_prep
         if ((rc = ins_cleanup())) return rc;      // the last reduction's events are about to be joined by new ones
-        if ((rc = ensure(b_rinfo, n * sizeof(KdRInfo))) || (rc = ensure(b_cold, (size_t)prep_regions * KD_COLD_REGION * sizeof(KdColdRec))) || (rc = ensure(b_coldcnt, (size_t)prep_regions * 4)) ||
+        if ((rc = ensure(b_rinfo, n * sizeof(KdRInfo))) || (rc = ensure(b_cold, (size_t)prep_regions * cold_region * sizeof(KdColdRec))) || (rc = ensure(b_coldcnt, (size_t)prep_regions * 4)) ||
             (rc = ensure(b_coldev, (size_t)prep_regions * 8)) || (rc = ensure(b_coldpool, (size_t)prep_regions * 8)) ||
             (rc = ensure(b_irreg, n * 4)) || (rc = ensure(b_long, n * 4)) || (rc = ensure(b_readev, n * 4)) ||
             (rc = ensure(b_readpool, n * 8)))
@@ -253,7 +258,7 @@ struct KdEngine {
         batch_status_clean = false;
         const uint64_t ev_before = h_status[KDS_N_EV], pool_before = h_status[KDS_POOL];  // as of the last fetch
         if (rt.launch("k_prep", k_prep, prep_grid, KD_BLOCK, 0, R, T, rinfo, cold, (uint32_t *)b_coldcnt.p, (kd_u64 *)b_coldev.p, (kd_u64 *)b_coldpool.p, irreg, lng, (uint32_t *)b_readev.p,
-                      (kd_u64 *)b_readpool.p, d_status))
+                      (kd_u64 *)b_readpool.p, d_status, prep_per))
             return hipfail("k_prep");
         // k_prep touches no table: the first batch's table zeroing is queued BEHIND it and behind the status copy, so that
         // the host's wait for the copy (a round trip of ~30 us) passes while the memset runs
@@ -449,7 +454,7 @@ struct KdEngine {
                 return rc;
             if (n_cold &&
                 rt.launch("k_cold_lane", k_cold_lane, prep_regions, KD_BLOCK, 0, R, T, I, (const KdColdRec *)cold,
-                          (const uint32_t *)b_coldcnt.p, (const kd_u64 *)b_coldev.p, (const kd_u64 *)b_coldpool.p, (uint32_t)KD_COLD_REGION, d_status))
+                          (const uint32_t *)b_coldcnt.p, (const kd_u64 *)b_coldev.p, (const kd_u64 *)b_coldpool.p, cold_region, d_status))
                 return hipfail("k_cold_lane");
             if (n_long &&
                 rt.launch("k_cold_long", k_cold_long, (unsigned)n_long, KD_BLOCK, 0, R, T, I, (const KdRInfo *)rinfo,
@@ -463,7 +468,7 @@ struct KdEngine {
         } else {
             // (k_pileup_wave looks a read's insertion slots up by read index: spell the regular reads' out)
             if (n_cold && rt.launch("k_cold_slots", k_cold_slots, prep_regions, KD_BLOCK, 0, (const KdColdRec *)cold, (const uint32_t *)b_coldcnt.p,
-                                    (const kd_u64 *)b_coldev.p, (const kd_u64 *)b_coldpool.p, (uint32_t)KD_COLD_REGION, (uint32_t *)b_readev.p,
+                                    (const kd_u64 *)b_coldev.p, (const kd_u64 *)b_coldpool.p, cold_region, (uint32_t *)b_readev.p,
                                     (kd_u64 *)b_readpool.p))
                 return hipfail("k_cold_slots");
             if (rt.launch("k_pileup_wave_all", k_pileup_wave<true, true>,

@@ -81,7 +81,9 @@ __device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc,
 __global__ void __launch_bounds__(KD_BLOCK, KD_PREP_OCC)
 k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold_cnt, kd_u64 *cold_evbase, kd_u64 *cold_poolbase,
        uint32_t *irreg_list, uint32_t *long_list,
-       uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
+       uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status, uint32_t per_thread) {
+    // per_thread: reads per lane, a multiple of KD_PREP_UNROLL up to KD_PREP_PER_THREAD (the engine picks fewer for small batches so
+    // that the launch still fills the chip: 32 reads per lane of a 2 M-read shard are 254 workgroups on 256 CUs)
     __shared__ kd_u64 s_red[8];       // reads, aligned, walked, ins_ops, ins_bases, n_reg, unsorted
     __shared__ uint32_t s_maxspan, s_maxlead;
     __shared__ uint32_t s_cnt[3];     // cold, irreg, long (block totals / running offsets)
@@ -93,7 +95,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
     if (t < 2) s_ins[t] = 0;
     if (t == 0) { s_maxspan = 0; s_maxlead = 0; }
     __syncthreads();
-    const kd_u64 chunk0 = (kd_u64)blockIdx.x * KD_PREP_CHUNK;
+    const kd_u64 chunk0 = (kd_u64)blockIdx.x * KD_BLOCK * per_thread;
     kd_u64 a_reads = 0, a_aligned = 0, a_walked = 0, a_ins = 0, a_insb = 0, a_reg = 0, a_unsorted = 0;
     kd_u64 a_ins_tail = 0, a_insb_tail = 0;
     uint32_t a_maxspan = 0, a_maxlead = 0, n_irreg = 0, n_long = 0;
@@ -103,7 +105,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
     // straight to HBM: neighbouring records from neighbouring lanes, no atomics, no staging, no limit on how many reads
     // are clipped.  cold_cnt[region] = records written.
     const kd_u64 wave_region = (kd_u64)blockIdx.x * KD_WAVES_PER_BLOCK + t / KD_WAVE;
-    KdColdRec *wave_rec = cold_rec + wave_region * KD_COLD_REGION;
+    KdColdRec *wave_rec = cold_rec + wave_region * (KD_WAVE * per_thread);
     uint32_t wcount = 0;
     // The insertion-event slots and pool bytes of these reads are handed out here too: a wavefront-wide prefix sum per read
     // gives every read its offset in the wavefront's range, the range's base follows when the block has reserved its share
@@ -114,7 +116,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
     kd_u64 cb_cached = 0;
     int64_t L_cached = 0;
     // 4 reads per step: all of their metadata loads are issued before any is consumed
-    for (int it0 = 0; it0 < KD_PREP_PER_THREAD; it0 += KD_PREP_UNROLL) {
+    for (int it0 = 0; it0 < (int)per_thread; it0 += KD_PREP_UNROLL) {
         uint32_t v_c[KD_PREP_UNROLL], v_pc[KD_PREP_UNROLL], v_nc[KD_PREP_UNROLL], v_fl[KD_PREP_UNROLL];
         int64_t v_pos[KD_PREP_UNROLL], v_ppos[KD_PREP_UNROLL], v_sl[KD_PREP_UNROLL];
         kd_u64 v_coff[KD_PREP_UNROLL];
