@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--shuffle", action="store_true", help="permute the read order (unsorted input: exercises the device bucket sort)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=0.0, help="fraction of reads for the CPU baseline (0 = auto)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="time the eager submission only (no kd_step / hipGraph replay)")
     ap.add_argument("--e2e-scale", type=float, default=0.1, help="N = 1: depth scale of the live end-to-end leg (BAM file -> FASTA; 0 = skip)")
     args = ap.parse_args()
 
@@ -170,13 +171,18 @@ def main():
 
         state = {}
 
-        def step():
-            eng.reset()
-            eng.push_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"])
-            eng.finalize()
-            eng.consensus_run(1)
-            # this rank's consensus bytes -> pinned host memory (at N = 1 that is the whole FASTA) ...
-            off = eng.consensus_fetch_all_into(pinned_np)
+        def step(graph=False):
+            if graph:
+                # the same work in ONE call (kd_step): a repeat of the same resident batch replays the captured hipGraph of the
+                # dispatch chain and verifies its decisions on the device's status words afterwards
+                off, state["replayed"] = eng.step_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"], pinned_np)
+            else:
+                eng.reset()
+                eng.push_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"])
+                eng.finalize()
+                eng.consensus_run(1)
+                # this rank's consensus bytes -> pinned host memory (at N = 1 that is the whole FASTA) ...
+                off = eng.consensus_fetch_all_into(pinned_np)
             seqs = [pinned_np[int(off[c]): int(off[c + 1])] for c in range(n_contigs)]
             # ... and, at N > 1, the all-gather that leaves the stitched consensus in every GPU's HBM
             if world > 1:
@@ -191,8 +197,8 @@ def main():
 
         for _ in range(args.warmup):
             seqs = step()
-        # timed region: hipEvents only around the dominant kernel's launches (mode 2; two events per step, for the
-        # roofline).  Events around EVERY launch cost a few microseconds each, so the per-kernel table comes from an
+        # timed region (eager submission): hipEvents only around the dominant kernel's launches (mode 2; two events per step,
+        # for the roofline).  Events around EVERY launch cost a few microseconds each, so the per-kernel table comes from an
         # extra, untimed pass of the same steps afterwards.
         eng.profile_enable(2)
         eng.profile_reset()
@@ -203,6 +209,25 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         prof_dom = eng.profile()
+        dt_eager, submission = dt, "eager: one dispatch per kernel, two blocking status read-backs per step"
+        if args.graph:
+            # timed region (one-launch step): the same K steps through kd_step.  The first call records + captures, so it is part
+            # of the warm-up; the timed steps must all have been served by the graph, else the eager figure stands.
+            eng.profile_enable(0)
+            for _ in range(max(2, args.warmup)):
+                seqs_g = step(graph=True)
+            barrier()
+            t0 = time.perf_counter()
+            all_replayed = True
+            for _ in range(args.steps):
+                seqs_g = step(graph=True)
+                all_replayed = all_replayed and state.get("replayed", False)
+            barrier()
+            dt_graph = time.perf_counter() - t0
+            if all_replayed:
+                assert all(bytes(memoryview(a)) == bytes(memoryview(b)) for a, b in zip(seqs, seqs_g))
+                dt, seqs = dt_graph, seqs_g
+                submission = "hipGraph replay of the step's dispatch chain (kd_step), decisions verified on the device's status words after every replay"
         eng.profile_enable(1)
         eng.profile_reset()
         for _ in range(args.steps):
@@ -247,7 +272,8 @@ def main():
                                 step_frac=round(B / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5))
             out = dict(
                 metric="aligned-base events/sec pileup+consensus", value=value, unit="events/s", n_gpus=world,
-                steps=args.steps, warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True,
+                steps=args.steps, warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, submission=submission,
+                eager_ms_per_step=round(dt_eager / args.steps * 1e3, 4),
                 scaling=scaling if world > 1 else "weak", vs_baseline=None, dtype="u32", data="synthetic",
                 config=dict(workload="%s: synthetic %s, %d contig(s), %d sites, depth %gx%s" % (
                     args.config, "150 bp short reads" if cfg["kind"] == "short" else "ONT-like long reads",
@@ -260,7 +286,7 @@ def main():
                     window_sites=eng.tuning()[0], work_items=info["work_items"]),
                 roofline=roofline,
                 kernels={k: dict(launches_per_step=n / args.steps, avg_ms=round(avg, 4)) for k, (n, avg) in sorted(rows.items())},
-                kernels_source="hipEvents per launch: %s inside the timed region, the others in an extra untimed pass of the same %d steps" % (
+                kernels_source="hipEvents per launch: %s inside the timed region of the eager submission, the others in an extra untimed pass of the same %d steps" % (
                     "/".join(sorted(prof_dom)) or "none", args.steps),
                 kernel_ms_per_step=round(kernel_ms_per_step, 4),
                 fasta_sha256=fasta_sha, consensus_len=sum(len(s) for s in seqs), gen_seconds=round(t_gen, 1),

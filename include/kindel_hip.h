@@ -191,6 +191,15 @@ int kd_consensus_device(kd_ctx *ctx, void **dev_ptr, uint64_t *n_bytes);
 /* Same for the per-site change codes: *dev_ptr + g = the change code of G-space site g, valid for the sites of the context's
  * interval [g_lo, g_hi) only (the array is shard-local like the tables; the pointer is biased to G-space indexing). */
 int kd_changes_device(kd_ctx *ctx, void **dev_ptr);
+/* One whole step over a DEVICE-resident batch in one call: kd_reset + kd_push_batch_device + kd_finalize + kd_consensus_run (no
+ * patches) + kd_consensus_fetch_all(seq_out ...), i.e. parse_records' loop and consensus_sequence's loop (kindel.py:40-81,
+ * :384-430) for every contig of the batch.  The first call with a given batch runs that sequence and captures it as a hipGraph;
+ * calls that repeat the same batch (same pointers, sizes, seq_out, shard, tuning) replay the graph -- one launch instead of ~20
+ * dispatches and two blocking read-backs -- and then verify on the device's status words and consensus offsets that the replay
+ * took exactly the decisions the eager sequence would have taken (else the eager sequence runs).  *replayed (may be NULL): 1
+ * if the graph served the call.  seq_out should be pinned host memory.  Errors as kd_finalize. */
+int kd_step(kd_ctx *ctx, const kd_batch *dev_batch, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out,
+            uint64_t *contig_off, int *replayed);
 /* Host-side metadata of the last run: contig_off[n_contigs+1] = byte offset of each contig in the
  * concatenated consensus (last entry = total), depth_minmax[2*n_contigs]. Either may be NULL. */
 int kd_consensus_offsets(kd_ctx *ctx, uint64_t *contig_off, uint32_t *depth_minmax);

@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error "
     "kd_stream_open kd_stream_n_contigs kd_stream_contig_name kd_stream_contig_len kd_stream_next kd_stream_n_records "
     "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_write_bam kd_host_threads kd_host_inflate "
-    "kd_bgzf_index kd_decode_open_span"
+    "kd_bgzf_index kd_decode_open_span kd_step"
 ).split()
 
 #: the reference exception each error code stands for (kindel.py:47,51-52,57,61,67,72,75,79)
@@ -97,6 +97,7 @@ class Library:
         L.kd_changes_device.argtypes = [p, C.POINTER(p)]
         L.kd_consensus_offsets.argtypes = [p, p, p]
         L.kd_consensus_fetch_all.argtypes = [p, p, u64, C.POINTER(u64), p, p]
+        L.kd_step.argtypes = [p, C.POINTER(kd_batch), u32, p, u64, C.POINTER(u64), p, C.POINTER(C.c_int)]
         L.kd_profile_enable.argtypes = [p, C.c_int]
         L.kd_profile_get.argtypes = [p, C.POINTER(u32), p, p, p]
         L.kd_profile_reset.argtypes = [p]
@@ -438,6 +439,18 @@ class Engine:
         b = self._struct(ptrs, n_reads)
         b.seq4_bytes, b.cigar_words = seq4_bytes, cigar_words
         self._check(self.lib.dll.kd_push_batch_device(self._h, C.byref(b)), "kd_push_batch_device")
+
+    def step_device(self, ptrs, n_reads, seq4_bytes, cigar_words, out, min_depth=1):
+        """One whole step over a device-resident batch (kd_step: reset + record loop + insertion reduction + consensus + all
+        contigs' consensus bytes into `out`, ideally pinned).  Repeating the same batch replays a captured hipGraph.
+        -> (contig_off uint64[n_contigs + 1], replayed bool)"""
+        b = self._struct(ptrs, n_reads)
+        b.seq4_bytes, b.cigar_words = seq4_bytes, cigar_words
+        ln, rep = C.c_uint64(0), C.c_int(0)
+        off = np.zeros(len(self.contig_lens) + 1, np.uint64)
+        self._n_patches = 0
+        self._check(self.lib.dll.kd_step(self._h, C.byref(b), int(min_depth), _ptr(out), out.size, C.byref(ln), _ptr(off), C.byref(rep)), "kd_step")
+        return off, bool(rep.value)
 
     def push_stream(self, stream):
         """Every remaining batch of a Stream: decode of batch k+1 overlapped with copy + kernels of batch k.

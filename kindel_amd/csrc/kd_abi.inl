@@ -121,6 +121,12 @@ int kd_consensus_device(kd_ctx *ctx, void **dev_ptr, uint64_t *n_bytes) {
     return KD_OK;
 }
 
+int kd_step(kd_ctx *ctx, const kd_batch *dev_batch, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out,
+            uint64_t *contig_off, int *replayed) {
+    if (!ctx || !dev_batch) return KD_E_ARG;
+    return ctx->e.step(*dev_batch, min_depth, seq_out, cap, len_out, contig_off, replayed);
+}
+
 int kd_changes_device(kd_ctx *ctx, void **dev_ptr) {
     if (!ctx || !dev_ptr) return KD_E_ARG;
     if (!ctx->e.have_cns) return ctx->e.fail(KD_E_ARG, "kd_changes_device: call kd_consensus_run first");

@@ -77,6 +77,22 @@ struct KdEngine {
     std::vector<uint8_t> h_insbytes;
     bool have_inskeys = false;
 
+    // ---- kd_step: one call = reset + record loop + insertion reduction + consensus + read-out.  The first call with a given
+    // (device-resident) batch runs the usual sequence and RECORDS what the host read back on the way (the status words that
+    // size buffers and choose paths, the consensus offsets); it then runs the sequence once more under stream capture with
+    // every host read answered from the record -- no synchronisation -- and keeps the hipGraph.  Later calls with the same batch
+    // REPLAY the graph (one launch instead of ~20 dispatches, two blocking read-backs and four copies) and then verify that the
+    // device's status words and offsets are the recorded ones -- every host decision of the eager sequence is a function of
+    // those, so equality means the graph did exactly what the eager sequence would have done; otherwise it is dropped and the
+    // eager sequence runs.
+    enum { STEP_OFF = 0, STEP_RECORD, STEP_REPLAY };
+    int step_mode = STEP_OFF;
+    std::vector<std::vector<kd_u64>> step_status;   // the status read-backs of the recorded step, in order
+    size_t step_pos = 0;
+    std::vector<uint64_t> step_meta, step_meta_seen, step_meta_up;   // consensus metadata: recorded / copied back by the graph / uploaded
+    uint64_t step_sig[12] = {0};
+    bool step_have = false;
+
     int fail(int code, const std::string &m) { err = m; return code; }
     int hipfail(const char *what) { return fail(KD_E_HIP, std::string(what) + ": " + rt.err()); }
 
@@ -220,7 +236,13 @@ struct KdEngine {
     }
 
     int fetch_status() {
+        if (step_mode == STEP_REPLAY) {
+            if (step_pos >= step_status.size()) return fail(KD_E_INTERNAL, "kd_step: replay asked for more read-backs than were recorded");
+            h_status = step_status[step_pos++];
+            return KD_OK;
+        }
         if (rt.d2h_small(h_status.data(), d_status, KDS_COUNT * 8)) return hipfail("status d2h");
+        if (step_mode == STEP_RECORD) step_status.push_back(h_status);
         return KD_OK;
     }
 
@@ -262,12 +284,16 @@ struct KdEngine {
             return hipfail("k_prep");
         // k_prep touches no table: the first batch's table zeroing is queued BEHIND it and behind the status copy, so that
         // the host's wait for the copy (a round trip of ~30 us) passes while the memset runs
-        if (rt.d2h_small_begin(d_status, KDS_COUNT * 8)) return hipfail("status d2h");
+        if (step_mode != STEP_REPLAY && rt.d2h_small_begin(d_status, KDS_COUNT * 8)) return hipfail("status d2h");
         if (!tables_ready) {
             if ((rc = prepare_tables())) return rc;
             T = tabs();      // (the tables may just have been allocated: k_prep only used the contig geometry of T)
         }
-        if (rt.d2h_small_end(h_status.data(), KDS_COUNT * 8)) return hipfail("status d2h");
+        if (step_mode == STEP_REPLAY) { if ((rc = fetch_status())) return rc; }
+        else {
+            if (rt.d2h_small_end(h_status.data(), KDS_COUNT * 8)) return hipfail("status d2h");
+            if (step_mode == STEP_RECORD) step_status.push_back(h_status);
+        }
         const uint64_t n_long = h_status[KDS_B_N_LONG];
         if (n_long) {
             if ((rc = ensure(b_ckpt, (size_t)n_long * KD_BLOCK * sizeof(KdCkpt))) ||
@@ -734,7 +760,10 @@ struct KdEngine {
         if ((rc = ensure(b_cns, cap)) || (rc = ensure(b_tilesum, n_tiles * 8)) || (rc = ensure(b_tilemm, n_tiles * sizeof(KdTileMM))) ||
             (rc = ensure(b_tileoff, (n_tiles + 1) * 8)) || (rc = ensure(b_coff, meta_words * 8)))
             return rc;
-        std::vector<uint64_t> meta(meta_words, 0);
+        // (kd_step uploads from a member: the copy node of a captured step reads that memory at every replay; nothing else touches it)
+        std::vector<uint64_t> meta_local;
+        std::vector<uint64_t> &meta = step_mode == STEP_OFF ? meta_local : step_meta_up;
+        meta.assign(meta_words, 0);
         uint64_t *m_poff = meta.data() + nc1, *m_ps = m_poff + np1, *m_pe = m_ps + np1;
         uint32_t *m_mm = reinterpret_cast<uint32_t *>(m_pe + np1);
         for (size_t k = 0; k < np1; k++) m_poff[k] = ~0ULL;
@@ -762,10 +791,23 @@ struct KdEngine {
         h_minmax.assign(2 * (size_t)n_contigs, 0);
         h_pstart.assign(ps, ps + n_patches);
         h_poff.assign(n_patches, ~0ULL);
-        if (rt.d2h(meta.data(), b_coff.p, meta_words * 8)) return hipfail("consensus: d2h");
-        std::copy(meta.begin(), meta.begin() + nc1, h_coff.begin());
-        std::copy(m_poff, m_poff + n_patches, h_poff.begin());
-        std::copy(m_mm, m_mm + 2 * (size_t)n_contigs, h_minmax.begin());
+        if (step_mode == STEP_REPLAY) {
+            // captured: the copy lands in step_meta_seen when the graph runs (verified then); the host continues with the record
+            step_meta_seen.assign(meta_words, 0);
+            if (step_meta.size() != meta_words) return fail(KD_E_INTERNAL, "kd_step: recorded consensus metadata has another shape");
+            if (rt.d2h_async(step_meta_seen.data(), b_coff.p, meta_words * 8)) return hipfail("consensus: d2h");
+        } else {
+            std::vector<uint64_t> down(meta_words, 0);
+            if (rt.d2h(down.data(), b_coff.p, meta_words * 8)) return hipfail("consensus: d2h");
+            if (step_mode == STEP_RECORD) step_meta = down;
+            else meta_local.swap(down);
+        }
+        const std::vector<uint64_t> &res = step_mode == STEP_OFF ? meta_local : step_meta;   // what came back (replay: what was recorded)
+        const uint64_t *r_poff = res.data() + nc1;
+        const uint32_t *r_mm = reinterpret_cast<const uint32_t *>(r_poff + 3 * np1);
+        std::copy(res.begin(), res.begin() + nc1, h_coff.begin());
+        std::copy(r_poff, r_poff + n_patches, h_poff.begin());
+        std::copy(r_mm, r_mm + 2 * (size_t)n_contigs, h_minmax.begin());
         if (h_coff[n_contigs] > cap) return fail(KD_E_INTERNAL, "consensus longer than its buffer");
         // contigs whose first site lies outside the processed tiles were not visited by k_cns_emit
         for (uint32_t c = 0; c < n_contigs; c++) {
@@ -813,9 +855,62 @@ struct KdEngine {
             for (uint32_t c = 0; c <= n_contigs; c++) contig_off[c] = h_coff[c] - o0;
         if (seq_out) {
             if (o1 - o0 > cap) return fail(KD_E_ARG, "kd_consensus_fetch_all: buffer too small");
-            if (o1 > o0 && rt.d2h(seq_out, (uint8_t *)b_cns.p + o0, o1 - o0)) return hipfail("consensus fetch: d2h");
+            if (o1 > o0 && (step_mode == STEP_REPLAY ? rt.d2h_async(seq_out, (uint8_t *)b_cns.p + o0, o1 - o0)
+                                                     : rt.d2h(seq_out, (uint8_t *)b_cns.p + o0, o1 - o0)))
+                return hipfail("consensus fetch: d2h");
         }
         if (changes && S && copy_changes(changes, 0, S)) return hipfail("consensus fetch: d2h changes");
+        return KD_OK;
+    }
+
+    // One step over a device-resident batch (kd_step): see step_mode above.  *replayed = 1 when the graph did it.
+    int step(const kd_batch &B, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint64_t *contig_off, int *replayed) {
+        if (replayed) *replayed = 0;
+        const uint64_t sig[12] = {(uint64_t)B.n_reads, (uint64_t)(uintptr_t)B.contig, (uint64_t)(uintptr_t)B.pos0, (uint64_t)(uintptr_t)B.seq_off,
+                                  (uint64_t)(uintptr_t)B.cig_off, (uint64_t)(uintptr_t)B.seq4, (uint64_t)(uintptr_t)B.cigar,
+                                  (uint64_t)B.seq4_bytes ^ ((uint64_t)B.cigar_words << 32), (uint64_t)(uintptr_t)seq_out, cap,
+                                  g_lo ^ (g_hi << 1) ^ ((uint64_t)min_depth << 56), (uint64_t)mode ^ ((uint64_t)W << 8) ^ ((uint64_t)slice_cfg << 32)};
+        auto sequence = [&]() -> int {
+            int rc;
+            if ((rc = reset()) || (rc = push_device(B)) || (rc = finalize(nullptr)) || (rc = consensus_run(min_depth, 0, nullptr, nullptr))) return rc;
+            return consensus_fetch_all(seq_out, cap, len_out, contig_off, nullptr);
+        };
+        // the words every host decision of the sequence is made from
+        static const int kDecisive[] = {KDS_ERR_READ, KDS_N_EV, KDS_POOL, KDS_B_INS_OPS, KDS_B_INS_BASES, KDS_B_MAXSPAN, KDS_B_MAXLEAD, KDS_B_MAXSEGSPAN,
+                                        KDS_B_UNSORTED, KDS_B_N_COLD, KDS_B_N_IRREG, KDS_B_N_LONG, KDS_B_N_REG, KDS_INS_COLLISION, KDS_INTERNAL,
+                                        KDS_BAD_BASE};
+        if (step_have && rt.has_graph() && !memcmp(sig, step_sig, sizeof sig) && !step_status.empty()) {
+            if (!rt.graph_launch() && !rt.sync()) {
+                std::vector<kd_u64> now(KDS_COUNT, 0);
+                bool same = !rt.d2h_small(now.data(), d_status, KDS_COUNT * 8) && step_meta_seen == step_meta;
+                for (int w : kDecisive) same = same && now[w] == step_status.back()[w];
+                if (same) {
+                    // host state as the recorded sequence left it (the capture pass ran the same host code)
+                    h_status = step_status.back();
+                    if (len_out) *len_out = h_coff[n_contigs] - h_coff[0];
+                    if (contig_off) for (uint32_t c = 0; c <= n_contigs; c++) contig_off[c] = h_coff[c] - h_coff[0];
+                    if (replayed) *replayed = 1;
+                    return KD_OK;
+                }
+            }
+            step_have = false;      // the input changed under the same pointers (or the launch failed): back to the eager sequence
+            rt.graph_drop();
+        }
+        step_have = false;
+        step_mode = STEP_RECORD; step_status.clear(); step_meta.clear();
+        int rc = sequence();
+        step_mode = STEP_OFF;
+        if (rc || !rt.graph_supported()) return rc;
+        // the same sequence once more, captured: every host read answered from the record, nothing executes
+        step_mode = STEP_REPLAY; step_pos = 0;
+        int rc2 = rt.capture_begin() ? 1 : 0;
+        if (!rc2) {
+            rc2 = sequence();
+            if (rt.capture_end(rc2 == KD_OK && step_pos == step_status.size())) rc2 = rc2 ? rc2 : 1;
+        }
+        step_mode = STEP_OFF;
+        if (rc2 == KD_OK && rt.has_graph()) { memcpy(step_sig, sig, sizeof sig); step_have = true; }
+        else { rt.graph_drop(); err.clear(); }     // no graph: the next call is eager again (and tries again)
         return KD_OK;
     }
 };

@@ -43,6 +43,7 @@ struct HipRt {
     }
     void shutdown() {
         profile_reset();
+        graph_drop();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; }
         if (ev_copy) { (void)hipEventDestroy(ev_copy); ev_copy = nullptr; }
         if (own_stream && stream) { (void)hipSetDevice(dev); (void)hipStreamDestroy(stream); }
@@ -67,6 +68,29 @@ struct HipRt {
         return bad(hipStreamSynchronize(stream));
     }
     int sync() { return bad(hipStreamSynchronize(stream)); }
+    int d2h_async(void *h, const void *d, size_t n) { return n ? bad(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream)) : 0; }
+    // ---- one-launch step (kd_step): the dispatch chain of a step captured into a hipGraph and replayed ----
+    hipGraphExec_t graph_exec = nullptr;
+    bool capturing = false;
+    bool graph_supported() const { return true; }
+    bool has_graph() const { return graph_exec != nullptr; }
+    void graph_drop() { if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; } }
+    int capture_begin() {
+        graph_drop();
+        if (bad(hipSetDevice(dev)) || bad(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed))) return 1;
+        capturing = true;
+        return 0;
+    }
+    int capture_end(bool keep) {
+        hipGraph_t g = nullptr;
+        capturing = false;
+        if (bad(hipStreamEndCapture(stream, &g)) || !g) return 1;
+        int rc = 0;
+        if (keep && bad(hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0))) { graph_exec = nullptr; rc = 1; }
+        (void)hipGraphDestroy(g);
+        return rc;
+    }
+    int graph_launch() { return bad(hipSetDevice(dev)) || bad(hipGraphLaunch(graph_exec, stream)); }
     // small readbacks (status words) go through a pinned bounce buffer: no pageable staging in the runtime
     void *pin = nullptr;
     int d2h_small(void *h, const void *d, size_t n) {
@@ -95,11 +119,11 @@ struct HipRt {
     template <class K, class... A>
     int launch(const char *name, K k, unsigned grid, unsigned block, size_t shmem, A... args) {
         if (bad(hipSetDevice(dev))) return 1;
-        if (shmem > 48 * 1024 &&
+        if (shmem > 48 * 1024 && !capturing &&
             bad(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)))
             return 1;
         Pending p;
-        const bool timed = prof == 1 || (prof == 2 && (!strcmp(name, "k_window") || !strcmp(name, "k_strip")));
+        const bool timed = !capturing && (prof == 1 || (prof == 2 && (!strcmp(name, "k_window") || !strcmp(name, "k_strip"))));
         if (timed) {
             if (bad(hipEventCreate(&p.a)) || bad(hipEventCreate(&p.b))) return 1;
             if (bad(hipEventRecord(p.a, stream))) return 1;

@@ -31,6 +31,14 @@ struct EmuRt {
     int d2h_small_begin(const void *d, size_t n) { if (n > sizeof small) return 1; ::memcpy(small, d, n); return 0; }
     int d2h_small_end(void *h, size_t n) { ::memcpy(h, small, n); return 0; }
     int sync() { return 0; }
+    int d2h_async(void *h, const void *d, size_t n) { ::memcpy(h, d, n); return 0; }
+    // (no graphs here: kd_step always takes the eager path on the emulator)
+    bool graph_supported() const { return false; }
+    bool has_graph() const { return false; }
+    void graph_drop() {}
+    int capture_begin() { return 1; }
+    int capture_end(bool) { return 1; }
+    int graph_launch() { return 1; }
     template <class K, class... A>
     int launch(const char *name, K k, unsigned grid, unsigned block, size_t shmem, A... args) {
         static const bool trace = getenv("KD_EMU_TRACE") != nullptr;

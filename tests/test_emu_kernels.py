@@ -289,3 +289,23 @@ def test_config_as_virtual_shards_through_gather_and_assemble(emu_lib, lens, dep
     """Config 4 / config 3 in miniature as `world` virtual shards through the rows of the all-gather (the GPU suite runs the
     same check at full size: tests/test_gpu_parity.py::test_full_size_config_as_eight_shards)."""
     P.check_as_shards(emu_lib, synth.to_numpy(synth.short_reads(lens, depth, seed=17)), world, window=256)
+
+
+def test_step_equals_the_classic_sequence(emu_lib):
+    """kd_step = kd_reset + kd_push_batch_device + kd_finalize + kd_consensus_run + kd_consensus_fetch_all in one call (the
+    emulator has no graphs: always the eager sequence; the GPU suite checks the replay)."""
+    batch = synth.to_numpy(synth.short_reads([4000, 1500], 20, seed=23))
+    run = P.Run(emu_lib, batch)
+    eng = N.Engine(batch["contig_lens"], lib=emu_lib)
+    try:
+        arrs = {name: np.ascontiguousarray(batch[name], dt) for name, dt in N._BATCH_FIELDS}
+        ptrs = {k: v.ctypes.data for k, v in arrs.items()}       # (on the emulator "device" memory is host memory)
+        out = np.zeros(8192, np.uint8)
+        for _ in range(2):
+            off, replayed = eng.step_device(ptrs, len(arrs["contig"]), arrs["seq4"].size, arrs["cigar"].size, out)
+            assert not replayed
+            for cid in run.order:
+                assert out[int(off[cid]): int(off[cid + 1])].tobytes() == run.cns[cid][0]
+                assert np.array_equal(eng.tables(cid), run.tables[cid])
+    finally:
+        eng.close()
