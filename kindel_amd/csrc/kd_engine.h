@@ -54,6 +54,7 @@ struct KdEngine {
     };
     Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_ckpt, b_seginfo, b_longacc, b_coldcnt, b_coldev, b_coldpool;
     Buf b_stage[9];
+    Buf b_srinfo, b_sseq, b_scig, b_sncig;   // an unsorted batch's regular reads in window order (k_sort_scatter_reads)
     Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
     uint64_t ev_cap = 0, pool_cap = 0;
     Buf b_hkey, b_hcnt, b_hrep, b_evslot, b_best, b_win, b_flag;
@@ -168,6 +169,7 @@ struct KdEngine {
                       &b_tilesum, &b_tilemm, &b_tileoff, &b_coff};
         for (Buf *b : all) release(*b);
         for (Buf &b : b_stage) release(b);
+        release(b_srinfo); release(b_sseq); release(b_scig); release(b_sncig);
         if (d_tab) rt.free(d_tab);
         if (d_clen) rt.free(d_clen);
         if (d_cbase) rt.free(d_cbase);
@@ -356,6 +358,8 @@ struct KdEngine {
                 }
                 slice = std::min<uint32_t>(slice, 32768u);   // u16 LDS counters: an item may not tally more reads than that
                 const uint32_t *order = nullptr;
+                const KdRInfo *walk_info = info;      // what k_window walks: the entries themselves, or their window-sorted copy
+                KdReads walk_R = R;
                 // the histogram reaches H sites past the window: an entry is tallied whole by the window it starts in (kd_window.h:
                 // OWNERSHIP); H = the longest footprint of this pass's entries, up to 256 sites (longer ones leave a remainder)
                 uint32_t H = use_coop ? 0u : (uint32_t)std::min<uint64_t>(256, (h_status[span_slot] + 63) & ~uint64_t(63));
@@ -364,8 +368,29 @@ struct KdEngine {
                     if (rt.launch("k_plan_ranges", k_plan_ranges, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, info, (kd_u64)ne, w0,
                                   n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status, span_slot == (uint32_t)KDS_B_MAXSPAN ? H : 0u))
                         return hipfail("k_plan_ranges");
+                } else if (!seg_read) {
+                    // an UNSORTED batch of reads: counting sort by window, the regular reads' footprints / offsets scattered
+                    // physically into window order (k_sort_scatter_reads); k_window then walks them like a sorted batch
+                    const uint32_t n_bins = (uint32_t)((S + W - 1) / W), reps = 8;
+                    const size_t n_cnt = ((size_t)n_bins + 1) * reps;
+                    if ((rc2 = ensure(b_bincnt, n_cnt * 4)) || (rc2 = ensure(b_binoff, (n_cnt + 1) * 8)) || (rc2 = ensure(b_srinfo, ne * sizeof(KdRInfo))) ||
+                        (rc2 = ensure(b_sseq, ne * 8)) || (rc2 = ensure(b_scig, ne * 8)) || (rc2 = ensure(b_sncig, ne * 4)))
+                        return rc2;
+                    uint32_t *bc = (uint32_t *)b_bincnt.p;
+                    kd_u64 *bo = (kd_u64 *)b_binoff.p;
+                    const unsigned gr = (unsigned)((ne + KD_BLOCK - 1) / KD_BLOCK);
+                    if (rt.memset(bc, 0, n_cnt * 4) ||
+                        rt.launch("k_sort_count", k_sort_count<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, reps) ||
+                        rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, (uint32_t)n_cnt) ||
+                        rt.launch("k_sort_scatter", k_sort_scatter_reads, gr, KD_BLOCK, 0, info, R, W, bc, (const kd_u64 *)bo, reps,
+                                  (KdRInfo *)b_srinfo.p, (kd_u64 *)b_sseq.p, (kd_u64 *)b_scig.p, (uint32_t *)b_sncig.p) ||
+                        rt.launch("k_plan_ranges_sorted", k_plan_ranges_sorted, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
+                                  (const kd_u64 *)bo, n_bins, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status, span_slot, reps))
+                        return hipfail("k_sort_*");
+                    walk_info = (const KdRInfo *)b_srinfo.p;
+                    walk_R.seq_off = (const kd_u64 *)b_sseq.p; walk_R.cig_off = (const kd_u64 *)b_scig.p; walk_R.n_cig = (const uint32_t *)b_sncig.p;
                 } else {
-                    // counting sort of the regular entries by window -> permutation `order`
+                    // the SEGMENTS of long reads: counting sort by window -> permutation `order`
                     const uint32_t n_bins = (uint32_t)((S + W - 1) / W);
                     if ((rc2 = ensure(b_order, ne * 4)) || (rc2 = ensure(b_bincnt, ((size_t)n_bins + 1) * 4)) ||
                         (rc2 = ensure(b_binoff, ((size_t)n_bins + 1) * 8)))
@@ -375,15 +400,15 @@ struct KdEngine {
                     const uint64_t run = seg_read ? KD_SORT_RUN : 1;   // segments arrive in reference order: merge runs
                     const unsigned gr = (unsigned)((ne + (uint64_t)KD_BLOCK * run - 1) / ((uint64_t)KD_BLOCK * run));
                     if (rt.memset(bc, 0, ((size_t)n_bins + 1) * 4) ||
-                        (seg_read ? rt.launch("k_sort_count", k_sort_count<KD_SORT_RUN>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc)
-                                  : rt.launch("k_sort_count", k_sort_count<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc)) ||
+                        (seg_read ? rt.launch("k_sort_count", k_sort_count<KD_SORT_RUN>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, 1u)
+                                  : rt.launch("k_sort_count", k_sort_count<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, 1u)) ||
                         rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, n_bins) ||
                         (seg_read ? rt.launch("k_sort_scatter", k_sort_scatter<KD_SORT_RUN>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc,
                                               (const kd_u64 *)bo, ord)
                                   : rt.launch("k_sort_scatter", k_sort_scatter<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc,
                                               (const kd_u64 *)bo, ord)) ||
                         rt.launch("k_plan_ranges_sorted", k_plan_ranges_sorted, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
-                                  (const kd_u64 *)bo, n_bins, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status, span_slot))
+                                  (const kd_u64 *)bo, n_bins, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status, span_slot, 1u))
                         return hipfail("k_sort_*");
                     order = ord;
                 }
@@ -406,7 +431,7 @@ struct KdEngine {
                     const size_t lds = KD_COOP_LDS_BYTES(P);
                     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
                     const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
-                    if (rt.launch("k_window", k_window_coop, grid, KD_BLOCK, lds, R, info, order, T, (const kd_u64 *)wl, (const kd_u64 *)wh,
+                    if (rt.launch("k_window", k_window_coop, grid, KD_BLOCK, lds, walk_R, walk_info, order, T, (const kd_u64 *)wl, (const kd_u64 *)wh,
                                   (const kd_u64 *)io, (const uint32_t *)iw, (kd_u64)items_cap, w0, W, P, slice, d_status))
                         return hipfail("k_window_coop");
                     return KD_OK;
@@ -415,7 +440,7 @@ struct KdEngine {
                 const size_t lds = KD_WINDOW_LDS_BYTES(Wh);
                 const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
                 const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
-                if (rt.launch(seg_read ? "k_window_segments" : "k_window", k_window, grid, KD_BLOCK, lds, R, info, order,
+                if (rt.launch(seg_read ? "k_window_segments" : "k_window", k_window, grid, KD_BLOCK, lds, walk_R, walk_info, order,
                               (const KdCkpt *)b_ckpt.p, seg_read, T, (const kd_u64 *)wl, (const kd_u64 *)wh, (const kd_u64 *)io,
                               (const uint32_t *)iw, (kd_u64)items_cap, w0, W, H, Wh, slice, d_status))
                     return hipfail("k_window");
@@ -450,12 +475,12 @@ struct KdEngine {
                     kd_u64 *bo = (kd_u64 *)b_binoff.p;
                     const unsigned gr = (unsigned)((ne + KD_BLOCK - 1) / KD_BLOCK);
                     if (rt.memset(bc, 0, ((size_t)n_bins + 1) * 4) ||
-                        rt.launch("k_sort_count", k_sort_count<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, Ws, bc) ||
+                        rt.launch("k_sort_count", k_sort_count<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, Ws, bc, 1u) ||
                         rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, n_bins) ||
                         rt.launch("k_sort_scatter", k_sort_scatter<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, Ws, bc, (const kd_u64 *)bo, ord) ||
                         rt.launch("k_plan_ranges_sorted", k_plan_ranges_sorted, (ns_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
                                   (const kd_u64 *)bo, n_bins, ws0, ns_win, Ws, slice, swl, swh, sio, (const kd_u64 *)d_status,
-                                  (uint32_t)KDS_B_MAXSPAN))
+                                  (uint32_t)KDS_B_MAXSPAN, 1u))
                         return hipfail("k_sort_*");
                     order = ord;
                 }

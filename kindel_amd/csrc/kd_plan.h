@@ -43,22 +43,26 @@ k_plan_ranges(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t w0, uint32_t n_win,
 // atomic per entry would serialise on a handful of addresses.  RUN = 1 for the reads of an unsorted batch
 // (nothing to merge; coalesced one-entry-per-lane access).
 #define KD_SORT_RUN 16
+// `reps` > 1: every bin has `reps` counters, a workgroup uses counter (blockIdx mod reps): the counters of a 5 Mbp genome are
+// 31 KB = 488 cache lines, and 1.7 x 10^7 device-scope atomics on 488 lines took 0.6 - 0.9 ms per pass (unsorted C3), which is
+// the atomic unit's rate per line, not the memory's.  Entries of one bin stay contiguous (its replicas are neighbours).
 template <int RUN>
 __global__ void __launch_bounds__(KD_BLOCK)
-k_sort_count(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t W, uint32_t *bin_cnt) {
+k_sort_count(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t W, uint32_t *bin_cnt, uint32_t reps) {
     const kd_u64 i0 = ((kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x) * RUN;
+    const uint32_t rep = blockIdx.x % reps;
     uint32_t cur = 0xffffffffu, run = 0;
     for (kd_u64 i = i0; i < i0 + RUN && i < n_reads; i++) {
         const KdRInfo ri = rinfo[i];
         if ((ri.span_cls & 3u) != KD_CLS_REG) continue;
         const uint32_t b = ri.gstart / W;
         if (b != cur) {
-            if (run) atomicAdd(&bin_cnt[cur], run);
+            if (run) atomicAdd(&bin_cnt[(kd_u64)cur * reps + rep], run);
             cur = b; run = 0;
         }
         run++;
     }
-    if (run) atomicAdd(&bin_cnt[cur], run);
+    if (run) atomicAdd(&bin_cnt[(kd_u64)cur * reps + rep], run);
 }
 // one workgroup: bin_off = exclusive scan of bin_cnt (n_bins + 1 entries), bin_cnt is reset to 0 (it becomes
 // the fill cursor of k_sort_scatter).  Every thread scans a contiguous run of bins, the run totals are scanned over the
@@ -76,6 +80,22 @@ k_sort_scan(uint32_t *bin_cnt, kd_u64 *bin_off, uint32_t n_bins) {
     for (uint32_t b = b0; b < b1; b++) { const kd_u64 v = bin_cnt[b]; bin_off[b] = o; bin_cnt[b] = 0; o += v; }
     if (t == 0) bin_off[n_bins] = total;
 }
+// The READS of an unsorted batch scattered PHYSICALLY into window order (round 3): footprint record, offsets and CIGAR word
+// count of every regular read land at its sorted position, so that k_window walks the bucket-sorted batch like a sorted one --
+// coalesced footprint / offset loads, no permutation to chase (it read rinfo[order[j]], seq_off[order[j]], ... before: 2.1 x the
+// sorted kernel's time).  The packed bases and CIGAR words stay where they are (their offsets travel).
+__global__ void __launch_bounds__(KD_BLOCK)
+k_sort_scatter_reads(const KdRInfo *rinfo, KdReads rd, uint32_t W, uint32_t *bin_fill, const kd_u64 *bin_off, uint32_t reps,
+                     KdRInfo *rinfo_s, kd_u64 *seq_off_s, kd_u64 *cig_off_s, uint32_t *n_cig_s) {
+    const kd_u64 i = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (i >= rd.n) return;
+    const KdRInfo ri = rinfo[i];
+    if ((ri.span_cls & 3u) != KD_CLS_REG) return;
+    const kd_u64 slot = (kd_u64)(ri.gstart / W) * reps + blockIdx.x % reps;
+    const kd_u64 at = bin_off[slot] + atomicAdd(&bin_fill[slot], 1u);
+    rinfo_s[at] = ri; seq_off_s[at] = rd.seq_off[i]; cig_off_s[at] = rd.cig_off[i]; n_cig_s[at] = rd.n_cig[i];
+}
+
 template <int RUN>
 __global__ void __launch_bounds__(KD_BLOCK)
 k_sort_scatter(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t W, uint32_t *bin_fill, const kd_u64 *bin_off,
@@ -106,7 +126,7 @@ k_sort_scatter(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t W, uint32_t *bin_f
 // candidate range of window w0 + w in `order`: whole bins covering [wlo - maxspan, whi + maxlead)
 __global__ void __launch_bounds__(KD_BLOCK)
 k_plan_ranges_sorted(const kd_u64 *bin_off, uint32_t n_bins, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t slice,
-                     kd_u64 *win_lo, kd_u64 *win_hi, kd_u64 *item_off, const kd_u64 *status, uint32_t span_slot) {
+                     kd_u64 *win_lo, kd_u64 *win_hi, kd_u64 *item_off, const kd_u64 *status, uint32_t span_slot, uint32_t reps) {
     const uint32_t w = blockIdx.x * KD_BLOCK + threadIdx.x;
     if (w >= n_win) return;
     const kd_u64 wlo = (kd_u64)(w0 + w) * W, whi = wlo + W;
@@ -114,7 +134,7 @@ k_plan_ranges_sorted(const kd_u64 *bin_off, uint32_t n_bins, uint32_t w0, uint32
     const kd_u64 blo = (wlo > maxspan ? wlo - maxspan : 0) / W;
     kd_u64 bhi = (whi + maxlead + W - 1) / W;   // exclusive
     if (bhi > n_bins) bhi = n_bins;
-    const kd_u64 lo = bin_off[blo < n_bins ? blo : n_bins], hi = bin_off[bhi];
+    const kd_u64 lo = bin_off[(blo < n_bins ? blo : n_bins) * reps], hi = bin_off[bhi * reps];   // (bin b = counters b * reps ..)
     win_lo[w] = lo; win_hi[w] = hi;
     item_off[w] = (hi - lo + slice - 1) / slice;
 }

@@ -410,7 +410,7 @@ def test_step_graph_replay_is_verified(hip_lib):
 
     def check(expect_replay):
         off, replayed = eng.step_device(synth.device_ptrs(tb), tb["contig"].numel(), tb["seq4_bytes"], tb["cigar_words"], out)
-        assert replayed == expect_replay
+        assert expect_replay is None or replayed == expect_replay
         host = synth.to_numpy(tb)
         for cid in ko.contig_order(host):
             oa = ko.parse_records(host, cid)
@@ -423,10 +423,13 @@ def test_step_graph_replay_is_verified(hip_lib):
         check(False)
         check(True)
         check(True)
-        # new bases under the same pointers: every host decision of the step is unchanged, the graph stays valid
+        # new bases under the same pointers: the replay runs the right kernels on the new data, but what it hands back from its
+        # record (offsets, depth ranges) may no longer be true -- the verification compares them with the device's and decides;
+        # either way the results must be those of the NEW data, and the step after is a replay again
         nib = torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device="cuda:0")
         r = torch.randint(0, 4, (tb["seq4_bytes"],), device="cuda:0")
         tb["seq4"][: tb["seq4_bytes"]] = (nib[r] << 4) | nib[(r + 1) % 4]
+        check(None)
         check(True)
         # one more insertion (an M op of a 1-op read becomes M I M): the event count changes -> eager, then captured again
         ncig = tb["n_cig"].cpu().numpy()
