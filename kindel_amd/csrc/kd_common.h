@@ -156,6 +156,8 @@ struct KdReads {
     const uint32_t *n_cig;
     const uint8_t *seq4;
     const uint32_t *cigar;
+    uint32_t osh;       // 0: seq_off / cig_off (and the KdRInfo array beside them) are the batch's own arrays; 1: they are
+                        // the fields of KdSortRec[] (an unsorted batch's regular reads in window order): KD_RI / KD_SOFF / KD_COFF
 };
 
 struct KdRInfo {
@@ -166,6 +168,14 @@ struct KdRInfo {
     uint32_t pad;       // long-CIGAR reads: 1 + index of the read's KdCkpt[256] block; regular short-CIGAR reads: query length
                         // (< 2^20) | CIGAR words << 24; 0 otherwise
 };
+
+// An unsorted batch's regular read in window order (k_sort_scatter_recs): everything the window walk needs of it in ONE
+// 32-byte record -- one scattered write per read when sorting, one sector per read when walking.  (A regular read's
+// CIGAR length sits in ri.pad >> 24.)
+struct alignas(16) KdSortRec { KdRInfo ri; kd_u64 seq_off, cig_off; };
+#define KD_RI(rinfo, rd, i) ((rinfo)[(kd_u64)(i) << (rd).osh])
+#define KD_SOFF(rd, i) ((rd).seq_off[(kd_u64)(i) << ((rd).osh * 2u)])
+#define KD_COFF(rd, i) ((rd).cig_off[(kd_u64)(i) << ((rd).osh * 2u)])
 
 // Long-CIGAR reads (k_prep_long): the state at the first op of each of the 256 per-thread op runs.  Lets
 // k_cold_long emit a read's insertion events with 256 threads and lets k_window enter the read near a window

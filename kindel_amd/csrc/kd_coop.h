@@ -254,7 +254,7 @@ __device__ __forceinline__ void kd_coop_list_general(unsigned char *hb, const Kd
         KdCoopRead R;
         R.grel = rc.grel; R.span_cls = rc.span_cls; R.lead = rc.lead; R.n_cig = rc.pad >> 24;
         R.seq = KD_SEQ_AT(rd, i);
-        R.cg = rd.cigar + rd.cig_off[i];
+        R.cg = rd.cigar + KD_COFF(rd, i);
         kd_coop_ops<false>(hb, R, Wi, PB, k, bad);
     }
 }
@@ -372,8 +372,8 @@ k_window_coop(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
                 a_ri.span_cls = KD_CLS_SKIP; a_ri.pad = 0; a_so = 0; a_co = 0;
                 if (j < last) {
                     const kd_u64 i = order ? (kd_u64)order[j] : j;
-                    a_ri = rinfo[i];
-                    a_so = rd.seq_off[i]; a_co = rd.cig_off[i];
+                    a_ri = KD_RI(rinfo, rd, i);
+                    a_so = KD_SOFF(rd, i); a_co = KD_COFF(rd, i);
                     if ((a_ri.span_cls & 3u) != KD_CLS_REG) { a_ri.pad = 0; a_so = 0; a_co = 0; }   // (pad means something else for long reads)
                 }
             }

@@ -54,7 +54,7 @@ struct KdEngine {
     };
     Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_ckpt, b_seginfo, b_longacc, b_coldcnt, b_coldev, b_coldpool;
     Buf b_stage[9];
-    Buf b_srinfo, b_sseq, b_scig, b_sncig;   // an unsorted batch's regular reads in window order (k_sort_scatter_reads)
+    Buf b_srec;   // an unsorted batch's regular reads in window order: KdSortRec[] (k_sort_scatter_reads)
     Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
     uint64_t ev_cap = 0, pool_cap = 0;
     Buf b_hkey, b_hcnt, b_hrep, b_evslot, b_best, b_win, b_flag;
@@ -169,7 +169,7 @@ struct KdEngine {
                       &b_tilesum, &b_tilemm, &b_tileoff, &b_coff};
         for (Buf *b : all) release(*b);
         for (Buf &b : b_stage) release(b);
-        release(b_srinfo); release(b_sseq); release(b_scig); release(b_sncig);
+        release(b_srec);
         if (d_tab) rt.free(d_tab);
         if (d_clen) rt.free(d_clen);
         if (d_cbase) rt.free(d_cbase);
@@ -272,7 +272,7 @@ struct KdEngine {
         R.n = n; R.base_index = reads_pushed;
         R.contig = B.contig; R.pos0 = B.pos0; R.flag = B.flag; R.seq_off = (const kd_u64 *)B.seq_off;
         R.seq_len = B.seq_len; R.cig_off = (const kd_u64 *)B.cig_off; R.n_cig = B.n_cig; R.seq4 = B.seq4;
-        R.cigar = B.cigar;
+        R.cigar = B.cigar; R.osh = 0;
         KdTabs T = tabs();
         KdRInfo *rinfo = (KdRInfo *)b_rinfo.p;
         KdColdRec *cold = (KdColdRec *)b_cold.p; uint32_t *irreg = (uint32_t *)b_irreg.p, *lng = (uint32_t *)b_long.p;
@@ -371,24 +371,39 @@ struct KdEngine {
                 } else if (!seg_read) {
                     // an UNSORTED batch of reads: counting sort by window, the regular reads' footprints / offsets scattered
                     // physically into window order (k_sort_scatter_reads); k_window then walks them like a sorted batch
-                    const uint32_t n_bins = (uint32_t)((S + W - 1) / W), reps = 8;
+                    const uint32_t n_bins = (uint32_t)((S + W - 1) / W);
+                    const bool lds_bins = (size_t)n_bins * 4 <= (size_t)156 * 1024 && ne < (1ull << 32) && !getenv("KD_SORT_GLOBAL");   // (knob: measurement)
+                    uint32_t reps = lds_bins ? 1u : 2u;   // (global counters, C3 shuffled on MI355X: 1: 4.40 ms, 2: 4.24, 4: 4.44, 8: 4.54 per step)
+                    if (const char *e = getenv("KD_SORT_REPS")) reps = lds_bins ? 1u : (uint32_t)std::max(1, atoi(e));
                     const size_t n_cnt = ((size_t)n_bins + 1) * reps;
-                    if ((rc2 = ensure(b_bincnt, n_cnt * 4)) || (rc2 = ensure(b_binoff, (n_cnt + 1) * 8)) || (rc2 = ensure(b_srinfo, ne * sizeof(KdRInfo))) ||
-                        (rc2 = ensure(b_sseq, ne * 8)) || (rc2 = ensure(b_scig, ne * 8)) || (rc2 = ensure(b_sncig, ne * 4)))
+                    if ((rc2 = ensure(b_bincnt, n_cnt * 4)) || (rc2 = ensure(b_binoff, (n_cnt + 1) * 8)) || (rc2 = ensure(b_srec, ne * sizeof(KdSortRec))))
                         return rc2;
                     uint32_t *bc = (uint32_t *)b_bincnt.p;
                     kd_u64 *bo = (kd_u64 *)b_binoff.p;
-                    const unsigned gr = (unsigned)((ne + KD_BLOCK - 1) / KD_BLOCK);
-                    if (rt.memset(bc, 0, n_cnt * 4) ||
-                        rt.launch("k_sort_count", k_sort_count<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, reps) ||
-                        rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, (uint32_t)n_cnt) ||
-                        rt.launch("k_sort_scatter", k_sort_scatter_reads, gr, KD_BLOCK, 0, info, R, W, bc, (const kd_u64 *)bo, reps,
-                                  (KdRInfo *)b_srinfo.p, (kd_u64 *)b_sseq.p, (kd_u64 *)b_scig.p, (uint32_t *)b_sncig.p) ||
-                        rt.launch("k_plan_ranges_sorted", k_plan_ranges_sorted, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
+                    if (rt.memset(bc, 0, n_cnt * 4)) return hipfail("k_sort_*");
+                    if (lds_bins) {
+                        // bin counters private to a workgroup in LDS (kd_plan.h): two workgroups of 1024 lanes per CU, one chunk each
+                        const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)rt.n_cus() * ((size_t)n_bins * 4 <= (size_t)72 * 1024 ? 2 : 1), (ne + KD_SORT_BLOCK - 1) / KD_SORT_BLOCK));
+                        const kd_u64 chunk = (((kd_u64)ne + gr - 1) / gr + KD_SORT_BLOCK - 1) / KD_SORT_BLOCK * KD_SORT_BLOCK;
+                        if (rt.launch("k_sort_count", k_sort_count_lds, gr, KD_SORT_BLOCK, (size_t)n_bins * 4, info, (kd_u64)ne, chunk, W, n_bins, bc) ||
+                            rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, (uint32_t)n_cnt) ||
+                            rt.launch("k_sort_scatter", k_sort_scatter_lds, gr, KD_SORT_BLOCK, (size_t)n_bins * 4, info, R, chunk, W, n_bins, bc,
+                                      (const kd_u64 *)bo, (KdSortRec *)b_srec.p))
+                            return hipfail("k_sort_*");
+                    } else {
+                        const unsigned gr = (unsigned)((ne + KD_BLOCK - 1) / KD_BLOCK);
+                        if (rt.launch("k_sort_count", k_sort_count<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, reps) ||
+                            rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, (uint32_t)n_cnt) ||
+                            rt.launch("k_sort_scatter", k_sort_scatter_reads, gr, KD_BLOCK, 0, info, R, W, bc, (const kd_u64 *)bo, reps,
+                                      (KdSortRec *)b_srec.p))
+                            return hipfail("k_sort_*");
+                    }
+                    if (rt.launch("k_plan_ranges_sorted", k_plan_ranges_sorted, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
                                   (const kd_u64 *)bo, n_bins, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status, span_slot, reps))
                         return hipfail("k_sort_*");
-                    walk_info = (const KdRInfo *)b_srinfo.p;
-                    walk_R.seq_off = (const kd_u64 *)b_sseq.p; walk_R.cig_off = (const kd_u64 *)b_scig.p; walk_R.n_cig = (const uint32_t *)b_sncig.p;
+                    walk_info = (const KdRInfo *)b_srec.p;
+                    walk_R.seq_off = (const kd_u64 *)b_srec.p + 2; walk_R.cig_off = (const kd_u64 *)b_srec.p + 3; walk_R.n_cig = nullptr;
+                    walk_R.osh = 1;
                 } else {
                     // the SEGMENTS of long reads: counting sort by window -> permutation `order`
                     const uint32_t n_bins = (uint32_t)((S + W - 1) / W);

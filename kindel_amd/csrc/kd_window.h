@@ -51,9 +51,9 @@
 //                     an optimistic bound, the real thing needs 36 counters per site pair)
 //   -DKD_WINDOW_OCC=7 __launch_bounds__ for 7 workgroups per CU (<= 72 VGPRs); run with a window of <= 448 sites
 #ifdef KD_EXP_NOSEQ
-#define KD_SEQ_AT(rd, i) ((rd).seq4 + ((rd).seq_off[i] & 0xff0u))
+#define KD_SEQ_AT(rd, i) ((rd).seq4 + (KD_SOFF(rd, i) & 0xff0u))
 #else
-#define KD_SEQ_AT(rd, i) ((rd).seq4 + (rd).seq_off[i])
+#define KD_SEQ_AT(rd, i) ((rd).seq4 + KD_SOFF(rd, i))
 #endif
 #define KD_HALO 8
 #define KD_HPITCH 19
@@ -177,10 +177,9 @@ __device__ __forceinline__ void kd_add_chunk_masked(uint32_t *hist0, const KdChu
 // at q: the whole CIGAR of a short read with many segments (k = 0, k_end = n_cig), or ONE SEGMENT of a long read
 // (k_prep_long's checkpoint).  `lead` / `foot_end`: reach of the leading clip / window-relative end of the footprint
 // (used by the clip ops, which sit in the first / last segment).
-__device__ __forceinline__ void kd_walk_ops(const KdReads &rd, kd_u64 i, uint32_t k, uint32_t k_end, int32_t grel, int32_t q,
+__device__ __forceinline__ void kd_walk_ops(const KdReads &rd, kd_u64 i, uint32_t nc, uint32_t k, uint32_t k_end, int32_t grel, int32_t q,
                                             int32_t lead, int32_t foot_end, int32_t Wi, int32_t Wh, uint32_t *hist0) {
-    const uint32_t nc = rd.n_cig[i];
-    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    const uint32_t *cg = rd.cigar + KD_COFF(rd, i);
     const KdChunk *src = reinterpret_cast<const KdChunk *>(KD_SEQ_AT(rd, i));
     uint32_t sg = 0;   // byte offset of the current run's channel group inside a pair
     // Per-lane state machine over WORK UNITS (one 16-byte chunk = up to 32 live bases of the
@@ -261,8 +260,8 @@ __device__ __forceinline__ void kd_walk_ops(const KdReads &rd, kd_u64 i, uint32_
 // has more than three segments: the caller then takes the general walk.
 __device__ __forceinline__ bool kd_walk_short(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi, int32_t Wh,
                                               uint32_t *hist0) {
-    const uint32_t nc = rd.n_cig[i];
-    const uint32_t *cg = rd.cigar + rd.cig_off[i];
+    const uint32_t nc = ri.pad >> 24;          // (k_prep: a regular short-CIGAR read's CIGAR length rides in its entry)
+    const uint32_t *cg = rd.cigar + KD_COFF(rd, i);
     // the first four CIGAR words, all in flight together (a short read rarely has more)
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     if (nc > 0) w0 = cg[0];
@@ -493,7 +492,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
             const kd_u64 j = first + u * KD_BLOCK + t;
             p_sc[u] = KD_CLS_SKIP; p_gs[u] = 0; p_ld[u] = 0;
             if (j < last) {
-                const KdRInfo ri = rinfo[order ? (kd_u64)order[j] : j];
+                const KdRInfo ri = KD_RI(rinfo, rd, order ? (kd_u64)order[j] : j);
                 p_gs[u] = ri.gstart; p_sc[u] = ri.span_cls; p_ld[u] = ri.lead;
             }
         }
@@ -531,7 +530,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 const kd_u64 j = tb + KD_TILE + u * KD_BLOCK + t;
                 p_sc[u] = KD_CLS_SKIP;
                 if (j < last) {
-                    const KdRInfo ri = rinfo[order ? (kd_u64)order[j] : j];
+                    const KdRInfo ri = KD_RI(rinfo, rd, order ? (kd_u64)order[j] : j);
                     p_gs[u] = ri.gstart; p_sc[u] = ri.span_cls; p_ld[u] = ri.lead;
                 }
             }
@@ -550,7 +549,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 const uint32_t e = ((lane / KD_LANE_GROUP) * rows_i + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
                 if (e < ni) {
                     const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
-                    kd_walk_inner(rd, i, rinfo[i], wlo, We, Wh, hist0);
+                    kd_walk_inner(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0);
                 }
             }
             // (each list's rows start at the wavefront after the one that took the last row of the list before)
@@ -559,7 +558,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 const uint32_t e = ((lane / KD_LANE_GROUP) * rows_p + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
                 if (e < np) {
                     const kd_u64 j = tb + l_plain[KD_TILE - 1u - e], i = order ? (kd_u64)order[j] : j;
-                    kd_walk_plain(rd, i, rinfo[i], wlo, We, Wh, hist0);
+                    kd_walk_plain(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0);
                 }
             }
             KD_MARK(c_plain)
@@ -569,16 +568,16 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 const uint32_t e = ((lane / KD_LANE_GROUP) * rows_c + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
                 if (e < ncx) {
                     const kd_u64 j = tb + l_cplx[e], i = order ? (kd_u64)order[j] : j;
-                    const KdRInfo ri = rinfo[i];
+                    const KdRInfo ri = KD_RI(rinfo, rd, i);
                     const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);
                     const int32_t foot_end = grel + (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
                     if (seg_read) {          // one segment of a long read
                         const kd_u64 ir = seg_read[i / KD_BLOCK];
                         const uint32_t nc = rd.n_cig[ir], per = (nc + KD_BLOCK - 1) / KD_BLOCK;
                         const uint32_t k0 = (uint32_t)(i % KD_BLOCK) * per, k1 = k0 + per < nc ? k0 + per : nc;
-                        kd_walk_ops(rd, ir, k0, k1, grel, (int32_t)ckpt[i].q, (int32_t)ri.lead, foot_end, We, Wh, hist0);
+                        kd_walk_ops(rd, ir, nc, k0, k1, grel, (int32_t)ckpt[i].q, (int32_t)ri.lead, foot_end, We, Wh, hist0);
                     } else if (!kd_walk_short(rd, i, ri, wlo, We, Wh, hist0)) {   // more than three segments: general walk
-                        kd_walk_ops(rd, i, 0u, rd.n_cig[i], grel, 0, (int32_t)ri.lead, foot_end, We, Wh, hist0);
+                        kd_walk_ops(rd, i, ri.pad >> 24, 0u, ri.pad >> 24, grel, 0, (int32_t)ri.lead, foot_end, We, Wh, hist0);
                     }
                 }
             }
@@ -591,7 +590,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                     const uint32_t code = l_cplx[KD_TILE - 1u - e];
                     const bool early = (code & 0x8000u) != 0;
                     const kd_u64 j = tb + (code & 0x3fffu), i = order ? (kd_u64)order[j] : j;
-                    const KdRInfo ri = rinfo[i];
+                    const KdRInfo ri = KD_RI(rinfo, rd, i);
                     const bool shifted = early && w != 0;          // early entry of a window that has windows in front
                     const kd_u64 org = shifted ? wlo + H : wlo;
                     uint32_t *h0 = shifted ? hist_early : hist0;
@@ -602,9 +601,9 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                         const kd_u64 ir = seg_read[i / KD_BLOCK];
                         const uint32_t nc = rd.n_cig[ir], per = (nc + KD_BLOCK - 1) / KD_BLOCK;
                         const uint32_t k0 = (uint32_t)(i % KD_BLOCK) * per, k1 = k0 + per < nc ? k0 + per : nc;
-                        kd_walk_ops(rd, ir, k0, k1, grel, (int32_t)ckpt[i].q, (int32_t)ri.lead, foot_end, Wx, Wh, h0);
+                        kd_walk_ops(rd, ir, nc, k0, k1, grel, (int32_t)ckpt[i].q, (int32_t)ri.lead, foot_end, Wx, Wh, h0);
                     } else {
-                        kd_walk_ops(rd, i, 0u, rd.n_cig[i], grel, 0, (int32_t)ri.lead, foot_end, Wx, Wh, h0);
+                        kd_walk_ops(rd, i, ri.pad >> 24, 0u, ri.pad >> 24, grel, 0, (int32_t)ri.lead, foot_end, Wx, Wh, h0);
                     }
                 }
             }

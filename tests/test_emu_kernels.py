@@ -70,6 +70,22 @@ def test_window_path_is_taken_also_for_unsorted_batches(emu_lib):
         assert np.array_equal(run.tables[cid], run2.tables[cid])  # sums are order independent
 
 
+def test_unsorted_batch_of_several_sort_chunks(emu_lib):
+    # the counting sort's bin counters are private to a workgroup (LDS) and every workgroup sorts one chunk of the batch: here the
+    # shuffled batch spans several chunks (1024-lane workgroups), clipped / indel reads and both contigs included
+    batch = synth.to_numpy(synth.short_reads([9000, 2500], 60, seed=3, clip_p=0.2, indel_p=0.2))
+    n = len(batch["contig"])
+    assert n > 3 * 1024
+    perm = np.random.default_rng(1).permutation(n)
+    sh = dict(batch)
+    for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+        sh[k] = batch[k][perm].copy()
+    for window in (128, 448):
+        run = P.Run(emu_lib, sh, window=window)
+        assert run.info["windowed"] == 1 and run.info["unsorted"] > 0
+        P.assert_matches_oracle(run)
+
+
 def test_multiple_pushes_accumulate(emu_lib):
     b = P.subset(P.load_fixture("segemehl__2.1.sub_test"), 100, 700)
     P.assert_matches_oracle(P.Run(emu_lib, b, window=256, n_pushes=3))
