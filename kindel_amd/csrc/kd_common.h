@@ -47,6 +47,7 @@ __device__ __forceinline__ uint32_t kd_readfirstlane(uint32_t v) { return (uint3
 __device__ __forceinline__ unsigned long long kd_readfirstlane64(unsigned long long v) {
     return ((unsigned long long)kd_readfirstlane((uint32_t)(v >> 32)) << 32) | kd_readfirstlane((uint32_t)v);
 }
+__device__ __forceinline__ uint32_t kd_readlane(uint32_t v, unsigned src_lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src_lane); }   // src_lane: a constant
 __device__ __forceinline__ int kd_popcll(unsigned long long m) { return __popcll(m); }
 // OR over the 64 lanes (wave-uniform result): an inclusive DPP scan inside each row of 16 lanes, two cross-row broadcasts, v_readlane 63
 __device__ __forceinline__ uint32_t kd_wave_or(uint32_t v) {
@@ -57,6 +58,26 @@ __device__ __forceinline__ uint32_t kd_wave_or(uint32_t v) {
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// Inclusive prefix sum over the 64 lanes with DPP adds (row_shr 1 / 2 / 4 / 8 inside each row of 16 lanes, then the last lane
+// of a row broadcast into the rows behind it): six VALU instructions.  __shfl_up is a ds_bpermute_b32 per step and operand
+// -- the LDS crossbar, 2.6 ns per CU-instruction (profiles/valu_issue_calibration.json) -- and kernels that scan per tile of
+// 256 CIGAR ops spent most of their time there.
+__device__ __forceinline__ uint32_t kd_wave_scan_add(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// running maximum over the lanes (inclusive), the same six DPP steps
+__device__ __forceinline__ uint32_t kd_wave_scan_max(uint32_t v) {
+#define KD_DPP_MAX(ctrl, rows) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false); v = o_ > v ? o_ : v; }
+    KD_DPP_MAX(0x111, 0xf) KD_DPP_MAX(0x112, 0xf) KD_DPP_MAX(0x114, 0xf) KD_DPP_MAX(0x118, 0xf) KD_DPP_MAX(0x142, 0xa) KD_DPP_MAX(0x143, 0xc)
+#undef KD_DPP_MAX
+    return v;
 }
 // v_perm_b32: byte i of the result = byte sel.byte[i] of {hi (bytes 4-7), lo (bytes 0-3)}
 __device__ __forceinline__ uint32_t kd_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
@@ -108,7 +129,8 @@ enum {
     KDS_B_INS_BASES,    // per batch: insertion bases
     KDS_B_MAXSPAN,      // per batch: max span of regular reads
     KDS_B_MAXLEAD,      // per batch: max leading-clip reach of regular reads
-    KDS_B_MAXSEGSPAN,   // per batch: max span of a long read's SEGMENT (k_prep_long; k_window's second pass)
+    KDS_B_MAXSEGSPAN,   // per batch: longest ROW of a long read (k_long_reduce; k_window's second pass), in sites
+    KDS_B_ROW_DWORDS,   // per batch: dwords of the row buffer handed out to the long reads (k_long_reduce)
     KDS_B_UNSORTED,     // per batch: reads not sorted by G-start
     KDS_B_N_COLD,       // per batch: entries in the cold list
     KDS_B_N_IRREG,      // per batch: entries in the irregular list
@@ -165,7 +187,7 @@ struct KdRInfo {
     uint32_t span_cls;  // span << KD_SPAN_SHIFT | KD_INFO_INS | KD_INFO_COLD | class; span = sites from
                         // gstart to the end of the last M / D / trailing-S write
     uint32_t lead;      // sites before gstart written by a leading soft clip (kindel.py:68-72)
-    uint32_t pad;       // long-CIGAR reads: 1 + index of the read's KdCkpt[256] block; regular short-CIGAR reads: query length
+    uint32_t pad;       // long-CIGAR reads: 1 + index of the read in the long list; regular short-CIGAR reads: query length
                         // (< 2^20) | CIGAR words << 24; 0 otherwise
 };
 
@@ -177,15 +199,13 @@ struct alignas(16) KdSortRec { KdRInfo ri; kd_u64 seq_off, cig_off; };
 #define KD_SOFF(rd, i) ((rd).seq_off[(kd_u64)(i) << ((rd).osh * 2u)])
 #define KD_COFF(rd, i) ((rd).cig_off[(kd_u64)(i) << ((rd).osh * 2u)])
 
-// Long-CIGAR reads (k_prep_long): the state at the first op of each of the 256 per-thread op runs.  Lets
-// k_cold_long emit a read's insertion events with 256 threads and lets k_window enter the read near a window
-// instead of walking thousands of ops from the start.
-struct KdCkpt {
-    uint32_t r_rel;   // reference advance (r - pos0) before the run
-    uint32_t q;       // query advance before the run
-    uint32_t ev;      // insertion events of the read before the run
-    uint32_t pool;    // insertion bases of the read before the run
-};
+// Long-CIGAR reads (> KD_PREP_MAX_OPS words; kd_long.h).  A regular long read is EXPANDED into a ROW: one 4-bit symbol per
+// reference site of its footprint (packed like BAM bases: high nibble first), so that the window pass tallies it as ONE plain
+// run whatever its CIGAR looks like -- an ONT read has an op every ~7 bases, and walking those op by op left most lanes idle.
+// Row symbols = LDS histogram channels of k_window<ROWS>:
+#define KD_ROW_SKIP 0u      // nothing aligned here (padding, the slot behind the last site, a base outside A,C,G,T,N)
+#define KD_ROW_DEL 6u       // a deleted site                      (1..5 = A,T,G,C,N in the reference's dict order: 1 + kd_chan)
+#define KD_ROW_INS 7u       // added to the symbol of a site that an insertion precedes: SKIP+ins 7, A+ins .. N+ins 8..12, DEL+ins 13
 
 // A regular short-CIGAR read with a soft clip or an insertion, as k_cold_lane needs it.  k_prep has all of this in
 // registers when it classifies the read; k_cold_lane, one lane per such read (one read in nine on C3), would gather it again
@@ -209,8 +229,10 @@ struct KdLongAcc {
     kd_u64 aligned, walked, insb;
     uint32_t n_ins;
     uint32_t lead;      // leading-clip reach of a regular read
-    uint32_t maxseg;    // longest segment span
+    uint32_t row_span;  // regular: symbols of its row = M / D footprint + 1 (the slot behind the last site takes trailing insertions)
     uint32_t regular;   // 1: stays class LONG, 0: irregular (goes to irreg_list)
+    uint32_t clip_adv;  // regular: sites a trailing soft clip writes behind the footprint (clip_start_weights)
+    uint32_t pad;
 };
 
 struct KdIns {

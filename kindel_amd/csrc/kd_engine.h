@@ -52,7 +52,7 @@ struct KdEngine {
         void *p = nullptr;
         size_t cap = 0;
     };
-    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_ckpt, b_seginfo, b_longacc, b_coldcnt, b_coldev, b_coldpool;
+    Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_rows, b_rowinfo, b_rowoff, b_longacc, b_coldcnt, b_coldev, b_coldpool;
     Buf b_stage[9];
     Buf b_srec;   // an unsorted batch's regular reads in window order: KdSortRec[] (k_sort_scatter_reads)
     Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
@@ -164,7 +164,7 @@ struct KdEngine {
     }
 
     void destroy() {
-        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_itemwin, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_ckpt, &b_seginfo, &b_longacc, &b_coldcnt, &b_coldev, &b_coldpool, &b_ev_site, &b_ev_len,
+        Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_itemwin, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_rows, &b_rowinfo, &b_rowoff, &b_longacc, &b_coldcnt, &b_coldev, &b_coldpool, &b_ev_site, &b_ev_len,
                       &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_win, &b_flag, &b_cns, &b_changes,
                       &b_tilesum, &b_tilemm, &b_tileoff, &b_coff};
         for (Buf *b : all) release(*b);
@@ -298,17 +298,20 @@ struct KdEngine {
         }
         const uint64_t n_long = h_status[KDS_B_N_LONG];
         if (n_long) {
-            if ((rc = ensure(b_ckpt, (size_t)n_long * KD_BLOCK * sizeof(KdCkpt))) ||
-                (rc = ensure(b_seginfo, (size_t)n_long * KD_BLOCK * sizeof(KdRInfo))))
+            // long-CIGAR reads (kd_long.h): validated one workgroup each, slots / rows handed out, then expanded into rows
+            if ((rc = ensure(b_rowinfo, (size_t)n_long * sizeof(KdRInfo))) || (rc = ensure(b_rowoff, (size_t)n_long * 8)) ||
+                (rc = ensure(b_longacc, (size_t)n_long * sizeof(KdLongAcc))))
                 return rc;
-            if ((rc = ensure(b_longacc, (size_t)n_long * sizeof(KdLongAcc)))) return rc;
-            if (rt.launch("k_prep_long", k_prep_long, (unsigned)n_long, KD_BLOCK, 0, R, T, rinfo,
-                          (const uint32_t *)lng, (KdCkpt *)b_ckpt.p, (KdRInfo *)b_seginfo.p, (KdLongAcc *)b_longacc.p))
+            const unsigned long_grid = (unsigned)((n_long + KD_WAVES_PER_BLOCK - 1) / KD_WAVES_PER_BLOCK);   // a wavefront per long read
+            if (rt.launch("k_prep_long", k_prep_long, long_grid, KD_BLOCK, 0, R, T, rinfo,
+                          (const uint32_t *)lng, (uint32_t)n_long, (KdLongAcc *)b_longacc.p))
                 return hipfail("k_prep_long");
             if (rt.launch("k_long_reduce", k_long_reduce, (unsigned)((n_long + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, (const KdLongAcc *)b_longacc.p,
-                          (const uint32_t *)lng, (uint32_t)n_long, irreg, (uint32_t *)b_readev.p, (kd_u64 *)b_readpool.p, d_status))
+                          (const uint32_t *)lng, (uint32_t)n_long, (const KdRInfo *)rinfo, irreg, (uint32_t *)b_readev.p, (kd_u64 *)b_readpool.p,
+                          (KdRInfo *)b_rowinfo.p, (kd_u64 *)b_rowoff.p, d_status))
                 return hipfail("k_long_reduce");
             if ((rc = fetch_status())) return rc;
+            if ((rc = ensure(b_rows, (size_t)h_status[KDS_B_ROW_DWORDS] * 4 + 64))) return rc;   // (+ 64: the walk loads 16-byte chunks)
         }
         // size the insertion event buffers from the exact counts of this batch
         // k_prep / k_prep_long have already reserved this batch's slots in KDS_N_EV / KDS_POOL
@@ -327,6 +330,10 @@ struct KdEngine {
             pool_cap = ncap;
         }
         KdIns I = insdesc();
+        if (n_long && mode != KD_MODE_GLOBAL &&
+            rt.launch("k_long_expand", k_long_expand, (unsigned)((n_long + KD_WAVES_PER_BLOCK - 1) / KD_WAVES_PER_BLOCK), KD_BLOCK, 0, R, T, I,
+                      (const KdRInfo *)rinfo, (const uint32_t *)lng, (uint32_t)n_long, (const KdLongAcc *)b_longacc.p, (const kd_u64 *)b_rowoff.p, (uint8_t *)b_rows.p, d_status))
+            return hipfail("k_long_expand");
         const uint64_t n_reg = h_status[KDS_B_N_REG], n_cold = h_status[KDS_B_N_COLD], n_irreg = h_status[KDS_B_N_IRREG];
         const bool windowed = (mode != KD_MODE_GLOBAL) && n_reg > 0;
         const bool sorted_input = h_status[KDS_B_UNSORTED] == 0;
@@ -344,9 +351,10 @@ struct KdEngine {
             if ((rc = ensure(b_winlo, nw_max * 8)) || (rc = ensure(b_winhi, nw_max * 8)) || (rc = ensure(b_itemoff, (nw_max + 1) * 8)))
                 return rc;
             kd_u64 *wl = (kd_u64 *)b_winlo.p, *wh = (kd_u64 *)b_winhi.p, *io = (kd_u64 *)b_itemoff.p;
-            // One pass over `ne` entries described by `info`: the batch's reads (seg_read == NULL; k_window_coop when `use_coop`),
-            // then the SEGMENTS of its long reads (k_prep_long), which are bucket-sorted by window like an unsorted batch.
-            auto window_pass = [&](const KdRInfo *info, uint64_t ne, bool in_order, const uint32_t *seg_read, uint32_t span_slot,
+            // One pass over `ne` entries described by `info`: the batch's reads (rows == false; k_window_coop when `use_coop`),
+            // then the ROWS of its long reads (k_long_expand; one entry per long read, in the order of the long list: bucket-
+            // sorted by window through a permutation).
+            auto window_pass = [&](const KdRInfo *info, uint64_t ne, bool in_order, bool rows, uint32_t span_slot,
                                    uint32_t W, bool use_coop) -> int {
                 int rc2;
                 uint32_t w0;
@@ -362,13 +370,14 @@ struct KdEngine {
                 KdReads walk_R = R;
                 // the histogram reaches H sites past the window: an entry is tallied whole by the window it starts in (kd_window.h:
                 // OWNERSHIP); H = the longest footprint of this pass's entries, up to 256 sites (longer ones leave a remainder)
-                uint32_t H = use_coop ? 0u : (uint32_t)std::min<uint64_t>(256, (h_status[span_slot] + 63) & ~uint64_t(63));
+                // (a row is thousands of sites long: every window tallies its own part of it, H = 0)
+                uint32_t H = (use_coop || rows) ? 0u : (uint32_t)std::min<uint64_t>(256, (h_status[span_slot] + 63) & ~uint64_t(63));
                 while (H && KD_WINDOW_LDS_BYTES((W + H + 2 * KD_HALO) / 2) > (size_t)160 * 1024 - 1024) H -= 64;   // (a hand-picked window near the LDS limit)
                 if (in_order) {
                     if (rt.launch("k_plan_ranges", k_plan_ranges, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, info, (kd_u64)ne, w0,
                                   n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status, span_slot == (uint32_t)KDS_B_MAXSPAN ? H : 0u))
                         return hipfail("k_plan_ranges");
-                } else if (!seg_read) {
+                } else if (!rows) {
                     // an UNSORTED batch of reads: counting sort by window, the regular reads' footprints / offsets scattered
                     // physically into window order (k_sort_scatter_reads); k_window then walks them like a sorted batch
                     const uint32_t n_bins = (uint32_t)((S + W - 1) / W);
@@ -405,23 +414,18 @@ struct KdEngine {
                     walk_R.seq_off = (const kd_u64 *)b_srec.p + 2; walk_R.cig_off = (const kd_u64 *)b_srec.p + 3; walk_R.n_cig = nullptr;
                     walk_R.osh = 1;
                 } else {
-                    // the SEGMENTS of long reads: counting sort by window -> permutation `order`
+                    // the ROWS of long reads: counting sort by window -> permutation `order`
                     const uint32_t n_bins = (uint32_t)((S + W - 1) / W);
                     if ((rc2 = ensure(b_order, ne * 4)) || (rc2 = ensure(b_bincnt, ((size_t)n_bins + 1) * 4)) ||
                         (rc2 = ensure(b_binoff, ((size_t)n_bins + 1) * 8)))
                         return rc2;
                     uint32_t *ord = (uint32_t *)b_order.p, *bc = (uint32_t *)b_bincnt.p;
                     kd_u64 *bo = (kd_u64 *)b_binoff.p;
-                    const uint64_t run = seg_read ? KD_SORT_RUN : 1;   // segments arrive in reference order: merge runs
-                    const unsigned gr = (unsigned)((ne + (uint64_t)KD_BLOCK * run - 1) / ((uint64_t)KD_BLOCK * run));
+                    const unsigned gr = (unsigned)((ne + (uint64_t)KD_BLOCK - 1) / (uint64_t)KD_BLOCK);
                     if (rt.memset(bc, 0, ((size_t)n_bins + 1) * 4) ||
-                        (seg_read ? rt.launch("k_sort_count", k_sort_count<KD_SORT_RUN>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, 1u)
-                                  : rt.launch("k_sort_count", k_sort_count<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, 1u)) ||
+                        rt.launch("k_sort_count", k_sort_count<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, 1u) ||
                         rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, n_bins) ||
-                        (seg_read ? rt.launch("k_sort_scatter", k_sort_scatter<KD_SORT_RUN>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc,
-                                              (const kd_u64 *)bo, ord)
-                                  : rt.launch("k_sort_scatter", k_sort_scatter<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc,
-                                              (const kd_u64 *)bo, ord)) ||
+                        rt.launch("k_sort_scatter", k_sort_scatter<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, (const kd_u64 *)bo, ord) ||
                         rt.launch("k_plan_ranges_sorted", k_plan_ranges_sorted, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
                                   (const kd_u64 *)bo, n_bins, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status, span_slot, 1u))
                         return hipfail("k_sort_*");
@@ -455,9 +459,14 @@ struct KdEngine {
                 const size_t lds = KD_WINDOW_LDS_BYTES(Wh);
                 const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
                 const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
-                if (rt.launch(seg_read ? "k_window_segments" : "k_window", k_window, grid, KD_BLOCK, lds, walk_R, walk_info, order,
-                              (const KdCkpt *)b_ckpt.p, seg_read, T, (const kd_u64 *)wl, (const kd_u64 *)wh, (const kd_u64 *)io,
-                              (const uint32_t *)iw, (kd_u64)items_cap, w0, W, H, Wh, slice, d_status))
+                if (rows) {
+                    walk_R.seq4 = (const uint8_t *)b_rows.p; walk_R.seq_off = (const kd_u64 *)b_rowoff.p;
+                    walk_R.cig_off = nullptr; walk_R.n_cig = nullptr; walk_R.osh = 0;
+                }
+                if (rows ? rt.launch("k_window_rows", k_window<true>, grid, KD_BLOCK, lds, walk_R, walk_info, order, T, (const kd_u64 *)wl,
+                                     (const kd_u64 *)wh, (const kd_u64 *)io, (const uint32_t *)iw, (kd_u64)items_cap, w0, W, H, Wh, slice, d_status)
+                         : rt.launch("k_window", k_window<false>, grid, KD_BLOCK, lds, walk_R, walk_info, order, T, (const kd_u64 *)wl,
+                                     (const kd_u64 *)wh, (const kd_u64 *)io, (const uint32_t *)iw, (kd_u64)items_cap, w0, W, H, Wh, slice, d_status))
                     return hipfail("k_window");
                 return KD_OK;
             };
@@ -513,19 +522,15 @@ struct KdEngine {
                 return KD_OK;
             };
             if (mode == KD_MODE_STRIP) rc = strip_pass((const KdRInfo *)rinfo, n, sorted_input);
-            else rc = window_pass((const KdRInfo *)rinfo, n, sorted_input, nullptr, (uint32_t)KDS_B_MAXSPAN, W_first, coop);
+            else rc = window_pass((const KdRInfo *)rinfo, n, sorted_input, false, (uint32_t)KDS_B_MAXSPAN, W_first, coop);
             if (rc) return rc;
-            if (n_long && (rc = window_pass((const KdRInfo *)b_seginfo.p, n_long * KD_BLOCK, false, (const uint32_t *)lng,
-                                            (uint32_t)KDS_B_MAXSEGSPAN, W_seg, false)))
+            if (n_long && h_status[KDS_B_MAXSEGSPAN] &&
+                (rc = window_pass((const KdRInfo *)b_rowinfo.p, n_long, false, true, (uint32_t)KDS_B_MAXSEGSPAN, W_seg, false)))
                 return rc;
             if (n_cold &&
                 rt.launch("k_cold_lane", k_cold_lane, prep_regions, KD_BLOCK, 0, R, T, I, (const KdColdRec *)cold,
                           (const uint32_t *)b_coldcnt.p, (const kd_u64 *)b_coldev.p, (const kd_u64 *)b_coldpool.p, cold_region, d_status))
                 return hipfail("k_cold_lane");
-            if (n_long &&
-                rt.launch("k_cold_long", k_cold_long, (unsigned)n_long, KD_BLOCK, 0, R, T, I, (const KdRInfo *)rinfo,
-                          (const uint32_t *)lng, (const KdCkpt *)b_ckpt.p, d_status))
-                return hipfail("k_cold_long");
             if (n_irreg &&
                 rt.launch("k_pileup_wave_irreg", k_pileup_wave<true, true>,
                           (unsigned)((n_irreg + KD_WAVES_PER_BLOCK - 1) / KD_WAVES_PER_BLOCK), KD_BLOCK, 0, R, T, I,
@@ -916,7 +921,7 @@ struct KdEngine {
             return consensus_fetch_all(seq_out, cap, len_out, contig_off, nullptr);
         };
         // the words every host decision of the sequence is made from
-        static const int kDecisive[] = {KDS_ERR_READ, KDS_N_EV, KDS_POOL, KDS_B_INS_OPS, KDS_B_INS_BASES, KDS_B_MAXSPAN, KDS_B_MAXLEAD, KDS_B_MAXSEGSPAN,
+        static const int kDecisive[] = {KDS_ERR_READ, KDS_N_EV, KDS_POOL, KDS_B_INS_OPS, KDS_B_INS_BASES, KDS_B_MAXSPAN, KDS_B_MAXLEAD, KDS_B_MAXSEGSPAN, KDS_B_ROW_DWORDS,
                                         KDS_B_UNSORTED, KDS_B_N_COLD, KDS_B_N_IRREG, KDS_B_N_LONG, KDS_B_N_REG, KDS_INS_COLLISION, KDS_INTERNAL,
                                         KDS_BAD_BASE};
         if (step_have && rt.has_graph() && !memcmp(sig, step_sig, sizeof sig) && !step_status.empty()) {

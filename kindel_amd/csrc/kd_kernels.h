@@ -11,15 +11,17 @@
 //            len+1 slots each, padded to 64) so that 64 lanes walking 64 consecutive sites
 //            hit 64 consecutive dwords (coalesced atomics / stores, conflict-free LDS banks).
 //   kd_prep.h     k_prep: lane per read: classify (skip / regular / irregular / long CIGAR, plain), footprint,
-//                 stats, deterministic insertion-event slots; k_prep_long (workgroup per read with > 16 CIGAR
-//                 words): checkpoints and one SEGMENT per thread
+//                 stats, deterministic insertion-event slots
+//   kd_long.h     reads with > 16 CIGAR words (workgroup per read, tiles of 256 ops, thread = op): k_prep_long validates,
+//                 k_long_reduce hands out slots, k_long_expand writes the read's ROW (one symbol per site: base / deleted /
+//                 nothing, + "insertion in front"), its insertion events and its clips
 //   kd_plan.h     k_plan_*: window -> candidate range (binary search on sorted starts) -> work items;
-//                 k_sort_*: bucket sort by window (unsorted batches, long-read segments)
-//   kd_window.h   k_window: persistent workgroups pull (window, slice) items; ONE LANE PER READ (or per long-read
-//                 segment), 8 bases per dword, every base one ds_add_u32 into an LDS histogram (weights, deletions
+//                 k_sort_*: bucket sort by window (unsorted batches, the rows of long reads)
+//   kd_window.h   k_window: persistent workgroups pull (window, slice) items; ONE LANE PER READ (second pass: per long
+//                 read's ROW), 8 bases per dword, every base one ds_add_u32 into an LDS histogram (weights, deletions
 //                 and both soft-clip weight tables; u16 counters, two sites per dword); one coalesced flush of
 //                 the non-zero counters per item into HBM
-//   kd_readwise.h k_cold_lane / k_cold_long: reads with S or I: clip start/end counters, insertion events;
+//   kd_readwise.h k_cold_lane: short reads with S or I: clip start/end counters, insertion events;
 //                 k_pileup_wave: one wavefront per read, every reference quirk incl. Python negative-index wrap,
 //                 32-bit atomics straight to HBM: irregular reads, KD_MODE_GLOBAL; k_diagnose
 //   kd_ins.h      k_ins_*: insertion events -> open-addressing hash multiset -> per-site unique max
@@ -30,6 +32,7 @@
 #pragma once
 #include "kd_common.h"
 #include "kd_prep.h"
+#include "kd_long.h"
 #include "kd_readwise.h"
 #include "kd_plan.h"
 #include "kd_window.h"

@@ -1,4 +1,4 @@
-// kd_prep.h -- k_prep, k_prep_long: classify reads, footprints, stats, insertion slots, long-read checkpoints and segments.
+// kd_prep.h -- k_prep: classify reads, footprints, stats, insertion slots.
 // Part of the device code of kd_kernels.h (included from there, in order; not a stand-alone header).
 #pragma once
 #include "kd_common.h"
@@ -288,194 +288,4 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
     }
 }
 
-// k_prep_long: one workgroup per read whose CIGAR has more than KD_PREP_MAX_OPS words
-// (long-read aligners: thousands of ops).  Each thread sums the reference / query advance
-// of a contiguous run of ops, an LDS scan turns the sums into start coordinates, and a
-// second sweep applies the same regularity rules as kd_scan_cigar.
-__global__ void __launch_bounds__(KD_BLOCK)
-k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, KdCkpt *ckpt, KdRInfo *seginfo,
-            KdLongAcc *long_acc) {
-    __shared__ int64_t s_r[KD_BLOCK], s_q[KD_BLOCK], s_gr[KD_BLOCK / KD_SCAN_SEG], s_gq[KD_BLOCK / KD_SCAN_SEG];
-    __shared__ uint32_t s_ni[KD_BLOCK], s_nb[KD_BLOCK], s_gni[KD_BLOCK / KD_SCAN_SEG], s_gnb[KD_BLOCK / KD_SCAN_SEG];
-    __shared__ kd_u64 s_acc[6];       // aligned, walked, n_ins, ins_bases, bad, cold
-    __shared__ uint32_t s_first_nfs, s_last_rel;
-    __shared__ uint32_t s_regular, s_lead, s_gstart, s_nfs_adv, s_maxseg;
-    const uint32_t t = threadIdx.x;
-    const kd_u64 i = long_list[blockIdx.x];
-    const uint32_t c = rd.contig[i];
-    const int64_t L = T.contig_len[c];
-    const int64_t pos0 = rd.pos0[i];
-    const int64_t sl = rd.seq_len[i];
-    const uint32_t nc = rd.n_cig[i];
-    const uint32_t *cg = rd.cigar + rd.cig_off[i];
-    const uint32_t per = (nc + KD_BLOCK - 1) / KD_BLOCK;
-    const uint32_t k0 = t * per < nc ? t * per : nc, k1 = k0 + per < nc ? k0 + per : nc;
-    if (t < 6) s_acc[t] = 0;
-    if (t == 0) { s_first_nfs = 0xffffffffu; s_last_rel = 0; s_regular = 0; s_lead = 0; s_gstart = 0; s_nfs_adv = 0; s_maxseg = 0; }
-    int64_t dr = 0, dq = 0;
-    for (uint32_t k = k0; k < k1; k++) {
-        const uint32_t w = cg[k];
-        const int64_t len = w >> 4;
-        const uint32_t op = w & 15u;
-        if (op == 0 || op == 7 || op == 8) { dr += len; dq += len; }
-        else if (op == 1) dq += len;
-        else if (op == 2) dr += len;
-        else if (op == 4 && k == 0) dq += len;
-        // a non-first S contributes nothing here: anything after it makes the read irregular,
-        // and if nothing follows its own advance is irrelevant to the span
-    }
-    int64_t incl_r, incl_q, tot_r, tot_q;   // prefix sums of the 256 partial advances
-    kd_block_scan2(s_r, s_q, s_gr, s_gq, dr, dq, incl_r, incl_q, tot_r, tot_q);
-    int64_t r = pos0 + incl_r - dr, q = incl_q - dq;
-    const int64_t r_end = pos0 + tot_r;
-    const int64_t r_run = r, q_run = q;   // checkpoint: state before this thread's run of ops
-    kd_u64 aligned = 0, walked = 0, n_ins = 0, insb = 0, bad = 0, cold = 0;
-    uint32_t first_nfs = 0xffffffffu, last_rel = 0;
-    for (uint32_t k = k0; k < k1; k++) {
-        const uint32_t w = cg[k];
-        const int64_t len = w >> 4;
-        const uint32_t op = w & 15u;
-        if (op == 0 || op == 7 || op == 8) {
-            if (r + len > L || q + len > sl) bad = 1;
-            r += len; q += len; aligned += (kd_u64)len; walked += (kd_u64)len; last_rel = k;
-        } else if (op == 1) {
-            cold = 1;
-            if (r > L) bad = 1;
-            int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
-            n_ins++; insb += (kd_u64)(q1 - q0); q += len; walked += (kd_u64)len; last_rel = k;
-        } else if (op == 2) {
-            if (r + len > L + 1) bad = 1;
-            r += len; walked += (kd_u64)len; last_rel = k;
-        } else if (op == 4) {
-            cold = 1; walked += (kd_u64)len;
-            if (k == 0) { if (r > L || len > sl) bad = 1; q += len; }
-            else {
-                if (k < first_nfs) first_nfs = k;
-                if (r - 1 > L) bad = 1;   // clip_starts[r - 1] must exist (kindel.py:75)
-                int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
-                if (n_adv > sl - q || (len > n_adv && q + n_adv >= sl)) bad = 1;
-                last_rel = k;
-            }
-        }
-    }
-    if (aligned) atomicAdd(&s_acc[0], aligned);
-    if (walked) atomicAdd(&s_acc[1], walked);
-    if (n_ins) atomicAdd(&s_acc[2], n_ins);
-    if (insb) atomicAdd(&s_acc[3], insb);
-    if (bad) atomicAdd(&s_acc[4], bad);
-    if (cold) atomicAdd(&s_acc[5], cold);
-    if (first_nfs != 0xffffffffu) atomicMin(&s_first_nfs, first_nfs);
-    if (last_rel) atomicMax(&s_last_rel, last_rel);
-    // exclusive prefix of the per-run insertion counts -> event / pool offsets inside the read
-    uint32_t incl_ni, incl_nb, tot_ni, tot_nb;
-    kd_block_scan2(s_ni, s_nb, s_gni, s_gnb, (uint32_t)n_ins, (uint32_t)insb, incl_ni, incl_nb, tot_ni, tot_nb);
-    {
-        KdCkpt ck;
-        ck.r_rel = (uint32_t)(r_run - pos0); ck.q = (uint32_t)q_run;
-        ck.ev = incl_ni - (uint32_t)n_ins; ck.pool = incl_nb - (uint32_t)insb;
-        ckpt[(kd_u64)blockIdx.x * KD_BLOCK + t] = ck;
-    }
-    if (t == 0) {
-        bool regular = pos0 >= 0 && s_acc[4] == 0;
-        // a non-first S must be the last op that touches r (M, I, D or S)
-        if (s_first_nfs != 0xffffffffu && s_last_rel > s_first_nfs) regular = false;
-        int64_t foot_end = r_end;
-        uint32_t lead = 0;
-        if (regular) {
-            if ((cg[0] & 15u) == 4u) { const int64_t l0 = cg[0] >> 4; lead = (uint32_t)(l0 < pos0 ? l0 : pos0); }
-            if (s_first_nfs != 0xffffffffu) {  // trailing clip: r at that op is r_end (nothing after it moves r)
-                const int64_t ls = cg[s_first_nfs] >> 4;
-                const int64_t adv = r_end < L ? (ls < L - r_end ? ls : L - r_end) : 0;
-                foot_end += adv;
-                s_nfs_adv = (uint32_t)adv;
-            }
-        }
-        kd_u64 span = foot_end > pos0 ? (kd_u64)(foot_end - pos0) : 0;
-        if (span > 0x07ffffffULL) { regular = false; span = 0; }
-        const uint32_t coldbit = s_acc[5] ? KD_INFO_COLD : 0u;
-        KdRInfo ri = rinfo[i];
-        // a regular long read KEEPS class LONG: k_window's first pass (class REG) leaves it alone, its aligned and
-        // deleted bases are tallied segment by segment in the second pass, its S / I side effects by k_cold_long
-        ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | (s_acc[2] ? KD_INFO_INS : 0u) | coldbit |
-                      (regular ? KD_CLS_LONG : KD_CLS_IRREG);
-        ri.lead = regular ? lead : 0u;
-        ri.pad = regular ? blockIdx.x + 1u : 0u;
-        rinfo[i] = ri;
-        s_regular = regular ? 1u : 0u; s_lead = ri.lead; s_gstart = ri.gstart;
-        // (its S / I side effects are done by k_cold_long, 256 threads per read; its statistics and its event / pool /
-        //  irregular-list slots by k_long_reduce)
-    }
-    __syncthreads();
-    // SEGMENTS: this thread's run of ops [k0, k1) as a work unit of its own -- where it starts on the reference
-    // (checkpoint), how far its M / D / trailing-clip tallies reach.  k_window's second pass treats the segments of all
-    // long reads like a batch of short reads: bucket-sorted by window, one lane per segment, a few ops each,
-    // instead of one lane crawling through the hundreds of ops a long read has inside a window.
-    {
-        KdRInfo v;
-        v.gstart = 0; v.span_cls = KD_CLS_SKIP; v.lead = 0; v.pad = 0;
-        if (s_regular && k0 < k1) {
-            kd_u64 sp = (kd_u64)(r - r_run);                         // M and D advance of the run
-            if (first_nfs != 0xffffffffu) sp += s_nfs_adv;           // the trailing clip's clip_start_weights reach
-            const uint32_t ld = k0 == 0 ? s_lead : 0u;               // the leading clip reaches back from the read's start
-            if (sp > 0 || ld > 0) {
-                v.gstart = s_gstart + (uint32_t)(r_run - pos0);
-                v.span_cls = ((uint32_t)sp << KD_SPAN_SHIFT) | KD_CLS_REG;
-                v.lead = ld; v.pad = blockIdx.x + 1u;
-                atomicMax(&s_maxseg, (uint32_t)sp);
-            }
-        }
-        seginfo[(kd_u64)blockIdx.x * KD_BLOCK + t] = v;
-    }
-    __syncthreads();
-    if (t == 0) {
-        KdLongAcc a;
-        a.aligned = s_acc[0]; a.walked = s_acc[1]; a.insb = s_acc[3]; a.n_ins = (uint32_t)s_acc[2];
-        a.lead = s_lead; a.maxseg = s_maxseg; a.regular = s_regular;
-        long_acc[blockIdx.x] = a;
-    }
-}
-
-// k_long_reduce: one thread per long read.  Sums k_prep_long's per-read records into the status words and hands every long
-// read its insertion-event slots, its pool range and (irregular ones) its place in irreg_list: three block scans give the
-// offsets inside the workgroup, three returning atomics per WORKGROUP reserve its ranges (slot order is free).
-__global__ void __launch_bounds__(KD_BLOCK)
-k_long_reduce(const KdLongAcc *long_acc, const uint32_t *long_list, uint32_t n_long, uint32_t *irreg_list,
-              uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status) {
-    __shared__ kd_u64 s_wave[KD_WAVES_PER_BLOCK], s_base[3], s_sum[3];
-    __shared__ uint32_t s_mx[2];
-    const uint32_t t = threadIdx.x;
-    const uint32_t b = blockIdx.x * KD_BLOCK + t;
-    if (t < 3) s_sum[t] = 0;
-    if (t < 2) s_mx[t] = 0;
-    __syncthreads();
-    KdLongAcc a;
-    a.aligned = a.walked = a.insb = 0; a.n_ins = a.lead = a.maxseg = 0; a.regular = 1;
-    const bool live = b < n_long;
-    if (live) a = long_acc[b];
-    const kd_u64 n_irreg = live && !a.regular ? 1 : 0;
-    kd_u64 tot_ev, tot_pool, tot_irreg;
-    const kd_u64 o_ev = kd_block_scan_incl(a.n_ins, s_wave, tot_ev) - a.n_ins;
-    const kd_u64 o_pool = kd_block_scan_incl(a.insb, s_wave, tot_pool) - a.insb;
-    const kd_u64 o_irreg = kd_block_scan_incl(n_irreg, s_wave, tot_irreg) - n_irreg;
-    if (a.aligned) atomicAdd(&s_sum[0], a.aligned);
-    if (a.walked) atomicAdd(&s_sum[1], a.walked);
-    if (live && a.regular) { atomicAdd(&s_sum[2], 1ULL); if (a.lead) atomicMax(&s_mx[0], a.lead); }
-    if (a.maxseg) atomicMax(&s_mx[1], a.maxseg);
-    __syncthreads();
-    if (t == 0) s_base[0] = tot_ev ? atomicAdd(&status[KDS_N_EV], tot_ev) : 0;
-    if (t == 1) s_base[1] = tot_pool ? atomicAdd(&status[KDS_POOL], tot_pool) : 0;
-    if (t == 2) s_base[2] = tot_irreg ? atomicAdd(&status[KDS_B_N_IRREG], tot_irreg) : 0;
-    if (t == 3 && s_sum[0]) atomicAdd(&status[KDS_ST_ALIGNED], s_sum[0]);
-    if (t == 4 && s_sum[1]) atomicAdd(&status[KDS_ST_WALKED], s_sum[1]);
-    if (t == 5 && tot_ev) { atomicAdd(&status[KDS_ST_INS], tot_ev); atomicAdd(&status[KDS_B_INS_OPS], tot_ev); }
-    if (t == 6 && tot_pool) atomicAdd(&status[KDS_B_INS_BASES], tot_pool);
-    if (t == 7 && s_sum[2]) atomicAdd(&status[KDS_B_N_REG], s_sum[2]);
-    if (t == 8 && s_mx[0]) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)s_mx[0]);
-    if (t == 9 && s_mx[1]) atomicMax(&status[KDS_B_MAXSEGSPAN], (kd_u64)s_mx[1]);
-    __syncthreads();
-    if (live) {
-        const uint32_t i = long_list[b];
-        if (a.n_ins) { read_ev[i] = (uint32_t)(s_base[0] + o_ev); read_pool[i] = s_base[1] + o_pool; }
-        if (!a.regular) irreg_list[s_base[2] + o_irreg] = i;
-    }
-}
+// (long-CIGAR reads -- k_prep_long, k_long_reduce, k_long_expand -- live in kd_long.h)

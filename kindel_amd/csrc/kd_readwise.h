@@ -1,4 +1,4 @@
-// kd_readwise.h -- k_pileup_wave (exact semantics, wavefront per read), k_cold_lane, k_cold_long, k_diagnose.
+// kd_readwise.h -- k_pileup_wave (exact semantics, wavefront per read), k_cold_lane, k_diagnose.
 // Part of the device code of kd_kernels.h (included from there, in order; not a stand-alone header).
 #pragma once
 #include "kd_common.h"
@@ -231,65 +231,6 @@ k_cold_slots(const KdColdRec *rec, const uint32_t *cold_cnt, const kd_u64 *cold_
         if (!(cr.len_ops & KD_COLD_HAS_INS)) continue;
         read_ev[cr.read] = (uint32_t)(cold_evbase[blockIdx.x] + cr.ev_rel);
         read_pool[cr.read] = cold_poolbase[blockIdx.x] + cr.pool_rel;
-    }
-}
-
-// k_cold_long: k_cold_lane's work for regular long-CIGAR reads, one WORKGROUP per read: thread t starts from
-// checkpoint t (state before its run of ops, incl. how many insertion events / bases precede it).
-__global__ void __launch_bounds__(KD_BLOCK)
-k_cold_long(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint32_t *long_list, const KdCkpt *ckpt,
-            kd_u64 *status) {
-    const uint32_t t = threadIdx.x;
-    const kd_u64 i = long_list[blockIdx.x];
-    const uint32_t sc = rinfo[i].span_cls;
-    if ((sc & 3u) != KD_CLS_LONG || !(sc & KD_INFO_COLD)) return;   // LONG after k_prep_long = regular long read
-    const uint32_t nc = rd.n_cig[i];
-    const uint32_t per = (nc + KD_BLOCK - 1) / KD_BLOCK;
-    const uint32_t k0 = t * per < nc ? t * per : nc, k1 = k0 + per < nc ? k0 + per : nc;
-    if (k0 >= k1) return;
-    const uint32_t c = rd.contig[i];
-    const int64_t L = T.contig_len[c];
-    const kd_u64 cb = T.contig_base[c];
-    const int64_t sl = rd.seq_len[i];
-    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
-    const uint32_t *cg = rd.cigar + rd.cig_off[i];
-    const KdCkpt ck = ckpt[(kd_u64)blockIdx.x * KD_BLOCK + t];
-    int64_t r = rd.pos0[i] + (int64_t)ck.r_rel, q = ck.q;
-    kd_u64 e = 0, po = 0;
-    if (sc & KD_INFO_INS) { e = (kd_u64)ins.read_ev[i] + ck.ev; po = ins.read_pool[i] + ck.pool; }
-    uint32_t *tab = T.tab;
-    const kd_u64 S = T.stride;
-    for (uint32_t k = k0; k < k1; k++) {
-        const uint32_t w = cg[k];
-        const int64_t len = w >> 4;
-        const uint32_t op = w & 15u;
-        if (op == 0 || op == 7 || op == 8) { r += len; q += len; }
-        else if (op == 2) { r += len; }
-        else if (op == 1) {
-            const int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
-            const kd_u64 n = (kd_u64)(q1 - q0);
-            const kd_u64 g = cb + (kd_u64)r;
-            if (e >= ins.ev_cap || po + n > ins.pool_cap) {
-                atomicAdd(&status[KDS_INTERNAL], 1ULL);
-            } else if (kd_commit(T, g)) {
-                ins.ev_site[e] = (uint32_t)g; ins.ev_len[e] = (uint32_t)n; ins.ev_off[e] = po;
-                for (kd_u64 b = 0; b < n; b++) ins.pool[po + b] = (uint8_t)kd_nib(seq, q0 + (int64_t)b);
-                atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g], 1u);
-            } else {
-                ins.ev_site[e] = KD_EV_DROPPED; ins.ev_len[e] = 0; ins.ev_off[e] = po;
-            }
-            e += 1; po += n; q += len;
-        } else if (op == 4) {
-            if (k == 0) {
-                const kd_u64 g = cb + (kd_u64)r;
-                if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g], 1u);
-                q += len;
-            } else {  // regular: the last op that touches r
-                const int64_t x = r - 1;
-                const kd_u64 g = cb + (kd_u64)(x < 0 ? x + L + 1 : x);
-                if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
-            }
-        }
     }
 }
 

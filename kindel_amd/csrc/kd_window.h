@@ -62,7 +62,10 @@
 // 8 packed bases -> byte offsets of their channels inside a pair (4 * {A,T,G,C,N = 0..4; anything else = 5, the group's
 // bad slot}): rh = bases 0,2,4,6, rl = bases 1,3,5,7 (byte k = base 2k / 2k + 1).  Two 8-entry tables (bit 3 of the nibble
 // clear / set) looked up with v_perm_b32, a third v_perm selects per byte.
+// ROWS: v holds eight ROW SYMBOLS of an expanded long read (kd_long.h) -- the symbol IS the channel: two instructions.
+template <bool ROWS = false>
 __device__ __forceinline__ void kd_codes8(uint32_t v, uint32_t &rh, uint32_t &rl) {
+    if (ROWS) { rl = (v & 0x0f0f0f0fu) << 2; rh = (v >> 2) & 0x3c3c3c3cu; return; }
     const uint32_t TL_LO = 0x140c0014u, TL_HI = 0x14141408u;   // nibbles 0-7:  '=',A,C,M,G,R,S,V
     const uint32_t TH_LO = 0x14141404u, TH_HI = 0x10141414u;   // nibbles 8-15: T,W,Y,H,K,D,B,N
     const uint32_t tl = v & 0x07070707u, th = (v >> 4) & 0x07070707u;
@@ -77,13 +80,14 @@ __device__ __forceinline__ void kd_hadd(uint32_t *hist0, uint32_t ch, int32_t s)
 // all 8 bases of dword v are added; s0 = window-relative site of its first base, gb = byte offset of the channel group
 // (0 weights, 28 clip_start_weights, 52 clip_end_weights).  Even bases go through pointer h with add value vp, odd bases
 // through hq = h + (s0 & 1) pairs with vq: no per-base parity arithmetic; the pair of base b is an immediate offset.
+template <bool ROWS = false>
 __device__ __forceinline__ void kd_add8_full(uint32_t *hist0, uint32_t v, int32_t s0, uint32_t gb) {
     const int32_t p = s0 & 1;
     unsigned char *h = reinterpret_cast<unsigned char *>(hist0) + KD_MUL24S(s0 >> 1, KD_HPITCHB) + gb;
     unsigned char *hq = h + KD_HPITCHB * p;
     const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
     uint32_t rh, rl;
-    kd_codes8(v, rh, rl);
+    kd_codes8<ROWS>(v, rh, rl);
 #ifdef KD_EXP_PAIRADD
     const uint32_t jj = rh + rl;
 #pragma unroll
@@ -102,9 +106,10 @@ __device__ __forceinline__ void kd_add8_full(uint32_t *hist0, uint32_t v, int32_
 #endif
 }
 // only bases [blo, bhi) belong to the run
+template <bool ROWS = false>
 __device__ __forceinline__ void kd_add8_part(uint32_t *hist0, uint32_t v, int32_t s0, int32_t blo, int32_t bhi, uint32_t gb) {
     uint32_t rh, rl;
-    kd_codes8(v, rh, rl);
+    kd_codes8<ROWS>(v, rh, rl);
 #pragma unroll
     for (int b = 0; b < 8; b++)
         if (b >= blo && b < bhi) kd_hadd(hist0, (gb >> 2) + (((((b & 1) ? rl : rh) >> (8 * (b >> 1))) & 0xffu) >> 2), s0 + b);
@@ -112,11 +117,12 @@ __device__ __forceinline__ void kd_add8_part(uint32_t *hist0, uint32_t v, int32_
 // One memory dword of a run.  xs = query index of the dword's first base; [xa, xb) = the run's query bases that
 // fall inside the window (decides whether the dword is touched at all); [ra, rb) = the run's own query bases
 // (decides which of its 8 bases exist); site of base x is sx + x.
+template <bool ROWS = false>
 __device__ __forceinline__ void kd_add_dword(uint32_t *hist0, uint32_t v, int32_t xs, int32_t xa, int32_t xb,
                                              int32_t ra, int32_t rb, int32_t sx, uint32_t gb) {
     if (xs + 8 <= xa || xs >= xb) return;
-    if (xs >= ra && xs + 8 <= rb) kd_add8_full(hist0, v, sx + xs, gb);
-    else kd_add8_part(hist0, v, sx + xs, ra - xs, rb - xs, gb);
+    if (xs >= ra && xs + 8 <= rb) kd_add8_full<ROWS>(hist0, v, sx + xs, gb);
+    else kd_add8_part<ROWS>(hist0, v, sx + xs, ra - xs, rb - xs, gb);
 }
 
 // Bases of dword v whose bit is set in m (bit b = base b) are added; the others add 0 to a counter at most
@@ -349,7 +355,8 @@ __device__ __forceinline__ bool kd_walk_short(const KdReads &rd, kd_u64 i, const
 }
 
 // A PLAIN read: one M/=/X run covering the whole read, no clips (k_prep: KD_INFO_PLAIN).  Nothing to decode:
-// query base x lands on site grel + x, for x in [0, span).
+// query base x lands on site grel + x, for x in [0, span).  ROWS: the ROW of a long read (kd_long.h), symbol x on site grel + x.
+template <bool ROWS = false>
 __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi,
                                               int32_t Wh, uint32_t *hist0) {
     const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);
@@ -367,10 +374,10 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
         KdChunk n3 = n2;
         if (c + 3 <= cb) n3 = src[c + 3];
         const int32_t xs = 32 * c;
-        kd_add_dword(hist0, cur.x, xs, xa, xb, 0, len, grel, 0u);
-        kd_add_dword(hist0, cur.y, xs + 8, xa, xb, 0, len, grel, 0u);
-        kd_add_dword(hist0, cur.z, xs + 16, xa, xb, 0, len, grel, 0u);
-        kd_add_dword(hist0, cur.w, xs + 24, xa, xb, 0, len, grel, 0u);
+        kd_add_dword<ROWS>(hist0, cur.x, xs, xa, xb, 0, len, grel, 0u);
+        kd_add_dword<ROWS>(hist0, cur.y, xs + 8, xa, xb, 0, len, grel, 0u);
+        kd_add_dword<ROWS>(hist0, cur.z, xs + 16, xa, xb, 0, len, grel, 0u);
+        kd_add_dword<ROWS>(hist0, cur.w, xs + 24, xa, xb, 0, len, grel, 0u);
         cur = n1; n1 = n2; n2 = n3;
     }
 }
@@ -436,8 +443,9 @@ __device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const
 #ifndef KD_WINDOW_OCC
 #define KD_WINDOW_OCC 5
 #endif
+template <bool ROWS>
 __global__ void __launch_bounds__(KD_BLOCK, KD_WINDOW_OCC)   // 5 wavefronts per SIMD = the 5 workgroups per CU the LDS footprint allows
-k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *ckpt, const uint32_t *seg_read, KdTabs T,
+k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
          const kd_u64 *win_lo, const kd_u64 *win_hi, const kd_u64 *item_off, const uint32_t *item_win, kd_u64 items_cap, uint32_t w0,
          uint32_t W, uint32_t H, uint32_t Wh_, uint32_t slice, kd_u64 *status) {
     // OWNERSHIP (round 3).  The histogram of window w covers the sites [wlo, whi + H): H sites more than the window.  An entry
@@ -449,9 +457,11 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
     // the reach of a leading clip back into the windows in FRONT of its read's start window is tallied there over
     // [wlo, whi) ("late" entries).  The flush adds the H extra sites to the tables like the others: table counters are
     // sums of work items anyway.
-    // seg_read == NULL: `rinfo` describes the batch's reads (first pass, class REG = short regular reads).
-    // seg_read != NULL: `rinfo` describes SEGMENTS of long reads (k_prep_long; entry e = 256 * b + t is thread t's
-    // run of ops of the long read seg_read[b], entered through checkpoint ckpt[e]); `order` is then never NULL.
+    // ROWS = false: `rinfo` describes the batch's reads (first pass, class REG = short regular reads).
+    // ROWS = true (second pass): `rinfo` / rd.seq_off / rd.seq4 describe the ROWS of the batch's long reads (kd_long.h: one
+    // symbol per site, the symbol is the LDS channel; k_long_reduce's entries are PLAIN runs thousands of sites long); H = 0:
+    // every window tallies what lies inside it of every row that crosses it, on the plain walk; `order` is never NULL.
+    // LDS channels of a row pass: nothing (0), A,T,G,C,N (1-5), deleted (6), the same seven with an insertion in front (7-13).
     KD_DYN_SHARED(uint32_t, hist);
     const int32_t Wh = (int32_t)Wh_;   // dwords per channel row (two u16 counters each, halos included; >= (W + 2*KD_HALO)/2)
     uint32_t *hist0 = hist + (KD_HALO / 2) * KD_HPITCH;   // pair of window-relative site 0
@@ -507,7 +517,10 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
 #pragma unroll
             for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
                 const kd_u64 gs = p_gs[u], span = p_sc[u] >> KD_SPAN_SHIFT;
-                if ((p_sc[u] & 3u) == KD_CLS_REG) {
+                if (ROWS) {
+                    if ((p_sc[u] & 3u) == KD_CLS_REG && gs < whi && gs + span > wlo)
+                        l_plain[atomicAdd(&s_cnt[par][0], 1u)] = (uint16_t)(u * KD_BLOCK + t);
+                } else if ((p_sc[u] & 3u) == KD_CLS_REG) {
                     const uint32_t rel = u * KD_BLOCK + t;
                     if (gs >= wlo && gs < whi) {             // starts here: this window's own
                         if (!(p_sc[u] & KD_INFO_PLAIN)) l_cplx[atomicAdd(&s_cnt[par][2], 1u)] = (uint16_t)rel;
@@ -549,9 +562,11 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                 const uint32_t e = ((lane / KD_LANE_GROUP) * rows_i + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
                 if (e < ni) {
                     const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
-                    kd_walk_inner(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0);
+                    if (ROWS) kd_walk_plain<true>(rd, i, KD_RI(rinfo, rd, i), wlo, Wi, Wh, hist0);
+                    else kd_walk_inner(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0);
                 }
             }
+            if (!ROWS) {
             // (each list's rows start at the wavefront after the one that took the last row of the list before)
             for (uint32_t r = (wave + KD_WAVES_PER_BLOCK - rows_i % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK; r < rows_p;
                  r += KD_WAVES_PER_BLOCK) {
@@ -571,12 +586,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                     const KdRInfo ri = KD_RI(rinfo, rd, i);
                     const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);
                     const int32_t foot_end = grel + (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
-                    if (seg_read) {          // one segment of a long read
-                        const kd_u64 ir = seg_read[i / KD_BLOCK];
-                        const uint32_t nc = rd.n_cig[ir], per = (nc + KD_BLOCK - 1) / KD_BLOCK;
-                        const uint32_t k0 = (uint32_t)(i % KD_BLOCK) * per, k1 = k0 + per < nc ? k0 + per : nc;
-                        kd_walk_ops(rd, ir, nc, k0, k1, grel, (int32_t)ckpt[i].q, (int32_t)ri.lead, foot_end, We, Wh, hist0);
-                    } else if (!kd_walk_short(rd, i, ri, wlo, We, Wh, hist0)) {   // more than three segments: general walk
+                    if (!kd_walk_short(rd, i, ri, wlo, We, Wh, hist0)) {   // more than three segments: general walk
                         kd_walk_ops(rd, i, ri.pad >> 24, 0u, ri.pad >> 24, grel, 0, (int32_t)ri.lead, foot_end, We, Wh, hist0);
                     }
                 }
@@ -597,16 +607,10 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                     const int32_t Wx = (early && !shifted) ? We : Wi;
                     const int32_t grel = (int32_t)(ri.gstart - (uint32_t)org);
                     const int32_t foot_end = grel + (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
-                    if (seg_read) {
-                        const kd_u64 ir = seg_read[i / KD_BLOCK];
-                        const uint32_t nc = rd.n_cig[ir], per = (nc + KD_BLOCK - 1) / KD_BLOCK;
-                        const uint32_t k0 = (uint32_t)(i % KD_BLOCK) * per, k1 = k0 + per < nc ? k0 + per : nc;
-                        kd_walk_ops(rd, ir, nc, k0, k1, grel, (int32_t)ckpt[i].q, (int32_t)ri.lead, foot_end, Wx, Wh, h0);
-                    } else {
-                        kd_walk_ops(rd, i, ri.pad >> 24, 0u, ri.pad >> 24, grel, 0, (int32_t)ri.lead, foot_end, Wx, Wh, h0);
-                    }
+                    kd_walk_ops(rd, i, ri.pad >> 24, 0u, ri.pad >> 24, grel, 0, (int32_t)ri.lead, foot_end, Wx, Wh, h0);
                 }
             }
+            }   // !ROWS
             KD_MARK(c_cplx)
             __syncthreads();
             KD_MARK(c_wait)
@@ -616,9 +620,18 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
         // LDS channel -> table channel (KD_CH_*): weights 0-4, deletions 5, csw 6-10, cew 11-15; 0xff = bad slot
         bool bad = false;
         for (uint32_t ch = 0; ch < KD_HCH; ch++) {
-            const uint32_t tch = ch < 5 ? ch : ch == KD_HCH_DEL ? (uint32_t)KDC_DEL
-                               : (ch >= 7 && ch < 12) ? ch - 1 : (ch >= 13 && ch < 18) ? ch - 2 : 0xffu;
+            uint32_t tch, tch2 = 0xffu;
+            if (ROWS) {   // row symbols (kd_common.h): 0 nothing, 1-5 A,T,G,C,N, 6 deleted; 7-13 the same with an insertion in front
+                if (ch == KD_ROW_SKIP || ch > KD_ROW_DEL + KD_ROW_INS) continue;
+                const uint32_t sym = ch >= KD_ROW_INS ? ch - KD_ROW_INS : ch;
+                tch = sym == KD_ROW_SKIP ? (uint32_t)KDC_INS_TOTAL : sym == KD_ROW_DEL ? (uint32_t)KDC_DEL : sym - 1u;
+                if (ch >= KD_ROW_INS && sym != KD_ROW_SKIP) tch2 = KDC_INS_TOTAL;
+            } else {
+                tch = ch < 5 ? ch : ch == KD_HCH_DEL ? (uint32_t)KDC_DEL
+                    : (ch >= 7 && ch < 12) ? ch - 1 : (ch >= 13 && ch < 18) ? ch - 2 : 0xffu;
+            }
             uint32_t *row = T.tab + (kd_u64)(tch == 0xffu ? 0u : tch) * T.stride;
+            uint32_t *row2 = T.tab + (kd_u64)(tch2 == 0xffu ? 0u : tch2) * T.stride;
             for (uint32_t xw = t; xw < (uint32_t)Wh; xw += KD_BLOCK) {
                 const uint32_t v = hist[xw * KD_HPITCH + ch];
 #ifdef KD_EXP_NOFLUSH
@@ -632,6 +645,8 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                     // both sites of the word live: ONE 64-bit add on the two adjacent u32 counters (the low counter
                     // cannot carry into the high one: a u32 table counter never wraps)
                     atomicAdd(reinterpret_cast<kd_u64 *>(row + g0), (kd_u64)(v & 0xffffu) | ((kd_u64)(v >> 16) << 32));
+                    if (ROWS && tch2 != 0xffu)
+                        atomicAdd(reinterpret_cast<kd_u64 *>(row2 + g0), (kd_u64)(v & 0xffffu) | ((kd_u64)(v >> 16) << 32));
                     continue;
                 }
                 for (int hlf = 0; hlf < 2; hlf++) {
@@ -640,7 +655,10 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, const KdCkpt *
                     if (!cnt || sw2 < 0 || sw2 >= We) continue;
                     const kd_u64 g = wlo + (kd_u64)sw2;
                     if (tch == 0xffu) bad = true;
-                    else if (g < T.sites && kd_commit(T, g)) atomicAdd(&row[g], cnt);
+                    else if (g < T.sites && kd_commit(T, g)) {
+                        atomicAdd(&row[g], cnt);
+                        if (ROWS && tch2 != 0xffu) atomicAdd(&row2[g], cnt);
+                    }
                 }
             }
         }

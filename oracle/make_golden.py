@@ -213,6 +213,48 @@ def do_quirks(K):
     return out
 
 
+def do_long_quirks(K):
+    """oracle/quirk_cases.py: long_cases() (reads with > 16 CIGAR words) through the unmodified reference: digests of every
+    table, the insertion dicts, consensus and change codes -- and the oracle asserted equal on all of them."""
+    out = {}
+    for name, (sam, exc) in quirk_cases.long_cases().items():
+        with tempfile.NamedTemporaryFile("w", suffix=".sam", delete=False) as fh:
+            fh.write(sam)
+            path = fh.name
+        _, refs, recs = samio_py.read_alignment_file(path)
+        batch = samio_py.records_to_batch(refs, recs)
+        names = [n for n, _ in refs]
+        entry = {}
+        try:
+            alns = K.parse_bam(path)
+        except Exception as e:
+            entry["raises"] = type(e).__name__
+            assert exc is not None and type(e) is exc, (name, e)
+            try:
+                for cid in ko.contig_order(batch):
+                    ko.parse_records(batch, cid)
+                raise AssertionError(name + ": oracle did not raise")
+            except (KeyError, IndexError, RuntimeError) as oe:
+                assert type(oe).__name__ == entry["raises"], (name, oe, entry["raises"])
+            out[name] = entry
+            os.unlink(path)
+            continue
+        assert exc is None, name + " expected to raise"
+        contigs = []
+        for ref_id, aln in alns.items():
+            rec, tabs = aln_record(aln)
+            oa = ko.parse_records(batch, names.index(ref_id))
+            check_oracle(name + ":" + ref_id, oa, tabs)
+            s, ch = K.consensus_sequence(aln.weights, aln.insertions, aln.deletions, None, False, 1, False)
+            assert oa.consensus_sequence(None, False, 1, False) == (s, ch), name
+            rec.update(name=ref_id, consensus=s, changes=changes_str(ch))
+            contigs.append(rec)
+        entry["contigs"] = contigs
+        out[name] = entry
+        os.unlink(path)
+    return out
+
+
 def do_patch_cases(K):
     """consensus_sequence with cdr_patches (kindel.py:393-401) on a tiny table, incl. overlaps."""
     sam = quirk_cases.CASES["clip_both_ends_pair"]
@@ -299,6 +341,11 @@ def main():
         fx = do_fixtures(K)
         with open(os.path.join(GOLD, "reference_outputs.json"), "w") as fh:
             json.dump(fx, fh, indent=0, sort_keys=True)
+    if not only or "long" in only:
+        lq = do_long_quirks(K)
+        with open(os.path.join(GOLD, "long_quirks.json"), "w") as fh:
+            json.dump(lq, fh, indent=0, sort_keys=True)
+        print("long-read cases:", len(lq), "raising:", sum("raises" in v for v in lq.values()))
     if not only or "weights" in only:
         do_weights(K)
     if not only or "features" in only:

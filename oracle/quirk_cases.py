@@ -113,3 +113,80 @@ CASES = {
 
 #: option sets every non-error case is run with: (min_depth, trim_ends, uppercase)
 OPTION_SETS = [(1, False, False), (0, False, False), (2, False, False), (3, True, False), (1, True, True)]
+
+
+def long_cases():
+    """Hand-built reads with more than 16 CIGAR words (the long-read path, kd_long.h: tiles of 256 ops, rows, "+ins" symbols):
+    name -> (SAM text, expected exception or None).  Every case also holds a few ordinary reads over the same sites."""
+    import random
+    rng = random.Random(99)
+    L = 4000
+
+    def filler(n_ops, rr):
+        """n_ops ops alternating short M runs with I / D / N / P ops, ending on an M"""
+        ops = []
+        while len(ops) < n_ops - 1:
+            ops.append("%dM" % rr.randint(1, 9))
+            ops.append(rr.choice(["1I", "2I", "1D", "3D", "2N", "1P", "1I", "1D"]))
+        ops = ops[: n_ops - 1] + ["%dM" % rr.randint(1, 9)]
+        return ops
+
+    def qlen(ops):
+        return sum(int(o[:-1]) for o in ops if o[-1] in "MIS=X")
+
+    def sam_of(reads, extra_len=L):
+        txt = "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:c\tLN:%d\n" % extra_len
+        for n, (pos, ops, seq) in enumerate(reads):
+            txt += "r%d\t0\tc\t%d\t60\t%s\t*\t0\t0\t%s\t*\n" % (n, pos + 1, "".join(ops), seq)
+        return txt
+
+    def rseq(n, alphabet="ACGTN"):
+        return "".join(rng.choice(alphabet) for _ in range(n))
+
+    shorts = [(p, ["60M"], rseq(60)) for p in range(0, 900, 37)]
+    cases = {}
+
+    def add(name, pos, ops, exc=None, seq=None, shorts_=shorts, Lc=L):
+        cases[name] = (sam_of([(pos, ops, seq if seq is not None else rseq(qlen(ops)))] + list(shorts_), Lc), exc)
+
+    rr = random.Random(5)
+    add("ins_first_after_clip", 40, ["5S", "3I"] + filler(40, rr))
+    add("ins_first", 0, ["2I"] + filler(30, rr))
+    add("ends_on_ins", 100, filler(33, rr) + ["2I"])
+    add("ends_on_ins_then_clip", 100, filler(33, rr) + ["2I", "6S"])
+    add("two_ins_one_site_N", 50, filler(21, rr) + ["2I", "3N", "1I"] + filler(5, rr))
+    add("three_ins_one_site", 50, filler(21, rr) + ["2I", "1P", "1I", "0M", "3I"] + filler(5, rr))
+    add("two_ins_at_the_end", 50, filler(25, rr) + ["1I", "2P", "2I"])
+    add("two_ins_at_the_start", 7, ["1I", "1P", "2I"] + filler(25, rr))
+    add("long_runs", 10, filler(9, rr) + ["300M", "100D", "17M", "64D", "8M", "1I", "8M", "1D", "16M"] + filler(9, rr))
+    for n_ops in (17, 255, 256, 257, 511, 512, 513, 1025):
+        add("ops_%d" % n_ops, 3, filler(n_ops, random.Random(n_ops)))
+    # one tile (64 ops) consumes more query bases than k_long_expand copies into LDS (8192): the fetches go to memory
+    add("runs_longer_than_the_copy", 5, ["700M", "1I", "650M", "2D"] * 7 + ["5M"] + filler(9, rr), Lc=12000)
+    add("tile_of_insertions", 20, ["5M"] + ["1I", "1P"] * 300 + ["9M"] + filler(7, rr))
+    add("clips_both_ends", 300, ["200S"] + filler(41, rr) + ["150S"])
+    add("leading_clip_over_the_contig_start", 30, ["100S"] + filler(41, rr))
+    ops = filler(35, rr)
+    foot = sum(int(o[:-1]) for o in ops if o[-1] in "MD")
+    add("ends_on_the_last_site_then_ins", L - foot, ops + ["3I"])
+    add("trailing_clip_over_the_contig_end", L - foot, ops + ["40S"])
+    # bad bases: the reference raises KeyError (a base outside A,C,G,T,N inside an aligned or clipped segment)
+    ops = filler(41, rr)
+    s = rseq(qlen(ops), "ACGT")
+    add("bad_base_aligned", 60, ops, KeyError, s[:70] + "R" + s[71:])
+    ops = ["30S"] + filler(41, rr)
+    s = rseq(qlen(ops), "ACGT")
+    add("bad_base_in_leading_clip", 200, ops, KeyError, s[:12] + "Y" + s[13:])
+    ops = filler(41, rr) + ["30S"]
+    s = rseq(qlen(ops), "ACGT")
+    add("bad_base_in_trailing_clip", 200, ops, KeyError, s[:-5] + "K" + s[-4:])
+    ops = filler(41, rr)
+    s = rseq(qlen(ops), "ACGT")
+    qi = 0
+    for o in ops:                       # a bad base inside an INSERTION is kept verbatim by the reference: no error
+        if o[-1] == "I":
+            break
+        if o[-1] in "M":
+            qi += int(o[:-1])
+    add("odd_base_inside_an_insertion_is_fine", 60, ops, None, s[:qi] + "N" + s[qi + 1:])
+    return cases

@@ -154,6 +154,7 @@ static inline unsigned long long kd_shfl_up64(unsigned long long v, unsigned d) 
 static inline uint32_t kd_shfl_xor(uint32_t v, unsigned m) { return (uint32_t)emu_exchange(v, (threadIdx.x & 63u) ^ m); }
 static inline uint32_t kd_readfirstlane(uint32_t v) { return (uint32_t)emu_exchange(v, 0); }
 static inline unsigned long long kd_readfirstlane64(unsigned long long v) { return emu_exchange(v, 0); }
+static inline uint32_t kd_readlane(uint32_t v, unsigned src_lane) { return (uint32_t)emu_exchange(v, src_lane); }
 static inline int kd_popcll(unsigned long long m) { return __builtin_popcountll(m); }
 static inline uint32_t kd_wave_or(uint32_t v) {
     unsigned long long *scratch = emu_ctx->wscratch[threadIdx.x / 64];
@@ -161,6 +162,24 @@ static inline uint32_t kd_wave_or(uint32_t v) {
     emu_wave_meet();
     uint32_t r = 0;
     for (unsigned l = 0; l < 64; l++) r |= (uint32_t)scratch[l];
+    emu_wave_meet();
+    return r;
+}
+static inline uint32_t kd_wave_scan_add(uint32_t v) {   // inclusive prefix sum over the wavefront's lanes
+    unsigned long long *scratch = emu_ctx->wscratch[threadIdx.x / 64];
+    scratch[threadIdx.x & 63u] = v;
+    emu_wave_meet();
+    uint32_t r = 0;
+    for (unsigned l = 0; l <= (threadIdx.x & 63u); l++) r += (uint32_t)scratch[l];
+    emu_wave_meet();
+    return r;
+}
+static inline uint32_t kd_wave_scan_max(uint32_t v) {   // running maximum over the wavefront's lanes (inclusive)
+    unsigned long long *scratch = emu_ctx->wscratch[threadIdx.x / 64];
+    scratch[threadIdx.x & 63u] = v;
+    emu_wave_meet();
+    uint32_t r = 0;
+    for (unsigned l = 0; l <= (threadIdx.x & 63u); l++) r = std::max(r, (uint32_t)scratch[l]);
     emu_wave_meet();
     return r;
 }

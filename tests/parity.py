@@ -272,3 +272,35 @@ def check_as_shards(lib, host, world, dev="cpu", tb=None, window=0):
         tot_w += int(t[0:5].sum())
     assert tot_w > 0
     return ivs
+
+
+def long_read_cases():
+    """name -> (SAM text, expected exception or None): oracle/quirk_cases.py: long_cases(), pinned against the unmodified
+    reference in tests/golden/long_quirks.json (oracle/make_golden.py long)"""
+    from oracle import quirk_cases
+    return quirk_cases.long_cases()
+
+
+def golden_long_quirks():
+    with open(os.path.join(GOLD, "long_quirks.json")) as fh:
+        return json.load(fh)
+
+
+def assert_matches_long_golden(run, entry, what=""):
+    """engine output == what the unmodified reference returned for the case (digests, oracle/make_golden.py: do_long_quirks)"""
+    names = [str(x) for x in run.batch["contig_names"]]
+    for rec in entry["contigs"]:
+        cid = names.index(rec["name"])
+        t, L = run.tables[cid], rec["L"]
+        tag = "%s %s: " % (what, rec["name"])
+        g = rec["sha"]
+        assert sha(np.ascontiguousarray(t[0:5, :L].T)) == g["weights"], tag + "weights"
+        assert sha(t[5]) == g["deletions"], tag + "deletions"
+        assert sha(np.ascontiguousarray(t[6:11, :L].T)) == g["clip_start_weights"], tag + "clip_start_weights"
+        assert sha(np.ascontiguousarray(t[11:16, :L].T)) == g["clip_end_weights"], tag + "clip_end_weights"
+        assert sha(t[16]) == g["clip_starts"] and sha(t[17]) == g["clip_ends"], tag + "clip_starts / clip_ends"
+        assert ins_digest(run.ins[cid]) == g["insertions"], tag + "insertion dicts"
+        assert int(t[18].sum()) == rec["sums"]["ins_events"], tag + "insertion totals"
+        seq, ch, _, _ = run.cns[cid]
+        assert seq.decode() == rec["consensus"], tag + "consensus"
+        assert changes_str(ch) == rec["changes"], tag + "changes"

@@ -141,6 +141,27 @@ def test_megabase_read_with_a_short_cigar_takes_the_general_path(emu_lib):
     P.assert_matches_oracle(run)
 
 
+LONG_CASES = P.long_read_cases()
+LONG_GOLD = P.golden_long_quirks()
+
+
+@pytest.mark.parametrize("mode", [N.KD_MODE_AUTO, N.KD_MODE_GLOBAL])
+@pytest.mark.parametrize("name", sorted(LONG_CASES))
+def test_long_read_case(emu_lib, name, mode):
+    """kd_long.h: rows, "+ins" symbols, duplicates on one site, tile boundaries, clips, bad bases -- vs the oracle"""
+    sam, exc = LONG_CASES[name]
+    batch = P.sam_to_batch(sam)
+    if exc:
+        with pytest.raises(exc):
+            P.Run(emu_lib, batch, mode=mode, window=64)
+        return
+    for window, sl in ((64, 0), (448, 16)):
+        run = P.Run(emu_lib, batch, mode=mode, window=window, slice_reads=sl)
+        assert run.info["long_cigar"] >= 1
+        P.assert_matches_oracle(run, what=name)
+        P.assert_matches_long_golden(run, LONG_GOLD[name], what=name)     # what the unmodified reference returned
+
+
 def test_synthetic_long_reads(emu_lib):
     batch = synth.to_numpy(synth.long_reads([30000], 4, seed=6, median_len=3000, min_len=1000, max_len=6000))
     run = P.Run(emu_lib, batch, window=1024)

@@ -323,6 +323,28 @@ def test_profile_modes(hip_lib):
         eng.close()
 
 
+LONG_CASES = P.long_read_cases()
+LONG_GOLD = P.golden_long_quirks()
+
+
+@pytest.mark.parametrize("mode", [N.KD_MODE_AUTO, N.KD_MODE_GLOBAL])
+@pytest.mark.parametrize("name", sorted(LONG_CASES))
+def test_long_read_case(hip_lib, name, mode):
+    """kd_long.h on the GPU: rows, "+ins" symbols, several insertions on one site, tile boundaries, clips, bad bases --
+    against the oracle and against what the unmodified reference returned (tests/golden/long_quirks.json)"""
+    sam, exc = LONG_CASES[name]
+    batch = P.sam_to_batch(sam)
+    if exc:
+        with pytest.raises(exc):
+            P.Run(hip_lib, batch, mode=mode, window=64)
+        return
+    for window, sl in ((64, 0), (448, 16)):
+        run = P.Run(hip_lib, batch, mode=mode, window=window, slice_reads=sl)
+        assert run.info["long_cigar"] >= 1
+        P.assert_matches_oracle(run, what=name)
+        P.assert_matches_long_golden(run, LONG_GOLD[name], what=name)
+
+
 def test_virtual_shards_with_long_reads(hip_lib):
     """Interval shards + the long-read segment pass (second k_window launch) on the GPU."""
     batch = synth.to_numpy(synth.long_reads([120_000], 12, seed=12, median_len=6000, min_len=1500, max_len=15000))
