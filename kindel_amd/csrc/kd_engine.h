@@ -297,6 +297,7 @@ struct KdEngine {
             if (step_mode == STEP_RECORD) step_status.push_back(h_status);
         }
         const uint64_t n_long = h_status[KDS_B_N_LONG];
+        const uint64_t n_reg_short = h_status[KDS_B_N_REG];   // (k_long_reduce adds the regular long reads: their rows are the second pass)
         if (n_long) {
             // long-CIGAR reads (kd_long.h): validated one workgroup each, slots / rows handed out, then expanded into rows
             if ((rc = ensure(b_rowinfo, (size_t)n_long * sizeof(KdRInfo))) || (rc = ensure(b_rowoff, (size_t)n_long * 8)) ||
@@ -521,7 +522,8 @@ struct KdEngine {
                     return hipfail("k_strip");
                 return KD_OK;
             };
-            if (mode == KD_MODE_STRIP) rc = strip_pass((const KdRInfo *)rinfo, n, sorted_input);
+            if (!n_reg_short) rc = KD_OK;      // (a batch of long reads only: nothing for the first pass)
+            else if (mode == KD_MODE_STRIP) rc = strip_pass((const KdRInfo *)rinfo, n, sorted_input);
             else rc = window_pass((const KdRInfo *)rinfo, n, sorted_input, false, (uint32_t)KDS_B_MAXSPAN, W_first, coop);
             if (rc) return rc;
             if (n_long && h_status[KDS_B_MAXSEGSPAN] &&

@@ -76,11 +76,12 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
     bool bad = false, cold = false;
     uint32_t first_nfs = 0xffffffffu, last_rel = 0;
     int64_t c_r = pos0, c_q = 0;      // coordinates in front of the tile
-    uint32_t w_nxt = lane < nc ? cg[lane] : 15u;      // (op 15, length 0: moves nothing)
+    uint32_t w_nxt = lane < nc ? cg[lane] : 15u, w_nxt2 = lane + KD_WAVE < nc ? cg[lane + KD_WAVE] : 15u;      // (op 15, length 0: moves nothing)
     for (uint32_t base = 0; base < nc; base += KD_WAVE) {
         const uint32_t k = base + lane;
         const uint32_t w = w_nxt;
-        { const uint32_t kn = k + KD_WAVE; w_nxt = kn < nc ? cg[kn] : 15u; }   // the next tile's words are in flight during this one
+        w_nxt = w_nxt2;
+        { const uint32_t kn = k + 2u * KD_WAVE; w_nxt2 = kn < nc ? cg[kn] : 15u; }   // the words two tiles ahead are in flight during this one
         const KdAdv adv = kd_op_advance(w, k);
         const uint32_t ra = adv.r, qa = adv.q;
         const uint32_t ir = kd_wave_scan_add(ra), iq = kd_wave_scan_add(qa);
@@ -251,13 +252,13 @@ __device__ __forceinline__ uint32_t kd_zero_nibbles(uint32_t x) {
 //   * lane = op: start coordinates from DPP scans; an I op writes its insertion event into the read's reserved slots
 //     (neighbouring ops -> neighbouring slots); the query bases the tile consumes are copied into LDS;
 //   * the row is written PIECE by piece.  A piece is what ONE op contributes to ONE row dword (8 sites): an M / D run of n
-//     sites cut at the dword boundaries; an I op is a piece of its own that only sets the "+ins" flag of the site it sits
-//     in front of.  An op knows how many pieces it has (the dwords it touches); a DPP scan numbers the tile's pieces; 64
+//     sites cut at the dword boundaries (an insertion in front of a run sets the "+ins" flag of the run's first site in
+//     the run's first piece; the slot behind the last site is a piece too).  An op knows how many pieces it has (the dwords it touches); a DPP scan numbers the tile's pieces; 64
 //     pieces at a time, lane = piece: the piece -> op table is the ops' own scatter of their first piece + a running
 //     maximum (no search), the piece's 8 symbols are one fetch from the copy + one table look-up (kd_rowcodes8), OR-ed into
 //     the chunk's dwords in LDS.  Pieces are in site order, so a chunk's dwords are consecutive and only its last one can
 //     continue in the next chunk (or tile): it is carried.  Every lane does the same amount of work whatever the CIGAR looks
-//     like -- a 5000-base M run is 625 pieces on 625 lanes, a run of 1-base indels a piece each.  (One lane per row dword,
+//     like -- a 5000-base M run is 625 pieces on 625 lanes, a run of 1-base deletions a piece each.  (One lane per row dword,
 //     walking the ops that cover it, diverged on the op count: 110 lane-instructions per site, 0.9 of this kernel's 1.2 ms.)
 //   * a second insertion at the SAME site of one read (I ops with nothing but N / P between them) cannot be a flag: it is
 //     added to ins_total directly.
@@ -303,11 +304,14 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
     // the row dword under construction: carried from chunk to chunk, tile to tile
     uint32_t cj = 0xffffffffu, cval = 0, cins = 0;
 #define KD_ROW_FINISH(v, ib) ((((v) + (ib) * KD_ROW_INS) & 0x0f0f0f0fu) << 4 | ((((v) + (ib) * KD_ROW_INS) >> 4) & 0x0f0f0f0fu))   /* "+ins" twins, BAM nibble order */
-    uint32_t w_nxt = lane < nc ? cg[lane] : 15u;
+    // (CIGAR words two tiles ahead, the first 256 bytes of the next tile's query bases one tile ahead: in flight while a tile is worked on)
+    uint32_t w_nxt = lane < nc ? cg[lane] : 15u, w_nxt2 = lane + KD_WAVE < nc ? cg[lane + KD_WAVE] : 15u;
+    uint32_t sq_pre = 4u * lane < (uint32_t)((sl + 1) >> 1) + 8u ? reinterpret_cast<const KdU32u *>(seq + 4u * lane)->v : 0u;
     for (uint32_t base = 0; base <= nc; base += KD_WAVE) {   // (<=: the terminator behind the last op is a piece too)
         const uint32_t k = base + lane;
         const uint32_t w = w_nxt;
-        { const uint32_t kn = k + KD_WAVE; w_nxt = kn < nc ? cg[kn] : 15u; }
+        w_nxt = w_nxt2;
+        { const uint32_t kn = k + 2u * KD_WAVE; w_nxt2 = kn < nc ? cg[kn] : 15u; }
         const uint32_t len = w >> 4, op = w & 15u;
         const KdAdv adv = kd_op_advance(w, k);
         const uint32_t ra = adv.r, qa = adv.q;
@@ -316,30 +320,37 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
         const uint32_t tot_q = kd_readlane(iq, KD_WAVE - 1);
         // pieces: an M / D run touches the dwords of its first to its last site; an I op and the terminator are one each
         const bool is_run = ra != 0, is_ins = op == 1 && k < nc;
-        bool dup = false;
+        bool dup = false, insf = false;        // insf: an insertion sits in front of this run's first site (or of the terminator)
         if (has_ins) {   // (wave-uniform) a second I op on the same site: the nearest I op before it has the same r
             const uint32_t m = kd_wave_scan_max(is_ins ? r_op + 1u : 0u);
             uint32_t prev = kd_shfl_up(m, 1u);
             if (lane == 0) prev = 0;
             prev = prev > last_ins ? prev : last_ins;
             dup = is_ins && prev == r_op + 1u;
+            insf = (is_run || k == nc) && prev == r_op + 1u;
             const uint32_t tile_last = kd_readlane(m, KD_WAVE - 1);
             last_ins = tile_last > last_ins ? tile_last : last_ins;
         }
-        const uint32_t cnt = is_run ? ((r_op + ra - 1u) >> 3) - (r_op >> 3) + 1u : ((is_ins && !dup) || k == nc) ? 1u : 0u;
+        const uint32_t cnt = is_run ? ((r_op + ra - 1u) >> 3) - (r_op >> 3) + 1u : k == nc ? 1u : 0u;
         const uint32_t ipb = kd_wave_scan_add(cnt);
         const uint32_t n_pieces = kd_readlane(ipb, KD_WAVE - 1);
         KD_WAVE_SYNC();                        // (the last tile's pieces are done with the arrays)
-        s_r[lane] = r_op; s_q[lane] = q_op; s_w[lane] = w; s_pb[lane] = ipb - cnt;
+        s_r[lane] = r_op; s_q[lane] = q_op; s_w[lane] = w; s_pb[lane] = (ipb - cnt) | (insf ? 0x80000000u : 0u);
         // the query bases of the tile (+ the 8-base fetch window): copied when they fit
         const uint32_t qb = c_q & ~7u;                                      // first copied base: a dword boundary of the read's bytes
         uint32_t q_end = c_q + tot_q;
         q_end = (int64_t)q_end < sl ? q_end : (uint32_t)sl;
         const uint32_t need = q_end > qb ? ((q_end - qb + 1u) >> 1) + 8u : 0u;   // bytes
         const bool staged = need <= KD_LONG_SEQ_LDS;
-        if (staged)
-            for (uint32_t o = 4u * lane; o < need; o += 4u * KD_WAVE)
+        if (staged) {
+            s_seq[lane] = sq_pre;              // bytes 0 .. 255 of the copy were requested a tile ago
+            for (uint32_t o = 4u * (KD_WAVE + lane); o < need; o += 4u * KD_WAVE)
                 s_seq[o >> 2] = reinterpret_cast<const KdU32u *>(seq + (qb >> 1) + o)->v;
+        }
+        {   // the next tile's copy starts at the dword of its first base
+            const uint32_t ob = ((c_q + tot_q) & ~7u) >> 1;
+            sq_pre = ob + 4u * lane < (uint32_t)((sl + 1) >> 1) + 8u ? reinterpret_cast<const KdU32u *>(seq + ob + 4u * lane)->v : 0u;
+        }
         KD_WAVE_SYNC();                        // the tile's arrays are written
         if (has_ins) {   // (wave-uniform) event / pool slots of the tile's I ops
             uint32_t ni = 0, nb = 0;
@@ -404,7 +415,8 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
             const uint32_t ko = oi - 1u;       // (a live piece always has its op: piece 0 starts one)
             uint32_t j = 0, val = 0, ib = 0;
             if (live) {
-                const uint32_t r_k = s_r[ko], w_k = s_w[ko], idx = p - s_pb[ko];
+                const uint32_t r_k = s_r[ko], w_k = s_w[ko], pbf = s_pb[ko], idx = p - (pbf & 0x7fffffffu);
+                if (idx == 0 && (pbf >> 31)) ib = 1u << (4u * (r_k & 7u));   // "+ins" flag of the run's first site
                 const uint32_t ln = w_k >> 4, o = w_k & 15u;
                 j = (r_k >> 3) + idx;
                 if (o == 0 || o == 7 || o == 8 || o == 2) {
@@ -418,8 +430,6 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
                         if (kd_zero_nibbles(sym) & msk) bad = true;     // a base outside A,C,G,T,N (KeyError in the reference)
                     }
                     val = (sym & msk) << (4u * ps);
-                } else if (o == 1 && base + ko < nc) {
-                    ib = 1u << (4u * (r_k & 7u));          // "+ins" flag of the site it sits in front of
                 }                                           // (else: the terminator: the slot behind the last site exists)
             }
             const uint32_t jf = kd_readfirstlane(j);

@@ -382,6 +382,42 @@ __device__ __forceinline__ void kd_walk_plain(const KdReads &rd, kd_u64 i, const
     }
 }
 
+// The ROW of a long read (kd_long.h) against the window: symbol x on site grel + x, one plain run thousands of sites long.
+// Every row of the wavefront covers the whole window, so lanes walking in step would all add to the same few counters in every
+// instruction (same-address LDS atomics serialise: 53 ns per instruction with 64 lanes on one address,
+// profiles/valu_issue_calibration.json).  Lane `rot` therefore starts at chunk (rot mod chunks) of the window's part of its
+// row, at dword (rot / chunks) mod 4 of every chunk, and wraps around: the lanes of a wavefront sit on different sites.
+__device__ __forceinline__ void kd_walk_row(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi, uint32_t rot,
+                                            uint32_t *hist0) {
+    const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);
+    const int32_t len = (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
+    const int32_t xa = grel < 0 ? -grel : 0;
+    const int32_t xb = Wi - grel < len ? Wi - grel : len;
+    if (xb <= xa) return;
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(KD_SEQ_AT(rd, i));
+    const int32_t ca = xa >> 5, n = ((xb - 1) >> 5) - ca + 1;
+    int32_t cpos = (int32_t)(rot % (uint32_t)n);
+    const uint32_t o = (rot / (uint32_t)n) & 3u;
+    KdChunk cur = src[ca + cpos];
+    for (int32_t t = 0; t < n; t++) {
+        const int32_t c = ca + cpos;
+        cpos = cpos + 1 < n ? cpos + 1 : 0;
+        KdChunk nxt = cur;
+        if (t + 1 < n) nxt = src[ca + cpos];
+        // the chunk's four dwords, starting at dword o
+        const uint32_t d0 = o == 0 ? cur.x : o == 1 ? cur.y : o == 2 ? cur.z : cur.w;
+        const uint32_t d1 = o == 0 ? cur.y : o == 1 ? cur.z : o == 2 ? cur.w : cur.x;
+        const uint32_t d2 = o == 0 ? cur.z : o == 1 ? cur.w : o == 2 ? cur.x : cur.y;
+        const uint32_t d3 = o == 0 ? cur.w : o == 1 ? cur.x : o == 2 ? cur.y : cur.z;
+        const int32_t xs = 32 * c;
+        kd_add_dword<true>(hist0, d0, xs + 8 * (int32_t)(o & 3u), xa, xb, 0, len, grel, 0u);
+        kd_add_dword<true>(hist0, d1, xs + 8 * (int32_t)((o + 1u) & 3u), xa, xb, 0, len, grel, 0u);
+        kd_add_dword<true>(hist0, d2, xs + 8 * (int32_t)((o + 2u) & 3u), xa, xb, 0, len, grel, 0u);
+        kd_add_dword<true>(hist0, d3, xs + 8 * (int32_t)((o + 3u) & 3u), xa, xb, 0, len, grel, 0u);
+        cur = nxt;
+    }
+}
+
 // The 8 bases of dword v through precomputed pointers (h: pair of the dword's first base + channel group, hq = h + one pair if
 // that base sits on an odd site) and add values: what kd_add8_full does after its address arithmetic.
 __device__ __forceinline__ void kd_add8_ptr(unsigned char *h, unsigned char *hq, uint32_t v, uint32_t vp, uint32_t vq) {
@@ -478,6 +514,9 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
     const int32_t Wi = (int32_t)W, We = (int32_t)(W + H);     // the window / the histogram's reach, in sites
     uint32_t *hist_early = hist0 + (H / 2) * KD_HPITCH;       // pair of site wlo + H: origin of the early entries' walk (H is even)
 #ifdef KD_PHASE_CLOCKS
+#ifndef KD_PHASE_CLOCKS_ROWS_ONLY
+#define KD_PHASE_CLOCKS_ROWS_ONLY 0   // 1: only the row pass (k_window<true>) adds its clocks
+#endif
     long long c_zero = 0, c_cls = 0, c_plain = 0, c_cplx = 0, c_wait = 0, c_flush = 0, c_deq = 0, c_mark;
 #define KD_MARK(acc) { const long long n_ = clock64(); acc += n_ - c_mark; c_mark = n_; }
     c_mark = clock64();
@@ -562,7 +601,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
                 const uint32_t e = ((lane / KD_LANE_GROUP) * rows_i + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
                 if (e < ni) {
                     const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
-                    if (ROWS) kd_walk_plain<true>(rd, i, KD_RI(rinfo, rd, i), wlo, Wi, Wh, hist0);
+                    if (ROWS) kd_walk_row(rd, i, KD_RI(rinfo, rd, i), wlo, Wi, lane + 17u * r, hist0);
                     else kd_walk_inner(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0);
                 }
             }
@@ -669,7 +708,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
         KD_MARK(c_wait)
     }
 #ifdef KD_PHASE_CLOCKS
-    if ((t & 63u) == 0) {   // lane 0 of every wavefront
+    if ((t & 63u) == 0 && (ROWS || !KD_PHASE_CLOCKS_ROWS_ONLY)) {   // lane 0 of every wavefront
         atomicAdd(&status[KDS_DBG0], (kd_u64)c_deq); atomicAdd(&status[KDS_DBG1], (kd_u64)c_zero);
         atomicAdd(&status[KDS_DBG2], (kd_u64)c_cls); atomicAdd(&status[KDS_DBG3], (kd_u64)c_plain);
         atomicAdd(&status[KDS_DBG4], (kd_u64)c_cplx); atomicAdd(&status[KDS_DBG5], (kd_u64)c_wait);
