@@ -20,58 +20,57 @@
 
 // result of scanning one CIGAR
 struct KdScan {
-    uint32_t cls, cold, lead;
-    kd_u64 span, n_ins, ins_bases, aligned, walked;
+    uint32_t cls, cold, lead, n_ins, ins_bases;
+    kd_u64 span, aligned, walked;
 };
 
-// Serial scan of ops [0, nc) of a read; shared by k_prep (short CIGARs) and k_diagnose-free
-// paths.  "Regular" means: k_window / the COLD pass can process the read with plain
-// G-space arithmetic and no Python wrap-around or exception can occur (bad bases aside).
-// `pre` = the first 4 CIGAR words, already in registers (loaded together with those of other reads), or NULL
-__device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc, int64_t pos0, int64_t sl, int64_t L,
-                                                const uint32_t *pre = nullptr) {
+// Serial scan of ops [0, nc) of a read with at most KD_PREP_MAX_OPS words.  "Regular" means: k_window / the COLD pass can
+// process the read with plain G-space arithmetic and no Python wrap-around or exception can occur (bad bases aside).
+// `pre` = the first 4 CIGAR words, already in registers (loaded together with those of other reads).
+// The rules are those of kindel.py:40-81 seen from the cursors; the arithmetic is branch-free per op (the lanes of a
+// wavefront hold different op kinds: a branch per kind runs every branch; round 2's version did that in 64-bit integers
+// throughout, 410 lane-instructions per read) and 32-bit but for one value:
+//   rem  sites left between the reference cursor and the contig's end (L - r; 64-bit, may be negative): every rule about r
+//        is a comparison against it;
+//   q    query cursor CLAMPED to the read length (qc = min(q, sl)) + `over` (q > sl): what min(q, sl), q + len > sl and
+//        sl - q need, exact for any length (an irregular read's insertion slots are reserved from these counts).
+__device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc, int32_t pos0, uint32_t sl, uint32_t L,
+                                                const uint32_t *pre) {
     KdScan s;
-    s.cls = KD_CLS_REG; s.cold = 0; s.lead = 0; s.span = 0; s.n_ins = 0; s.ins_bases = 0; s.aligned = 0; s.walked = 0;
-    bool regular = pos0 >= 0;
-    bool seen_nfs = false;  // a non-first S was seen: r is no longer plain prefix arithmetic
-    int64_t r = pos0, q = 0, hot_hi = pos0;
+    s.cold = 0; s.lead = 0; s.n_ins = 0; s.ins_bases = 0; s.aligned = 0; s.walked = 0;
+    const int64_t rem0 = (int64_t)L - (int64_t)pos0;
+    int64_t rem = rem0, rem_hot = rem0;          // rem_hot: rem behind the last op that wrote (M, D, non-first S)
+    bool regular = pos0 >= 0, seen_nfs = false, over = false;
+    uint32_t qc = 0;
     for (uint32_t k = 0; k < nc; k++) {
-        const uint32_t c = (pre && k < 4) ? (k == 0 ? pre[0] : k == 1 ? pre[1] : k == 2 ? pre[2] : pre[3]) : cg[k];
-        const int64_t len = c >> 4;
-        const uint32_t op = c & 15u;
-        if (op == 0 || op == 7 || op == 8) {  // M = X
-            if (seen_nfs || r + len > L || q + len > sl) regular = false;
-            r += len; q += len; hot_hi = r;
-            s.aligned += (kd_u64)len; s.walked += (kd_u64)len;
-        } else if (op == 1) {  // I
-            s.cold = KD_INFO_COLD;
-            if (seen_nfs || r > L) regular = false;
-            int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
-            s.n_ins += 1; s.ins_bases += (kd_u64)(q1 - q0);
-            q += len; s.walked += (kd_u64)len;
-        } else if (op == 2) {  // D
-            if (seen_nfs || r + len > L + 1) regular = false;
-            r += len; hot_hi = r;
-            s.walked += (kd_u64)len;
-        } else if (op == 4) {  // S
-            s.cold = KD_INFO_COLD;
-            s.walked += (kd_u64)len;
-            if (k == 0) {
-                if (r > L || len > sl) regular = false;
-                s.lead = (uint32_t)(len < r ? len : (r > 0 ? r : 0));
-                q += len;
-            } else {
-                if (seen_nfs || r - 1 > L) regular = false;   // clip_starts[r - 1] must exist (kindel.py:75)
-                seen_nfs = true;
-                int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
-                if (n_adv > sl - q || (len > n_adv && q + n_adv >= sl)) regular = false;
-                r += n_adv; q += n_adv;
-                hot_hi = r;  // the clip_start_weights writes extend the read's footprint
-            }
-        }
+        const uint32_t c = k < 4 ? (k == 0 ? pre[0] : k == 1 ? pre[1] : k == 2 ? pre[2] : pre[3]) : cg[k];
+        const uint32_t len = c >> 4, op = c & 15u;
+        const bool m = (0x181u >> op) & 1u, i_ = op == 1, d = op == 2, sc = op == 4, sf = sc && k == 0, sn = sc && k != 0;
+        const uint32_t room = sl - qc;                          // query bases left (qc <= sl)
+        // non-first clip: sites it advances over (kindel.py:74-81): min(len, L - r) while r < L
+        const uint32_t n_adv = rem > 0 ? ((int64_t)len < rem ? len : (uint32_t)rem) : 0u;
+        bool irr = seen_nfs && (m || i_ || d || sn);
+        irr = irr || (m && ((int64_t)len > rem || over || len > room));            // r + len > L, q + len > sl
+        irr = irr || (i_ && rem < 0);                                               // r > L
+        irr = irr || (d && (int64_t)len > rem + 1);                                 // r + len > L + 1
+        irr = irr || (sf && (rem < 0 || len > sl));
+        irr = irr || (sn && (rem < -1 || over || n_adv > room || (len > n_adv && n_adv >= room)));   // clip_starts[r - 1]; q + n_adv vs sl
+        regular = regular && !irr;
+        if (m) s.aligned += len;
+        if (m || i_ || d || sc) s.walked += len;
+        if (i_) { s.n_ins++; s.ins_bases += over ? 0u : (len < room ? len : room); }   // min(q + len, sl) - min(q, sl)
+        if (i_ || sc) s.cold = KD_INFO_COLD;
+        if (sf) s.lead = (uint32_t)(pos0 > 0 ? ((int64_t)len < (int64_t)pos0 ? (int32_t)len : pos0) : 0);
+        const uint32_t radv = (m || d) ? len : sn ? n_adv : 0u;
+        const uint32_t qadv = (m || i_ || sf) ? len : sn ? n_adv : 0u;
+        rem -= (int64_t)radv;
+        over = over || qadv > room;
+        qc = over ? sl : qc + qadv;
+        if (m || d || sn) rem_hot = rem;
+        seen_nfs = seen_nfs || sn;
     }
-    if (!regular) s.cls = KD_CLS_IRREG;
-    s.span = hot_hi > pos0 ? (kd_u64)(hot_hi - pos0) : 0;
+    s.cls = regular ? KD_CLS_REG : KD_CLS_IRREG;
+    s.span = (kd_u64)(rem0 - rem_hot);           // sites from pos0 to the end of the last write
     return s;
 }
 
@@ -170,7 +169,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
                 cls = KD_CLS_LONG;
                 a_reads++;
             } else {
-                KdScan s = kd_scan_cigar(rd.cigar + v_coff[u], nc, pos0, sl, L_cached, v_cw[u]);
+                KdScan s = kd_scan_cigar(rd.cigar + v_coff[u], nc, (int32_t)pos0, (uint32_t)sl, (uint32_t)L_cached, v_cw[u]);
                 cls = s.cls; cold = s.cold; span = s.span; lead = s.lead; has_ins = s.n_ins != 0; al = s.aligned;
                 n_ins_r = s.n_ins; n_insb_r = s.ins_bases;
                 a_reads++; a_aligned += s.aligned; a_walked += s.walked; a_ins += s.n_ins; a_insb += s.ins_bases;

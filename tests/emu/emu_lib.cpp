@@ -53,3 +53,15 @@ struct EmuRt {
 
 #define KD_RT EmuRt
 #include "../../kindel_amd/csrc/kd_abi.inl"
+
+// ---- test hook: the product's kd_scan_cigar (32-bit, branch-free) next to its 64-bit reference statement (scan_ref.h) ----
+#include "scan_ref.h"
+// out[0..7] = product: cls, cold, lead, span, n_ins, ins_bases, aligned, walked; out[8..15] = reference
+extern "C" void kd_emu_scan_compare(const uint32_t *cigar, uint32_t nc, int32_t pos0, uint32_t sl, uint32_t L, uint64_t *out) {
+    uint32_t pre[4] = {0, 0, 0, 0};
+    for (uint32_t k = 0; k < 4 && k < nc; k++) pre[k] = cigar[k];
+    const KdScan a = kd_scan_cigar(cigar, nc, pos0, sl, L, pre);
+    const KdScanRef b = kd_scan_cigar_ref(cigar, nc, pos0, sl, L);
+    out[0] = a.cls; out[1] = a.cold; out[2] = a.lead; out[3] = a.span; out[4] = a.n_ins; out[5] = a.ins_bases; out[6] = a.aligned; out[7] = a.walked;
+    out[8] = b.cls; out[9] = b.cold; out[10] = b.lead; out[11] = b.span; out[12] = b.n_ins; out[13] = b.ins_bases; out[14] = b.aligned; out[15] = b.walked;
+}

@@ -346,3 +346,46 @@ def test_step_equals_the_classic_sequence(emu_lib):
                 assert np.array_equal(eng.tables(cid), run.tables[cid])
     finally:
         eng.close()
+
+
+def test_scan_cigar_matches_its_reference_statement(emu_lib):
+    """k_prep's kd_scan_cigar (32-bit, branch-free per op) against the 64-bit branch-per-kind statement of the same rules
+    (tests/emu/scan_ref.h) on random CIGARs: op lengths up to 2^28, reads at / across / behind the contig's end, negative
+    positions, query lengths around the CIGAR's.  Class and every count must agree; footprint and leading-clip reach
+    wherever the read is regular."""
+    import ctypes as C
+    f = emu_lib.dll.kd_emu_scan_compare
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p]
+    f.restype = None
+    rng = np.random.default_rng(20260922)
+    out = np.zeros(16, np.uint64)
+    n_reg = 0
+    for it in range(40000):
+        nc = int(rng.integers(1, 17))
+        mode = int(rng.integers(0, 4))
+        ops = rng.choice(10, nc, p=[.4, .12, .12, .04, .1, .04, .04, .06, .06, .02])
+        if mode == 0:
+            lens = rng.integers(0, 12, nc)
+        elif mode == 1:
+            lens = rng.integers(0, 300, nc)
+        elif mode == 2:
+            lens = np.where(rng.random(nc) < 0.1, rng.integers(1 << 22, 1 << 28, nc), rng.integers(0, 50, nc))
+        else:
+            lens = rng.integers(0, 5, nc)
+        cig = ((lens.astype(np.uint64) << 4) | ops.astype(np.uint64)).astype(np.uint32)
+        q = int(sum(l for l, o in zip(lens, ops) if o in (0, 1, 4, 7, 8)))
+        rr = int(sum(l for l, o in zip(lens, ops) if o in (0, 2, 7, 8)))
+        L = int([30, 1000, rr + int(rng.integers(0, 3)), 2 ** 32 - 1, 2 ** 31][int(rng.integers(0, 5))]) & 0xffffffff or 1
+        pos0 = int([0, -3, max(0, L - rr), max(0, L - rr) + int(rng.integers(-2, 3)), L + int(rng.integers(-1, 4)),
+                    int(rng.integers(0, 50))][int(rng.integers(0, 6))])
+        pos0 = max(-2 ** 31, min(2 ** 31 - 1, pos0))
+        sl = q + int(rng.integers(-2, 3)) if rng.random() < 0.7 else int(rng.integers(0, 40))
+        sl = max(0, min(2 ** 32 - 1, sl))
+        f(cig.ctypes.data, nc, pos0, sl, L, out.ctypes.data)
+        a, b = out[:8].tolist(), out[8:].tolist()
+        what = (list(zip(lens.tolist(), ops.tolist())), pos0, sl, L, a, b)
+        assert [a[i] for i in (0, 1, 4, 5, 6, 7)] == [b[i] for i in (0, 1, 4, 5, 6, 7)], what
+        if b[0] == 1:
+            n_reg += 1
+            assert a[2] == b[2] and a[3] == b[3], what
+    assert n_reg > 4000
