@@ -242,6 +242,9 @@ uint32_t kd_host_threads(void);
    out_len bytes; KD_OK or KD_E_IO (malformed / truncated stream, other size).  Never writes outside out[0, out_len).
    Replaces what pysam / htslib's bgzf_read do under kindel.py:131-134. */
 int kd_host_inflate(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_len);
+/* The CRC-32 the BGZF reader checks every inflated block with (kd_crc32.h; zlib's crc32 convention): htslib refuses a block whose
+   trailer does not match, and so does this reader. */
+uint32_t kd_host_crc32(const uint8_t *data, uint64_t len);
 
 /* ---- tool: write a host batch as a BGZF-compressed BAM (synthetic inputs for end-to-end runs; parallel deflate) ---- */
 int kd_write_bam(const char *path, const kd_batch *host_batch, uint32_t n_contigs, const char *const *names,

@@ -30,7 +30,7 @@ ABI_SYMBOLS = (
     "kd_profile_enable kd_profile_get kd_profile_reset kd_decode_open kd_decode_batch kd_decode_n_contigs "
     "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error "
     "kd_stream_open kd_stream_n_contigs kd_stream_contig_name kd_stream_contig_len kd_stream_next kd_stream_n_records "
-    "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_write_bam kd_host_threads kd_host_inflate "
+    "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_write_bam kd_host_threads kd_host_inflate kd_host_crc32 "
     "kd_bgzf_index kd_decode_open_span kd_step"
 ).split()
 
@@ -244,6 +244,15 @@ def host_threads(lib=None):
     lib = lib or default_library()
     lib.dll.kd_host_threads.restype = C.c_uint32
     return int(lib.dll.kd_host_threads())
+
+
+def host_crc32(data, lib=None):
+    """CRC-32 of `data` as the BGZF reader computes it (kd_host_crc32; zlib's convention)."""
+    lib = lib or default_library()
+    f = lib.dll.kd_host_crc32
+    f.argtypes = [C.c_char_p, C.c_uint64]
+    f.restype = C.c_uint32
+    return int(f(bytes(data), len(data)))
 
 
 def host_inflate(data, out_len, lib=None):

@@ -114,40 +114,74 @@ __device__ __forceinline__ uint32_t kd_alignbyte(uint32_t hi, uint32_t lo, uint3
 #define KD_SPAN_SHIFT 5
 #define KD_EV_DROPPED 0xffffffffu  // reserved insertion-event slot whose site belongs to another shard
 
-// device status words (kd_u64 each)
-enum {
-    KDS_ERR_READ = 0,   // smallest global index of a failing read (init ~0): "some read failed"; WHICH exception is
-                        // reported is decided per contig (KdTabs::err_first / err_code)
-    KDS_ERR_CODE,       // (unused)
-    KDS_N_EV,           // insertion events used
-    KDS_POOL,           // insertion pool bytes used
-    KDS_ST_READS,       // reads counted
-    KDS_ST_ALIGNED,     // aligned-base events
-    KDS_ST_WALKED,      // walked events
-    KDS_ST_INS,         // insertion ops seen
-    KDS_B_INS_OPS,      // per batch: insertion ops
-    KDS_B_INS_BASES,    // per batch: insertion bases
-    KDS_B_MAXSPAN,      // per batch: max span of regular reads
-    KDS_B_MAXLEAD,      // per batch: max leading-clip reach of regular reads
-    KDS_B_MAXSEGSPAN,   // per batch: longest ROW of a long read (k_long_reduce; k_window's second pass), in sites
-    KDS_B_ROW_DWORDS,   // per batch: dwords of the row buffer handed out to the long reads (k_long_reduce)
-    KDS_B_UNSORTED,     // per batch: reads not sorted by G-start
-    KDS_B_N_COLD,       // per batch: entries in the cold list
-    KDS_B_N_IRREG,      // per batch: entries in the irregular list
-    KDS_B_N_LONG,       // per batch: entries in the long-CIGAR list
-    KDS_B_N_REG,        // per batch: regular reads
-    KDS_NEXT_ITEM,      // window work queue head
-    KDS_TOTAL_ITEMS,    // window work queue length
-    KDS_INS_COLLISION,  // hash verification failed
-    KDS_INTERNAL,       // capacity overrun etc.
-    KDS_BAD_BASE,       // k_window / k_strip: work items that saw a base outside A,C,G,T,N
-    KDS_QUEUE0,         // k_strip: heads of the eight work queues (reset by k_plan_scan)
-    KDS_QUEUE7 = KDS_QUEUE0 + 7,
-#ifdef KD_PHASE_CLOCKS
-    KDS_DBG0, KDS_DBG1, KDS_DBG2, KDS_DBG3, KDS_DBG4, KDS_DBG5, KDS_DBG6, KDS_DBG7,   // phase clocks (profiling build only)
+// device status words (kd_u64 each), KDS_STRIDE words apart: every wavefront of k_prep ends with a dozen atomics on them, and
+// atomics on different words of ONE 128-byte line queue up behind each other like atomics on one word (~4.4 ns each measured:
+// 8136 wavefronts x 14 atomics = 0.5 ms).  One line per counter: status[KDS_X] with KDS_X = ordinal KDO_X * KDS_STRIDE.
+#ifndef KDS_STRIDE
+#define KDS_STRIDE 16
 #endif
-    KDS_COUNT
+enum {
+    KDO_ERR_READ = 0,   // smallest global index of a failing read (init ~0): "some read failed"; WHICH exception is
+                        // reported is decided per contig (KdTabs::err_first / err_code)
+    KDO_ERR_CODE,       // (unused)
+    KDO_N_EV,           // insertion events used
+    KDO_POOL,           // insertion pool bytes used
+    KDO_ST_READS,       // reads counted
+    KDO_ST_ALIGNED,     // aligned-base events
+    KDO_ST_WALKED,      // walked events
+    KDO_ST_INS,         // insertion ops seen
+    KDO_B_INS_OPS,      // per batch: insertion ops
+    KDO_B_INS_BASES,    // per batch: insertion bases
+    KDO_B_MAXSPAN,      // per batch: max span of regular reads
+    KDO_B_MAXLEAD,      // per batch: max leading-clip reach of regular reads
+    KDO_B_MAXSEGSPAN,   // per batch: longest ROW of a long read (k_long_reduce; k_window's second pass), in sites
+    KDO_B_ROW_DWORDS,   // per batch: dwords of the row buffer handed out to the long reads (k_long_reduce)
+    KDO_B_UNSORTED,     // per batch: reads not sorted by G-start
+    KDO_B_N_COLD,       // per batch: entries in the cold list
+    KDO_B_N_IRREG,      // per batch: entries in the irregular list
+    KDO_B_N_LONG,       // per batch: entries in the long-CIGAR list
+    KDO_B_N_REG,        // per batch: regular reads
+    KDO_NEXT_ITEM,      // window work queue head
+    KDO_TOTAL_ITEMS,    // window work queue length
+    KDO_INS_COLLISION,  // hash verification failed
+    KDO_INTERNAL,       // capacity overrun etc.
+    KDO_BAD_BASE,       // k_window / k_strip: work items that saw a base outside A,C,G,T,N
+    KDO_QUEUE0,         // k_strip: heads of the eight work queues (reset by k_plan_scan)
+    KDO_QUEUE7 = KDO_QUEUE0 + 7,
+#ifdef KD_PHASE_CLOCKS
+    KDO_DBG0, KDO_DBG1, KDO_DBG2, KDO_DBG3, KDO_DBG4, KDO_DBG5, KDO_DBG6, KDO_DBG7,   // phase clocks (profiling build only)
+#endif
+    KDO_COUNT
 };
+#define KDS_ERR_READ (KDO_ERR_READ * KDS_STRIDE)
+#define KDS_ERR_CODE (KDO_ERR_CODE * KDS_STRIDE)
+#define KDS_N_EV (KDO_N_EV * KDS_STRIDE)
+#define KDS_POOL (KDO_POOL * KDS_STRIDE)
+#define KDS_ST_READS (KDO_ST_READS * KDS_STRIDE)
+#define KDS_ST_ALIGNED (KDO_ST_ALIGNED * KDS_STRIDE)
+#define KDS_ST_WALKED (KDO_ST_WALKED * KDS_STRIDE)
+#define KDS_ST_INS (KDO_ST_INS * KDS_STRIDE)
+#define KDS_B_INS_OPS (KDO_B_INS_OPS * KDS_STRIDE)
+#define KDS_B_INS_BASES (KDO_B_INS_BASES * KDS_STRIDE)
+#define KDS_B_MAXSPAN (KDO_B_MAXSPAN * KDS_STRIDE)
+#define KDS_B_MAXLEAD (KDO_B_MAXLEAD * KDS_STRIDE)
+#define KDS_B_MAXSEGSPAN (KDO_B_MAXSEGSPAN * KDS_STRIDE)
+#define KDS_B_ROW_DWORDS (KDO_B_ROW_DWORDS * KDS_STRIDE)
+#define KDS_B_UNSORTED (KDO_B_UNSORTED * KDS_STRIDE)
+#define KDS_B_N_COLD (KDO_B_N_COLD * KDS_STRIDE)
+#define KDS_B_N_IRREG (KDO_B_N_IRREG * KDS_STRIDE)
+#define KDS_B_N_LONG (KDO_B_N_LONG * KDS_STRIDE)
+#define KDS_B_N_REG (KDO_B_N_REG * KDS_STRIDE)
+#define KDS_NEXT_ITEM (KDO_NEXT_ITEM * KDS_STRIDE)
+#define KDS_TOTAL_ITEMS (KDO_TOTAL_ITEMS * KDS_STRIDE)
+#define KDS_INS_COLLISION (KDO_INS_COLLISION * KDS_STRIDE)
+#define KDS_INTERNAL (KDO_INTERNAL * KDS_STRIDE)
+#define KDS_BAD_BASE (KDO_BAD_BASE * KDS_STRIDE)
+#define KDS_QUEUE0 (KDO_QUEUE0 * KDS_STRIDE)
+#define KDS_DBG0 (KDO_DBG0 * KDS_STRIDE)
+#define KDS_COUNT (KDO_COUNT * KDS_STRIDE)
+#define KDS_QUEUE7 (KDO_QUEUE7 * KDS_STRIDE)
+
 
 struct KdTabs {
     uint32_t *tab;               // counter of (channel ch, G-site g) = tab[ch * stride + g].  The allocation only covers the
@@ -178,6 +212,7 @@ struct KdReads {
     const uint32_t *n_cig;
     const uint8_t *seq4;
     const uint32_t *cigar;
+    kd_u64 n_cigar;     // words in `cigar` (>= 4: the engine pads a smaller array; k_prep loads a read's first four words at once)
     uint32_t osh;       // 0: seq_off / cig_off (and the KdRInfo array beside them) are the batch's own arrays; 1: they are
                         // the fields of KdSortRec[] (an unsorted batch's regular reads in window order): KD_RI / KD_SOFF / KD_COFF
 };

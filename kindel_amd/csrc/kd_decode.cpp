@@ -14,6 +14,7 @@
 #include <unistd.h>
 #include <zlib.h>
 #include "kd_inflate.h"
+#include "kd_crc32.h"
 
 #include <atomic>
 #include <chrono>
@@ -243,10 +244,15 @@ bool scan_bgzf_some(const uint8_t *raw, size_t n, size_t *o, std::vector<Block> 
     return *o + 18 <= n || *o == n;     // stopped early, or consumed the file exactly
 }
 
-// one BGZF block: kd_inflate.h (whole-buffer raw DEFLATE decoder; zlib's streaming inflate was 79 % of the decoder's CPU time)
+// one BGZF block: kd_inflate.h (whole-buffer raw DEFLATE decoder; zlib's streaming inflate was 79 % of the decoder's CPU time),
+// then the block's CRC-32 against its trailer -- in[in_len .. in_len + 4), in front of ISIZE; scan_bgzf* made sure it lies inside
+// the file -- as htslib's bgzf_read does for the reference (kd_crc32.h: carry-less-multiply folding, a few percent of the
+// inflater's time).  KD_BGZF_NO_CRC=1 skips the check (measurement).
+static bool bgzf_check_crc() { static const bool on = !getenv("KD_BGZF_NO_CRC"); return on; }
 bool inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len) {
     if (!out_len) return true;
-    return kdz::inflate_raw(in, in_len, out, out_len);
+    if (!kdz::inflate_raw(in, in_len, out, out_len)) return false;
+    return !bgzf_check_crc() || kdz::crc32_buf(out, out_len) == rd32(in + in_len);
 }
 
 // generic (non-BGZF) gzip: single stream, possibly several members
@@ -1221,6 +1227,7 @@ uint32_t kd_host_threads(void) { return hw_threads(); }
 int kd_host_inflate(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_len) {
     return kdz::inflate_raw(in, (size_t)in_len, out, (size_t)out_len) ? KD_OK : KD_E_IO;
 }
+uint32_t kd_host_crc32(const uint8_t *data, uint64_t len) { return kdz::crc32_buf(data, (size_t)len); }
 
 // ---- chunked reading (kd_stream_*) ----
 struct kd_stream {

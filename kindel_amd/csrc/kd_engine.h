@@ -54,6 +54,7 @@ struct KdEngine {
     };
     Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_rows, b_rowinfo, b_rowoff, b_longacc, b_coldcnt, b_coldev, b_coldpool;
     Buf b_stage[9];
+    Buf b_smallcig;   // a batch with fewer than 4 CIGAR words: its padded copy
     Buf b_srec;   // an unsorted batch's regular reads in window order: KdSortRec[] (k_sort_scatter_reads)
     Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
     uint64_t ev_cap = 0, pool_cap = 0;
@@ -169,7 +170,7 @@ struct KdEngine {
                       &b_tilesum, &b_tilemm, &b_tileoff, &b_coff};
         for (Buf *b : all) release(*b);
         for (Buf &b : b_stage) release(b);
-        release(b_srec);
+        release(b_srec); release(b_smallcig);
         if (d_tab) rt.free(d_tab);
         if (d_clen) rt.free(d_clen);
         if (d_cbase) rt.free(d_cbase);
@@ -255,13 +256,15 @@ struct KdEngine {
         if (n >= 0xffffffffULL) return fail(KD_E_ARG, "kd_push_batch: more than 2^32-1 reads in one batch");
         if (reinterpret_cast<uintptr_t>(B.seq4) & 15u) return fail(KD_E_ARG, "kd_push_batch_device: seq4 must be 16-byte aligned");
         int rc;
-        // reads per lane of k_prep: 32 amortise its per-block reductions best, but a small batch (a shard of a strong-scaling run, a
-        // deep small genome) then launches fewer workgroups than the chip has slots: halve until ~3 workgroups per CU are there
+        // reads per lane of k_prep (one wavefront per workgroup): 64 keep its per-wavefront atomics few (one per counter and 4096
+        // reads), but a small batch (a shard of a strong-scaling run, a deep small genome) then launches fewer wavefronts than the
+        // chip has slots: halve until ~8 wavefronts per CU are there
         uint32_t prep_per = KD_PREP_PER_THREAD;
-        while (prep_per > KD_PREP_UNROLL && n / ((uint64_t)KD_BLOCK * prep_per) < (uint64_t)3 * rt.n_cus()) prep_per /= 2;
-        const uint32_t prep_chunk = KD_BLOCK * prep_per, cold_region = KD_WAVE * prep_per;
+        if (const char *e = getenv("KD_PREP_PER")) prep_per = (uint32_t)std::min(KD_PREP_PER_THREAD, std::max(KD_PREP_UNROLL, atoi(e) / KD_PREP_UNROLL * KD_PREP_UNROLL));   // (knob: measurement)
+        else while (prep_per > KD_PREP_UNROLL && n / ((uint64_t)KD_PREP_BLOCK * prep_per) < (uint64_t)8 * rt.n_cus()) prep_per /= 2;
+        const uint32_t prep_chunk = KD_PREP_BLOCK * prep_per, cold_region = KD_WAVE * prep_per;
         const unsigned prep_grid = (unsigned)((n + prep_chunk - 1) / prep_chunk);
-        const unsigned prep_regions = prep_grid * KD_WAVES_PER_BLOCK;     // one region of compact cold-read records per wavefront of k_prep
+        const unsigned prep_regions = prep_grid;     // one region of compact cold-read records per wavefront of k_prep
         if ((rc = ins_cleanup())) return rc;      // the last reduction's events are about to be joined by new ones
         if ((rc = ensure(b_rinfo, n * sizeof(KdRInfo))) || (rc = ensure(b_cold, (size_t)prep_regions * cold_region * sizeof(KdColdRec))) || (rc = ensure(b_coldcnt, (size_t)prep_regions * 4)) ||
             (rc = ensure(b_coldev, (size_t)prep_regions * 8)) || (rc = ensure(b_coldpool, (size_t)prep_regions * 8)) ||
@@ -272,7 +275,12 @@ struct KdEngine {
         R.n = n; R.base_index = reads_pushed;
         R.contig = B.contig; R.pos0 = B.pos0; R.flag = B.flag; R.seq_off = (const kd_u64 *)B.seq_off;
         R.seq_len = B.seq_len; R.cig_off = (const kd_u64 *)B.cig_off; R.n_cig = B.n_cig; R.seq4 = B.seq4;
-        R.cigar = B.cigar; R.osh = 0;
+        R.cigar = B.cigar; R.n_cigar = B.cigar_words; R.osh = 0;
+        if (R.n_cigar < 4) {   // k_prep loads a read's first four CIGAR words in one go: a batch with fewer gets a padded copy
+            if ((rc = ensure(b_smallcig, 16)) || rt.memset(b_smallcig.p, 0, 16) || rt.d2d(b_smallcig.p, B.cigar, (size_t)B.cigar_words * 4))
+                return rc ? rc : hipfail("push: CIGAR copy");
+            R.cigar = (const uint32_t *)b_smallcig.p; R.n_cigar = 4;
+        }
         KdTabs T = tabs();
         KdRInfo *rinfo = (KdRInfo *)b_rinfo.p;
         KdColdRec *cold = (KdColdRec *)b_cold.p; uint32_t *irreg = (uint32_t *)b_irreg.p, *lng = (uint32_t *)b_long.p;
@@ -281,7 +289,7 @@ struct KdEngine {
             return hipfail("push: memset status");      // (the first batch after kd_reset finds them zeroed by k_reset)
         batch_status_clean = false;
         const uint64_t ev_before = h_status[KDS_N_EV], pool_before = h_status[KDS_POOL];  // as of the last fetch
-        if (rt.launch("k_prep", k_prep, prep_grid, KD_BLOCK, 0, R, T, rinfo, cold, (uint32_t *)b_coldcnt.p, (kd_u64 *)b_coldev.p, (kd_u64 *)b_coldpool.p, irreg, lng, (uint32_t *)b_readev.p,
+        if (rt.launch("k_prep", k_prep, prep_grid, KD_PREP_BLOCK, 0, R, T, rinfo, cold, (uint32_t *)b_coldcnt.p, (kd_u64 *)b_coldev.p, (kd_u64 *)b_coldpool.p, irreg, lng, (uint32_t *)b_readev.p,
                       (kd_u64 *)b_readpool.p, d_status, prep_per))
             return hipfail("k_prep");
         // k_prep touches no table: the first batch's table zeroing is queued BEHIND it and behind the status copy, so that
@@ -656,9 +664,9 @@ struct KdEngine {
         {
             const char *nm[8] = {"dequeue", "zero", "classify", "plain", "complex", "barrier-wait", "flush", "waves"};
             double tot = 0;
-            for (int k = 0; k < 7; k++) tot += (double)h_status[KDS_DBG0 + k];
+            for (int k = 0; k < 7; k++) tot += (double)h_status[KDS_DBG0 + k * KDS_STRIDE];
             fprintf(stderr, "k_window phase clocks (sum over wavefronts):");
-            for (int k = 0; k < 8; k++) fprintf(stderr, " %s=%.3g(%.1f%%)", nm[k], (double)h_status[KDS_DBG0 + k], 100.0 * h_status[KDS_DBG0 + k] / tot);
+            for (int k = 0; k < 8; k++) fprintf(stderr, " %s=%.3g(%.1f%%)", nm[k], (double)h_status[KDS_DBG0 + k * KDS_STRIDE], 100.0 * h_status[KDS_DBG0 + k * KDS_STRIDE] / tot);
             fprintf(stderr, "\n");
         }
 #endif

@@ -45,15 +45,21 @@ static inline uint32_t rev_bits(uint32_t code, int len) {
 
 // Canonical Huffman code of `n` symbols with lengths lens[] (0 = unused) -> look-up table indexed by the next bits of the
 // stream (LSB first).  entry_of(sym) gives kind / extra / value; the code length is filled in here.  Returns false for an
-// over-subscribed code; an incomplete code leaves K_BAD entries (an error only if the stream uses them), as zlib allows
-// for a distance code with a single symbol.
+// over-subscribed code and -- zlib's rule (inflate_table: "incomplete set"), so that this reader refuses what htslib refuses --
+// for an INCOMPLETE one, unless it has no symbol at all or is a literal / length or distance code of one single 1-bit word (then
+// the unused half stays K_BAD: an error only if the stream uses it); the code-length code (`cl_code`) must be complete.
 template <class EntryOf>
-static bool build_table(const uint8_t *lens, int n, int primary_bits, uint32_t *table, int table_cap, EntryOf entry_of) {
+static bool build_table(const uint8_t *lens, int n, int primary_bits, uint32_t *table, int table_cap, EntryOf entry_of, bool cl_code = false) {
     int count[16] = {0};
     for (int i = 0; i < n; i++) count[lens[i]]++;
     count[0] = 0;
     int left = 1;
     for (int l = 1; l <= 15; l++) { left = (left << 1) - count[l]; if (left < 0) return false; }
+    {
+        int mx = 15;
+        while (mx > 0 && !count[mx]) mx--;
+        if (left > 0 && mx != 0 && (cl_code || mx != 1)) return false;
+    }
     uint32_t next_code[16];
     { uint32_t code = 0; for (int l = 1; l <= 15; l++) { code = (code + (uint32_t)count[l - 1]) << 1; next_code[l] = code; } }
     const int psize = 1 << primary_bits;
@@ -173,7 +179,7 @@ struct Decoder {
         uint8_t cl[19] = {0};
         for (int i = 0; i < hclen; i++) { if (bc < 3) refill(); cl[order[i]] = (uint8_t)take(3); }
         uint32_t clt[128 + 19 * 2];
-        if (!build_table(cl, 19, 7, clt, 128 + 19 * 2, [](int s) { return mk(K_LIT, 0, 0, (uint32_t)s); })) return false;
+        if (!build_table(cl, 19, 7, clt, 128 + 19 * 2, [](int s) { return mk(K_LIT, 0, 0, (uint32_t)s); }, true)) return false;
         uint8_t lens[286 + 30 + 138];
         int n = 0;
         while (n < hlit + hdist) {

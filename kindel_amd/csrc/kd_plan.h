@@ -220,7 +220,7 @@ k_plan_scan(kd_u64 *item_off, uint32_t n_win, uint32_t *item_win, kd_u64 cap, kd
         o += v;
     }
     if (t == 0) { item_off[n_win] = total; status[KDS_TOTAL_ITEMS] = total; status[KDS_NEXT_ITEM] = 0; }
-    if (t < 8) status[KDS_QUEUE0 + t] = 0;   // k_strip's work queues
+    if (t < 8) status[KDS_QUEUE0 + t * KDS_STRIDE] = 0;   // k_strip's work queues
 }
 
 // k_plan_items: work item -> window table with one thread per window (after a k_plan_scan that was given no table to fill)

@@ -5,16 +5,15 @@
 
 // ---------------------------------------------------------------------------------------
 // k_prep: classify reads, compute the reference span of their table writes, count events.
-// One lane per read, KD_PREP_PER_THREAD reads per lane so that the per-block reductions
-// (stats, list reservations) cost one global atomic per 8192 reads.
+// One lane per read, one wavefront per workgroup, KD_PREP_PER_THREAD reads per lane so that the
+// wavefront's totals (stats, list / slot reservations) cost one atomic per counter and 4096 reads.
 // ---------------------------------------------------------------------------------------
 #ifndef KD_PREP_PER_THREAD
-#define KD_PREP_PER_THREAD 32
+#define KD_PREP_PER_THREAD 64
 #endif
-#define KD_PREP_CHUNK (KD_BLOCK * KD_PREP_PER_THREAD)
 #define KD_COLD_REGION (KD_WAVE * KD_PREP_PER_THREAD)   // record slots per wavefront of k_prep (one per read it classifies)
 #ifndef KD_PREP_UNROLL
-#define KD_PREP_UNROLL 4   // reads whose loads are issued together (a divisor of KD_PREP_PER_THREAD)
+#define KD_PREP_UNROLL 2   // reads whose loads are issued together (a divisor of KD_PREP_PER_THREAD; 4: 128 registers + scratch, 0.236 vs 0.219 ms)
 #endif
 #define KD_PREP_MAX_OPS 16
 
@@ -34,8 +33,11 @@ struct KdScan {
 //        is a comparison against it;
 //   q    query cursor CLAMPED to the read length (qc = min(q, sl)) + `over` (q > sl): what min(q, sl), q + len > sl and
 //        sl - q need, exact for any length (an irregular read's insertion slots are reserved from these counts).
-__device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc, int32_t pos0, uint32_t sl, uint32_t L,
-                                                const uint32_t *pre) {
+#ifndef KD_SCAN_EXACT_INLINE
+#define KD_SCAN_EXACT_INLINE __forceinline__   // (out of line -- one copy, called for the few reads kd_scan_cigar_inside leaves over -- measured 0.50 vs 0.37 ms: the call's spills)
+#endif
+__device__ KD_SCAN_EXACT_INLINE KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc, int32_t pos0, uint32_t sl, uint32_t L,
+                                                     const uint32_t *pre) {
     KdScan s;
     s.cold = 0; s.lead = 0; s.n_ins = 0; s.ins_bases = 0; s.aligned = 0; s.walked = 0;
     const int64_t rem0 = (int64_t)L - (int64_t)pos0;
@@ -74,207 +76,289 @@ __device__ __forceinline__ KdScan kd_scan_cigar(const uint32_t *cg, uint32_t nc,
     return s;
 }
 
+// The same scan for the read every aligner writes: one that lies INSIDE its contig and whose CIGAR consumes no more query
+// than the read has.  With  R = sum of the M / = / X / D / non-first-S lengths,  Q = sum of the M / = / X / I / S lengths,
+//      pos0 >= 0,   pos0 + R <= L,   Q <= sl
+// no rule of kd_scan_cigar about the contig's end or the query's end can fire at any op (the cursors are prefix sums of R
+// and Q: rem >= the op's length wherever it is compared, never `over`, min(len, rem) = min(len, room) = len), so the only
+// way left to be irregular is an op that writes behind a non-first soft clip, and every count is a plain sum: 32-bit adds
+// behind one-bit tests of the op kind (16 words of < 2^28 sum to < 2^32), a dozen instructions per op where the exact scan
+// needs sixty and 64-bit compares.  Returns false when the premise does not hold (a read at a contig's end, a CIGAR longer
+// than its read, POS 0, ...): the caller then runs kd_scan_cigar, which decides.  On C3 the exact scan was ~80 % of k_prep's
+// VALU instructions (0.38 ms for a kernel that streams 0.9 GB).
+__device__ __forceinline__ bool kd_scan_cigar_inside(const uint32_t *cg, uint32_t nc, int32_t pos0, uint32_t sl, uint32_t L,
+                                                     const uint32_t *pre, KdScan &s) {
+    uint32_t R = 0, Q = 0, aligned = 0, walked = 0, n_ins = 0, insb = 0, cold = 0, lead = 0, nfs = 0, bad = 0;
+#define KD_SCAN_STEP(c, first)                                                                        \
+    {                                                                                                 \
+        const uint32_t len = (c) >> 4, op = (c) & 15u;                                                \
+        const uint32_t m = (0x181u >> op) & 1u, id = (0x006u >> op) & 1u, i_ = (0x002u >> op) & 1u;   \
+        const uint32_t sc = (0x010u >> op) & 1u, sn = (first) ? 0u : sc, w = m | id | sc;            \
+        bad |= nfs & (m | id | sn);                                                                   \
+        aligned += m ? len : 0u;                                                                      \
+        walked += w ? len : 0u;                                                                       \
+        n_ins += i_;                                                                                  \
+        insb += i_ ? len : 0u;                                                                        \
+        cold |= i_ | sc;                                                                              \
+        R += (m | (id & ~i_) | sn) ? len : 0u;                                                        \
+        Q += (m | i_ | sc) ? len : 0u;                                                                \
+        nfs |= sn;                                                                                    \
+    }
+    {   // word 0: the only place a soft clip is a LEADING one
+        const uint32_t c = nc > 0 ? pre[0] : 0x3u;     // (a padding word: N, length 0, moves nothing)
+        if ((c & 15u) == 4u) lead = pos0 > 0 ? ((c >> 4) < (uint32_t)pos0 ? (c >> 4) : (uint32_t)pos0) : 0u;
+        KD_SCAN_STEP(c, true)
+    }
+#pragma unroll
+    for (uint32_t k = 1; k < 4; k++) {
+        const uint32_t c = k < nc ? pre[k] : 0x3u;
+        KD_SCAN_STEP(c, false)
+    }
+    for (uint32_t k = 4; k < nc; k++) {
+        const uint32_t c = cg[k];
+        KD_SCAN_STEP(c, false)
+    }
+#undef KD_SCAN_STEP
+    s.cls = KD_CLS_REG; s.cold = cold ? KD_INFO_COLD : 0u; s.lead = lead; s.n_ins = n_ins; s.ins_bases = insb;
+    s.span = R; s.aligned = aligned; s.walked = walked;
+    return pos0 >= 0 && !bad && (kd_u64)(uint32_t)pos0 + (kd_u64)R <= (kd_u64)L && Q <= sl;
+}
+
 #ifndef KD_PREP_OCC
-#define KD_PREP_OCC 4     // workgroups per CU the register budget is set for (5: measured slower)
+#define KD_PREP_OCC 4     // wavefronts per SIMD the register budget is set for
 #endif
-__global__ void __launch_bounds__(KD_BLOCK, KD_PREP_OCC)
+// ---------------------------------------------------------------------------------------------------------------------
+// k_prep, round 3.  Where the round-2 kernel's wavefronts spent their clocks (s_memtime marks, forced waits; C3, 0.37 ms):
+// issuing loads 18 %, waiting for them 12 %, classifying 49 %, and 21 % BEHIND the loop -- at the workgroup's barriers, waiting
+// for its slowest wavefront and for a dozen returning atomics.  The bytes were never the problem (the same seven arrays
+// stream through a kernel that only adds them up in 0.15 ms, scripts/stream_calib.hip), and neither was the CIGAR scan (four
+// fifths of its instructions removed: no change).  What was, in the order found (profiles/r03_kprep_experiments.json):
+//   * the status words.  Every workgroup ended with 14 atomics on words of ONE 128-byte line, and atomics on different words
+//     of a line queue up behind each other like atomics on one word (~4.4 ns each: +0.25 ms for every 4 068 wavefronts more
+//     that end that way).  One line per counter (KDS_STRIDE, kd_common.h): 0.37 -> 0.32 ms for the old kernel;
+//   * the barriers: one WAVEFRONT per workgroup -- no barrier, no LDS; a wavefront reduces its counts by cross-lane adds and
+//     one lane per counter issues the atomic (the returning ones -- event / pool / list slots -- all in flight together);
+//   * the scalar unit and the register budget: the classification was a dozen bool conditions per read, i.e. 1 500 s_and /
+//     s_or / s_cbranch per 4 reads on the CU's ONE scalar unit, and 128 registers with spills.  Now the read every aligner
+//     writes is decided by kd_scan_cigar_inside (sums: no rule about the contig's / the query's end can fire), conditions
+//     are 0 / 1 integers combined in vector registers, and what the sums cannot decide is DEFERRED to a loop behind the
+//     main one: the exact scan (kd_scan_cigar) counts it and it takes the general walk (class IRREG: k_pileup_wave follows
+//     the reference statement by statement, so that is always right; only the malformed and the reads hanging over a
+//     contig's end go there).  2 reads per step at 96 registers (5 wavefronts per SIMD): 0.32 -> 0.22 ms.
+// ---------------------------------------------------------------------------------------------------------------------
+#define KD_PREP_BLOCK KD_WAVE
+__global__ void __launch_bounds__(KD_PREP_BLOCK, KD_PREP_OCC)
 k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold_cnt, kd_u64 *cold_evbase, kd_u64 *cold_poolbase,
        uint32_t *irreg_list, uint32_t *long_list,
        uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status, uint32_t per_thread) {
-    // per_thread: reads per lane, a multiple of KD_PREP_UNROLL up to KD_PREP_PER_THREAD (the engine picks fewer for small batches so
-    // that the launch still fills the chip: 32 reads per lane of a 2 M-read shard are 254 workgroups on 256 CUs)
-    __shared__ kd_u64 s_red[8];       // reads, aligned, walked, ins_ops, ins_bases, n_reg, unsorted
-    __shared__ uint32_t s_maxspan, s_maxlead;
-    __shared__ uint32_t s_cnt[3];     // cold, irreg, long (block totals / running offsets)
-    __shared__ kd_u64 s_base[5];
-    __shared__ kd_u64 s_ins[2];       // insertion events / insertion bases of the block's short-CIGAR reads
-    const uint32_t t = threadIdx.x;
-    if (t < 8) s_red[t] = 0;
-    if (t < 3) s_cnt[t] = 0;
-    if (t < 2) s_ins[t] = 0;
-    if (t == 0) { s_maxspan = 0; s_maxlead = 0; }
-    __syncthreads();
-    const kd_u64 chunk0 = (kd_u64)blockIdx.x * KD_BLOCK * per_thread;
-    kd_u64 a_reads = 0, a_aligned = 0, a_walked = 0, a_ins = 0, a_insb = 0, a_reg = 0, a_unsorted = 0;
-    kd_u64 a_ins_tail = 0, a_insb_tail = 0;
-    uint32_t a_maxspan = 0, a_maxlead = 0, n_irreg = 0, n_long = 0;
-    uint32_t m_irreg = 0, m_long = 0, m_ins = 0;  // bit `it` = this thread's it-th read is in the list
-    // Compact records of the clipped / inserted reads (for k_cold_lane): every WAVEFRONT owns a region of the record array
+    // per_thread: reads per lane, a multiple of KD_PREP_UNROLL up to KD_PREP_PER_THREAD (= 64: the bits of the list masks)
+    const uint32_t t = threadIdx.x;                      // = the lane
+    const kd_u64 chunk0 = (kd_u64)blockIdx.x * KD_PREP_BLOCK * per_thread;
+    uint32_t a_reads = 0, a_ins = 0, a_reg = 0, a_unsorted = 0, a_ins_tail = 0;    // (counts over <= 64 reads of <= 16 ops)
+    kd_u64 a_aligned = 0, a_walked = 0, a_insb = 0, a_insb_tail = 0;
+    uint32_t a_maxspan = 0, a_maxlead = 0;
+    kd_u64 m_irreg = 0, m_long = 0, m_ins = 0, m_defer = 0;   // bit `it` = this lane's it-th read is in the list
+    // Compact records of the clipped / inserted reads (for k_cold_lane): the wavefront owns a region of the record array
     // (one slot per read it classifies), the lanes whose read qualifies take consecutive slots (__ballot + mbcnt) and store
-    // straight to HBM: neighbouring records from neighbouring lanes, no atomics, no staging, no limit on how many reads
-    // are clipped.  cold_cnt[region] = records written.
-    const kd_u64 wave_region = (kd_u64)blockIdx.x * KD_WAVES_PER_BLOCK + t / KD_WAVE;
-    KdColdRec *wave_rec = cold_rec + wave_region * (KD_WAVE * per_thread);
+    // straight to HBM: neighbouring records from neighbouring lanes, no atomics, no staging.  cold_cnt[region] = records written.
+    const kd_u64 wave_region = blockIdx.x;
+    KdColdRec *wave_rec = cold_rec + wave_region * ((kd_u64)KD_WAVE * per_thread);
     uint32_t wcount = 0;
     // The insertion-event slots and pool bytes of these reads are handed out here too: a wavefront-wide prefix sum per read
-    // gives every read its offset in the wavefront's range, the range's base follows when the block has reserved its share
-    // (one returning atomic per block, as before).  Only irregular reads with insertions (rare) still go through the last loop.
+    // gives every read its offset in the wavefront's range, the range's base follows from ONE returning atomic per wavefront.
     uint32_t w_ev_total = 0;
     kd_u64 w_pool_total = 0;
     uint32_t c_cached = 0xffffffffu;                             // one-entry cache of the contig table
-    kd_u64 cb_cached = 0;
-    int64_t L_cached = 0;
-    // 4 reads per step: all of their metadata loads are issued before any is consumed
+    uint32_t cb_cached = 0, L_cached = 0;                         // (G-space fits 32 bits)
     for (int it0 = 0; it0 < (int)per_thread; it0 += KD_PREP_UNROLL) {
-        uint32_t v_c[KD_PREP_UNROLL], v_pc[KD_PREP_UNROLL], v_nc[KD_PREP_UNROLL], v_fl[KD_PREP_UNROLL];
-        int64_t v_pos[KD_PREP_UNROLL], v_ppos[KD_PREP_UNROLL], v_sl[KD_PREP_UNROLL];
+        // KD_PREP_UNROLL reads per step: all of their metadata loads are issued before any is consumed, none inside a branch
+        uint32_t v_c[KD_PREP_UNROLL], v_nc[KD_PREP_UNROLL], v_fl[KD_PREP_UNROLL], v_sl[KD_PREP_UNROLL], v_pc[KD_PREP_UNROLL];
+        int32_t v_pos[KD_PREP_UNROLL], v_ppos[KD_PREP_UNROLL];
         kd_u64 v_coff[KD_PREP_UNROLL];
-        bool v_ok[KD_PREP_UNROLL];
 #pragma unroll
         for (int u = 0; u < KD_PREP_UNROLL; u++) {
-            const kd_u64 i = chunk0 + (kd_u64)(it0 + u) * KD_BLOCK + t;
-            v_ok[u] = i < rd.n;
-            const kd_u64 j = v_ok[u] ? i : 0, jp = (v_ok[u] && i > 0) ? i - 1 : j;
+            const kd_u64 i = chunk0 + (kd_u64)(it0 + u) * KD_PREP_BLOCK + t;
+            const kd_u64 j = i < rd.n ? i : 0;
             v_c[u] = rd.contig[j]; v_pos[u] = rd.pos0[j];
-            v_pc[u] = rd.contig[jp]; v_ppos[u] = rd.pos0[jp];
             v_sl[u] = rd.seq_len[j]; v_nc[u] = rd.n_cig[j]; v_fl[u] = rd.flag[j]; v_coff[u] = rd.cig_off[j];
+            // the record in front of this one (sortedness, first record of a contig): the neighbouring lane holds it, but for
+            // lane 0, which loads it (the other lanes load their own record again: the same line)
+            const kd_u64 jp = (t == 0 && j > 0) ? j - 1 : j;
+            v_pc[u] = rd.contig[jp]; v_ppos[u] = rd.pos0[jp];
         }
-        // second level: the first 4 CIGAR words of each of the 4 reads, again all in flight together
-        uint32_t v_cw[KD_PREP_UNROLL][4];
+        // second level: the first 4 CIGAR words of each read as ONE unaligned 16-byte load at the read's first word -- or, for the
+        // last reads of the batch, at the array's last four words (rd.n_cigar >= 4: the engine sees to it), shifted into place below
+        uint32_t v_cw[KD_PREP_UNROLL][4], v_cd[KD_PREP_UNROLL];
 #pragma unroll
         for (int u = 0; u < KD_PREP_UNROLL; u++) {
-            const uint32_t *cgp = rd.cigar + v_coff[u];
-            const uint32_t ncu = v_ok[u] ? v_nc[u] : 0u;
-#pragma unroll
-            for (int k = 0; k < 4; k++) v_cw[u][k] = (uint32_t)k < ncu ? cgp[k] : 0u;
+            const kd_u64 i = chunk0 + (kd_u64)(it0 + u) * KD_PREP_BLOCK + t;
+            const kd_u64 last = rd.n_cigar - 4;
+            const kd_u64 at = i < rd.n ? (v_coff[u] < last ? v_coff[u] : last) : 0;
+            const kd_u64 d64 = v_coff[u] - at;
+            v_cd[u] = (i < rd.n && d64 < 4) ? (uint32_t)d64 : 4u;          // 0 but for the batch's last reads (4: no word of it)
+            const KdChunk w = *reinterpret_cast<const KdChunk *>(rd.cigar + at);
+            v_cw[u][0] = w.x; v_cw[u][1] = w.y; v_cw[u][2] = w.z; v_cw[u][3] = w.w;
         }
 #pragma unroll
         for (int u = 0; u < KD_PREP_UNROLL; u++) {
-            const bool ok = v_ok[u];   // (no early exit for a lane past the end of the batch: the wavefront votes below)
             const int it = it0 + u;
-            const kd_u64 i = chunk0 + (kd_u64)it * KD_BLOCK + t;
+            const kd_u64 i = chunk0 + (kd_u64)it * KD_PREP_BLOCK + t;
+            const bool ok = i < rd.n;   // (no early exit for a lane past the end of the batch: the wavefront votes below)
             const uint32_t c = v_c[u];
-            if (c != c_cached) { c_cached = c; cb_cached = T.contig_base[c]; L_cached = (int64_t)T.contig_len[c]; }
-            const int64_t pos0 = v_pos[u];
+            if (c != c_cached) { c_cached = c; cb_cached = (uint32_t)T.contig_base[c]; L_cached = T.contig_len[c]; }
+            const int32_t pos0 = v_pos[u];
+            const uint32_t pc_n = kd_shfl_up(c, 1), ppos_n = kd_shfl_up((uint32_t)pos0, 1);
+            const uint32_t pc = t == 0 ? v_pc[u] : pc_n;             // (the batch's first read is its own predecessor)
+            const int32_t ppos = t == 0 ? v_ppos[u] : (int32_t)ppos_n;
             // first record of its contig in the file (any record with that RNAME counts, kindel.py:143-145): only where
             // the contig changes from one record to the next can a contig appear for the first time
-            if (ok && (i == 0 || v_pc[u] != c)) atomicMin(&T.first_idx[c], rd.base_index + i);
-            const kd_u64 gkey = cb_cached + (kd_u64)(pos0 > 0 ? pos0 : 0);
+            if (ok && (i == 0 || pc != c)) atomicMin(&T.first_idx[c], rd.base_index + i);
+            const uint32_t gkey = cb_cached + (uint32_t)(pos0 > 0 ? pos0 : 0);
             {   // sortedness of G-start over ALL reads of the batch (window ranges rely on it)
-                const kd_u64 pcb = v_pc[u] == c ? cb_cached : T.contig_base[v_pc[u]];
-                const kd_u64 pk = pcb + (kd_u64)(v_ppos[u] > 0 ? v_ppos[u] : 0);
-                if (ok && pk > gkey) a_unsorted++;
+                const uint32_t pcb = pc == c ? cb_cached : (uint32_t)T.contig_base[pc];
+                const uint32_t pk = pcb + (uint32_t)(ppos > 0 ? ppos : 0);
+                a_unsorted += (ok && pk > gkey) ? 1u : 0u;
             }
-            const int64_t sl = v_sl[u];
-            const uint32_t nc = v_nc[u];
-            uint32_t cls, cold = 0, lead = 0;
-            kd_u64 span = 0, al = 0, n_ins_r = 0, n_insb_r = 0;
-            bool has_ins = false, has_ins_tail = true;   // has_ins_tail: the read's slots come from the last loop
-            if (!ok || (v_fl[u] & 4u) || sl <= 1) {
-                cls = KD_CLS_SKIP;
-            } else if (nc == 0) {
-                cls = KD_CLS_IRREG;  // CIGAR '*': k_pileup_wave raises KD_E_CIGAR
-                a_reads++;
-            } else if (nc > KD_PREP_MAX_OPS) {
-                cls = KD_CLS_LONG;
-                a_reads++;
-            } else {
-                KdScan s = kd_scan_cigar(rd.cigar + v_coff[u], nc, (int32_t)pos0, (uint32_t)sl, (uint32_t)L_cached, v_cw[u]);
-                cls = s.cls; cold = s.cold; span = s.span; lead = s.lead; has_ins = s.n_ins != 0; al = s.aligned;
-                n_ins_r = s.n_ins; n_insb_r = s.ins_bases;
-                a_reads++; a_aligned += s.aligned; a_walked += s.walked; a_ins += s.n_ins; a_insb += s.ins_bases;
-            }
-            if (span > 0x07ffffffULL || (cls == KD_CLS_REG && sl >= (int64_t)KD_COLD_MAX_SEQ)) { cls = KD_CLS_IRREG; span = 0; }
-            if (cls == KD_CLS_REG) {
-                a_reg++;
-                if ((uint32_t)span > a_maxspan) a_maxspan = (uint32_t)span;
-                if (lead > a_maxlead) a_maxlead = lead;
-            }
+            const uint32_t sl = v_sl[u], nc = v_nc[u];
+            // the read's first four words in place (the batch's last reads were loaded from in front of their first word)
+            uint32_t cw[4];
             {
-                const bool is_cold = cls == KD_CLS_REG && cold != 0;
+                const uint32_t d = v_cd[u];
+                if (d) {   // (rare: at most the last four reads of the batch)
+                    uint32_t sh[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++)
+                        sh[k] = d == 1 ? (k + 1 < 4 ? v_cw[u][(k + 1) & 3] : 0u) : d == 2 ? (k + 2 < 4 ? v_cw[u][(k + 2) & 3] : 0u)
+                                       : d == 3 ? (k + 3 < 4 ? v_cw[u][(k + 3) & 3] : 0u) : 0u;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) v_cw[u][k] = sh[k];
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) cw[k] = k < nc ? v_cw[u][k] : 0x3u;   // (behind the read's words: N, length 0)
+            }
+            // class: 0 / 1 integers, combined in vector registers
+            const uint32_t skip = (!ok || (v_fl[u] & 4u) || sl <= 1) ? 1u : 0u;       // kindel.py:43-46
+            const uint32_t star = (!skip && nc == 0) ? 1u : 0u;                        // CIGAR '*': k_pileup_wave raises KD_E_CIGAR
+            const uint32_t lng = (!skip && nc > KD_PREP_MAX_OPS) ? 1u : 0u;
+            const uint32_t scanned = (skip | star | lng) ^ 1u;
+            KdScan s;
+            const bool inside = kd_scan_cigar_inside(rd.cigar + v_coff[u], scanned ? nc : 0u, pos0, sl, L_cached, cw, s);
+            // regular: decided by the sums, footprint and length within what the window kernels index with
+            const uint32_t reg = (scanned && inside && s.span <= 0x07ffffffULL && sl < KD_COLD_MAX_SEQ) ? 1u : 0u;
+            const uint32_t defer = (scanned && !inside) ? 1u : 0u;                     // the exact scan decides, behind the loop
+            const uint32_t irr = star | (scanned & (reg | defer) ^ scanned);            // scanned, inside, but too long / too wide
+            const uint32_t counted = scanned & (defer ^ 1u);                           // its counts are the sums'
+            a_reads += (skip ^ 1u) & (defer ^ 1u);
+            a_aligned += counted ? s.aligned : 0ULL; a_walked += counted ? s.walked : 0ULL;
+            a_ins += counted ? s.n_ins : 0u; a_insb += counted ? s.ins_bases : 0u;
+            a_reg += reg;
+            const uint32_t span = reg ? (uint32_t)s.span : 0u, lead = reg ? s.lead : 0u;
+            a_maxspan = span > a_maxspan ? span : a_maxspan;
+            a_maxlead = lead > a_maxlead ? lead : a_maxlead;
+            const uint32_t cold = counted ? s.cold : 0u;
+            const uint32_t has_ins = (counted && s.n_ins) ? 1u : 0u;
+            {
+                const bool is_cold = reg && cold;
                 const unsigned long long cm = kd_ballot(is_cold);
                 const bool reg_ins = is_cold && has_ins;
                 uint32_t ev_rel = 0, pool_rel = 0;
-                if (kd_ballot(reg_ins)) {   // (wave-uniform) inclusive scan of (pool bytes << 16 | events): <= 16 events per read
-                    const kd_u64 v = reg_ins ? ((kd_u64)n_insb_r << 16) | n_ins_r : 0ULL;
-                    kd_u64 incl = v;
-#pragma unroll
-                    for (uint32_t d = 1; d < KD_WAVE; d <<= 1) {
-                        const kd_u64 up = kd_shfl_up64(incl, d);
-                        if ((t & (KD_WAVE - 1)) >= d) incl += up;
-                    }
-                    const kd_u64 tot = kd_shfl64(incl, KD_WAVE - 1);
-                    ev_rel = w_ev_total + (uint32_t)((incl - v) & 0xffffu);
-                    pool_rel = (uint32_t)(w_pool_total + ((incl - v) >> 16));
-                    w_ev_total += (uint32_t)(tot & 0xffffu);
-                    w_pool_total += tot >> 16;
+                if (kd_ballot(reg_ins)) {   // (wave-uniform) two DPP prefix sums: events (<= 16 per read) and pool bytes (< 2^20 per
+                                            // regular read: 64 of them stay below 2^32)
+                    const uint32_t ve = reg_ins ? s.n_ins : 0u, vb = reg_ins ? s.ins_bases : 0u;
+                    const uint32_t ie = kd_wave_scan_add(ve), ib = kd_wave_scan_add(vb);
+                    ev_rel = w_ev_total + (ie - ve);
+                    pool_rel = (uint32_t)(w_pool_total + (ib - vb));
+                    w_ev_total += kd_readlane(ie, KD_WAVE - 1);
+                    w_pool_total += kd_readlane(ib, KD_WAVE - 1);
                 }
                 if (is_cold) {
                     KdColdRec cr;
                     cr.cig_off = v_coff[u]; cr.read = (uint32_t)i; cr.pos0 = (uint32_t)pos0; cr.contig = c;
-                    cr.len_ops = (uint32_t)sl | (nc << 20) | (has_ins ? KD_COLD_HAS_INS : 0u);
+                    cr.len_ops = sl | (nc << 20) | (has_ins ? KD_COLD_HAS_INS : 0u);
                     cr.ev_rel = ev_rel; cr.pool_rel = pool_rel;
                     wave_rec[wcount + kd_mbcnt(cm)] = cr;
                 }
                 wcount += (uint32_t)kd_popcll(cm);
-                if (reg_ins) has_ins_tail = false;
             }
-            if (cls == KD_CLS_IRREG) { n_irreg++; m_irreg |= 1u << it; }
-            if (cls == KD_CLS_LONG) { n_long++; m_long |= 1u << it; }
-            if (has_ins && has_ins_tail) {   // (an irregular read with insertions) counts, see the last loop
-                m_ins |= 1u << it; read_ev[i] = (uint32_t)n_ins_r; read_pool[i] = n_insb_r;
-                a_ins_tail += n_ins_r; a_insb_tail += n_insb_r;
+            const kd_u64 bit = 1ULL << it;
+            if (irr) m_irreg |= bit;
+            if (lng) m_long |= bit;
+            if (defer) m_defer |= bit;
+            if (irr && has_ins) {   // (an irregular read with insertions: counted by the sums, too long for the window path) its slots
+                m_ins |= bit; read_ev[i] = s.n_ins; read_pool[i] = s.ins_bases;     //   come from the last loop
+                a_ins_tail += s.n_ins; a_insb_tail += s.ins_bases;
             }
             KdRInfo ri;
-            ri.gstart = (uint32_t)gkey;
+            ri.gstart = gkey;
             // plain: the whole read is ONE aligned run: a single op whose aligned length is the read length
-            const uint32_t plain = (cls == KD_CLS_REG && nc == 1 && !cold && al == (kd_u64)sl && span == al) ? KD_INFO_PLAIN : 0u;
-            ri.span_cls = ((uint32_t)span << KD_SPAN_SHIFT) | plain | (has_ins ? KD_INFO_INS : 0u) | cold | cls;
+            const uint32_t plain = (reg && nc == 1 && !cold && s.aligned == (kd_u64)sl && s.span == s.aligned) ? KD_INFO_PLAIN : 0u;
+            const uint32_t cls = reg ? KD_CLS_REG : lng ? KD_CLS_LONG : (irr | defer) ? KD_CLS_IRREG : KD_CLS_SKIP;
+            ri.span_cls = (span << KD_SPAN_SHIFT) | plain | (has_ins ? KD_INFO_INS : 0u) | cold | cls;
             // pad of a REGULAR short-CIGAR read: query length | CIGAR words << 24 (k_window_coop routes on them without touching
             // seq_len / n_cig again; a regular read is shorter than KD_COLD_MAX_SEQ = 2^20 bases and has <= 16 words)
-            ri.lead = lead; ri.pad = cls == KD_CLS_REG ? ((uint32_t)sl | (nc << 24)) : 0u;
+            ri.lead = lead; ri.pad = reg ? (sl | (nc << 24)) : 0u;
             if (ok) rinfo[i] = ri;
         }
     }
-    kd_u64 wave_off_ev = 0, wave_off_pool = 0;     // the wavefront's range inside the block's reservation (lane 0)
-    if ((t & (KD_WAVE - 1)) == 0) {
-        cold_cnt[wave_region] = wcount;
-        if (wcount) atomicAdd(&s_cnt[0], wcount);
-        if (w_ev_total) { wave_off_ev = atomicAdd(&s_ins[0], (kd_u64)w_ev_total); wave_off_pool = atomicAdd(&s_ins[1], w_pool_total); }
+    // The reads the sums could not decide (rare: at a contig's end, CIGAR and read length at odds, POS 0): the exact scan counts
+    // them -- an irregular read's insertion slots are reserved from its counts -- and they take the general walk.
+    for (kd_u64 todo = m_defer; todo; todo &= todo - 1) {
+        const int it = __builtin_ctzll(todo);
+        const kd_u64 i = chunk0 + (kd_u64)it * KD_PREP_BLOCK + t;
+        const uint32_t c = rd.contig[i], nc = rd.n_cig[i];
+        const kd_u64 coff = rd.cig_off[i];
+        uint32_t pre[4];
+        for (uint32_t k = 0; k < 4; k++) pre[k] = k < nc ? rd.cigar[coff + k] : 0u;
+        const KdScan s = kd_scan_cigar(rd.cigar + coff, nc, rd.pos0[i], rd.seq_len[i], T.contig_len[c], pre);
+        a_reads++; a_aligned += s.aligned; a_walked += s.walked; a_ins += s.n_ins; a_insb += s.ins_bases;
+        m_irreg |= 1ULL << it;
+        if (s.n_ins) {
+            m_ins |= 1ULL << it; read_ev[i] = s.n_ins; read_pool[i] = s.ins_bases;
+            a_ins_tail += s.n_ins; a_insb_tail += s.ins_bases;
+            rinfo[i].span_cls |= KD_INFO_INS | s.cold;
+        } else if (s.cold) rinfo[i].span_cls |= s.cold;
     }
-    // block reduction through LDS atomics, then one global atomic per word per block
-    if (a_reads) atomicAdd(&s_red[0], a_reads);
-    if (a_aligned) atomicAdd(&s_red[1], a_aligned);
-    if (a_walked) atomicAdd(&s_red[2], a_walked);
-    if (a_ins) atomicAdd(&s_red[3], a_ins);
-    if (a_insb) atomicAdd(&s_red[4], a_insb);
-    if (a_reg) atomicAdd(&s_red[5], a_reg);
-    if (a_unsorted) atomicAdd(&s_red[6], a_unsorted);
-    if (a_maxspan) atomicMax(&s_maxspan, a_maxspan);
-    if (a_maxlead) atomicMax(&s_maxlead, a_maxlead);
-    // list slots: thread-local offset inside the block
-    uint32_t o_irreg = n_irreg ? atomicAdd(&s_cnt[1], n_irreg) : 0;
-    uint32_t o_long = n_long ? atomicAdd(&s_cnt[2], n_long) : 0;
-    // insertion event / pool slots: thread-local offsets inside the block, one global reservation per block
-    // (a global counter bumped per event serialises at ~11 ns per returning atomic on one address)
-    const kd_u64 o_ev = a_ins_tail ? atomicAdd(&s_ins[0], a_ins_tail) : 0;
-    const kd_u64 o_pool = a_ins_tail ? atomicAdd(&s_ins[1], a_insb_tail) : 0;
-    __syncthreads();
-    // one global atomic per word and block, issued by DIFFERENT threads (a dozen returning atomics in a row from one
-    // thread are a dozen round trips the other 255 threads wait for)
-    if (t == 0 && s_red[0]) atomicAdd(&status[KDS_ST_READS], s_red[0]);
-    if (t == 1 && s_red[1]) atomicAdd(&status[KDS_ST_ALIGNED], s_red[1]);
-    if (t == 2 && s_red[2]) atomicAdd(&status[KDS_ST_WALKED], s_red[2]);
-    if (t == 3 && s_red[3]) { atomicAdd(&status[KDS_ST_INS], s_red[3]); atomicAdd(&status[KDS_B_INS_OPS], s_red[3]); }
-    if (t == 4 && s_red[4]) atomicAdd(&status[KDS_B_INS_BASES], s_red[4]);
-    if (t == 5) s_base[3] = s_ins[0] ? atomicAdd(&status[KDS_N_EV], s_ins[0]) : 0;
-    if (t == 6) s_base[4] = s_ins[0] ? atomicAdd(&status[KDS_POOL], s_ins[1]) : 0;
-    if (t == 7 && s_red[5]) atomicAdd(&status[KDS_B_N_REG], s_red[5]);
-    if (t == 8 && s_red[6]) atomicAdd(&status[KDS_B_UNSORTED], s_red[6]);
-    if (t == 9 && s_maxspan) atomicMax(&status[KDS_B_MAXSPAN], (kd_u64)s_maxspan);
-    if (t == 10 && s_maxlead) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)s_maxlead);
-    if (t == 64 && s_cnt[0]) atomicAdd(&status[KDS_B_N_COLD], (kd_u64)s_cnt[0]);
-    if (t == 65) s_base[1] = s_cnt[1] ? atomicAdd(&status[KDS_B_N_IRREG], (kd_u64)s_cnt[1]) : 0;
-    if (t == 66) s_base[2] = s_cnt[2] ? atomicAdd(&status[KDS_B_N_LONG], (kd_u64)s_cnt[2]) : 0;
-    __syncthreads();
-    if ((t & (KD_WAVE - 1)) == 0) { cold_evbase[wave_region] = s_base[3] + wave_off_ev; cold_poolbase[wave_region] = s_base[4] + wave_off_pool; }
+    // ---- the wavefront's totals: cross-lane sums, then ONE lane per counter issues the atomic ----
+    const uint32_t n_irreg = (uint32_t)kd_popcll(m_irreg), n_long = (uint32_t)kd_popcll(m_long);
+    const uint32_t i_irreg = kd_wave_scan_add(n_irreg), i_long = kd_wave_scan_add(n_long);      // inclusive prefix sums over the lanes
+    const uint32_t i_evt = kd_wave_scan_add(a_ins_tail);
+    const uint32_t t_irreg = kd_readlane(i_irreg, KD_WAVE - 1), t_long = kd_readlane(i_long, KD_WAVE - 1), t_evt = kd_readlane(i_evt, KD_WAVE - 1);
+    kd_u64 i_poolt = a_insb_tail;    // (64-bit: an irregular read's insertion may be 2^28 bases long)
+#pragma unroll
+    for (uint32_t d = 1; d < KD_WAVE; d <<= 1) { const kd_u64 up = kd_shfl_up64(i_poolt, d); if (t >= d) i_poolt += up; }
+    const kd_u64 t_poolt = kd_shfl64(i_poolt, KD_WAVE - 1);
+    const uint32_t r_reads = kd_wave_sum(a_reads), r_ins = kd_wave_sum(a_ins), r_reg = kd_wave_sum(a_reg), r_uns = kd_wave_sum(a_unsorted);
+    const uint32_t r_span = kd_wave_max(a_maxspan), r_lead = kd_wave_max(a_maxlead);
+    kd_u64 r_al = a_aligned, r_wk = a_walked, r_ib = a_insb;
+#pragma unroll
+    for (uint32_t m = 1; m < KD_WAVE; m <<= 1) {
+        r_al += kd_shfl64(r_al, t ^ m); r_wk += kd_shfl64(r_wk, t ^ m); r_ib += kd_shfl64(r_ib, t ^ m);
+    }
+    const kd_u64 ev_all = (kd_u64)w_ev_total + t_evt, pool_all = w_pool_total + t_poolt;   // regular reads' slots first, then the tail's
+    kd_u64 got = 0;      // lane k's returning atomic (all in flight together)
+    if (t == 0 && r_reads) atomicAdd(&status[KDS_ST_READS], (kd_u64)r_reads);
+    if (t == 1 && r_al) atomicAdd(&status[KDS_ST_ALIGNED], r_al);
+    if (t == 2 && r_wk) atomicAdd(&status[KDS_ST_WALKED], r_wk);
+    if (t == 3 && r_ins) { atomicAdd(&status[KDS_ST_INS], (kd_u64)r_ins); atomicAdd(&status[KDS_B_INS_OPS], (kd_u64)r_ins); }
+    if (t == 4 && r_ib) atomicAdd(&status[KDS_B_INS_BASES], r_ib);
+    if (t == 5 && ev_all) got = atomicAdd(&status[KDS_N_EV], ev_all);
+    if (t == 6 && ev_all) got = atomicAdd(&status[KDS_POOL], pool_all);
+    if (t == 7 && r_reg) atomicAdd(&status[KDS_B_N_REG], (kd_u64)r_reg);
+    if (t == 8 && r_uns) atomicAdd(&status[KDS_B_UNSORTED], (kd_u64)r_uns);
+    if (t == 9 && r_span) atomicMax(&status[KDS_B_MAXSPAN], (kd_u64)r_span);
+    if (t == 10 && r_lead) atomicMax(&status[KDS_B_MAXLEAD], (kd_u64)r_lead);
+    if (t == 11 && wcount) atomicAdd(&status[KDS_B_N_COLD], (kd_u64)wcount);
+    if (t == 12 && t_irreg) got = atomicAdd(&status[KDS_B_N_IRREG], (kd_u64)t_irreg);
+    if (t == 13 && t_long) got = atomicAdd(&status[KDS_B_N_LONG], (kd_u64)t_long);
+    const kd_u64 b_ev = kd_shfl64(got, 5), b_pool = kd_shfl64(got, 6), b_irreg = kd_shfl64(got, 12), b_long = kd_shfl64(got, 13);
+    if (t == 0) { cold_cnt[wave_region] = wcount; cold_evbase[wave_region] = b_ev; cold_poolbase[wave_region] = b_pool; }
     if (m_irreg | m_long | m_ins) {
-        kd_u64 w_irreg = s_base[1] + o_irreg, w_long = s_base[2] + o_long;
-        kd_u64 w_ev = s_base[3] + o_ev, w_pool = s_base[4] + o_pool;
-        for (uint32_t todo = m_irreg | m_long | m_ins; todo; todo &= todo - 1) {
-            const int it = __builtin_ctz(todo);
-            const kd_u64 i = chunk0 + (kd_u64)it * KD_BLOCK + t;
-            const uint32_t bit = 1u << it;
+        kd_u64 w_irreg = b_irreg + (i_irreg - n_irreg), w_long = b_long + (i_long - n_long);
+        kd_u64 w_ev = b_ev + w_ev_total + (i_evt - a_ins_tail), w_pool = b_pool + w_pool_total + (i_poolt - a_insb_tail);
+        for (kd_u64 todo = m_irreg | m_long | m_ins; todo; todo &= todo - 1) {
+            const int it = __builtin_ctzll(todo);
+            const kd_u64 i = chunk0 + (kd_u64)it * KD_PREP_BLOCK + t;
+            const kd_u64 bit = 1ULL << it;
             if (m_ins & bit) {  // the first pass left the read's event / base COUNTS here: turn them into its slots
                 const uint32_t n_ev = read_ev[i];
                 const kd_u64 n_b = read_pool[i];

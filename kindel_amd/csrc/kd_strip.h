@@ -353,7 +353,7 @@ k_strip(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, const
         if (qlo >= qhi) continue;
         for (;;) {
             kd_u64 it = 0;
-            if (lane == 0) it = atomicAdd(&status[KDS_QUEUE0 + q], (kd_u64)KD_GRAB);
+            if (lane == 0) it = atomicAdd(&status[KDS_QUEUE0 + q * KDS_STRIDE], (kd_u64)KD_GRAB);
             it = kd_readfirstlane64(it) + qlo;
             if (it >= qhi) break;
             const kd_u64 it_end = it + KD_GRAB < qhi ? it + KD_GRAB : qhi;

@@ -60,7 +60,14 @@ struct EmuRt {
 extern "C" void kd_emu_scan_compare(const uint32_t *cigar, uint32_t nc, int32_t pos0, uint32_t sl, uint32_t L, uint64_t *out) {
     uint32_t pre[4] = {0, 0, 0, 0};
     for (uint32_t k = 0; k < 4 && k < nc; k++) pre[k] = cigar[k];
-    const KdScan a = kd_scan_cigar(cigar, nc, pos0, sl, L, pre);
+    KdScan a;      // as k_prep does it: the sums-only scan where its premise holds, the exact one otherwise
+    const bool inside = kd_scan_cigar_inside(cigar, nc, pos0, sl, L, pre, a);
+    const KdScan exact = kd_scan_cigar(cigar, nc, pos0, sl, L, pre);
+    if (inside) {  // ... and wherever the premise holds the exact scan must say the same, field by field
+        if (exact.cls != a.cls || exact.cold != a.cold || exact.lead != a.lead || exact.span != a.span || exact.n_ins != a.n_ins ||
+            exact.ins_bases != a.ins_bases || exact.aligned != a.aligned || exact.walked != a.walked) a.cls = 0xdeadu;
+    } else a = exact;
+    out[16] = inside ? 1 : 0;
     const KdScanRef b = kd_scan_cigar_ref(cigar, nc, pos0, sl, L);
     out[0] = a.cls; out[1] = a.cold; out[2] = a.lead; out[3] = a.span; out[4] = a.n_ins; out[5] = a.ins_bases; out[6] = a.aligned; out[7] = a.walked;
     out[8] = b.cls; out[9] = b.cold; out[10] = b.lead; out[11] = b.span; out[12] = b.n_ins; out[13] = b.ins_bases; out[14] = b.aligned; out[15] = b.walked;

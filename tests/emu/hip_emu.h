@@ -107,6 +107,7 @@ static inline void emu_wave_meet() {
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ static __attribute__((noinline))
 #define __shared__ static thread_local
 #define __launch_bounds__(...)
 #define KD_MUL24(a, b) ((uint32_t)(a) * (uint32_t)(b))

@@ -358,8 +358,8 @@ def test_scan_cigar_matches_its_reference_statement(emu_lib):
     f.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p]
     f.restype = None
     rng = np.random.default_rng(20260922)
-    out = np.zeros(16, np.uint64)
-    n_reg = 0
+    out = np.zeros(17, np.uint64)
+    n_reg = n_inside = n_inside_irreg = 0
     for it in range(40000):
         nc = int(rng.integers(1, 17))
         mode = int(rng.integers(0, 4))
@@ -375,17 +375,26 @@ def test_scan_cigar_matches_its_reference_statement(emu_lib):
         cig = ((lens.astype(np.uint64) << 4) | ops.astype(np.uint64)).astype(np.uint32)
         q = int(sum(l for l, o in zip(lens, ops) if o in (0, 1, 4, 7, 8)))
         rr = int(sum(l for l, o in zip(lens, ops) if o in (0, 2, 7, 8)))
-        L = int([30, 1000, rr + int(rng.integers(0, 3)), 2 ** 32 - 1, 2 ** 31][int(rng.integers(0, 5))]) & 0xffffffff or 1
+        rs = rr + int(sum(l for l, o in zip(lens[1:], ops[1:]) if o == 4))     # + the non-first clips: the footprint's end
+        L = int([30, 1000, rr + int(rng.integers(0, 3)), 2 ** 32 - 1, 2 ** 31, rs + int(rng.integers(0, 3)), rs + int(rng.integers(0, 40))][
+            int(rng.integers(0, 7))]) & 0xffffffff or 1
         pos0 = int([0, -3, max(0, L - rr), max(0, L - rr) + int(rng.integers(-2, 3)), L + int(rng.integers(-1, 4)),
-                    int(rng.integers(0, 50))][int(rng.integers(0, 6))])
+                    int(rng.integers(0, 50)), max(0, L - rs) + int(rng.integers(-2, 3)), max(0, L - rs)][int(rng.integers(0, 8))])
         pos0 = max(-2 ** 31, min(2 ** 31 - 1, pos0))
         sl = q + int(rng.integers(-2, 3)) if rng.random() < 0.7 else int(rng.integers(0, 40))
         sl = max(0, min(2 ** 32 - 1, sl))
         f(cig.ctypes.data, nc, pos0, sl, L, out.ctypes.data)
-        a, b = out[:8].tolist(), out[8:].tolist()
+        a, b = out[:8].tolist(), out[8:16].tolist()
+        assert a[0] != 0xdead, ("the sums-only scan and the exact scan disagree where the premise holds",
+                                list(zip(lens.tolist(), ops.tolist())), pos0, sl, L)
+        n_inside += int(out[16])
+        n_inside_irreg += int(out[16]) and b[0] == 2
         what = (list(zip(lens.tolist(), ops.tolist())), pos0, sl, L, a, b)
         assert [a[i] for i in (0, 1, 4, 5, 6, 7)] == [b[i] for i in (0, 1, 4, 5, 6, 7)], what
         if b[0] == 1:
             n_reg += 1
             assert a[2] == b[2] and a[3] == b[3], what
     assert n_reg > 4000
+    # the sums-only scan (kd_scan_cigar_inside) decided a good share of them itself -- only ever "regular" -- and left the
+    # reads at / over the contig's or the query's end, and those that write behind a trailing clip, to the exact scan
+    assert n_inside > 3000 and n_inside_irreg == 0 and n_inside < 38000, (n_inside, n_inside_irreg)
