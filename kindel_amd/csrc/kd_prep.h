@@ -77,30 +77,33 @@ __device__ KD_SCAN_EXACT_INLINE KdScan kd_scan_cigar(const uint32_t *cg, uint32_
 }
 
 // The same scan for the read every aligner writes: one that lies INSIDE its contig and whose CIGAR consumes no more query
-// than the read has.  With  R = sum of the M / = / X / D / non-first-S lengths,  Q = sum of the M / = / X / I / S lengths,
-//      pos0 >= 0,   pos0 + R <= L,   Q <= sl
-// no rule of kd_scan_cigar about the contig's end or the query's end can fire at any op (the cursors are prefix sums of R
-// and Q: rem >= the op's length wherever it is compared, never `over`, min(len, rem) = min(len, room) = len), so the only
-// way left to be irregular is an op that writes behind a non-first soft clip, and every count is a plain sum: 32-bit adds
-// behind one-bit tests of the op kind (16 words of < 2^28 sum to < 2^32), a dozen instructions per op where the exact scan
-// needs sixty and 64-bit compares.  Returns false when the premise does not hold (a read at a contig's end, a CIGAR longer
-// than its read, POS 0, ...): the caller then runs kd_scan_cigar, which decides.  On C3 the exact scan was ~80 % of k_prep's
-// VALU instructions (0.38 ms for a kernel that streams 0.9 GB).
+// than the read has.  With  rem = sites left between the reference cursor and the contig's end (L - pos0 at the start),
+// Q = sum of the M / = / X / I / S lengths:
+//      0 <= pos0 <= L,   every M / = / X / D no longer than rem where it stands,   Q <= sl
+// no rule of kd_scan_cigar about the contig's or the query's end can fire (never `over`; min(len, room) = len; a non-first
+// soft clip advances min(len, rem) <= room sites, so a read whose trailing clip hangs over the contig's end -- what an aligner
+// makes of a read that does -- stays regular as kindel.py:74-81 has it), the only way left to be irregular is an op that
+// writes behind a non-first soft clip, and every count is a plain sum: 32-bit adds behind one-bit tests of the op kind (16
+// words of < 2^28 sum to < 2^32), fifteen instructions per op where the exact scan needs sixty and 64-bit compares.
+// Returns false when the premise does not hold (an aligned run or a deletion over a contig's end, a CIGAR longer than its
+// read, ...): the caller then leaves the read to kd_scan_cigar, which decides.
 __device__ __forceinline__ bool kd_scan_cigar_inside(const uint32_t *cg, uint32_t nc, int32_t pos0, uint32_t sl, uint32_t L,
                                                      const uint32_t *pre, KdScan &s) {
-    uint32_t R = 0, Q = 0, aligned = 0, walked = 0, n_ins = 0, insb = 0, cold = 0, lead = 0, nfs = 0, bad = 0;
+    const uint32_t rem0 = L - (uint32_t)pos0;     // (meaningful when 0 <= pos0 <= L: checked at the end)
+    uint32_t rem = rem0, Q = 0, aligned = 0, walked = 0, n_ins = 0, insb = 0, cold = 0, lead = 0, nfs = 0, bad = 0;
 #define KD_SCAN_STEP(c, first)                                                                        \
     {                                                                                                 \
         const uint32_t len = (c) >> 4, op = (c) & 15u;                                                \
         const uint32_t m = (0x181u >> op) & 1u, id = (0x006u >> op) & 1u, i_ = (0x002u >> op) & 1u;   \
-        const uint32_t sc = (0x010u >> op) & 1u, sn = (first) ? 0u : sc, w = m | id | sc;            \
+        const uint32_t sc = (0x010u >> op) & 1u, sn = (first) ? 0u : sc, md = m | (id & ~i_);         \
         bad |= nfs & (m | id | sn);                                                                   \
+        bad |= (md && len > rem) ? 1u : 0u;                                                           \
         aligned += m ? len : 0u;                                                                      \
-        walked += w ? len : 0u;                                                                       \
+        walked += (m | id | sc) ? len : 0u;                                                           \
         n_ins += i_;                                                                                  \
         insb += i_ ? len : 0u;                                                                        \
         cold |= i_ | sc;                                                                              \
-        R += (m | (id & ~i_) | sn) ? len : 0u;                                                        \
+        rem -= md ? len : sn ? (len < rem ? len : rem) : 0u;                                          \
         Q += (m | i_ | sc) ? len : 0u;                                                                \
         nfs |= sn;                                                                                    \
     }
@@ -120,8 +123,8 @@ __device__ __forceinline__ bool kd_scan_cigar_inside(const uint32_t *cg, uint32_
     }
 #undef KD_SCAN_STEP
     s.cls = KD_CLS_REG; s.cold = cold ? KD_INFO_COLD : 0u; s.lead = lead; s.n_ins = n_ins; s.ins_bases = insb;
-    s.span = R; s.aligned = aligned; s.walked = walked;
-    return pos0 >= 0 && !bad && (kd_u64)(uint32_t)pos0 + (kd_u64)R <= (kd_u64)L && Q <= sl;
+    s.span = rem0 - rem; s.aligned = aligned; s.walked = walked;
+    return pos0 >= 0 && (uint32_t)pos0 <= L && !bad && Q <= sl;
 }
 
 #ifndef KD_PREP_OCC

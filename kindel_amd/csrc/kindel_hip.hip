@@ -91,11 +91,13 @@ struct HipRt {
         return rc;
     }
     int graph_launch() { return bad(hipSetDevice(dev)) || bad(hipGraphLaunch(graph_exec, stream)); }
-    // small readbacks (status words) go through a pinned bounce buffer: no pageable staging in the runtime
+    // small readbacks (the status words, one cache line each: 4 KiB, 5 KiB in a profiling build) go through a pinned bounce buffer:
+    // no pageable staging in the runtime
+    static constexpr size_t KD_SMALL_COPY = 16384;
     void *pin = nullptr;
     int d2h_small(void *h, const void *d, size_t n) {
-        if (!pin && bad(hipHostMalloc(&pin, 4096, hipHostMallocDefault))) return 1;
-        if (n > 4096) return d2h(h, d, n);
+        if (!pin && bad(hipHostMalloc(&pin, KD_SMALL_COPY, hipHostMallocDefault))) return 1;
+        if (n > KD_SMALL_COPY) return d2h(h, d, n);
         if (bad(hipMemcpyAsync(pin, d, n, hipMemcpyDeviceToHost, stream))) return 1;
         if (bad(hipStreamSynchronize(stream))) return 1;
         memcpy(h, pin, n);
@@ -105,8 +107,8 @@ struct HipRt {
     // the same read-back in two halves: work queued between begin and end runs while the host waits for the copy
     hipEvent_t ev_copy = nullptr;
     int d2h_small_begin(const void *d, size_t n) {
-        if (n > 4096) return 1;
-        if (!pin && bad(hipHostMalloc(&pin, 4096, hipHostMallocDefault))) return 1;
+        if (n > KD_SMALL_COPY) return 1;
+        if (!pin && bad(hipHostMalloc(&pin, KD_SMALL_COPY, hipHostMallocDefault))) return 1;
         if (!ev_copy && bad(hipEventCreateWithFlags(&ev_copy, hipEventDisableTiming))) return 1;
         return bad(hipMemcpyAsync(pin, d, n, hipMemcpyDeviceToHost, stream)) || bad(hipEventRecord(ev_copy, stream));
     }

@@ -1,0 +1,24 @@
+// gpu_inflate_proto.hip -- PROTOTYPE driver of scripts/gpu_inflate_proto.h (not part of libkindel_hip.so):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC scripts/gpu_inflate_proto.hip -o exp/libgpu_inflate_proto.so
+// C-ABI for scripts/gpu_inflate_proto.py: all pointers are DEVICE pointers but `ms`.
+#include <hip/hip_runtime.h>
+#include "gpu_inflate_proto.h"
+
+extern "C" int gi_inflate_blocks(const uint8_t *comp, const GiBlock *blocks, uint32_t n_blocks, uint8_t *out, uint32_t *status, int repeat,
+                                 float *ms) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
+    float best = 1e30f;
+    for (int r = 0; r < (repeat > 0 ? repeat : 1); r++) {
+        hipEventRecord(e0, 0);
+        k_gpu_inflate<<<n_blocks, 64, 0, 0>>>(comp, blocks, n_blocks, out, status);
+        hipEventRecord(e1, 0);
+        if (hipEventSynchronize(e1) != hipSuccess) return 2;
+        float t = 0;
+        hipEventElapsedTime(&t, e0, e1);
+        if (t < best) best = t;
+    }
+    if (ms) *ms = best;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
