@@ -8,7 +8,7 @@
 //
 //   * input: the lanes hold 256 bytes of the compressed stream in one register (lane l = dword l), the next 256 in another;
 //     the bit buffer is refilled with v_readlane -- no memory latency on the symbol path;
-//   * tables in LDS: 10-bit primary table for literals / lengths, 8-bit for distances (entries: symbol << 4 | code length); a
+//   * tables in LDS: 10-bit primary table for literals / lengths, 8-bit for distances (16-bit entries: symbol << 4 | code length); a
 //     longer code (rare: they belong to rare symbols) falls back to the canonical bit-by-bit walk over count[] / sorted[];
 //   * output: an 8 KiB ring in LDS; every completed 256 bytes are stored to HBM by all lanes at once (one dword each); a
 //     match whose source is still in the ring is copied LDS -> LDS by all lanes, an older one is read back from HBM
@@ -36,6 +36,14 @@ __device__ __forceinline__ uint32_t gi_readlane(uint32_t v, uint32_t lane) {
 static inline uint32_t gi_readlane(uint32_t v, uint32_t lane) { return kd_shfl(v, lane); }
 #endif
 
+// a value every lane holds alike, moved to a scalar register: the whole symbol walk (bit buffer, cursors, table entries) is
+// wave-uniform, and on the scalar unit it costs one issue cycle per step instead of a vector instruction's latency
+#ifndef KD_EMU
+__device__ __forceinline__ uint32_t gi_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+#else
+static inline uint32_t gi_uni(uint32_t v) { return v; }
+#endif
+
 #define GI_RING 8192u
 #define GI_RING_MASK (GI_RING - 1u)
 #define GI_NEAR (GI_RING - 512u)      // a match at most this far back is copied inside the ring
@@ -50,7 +58,7 @@ struct __attribute__((packed, aligned(1))) GiU32 { uint32_t v; };
 struct GiBlock { unsigned long long in_off, out_off; uint32_t in_len, out_len; };
 
 // one Huffman code: primary table + what the canonical walk needs
-struct GiCode { uint32_t *table; uint16_t *cnt; uint16_t *sorted; uint32_t bits; };
+struct GiCode { uint16_t *table; uint16_t *cnt; uint16_t *sorted; uint32_t bits; };
 
 // Serial part of a table's construction (lane 0; `flag` = 0 if the lengths do not form a code zlib would accept):
 // counts per length, the symbols sorted by (length, value).
@@ -109,14 +117,14 @@ __device__ __forceinline__ uint32_t gi_take(GiStream &s, uint32_t n) {
 }
 // one symbol of code c (the bit buffer holds > 32 bits); 0xffffffff = no such code word
 __device__ __forceinline__ uint32_t gi_symbol(GiStream &s, const GiCode &c) {
-    const uint32_t e = c.table[(uint32_t)s.bb & ((1u << c.bits) - 1u)];
+    const uint32_t e = gi_uni(c.table[(uint32_t)s.bb & ((1u << c.bits) - 1u)]);
     if (e & 15u) { s.bb >>= (e & 15u); s.bc -= (e & 15u); return e >> 4; }
     uint32_t code = 0, first = 0, index = 0;      // a code longer than the primary index: the canonical walk, bit by bit
     for (uint32_t l = 1; l <= 15; l++) {
         code |= (uint32_t)(s.bb & 1ull);
         s.bb >>= 1; s.bc -= 1;
-        const uint32_t cn = c.cnt[l];
-        if (code < first + cn) return c.sorted[index + (code - first)];
+        const uint32_t cn = gi_uni(c.cnt[l]);
+        if (code < first + cn) return gi_uni(c.sorted[index + (code - first)]);
         index += cn; first += cn; first <<= 1; code <<= 1;
     }
     return 0xffffffffu;
@@ -127,7 +135,7 @@ __device__ __forceinline__ uint32_t gi_symbol(GiStream &s, const GiCode &c) {
 __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const GiBlock *blocks, uint32_t n_blocks, uint8_t *out,
                                                     uint32_t *status) {
     __shared__ __attribute__((aligned(16))) uint8_t ring[GI_RING];
-    __shared__ uint32_t t_lit[1u << GI_LIT_BITS], t_dist[1u << GI_DIST_BITS], t_cl[1u << GI_CL_BITS];
+    __shared__ uint16_t t_lit[1u << GI_LIT_BITS], t_dist[1u << GI_DIST_BITS], t_cl[1u << GI_CL_BITS];
     __shared__ uint16_t cnt_lit[16], cnt_dist[16], cnt_cl[16], srt_lit[288], srt_dist[32], srt_cl[19];
     __shared__ uint8_t lens[288 + 32 + 4];
     __shared__ uint32_t s_flag;
@@ -158,9 +166,9 @@ __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const G
         GI_WAVE_SYNC();
         if (lane == 0) gi_build_serial(ln, n, c, cl_code, &s_flag);
         GI_WAVE_SYNC();
-        for (uint32_t i = lane; i < (1u << c.bits); i += 64u) c.table[i] = gi_entry(c, i);
+        for (uint32_t i = lane; i < (1u << c.bits); i += 64u) c.table[i] = (uint16_t)gi_entry(c, i);
         GI_WAVE_SYNC();
-        return s_flag != 0;
+        return gi_uni(s_flag) != 0;
     };
     for (bool last = false; !last && err == GI_OK;) {
         gi_refill(s, lane);
@@ -229,7 +237,7 @@ __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const G
             }
             if (bad) { err = GI_E_CODES; break; }
             GI_WAVE_SYNC();
-            if (lens[256] == 0) { err = GI_E_CODES; break; }
+            if (gi_uni(lens[256]) == 0) { err = GI_E_CODES; break; }
         }
         // literal / length code over lens[0, hlit), distance code over lens[hlit, hlit + hdist)
         if (!build(lens, hlit, c_lit, false) || !build(lens + hlit, hdist, c_dist, false)) { err = GI_E_CODES; break; }
