@@ -58,7 +58,10 @@ def main():
                          "config-sized input, work-balanced contiguous position intervals (whole contigs where possible), every "
                          "rank takes its reads from the one shared batch (total work fixed)")
     ap.add_argument("--one-scaling", action="store_true", help="N > 1: do not also measure the other scaling rule")
-    ap.add_argument("--shuffle", action="store_true", help="permute the read order (unsorted input: exercises the device bucket sort)")
+    ap.add_argument("--shuffle", nargs="?", const="records", default="", choices=["records", "index"],
+                    help="permute the read order (unsorted input: exercises the device bucket sort).  records (default): the batch a decoder "
+                         "hands over for an unsorted FILE -- bases and CIGAR words lie in record order too; index: only the per-read arrays "
+                         "are permuted, every read's bases / CIGAR stay where the sorted batch had them (rounds 1 - 2; a layout no file produces)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=0.0, help="fraction of reads for the CPU baseline (0 = auto)")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="time the eager submission only (no kd_step / hipGraph replay)")
@@ -127,9 +130,7 @@ def main():
         t_gen = time.time() - t0
         n_reads = int(batch["contig"].numel())
         if args.shuffle:
-            perm = torch.randperm(n_reads, device=dev)
-            for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
-                batch[k] = batch[k][perm].contiguous()
+            batch = synth.shuffled(batch, mode=args.shuffle)
         # events are credited to the rank that owns the read's start, so every read counts once
         if strong:      # every rank holds the whole CIGAR array: the totals of the ONE input, no reduction needed
             cg = full_cigar[: full_words].long()

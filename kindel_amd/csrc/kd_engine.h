@@ -54,6 +54,7 @@ struct KdEngine {
     };
     Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_rows, b_rowinfo, b_rowoff, b_longacc, b_coldcnt, b_coldev, b_coldpool;
     Buf b_stage[9];
+    Buf b_sortrows, b_sortseg;   // unsorted input: per-workgroup bin counts / starts and their segment totals (kd_plan.h)
     Buf b_smallcig;   // a batch with fewer than 4 CIGAR words: its padded copy
     Buf b_srec;   // an unsorted batch's regular reads in window order: KdSortRec[] (k_sort_scatter_reads)
     Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
@@ -170,7 +171,7 @@ struct KdEngine {
                       &b_tilesum, &b_tilemm, &b_tileoff, &b_coff};
         for (Buf *b : all) release(*b);
         for (Buf &b : b_stage) release(b);
-        release(b_srec); release(b_smallcig);
+        release(b_srec); release(b_smallcig); release(b_sortrows); release(b_sortseg);
         if (d_tab) rt.free(d_tab);
         if (d_clen) rt.free(d_clen);
         if (d_cbase) rt.free(d_cbase);
@@ -400,13 +401,21 @@ struct KdEngine {
                     kd_u64 *bo = (kd_u64 *)b_binoff.p;
                     if (rt.memset(bc, 0, n_cnt * 4)) return hipfail("k_sort_*");
                     if (lds_bins) {
-                        // bin counters private to a workgroup in LDS (kd_plan.h): two workgroups of 1024 lanes per CU, one chunk each
-                        const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)rt.n_cus() * ((size_t)n_bins * 4 <= (size_t)72 * 1024 ? 2 : 1), (ne + KD_SORT_BLOCK - 1) / KD_SORT_BLOCK));
+                        // bin counters private to a workgroup in LDS (kd_plan.h): two workgroups of 1024 lanes per CU, one chunk each;
+                        // no global atomics: count rows -> column scan -> bin offsets -> scatter
+                        uint64_t want_wgs = (uint64_t)rt.n_cus() * ((size_t)n_bins * 4 <= (size_t)72 * 1024 ? 2 : 1);
+                        if (const char *e = getenv("KD_SORT_WGS")) want_wgs = (uint64_t)std::max(1, atoi(e));   // (knob: tests, measurement)
+                        const unsigned gr = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want_wgs, (ne + KD_SORT_BLOCK - 1) / KD_SORT_BLOCK));
                         const kd_u64 chunk = (((kd_u64)ne + gr - 1) / gr + KD_SORT_BLOCK - 1) / KD_SORT_BLOCK * KD_SORT_BLOCK;
-                        if (rt.launch("k_sort_count", k_sort_count_lds, gr, KD_SORT_BLOCK, (size_t)n_bins * 4, info, (kd_u64)ne, chunk, W, n_bins, bc) ||
+                        const unsigned n_seg = (gr + KD_SORT_SEG - 1) / KD_SORT_SEG;
+                        if ((rc2 = ensure(b_sortrows, (size_t)gr * n_bins * 4)) || (rc2 = ensure(b_sortseg, (size_t)n_seg * n_bins * 4))) return rc2;
+                        uint32_t *rows = (uint32_t *)b_sortrows.p, *segt = (uint32_t *)b_sortseg.p;
+                        if (rt.launch("k_sort_count", k_sort_count_lds, gr, KD_SORT_BLOCK, (size_t)n_bins * 4, info, (kd_u64)ne, chunk, W, n_bins, rows) ||
+                            rt.launch("k_sort_colscan", k_sort_colscan, (unsigned)(((uint64_t)n_seg * n_bins + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, rows, gr, n_bins, segt) ||
+                            rt.launch("k_sort_colscan2", k_sort_colscan2, (n_bins + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, segt, n_seg, n_bins, bc) ||
                             rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, (uint32_t)n_cnt) ||
-                            rt.launch("k_sort_scatter", k_sort_scatter_lds, gr, KD_SORT_BLOCK, (size_t)n_bins * 4, info, R, chunk, W, n_bins, bc,
-                                      (const kd_u64 *)bo, (KdSortRec *)b_srec.p))
+                            rt.launch("k_sort_scatter", k_sort_scatter_lds, gr, KD_SORT_BLOCK, (size_t)n_bins * 4, info, R, chunk, W, n_bins, (const uint32_t *)rows,
+                                      (const uint32_t *)segt, (const kd_u64 *)bo, (KdSortRec *)b_srec.p))
                             return hipfail("k_sort_*");
                     } else {
                         const unsigned gr = (unsigned)((ne + KD_BLOCK - 1) / KD_BLOCK);

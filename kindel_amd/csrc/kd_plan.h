@@ -98,15 +98,19 @@ k_sort_scatter_reads(const KdRInfo *rinfo, KdReads rd, uint32_t W, uint32_t *bin
 }
 
 // The same two passes with the bin counters PRIVATE to a workgroup in LDS (round 3; an unsorted batch whose bin table fits:
-// n_bins * 4 bytes of LDS, ~ 17 Mbp of reference at the default window).  A workgroup of KD_SORT_BLOCK threads takes one
-// contiguous chunk of the batch; its reads hit LDS counters (random addresses cost an LDS atomic, not a device-scope one),
-// and only the chunk's non-empty bins go to the global table -- n_workgroups * n_bins atomics at most instead of one per read
-// (C3 shuffled: 1.7 x 10^7 -> < 4 x 10^6, spread evenly).  k_sort_scatter_lds counts its chunk again, RESERVES each bin's
-// slots with one returning atomic, and hands out the slots from LDS: the reads of one chunk that fall into one window land
-// next to each other.
+// n_bins * 4 bytes of LDS, ~ 17 Mbp of reference at the default window) and NO global atomics.  A workgroup of KD_SORT_BLOCK
+// threads takes one contiguous chunk of the batch; its reads hit LDS counters (random addresses cost an LDS atomic, not a
+// device-scope one) and the workgroup leaves its counts as ONE ROW of a (workgroups x bins) matrix -- plain coalesced stores.
+// The slot range of (workgroup g, bin b) starts at  bin_off[b] + sum of rows[g' < g][b]:  a column scan in two small kernels
+// (k_sort_colscan: KD_SORT_SEG rows per thread, all loads in flight together; k_sort_colscan2: the segment totals of a bin),
+// then k_sort_scatter_lds reads its row of starts and hands the slots out from LDS: the reads of one chunk that fall into one
+// window land next to each other.  (Until the k_prep experiments of round 3 the workgroups reserved their ranges with one
+// RETURNING atomic per bin and workgroup on a table of adjacent words: 5.7 x 10^6 atomics, 16 000 per 128-byte line, which
+// serialise per line -- profiles/r03_kprep_experiments.json.)
 #define KD_SORT_BLOCK 1024
+#define KD_SORT_SEG 32
 __global__ void __launch_bounds__(KD_SORT_BLOCK)
-k_sort_count_lds(const KdRInfo *rinfo, kd_u64 n_reads, kd_u64 chunk, uint32_t W, uint32_t n_bins, uint32_t *bin_cnt) {
+k_sort_count_lds(const KdRInfo *rinfo, kd_u64 n_reads, kd_u64 chunk, uint32_t W, uint32_t n_bins, uint32_t *rows) {
     KD_DYN_SHARED(uint32_t, s_bins);
     for (uint32_t b = threadIdx.x; b < n_bins; b += KD_SORT_BLOCK) s_bins[b] = 0;
     __syncthreads();
@@ -116,33 +120,46 @@ k_sort_count_lds(const KdRInfo *rinfo, kd_u64 n_reads, kd_u64 chunk, uint32_t W,
         if ((ri.span_cls & 3u) == KD_CLS_REG) atomicAdd(&s_bins[ri.gstart / W], 1u);
     }
     __syncthreads();
-    // (workgroups start their flush at different bins: they finish together and would otherwise sweep the table in step)
-    const uint32_t rot = (uint32_t)(((kd_u64)blockIdx.x * n_bins) / gridDim.x);
-    for (uint32_t x = threadIdx.x; x < n_bins; x += KD_SORT_BLOCK) {
-        uint32_t b = x + rot; b = b >= n_bins ? b - n_bins : b;
-        const uint32_t v = s_bins[b];
-        if (v) atomicAdd(&bin_cnt[b], v);
+    uint32_t *row = rows + (kd_u64)blockIdx.x * n_bins;
+    for (uint32_t b = threadIdx.x; b < n_bins; b += KD_SORT_BLOCK) row[b] = s_bins[b];
+}
+// thread (segment s, bin b): rows[s * SEG + k][b], k < SEG, -> their exclusive prefix sums in place, seg_tot[s][b] = their sum
+__global__ void __launch_bounds__(KD_BLOCK)
+k_sort_colscan(uint32_t *rows, uint32_t n_rows, uint32_t n_bins, uint32_t *seg_tot) {
+    const kd_u64 x = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    const uint32_t n_seg = (n_rows + KD_SORT_SEG - 1) / KD_SORT_SEG;
+    if (x >= (kd_u64)n_seg * n_bins) return;
+    const uint32_t s = (uint32_t)(x / n_bins), b = (uint32_t)(x % n_bins);
+    const uint32_t r0 = s * KD_SORT_SEG;
+    uint32_t v[KD_SORT_SEG];
+#pragma unroll
+    for (uint32_t k = 0; k < KD_SORT_SEG; k++) v[k] = r0 + k < n_rows ? rows[(kd_u64)(r0 + k) * n_bins + b] : 0u;
+    uint32_t run = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < KD_SORT_SEG; k++) {
+        if (r0 + k < n_rows) rows[(kd_u64)(r0 + k) * n_bins + b] = run;
+        run += v[k];
     }
+    seg_tot[(kd_u64)s * n_bins + b] = run;
+}
+// thread per bin: the segment totals of the bin -> their exclusive prefix sums in place, bin_cnt[b] = the bin's reads
+__global__ void __launch_bounds__(KD_BLOCK)
+k_sort_colscan2(uint32_t *seg_tot, uint32_t n_seg, uint32_t n_bins, uint32_t *bin_cnt) {
+    const uint32_t b = blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (b >= n_bins) return;
+    uint32_t run = 0;
+    for (uint32_t s = 0; s < n_seg; s++) { const uint32_t v = seg_tot[(kd_u64)s * n_bins + b]; seg_tot[(kd_u64)s * n_bins + b] = run; run += v; }
+    bin_cnt[b] = run;
 }
 __global__ void __launch_bounds__(KD_SORT_BLOCK)
-k_sort_scatter_lds(const KdRInfo *rinfo, KdReads rd, kd_u64 chunk, uint32_t W, uint32_t n_bins, uint32_t *bin_fill,
-                   const kd_u64 *bin_off, KdSortRec *rec) {
+k_sort_scatter_lds(const KdRInfo *rinfo, KdReads rd, kd_u64 chunk, uint32_t W, uint32_t n_bins, const uint32_t *rows,
+                   const uint32_t *seg_tot, const kd_u64 *bin_off, KdSortRec *rec) {
     KD_DYN_SHARED(uint32_t, s_bins);
-    for (uint32_t b = threadIdx.x; b < n_bins; b += KD_SORT_BLOCK) s_bins[b] = 0;
+    // the first slot of every bin for this workgroup's chunk (sorted positions are < n_reads < 2^32)
+    const uint32_t *row = rows + (kd_u64)blockIdx.x * n_bins, *seg = seg_tot + (kd_u64)(blockIdx.x / KD_SORT_SEG) * n_bins;
+    for (uint32_t b = threadIdx.x; b < n_bins; b += KD_SORT_BLOCK) s_bins[b] = (uint32_t)bin_off[b] + seg[b] + row[b];
     __syncthreads();
     const kd_u64 c0 = (kd_u64)blockIdx.x * chunk, c1 = c0 + chunk < rd.n ? c0 + chunk : rd.n;
-    for (kd_u64 i = c0 + threadIdx.x; i < c1; i += KD_SORT_BLOCK) {
-        const KdRInfo ri = rinfo[i];
-        if ((ri.span_cls & 3u) == KD_CLS_REG) atomicAdd(&s_bins[ri.gstart / W], 1u);
-    }
-    __syncthreads();
-    const uint32_t rot = (uint32_t)(((kd_u64)blockIdx.x * n_bins) / gridDim.x);
-    for (uint32_t x = threadIdx.x; x < n_bins; x += KD_SORT_BLOCK) {
-        uint32_t b = x + rot; b = b >= n_bins ? b - n_bins : b;
-        const uint32_t v = s_bins[b];
-        if (v) s_bins[b] = (uint32_t)(bin_off[b] + atomicAdd(&bin_fill[b], v));   // (sorted positions are < n_reads < 2^32)
-    }
-    __syncthreads();
     for (kd_u64 i = c0 + threadIdx.x; i < c1; i += KD_SORT_BLOCK) {
         const KdRInfo ri = rinfo[i];
         if ((ri.span_cls & 3u) != KD_CLS_REG) continue;

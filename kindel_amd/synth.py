@@ -298,6 +298,41 @@ def make(config, scale=1.0, device="cpu", shard=None):
     return fn(device=device, shard=shard, **cfg)
 
 
+def shuffled(batch, mode="records", seed=None):
+    """The batch with its reads in random order (unsorted input).  mode "records": what a decoder hands over for an unsorted FILE --
+    bases and CIGAR words lie in record order too, offsets ascend with the read index; "index": only the per-read arrays are
+    permuted, every read's bases / CIGAR stay where the sorted batch had them (a layout no file produces: rounds 1 - 2 measured it)."""
+    dev = batch["contig"].device
+    n = int(batch["contig"].numel())
+    gen = None
+    if seed is not None:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+    perm = torch.randperm(n, device=dev, generator=gen)
+    out = dict(batch)
+    for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+        out[k] = batch[k][perm].contiguous()
+    if mode == "index":
+        return out
+
+    def regroup(data, off, cnt, pad):
+        cnt = cnt.long()
+        new_off = torch.cumsum(cnt, 0) - cnt
+        total = int(cnt.sum())
+        res = torch.zeros(total + pad, dtype=data.dtype, device=dev)
+        step = 1 << 24                      # reads per piece: bounds the index tensors
+        for a0 in range(0, n, step):
+            c, no, oo = cnt[a0:a0 + step], new_off[a0:a0 + step], off[a0:a0 + step].long()
+            seg = torch.repeat_interleave(torch.arange(c.numel(), device=dev), c)
+            dst = torch.arange(int(no[0]), int(no[0]) + int(c.sum()), device=dev)
+            res[dst] = data[oo[seg] + (dst - no[seg])]
+        return res, new_off.to(off.dtype), total
+
+    out["cigar"], out["cig_off"], out["cigar_words"] = regroup(batch["cigar"], out["cig_off"], out["n_cig"], 2)
+    out["seq4"], out["seq_off"], out["seq4_bytes"] = regroup(batch["seq4"], out["seq_off"], (out["seq_len"].long() + 1) // 2, 64)
+    return out
+
+
 def to_numpy(batch):
     """torch batch -> dict of numpy arrays in the dtypes of kd_batch (for the oracle / kd_push_batch)."""
     dt = dict(contig=np.uint32, pos0=np.int32, flag=np.uint32, seq_off=np.uint64, seq_len=np.uint32,

@@ -86,6 +86,23 @@ def test_unsorted_batch_of_several_sort_chunks(emu_lib):
         P.assert_matches_oracle(run)
 
 
+def test_unsorted_batch_sorted_by_more_workgroups_than_one_scan_segment(emu_lib, monkeypatch):
+    # the slot range of (workgroup, bin) follows from a column scan over the workgroups' count rows, KD_SORT_SEG = 32 rows per
+    # thread and then over the segments: 70 workgroups = 3 segments, the last one partial (KD_SORT_WGS: the engine's knob);
+    # the shuffled batch in both layouts -- payload in record order (a decoder's output) and left in place
+    monkeypatch.setenv("KD_SORT_WGS", "70")
+    import torch
+    tb = synth.short_reads([30000], 400, seed=8)
+    assert int(tb["contig"].numel()) > 70 * 1024
+    ref = P.Run(emu_lib, synth.to_numpy(tb), window=448)
+    for mode in ("records", "index"):
+        run = P.Run(emu_lib, synth.to_numpy(synth.shuffled(tb, mode=mode, seed=5)), window=448)
+        assert run.info["windowed"] == 1 and run.info["unsorted"] > 0
+        for cid in ref.order:
+            assert np.array_equal(run.tables[cid], ref.tables[cid]) and run.cns[cid][0] == ref.cns[cid][0]
+    P.assert_matches_oracle(run)
+
+
 def test_multiple_pushes_accumulate(emu_lib):
     b = P.subset(P.load_fixture("segemehl__2.1.sub_test"), 100, 700)
     P.assert_matches_oracle(P.Run(emu_lib, b, window=256, n_pushes=3))
