@@ -43,6 +43,7 @@ extern "C" {
 #define KD_E_ARG (-6)    /* bad argument / bad state                                         */
 #define KD_E_IO (-7)     /* decoder: unreadable or malformed SAM/BAM                         */
 #define KD_E_INTERNAL (-8)
+#define KD_E_UNSUPPORTED (-10) /* kd_push_bam_gpu: this file needs the host decoder (CG-tag CIGARs, a chain the device walk could not verify) */
 #define KD_E_NOREF (-9)  /* KeyError   : a record names a reference without @SQ line   kindel.py:151 (message = the name) */
 
 /* table channels of kd_get_tables(); order of the reference's dicts is A,T,G,C,N (kindel.py:29) */
@@ -245,6 +246,27 @@ int kd_host_inflate(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t o
 /* The CRC-32 the BGZF reader checks every inflated block with (kd_crc32.h; zlib's crc32 convention): htslib refuses a block whose
    trailer does not match, and so does this reader. */
 uint32_t kd_host_crc32(const uint8_t *data, uint64_t len);
+
+/* ---- device-side ingest (opt-in) ----------------------------------------
+ * parse_bam's record iteration (kindel.py:131-153) with the FILE's bytes as the only thing the host touches: the BGZF blocks are
+ * inflated on the GPU (one wavefront per block), the BAM record chain is walked there from speculative, verified starts, the
+ * kd_batch arrays are written in HBM and pushed like kd_push_batch_device would.  kd_bgzf_plan_*: the host's share -- the file
+ * mapped, the BGZF block table, the BAM header (the first blocks inflated on the host) -- also what a caller needs to create
+ * the context (contig table).  kd_push_bam_gpu returns KD_E_UNSUPPORTED when the file needs the host decoder (SAM text / plain
+ * gzip never get here: kd_bgzf_plan_open refuses them with KD_E_UNSUPPORTED too); KD_E_IO for a corrupt file.
+ * stats (may be NULL): [0] records seen, [1] records kept (mapped), [2] inflated bytes, [3] BGZF blocks,
+ * [4] us host plan, [5] us H2D + kernels until the batch exists, [6] us push. */
+typedef struct kd_bgzf_plan kd_bgzf_plan;
+int kd_bgzf_plan_open(kd_bgzf_plan **out, const char *path);
+uint32_t kd_bgzf_plan_n_contigs(const kd_bgzf_plan *p);
+const char *kd_bgzf_plan_contig_name(const kd_bgzf_plan *p, uint32_t i);
+uint32_t kd_bgzf_plan_contig_len(const kd_bgzf_plan *p, uint32_t i);
+/* the plan's arrays: file bytes, n_blocks x {payload offset, inflated offset, payload bytes, inflated bytes} (blocks that inflate
+   to nothing left out), length of the inflated stream, offset of the first record in it */
+int kd_bgzf_plan_view(const kd_bgzf_plan *p, const uint8_t **file, uint64_t *file_bytes, const void **blocks, uint32_t *n_blocks,
+                      uint64_t *total_out, uint64_t *hdr_end);
+void kd_bgzf_plan_close(kd_bgzf_plan *p);
+int kd_push_bam_gpu(kd_ctx *ctx, const kd_bgzf_plan *plan, uint64_t stats[8]);
 
 /* ---- tool: write a host batch as a BGZF-compressed BAM (synthetic inputs for end-to-end runs; parallel deflate) ---- */
 int kd_write_bam(const char *path, const kd_batch *host_batch, uint32_t n_contigs, const char *const *names,

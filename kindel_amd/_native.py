@@ -16,6 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libkindel_hip.so")
 
+KD_E_UNSUPPORTED = -10
 KD_OK, KD_E_BASE, KD_E_RANGE, KD_E_CIGAR, KD_E_HIP, KD_E_NOMEM, KD_E_ARG, KD_E_IO, KD_E_INTERNAL, KD_E_NOREF = (
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9)
 KD_MODE_AUTO, KD_MODE_GLOBAL, KD_MODE_WINDOW, KD_MODE_STRIP, KD_MODE_COOP = 0, 1, 2, 3, 4
@@ -31,7 +32,8 @@ ABI_SYMBOLS = (
     "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error "
     "kd_stream_open kd_stream_n_contigs kd_stream_contig_name kd_stream_contig_len kd_stream_next kd_stream_n_records "
     "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_write_bam kd_host_threads kd_host_inflate kd_host_crc32 "
-    "kd_bgzf_index kd_decode_open_span kd_step"
+    "kd_bgzf_index kd_decode_open_span kd_step kd_bgzf_plan_open kd_bgzf_plan_n_contigs kd_bgzf_plan_contig_name kd_bgzf_plan_contig_len "
+    "kd_bgzf_plan_view kd_bgzf_plan_close kd_push_bam_gpu"
 ).split()
 
 #: the reference exception each error code stands for (kindel.py:47,51-52,57,61,67,72,75,79)
@@ -101,6 +103,17 @@ class Library:
         L.kd_profile_enable.argtypes = [p, C.c_int]
         L.kd_profile_get.argtypes = [p, C.POINTER(u32), p, p, p]
         L.kd_profile_reset.argtypes = [p]
+        L.kd_bgzf_plan_open.argtypes = [C.POINTER(p), C.c_char_p]
+        L.kd_bgzf_plan_n_contigs.argtypes = [p]
+        L.kd_bgzf_plan_n_contigs.restype = u32
+        L.kd_bgzf_plan_contig_name.argtypes = [p, u32]
+        L.kd_bgzf_plan_contig_name.restype = C.c_char_p
+        L.kd_bgzf_plan_contig_len.argtypes = [p, u32]
+        L.kd_bgzf_plan_contig_len.restype = u32
+        L.kd_bgzf_plan_view.argtypes = [p, C.POINTER(p), C.POINTER(u64), C.POINTER(p), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
+        L.kd_bgzf_plan_close.argtypes = [p]
+        L.kd_bgzf_plan_close.restype = None
+        L.kd_push_bam_gpu.argtypes = [p, p, p]
         L.kd_decode_open.argtypes = [C.POINTER(p), C.c_char_p, C.c_int]
         L.kd_bgzf_index.argtypes = [C.c_char_p, C.POINTER(u64), p, u64]
         L.kd_decode_open_span.argtypes = [C.POINTER(p), C.c_char_p, C.c_int, u64, u64, p]
@@ -366,6 +379,38 @@ def decode_file(path, threads=0, lib=None):
     return out
 
 
+class UnsupportedByGpuIngest(KindelNativeError):
+    """The device-side ingest cannot read this file (SAM text, plain gzip, CG-tag CIGARs, a record chain it could not verify):
+    the host decoder does."""
+
+
+class BgzfPlan:
+    """The host's share of the device-side ingest (kd_bgzf_plan_*): the BAM file mapped, its BGZF block table, its header."""
+
+    def __init__(self, path, lib=None):
+        self.lib = lib or default_library()
+        h = C.c_void_p()
+        rc = self.lib.dll.kd_bgzf_plan_open(C.byref(h), os.fsencode(str(path)))
+        if rc:
+            msg = "%s: %s" % (path, self.lib.dll.kd_decode_last_error().decode())
+            raise (UnsupportedByGpuIngest if rc == KD_E_UNSUPPORTED else _EXC.get(rc, KindelNativeError))(msg)
+        self._h = h
+        n = self.lib.dll.kd_bgzf_plan_n_contigs(h)
+        self.contig_names = [self.lib.dll.kd_bgzf_plan_contig_name(h, i).decode() for i in range(n)]
+        self.contig_lens = np.asarray([self.lib.dll.kd_bgzf_plan_contig_len(h, i) for i in range(n)], np.uint32)
+
+    def close(self):
+        if self._h:
+            self.lib.dll.kd_bgzf_plan_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 class Engine:
     """One kd_ctx: device tables for a set of contigs on one GPU."""
 
@@ -470,6 +515,17 @@ class Engine:
             raise KeyError(self.lib.dll.kd_last_error(self._h).decode())
         self._check(rc, "kd_push_stream")
         return dict(batches=int(st[0]), decode_s=st[1] / 1e6, push_s=st[2] / 1e6, wall_s=st[3] / 1e6)
+
+    def push_bam_gpu(self, plan):
+        """The whole BAM file of a BgzfPlan through the DEVICE-side ingest (kd_push_bam_gpu): BGZF inflate, record walk and the
+        batch arrays on the GPU, then the pileup.  UnsupportedByGpuIngest: read the file with the host decoder instead.
+        -> dict(records, kept, inflated_bytes, blocks, ingest_s, push_s)"""
+        st = (C.c_uint64 * 8)()
+        rc = self.lib.dll.kd_push_bam_gpu(self._h, plan._h, st)
+        if rc == KD_E_UNSUPPORTED:
+            raise UnsupportedByGpuIngest(self.lib.dll.kd_last_error(self._h).decode())
+        self._check(rc, "kd_push_bam_gpu")
+        return dict(records=int(st[0]), kept=int(st[1]), inflated_bytes=int(st[2]), blocks=int(st[3]), ingest_s=st[5] / 1e6, push_s=st[6] / 1e6)
 
     def contig_first(self):
         """uint64[n_contigs]: index of each contig's first record over all pushed records, 2^64-1 = none"""

@@ -200,6 +200,19 @@ int kd_push_stream(kd_ctx *ctx, kd_stream *s, uint64_t stats[4]) {
     return rc;
 }
 
+int kd_push_bam_gpu(kd_ctx *ctx, const kd_bgzf_plan *plan, uint64_t stats[8]) {
+    if (!ctx || !plan) return KD_E_ARG;
+    const uint8_t *file = nullptr; const void *blocks = nullptr;
+    uint64_t file_bytes = 0, total = 0, hdr_end = 0;
+    uint32_t n_blocks = 0;
+    int rc = kd_bgzf_plan_view(plan, &file, &file_bytes, &blocks, &n_blocks, &total, &hdr_end);
+    if (rc) return ctx->e.fail(rc, "kd_push_bam_gpu: more than 2^32 BGZF blocks");
+    bool same = kd_bgzf_plan_n_contigs(plan) == ctx->e.n_contigs;
+    for (uint32_t c = 0; same && c < ctx->e.n_contigs; c++) same = kd_bgzf_plan_contig_len(plan, c) == ctx->e.clen[c];
+    if (!same) return ctx->e.fail(KD_E_ARG, "kd_push_bam_gpu: the file's @SQ table differs from the context's contig table");
+    return ctx->e.ingest_bam(file, file_bytes, blocks, n_blocks, total, hdr_end, stats);
+}
+
 int kd_decode_push_file(kd_ctx *ctx, const char *path, int n_threads, uint64_t chunk_bytes, uint64_t stats[4]) {
     if (!ctx || !path) return KD_E_ARG;
     kd_stream *s = nullptr;

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1222,6 +1223,66 @@ int kd_decode_open_span(kd_file **out, const char *path, int n_threads, uint64_t
 }
 
 const char *kd_decode_last_error(void) { return g_decode_error.c_str(); }
+/* ---- the host's share of the device-side ingest (kd_ingest.h): file mapped, BGZF block table, BAM header ---- */
+struct kd_bgzf_plan {
+    RawView raw;
+    struct Blk { uint64_t in_off, out_off; uint32_t in_len, out_len; };     // = GiBlock (kd_gpu_inflate.h)
+    std::vector<Blk> blocks;
+    uint64_t total = 0, hdr_end = 0;
+    std::vector<std::string> names;
+    std::vector<uint32_t> lens;
+};
+int kd_bgzf_plan_open(kd_bgzf_plan **out, const char *path) {
+    if (!out || !path) return KD_E_ARG;
+    *out = nullptr;
+    std::unique_ptr<kd_bgzf_plan> P(new kd_bgzf_plan());
+    if (!P->raw.open(path)) { g_decode_error = std::string("cannot read ") + path; return KD_E_IO; }
+    const uint8_t *raw = P->raw.data();
+    const size_t n = P->raw.size();
+    if (n < 18 || raw[0] != 0x1f || raw[1] != 0x8b) { g_decode_error = "not a BGZF file (SAM text or uncompressed: the host decoder reads those)"; return KD_E_UNSUPPORTED; }
+    std::vector<Block> blocks;
+    size_t o = 0, total = 0;
+    if (!scan_bgzf_some(raw, n, &o, blocks, &total, ~(size_t)0 >> 1) || o != n) {
+        g_decode_error = blocks.empty() ? "not a BGZF file (plain gzip: the host decoder reads it)" : "malformed or truncated BGZF block";
+        return blocks.empty() ? KD_E_UNSUPPORTED : KD_E_IO;
+    }
+    P->total = total;
+    // the BAM header: inflate blocks on the host until it is complete
+    Arr<uint8_t> head;
+    size_t have = 0, b = 0;
+    for (;;) {
+        bool need_more = false;
+        size_t hdr = 0;
+        P->names.clear(); P->lens.clear();
+        const int rc = have ? parse_bam_header(head.data(), have, P->names, P->lens, &hdr, &need_more) : KD_E_IO;
+        if (have && rc == KD_OK) { P->hdr_end = hdr; break; }
+        if (have && !need_more) return KD_E_IO;
+        if (b >= blocks.size()) { g_decode_error = "truncated BAM header"; return KD_E_IO; }
+        if (!head.resize(have + blocks[b].out_len)) { g_decode_error = "out of memory"; return KD_E_NOMEM; }
+        if (!inflate_raw(raw + blocks[b].in_off, blocks[b].in_len, head.data() + have, blocks[b].out_len)) { g_decode_error = "BGZF inflate failed"; return KD_E_IO; }
+        have += blocks[b].out_len; b++;
+    }
+    for (const Block &B : blocks)
+        if (B.out_len) P->blocks.push_back({(uint64_t)B.in_off, (uint64_t)B.out_off, (uint32_t)B.in_len, (uint32_t)B.out_len});
+    *out = P.release();
+    return KD_OK;
+}
+uint32_t kd_bgzf_plan_n_contigs(const kd_bgzf_plan *p) { return p ? (uint32_t)p->lens.size() : 0; }
+const char *kd_bgzf_plan_contig_name(const kd_bgzf_plan *p, uint32_t i) { return p && i < p->names.size() ? p->names[i].c_str() : ""; }
+uint32_t kd_bgzf_plan_contig_len(const kd_bgzf_plan *p, uint32_t i) { return p && i < p->lens.size() ? p->lens[i] : 0; }
+int kd_bgzf_plan_view(const kd_bgzf_plan *p, const uint8_t **file, uint64_t *file_bytes, const void **blocks, uint32_t *n_blocks,
+                      uint64_t *total_out, uint64_t *hdr_end) {
+    if (!p) return KD_E_ARG;
+    if (file) *file = p->raw.data();
+    if (file_bytes) *file_bytes = p->raw.size();
+    if (blocks) *blocks = p->blocks.data();
+    if (n_blocks) *n_blocks = (uint32_t)p->blocks.size();
+    if (total_out) *total_out = p->total;
+    if (hdr_end) *hdr_end = p->hdr_end;
+    return p->blocks.size() > 0xffffffffULL ? KD_E_ARG : KD_OK;
+}
+void kd_bgzf_plan_close(kd_bgzf_plan *p) { delete p; }
+
 /* host threads the decoder uses by default: visible cores capped by the cgroup CPU quota */
 uint32_t kd_host_threads(void) { return hw_threads(); }
 int kd_host_inflate(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_len) {

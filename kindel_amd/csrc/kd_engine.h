@@ -10,6 +10,7 @@
 // consensus(insertions[pos]) (:420), consensus_run = consensus_sequence (:384-430).
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -54,6 +55,7 @@ struct KdEngine {
     };
     Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_rows, b_rowinfo, b_rowoff, b_longacc, b_coldcnt, b_coldev, b_coldpool;
     Buf b_stage[9];
+    Buf b_gi_file, b_gi_blocks, b_gi_out, b_gi_bstat, b_gi_start, b_gi_cnt, b_gi_tot, b_gi_recat;   // device-side ingest (kd_ingest.h)
     Buf b_sortrows, b_sortseg;   // unsorted input: per-workgroup bin counts / starts and their segment totals (kd_plan.h)
     Buf b_smallcig;   // a batch with fewer than 4 CIGAR words: its padded copy
     Buf b_srec;   // an unsorted batch's regular reads in window order: KdSortRec[] (k_sort_scatter_reads)
@@ -172,6 +174,7 @@ struct KdEngine {
         for (Buf *b : all) release(*b);
         for (Buf &b : b_stage) release(b);
         release(b_srec); release(b_smallcig); release(b_sortrows); release(b_sortseg);
+        for (Buf *g : {&b_gi_file, &b_gi_blocks, &b_gi_out, &b_gi_bstat, &b_gi_start, &b_gi_cnt, &b_gi_tot, &b_gi_recat}) release(*g);
         if (d_tab) rt.free(d_tab);
         if (d_clen) rt.free(d_clen);
         if (d_cbase) rt.free(d_cbase);
@@ -597,6 +600,69 @@ struct KdEngine {
         D.n_cig = (const uint32_t *)b_stage[6].p; D.seq4 = (const uint8_t *)b_stage[7].p;
         D.cigar = (const uint32_t *)b_stage[8].p;
         return push_device(D);
+    }
+
+    // ---- device-side ingest (kd_ingest.h): the FILE's bytes -> inflated stream -> kd_batch arrays in HBM -> push_device ----
+    // file / blocks: host memory (the mapped file, the BGZF block table of kd_bgzf_plan_open); total_out: length of the inflated
+    // stream, hdr_end: offset of its first record.  KD_E_UNSUPPORTED: the host decoder must read this file.
+    int ingest_bam(const uint8_t *file, uint64_t file_bytes, const void *blocks, uint32_t n_blocks, uint64_t total_out, uint64_t hdr_end,
+                   uint64_t *stats) {
+        typedef std::chrono::steady_clock clk;
+        const clk::time_point t0 = clk::now();
+        auto us = [](clk::time_point a, clk::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        int rc;
+        if (stats) for (int k = 0; k < 8; k++) stats[k] = 0;
+        if (!n_blocks || hdr_end >= total_out) return KD_OK;        // a header and nothing else
+        if (rt.sync()) return hipfail("ingest: sync");              // (the previous batch's kernels read the staging buffers)
+        if ((rc = ensure(b_gi_file, file_bytes + 64)) || (rc = ensure(b_gi_blocks, (size_t)n_blocks * sizeof(GiBlock))) ||
+            (rc = ensure(b_gi_out, total_out + 64)) || (rc = ensure(b_gi_bstat, (size_t)n_blocks * 4)) || (rc = ensure(b_gi_start, (size_t)n_blocks * 8)) ||
+            (rc = ensure(b_gi_cnt, (size_t)n_blocks * 8 * 3)) || (rc = ensure(b_gi_tot, 64)))
+            return rc;
+        if (rt.h2d(b_gi_file.p, file, file_bytes) || rt.memset((uint8_t *)b_gi_file.p + file_bytes, 0, 64) ||
+            rt.h2d(b_gi_blocks.p, blocks, (size_t)n_blocks * sizeof(GiBlock)) || rt.memset(b_gi_tot.p, 0, 64))
+            return hipfail("ingest: h2d");
+        const GiBlock *d_blocks = (const GiBlock *)b_gi_blocks.p;
+        uint32_t *bstat = (uint32_t *)b_gi_bstat.p;
+        kd_u64 *start = (kd_u64 *)b_gi_start.p, *c_rec = (kd_u64 *)b_gi_cnt.p, *c_seq = c_rec + n_blocks, *c_cig = c_seq + n_blocks;
+        kd_u64 *tot = (kd_u64 *)b_gi_tot.p;          // [0..2] kept records / packed-base bytes / CIGAR words, [3] records seen, [4] status
+        KdBam Bm;
+        Bm.d = (const uint8_t *)b_gi_out.p; Bm.n = total_out; Bm.hdr_end = hdr_end; Bm.blocks = d_blocks; Bm.n_blocks = n_blocks; Bm.n_ref = n_contigs;
+        const unsigned gb = (n_blocks + KD_BLOCK - 1) / KD_BLOCK;
+        if (rt.launch("k_gpu_inflate", k_gpu_inflate, n_blocks, KD_WAVE, 0, (const uint8_t *)b_gi_file.p, d_blocks, n_blocks, (uint8_t *)b_gi_out.p, bstat) ||
+            rt.launch("k_bam_starts", k_bam_starts, n_blocks, KD_WAVE, 0, Bm, start) ||
+            rt.launch("k_bam_count", k_bam_count, gb, KD_BLOCK, 0, Bm, (const kd_u64 *)start, (const uint32_t *)bstat, c_rec, c_seq, c_cig, tot + 3, (uint32_t *)(tot + 4)) ||
+            rt.launch("k_bam_scan", k_bam_scan, 1u, KD_BLOCK, 0, c_rec, c_seq, c_cig, n_blocks, tot))
+            return hipfail("ingest kernels");
+        kd_u64 h_tot[8];
+        if (rt.d2h_small(h_tot, tot, 64)) return hipfail("ingest: totals d2h");
+        const uint32_t st = (uint32_t)h_tot[4];
+        if (st & (KD_INGEST_INFLATE | KD_INGEST_RECORD)) return fail(KD_E_IO, st & KD_INGEST_INFLATE ? "BGZF inflate failed (device-side ingest)" : "malformed or truncated BAM record (device-side ingest)");
+        if (st & (KD_INGEST_CHAIN | KD_INGEST_HOST))
+            return fail(KD_E_UNSUPPORTED, st & KD_INGEST_HOST ? "a CIGAR in a CG:B,I tag: the host decoder reads this file" : "the device-side record walk could not verify its starts: the host decoder reads this file");
+        const uint64_t n = h_tot[0], seq_bytes = h_tot[1], cig_words = h_tot[2];
+        if (stats) { stats[0] = h_tot[3]; stats[1] = n; stats[2] = total_out; stats[3] = n_blocks; }
+        if (!n) return KD_OK;
+        const size_t bytes[9] = {n * 4, n * 4, n * 4, n * 8, n * 4, n * 8, n * 4, (size_t)seq_bytes + 64, (size_t)cig_words * 4 + 8};
+        for (int k = 0; k < 9; k++) if ((rc = ensure(b_stage[k], bytes[k]))) return rc;
+        if ((rc = ensure(b_gi_recat, n * 8))) return rc;
+        KdBamOut O;
+        O.contig = (uint32_t *)b_stage[0].p; O.pos0 = (int32_t *)b_stage[1].p; O.flag = (uint32_t *)b_stage[2].p; O.seq_off = (kd_u64 *)b_stage[3].p;
+        O.seq_len = (uint32_t *)b_stage[4].p; O.cig_off = (kd_u64 *)b_stage[5].p; O.n_cig = (uint32_t *)b_stage[6].p;
+        O.seq4 = (uint8_t *)b_stage[7].p; O.cigar = (uint32_t *)b_stage[8].p; O.rec_at = (kd_u64 *)b_gi_recat.p;
+        if (rt.memset((uint8_t *)b_stage[7].p + seq_bytes, 0, 64) ||
+            rt.launch("k_bam_fields", k_bam_fields, gb, KD_BLOCK, 0, Bm, (const kd_u64 *)start, (const kd_u64 *)c_rec, (const kd_u64 *)c_seq, (const kd_u64 *)c_cig, O) ||
+            rt.launch("k_bam_payload", k_bam_payload, (unsigned)((n + KD_WAVE - 1) / KD_WAVE), KD_WAVE, 0, Bm, (kd_u64)n, O, (kd_u64)seq_bytes, (kd_u64)cig_words))
+            return hipfail("ingest kernels");
+        kd_batch D;
+        memset(&D, 0, sizeof D);
+        D.n_reads = n; D.seq4_bytes = seq_bytes; D.cigar_words = cig_words;
+        D.contig = O.contig; D.pos0 = O.pos0; D.flag = O.flag; D.seq_off = (const uint64_t *)O.seq_off; D.seq_len = O.seq_len;
+        D.cig_off = (const uint64_t *)O.cig_off; D.n_cig = O.n_cig; D.seq4 = O.seq4; D.cigar = O.cigar;
+        const clk::time_point t1 = clk::now();
+        if (stats && !rt.sync()) stats[5] = us(t0, clk::now());      // (measurement: the batch exists)
+        rc = push_device(D);
+        if (stats) stats[6] = us(t1, clk::now());
+        return rc;
     }
 
     // ---- finalize: insertion multiset -> per-site winner ----

@@ -26,6 +26,8 @@
 //                 32-bit atomics straight to HBM: irregular reads, KD_MODE_GLOBAL; k_diagnose
 //   kd_ins.h      k_ins_*: insertion events -> open-addressing hash multiset -> per-site unique max
 //   kd_cns.h      k_cns_*: per-site argmax / tie / indel rules, exclusive scan, byte emission
+//   kd_gpu_inflate.h, kd_ingest.h   the device-side ingest (opt-in): k_gpu_inflate (raw DEFLATE of BGZF blocks, one wavefront each),
+//                 k_bam_*: the BAM record chain walked from speculative, verified starts -> the kd_batch arrays in HBM
 //
 // The file has no host API calls and only uses __syncthreads + atomics across lanes, so
 // tests/emu/ can execute the same source on the CPU for logic checks (test infrastructure).
@@ -40,3 +42,4 @@
 #include "kd_strip.h"
 #include "kd_ins.h"
 #include "kd_cns.h"
+#include "kd_ingest.h"

@@ -197,9 +197,31 @@ def pileup_batch(batch, bam_path=None, device=0, lib=None, mode=N.KD_MODE_AUTO, 
 STREAM_MAX_SITES = 1 << 26      # 67 M sites = 5 GB of tables at 76 B/site (the streamed path lays out every @SQ contig)
 
 
-def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=None):
+def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=None, ingest=None):
     """Decode + device record loop of one SAM / BAM file -> Pileup.  stream: True / False forces the path, None decides by
-    the size of the header (see STREAM_MAX_SITES)."""
+    the size of the header (see STREAM_MAX_SITES).  ingest: "host" (default: the native host decoder feeds the GPU) or "gpu"
+    (opt-in, also KINDEL_INGEST=gpu: the BGZF blocks are inflated and the BAM records walked ON the GPU, kd_push_bam_gpu; a file
+    that path cannot read -- SAM text, plain gzip, CG-tag CIGARs, a header larger than STREAM_MAX_SITES -- takes the host path)."""
+    if (ingest or os.environ.get("KINDEL_INGEST", "host")) == "gpu" and stream is not False:
+        try:
+            with N.BgzfPlan(bam_path, lib=lib) as plan:
+                total = int(plan.contig_lens.astype(np.uint64).sum())
+                if len(plan.contig_lens) and total <= STREAM_MAX_SITES:
+                    eng = N.Engine(plan.contig_lens, device=device, lib=lib)
+                    try:
+                        info = eng.push_bam_gpu(plan)
+                    except BaseException:
+                        eng.close()
+                        raise
+                    eng.finalize()
+                    first = eng.contig_first()
+                    used = np.flatnonzero(first != np.uint64(0xFFFFFFFFFFFFFFFF))
+                    order = [int(c) for c in used[np.argsort(first[used], kind="stable")]]   # first appearance, kindel.py:143-151
+                    pl = Pileup(eng, list(plan.contig_names), plan.contig_lens, order, bam_path)
+                    pl.ingest = dict(info, path="gpu")
+                    return pl
+        except N.UnsupportedByGpuIngest:
+            pass
     if stream is not False:
         st = N.Stream(bam_path, threads=threads, chunk_bytes=chunk_bytes, lib=lib)
         try:

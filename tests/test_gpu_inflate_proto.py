@@ -16,7 +16,7 @@ from tests.test_inflate import PAYLOADS, raw_deflate
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "emu", "gpu_inflate_emu.cpp")
 LIB = os.path.join(ROOT, "tests", "emu", "libgpu_inflate_emu.so")
-DEPS = [SRC, os.path.join(ROOT, "tests", "emu", "hip_emu.h"), os.path.join(ROOT, "scripts", "gpu_inflate_proto.h")]
+DEPS = [SRC, os.path.join(ROOT, "tests", "emu", "hip_emu.h"), os.path.join(ROOT, "kindel_amd", "csrc", "kd_gpu_inflate.h")]
 
 
 class GiBlock(C.Structure):
