@@ -638,7 +638,9 @@ struct KdEngine {
         const uint32_t st = (uint32_t)h_tot[4];
         if (st & (KD_INGEST_INFLATE | KD_INGEST_RECORD)) return fail(KD_E_IO, st & KD_INGEST_INFLATE ? "BGZF inflate failed (device-side ingest)" : "malformed or truncated BAM record (device-side ingest)");
         if (st & (KD_INGEST_CHAIN | KD_INGEST_HOST))
-            return fail(KD_E_UNSUPPORTED, st & KD_INGEST_HOST ? "a CIGAR in a CG:B,I tag: the host decoder reads this file" : "the device-side record walk could not verify its starts: the host decoder reads this file");
+            return fail(KD_E_UNSUPPORTED, st & KD_INGEST_HOST ? "a CIGAR in a CG:B,I tag: the host decoder reads this file"
+                                                               : "the device-side record walk could not verify its starts (the part from BGZF block " + std::to_string((h_tot[5] >> 32) - 1) +
+                                                                     " did not end on the start guessed in block " + std::to_string((h_tot[5] & 0xffffffffu) - 1) + "): the host decoder reads this file");
         const uint64_t n = h_tot[0], seq_bytes = h_tot[1], cig_words = h_tot[2];
         if (stats) { stats[0] = h_tot[3]; stats[1] = n; stats[2] = total_out; stats[3] = n_blocks; }
         if (!n) return KD_OK;

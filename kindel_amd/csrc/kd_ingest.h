@@ -40,8 +40,14 @@ struct KdBam {
 
 __device__ __forceinline__ uint32_t kd_rd32(const uint8_t *p) { return reinterpret_cast<const GiU32 *>(p)->v; }
 
-// Does d[q, n) begin with a well-formed BAM record?  -> the offset of the record behind it, 0 if not (kd_decode.cpp:
-// bam_record_plausible; the whole stream is there, so "cannot tell yet" does not occur)
+// Does d[q, n) begin with a well-formed BAM record?  -> the offset of the record behind it, 0 if not.  The host's rule
+// (kd_decode.cpp: bam_record_plausible: block_size, refID, pos, l_read_name, the lengths fitting, the read name NUL-terminated)
+// and more, because here a start is guessed for every 64 KiB block, not for every megabyte, and a wrong guess costs the whole
+// device-side ingest: the mate's refID / pos in range, and the AUXILIARY FIELDS must parse -- tag letters, a known type, every
+// value inside the record -- and end exactly where block_size says.  (Measured need: on a 5 Mbp x 50 x file without base
+// qualities -- every record the same shape, runs of 0xff -- the host's rule accepted the offset two bytes in front of a true
+// record in one block of 6 857: block_size 0x010fffff, refID 0, a NUL where the shifted name length pointed, and sixteen hops
+// on from there.  The shifted mate refID is 0xffff0000, and 17 MB of other records do not parse as tags.)
 __device__ __forceinline__ kd_u64 kd_bam_plausible(const KdBam &B, kd_u64 q) {
     if (q + 36 > B.n) return 0;
     const uint32_t bs = kd_rd32(B.d + q);
@@ -49,10 +55,34 @@ __device__ __forceinline__ kd_u64 kd_bam_plausible(const KdBam &B, kd_u64 q) {
     const uint8_t *r = B.d + q + 4;
     const int32_t refid = (int32_t)kd_rd32(r), pos = (int32_t)kd_rd32(r + 4);
     const uint32_t w2 = kd_rd32(r + 8), w3 = kd_rd32(r + 12), l_seq = kd_rd32(r + 16);
+    const int32_t m_refid = (int32_t)kd_rd32(r + 20), m_pos = (int32_t)kd_rd32(r + 24);
     const uint32_t l_rn = w2 & 0xffu, n_cig = w3 & 0xffffu;
     if (refid < -1 || (refid >= 0 && (uint32_t)refid >= B.n_ref) || pos < -1 || l_rn == 0) return 0;
-    if (32ull + l_rn + 4ull * n_cig + ((kd_u64)l_seq + 1) / 2 + (kd_u64)l_seq > bs) return 0;
+    if (m_refid < -1 || (m_refid >= 0 && (uint32_t)m_refid >= B.n_ref) || m_pos < -1) return 0;
+    kd_u64 a = 32ull + l_rn + 4ull * n_cig + ((kd_u64)l_seq + 1) / 2 + (kd_u64)l_seq;
+    if (a > bs) return 0;
     if (r[32 + l_rn - 1] != 0) return 0;        // read name is NUL-terminated
+    while (a < bs) {                            // auxiliary fields: TAG (2 letters / digits), type, value
+        if (a + 3 > bs) return 0;
+        const uint32_t t0 = r[a], t1 = r[a + 1], ty = r[a + 2];
+        const bool alpha0 = (t0 | 32u) - 'a' < 26u, alnum1 = (t1 | 32u) - 'a' < 26u || t1 - '0' < 10u;
+        if (!alpha0 || !alnum1) return 0;
+        a += 3;
+        kd_u64 len;
+        if (ty == 'A' || ty == 'c' || ty == 'C') len = 1;
+        else if (ty == 's' || ty == 'S') len = 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
+        else if (ty == 'Z' || ty == 'H') { len = 0; while (a + len < bs && r[a + len]) len++; if (a + len >= bs) return 0; len++; }
+        else if (ty == 'B') {
+            if (a + 5 > bs) return 0;
+            const uint32_t sub = r[a], cnt = kd_rd32(r + a + 1);
+            const kd_u64 es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : 0;
+            if (!es) return 0;
+            len = 5 + es * (kd_u64)cnt;
+        } else return 0;
+        a += len;
+        if (a > bs) return 0;
+    }
     return q + 4 + bs;
 }
 
@@ -129,7 +159,10 @@ k_bam_count(KdBam B, const kd_u64 *start, const uint32_t *inflate_status, kd_u64
             q += 4 + (kd_u64)R.bs;
         }
         // the walk ended on the first record that starts behind this block: the part that begins there must have guessed it
-        if (q < B.n) { if (start[kd_bam_block_of(B, q)] != q) atomicOr(status, KD_INGEST_CHAIN); }
+        if (q < B.n) {
+            const uint32_t nb = kd_bam_block_of(B, q);
+            if (start[nb] != q) { atomicOr(status, KD_INGEST_CHAIN); atomicMax((kd_u64 *)(status + 2), ((kd_u64)(b + 1) << 32) | (nb + 1)); }   // (diagnosis: which hand-off)
+        }
         else if (q > B.n) atomicOr(status, KD_INGEST_RECORD);
     }
     cnt_rec[b] = kept; cnt_seq[b] = sb; cnt_cig[b] = cw;

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--qual", default="absent", choices=["absent", "phred"], help="base qualities of the written BAM: absent (0xff, compresses "
                     "~15x) or a Phred-like spread (compresses 3-4x like sequencer output: what the inflater really has to do)")
+    ap.add_argument("--no-gpu-ingest", action="store_true", help="skip the device-side ingest leg (kd_push_bam_gpu)")
     ap.add_argument("--check", action="store_true", help="compare the FASTA with the oracle's consensus of the same batch (full-size bit-exactness)")
     ap.add_argument("--sweep", default="", help="streamed ingest only, for each THREADSxCHUNK_MB of a comma-separated list (e.g. 16x64,24x128)")
     a = ap.parse_args()
@@ -98,6 +99,20 @@ def main():
         pl.engine.close()
         return out, fa
 
+    def gpu_ingest():      # the device-side ingest (kd_push_bam_gpu): BGZF inflate + record walk + batch arrays on the GPU
+        out = {}
+        t = time.perf_counter()
+        pl = K.pileup_file(path, ingest="gpu")
+        out["ingest_s"] = time.perf_counter() - t
+        assert pl.ingest.get("path") == "gpu", "the device-side ingest handed the file to the host decoder"
+        out.update({"ingest_" + k: v for k, v in pl.ingest.items() if k != "path"})
+        t = time.perf_counter()
+        fa = fasta_of(pl)
+        out["consensus_s"] = time.perf_counter() - t
+        out["total_s"] = out["ingest_s"] + out["consensus_s"]
+        pl.engine.close()
+        return out, fa
+
     if a.sweep:
         for spec in a.sweep.split(","):
             th, mb = (int(x) for x in spec.split("x"))
@@ -113,6 +128,11 @@ def main():
     bw = min(runs_w, key=lambda r: r[0]["total_s"])
     bs = min(runs_s, key=lambda r: r[0]["total_s"])
     assert bw[1] == bs[1], "streamed and whole-file FASTA differ"
+    bg = None
+    if not a.no_gpu_ingest:
+        runs_g = [gpu_ingest() for _ in range(a.repeat)]
+        bg = min(runs_g, key=lambda r: r[0]["total_s"])
+        assert bg[1] == bs[1], "device-side ingest and host decoder give different FASTA"
     if want_fasta is not None:
         assert bs[1] == want_fasta, "end-to-end FASTA differs from the oracle's"
     import hashlib
@@ -127,6 +147,10 @@ def main():
         "streamed_events_per_s": ev / bs[0]["total_s"],
         "synth_plus_write_s": round(t_make, 1), "native_bam_write_s": round(t_write, 2),
     }
+    if bg is not None:
+        line["gpu_ingest"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in bg[0].items()}
+        line["gpu_ingest_events_per_s"] = ev / bg[0]["total_s"]
+        line["gpu_ingest_same_fasta"] = True
     s = json.dumps(line)
     print(s)
     if a.out:
