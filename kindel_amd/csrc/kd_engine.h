@@ -618,18 +618,36 @@ struct KdEngine {
             (rc = ensure(b_gi_out, total_out + 64)) || (rc = ensure(b_gi_bstat, (size_t)n_blocks * 4)) || (rc = ensure(b_gi_start, (size_t)n_blocks * 8)) ||
             (rc = ensure(b_gi_cnt, (size_t)n_blocks * 8 * 3)) || (rc = ensure(b_gi_tot, 64)))
             return rc;
-        if (rt.h2d(b_gi_file.p, file, file_bytes) || rt.memset((uint8_t *)b_gi_file.p + file_bytes, 0, 64) ||
+        if (rt.memset((uint8_t *)b_gi_file.p + file_bytes, 0, 64) ||
             rt.h2d(b_gi_blocks.p, blocks, (size_t)n_blocks * sizeof(GiBlock)) || rt.memset(b_gi_tot.p, 0, 64))
             return hipfail("ingest: h2d");
         const GiBlock *d_blocks = (const GiBlock *)b_gi_blocks.p;
         uint32_t *bstat = (uint32_t *)b_gi_bstat.p;
+        // the file goes up in pieces (rt.upload: pinned double buffer, its own copy stream); the blocks whose bytes have arrived are
+        // inflated while the next piece is on its way
+        {
+            const GiBlock *hb = (const GiBlock *)blocks;
+            uint32_t next_block = 0;
+            auto after = [&](size_t there) -> int {
+                uint32_t e = next_block;
+                while (e < n_blocks && hb[e].in_off + hb[e].in_len + 8 <= there) e++;     // (+ 8: the block's trailer; the kernel's last dword load ends inside it)
+                if (there >= file_bytes) e = n_blocks;
+                // one wavefront works ~15 ms on a block and launches on one stream run one after the other: a launch of fewer blocks
+                // than two rounds of the chip's slots (13 wavefronts per CU) leaves most of it idle for that long
+                if (e == next_block || (e < n_blocks && e - next_block < 26u * (uint32_t)rt.n_cus() && !getenv("KD_UPLOAD_CHUNK"))) return 0;
+                const int bad = rt.launch("k_gpu_inflate", k_gpu_inflate, e - next_block, KD_WAVE, 0, (const uint8_t *)b_gi_file.p, d_blocks + next_block, e - next_block,
+                                          (uint8_t *)b_gi_out.p, bstat + next_block);
+                next_block = e;
+                return bad;
+            };
+            if (rt.upload(b_gi_file.p, file, file_bytes, after)) return hipfail("ingest: upload / k_gpu_inflate");
+        }
         kd_u64 *start = (kd_u64 *)b_gi_start.p, *c_rec = (kd_u64 *)b_gi_cnt.p, *c_seq = c_rec + n_blocks, *c_cig = c_seq + n_blocks;
         kd_u64 *tot = (kd_u64 *)b_gi_tot.p;          // [0..2] kept records / packed-base bytes / CIGAR words, [3] records seen, [4] status
         KdBam Bm;
         Bm.d = (const uint8_t *)b_gi_out.p; Bm.n = total_out; Bm.hdr_end = hdr_end; Bm.blocks = d_blocks; Bm.n_blocks = n_blocks; Bm.n_ref = n_contigs;
         const unsigned gb = (n_blocks + KD_BLOCK - 1) / KD_BLOCK;
-        if (rt.launch("k_gpu_inflate", k_gpu_inflate, n_blocks, KD_WAVE, 0, (const uint8_t *)b_gi_file.p, d_blocks, n_blocks, (uint8_t *)b_gi_out.p, bstat) ||
-            rt.launch("k_bam_starts", k_bam_starts, n_blocks, KD_WAVE, 0, Bm, start) ||
+        if (rt.launch("k_bam_starts", k_bam_starts, n_blocks, KD_WAVE, 0, Bm, start) ||
             rt.launch("k_bam_count", k_bam_count, gb, KD_BLOCK, 0, Bm, (const kd_u64 *)start, (const uint32_t *)bstat, c_rec, c_seq, c_cig, tot + 3, (uint32_t *)(tot + 4)) ||
             rt.launch("k_bam_scan", k_bam_scan, 1u, KD_BLOCK, 0, c_rec, c_seq, c_cig, n_blocks, tot))
             return hipfail("ingest kernels");

@@ -6,6 +6,7 @@
 
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kd_engine.h"
@@ -45,6 +46,8 @@ struct HipRt {
         profile_reset();
         graph_drop();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; }
+        for (int k = 0; k < 2; k++) { if (up_pin[k]) { (void)hipHostFree(up_pin[k]); up_pin[k] = nullptr; } if (up_ev[k]) { (void)hipEventDestroy(up_ev[k]); up_ev[k] = nullptr; } }
+        if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
         if (ev_copy) { (void)hipEventDestroy(ev_copy); ev_copy = nullptr; }
         if (own_stream && stream) { (void)hipSetDevice(dev); (void)hipStreamDestroy(stream); }
         stream = nullptr;
@@ -91,6 +94,43 @@ struct HipRt {
         return rc;
     }
     int graph_launch() { return bad(hipSetDevice(dev)) || bad(hipGraphLaunch(graph_exec, stream)); }
+    // ---- a large host buffer (pageable: a mapped file) -> device, PIPELINED: worker threads copy 32 MiB pieces into two pinned
+    // buffers, a copy stream moves them on (hipMemcpyAsync from pageable memory stages through one thread of the runtime: 8 GB/s
+    // measured on the GPU node, 40 % of the device-side ingest), and after every piece `after(bytes_there)` may launch work on the
+    // compute stream that needs only the bytes [0, bytes_there): it is ordered behind that piece's copy by an event.
+    hipStream_t copy_stream = nullptr;
+    void *up_pin[2] = {nullptr, nullptr};
+    hipEvent_t up_ev[2] = {nullptr, nullptr};
+    static constexpr size_t UP_CHUNK = (size_t)32 << 20;
+    template <class F>
+    int upload(void *dst, const uint8_t *src, size_t n, F &&after) {
+        if (bad(hipSetDevice(dev))) return 1;
+        if (!copy_stream && bad(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking))) return 1;
+        for (int k = 0; k < 2; k++) {
+            if (!up_pin[k] && bad(hipHostMalloc(&up_pin[k], UP_CHUNK, hipHostMallocDefault))) return 1;
+            if (!up_ev[k] && bad(hipEventCreateWithFlags(&up_ev[k], hipEventDisableTiming))) return 1;
+        }
+        unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        if (const char *e = getenv("KD_UPLOAD_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+        size_t c = 0;
+        for (size_t o = 0; o < n; o += UP_CHUNK, c++) {
+            const size_t len = std::min(UP_CHUNK, n - o);
+            const int k = (int)(c & 1);
+            if (c >= 2 && bad(hipEventSynchronize(up_ev[k]))) return 1;      // the copy that read this buffer two pieces ago is done
+            const size_t per = (len / nt + 4095) & ~(size_t)4095;
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt && (size_t)t * per < len; t++)
+                th.emplace_back([=] { memcpy((uint8_t *)up_pin[k] + (size_t)t * per, src + o + (size_t)t * per, std::min(per, len - (size_t)t * per)); });
+            memcpy(up_pin[k], src + o, std::min(per, len));
+            for (auto &x : th) x.join();
+            if (bad(hipMemcpyAsync((uint8_t *)dst + o, up_pin[k], len, hipMemcpyHostToDevice, copy_stream)) || bad(hipEventRecord(up_ev[k], copy_stream)) ||
+                bad(hipStreamWaitEvent(stream, up_ev[k], 0)))
+                return 1;
+            if (after(o + len)) return 1;
+        }
+        return 0;
+    }
+
     // small readbacks (the status words, one cache line each: 4 KiB, 5 KiB in a profiling build) go through a pinned bounce buffer:
     // no pageable staging in the runtime
     static constexpr size_t KD_SMALL_COPY = 16384;

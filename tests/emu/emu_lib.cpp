@@ -30,6 +30,17 @@ struct EmuRt {
     unsigned char small[16384];
     int d2h_small_begin(const void *d, size_t n) { if (n > sizeof small) return 1; ::memcpy(small, d, n); return 0; }
     int d2h_small_end(void *h, size_t n) { ::memcpy(h, small, n); return 0; }
+    template <class F>
+    int upload(void *dst, const uint8_t *src, size_t n, F &&after) {     // (pieces as on the GPU, small ones on request: KD_UPLOAD_CHUNK)
+        size_t chunk = (size_t)32 << 20;
+        if (const char *e = getenv("KD_UPLOAD_CHUNK")) chunk = (size_t)std::max(1, atoi(e));
+        for (size_t o = 0; o < n; o += chunk) {
+            const size_t len = std::min(chunk, n - o);
+            ::memcpy((uint8_t *)dst + o, src + o, len);
+            if (after(o + len)) return 1;
+        }
+        return 0;
+    }
     int sync() { return 0; }
     int d2h_async(void *h, const void *d, size_t n) { ::memcpy(h, d, n); return 0; }
     // (no graphs here: kd_step always takes the eager path on the emulator)

@@ -53,6 +53,16 @@ def test_synthetic_bams_small_blocks_and_unmapped_reads(emu_lib, tmp_path):
     both_ways(emu_lib, p)
 
 
+def test_the_file_uploaded_in_many_small_pieces(emu_lib, tmp_path, monkeypatch):
+    # the file goes to the device in pieces and every piece's complete BGZF blocks are inflated while the next piece is copied:
+    # here pieces of 3000 bytes against blocks of ~1 - 2 KB (a block is launched only when its trailer has arrived)
+    monkeypatch.setenv("KD_UPLOAD_CHUNK", "3000")
+    batch = synth.to_numpy(synth.short_reads([9000, 2500], 30, seed=6, clip_p=0.2, indel_p=0.2))
+    p = str(tmp_path / "pieces.bam")
+    synth.write_bam(p, batch, block_bytes=4096)
+    both_ways(emu_lib, p)
+
+
 def test_long_reads_and_odd_lengths(emu_lib, tmp_path):
     batch = synth.to_numpy(synth.long_reads([60000], 6, seed=3, median_len=4000, min_len=501, max_len=9001))
     assert (batch["seq_len"] & 1).any() and (batch["n_cig"] > 16).any()
