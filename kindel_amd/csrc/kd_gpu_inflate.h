@@ -14,8 +14,11 @@
 //     match whose source is still in the ring is copied LDS -> LDS by all lanes, an older one is read back from HBM
 //     (behind a release fence, with loads that bypass the L1);
 //   * per block: a status word (0 = ok); nothing is ever written outside [out_off, out_off + out_len);
-//   * bound (measured): instruction issue of the ONE wavefront per block, ~120 instructions per symbol; a product-grade loop
-//     (multi-literal table entries, refill without a loop) is the next step, not more wavefronts.
+//   * bound (measured): the ONE wavefront per block -- ~340 ns per symbol whatever was tried inside that frame (the symbol walk on
+//     the scalar unit, 16-bit tables, a run loop for literals with the next look-up in flight: 34.1 -> 36.5 ms; a 4 KiB ring = 20
+//     instead of 13 wavefronts per CU: no gain with Phred qualities, 12.9 -> 16.2 ms without (far matches), profiles/
+//     r03_gpu_inflate_prototype.json).  What is left is decoding a block with more than one wavefront (speculative starts inside
+//     the block, as the record walk does it), not a tighter loop.
 #pragma once
 #include <stdint.h>
 
@@ -46,7 +49,9 @@ __device__ __forceinline__ uint32_t gi_uni(uint32_t v) { return (uint32_t)__buil
 static inline uint32_t gi_uni(uint32_t v) { return v; }
 #endif
 
+#ifndef GI_RING
 #define GI_RING 8192u
+#endif
 #define GI_RING_MASK (GI_RING - 1u)
 #define GI_NEAR (GI_RING - 512u)      // a match at most this far back is copied inside the ring
 #define GI_LIT_BITS 10
