@@ -35,8 +35,11 @@ if st:
     rows = list(csv.reader(open(st[0])))   # the same table without the synthetic-input generator's torch kernels
     with open(os.path.join(P, "%s_c3_kernel_stats_kd_only.csv" % tag), "w", newline="") as fh:
         w = csv.writer(fh)
-        for r in rows[:1] + [r for r in rows[1:] if r and r[0].startswith("k_")]:
-            w.writerow([r[0].split("(")[0]] + r[1:])
+        def kname(n):     # "void k_window<false>(KdReads, ...)" -> "k_window<false>"
+            n = n.split("(")[0]
+            return n[5:] if n.startswith("void ") else n
+        for r in rows[:1] + [r for r in rows[1:] if r and kname(r[0]).startswith("k_")]:
+            w.writerow([kname(r[0])] + r[1:])
 for src, dst in (("bench_c3.json", "%s_c3_bench.json"), ("prof_c3_bench.json", "%s_c3_bench_under_rocprof.json"),
                  ("bench_C2.json", "%s_C2_bench.json"), ("bench_C4.json", "%s_C4_bench.json"), ("bench_C5.json", "%s_C5_bench.json"),
                  ("exp_strip.json", "%s_c3_bench_mode_strip.json"), ("exp_shuf.json", "%s_c3_bench_shuffled.json")):
@@ -51,7 +54,8 @@ for i in (1, 2, 3, 4):
                     key=os.path.getmtime, reverse=True)[:1]:   # the newest run only (gpurun merges, it does not delete)
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
-            k = k.split("<")[0] if k.startswith("void ") is False else k
+            k = k[5:] if k.startswith("void ") else k          # templated kernels: "void k_window<false>(...)"
+            k = {"k_window<false>": "k_window", "k_window<true>": "k_window_rows"}.get(k, k.split("<")[0])
             if not k.startswith("k_"):
                 continue
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
