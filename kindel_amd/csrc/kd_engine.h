@@ -632,9 +632,9 @@ struct KdEngine {
                 uint32_t e = next_block;
                 while (e < n_blocks && hb[e].in_off + hb[e].in_len + 8 <= there) e++;     // (+ 8: the block's trailer; the kernel's last dword load ends inside it)
                 if (there >= file_bytes) e = n_blocks;
-                // one wavefront works ~15 ms on a block and launches on one stream run one after the other: a launch of fewer blocks
-                // than two rounds of the chip's slots (13 wavefronts per CU) leaves most of it idle for that long
-                if (e == next_block || (e < n_blocks && e - next_block < 26u * (uint32_t)rt.n_cus() && !getenv("KD_UPLOAD_CHUNK"))) return 0;
+                // one wavefront works ~20 ms on a block and launches on one stream run one after the other: a launch of fewer blocks
+                // than two rounds of the chip's slots (26 wavefronts per CU) leaves most of it idle for that long
+                if (e == next_block || (e < n_blocks && e - next_block < 52u * (uint32_t)rt.n_cus() && !getenv("KD_UPLOAD_CHUNK"))) return 0;
                 const int bad = rt.launch("k_gpu_inflate", k_gpu_inflate, e - next_block, KD_WAVE, 0, (const uint8_t *)b_gi_file.p, d_blocks + next_block, e - next_block,
                                           (uint8_t *)b_gi_out.p, bstat + next_block);
                 next_block = e;

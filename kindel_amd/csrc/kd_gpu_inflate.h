@@ -10,15 +10,16 @@
 //     the bit buffer is refilled with v_readlane -- no memory latency on the symbol path;
 //   * tables in LDS: 10-bit primary table for literals / lengths, 8-bit for distances (16-bit entries: symbol << 4 | code length); a
 //     longer code (rare: they belong to rare symbols) falls back to the canonical bit-by-bit walk over count[] / sorted[];
-//   * output: an 8 KiB ring in LDS; every completed 256 bytes are stored to HBM by all lanes at once (one dword each); a
-//     match whose source is still in the ring is copied LDS -> LDS by all lanes, an older one is read back from HBM
-//     (behind a release fence, with loads that bypass the L1);
+//   * output: a 2 KiB ring in LDS (small on purpose: 6 KB of LDS per wavefront = 26 wavefronts per CU, and the kernel lives on
+//     wavefronts in flight); every completed 256 bytes are stored to HBM by all lanes at once (one dword each); a match whose
+//     source is still in the ring is copied LDS -> LDS by all lanes, an older one is read back from HBM with loads that bypass
+//     the L1, behind a wait for all but the newest stores (its bytes left the ring many flushes ago);
 //   * per block: a status word (0 = ok); nothing is ever written outside [out_off, out_off + out_len);
-//   * bound (measured): the ONE wavefront per block -- ~340 ns per symbol whatever was tried inside that frame (the symbol walk on
-//     the scalar unit, 16-bit tables, a run loop for literals with the next look-up in flight: 34.1 -> 36.5 ms; a 4 KiB ring = 20
-//     instead of 13 wavefronts per CU: no gain with Phred qualities, 12.9 -> 16.2 ms without (far matches), profiles/
-//     r03_gpu_inflate_prototype.json).  What is left is decoding a block with more than one wavefront (speculative starts inside
-//     the block, as the record walk does it), not a tighter loop.
+//   * bound (measured, profiles/r03_gpu_inflate_prototype.json): ~100 instructions per symbol, 70 of them on the scalar unit, issued
+//     one per ~4 clocks and SIMD -- with 26 wavefronts per CU the scalar issue slots are ~75 % taken.  What moved it: the far-match
+//     wait (a release fence per far match was 44 % of a quality-less file's time), no integer modulo per match, the small ring
+//     (13 -> 26 wavefronts per CU): 34.1 -> 23.4 ms (Phred qualities), 12.9 -> 4.9 ms (none) for 448 MB.  What did not: a run loop for
+//     literals with the next look-up in flight.  Beyond: several wavefronts per block from speculative bit positions.
 #pragma once
 #include <stdint.h>
 
@@ -30,7 +31,11 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 #define GI_LOAD_FAR(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define GI_DRAIN_STORES() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+// Before a far match reads flushed output back: its bytes left the ring >= 28 flushes (one store instruction each) ago, stores
+// complete in the order issued, so "at most 8 vector memory operations outstanding" means they have reached the L2 (which the sc1
+// loads read).  A release fence here waits for the NEWEST flush as well: 8 us per far match measured, 44 % of a quality-less file's
+// inflate time.
+#define GI_DRAIN_STORES() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 __device__ __forceinline__ uint32_t gi_readlane(uint32_t v, uint32_t lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)lane));
 }
@@ -50,7 +55,7 @@ static inline uint32_t gi_uni(uint32_t v) { return v; }
 #endif
 
 #ifndef GI_RING
-#define GI_RING 8192u
+#define GI_RING 2048u      // (bytes, a power of two >= 1024; measured 16 / 8 / 4 / 2 KiB: 34.2 / 29.8 / 26.5 / 23.4 ms -- wavefronts per CU decide)
 #endif
 #define GI_RING_MASK (GI_RING - 1u)
 #define GI_NEAR (GI_RING - 512u)      // a match at most this far back is copied inside the ring
@@ -108,8 +113,10 @@ struct GiStream {
 __device__ __forceinline__ uint32_t gi_load_dw(const GiStream &s, uint32_t d) {
     return d < s.n_dw ? reinterpret_cast<const GiU32 *>(s.in + 4ull * d)->v : 0u;
 }
+// (one dword is enough: no consumer takes more than 32 bits between two refills -- a literal / length code and its extra bits 20, a
+// distance code and its extra bits 28, LEN + NLEN of a stored block 32 -- and a buffer of >= 0 bits + 32 holds them)
 __device__ __forceinline__ void gi_refill(GiStream &s, uint32_t lane) {
-    while (s.bc <= 32) {
+    if (s.bc <= 32) {
         const uint32_t w = gi_readlane(s.cur, s.idx & 63u);
         s.bb |= (unsigned long long)w << s.bc;
         s.bc += 32;
@@ -127,6 +134,7 @@ __device__ __forceinline__ uint32_t gi_symbol(GiStream &s, const GiCode &c) {
     const uint32_t e = gi_uni(c.table[(uint32_t)s.bb & ((1u << c.bits) - 1u)]);
     if (e & 15u) { s.bb >>= (e & 15u); s.bc -= (e & 15u); return e >> 4; }
     uint32_t code = 0, first = 0, index = 0;      // a code longer than the primary index: the canonical walk, bit by bit
+#pragma unroll 1
     for (uint32_t l = 1; l <= 15; l++) {
         code |= (uint32_t)(s.bb & 1ull);
         s.bb >>= 1; s.bc -= 1;
@@ -158,8 +166,18 @@ __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const G
     const GiCode c_lit{t_lit, cnt_lit, srt_lit, GI_LIT_BITS}, c_dist{t_dist, cnt_dist, srt_dist, GI_DIST_BITS}, c_cl{t_cl, cnt_cl, srt_cl, GI_CL_BITS};
     uint32_t pos = 0, flushed = 0, err = GI_OK;
     bool dirty = false;      // flushed bytes whose stores may still be on their way
+#ifdef GI_CLOCKS             // profiling build (scripts/gpu_inflate_proto.py --clocks): where the wavefront's clocks go
+    long long gc_mark = clock64(), gc_build = 0, gc_sym = 0, gc_near = 0, gc_far = 0, gc_flush = 0, gc_other = 0;
+    unsigned long long gn_lit = 0, gn_near = 0, gn_far = 0, gn_flush = 0, gn_slow = 0;
+#define GI_MARK(acc) { const long long n_ = clock64(); acc += n_ - gc_mark; gc_mark = n_; }
+#define GI_COUNT(x) x++
+#else
+#define GI_MARK(acc)
+#define GI_COUNT(x)
+#endif
     // all completed 256-byte pieces of the ring -> HBM, one dword per lane and piece
     auto flush = [&]() {
+        GI_MARK(gc_sym) GI_COUNT(gn_flush);
         GI_WAVE_SYNC();
         while (pos - flushed >= 256u) {
             const uint32_t at = flushed + 4u * lane;
@@ -168,6 +186,7 @@ __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const G
         }
         dirty = true;
         GI_WAVE_SYNC();
+        GI_MARK(gc_flush)
     };
     auto build = [&](const uint8_t *ln, uint32_t n, const GiCode &c, bool cl_code) -> bool {
         GI_WAVE_SYNC();
@@ -248,6 +267,7 @@ __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const G
         }
         // literal / length code over lens[0, hlit), distance code over lens[hlit, hlit + hdist)
         if (!build(lens, hlit, c_lit, false) || !build(lens + hlit, hdist, c_dist, false)) { err = GI_E_CODES; break; }
+        GI_MARK(gc_build)
         for (;;) {
             gi_refill(s, lane);
             const uint32_t sy = gi_symbol(s, c_lit);
@@ -255,6 +275,7 @@ __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const G
                 if (pos >= B.out_len) { err = GI_E_SIZE; break; }
                 if (lane == 0) ring[pos & GI_RING_MASK] = (uint8_t)sy;
                 pos++;
+                GI_COUNT(gn_lit);
             } else if (sy == 256u) {
                 break;
             } else {
@@ -272,12 +293,21 @@ __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const G
                 else { const uint32_t e = (dc >> 1) - 1u; dist = 1u + ((2u + (dc & 1u)) << e) + gi_take(s, e); }
                 if (dist > pos) { err = GI_E_DIST; break; }
                 if (pos + len > B.out_len) { err = GI_E_SIZE; break; }
+                GI_MARK(gc_sym)
                 GI_WAVE_SYNC();
                 if (dist <= GI_NEAR) {
-                    // inside the ring; an overlapping match (dist < len) repeats its first `dist` bytes
-                    for (uint32_t i = lane; i < len; i += 64u) {
-                        const uint32_t j = dist >= len ? i : i % dist;
-                        ring[(pos + i) & GI_RING_MASK] = ring[(pos - dist + j) & GI_RING_MASK];
+                    // inside the ring.  (The branch is wave-uniform; `i % dist` for every match was ~35 vector instructions each.)
+                    if (dist >= len) {
+                        for (uint32_t i = lane; i < len; i += 64u) ring[(pos + i) & GI_RING_MASK] = ring[(pos - dist + i) & GI_RING_MASK];
+                    } else {
+                        // an overlapping match repeats its first `dist` bytes: i mod dist through a float reciprocal (i < 322, dist < 258:
+                        // the product is off by far less than 1 / dist, so the floor is the quotient or one less)
+                        const float rd = 1.0f / (float)dist;
+                        for (uint32_t i = lane; i < len; i += 64u) {
+                            uint32_t j = i - (uint32_t)((float)i * rd) * dist;
+                            if (j >= dist) j -= dist;
+                            ring[(pos + i) & GI_RING_MASK] = ring[(pos - dist + j) & GI_RING_MASK];
+                        }
                     }
                 } else {
                     if (dirty) { GI_DRAIN_STORES(); dirty = false; }
@@ -285,6 +315,9 @@ __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const G
                 }
                 GI_WAVE_SYNC();
                 pos += len;
+#ifdef GI_CLOCKS
+                if (dist <= GI_NEAR) { GI_MARK(gc_near) gn_near++; } else { GI_MARK(gc_far) gn_far++; }
+#endif
             }
             if (pos - flushed >= 256u) flush();
         }
@@ -296,4 +329,13 @@ __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const G
     GI_WAVE_SYNC();
     if (err == GI_OK) for (uint32_t i = flushed + lane; i < pos; i += 64u) dst[i] = ring[i & GI_RING_MASK];
     if (lane == 0) status[b] = err;
+#ifdef GI_CLOCKS
+    GI_MARK(gc_sym)
+    if (lane == 0) {
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(status + ((n_blocks + 1u) & ~1u));     // 16 words behind the status array
+        const unsigned long long v[11] = {(unsigned long long)gc_build, (unsigned long long)gc_sym, (unsigned long long)gc_near, (unsigned long long)gc_far,
+                                          (unsigned long long)gc_flush, (unsigned long long)gc_other, gn_lit, gn_near, gn_far, gn_flush, gn_slow};
+        for (int k = 0; k < 11; k++) atomicAdd(&dbg[k], v[k]);
+    }
+#endif
 }

@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--scale", type=float, default=0.1)
     ap.add_argument("--out", default="")
     ap.add_argument("--lib", default="", help="a prebuilt variant of exp/libgpu_inflate_proto.so")
+    ap.add_argument("--clocks", action="store_true", help="the library was built with -DGI_CLOCKS: print where the wavefronts' clocks went")
     ap.add_argument("--no-verify", action="store_true", help="skip the zlib comparison and the host decoder (variants: timing only)")
     a = ap.parse_args()
     import torch
@@ -89,12 +90,20 @@ def main():
         d_comp = torch.from_numpy(np.frombuffer(raw + b"\0" * 64, np.uint8).copy()).cuda()
         d_blocks = torch.from_numpy(blocks.view(np.uint8).copy()).cuda()
         d_out = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
-        d_status = torch.full((nb,), 99, dtype=torch.int32, device="cuda")
+        d_status = torch.zeros(nb + 64, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         ms = C.c_float(0)
-        rc = dll.gi_inflate_blocks(d_comp.data_ptr(), d_blocks.data_ptr(), nb, d_out.data_ptr(), d_status.data_ptr(), 5, C.byref(ms))
+        rc = dll.gi_inflate_blocks(d_comp.data_ptr(), d_blocks.data_ptr(), nb, d_out.data_ptr(), d_status.data_ptr(), 1 if a.clocks else 5, C.byref(ms))
         assert rc == 0, rc
         status = d_status.cpu().numpy()
+        if a.clocks:
+            dbg = status[(nb + 1) & ~1:][:22].view(np.uint64)
+            names = ["build", "symbols", "near", "far", "flush", "other", "n_lit", "n_near", "n_far", "n_flush", "n_slow"]
+            tot = float(sum(int(x) for x in dbg[:6])) or 1.0
+            print(qual, "clocks:", " ".join("%s=%.1f%%" % (n, 100.0 * int(v) / tot) for n, v in zip(names[:6], dbg[:6])),
+                  "| per block:", " ".join("%s=%.0f" % (n, int(v) / nb) for n, v in zip(names[6:], dbg[6:11])),
+                  "| clocks per symbol %.0f" % (int(dbg[1]) / max(1, int(dbg[6]) + int(dbg[7]) + int(dbg[8]))), flush=True)
+        status = status[:nb]
         out = d_out.cpu().numpy()
         if a.no_verify:
             print(qual, "gpu_ms %.3f GBps_out %.1f blocks_ok %d / %d" % (ms.value, total / ms.value * 1e-6, int((status == 0).sum()), nb), flush=True)
