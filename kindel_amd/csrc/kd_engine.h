@@ -642,6 +642,9 @@ struct KdEngine {
             };
             if (rt.upload(b_gi_file.p, file, file_bytes, after)) return hipfail("ingest: upload / k_gpu_inflate");
         }
+        const bool trace = getenv("KD_INGEST_TRACE") != nullptr;
+        const clk::time_point t_up = clk::now();
+        if (trace) { (void)rt.sync(); fprintf(stderr, "kd ingest: upload loop %.1f ms (host: copies into the pinned pieces), inflate done %.1f ms after start\n", us(t0, t_up) / 1e3, us(t0, clk::now()) / 1e3); }
         kd_u64 *start = (kd_u64 *)b_gi_start.p, *c_rec = (kd_u64 *)b_gi_cnt.p, *c_seq = c_rec + n_blocks, *c_cig = c_seq + n_blocks;
         kd_u64 *tot = (kd_u64 *)b_gi_tot.p;          // [0..2] kept records / packed-base bytes / CIGAR words, [3] records seen, [4] status
         KdBam Bm;
