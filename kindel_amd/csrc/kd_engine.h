@@ -646,10 +646,15 @@ struct KdEngine {
         const clk::time_point t_up = clk::now();
         if (trace) { (void)rt.sync(); fprintf(stderr, "kd ingest: upload loop %.1f ms (host: copies into the pinned pieces), inflate done %.1f ms after start\n", us(t0, t_up) / 1e3, us(t0, clk::now()) / 1e3); }
         kd_u64 *start = (kd_u64 *)b_gi_start.p, *c_rec = (kd_u64 *)b_gi_cnt.p, *c_seq = c_rec + n_blocks, *c_cig = c_seq + n_blocks;
-        kd_u64 *tot = (kd_u64 *)b_gi_tot.p;          // [0..2] kept records / packed-base bytes / CIGAR words, [3] records seen, [4] status
+        kd_u64 *tot = (kd_u64 *)b_gi_tot.p;          // [0..2] kept records / packed-base bytes / CIGAR words, [3] records seen, [4] status, [5] diagnosis, [6] blocks with a wrong CRC
         KdBam Bm;
         Bm.d = (const uint8_t *)b_gi_out.p; Bm.n = total_out; Bm.hdr_end = hdr_end; Bm.blocks = d_blocks; Bm.n_blocks = n_blocks; Bm.n_ref = n_contigs;
         const unsigned gb = (n_blocks + KD_BLOCK - 1) / KD_BLOCK;
+        // every block's CRC-32 against its trailer, as the host reader and htslib check it (KD_BGZF_NO_CRC=1: measurement)
+        if (!getenv("KD_BGZF_NO_CRC") &&
+            rt.launch("k_bgzf_crc", k_bgzf_crc, std::min<unsigned>(n_blocks, 16u * (unsigned)rt.n_cus()), KD_WAVE, 0, (const uint8_t *)b_gi_file.p, d_blocks, n_blocks,
+                      (const uint8_t *)b_gi_out.p, (uint32_t *)(tot + 6)))
+            return hipfail("k_bgzf_crc");
         if (rt.launch("k_bam_starts", k_bam_starts, n_blocks, KD_WAVE, 0, Bm, start) ||
             rt.launch("k_bam_count", k_bam_count, gb, KD_BLOCK, 0, Bm, (const kd_u64 *)start, (const uint32_t *)bstat, c_rec, c_seq, c_cig, tot + 3, (uint32_t *)(tot + 4)) ||
             rt.launch("k_bam_scan", k_bam_scan, 1u, KD_BLOCK, 0, c_rec, c_seq, c_cig, n_blocks, tot))
@@ -657,6 +662,8 @@ struct KdEngine {
         kd_u64 h_tot[8];
         if (rt.d2h_small(h_tot, tot, 64)) return hipfail("ingest: totals d2h");
         const uint32_t st = (uint32_t)h_tot[4];
+        if (!(st & KD_INGEST_INFLATE) && (uint32_t)h_tot[6])
+            return fail(KD_E_IO, "BGZF block CRC-32 mismatch in " + std::to_string((uint32_t)h_tot[6]) + " block(s) (device-side ingest)");
         if (st & (KD_INGEST_INFLATE | KD_INGEST_RECORD)) return fail(KD_E_IO, st & KD_INGEST_INFLATE ? "BGZF inflate failed (device-side ingest)" : "malformed or truncated BAM record (device-side ingest)");
         if (st & (KD_INGEST_CHAIN | KD_INGEST_HOST))
             return fail(KD_E_UNSUPPORTED, st & KD_INGEST_HOST ? "a CIGAR in a CG:B,I tag: the host decoder reads this file"

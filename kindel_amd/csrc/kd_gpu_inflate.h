@@ -339,3 +339,82 @@ __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const G
     }
 #endif
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_bgzf_crc: the CRC-32 of every inflated block against the block's trailer, as htslib's bgzf_read (and the host reader,
+// kd_crc32.h) check it.  A wavefront takes blocks in turn; inside a block lane l owns dword column l of the rows of 256 bytes, so
+// every load is one coalesced 256-byte row, and CRC's linearity puts the 64 columns together:
+//     state after A || B  =  Z_|B|(state after A)  xor  raw(B)         Z_k = "k zero bytes" = multiplication by x^(8k) mod P
+// per row  acc = Z_256(acc) xor raw(own dword)  (Z_256 and raw() by byte-indexed tables in LDS, built once per wavefront), at the end
+// every lane shifts its column to the block's end (x^(8k) by square-and-multiply over x^(2^j), zlib's multmodp / x2nmodp), the
+// lanes are xor-ed together, and the initial 0xffffffff travels |block| bytes.  ~10 us per 64 KiB block and wavefront.
+// A pure-Python model of exactly this decomposition is pinned against zlib.crc32 in tests/test_gpu_inflate_proto.py.
+// ---------------------------------------------------------------------------------------------------------------------
+#define GI_CRC_POLY 0xEDB88320u
+// a(x) * b(x) mod P, reflected bit order (bit 31 = x^0); a != 0 (zlib: multmodp)
+__device__ __forceinline__ uint32_t gi_multmodp(uint32_t a, uint32_t b) {
+    uint32_t m = 1u << 31, p = 0;
+    for (int it = 0; it < 32; it++) {
+        if (a & m) { p ^= b; if ((a & (m - 1u)) == 0) break; }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ GI_CRC_POLY : b >> 1;
+    }
+    return p;
+}
+// x^(8k) mod P from the table x2n[j] = x^(2^j)
+__device__ __forceinline__ uint32_t gi_xpow8(const uint32_t *x2n, uint32_t k) {
+    uint32_t p = 1u << 31;
+    uint32_t n = 8u * k;
+    for (uint32_t j = 0; n; n >>= 1, j++) if (n & 1u) p = gi_multmodp(x2n[j], p);
+    return p;
+}
+__global__ void __launch_bounds__(64) k_bgzf_crc(const uint8_t *comp, const GiBlock *blocks, uint32_t n_blocks, const uint8_t *out,
+                                                  uint32_t *n_bad) {
+    __shared__ uint32_t t_byte[256], t_z256[4][256], x2n[24];
+    const uint32_t lane = threadIdx.x;
+    if (lane == 0) {
+        x2n[0] = 1u << 30;                              // x^1
+        for (int j = 1; j < 24; j++) x2n[j] = gi_multmodp(x2n[j - 1], x2n[j - 1]);
+    }
+    for (uint32_t i = lane; i < 256u; i += 64u) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ GI_CRC_POLY : c >> 1;
+        t_byte[i] = c;
+    }
+    GI_WAVE_SYNC();
+    const uint32_t c256 = gi_xpow8(x2n, 256u);
+    for (uint32_t i = lane; i < 1024u; i += 64u) t_z256[i >> 8][i & 255u] = gi_multmodp(c256, (i & 255u) << (8u * (i >> 8)));
+    GI_WAVE_SYNC();
+    auto raw = [&](uint32_t s, uint32_t byte) -> uint32_t { return t_byte[(s ^ byte) & 0xffu] ^ (s >> 8); };
+    for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const GiBlock B = blocks[b];
+        const uint8_t *d = out + B.out_off;
+        const uint32_t n = B.out_len, rows = n >> 8;
+        uint32_t acc = 0, end = 0;                      // end: the byte position acc has been shifted to (0 = no byte yet)
+        for (uint32_t j = 0; j < rows; j++) {
+            const uint32_t w = reinterpret_cast<const GiU32 *>(d + 256u * j + 4u * lane)->v;
+            uint32_t r = raw(0u, w & 0xffu);
+            r = raw(r, (w >> 8) & 0xffu); r = raw(r, (w >> 16) & 0xffu); r = raw(r, w >> 24);
+            acc = t_z256[0][acc & 0xffu] ^ t_z256[1][(acc >> 8) & 0xffu] ^ t_z256[2][(acc >> 16) & 0xffu] ^ t_z256[3][acc >> 24] ^ r;
+        }
+        if (rows) end = 256u * (rows - 1u) + 4u * lane + 4u;
+        const uint32_t s0 = 256u * rows + 4u * lane;    // the partial last row
+        if (s0 < n) {
+            const uint32_t k = n - s0 < 4u ? n - s0 : 4u;
+            uint32_t r = 0;
+            for (uint32_t t = 0; t < k; t++) r = raw(r, d[s0 + t]);
+            acc = (end ? gi_multmodp(gi_xpow8(x2n, s0 + k - end), acc) : 0u) ^ r;
+            end = s0 + k;
+        }
+        uint32_t v = (end && end < n) ? gi_multmodp(gi_xpow8(x2n, n - end), acc) : (end ? acc : 0u);
+        if (lane == 0) v ^= gi_multmodp(gi_xpow8(x2n, n), 0xffffffffu);          // the initial state, n bytes on
+#ifndef KD_EMU
+        for (uint32_t m = 1; m < 64u; m <<= 1) v ^= (uint32_t)__shfl_xor((int)v, (int)m, 64);
+#else
+        for (uint32_t m = 1; m < 64u; m <<= 1) v ^= kd_shfl_xor(v, m);
+#endif
+        const uint32_t crc = v ^ 0xffffffffu;
+        const uint32_t want = reinterpret_cast<const GiU32 *>(comp + B.in_off + B.in_len)->v;
+        if (lane == 0 && crc != want) atomicAdd(n_bad, 1u);
+    }
+}

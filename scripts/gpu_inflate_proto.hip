@@ -22,3 +22,8 @@ extern "C" int gi_inflate_blocks(const uint8_t *comp, const GiBlock *blocks, uin
     hipEventDestroy(e0); hipEventDestroy(e1);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
+
+extern "C" int gi_crc_blocks(const uint8_t *comp, const GiBlock *blocks, uint32_t n_blocks, const uint8_t *out, uint32_t *n_bad, uint32_t grid) {
+    k_bgzf_crc<<<grid, 64, 0, 0>>>(comp, blocks, n_blocks, out, n_bad);
+    return hipDeviceSynchronize() == hipSuccess ? 0 : 1;
+}

@@ -106,3 +106,86 @@ def test_wrong_sizes_and_corrupted_streams_are_refused_or_harmless(proto):
     for zz, o, st in zip(streams, outs, status):    # what it accepts, zlib accepts with the same bytes (no CRC at this level)
         if st == 0:
             assert zlib.decompress(zz, -15)[:len(data)] == o
+
+
+def test_lane_parallel_crc_model_equals_zlib():
+    """The decomposition k_bgzf_crc uses (kd_gpu_inflate.h), in Python: lane l owns dword column l of the rows of 256 bytes,
+    acc = Z_256(acc) ^ raw(dword) per row, every column shifted to the block's end, the columns xor-ed, the initial state n bytes on."""
+    POLY = 0xEDB88320
+    T = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ POLY if c & 1 else c >> 1
+        T.append(c)
+
+    def multmodp(a, b):
+        m, p = 1 << 31, 0
+        while True:
+            if a & m:
+                p ^= b
+                if (a & (m - 1)) == 0:
+                    return p
+            m >>= 1
+            b = (b >> 1) ^ POLY if b & 1 else b >> 1
+    x2n = [1 << 30]
+    for _ in range(24):
+        x2n.append(multmodp(x2n[-1], x2n[-1]))
+
+    def xpow8(k):
+        n, p, j = 8 * k, 1 << 31, 0
+        while n:
+            if n & 1:
+                p = multmodp(x2n[j], p)
+            n >>= 1
+            j += 1
+        return p
+
+    def raw(bs, s=0):
+        for b in bs:
+            s = T[(s ^ b) & 0xff] ^ (s >> 8)
+        return s
+    c256 = xpow8(256)
+    for n in (0, 1, 3, 4, 5, 255, 256, 257, 300, 511, 512, 1000, 4097, 65279, 65280):
+        M = os.urandom(n)
+        rows, total = n // 256, 0
+        for l in range(64):
+            acc, end = 0, 0
+            for j in range(rows):
+                acc = multmodp(c256, acc) ^ raw(M[256 * j + 4 * l:256 * j + 4 * l + 4]) if acc else raw(M[256 * j + 4 * l:256 * j + 4 * l + 4])
+            if rows:
+                end = 256 * (rows - 1) + 4 * l + 4
+            s0 = 256 * rows + 4 * l
+            if s0 < n:
+                d = M[s0:min(s0 + 4, n)]
+                acc = (multmodp(xpow8(s0 + len(d) - end), acc) if end and acc else 0) ^ raw(d)
+                end = s0 + len(d)
+            if end:
+                total ^= multmodp(xpow8(n - end), acc) if acc else 0
+        total ^= multmodp(xpow8(n), 0xffffffff)
+        assert total ^ 0xffffffff == zlib.crc32(M), n
+
+
+def test_block_crc_kernel_against_zlib(proto):
+    """k_bgzf_crc on the emulator: blocks of every size class (empty, shorter than a row, partial last rows, a full BGZF block) laid
+    out as in a BGZF file (payload, CRC-32, ISIZE); a flipped bit in one inflated block is counted, and only that one."""
+    import struct
+    rng = random.Random(9)
+    datas = [b"", b"a", b"abc", b"abcd", os.urandom(255), os.urandom(256), os.urandom(257), os.urandom(1000), PAYLOADS["bam_like"][:65280],
+             PAYLOADS["acgt"][:4097], b"\xff" * 65279] + [os.urandom(rng.randint(1, 3000)) for _ in range(20)]
+    comp, blocks, outs = b"", (GiBlock * len(datas))(), b""
+    for k, d in enumerate(datas):
+        z = raw_deflate(d, 6)
+        blocks[k] = GiBlock(len(comp), len(outs), len(z), len(d))
+        comp += z + struct.pack("<II", zlib.crc32(d), len(d))
+        outs += d
+    proto.gi_crc_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+    cbuf = np.frombuffer(comp + b"\0" * 16, np.uint8).copy()
+    for grid in (1, 3, 64):           # a wavefront takes blocks in turn
+        obuf = np.frombuffer(outs + b"\0" * 16, np.uint8).copy()
+        bad = np.zeros(1, np.uint32)
+        assert proto.gi_crc_blocks(cbuf.ctypes.data, C.addressof(blocks), len(datas), obuf.ctypes.data, bad.ctypes.data, grid) == 0
+        assert int(bad[0]) == 0, grid
+        obuf[int(blocks[8].out_off) + 4321] ^= 0x10
+        assert proto.gi_crc_blocks(cbuf.ctypes.data, C.addressof(blocks), len(datas), obuf.ctypes.data, bad.ctypes.data, grid) == 0
+        assert int(bad[0]) == 1, grid

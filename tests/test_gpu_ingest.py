@@ -144,6 +144,26 @@ def test_files_for_the_host_decoder(emu_lib, api_on_emu, tmp_path, monkeypatch):
     assert int(np.asarray(pl.tables(0))[:5].sum()) == sl        # every base of the one read tallied (A / deleted site alternating)
 
 
+def test_a_block_with_a_wrong_crc_is_refused(emu_lib, tmp_path):
+    # htslib: "CRC32 checksum mismatch"; the host reader checks every block's trailer, and so does the device-side path (k_bgzf_crc)
+    batch = synth.to_numpy(synth.short_reads([4000], 30, seed=2))
+    p = str(tmp_path / "x.bam")
+    synth.write_bam(p, batch, block_bytes=3000)
+    raw = bytearray(open(p, "rb").read())
+    o = 0
+    for _ in range(3):                                   # the third block's trailer
+        o += struct.unpack_from("<H", raw, o + 16)[0] + 1
+    raw[o - 8] ^= 0x01
+    q = str(tmp_path / "bad_crc.bam")
+    open(q, "wb").write(bytes(raw))
+    with N.BgzfPlan(q, lib=emu_lib) as plan:
+        eng = N.Engine(plan.contig_lens, lib=emu_lib)
+        with pytest.raises(OSError, match="CRC-32"):
+            eng.push_bam_gpu(plan)
+        eng.close()
+    both_ways(emu_lib, p)                                # (the untouched file is fine)
+
+
 def test_corrupt_files_are_refused_not_crashed_on(emu_lib, tmp_path):
     batch = synth.to_numpy(synth.short_reads([4000], 30, seed=2))
     p = str(tmp_path / "x.bam")
@@ -163,7 +183,7 @@ def test_corrupt_files_are_refused_not_crashed_on(emu_lib, tmp_path):
                 try:
                     eng.push_bam_gpu(plan)
                     eng.finalize()
-                    outcomes.add("ok")            # (a flipped bit in a quality byte or a name: no CRC check on this path yet)
+                    outcomes.add("ok")            # (a flipped bit outside the deflate payload and the checked fields, e.g. in the gzip header's MTIME)
                 except (OSError, N.UnsupportedByGpuIngest, KeyError, IndexError, RuntimeError, N.KindelNativeError) as e:
                     outcomes.add(type(e).__name__)
                 finally:
