@@ -10,9 +10,9 @@
 //   tables   u32 tab[KD_NCH][S]  channel-major over "G-space" (all contigs back to back,
 //            len+1 slots each, padded to 64) so that 64 lanes walking 64 consecutive sites
 //            hit 64 consecutive dwords (coalesced atomics / stores, conflict-free LDS banks).
-//   kd_prep.h     k_prep: lane per read: classify (skip / regular / irregular / long CIGAR, plain), footprint,
+//   kd_prep.h     k_prep: lane per read, one wavefront per workgroup: classify (skip / regular / irregular / long CIGAR, plain), footprint,
 //                 stats, deterministic insertion-event slots
-//   kd_long.h     reads with > 16 CIGAR words (workgroup per read, tiles of 256 ops, thread = op): k_prep_long validates,
+//   kd_long.h     reads with > 16 CIGAR words (wavefront per read, tiles of 64 ops, lane = op): k_prep_long validates,
 //                 k_long_reduce hands out slots, k_long_expand writes the read's ROW (one symbol per site: base / deleted /
 //                 nothing, + "insertion in front"), its insertion events and its clips
 //   kd_plan.h     k_plan_*: window -> candidate range (binary search on sorted starts) -> work items;

@@ -23,7 +23,7 @@
 //   kd_walk_ops     the general op-by-op walk: short reads with more than three segments, and -- in the second launch --
 //                   the SEGMENTS of long reads (k_prep_long), one lane per segment
 // Only regular reads are handled here; their clip_starts / clip_ends counters and insertion events are done by
-// k_cold_lane / k_cold_long, irregular reads by k_pileup_wave.
+// k_cold_lane / k_long_expand, irregular reads by k_pileup_wave.
 #define KD_HCH 19
 #define KD_HCH_DEL 6u
 #define KD_HCH_CSW 7u

@@ -41,7 +41,7 @@ def test_fuzz_batch_sizes_around_the_prep_block_emulated(emu_lib, n_reads):
 
 def _long_campaign(lib, seeds, n_reads):
     """Reads with hundreds of ops (clips at both ends, indels, N/H/P) on contigs that hold them: the long-read
-    path (k_prep_long checkpoints, k_window's segment pass, k_cold_long), sorted and unsorted, two window sizes."""
+    path (k_prep_long, k_long_expand's rows, k_window's row pass), sorted and unsorted, two window sizes."""
     n_ok = 0
     for seed in seeds:
         rng = np.random.default_rng(seed)
