@@ -614,6 +614,14 @@ struct KdEngine {
         if (stats) for (int k = 0; k < 8; k++) stats[k] = 0;
         if (!n_blocks || hdr_end >= total_out) return KD_OK;        // a header and nothing else
         if (rt.sync()) return hipfail("ingest: sync");              // (the previous batch's kernels read the staging buffers)
+        {   // the file, its inflated stream and the batch are all resident at once on this path: a file too big for that is the
+            // streamed host decoder's (chunks of 64 MiB)
+            const uint64_t have = b_gi_file.cap + b_gi_out.cap, need = file_bytes + 2 * total_out;
+            const uint64_t free_now = rt.free_bytes();
+            if (need > have && need - have > free_now / 10 * 8)
+                return fail(KD_E_UNSUPPORTED, "the file (" + std::to_string(file_bytes >> 20) + " MiB, " + std::to_string(total_out >> 20) +
+                                                  " MiB inflated) does not fit the GPU's free memory at once: the streamed host decoder reads it");
+        }
         if ((rc = ensure(b_gi_file, file_bytes + 64)) || (rc = ensure(b_gi_blocks, (size_t)n_blocks * sizeof(GiBlock))) ||
             (rc = ensure(b_gi_out, total_out + 64)) || (rc = ensure(b_gi_bstat, (size_t)n_blocks * 4)) || (rc = ensure(b_gi_start, (size_t)n_blocks * 8)) ||
             (rc = ensure(b_gi_cnt, (size_t)n_blocks * 8 * 3)) || (rc = ensure(b_gi_tot, 64)))

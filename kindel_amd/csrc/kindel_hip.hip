@@ -53,6 +53,7 @@ struct HipRt {
         stream = nullptr;
     }
     int n_cus() const { return cus; }
+    size_t free_bytes() { size_t f = 0, t = 0; if (bad(hipSetDevice(dev)) || bad(hipMemGetInfo(&f, &t))) return 0; return f; }
     void *alloc(size_t bytes) {
         void *p = nullptr;
         if (bad(hipSetDevice(dev))) return nullptr;

@@ -16,6 +16,7 @@ struct EmuRt {
     int init(int, void *) { return 0; }
     void shutdown() {}
     int n_cus() const { return 2; }
+    size_t free_bytes() { if (const char *e = getenv("KD_EMU_FREE_BYTES")) return (size_t)strtoull(e, nullptr, 10); return (size_t)1 << 40; }
     void *alloc(size_t bytes) { return aligned_alloc(256, (bytes + 255) & ~size_t(255)); }
     void free(void *p) { ::free(p); }
     int memset(void *p, int v, size_t n) { ::memset(p, v, n); return 0; }

@@ -226,3 +226,20 @@ def test_gpu_ingest_api_consensus_on_the_gpu(hip_lib, tmp_path, monkeypatch):
     gpu = kindel.bam_to_consensus(p)
     assert [str(s.sequence) for s in gpu.consensuses] == [str(s.sequence) for s in host.consensuses]
     assert gpu.refs_reports == host.refs_reports and gpu.refs_changes == host.refs_changes
+
+
+def test_a_file_too_big_for_the_device_goes_to_the_host_decoder(emu_lib, api_on_emu, tmp_path, monkeypatch):
+    # file + inflated stream + batch are resident at once on the device-side path: what does not fit takes the streamed host decoder
+    from kindel_amd import kindel
+    batch = synth.to_numpy(synth.short_reads([4000], 30, seed=2))
+    p = str(tmp_path / "x.bam")
+    synth.write_bam(p, batch)
+    monkeypatch.setenv("KD_EMU_FREE_BYTES", "100000")
+    with N.BgzfPlan(p, lib=emu_lib) as plan:
+        eng = N.Engine(plan.contig_lens, lib=emu_lib)
+        with pytest.raises(N.UnsupportedByGpuIngest, match="does not fit"):
+            eng.push_bam_gpu(plan)
+        eng.close()
+    monkeypatch.setenv("KINDEL_INGEST", "gpu")
+    pl = kindel.pileup_file(p)
+    assert getattr(pl, "ingest", {}).get("path") != "gpu" and int(np.asarray(pl.tables(0))[:5].sum()) > 0
