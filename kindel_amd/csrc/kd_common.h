@@ -382,6 +382,26 @@ __device__ __forceinline__ kd_u64 kd_block_scan_incl(kd_u64 v, kd_u64 *s_wave, k
     __syncthreads();   // s_wave may be reused by the caller
     return v + off;
 }
+// the same for a workgroup of KD_SCAN_WIDE threads (16 wavefronts): the one-workgroup scans of a step (k_plan_scan, k_cns_scan,
+// k_sort_scan, k_bam_scan) are latency chains -- every thread walks its own contiguous run of the array -- and 1024 threads
+// make the runs a quarter as long.  s_wave: [KD_SCAN_WIDE / KD_WAVE].
+#define KD_SCAN_WIDE 1024
+__device__ __forceinline__ kd_u64 kd_block_scan_incl_wide(kd_u64 v, kd_u64 *s_wave, kd_u64 &total) {
+    const uint32_t lane = threadIdx.x & (KD_WAVE - 1), wave = threadIdx.x / KD_WAVE;
+#pragma unroll
+    for (uint32_t d = 1; d < KD_WAVE; d <<= 1) {
+        const kd_u64 t = kd_shfl_up64(v, d);
+        if (lane >= d) v += t;
+    }
+    if (lane == KD_WAVE - 1) s_wave[wave] = v;
+    __syncthreads();
+    kd_u64 off = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < KD_SCAN_WIDE / KD_WAVE; w++) { const kd_u64 x = s_wave[w]; if (w < wave) off += x; tot += x; }
+    total = tot;
+    __syncthreads();   // s_wave may be reused by the caller
+    return v + off;
+}
 // min / max / sum over the 64 lanes by butterfly shuffles (every lane gets the result)
 __device__ __forceinline__ uint32_t kd_wave_min(uint32_t v) {
 #pragma unroll

@@ -416,14 +416,14 @@ struct KdEngine {
                         if (rt.launch("k_sort_count", k_sort_count_lds, gr, KD_SORT_BLOCK, (size_t)n_bins * 4, info, (kd_u64)ne, chunk, W, n_bins, rows) ||
                             rt.launch("k_sort_colscan", k_sort_colscan, (unsigned)(((uint64_t)n_seg * n_bins + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, rows, gr, n_bins, segt) ||
                             rt.launch("k_sort_colscan2", k_sort_colscan2, (n_bins + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, segt, n_seg, n_bins, bc) ||
-                            rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, (uint32_t)n_cnt) ||
+                            rt.launch("k_sort_scan", k_sort_scan, 1u, KD_SCAN_WIDE, 0, bc, bo, (uint32_t)n_cnt) ||
                             rt.launch("k_sort_scatter", k_sort_scatter_lds, gr, KD_SORT_BLOCK, (size_t)n_bins * 4, info, R, chunk, W, n_bins, (const uint32_t *)rows,
                                       (const uint32_t *)segt, (const kd_u64 *)bo, (KdSortRec *)b_srec.p))
                             return hipfail("k_sort_*");
                     } else {
                         const unsigned gr = (unsigned)((ne + KD_BLOCK - 1) / KD_BLOCK);
                         if (rt.launch("k_sort_count", k_sort_count<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, reps) ||
-                            rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, (uint32_t)n_cnt) ||
+                            rt.launch("k_sort_scan", k_sort_scan, 1u, KD_SCAN_WIDE, 0, bc, bo, (uint32_t)n_cnt) ||
                             rt.launch("k_sort_scatter", k_sort_scatter_reads, gr, KD_BLOCK, 0, info, R, W, bc, (const kd_u64 *)bo, reps,
                                       (KdSortRec *)b_srec.p))
                             return hipfail("k_sort_*");
@@ -445,7 +445,7 @@ struct KdEngine {
                     const unsigned gr = (unsigned)((ne + (uint64_t)KD_BLOCK - 1) / (uint64_t)KD_BLOCK);
                     if (rt.memset(bc, 0, ((size_t)n_bins + 1) * 4) ||
                         rt.launch("k_sort_count", k_sort_count<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, 1u) ||
-                        rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, n_bins) ||
+                        rt.launch("k_sort_scan", k_sort_scan, 1u, KD_SCAN_WIDE, 0, bc, bo, n_bins) ||
                         rt.launch("k_sort_scatter", k_sort_scatter<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, (const kd_u64 *)bo, ord) ||
                         rt.launch("k_plan_ranges_sorted", k_plan_ranges_sorted, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
                                   (const kd_u64 *)bo, n_bins, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status, span_slot, 1u))
@@ -461,7 +461,7 @@ struct KdEngine {
                 uint32_t *iw = (uint32_t *)b_itemwin.p;
                 // (up to 2^16 windows the scan's workgroup also writes the item -> window table; beyond, a kernel of its own)
                 const bool fused_items = n_win <= 65536u;
-                if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, io, n_win, fused_items ? iw : (uint32_t *)nullptr, (kd_u64)items_cap, d_status) ||
+                if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_SCAN_WIDE, 0, io, n_win, fused_items ? iw : (uint32_t *)nullptr, (kd_u64)items_cap, d_status) ||
                     (!fused_items && rt.launch("k_plan_items", k_plan_items, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, (const kd_u64 *)io,
                                                n_win, iw, (kd_u64)items_cap, d_status)))
                     return hipfail("k_plan_scan");
@@ -521,7 +521,7 @@ struct KdEngine {
                     const unsigned gr = (unsigned)((ne + KD_BLOCK - 1) / KD_BLOCK);
                     if (rt.memset(bc, 0, ((size_t)n_bins + 1) * 4) ||
                         rt.launch("k_sort_count", k_sort_count<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, Ws, bc, 1u) ||
-                        rt.launch("k_sort_scan", k_sort_scan, 1u, KD_BLOCK, 0, bc, bo, n_bins) ||
+                        rt.launch("k_sort_scan", k_sort_scan, 1u, KD_SCAN_WIDE, 0, bc, bo, n_bins) ||
                         rt.launch("k_sort_scatter", k_sort_scatter<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, Ws, bc, (const kd_u64 *)bo, ord) ||
                         rt.launch("k_plan_ranges_sorted", k_plan_ranges_sorted, (ns_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
                                   (const kd_u64 *)bo, n_bins, ws0, ns_win, Ws, slice, swl, swh, sio, (const kd_u64 *)d_status,
@@ -532,7 +532,7 @@ struct KdEngine {
                 const uint64_t items_cap = (uint64_t)ns_win + (ne * reach) / slice + 1;
                 if ((rc2 = ensure(b_itemwin, items_cap * 4))) return rc2;
                 uint32_t *siw = (uint32_t *)b_itemwin.p;
-                if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_BLOCK, 0, sio, ns_win, (uint32_t *)nullptr, (kd_u64)items_cap, d_status) ||
+                if (rt.launch("k_plan_scan", k_plan_scan, 1u, KD_SCAN_WIDE, 0, sio, ns_win, (uint32_t *)nullptr, (kd_u64)items_cap, d_status) ||
                     rt.launch("k_plan_items", k_plan_items, (ns_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, (const kd_u64 *)sio, ns_win, siw,
                               (kd_u64)items_cap, d_status))
                     return hipfail("k_plan_scan");
@@ -665,7 +665,7 @@ struct KdEngine {
             return hipfail("k_bgzf_crc");
         if (rt.launch("k_bam_starts", k_bam_starts, n_blocks, KD_WAVE, 0, Bm, start) ||
             rt.launch("k_bam_count", k_bam_count, gb, KD_BLOCK, 0, Bm, (const kd_u64 *)start, (const uint32_t *)bstat, c_rec, c_seq, c_cig, tot + 3, (uint32_t *)(tot + 4)) ||
-            rt.launch("k_bam_scan", k_bam_scan, 1u, KD_BLOCK, 0, c_rec, c_seq, c_cig, n_blocks, tot))
+            rt.launch("k_bam_scan", k_bam_scan, 1u, KD_SCAN_WIDE, 0, c_rec, c_seq, c_cig, n_blocks, tot))
             return hipfail("ingest kernels");
         kd_u64 h_tot[8];
         if (rt.d2h_small(h_tot, tot, 64)) return hipfail("ingest: totals d2h");
@@ -949,7 +949,7 @@ struct KdEngine {
         if (rt.launch("k_cns_count", k_cns_count, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64)tile_first, (kd_u64 *)b_tilesum.p,
                       (KdTileMM *)b_tilemm.p, d_mm))
             return hipfail("k_cns_count");
-        if (rt.launch("k_cns_scan", k_cns_scan, 1u, KD_BLOCK, 0, (const kd_u64 *)b_tilesum.p, (kd_u64 *)b_tileoff.p,
+        if (rt.launch("k_cns_scan", k_cns_scan, 1u, KD_SCAN_WIDE, 0, (const kd_u64 *)b_tilesum.p, (kd_u64 *)b_tileoff.p,
                       (kd_u64)n_tiles, (const KdTileMM *)b_tilemm.p, d_mm))
             return hipfail("k_cns_scan");
         if (rt.launch("k_cns_emit", k_cns_emit, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64)tile_first, (const kd_u64 *)b_tileoff.p,

@@ -170,18 +170,18 @@ k_bam_count(KdBam B, const kd_u64 *start, const uint32_t *inflate_status, kd_u64
 }
 
 // exclusive prefix sums of three arrays over the blocks (in place), tot[0..2] = the totals; one workgroup
-__global__ void __launch_bounds__(KD_BLOCK)
+__global__ void __launch_bounds__(KD_SCAN_WIDE)
 k_bam_scan(kd_u64 *a0, kd_u64 *a1, kd_u64 *a2, uint32_t n, kd_u64 *tot) {
-    __shared__ kd_u64 s_wave[KD_WAVES_PER_BLOCK];
+    __shared__ kd_u64 s_wave[KD_SCAN_WIDE / KD_WAVE];
     const uint32_t t = threadIdx.x;
-    const uint32_t per = (n + KD_BLOCK - 1) / KD_BLOCK;
+    const uint32_t per = (n + KD_SCAN_WIDE - 1) / KD_SCAN_WIDE;
     const uint32_t b0 = t * per < n ? t * per : n, b1 = b0 + per < n ? b0 + per : n;
     kd_u64 *arr[3] = {a0, a1, a2};
     for (int k = 0; k < 3; k++) {
         kd_u64 mine = 0;
         for (uint32_t b = b0; b < b1; b++) mine += arr[k][b];
         kd_u64 total;
-        kd_u64 o = kd_block_scan_incl(mine, s_wave, total) - mine;
+        kd_u64 o = kd_block_scan_incl_wide(mine, s_wave, total) - mine;
         for (uint32_t b = b0; b < b1; b++) { const kd_u64 v = arr[k][b]; arr[k][b] = o; o += v; }
         if (t == 0) tot[k] = total;
     }

@@ -67,16 +67,16 @@ k_sort_count(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t W, uint32_t *bin_cnt
 // one workgroup: bin_off = exclusive scan of bin_cnt (n_bins + 1 entries), bin_cnt is reset to 0 (it becomes
 // the fill cursor of k_sort_scatter).  Every thread scans a contiguous run of bins, the run totals are scanned over the
 // workgroup with __shfl_up (kd_block_scan_incl): two barriers whatever n_bins is.
-__global__ void __launch_bounds__(KD_BLOCK)
+__global__ void __launch_bounds__(KD_SCAN_WIDE)
 k_sort_scan(uint32_t *bin_cnt, kd_u64 *bin_off, uint32_t n_bins) {
-    __shared__ kd_u64 s_wave[KD_WAVES_PER_BLOCK];
+    __shared__ kd_u64 s_wave[KD_SCAN_WIDE / KD_WAVE];
     const uint32_t t = threadIdx.x;
-    const uint32_t per = (n_bins + KD_BLOCK - 1) / KD_BLOCK;
+    const uint32_t per = (n_bins + KD_SCAN_WIDE - 1) / KD_SCAN_WIDE;
     const uint32_t b0 = t * per < n_bins ? t * per : n_bins, b1 = b0 + per < n_bins ? b0 + per : n_bins;
     kd_u64 mine = 0;
     for (uint32_t b = b0; b < b1; b++) mine += bin_cnt[b];
     kd_u64 total;
-    kd_u64 o = kd_block_scan_incl(mine, s_wave, total) - mine;
+    kd_u64 o = kd_block_scan_incl_wide(mine, s_wave, total) - mine;
     for (uint32_t b = b0; b < b1; b++) { const kd_u64 v = bin_cnt[b]; bin_off[b] = o; bin_cnt[b] = 0; o += v; }
     if (t == 0) bin_off[n_bins] = total;
 }
@@ -215,16 +215,16 @@ k_plan_ranges_sorted(const kd_u64 *bin_off, uint32_t n_bins, uint32_t w0, uint32
 // k_plan_scan: one workgroup, in-place exclusive scan of the per-window item counts (contiguous run per thread, run totals
 // scanned with __shfl_up), and the work item -> window table on the way (k_window then needs one load, not a binary search
 // over item_off, to find the window of the item it dequeued).
-__global__ void __launch_bounds__(KD_BLOCK)
+__global__ void __launch_bounds__(KD_SCAN_WIDE)
 k_plan_scan(kd_u64 *item_off, uint32_t n_win, uint32_t *item_win, kd_u64 cap, kd_u64 *status) {
-    __shared__ kd_u64 s_wave[KD_WAVES_PER_BLOCK];
+    __shared__ kd_u64 s_wave[KD_SCAN_WIDE / KD_WAVE];
     const uint32_t t = threadIdx.x;
-    const uint32_t per = (n_win + KD_BLOCK - 1) / KD_BLOCK;
+    const uint32_t per = (n_win + KD_SCAN_WIDE - 1) / KD_SCAN_WIDE;
     const uint32_t w0 = t * per < n_win ? t * per : n_win, w1 = w0 + per < n_win ? w0 + per : n_win;
     kd_u64 mine = 0;
     for (uint32_t w = w0; w < w1; w++) mine += item_off[w];
     kd_u64 total;
-    kd_u64 o = kd_block_scan_incl(mine, s_wave, total) - mine;
+    kd_u64 o = kd_block_scan_incl_wide(mine, s_wave, total) - mine;
     for (uint32_t w = w0; w < w1; w++) {
         const kd_u64 v = item_off[w];
         item_off[w] = o;
