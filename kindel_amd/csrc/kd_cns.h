@@ -143,13 +143,15 @@ k_cns_count(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, kd_u64 *tile_sum, K
 
 // pass 2 (one workgroup): exclusive scan of the tile sums, tile_off[n_tiles] = total; fold the tiles' depth ranges into the
 // per-contig ranges (a thread merges its consecutive tiles of one contig before touching the contig's words)
-__global__ void __launch_bounds__(KD_SCAN_WIDE)
+// (256 threads on purpose: every thread ends with an atomicMin / atomicMax on its contig's two words, and 1024 threads are 2048
+// same-address atomics -- measured 0.034 instead of 0.022 ms on C3's one contig)
+__global__ void __launch_bounds__(KD_BLOCK)
 k_cns_scan(const kd_u64 *tile_sum, kd_u64 *tile_off, kd_u64 n_tiles, const KdTileMM *tile_mm, uint32_t *depth_minmax) {
-    __shared__ kd_u64 s_wave[KD_SCAN_WIDE / KD_WAVE];
+    __shared__ kd_u64 s_wave[KD_WAVES_PER_BLOCK];
     const uint32_t t = threadIdx.x;
     kd_u64 carry = 0;
     // each thread owns a contiguous run of tiles (contiguous -> few contig changes per thread)
-    const kd_u64 per = (n_tiles + KD_SCAN_WIDE - 1) / KD_SCAN_WIDE;
+    const kd_u64 per = (n_tiles + KD_BLOCK - 1) / KD_BLOCK;
     const kd_u64 b0 = (kd_u64)t * per < n_tiles ? (kd_u64)t * per : n_tiles, b1 = b0 + per < n_tiles ? b0 + per : n_tiles;
     kd_u64 mine = 0;
     uint32_t cur = 0xffffffffu, mn = 0xffffffffu, mx = 0;
@@ -164,7 +166,7 @@ k_cns_scan(const kd_u64 *tile_sum, kd_u64 *tile_off, kd_u64 n_tiles, const KdTil
     }
     if (cur != 0xffffffffu) { atomicMin(&depth_minmax[2 * cur], mn); atomicMax(&depth_minmax[2 * cur + 1], mx); }
     kd_u64 total;
-    const kd_u64 incl = kd_block_scan_incl_wide(mine, s_wave, total);
+    const kd_u64 incl = kd_block_scan_incl(mine, s_wave, total);
     kd_u64 o = carry + incl - mine;
     for (kd_u64 b = b0; b < b1; b++) { tile_off[b] = o; o += tile_sum[b]; }
     if (t == 0) tile_off[n_tiles] = total;

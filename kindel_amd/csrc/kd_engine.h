@@ -949,7 +949,7 @@ struct KdEngine {
         if (rt.launch("k_cns_count", k_cns_count, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64)tile_first, (kd_u64 *)b_tilesum.p,
                       (KdTileMM *)b_tilemm.p, d_mm))
             return hipfail("k_cns_count");
-        if (rt.launch("k_cns_scan", k_cns_scan, 1u, KD_SCAN_WIDE, 0, (const kd_u64 *)b_tilesum.p, (kd_u64 *)b_tileoff.p,
+        if (rt.launch("k_cns_scan", k_cns_scan, 1u, KD_BLOCK, 0, (const kd_u64 *)b_tilesum.p, (kd_u64 *)b_tileoff.p,
                       (kd_u64)n_tiles, (const KdTileMM *)b_tilemm.p, d_mm))
             return hipfail("k_cns_scan");
         if (rt.launch("k_cns_emit", k_cns_emit, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64)tile_first, (const kd_u64 *)b_tileoff.p,
