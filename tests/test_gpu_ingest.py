@@ -243,3 +243,32 @@ def test_a_file_too_big_for_the_device_goes_to_the_host_decoder(emu_lib, api_on_
     monkeypatch.setenv("KINDEL_INGEST", "gpu")
     pl = kindel.pileup_file(p)
     assert getattr(pl, "ingest", {}).get("path") != "gpu" and int(np.asarray(pl.tables(0))[:5].sum()) > 0
+
+
+def test_plan_edge_cases(emu_lib, tmp_path):
+    """kd_bgzf_plan_open: a BAM header that spans several BGZF blocks (a thousand contigs, 300-byte blocks), a truncated file, plain
+    gzip, a context whose contig table is not the file's."""
+    import gzip
+    lens = [1000 + 7 * i for i in range(1000)]
+    batch = synth.to_numpy(synth.short_reads([lens[0], lens[1]], 20, seed=3))
+    batch = dict(batch, contig_lens=np.asarray(lens, np.uint32), contig_names=np.asarray(["contig_number_%04d" % i for i in range(1000)]))
+    p = str(tmp_path / "many.bam")
+    synth.write_bam(p, batch, block_bytes=300)
+    with N.BgzfPlan(p, lib=emu_lib) as plan:
+        assert plan.contig_names[999] == "contig_number_0999" and plan.contig_lens.tolist() == lens
+    both_ways(emu_lib, p)
+    raw = open(p, "rb").read()
+    q = str(tmp_path / "cut.bam")
+    open(q, "wb").write(raw[:len(raw) // 2 + 5])
+    with pytest.raises(OSError):
+        N.BgzfPlan(q, lib=emu_lib)
+    g = str(tmp_path / "plain.bam.gz")
+    with gzip.open(g, "wb") as fh:
+        fh.write(b"BAM\x01" + b"\0" * 100)
+    with pytest.raises(N.UnsupportedByGpuIngest):
+        N.BgzfPlan(g, lib=emu_lib)
+    with N.BgzfPlan(p, lib=emu_lib) as plan:
+        eng = N.Engine(np.asarray([5, 6, 7], np.uint32), lib=emu_lib)
+        with pytest.raises(Exception, match="@SQ table"):
+            eng.push_bam_gpu(plan)
+        eng.close()
