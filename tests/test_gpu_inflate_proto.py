@@ -25,9 +25,8 @@ class GiBlock(C.Structure):
 
 @pytest.fixture(scope="module")
 def proto():
-    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS):
-        subprocess.check_call(["g++", "-O1", "-std=c++20", "-shared", "-fPIC", "-pthread", "-Wno-unknown-pragmas", SRC, "-o", LIB])
-    dll = C.CDLL(LIB)
+    import __graft_entry__ as g
+    dll = C.CDLL(g.build_inflate_emu())
     dll.gi_inflate_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     dll.gi_inflate_blocks.restype = C.c_int
     return dll
