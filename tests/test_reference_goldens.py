@@ -19,6 +19,16 @@ def test_reference_fasta(api_on_emu, tmp_path, key, tag):
     RC.check_reference_fasta(K, tmp_path, key, tag)
 
 
+@pytest.mark.parametrize("key,tag", RC.FASTA_CASES)
+def test_reference_fasta_through_the_device_side_ingest(api_on_emu, tmp_path, monkeypatch, key, tag):
+    """The same 21 golden FASTA files of the reference with KINDEL_INGEST=gpu: BGZF inflate, BAM record walk and the batch arrays by
+    the device-side kernels (emulated here), then the same engine."""
+    from kindel_amd import kindel as K
+    monkeypatch.setenv("KINDEL_INGEST", "gpu")
+    assert K.pileup_file(RC.bam_of(tmp_path, key)).ingest.get("path") == "gpu"
+    RC.check_reference_fasta(K, tmp_path, key, tag)
+
+
 @pytest.mark.parametrize("key", RC.FEATURE_KEYS)
 def test_features_dataframe(api_on_emu, tmp_path, key):
     from kindel_amd import kindel as K
