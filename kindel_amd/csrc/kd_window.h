@@ -722,9 +722,6 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
 __global__ void __launch_bounds__(KD_BLOCK)
 k_find_bad_base(KdReads rd, KdTabs T, const KdRInfo *rinfo, kd_u64 *status) {
     if (status[KDS_BAD_BASE] == 0) return;
-#ifdef KD_EMU
-    if (getenv("KD_EMU_TRACE") && threadIdx.x == 0) fprintf(stderr, "k_find_bad_base: flag raised %llu\n", status[KDS_BAD_BASE]);
-#endif
     for (kd_u64 i = threadIdx.x; i < rd.n; i += KD_BLOCK) {
         const uint32_t cls_i = rinfo[i].span_cls & 3u;
         if (cls_i != KD_CLS_REG && cls_i != KD_CLS_LONG) continue;   // regular reads, short and long
