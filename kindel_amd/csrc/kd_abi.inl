@@ -88,7 +88,7 @@ int kd_get_batch_info(kd_ctx *ctx, uint64_t out[8]) {
     if (rc) return rc;
     const auto &h = ctx->e.h_status;
     out[0] = ctx->e.last_windowed; out[1] = h[KDS_B_N_REG]; out[2] = h[KDS_B_N_COLD]; out[3] = h[KDS_B_N_IRREG];
-    out[4] = h[KDS_B_N_LONG]; out[5] = h[KDS_TOTAL_ITEMS]; out[6] = h[KDS_B_MAXSPAN]; out[7] = h[KDS_B_UNSORTED];
+    out[4] = h[KDS_B_N_LONG]; out[5] = ctx->e.last_nwin + h[KDS_TOTAL_ITEMS] /* work items: windows planned + the extra slices of deep windows */; out[6] = h[KDS_B_MAXSPAN]; out[7] = h[KDS_B_UNSORTED];
     return KD_OK;
 }
 

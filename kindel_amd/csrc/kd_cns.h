@@ -12,7 +12,11 @@
 
 struct KdCns {
     const uint32_t *seg_contig;  // [S/64] contig of each 64-site segment
-    const uint32_t *ins_win;     // [S] KD_INS_NONE / KD_INS_TIE / 1 + event index of the unique majority
+    // the insertion reduction's per-site maxima (kd_ins.h: k_ins_verify_max), shard-local, biased like the tables:
+    //   best_a[g] = max over the site's hash slots of (count << 32 | slot),  best_b[g] = max of (count << 32 | ~slot);
+    //   0 = no insertion string was reduced on the site.  The slot with the top count is unique iff both name the same slot.
+    const kd_u64 *best_a, *best_b;
+    const uint32_t *ins_rep;     // [hash capacity] representative event of a slot
     uint32_t min_depth;
     uint32_t n_patches;
     const kd_u64 *patch_start, *patch_end;  // skip ranges in G-space (kindel.py:393-401)
@@ -51,9 +55,12 @@ __device__ __forceinline__ KdSite kd_site_eval(const KdTabs &T, const KdCns &C, 
     if (ad < (kd_u64)C.min_depth) { s.has_base = 1; s.change = 'N'; s.base = 'N'; return s; }  // :415-417
     if (2ULL * ins_total > ind2) {                                 // :419-422
         s.change = 'I';
-        const uint32_t wv = C.ins_win[g];
-        if (wv == KD_INS_TIE || wv == KD_INS_NONE) { s.ins = 2; s.ins_len = 1; }
-        else { s.ins = 1; s.ins_ev = wv - 1u; s.ins_len = ins.ev_len[wv - 1u]; }
+        // consensus(insertions[pos]) (:420-421): the string with the top count, or a tie -> 'N' (:377).  Several strings
+        // share the top count iff the largest and the smallest slot holding it differ.
+        const kd_u64 ba = C.best_a[g];
+        const uint32_t sa = (uint32_t)ba, sb = ~(uint32_t)C.best_b[g];
+        if (ba == 0ULL || sa != sb) { s.ins = 2; s.ins_len = 1; }
+        else { const uint32_t ev = C.ins_rep[sa]; s.ins = 1; s.ins_ev = ev; s.ins_len = ins.ev_len[ev]; }
     }
     // consensus(weight): first max in A,T,G,C,N order, tie -> 'N'  (kindel.py:369-381, :423-424)
     uint32_t best = a; uint8_t bc = 'A';
@@ -172,27 +179,61 @@ k_cns_scan(const kd_u64 *tile_sum, kd_u64 *tile_off, kd_u64 n_tiles, const KdTil
     if (t == 0) tile_off[n_tiles] = total;
 }
 
-// pass 3: recompute, scan inside the tile, write bytes / changes / per-contig start offsets
+// The per-contig fold of the tiles' depth ranges (a thread merges its consecutive tiles of one contig before touching the
+// contig's words): all threads of ONE workgroup.
+__device__ __forceinline__ void kd_cns_fold_mm(const KdTileMM *tile_mm, kd_u64 n_tiles, uint32_t *depth_minmax, uint32_t t, uint32_t nt) {
+    const kd_u64 per = (n_tiles + nt - 1) / nt;
+    const kd_u64 b0 = (kd_u64)t * per < n_tiles ? (kd_u64)t * per : n_tiles, b1 = b0 + per < n_tiles ? b0 + per : n_tiles;
+    uint32_t cur = 0xffffffffu, mn = 0xffffffffu, mx = 0;
+    for (kd_u64 b = b0; b < b1; b++) {
+        const KdTileMM m = tile_mm[b];
+        if (m.mn == 0xffffffffu) continue;        // no live site of its first contig
+        if (m.contig != cur) {
+            if (cur != 0xffffffffu) { atomicMin(&depth_minmax[2 * cur], mn); atomicMax(&depth_minmax[2 * cur + 1], mx); }
+            cur = m.contig; mn = m.mn; mx = m.mx;
+        } else { mn = m.mn < mn ? m.mn : mn; mx = m.mx > mx ? m.mx : mx; }
+    }
+    if (cur != 0xffffffffu) { atomicMin(&depth_minmax[2 * cur], mn); atomicMax(&depth_minmax[2 * cur + 1], mx); }
+}
+
+// pass 2 (round 4: the last pass): recompute, scan inside the tile, write bytes / changes / per-contig start offsets.
+// tile_off == NULL (up to KD_CNS_SELF_SCAN tiles): there is no scan kernel between the passes -- every workgroup sums the byte
+// counts of the tiles in front of its own (<= 64 coalesced loads per thread out of the L2) and workgroup 0 folds the tiles'
+// depth ranges into the per-contig ranges on the way; k_cns_scan (one workgroup, 19 us on C3 for a prefix sum of 4 883 numbers,
+// most of it the dispatch and its dependent round trips) is only launched beyond that, where the quadratic sum would cost more.
+#define KD_CNS_SELF_SCAN 16384u
 __global__ void __launch_bounds__(KD_BLOCK)
-k_cns_emit(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, const kd_u64 *tile_off, uint8_t *out, uint8_t *changes,
-           kd_u64 *contig_off, uint32_t n_contigs, kd_u64 *patch_off) {
+k_cns_emit(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, const kd_u64 *tile_sum, const kd_u64 *tile_off, const KdTileMM *tile_mm,
+           uint32_t *depth_minmax, uint8_t *out, uint8_t *changes, kd_u64 *contig_off, uint32_t n_contigs, kd_u64 *patch_off) {
     __shared__ kd_u64 s_wave[KD_WAVES_PER_BLOCK];
     const uint32_t t = threadIdx.x;
     const kd_u64 tile0 = (tile_first + blockIdx.x) * KD_CNS_TILE;
     const kd_u64 g0 = tile0 + (kd_u64)t * KD_CNS_PER_THREAD;
-    if (blockIdx.x == 0 && t == 0) contig_off[n_contigs] = tile_off[gridDim.x];   // total length, next to the per-contig offsets
     KdSite s[KD_CNS_PER_THREAD];
     kd_cns_load_eval(T, C, ins, g0, s);
+    kd_u64 base;
+    if (tile_off) base = tile_off[blockIdx.x];
+    else {
+        kd_u64 part = 0;
+        for (kd_u64 b = t; b < blockIdx.x; b += KD_BLOCK) part += tile_sum[b];
+        kd_u64 tot;
+        (void)kd_block_scan_incl(part, s_wave, tot);
+        base = tot;
+        if (blockIdx.x == 0) kd_cns_fold_mm(tile_mm, gridDim.x, depth_minmax, t, KD_BLOCK);
+    }
     uint32_t sum = 0;
     for (int k = 0; k < KD_CNS_PER_THREAD; k++) sum += s[k].ins_len + s[k].has_base;
     kd_u64 tile_total;
     const kd_u64 incl = kd_block_scan_incl((kd_u64)sum, s_wave, tile_total);   // __shfl_up scans, two barriers
-    kd_u64 o = tile_off[blockIdx.x] + incl - sum;
+    if (blockIdx.x == gridDim.x - 1 && t == 0) contig_off[n_contigs] = base + tile_total;   // total length, next to the per-contig offsets
+    kd_u64 o = base + incl - sum;
     const char lower[17] = "=acmgrsvtwyhkdbn";
+    // the thread's four change codes as one store (g0 is a multiple of 4, S a multiple of 1024, the array 4-byte aligned)
+    if (g0 < T.sites)
+        *reinterpret_cast<uint32_t *>(changes + g0) = (uint32_t)s[0].change | (uint32_t)s[1].change << 8 | (uint32_t)s[2].change << 16 | (uint32_t)s[3].change << 24;
     for (int k = 0; k < KD_CNS_PER_THREAD; k++) {
         const kd_u64 g = g0 + k;
         if (g >= T.sites) break;
-        changes[g] = s[k].change;
         // contig c starts at G-site contig_base[c]: record the output offset there
         if ((g & 63) == 0) {
             const uint32_t c = C.seg_contig[g >> 6];

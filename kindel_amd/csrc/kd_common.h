@@ -83,6 +83,12 @@ __device__ __forceinline__ uint32_t kd_wave_scan_max(uint32_t v) {
 __device__ __forceinline__ uint32_t kd_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 // v_alignbyte_b32: ({hi, lo} >> 8 * (sh & 3)) [31:0]
 __device__ __forceinline__ uint32_t kd_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+// a word another workgroup of the SAME kernel publishes (k_window's work queue): device-scope acquire load; the pause keeps a
+// waiting wavefront off the issue slots of the ones it waits for
+__device__ __forceinline__ unsigned long long kd_ld_acquire(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void kd_spin_pause() { __builtin_amdgcn_s_sleep(8); }
 #endif
 
 #define KD_WAVE 64
@@ -141,7 +147,10 @@ enum {
     KDO_B_N_IRREG,      // per batch: entries in the irregular list
     KDO_B_N_LONG,       // per batch: entries in the long-CIGAR list
     KDO_B_N_REG,        // per batch: regular reads
-    KDO_NEXT_ITEM,      // window work queue head
+    KDO_WQ_TICKET,      // k_window's self-planned work queue (kd_window.h): window tickets handed out,
+    KDO_WQ_PUB,         //   windows whose owner has published its slice count,
+    KDO_WQ_HOT,         //   entries of the list of windows with more than one slice
+    KDO_NEXT_ITEM,      // window work queue head (planned queues: k_window_coop, k_strip)
     KDO_TOTAL_ITEMS,    // window work queue length
     KDO_INS_COLLISION,  // hash verification failed
     KDO_INTERNAL,       // capacity overrun etc.
@@ -172,6 +181,9 @@ enum {
 #define KDS_B_N_IRREG (KDO_B_N_IRREG * KDS_STRIDE)
 #define KDS_B_N_LONG (KDO_B_N_LONG * KDS_STRIDE)
 #define KDS_B_N_REG (KDO_B_N_REG * KDS_STRIDE)
+#define KDS_WQ_TICKET (KDO_WQ_TICKET * KDS_STRIDE)
+#define KDS_WQ_PUB (KDO_WQ_PUB * KDS_STRIDE)
+#define KDS_WQ_HOT (KDO_WQ_HOT * KDS_STRIDE)
 #define KDS_NEXT_ITEM (KDO_NEXT_ITEM * KDS_STRIDE)
 #define KDS_TOTAL_ITEMS (KDO_TOTAL_ITEMS * KDS_STRIDE)
 #define KDS_INS_COLLISION (KDO_INS_COLLISION * KDS_STRIDE)
@@ -197,7 +209,7 @@ struct KdTabs {
     // exception it raises is that of the first failing read of the EARLIEST-APPEARING contig that has one:
     kd_u64 *first_idx;           // [n_contigs] global index of the contig's first record (k_prep), ~0 = none yet
     kd_u64 *err_first;           // [n_contigs] global index of the contig's first failing read, ~0 = none
-    uint32_t *err_code;          // [n_contigs] its exception (k_diagnose): 1 KeyError, 2 IndexError, 3 RuntimeError
+    uint32_t *err_code;          // [n_contigs] its exception (k_errors): 1 KeyError, 2 IndexError, 3 RuntimeError
 };
 
 struct KdReads {

@@ -423,6 +423,6 @@ k_window_coop(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
         }
         __syncthreads();
     }
-    // a base outside A,C,G,T,N inside an aligned or clipped segment: k_find_bad_base pins down the read
+    // a base outside A,C,G,T,N inside an aligned or clipped segment: k_errors (kd_find_bad_base) pins down the read
     if (bad) atomicAdd(&status[KDS_BAD_BASE], 1ULL);
 }

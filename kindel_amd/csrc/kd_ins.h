@@ -7,10 +7,10 @@
 // Insertion multiset: insertions[site][string] += 1 (kindel.py:55-58) and
 // consensus(insertions[site]) (kindel.py:420-421) -> per site: unique majority string or tie.
 // ---------------------------------------------------------------------------------------
-// win[site]: 0 = no insertion string, event index + 1 = the unique majority string, KD_INS_TIE = several strings
-// share the top count.  Ordered so that one atomicMax per hash slot settles it (TIE beats a winner beats NONE).
-#define KD_INS_NONE 0u
-#define KD_INS_TIE 0xffffffffu
+// Per site the reduction leaves TWO maxima over the site's hash slots (k_ins_verify_max): best_a = max (count << 32 | slot),
+// best_b = max (count << 32 | ~slot).  Both carry the top count; best_a names the largest slot holding it, best_b the
+// smallest: the majority string is unique iff they name the same slot (kd_cns.h reads them -- round 4: no k_ins_pick pass,
+// no win[] array).  0 = nothing reduced on the site.
 
 struct KdInsTab {
     kd_u64 *key;     // [cap] 0 = empty
@@ -29,10 +29,21 @@ struct KdInsTab {
 // the deletion / min_depth tests before it can only remove sites.  On sequencing data that is a handful of sites, while
 // EVERY read with an I op contributes an event: flag the sites first, reduce only the events on flagged sites.
 // One thread per 4 sites (16-byte loads per channel), flag[g] = 1 / 0.
+// Round 4: the kernel also leaves the words the kernels behind it start from -- the hash verification's collision counter,
+// and the consensus run's per-contig depth range (min = ~0, max = 0) and output offsets -- which were a memset and an upload
+// of their own between the kernels.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_flag(KdTabs T, kd_u64 g_first, kd_u64 g_end, uint8_t *flag) {
-    const kd_u64 g0 = g_first + ((kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x) * 4;
-    if (g0 >= g_end) return;
+k_ins_flag(KdTabs T, kd_u64 g_first, kd_u64 g_end, uint8_t *flag, kd_u64 *status, kd_u64 *contig_off, uint32_t *depth_minmax,
+           uint32_t n_contigs) {
+    const kd_u64 gt = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (gt == 0) status[KDS_INS_COLLISION] = 0ULL;
+    if (depth_minmax)
+        for (kd_u64 c = gt; c <= n_contigs; c += (kd_u64)gridDim.x * KD_BLOCK) {
+            contig_off[c] = 0ULL;
+            if (c < n_contigs) { depth_minmax[2 * c] = 0xffffffffu; depth_minmax[2 * c + 1] = 0u; }
+        }
+    const kd_u64 g0 = g_first + gt * 4;
+    if (g0 >= g_end || !flag) return;
     uint32_t v[5][5];
     const int chs[5] = {KDC_A, KDC_T, KDC_G, KDC_C, KDC_INS_TOTAL};
 #pragma unroll
@@ -52,33 +63,36 @@ k_ins_flag(KdTabs T, kd_u64 g_first, kd_u64 g_end, uint8_t *flag) {
     }
     *reinterpret_cast<uint32_t *>(flag + g0) = out;
 }
-// events on flagged sites are marked to take part (no compaction: the kernels below run over all events and the others
-// leave after one coalesced 4-byte load; a compacted list needed one atomic per wavefront on one counter, 0.5 ms on C4)
-__global__ void __launch_bounds__(KD_BLOCK)
-k_ins_filter(KdIns ins, kd_u64 n_ev, const uint8_t *flag, kd_u64 sites, uint32_t *ev_slot) {
-    const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (e >= n_ev) return;
-    const uint32_t site = ins.ev_site[e];
-    // a reserved slot that was never written (its read raised a reference exception half way: the batch is rejected by
-    // kd_finalize anyway) holds stale data: keep it out unless it is at least in bounds
-    const bool take = site != KD_EV_DROPPED && site < sites && ins.ev_off[e] + ins.ev_len[e] <= ins.pool_cap && flag[site];
-    ev_slot[e] = take ? KD_EV_TAKE : KD_EV_DROPPED;
-}
-
 __device__ __forceinline__ kd_u64 kd_mix64(kd_u64 x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return x;
 }
 
+// k_ins_insert: lane per event.  An event takes part iff its site is flagged (no compaction: the others leave after two
+// coalesced loads and one byte; a compacted list needed one atomic per wavefront on one counter, 0.5 ms on C4); round 4: the
+// marking pass (k_ins_filter) is part of this kernel -- `flag` != NULL: decide here and record the decision in ev_slot;
+// NULL (the re-seeded repeat after a hash collision): ev_slot holds KD_EV_TAKE / KD_EV_DROPPED from the first attempt.
 // (events of one deep site sit next to each other in event order and carry the same insertion: neighbouring lanes with
 //  the same 64-bit key probe once and add their number, kd_run_heads)
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev) {
+k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev, const uint8_t *flag) {
     const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    const bool take = e < n_ev && H.ev_slot[e] == KD_EV_TAKE;
+    bool take = false;
+    uint32_t site = 0, len = 0;
+    if (e < n_ev) {
+        if (flag) {
+            site = ins.ev_site[e]; len = ins.ev_len[e];
+            // a reserved slot that was never written (its read raised a reference exception half way: the batch is rejected by
+            // kd_finalize anyway) holds stale data: keep it out unless it is at least in bounds
+            take = site != KD_EV_DROPPED && site < H.sites && ins.ev_off[e] + len <= ins.pool_cap && flag[site];
+            if (!take) H.ev_slot[e] = KD_EV_DROPPED;
+        } else {
+            take = H.ev_slot[e] == KD_EV_TAKE;
+            if (take) { site = ins.ev_site[e]; len = ins.ev_len[e]; }
+        }
+    }
     kd_u64 h = 0;
     if (take) {
-        const uint32_t site = ins.ev_site[e], len = ins.ev_len[e];
         const uint8_t *p = ins.pool + ins.ev_off[e];
         h = kd_mix64(H.seed ^ ((kd_u64)site << 32 | len));
         for (uint32_t b = 0; b < len; b++) h = (h ^ p[b]) * 0x100000001b3ULL;
@@ -115,7 +129,7 @@ k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev) {
 // are final).  The representative itself nominates its slot for its site: best[site] = max over the site's slots of
 // (count << 32 | slot).  Per EVENT: nothing here is proportional to the table capacity or to the sites.
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_verify_max(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, kd_u64 *status) {
+k_ins_verify_max(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best_a, kd_u64 *best_b, kd_u64 *status) {
     const kd_u64 k0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x;
     uint32_t ev[KD_INS_PER_THREAD], s[KD_INS_PER_THREAD], r[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD], cnt[KD_INS_PER_THREAD];
 #pragma unroll
@@ -132,7 +146,11 @@ k_ins_verify_max(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, kd_u64 *statu
     for (int k = 0; k < KD_INS_PER_THREAD; k++) {
         const kd_u64 e = ev[k];
         if (s[k] == KD_EV_DROPPED) continue;
-        if (r[k] == (uint32_t)e) { atomicMax(&best[site[k]], ((kd_u64)cnt[k] << 32) | s[k]); continue; }
+        if (r[k] == (uint32_t)e) {   // the representative nominates its slot: largest / smallest slot with the top count
+            atomicMax(&best_a[site[k]], ((kd_u64)cnt[k] << 32) | s[k]);
+            atomicMax(&best_b[site[k]], ((kd_u64)cnt[k] << 32) | (uint32_t)~s[k]);
+            continue;
+        }
         const uint32_t rr = r[k];
         bool same = site[k] == ins.ev_site[rr] && ins.ev_len[e] == ins.ev_len[rr];
         if (same) {
@@ -142,40 +160,17 @@ k_ins_verify_max(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, kd_u64 *statu
         if (!same) atomicAdd(&status[KDS_INS_COLLISION], 1ULL);
     }
 }
-// the best slot of a site nominates its representative event; any OTHER slot of the site with the same count makes it
-// a tie (kindel.py:377, :421).  Only representatives act.
-__global__ void __launch_bounds__(KD_BLOCK)
-k_ins_pick(KdIns ins, KdInsTab H, kd_u64 n_ev, const kd_u64 *best, uint32_t *win) {
-    const kd_u64 k0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x;
-    uint32_t ev[KD_INS_PER_THREAD], s[KD_INS_PER_THREAD], r[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD], cnt[KD_INS_PER_THREAD];
-    kd_u64 b[KD_INS_PER_THREAD];
-#pragma unroll
-    for (int k = 0; k < KD_INS_PER_THREAD; k++) { const kd_u64 j = k0 + (kd_u64)k * KD_BLOCK; ev[k] = j < n_ev ? (uint32_t)j : 0xffffffffu; }
-#pragma unroll
-    for (int k = 0; k < KD_INS_PER_THREAD; k++) s[k] = ev[k] != 0xffffffffu ? H.ev_slot[ev[k]] : KD_EV_DROPPED;
-#pragma unroll
-    for (int k = 0; k < KD_INS_PER_THREAD; k++) {
-        const kd_u64 e = ev[k];
-        r[k] = 0xffffffffu; site[k] = 0; cnt[k] = 0;
-        if (s[k] != KD_EV_DROPPED) { r[k] = H.rep[s[k]]; site[k] = ins.ev_site[e]; cnt[k] = H.cnt[s[k]]; }
-    }
-#pragma unroll
-    for (int k = 0; k < KD_INS_PER_THREAD; k++) {
-        const kd_u64 e = ev[k];
-        b[k] = (s[k] != KD_EV_DROPPED && r[k] == (uint32_t)e) ? best[site[k]] : 0ULL;
-    }
-#pragma unroll
-    for (int k = 0; k < KD_INS_PER_THREAD; k++) {
-        const kd_u64 e = ev[k];
-        if (s[k] == KD_EV_DROPPED || r[k] != (uint32_t)e) continue;
-        if ((uint32_t)(b[k] >> 32) != cnt[k]) continue;
-        atomicMax(&win[site[k]], (uint32_t)b[k] == s[k] ? (uint32_t)e + 1u : KD_INS_TIE);
-    }
-}
-// undo what the events of the last reduction left in the hash table and in best[] / win[] (all of them are zero between
+// undo what the events of the last reduction left in the hash table and in best_a[] / best_b[] (all of them are zero between
 // reductions: no capacity- or site-proportional memset per kd_finalize)
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_cleanup(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, uint32_t *win) {
+k_ins_cleanup(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best_a, kd_u64 *best_b,
+              kd_u64 *status, kd_u64 *first_idx, kd_u64 *err_first, uint32_t *err_code, uint32_t n_contigs) {
+    // (kd_reset: the status words and the per-contig first-record / first-error state on the way -- k_reset's job, one launch)
+    if (status) {
+        const kd_u64 i = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+        if (i < KDS_COUNT) status[i] = i == KDS_ERR_READ ? ~0ULL : 0ULL;
+        if (i < n_contigs) { first_idx[i] = ~0ULL; err_first[i] = ~0ULL; err_code[i] = 0u; }
+    }
     const kd_u64 k0 = (kd_u64)blockIdx.x * KD_INS_CHUNK + threadIdx.x;
     uint32_t ev[KD_INS_PER_THREAD], s[KD_INS_PER_THREAD], site[KD_INS_PER_THREAD];
 #pragma unroll
@@ -189,9 +184,9 @@ k_ins_cleanup(KdIns ins, KdInsTab H, kd_u64 n_ev, kd_u64 *best, uint32_t *win) {
     for (int k = 0; k < KD_INS_PER_THREAD; k++) {
         if (s[k] >= KD_EV_TAKE) continue;   // dropped, or marked but never inserted
         H.key[s[k]] = 0ULL; H.cnt[s[k]] = 0u;
-        best[site[k]] = 0ULL; win[site[k]] = KD_INS_NONE;
+        best_a[site[k]] = 0ULL; best_b[site[k]] = 0ULL;
         // the event takes part again should the reduction be repeated (re-seeded after a hash collision); a later
-        // kd_finalize marks all events afresh (k_ins_filter)
+        // kd_finalize marks all events afresh (k_ins_insert with the site flags)
         H.ev_slot[ev[k]] = KD_EV_TAKE;
     }
 }

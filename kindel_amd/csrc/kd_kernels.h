@@ -23,7 +23,8 @@
 //                 the non-zero counters per item into HBM
 //   kd_readwise.h k_cold_lane: short reads with S or I: clip start/end counters, insertion events;
 //                 k_pileup_wave: one wavefront per read, every reference quirk incl. Python negative-index wrap,
-//                 32-bit atomics straight to HBM: irregular reads, KD_MODE_GLOBAL; k_diagnose
+//                 32-bit atomics straight to HBM: irregular reads, KD_MODE_GLOBAL
+//   kd_errors.h   k_errors: which read / which reference exception (rare path; rides as k_cold_lane's last workgroup)
 //   kd_ins.h      k_ins_*: insertion events -> open-addressing hash multiset -> per-site unique max
 //   kd_cns.h      k_cns_*: per-site argmax / tie / indel rules, exclusive scan, byte emission
 //   kd_gpu_inflate.h, kd_ingest.h   the device-side ingest (opt-in): k_gpu_inflate (raw DEFLATE of BGZF blocks, one wavefront each),
@@ -35,6 +36,7 @@
 #include "kd_common.h"
 #include "kd_prep.h"
 #include "kd_long.h"
+#include "kd_errors.h"
 #include "kd_readwise.h"
 #include "kd_plan.h"
 #include "kd_window.h"

@@ -485,6 +485,6 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
             else if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)(KDC_CSW + ch) * S + g], 1u);
         }
     }
-    // k_find_bad_base pins down the read and the contig's first failure (it walks regular long reads too)
+    // k_errors (kd_find_bad_base) pins down the read and the contig's first failure (it walks regular long reads too)
     if (bad) atomicAdd(&status[KDS_BAD_BASE], 1ULL);
 }

@@ -153,7 +153,7 @@ __device__ __forceinline__ bool kd_scan_cigar_inside(const uint32_t *cg, uint32_
 __global__ void __launch_bounds__(KD_PREP_BLOCK, KD_PREP_OCC)
 k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold_cnt, kd_u64 *cold_evbase, kd_u64 *cold_poolbase,
        uint32_t *irreg_list, uint32_t *long_list,
-       uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status, uint32_t per_thread) {
+       uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status, uint32_t per_thread, uint32_t *bound, uint32_t nb) {
     // per_thread: reads per lane, a multiple of KD_PREP_UNROLL up to KD_PREP_PER_THREAD (= 64: the bits of the list masks)
     const uint32_t t = threadIdx.x;                      // = the lane
     const kd_u64 chunk0 = (kd_u64)blockIdx.x * KD_PREP_BLOCK * per_thread;
@@ -171,6 +171,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
     // gives every read its offset in the wavefront's range, the range's base follows from ONE returning atomic per wavefront.
     uint32_t w_ev_total = 0;
     kd_u64 w_pool_total = 0;
+    const bool tail_wave = chunk0 < rd.n && chunk0 + (kd_u64)KD_PREP_BLOCK * per_thread >= rd.n;
     uint32_t c_cached = 0xffffffffu;                             // one-entry cache of the contig table
     uint32_t cb_cached = 0, L_cached = 0;                         // (G-space fits 32 bits)
     for (int it0 = 0; it0 < (int)per_thread; it0 += KD_PREP_UNROLL) {
@@ -221,6 +222,33 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
                 const uint32_t pcb = pc == c ? cb_cached : (uint32_t)T.contig_base[pc];
                 const uint32_t pk = pcb + (uint32_t)(ppos > 0 ? ppos : 0);
                 a_unsorted += (ok && pk > gkey) ? 1u : 0u;
+                // k_window's BOUNDARY TABLE (kd_window.h: KdWq): bound[j] = first read that starts at or behind site 64 j.  A read in
+                // a later granule than its predecessor fills the granules in between (the batch's first read: from granule 0) --
+                // by itself when that is one or two entries (deep coverage: every granule holds reads), the whole wavefront
+                // together when it is a gap in the coverage.  Meaningless for an unsorted batch (which is bucket-sorted instead).
+                if (bound) {
+                    const uint32_t kj = gkey >> 6;
+                    const uint32_t b0 = i == 0 ? 0u : (pk >> 6) + 1u;         // first granule to fill
+                    uint32_t cnt = (ok && kj >= b0) ? kj - b0 + 1u : 0u;
+                    if (cnt <= 2u) {
+                        if (cnt) bound[b0] = (uint32_t)i;
+                        if (cnt == 2u) bound[b0 + 1u] = (uint32_t)i;
+                        cnt = 0;
+                    }
+                    for (unsigned long long m = kd_ballot(cnt != 0); m; m &= m - 1) {
+                        const uint32_t l = (uint32_t)__builtin_ctzll(m);
+                        const uint32_t f0 = kd_shfl(b0, l), fn = kd_shfl(cnt, l), fv = kd_shfl((uint32_t)i, l);
+                        for (uint32_t x = t; x < fn; x += KD_WAVE) bound[f0 + x] = fv;
+                    }
+                    // behind the batch's last read: "none" = the number of reads
+                    if (tail_wave) {   // (uniform: the wavefront that holds the batch's last read)
+                        const unsigned long long lm = kd_ballot(ok && i + 1 == rd.n);
+                        if (lm) {
+                            const uint32_t f0 = kd_shfl(kj, (uint32_t)__builtin_ctzll(lm)) + 1u;
+                            for (uint32_t x = f0 + t; x <= nb; x += KD_WAVE) bound[x] = (uint32_t)rd.n;
+                        }
+                    }
+                }
             }
             const uint32_t sl = v_sl[u], nc = v_nc[u];
             // the read's first four words in place (the batch's last reads were loaded from in front of their first word)

@@ -1,4 +1,4 @@
-// kd_readwise.h -- k_pileup_wave (exact semantics, wavefront per read), k_cold_lane, k_diagnose.
+// kd_readwise.h -- k_pileup_wave (exact semantics, wavefront per read), k_cold_lane.
 // Part of the device code of kd_kernels.h (included from there, in order; not a stand-alone header).
 #pragma once
 #include "kd_common.h"
@@ -138,9 +138,12 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
 // k_window has tallied the clipped bases: the clip_ends / clip_starts counters (one 32-bit atomic each) and
 // the insertion events, written into the slots k_prep reserved for the read.  One LANE per read of the cold
 // list.  Regular reads cannot raise and never wrap (k_prep checked), so this is plain G-space arithmetic.
+// The workgroup behind the last record region is the batch's error classification (kd_errors.h): the other kernels of the
+// batch have finished, this kernel flags nothing.
 __global__ void __launch_bounds__(KD_BLOCK)
 k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const KdColdRec *rec, const uint32_t *cold_cnt, const kd_u64 *cold_evbase,
-            const kd_u64 *cold_poolbase, uint32_t region_slots, kd_u64 *status) {
+            const kd_u64 *cold_poolbase, uint32_t region_slots, kd_u64 *status, const KdRInfo *rinfo, uint32_t n_contigs) {
+    if (blockIdx.x + 1 == gridDim.x) { kd_errors(rd, T, rinfo, n_contigs, status, true); return; }
     // one workgroup per record region (= per wavefront of k_prep): cnt records, usually fewer than 256
     const uint32_t cnt = cold_cnt[blockIdx.x];
     const KdColdRec *reg = rec + (kd_u64)blockIdx.x * region_slots;
@@ -232,76 +235,4 @@ k_cold_slots(const KdColdRec *rec, const uint32_t *cold_cnt, const kd_u64 *cold_
         read_ev[cr.read] = (uint32_t)(cold_evbase[blockIdx.x] + cr.ev_rel);
         read_pool[cr.read] = cold_poolbase[blockIdx.x] + cr.pool_rel;
     }
-}
-
-// k_diagnose: one thread per contig re-walks the contig's first failing read of this batch serially, in the reference's
-// own statement order, to decide WHICH exception the reference raises (KeyError vs IndexError vs RuntimeError).
-// Error classification only -- it writes no table.  (A contig's first failing read is final once the batch that
-// contains it has been pushed: later batches only hold larger read indices.)
-__global__ void __launch_bounds__(KD_BLOCK)
-k_diagnose(KdReads rd, KdTabs T, uint32_t n_contigs, kd_u64 *status) {
-    if (status[KDS_ERR_READ] == ~0ULL) return;
-    const uint32_t cdx = blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (cdx >= n_contigs) return;
-    const kd_u64 gidx = T.err_first[cdx];
-    if (gidx == ~0ULL || gidx < rd.base_index || gidx >= rd.base_index + rd.n) return;
-    const kd_u64 i = gidx - rd.base_index;
-    const int64_t sl = rd.seq_len[i];
-    const uint32_t nc = rd.n_cig[i];
-    const int64_t L = T.contig_len[rd.contig[i]];
-    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
-    const uint32_t *cg = rd.cigar + rd.cig_off[i];
-    kd_u64 code = 8;  // KD_E_INTERNAL magnitude: flagged but no exception reproduced
-    if (nc == 0) { T.err_code[cdx] = 3u; return; }
-    int64_t r = rd.pos0[i], q = 0;
-    for (uint32_t k = 0; k < nc && code == 8; k++) {
-        const int64_t len = cg[k] >> 4;
-        const uint32_t op = cg[k] & 15u;
-        if (op == 0 || op == 7 || op == 8) {
-            for (int64_t j = 0; j < len; j++) {
-                if (q >= sl) { code = 2; break; }
-                int64_t idx = r < 0 ? r + L : r;
-                if (idx < 0 || idx >= L) { code = 2; break; }
-                if (kd_chan(kd_nib(seq, q)) == 7u) { code = 1; break; }
-                r++; q++;
-            }
-        } else if (op == 1) {
-            int64_t idx = r < 0 ? r + L + 1 : r;
-            if (idx < 0 || idx > L) { code = 2; break; }
-            q += len;
-        } else if (op == 2) {
-            for (int64_t j = 0; j < len; j++) {
-                int64_t idx = r + j < 0 ? r + j + L + 1 : r + j;
-                if (idx < 0 || idx > L) { code = 2; break; }
-            }
-            r += len;
-        } else if (op == 4) {
-            if (k == 0) {
-                int64_t idx = r < 0 ? r + L + 1 : r;
-                if (idx < 0 || idx > L) { code = 2; break; }
-                for (int64_t j = 0; j < len; j++) {
-                    if (j >= sl) { code = 2; break; }
-                    const int64_t rel = r - len + j;
-                    if (rel >= 0) {
-                        if (rel >= L) { code = 2; break; }
-                        if (kd_chan(kd_nib(seq, j)) == 7u) { code = 1; break; }
-                    }
-                }
-                q += len;
-            } else {
-                int64_t idx = r - 1 < 0 ? r - 1 + L + 1 : r - 1;
-                if (idx < 0 || idx > L) { code = 2; break; }
-                for (int64_t j = 0; j < len; j++) {
-                    if (q >= sl) { code = 2; break; }
-                    if (r < L) {
-                        int64_t wi = r < 0 ? r + L : r;
-                        if (wi < 0 || wi >= L) { code = 2; break; }
-                        if (kd_chan(kd_nib(seq, q)) == 7u) { code = 1; break; }
-                        r++; q++;
-                    }
-                }
-            }
-        }
-    }
-    T.err_code[cdx] = (uint32_t)code;
 }

@@ -1,4 +1,4 @@
-// kd_window.h -- k_window: the LDS-histogram pileup (dominant kernel), its walkers, k_find_bad_base.
+// kd_window.h -- k_window: the LDS-histogram pileup (dominant kernel), its walkers.
 // Part of the device code of kd_kernels.h (included from there, in order; not a stand-alone header).
 #pragma once
 #include "kd_common.h"
@@ -479,10 +479,45 @@ __device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const
 #ifndef KD_WINDOW_OCC
 #define KD_WINDOW_OCC 5
 #endif
+// k_window's WORK QUEUE (round 4: the kernel plans for itself).  Rounds 1 - 3 planned in two kernels of their own -- a binary
+// search per window for its candidate range (k_plan_ranges, 24 us on C3: 24 dependent loads), a one-workgroup scan of the
+// per-window item counts that also wrote an item -> window table (k_plan_scan, 29 us) -- a twentieth of the step on C3 and
+// a tenth on a small input (C2, an eighth of C3 on one of eight GPUs).  Now:
+//   * the candidate range of a window comes from a BOUNDARY TABLE: first entry whose start lies at or behind site j * gran.
+//     For a sorted batch k_prep writes it as it classifies the reads (gran 64: a lane whose read starts in a later granule
+//     than its predecessor's fills the granules in between); for a bucket-sorted one it is the bin offsets of the sort (gran W);
+//   * a workgroup takes a WINDOW TICKET, reads its range from the table and tallies the window's first `slice` candidates.  A
+//     window with more (a deep small genome: C2 has 23 windows of 29 000 reads) goes onto the HOT LIST with a slice counter;
+//     its owner keeps taking slices from the counter, and workgroups that find the tickets gone wait until every ticket holder
+//     has published (a count: owners publish right after the dequeue, before they tally) and then help with the hot windows.
+//     No scan, no item table, nothing sized by an upper bound on the items.
+struct KdWq {
+    const uint32_t *bound32;   // k_prep's table (gran 64), or NULL:
+    const kd_u64 *bound64;     //   the bin offsets of the bucket sort (entry b * reps = first slot of bin b)
+    uint32_t gran, reps;
+    uint32_t nb;               // last valid index of the table (= its entry for "behind the last site")
+    uint32_t *hot;             // [2 * n_win]: window, next slice
+    uint32_t n_win, span_slot;
+};
+__device__ __forceinline__ kd_u64 kd_wq_bound(const KdWq &Q, kd_u64 j) {
+    j = j < Q.nb ? j : Q.nb;
+    return Q.bound32 ? (kd_u64)Q.bound32[j] : Q.bound64[j * Q.reps];
+}
+// candidate range of local window w: entries that start in [wlo - back, whi + maxlead), `back` = what an entry in front of the
+// window can have left for it (OWNERSHIP below: nothing unless it is longer than H -- except for the plan's first window)
+__device__ __forceinline__ void kd_wq_range(const KdWq &Q, const kd_u64 *status, uint32_t w0, uint32_t w, uint32_t W, uint32_t H,
+                                            kd_u64 &lo, kd_u64 &hi) {
+    kd_u64 back = status[Q.span_slot];
+    if (w) back = back > H ? back - H : 0;
+    const kd_u64 wlo = (kd_u64)(w0 + w) * W, whi = wlo + W;
+    lo = kd_wq_bound(Q, (wlo > back ? wlo - back : 0) / Q.gran);
+    hi = kd_wq_bound(Q, (whi + status[KDS_B_MAXLEAD] + Q.gran - 1) / Q.gran);
+    if (hi < lo) hi = lo;      // (an unsorted batch's table is meaningless -- and unused; never a negative range)
+}
+
 template <bool ROWS>
 __global__ void __launch_bounds__(KD_BLOCK, KD_WINDOW_OCC)   // 5 wavefronts per SIMD = the 5 workgroups per CU the LDS footprint allows
-k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
-         const kd_u64 *win_lo, const kd_u64 *win_hi, const kd_u64 *item_off, const uint32_t *item_win, kd_u64 items_cap, uint32_t w0,
+k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq Q, uint32_t w0,
          uint32_t W, uint32_t H, uint32_t Wh_, uint32_t slice, kd_u64 *status) {
     // OWNERSHIP (round 3).  The histogram of window w covers the sites [wlo, whi + H): H sites more than the window.  An entry
     // is tallied by the window its START lies in, over [start, min(end, whi + H)) -- with H >= the longest footprint of the
@@ -503,13 +538,13 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
     uint32_t *hist0 = hist + (KD_HALO / 2) * KD_HPITCH;   // pair of window-relative site 0
     uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * Wh);  // tile-relative read indices
     uint16_t *l_cplx = l_plain + KD_TILE;
-    __shared__ kd_u64 s_item;
+    __shared__ kd_u64 s_first, s_last;
+    __shared__ uint32_t s_win;
     // [tile parity][list]: 0 own plain entries that end inside the histogram (l_plain from the front), 1 own plain entries cut by
     // its end (l_plain from the back), 2 own complex entries (l_cplx from the front), 3 early / late entries (l_cplx from the back)
     __shared__ uint32_t s_cnt[2][4];
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
-    const kd_u64 total = status[KDS_TOTAL_ITEMS];
     const uint32_t nh = (uint32_t)KD_HCH * (uint32_t)Wh;   // histogram dwords
     const int32_t Wi = (int32_t)W, We = (int32_t)(W + H);     // the window / the histogram's reach, in sites
     uint32_t *hist_early = hist0 + (H / 2) * KD_HPITCH;       // pair of site wlo + H: origin of the early entries' walk (H is even)
@@ -523,16 +558,68 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
 #else
 #define KD_MARK(acc)
 #endif
+    // thread 0's view of the queue, kept across items -- in LDS, not in registers: every lane would carry them, and the walk
+    // needs its 96
+    const uint32_t NONE = 0xffffffffu;
+    __shared__ uint32_t q_hot_w, q_hot_j, q_hot_K;      // the hot window this workgroup is taking slices from
+    __shared__ kd_u64 q_hot_lo, q_hot_hi;
+    __shared__ uint32_t q_state, q_scan, q_nhot;        // q_state: 0 window tickets may be left, 1 none left, 2 helping
+    if (t == 0) { q_hot_w = NONE; q_state = 0; }
     for (;;) {
-        if (t == 0) { s_item = atomicAdd(&status[KDS_NEXT_ITEM], 1ULL); s_cnt[0][0] = 0; s_cnt[0][1] = 0; s_cnt[0][2] = 0; s_cnt[0][3] = 0; }
+        if (t == 0) {
+            uint32_t w = NONE, k = 0;
+            kd_u64 lo = 0, hi = 0;
+            for (;;) {
+                if (q_hot_w != NONE) {                   // a window with several slices: the next one nobody has taken
+                    k = atomicAdd(&Q.hot[2 * q_hot_j + 1], 1u);
+                    if (k < q_hot_K) { w = q_hot_w; lo = q_hot_lo; hi = q_hot_hi; break; }
+                    q_hot_w = NONE;
+                    continue;
+                }
+                if (q_state == 0) {
+                    const kd_u64 tk = atomicAdd(&status[KDS_WQ_TICKET], 1ULL);
+                    if (tk >= Q.n_win) { q_state = 1; continue; }
+                    kd_wq_range(Q, status, w0, (uint32_t)tk, W, H, lo, hi);
+                    const kd_u64 K = (hi - lo + slice - 1) / slice;
+                    if (K > 1) {                         // publish the window for helpers; slice 0 is this workgroup's
+                        const uint32_t j = (uint32_t)atomicAdd(&status[KDS_WQ_HOT], 1ULL);
+                        Q.hot[2 * j] = (uint32_t)tk; Q.hot[2 * j + 1] = 1u;
+                        q_hot_w = (uint32_t)tk; q_hot_j = j; q_hot_K = (uint32_t)(K < 0xffffffffULL ? K : 0xffffffffULL);
+                        q_hot_lo = lo; q_hot_hi = hi;
+                        atomicAdd(&status[KDS_TOTAL_ITEMS], K - 1);      // (statistics: kd_get_batch_info)
+                        __threadfence();
+                    }
+                    atomicAdd(&status[KDS_WQ_PUB], 1ULL);
+                    if (K == 0) continue;                // nothing starts near this window
+                    w = (uint32_t)tk; k = 0;
+                    break;
+                }
+                if (q_state == 1) {                      // every ticket is taken: wait until their holders have published
+                    while (kd_ld_acquire(&status[KDS_WQ_PUB]) < (kd_u64)Q.n_win) kd_spin_pause();
+                    q_nhot = (uint32_t)kd_ld_acquire(&status[KDS_WQ_HOT]);
+                    q_state = 2; q_scan = 0;
+                }
+                if (q_scan >= q_nhot) break;             // w == NONE: done
+                // (workgroups start at different entries of the list and go round)
+                const uint32_t j = (blockIdx.x + q_scan) % q_nhot;
+                q_scan++;
+                kd_u64 hlo, hhi;
+                const uint32_t hw = Q.hot[2 * j];
+                kd_wq_range(Q, status, w0, hw, W, H, hlo, hhi);
+                const kd_u64 K = (hhi - hlo + slice - 1) / slice;
+                q_hot_w = hw; q_hot_j = j; q_hot_K = (uint32_t)(K < 0xffffffffULL ? K : 0xffffffffULL); q_hot_lo = hlo; q_hot_hi = hhi;
+            }
+            s_win = w;
+            s_first = lo + (kd_u64)k * slice;
+            s_last = lo + (kd_u64)k * slice + slice < hi ? lo + (kd_u64)k * slice + slice : hi;
+            s_cnt[0][0] = 0; s_cnt[0][1] = 0; s_cnt[0][2] = 0; s_cnt[0][3] = 0;
+        }
         __syncthreads();
-        const kd_u64 item = s_item;
-        if (item >= total || item >= items_cap) break;   // (>= items_cap: k_plan_items has raised KDS_INTERNAL)
+        const uint32_t w = s_win;
+        if (w == NONE) break;
         KD_MARK(c_deq)
-        const uint32_t w = item_win[item];   // k_plan_items: the window with item_off[w] <= item < item_off[w + 1]
         const kd_u64 wlo = (kd_u64)(w0 + w) * W, whi = wlo + W;
-        const kd_u64 first = win_lo[w] + (item - item_off[w]) * slice;
-        const kd_u64 last = first + slice < win_hi[w] ? first + slice : win_hi[w];
+        const kd_u64 first = s_first, last = s_last;
         // The classification keys (start, span | flags, lead) of a tile are fetched ONE TILE AHEAD into registers:
         // the loads of tile k + 1 are in flight while tile k is walked.  `order`: bucket-sorted permutation.
         uint32_t p_gs[KD_TILE_PER_THREAD], p_sc[KD_TILE_PER_THREAD], p_ld[KD_TILE_PER_THREAD];
@@ -701,7 +788,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
                 }
             }
         }
-        // a base outside A,C,G,T,N inside an aligned or clipped segment: k_find_bad_base pins down the read
+        // a base outside A,C,G,T,N inside an aligned or clipped segment: k_errors (kd_find_bad_base) pins down the read
         if (bad) atomicAdd(&status[KDS_BAD_BASE], 1ULL);
         KD_MARK(c_flush)
         __syncthreads();
@@ -715,37 +802,4 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
         atomicAdd(&status[KDS_DBG6], (kd_u64)c_flush); atomicAdd(&status[KDS_DBG7], 1ULL);
     }
 #endif
-}
-
-// Rare path: k_window saw a base outside A,C,G,T,N.  One workgroup walks the regular reads of the
-// batch and records the first offender (atomicMin of the read index), for k_diagnose to classify.
-__global__ void __launch_bounds__(KD_BLOCK)
-k_find_bad_base(KdReads rd, KdTabs T, const KdRInfo *rinfo, kd_u64 *status) {
-    if (status[KDS_BAD_BASE] == 0) return;
-    for (kd_u64 i = threadIdx.x; i < rd.n; i += KD_BLOCK) {
-        const uint32_t cls_i = rinfo[i].span_cls & 3u;
-        if (cls_i != KD_CLS_REG && cls_i != KD_CLS_LONG) continue;   // regular reads, short and long
-        if (rd.base_index + i >= T.err_first[rd.contig[i]]) continue;   // the contig already has an earlier failing read
-        const uint8_t *seq = rd.seq4 + rd.seq_off[i];
-        const uint32_t *cg = rd.cigar + rd.cig_off[i];
-        const uint32_t nc = rd.n_cig[i];
-        const int64_t L = T.contig_len[rd.contig[i]];
-        int64_t q = 0, r = rd.pos0[i];
-        bool found = false;
-        for (uint32_t k = 0; k < nc && !found; k++) {
-            const int64_t len = cg[k] >> 4;
-            const uint32_t op = cg[k] & 15u;
-            int64_t x0 = 0, x1 = 0;  // query bases the reference looks up in a weight dict
-            if (op == 0 || op == 7 || op == 8) { x0 = q; x1 = q + len; q += len; r += len; }
-            else if (op == 1) q += len;
-            else if (op == 2) r += len;
-            else if (op == 4) {
-                if (k == 0) { x0 = r < len ? len - r : 0; x1 = len; q += len; }
-                else { const int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0; x0 = q; x1 = q + n_adv; k = nc; }
-            }
-            for (int64_t x = x0; x < x1; x++)
-                if (kd_chan(kd_nib(seq, x)) == 7u) { found = true; break; }
-        }
-        if (found) kd_flag_error(T, status, rd.contig[i], rd.base_index + i);
-    }
 }

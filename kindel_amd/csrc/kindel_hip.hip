@@ -46,6 +46,7 @@ struct HipRt {
         profile_reset();
         graph_drop();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; }
+        if (stage_buf) { (void)hipHostFree(stage_buf); stage_buf = nullptr; stage_cap = 0; }
         for (int k = 0; k < 2; k++) { if (up_pin[k]) { (void)hipHostFree(up_pin[k]); up_pin[k] = nullptr; } if (up_ev[k]) { (void)hipEventDestroy(up_ev[k]); up_ev[k] = nullptr; } }
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
         if (ev_copy) { (void)hipEventDestroy(ev_copy); ev_copy = nullptr; }
@@ -130,6 +131,19 @@ struct HipRt {
             if (after(o + len)) return 1;
         }
         return 0;
+    }
+
+    // a pinned host buffer for a step's closing round trip (status words + run metadata), grown on demand
+    void *stage_buf = nullptr;
+    size_t stage_cap = 0;
+    void *stage(size_t bytes) {
+        if (bytes <= stage_cap) return stage_buf;
+        if (bad(hipSetDevice(dev))) return nullptr;
+        if (stage_buf) { (void)hipStreamSynchronize(stream); (void)hipHostFree(stage_buf); stage_buf = nullptr; stage_cap = 0; }
+        const size_t n = (bytes + 65535) & ~(size_t)65535;
+        if (bad(hipHostMalloc(&stage_buf, n, hipHostMallocDefault))) { stage_buf = nullptr; return nullptr; }
+        stage_cap = n;
+        return stage_buf;
     }
 
     // small readbacks (the status words, one cache line each: 4 KiB, 5 KiB in a profiling build) go through a pinned bounce buffer:

@@ -7,6 +7,7 @@
 #include "hip_emu.h"
 
 #include <string>
+#include <vector>
 
 #include "../../kindel_amd/csrc/kd_engine.h"
 
@@ -43,6 +44,8 @@ struct EmuRt {
         return 0;
     }
     int sync() { return 0; }
+    std::vector<unsigned char> stage_buf;
+    void *stage(size_t bytes) { if (stage_buf.size() < bytes) stage_buf.resize(bytes); return stage_buf.data(); }
     int d2h_async(void *h, const void *d, size_t n) { ::memcpy(h, d, n); return 0; }
     // (no graphs here: kd_step always takes the eager path on the emulator)
     bool graph_supported() const { return false; }

@@ -231,6 +231,10 @@ static inline uint32_t atomicCAS(uint32_t *p, uint32_t cmp, uint32_t v) {
     return cmp;
 }
 
+static inline unsigned long long kd_ld_acquire(const unsigned long long *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+static inline void kd_spin_pause() { std::this_thread::yield(); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
 namespace emu {
 
 constexpr size_t kStack = 64 * 1024;   // per fiber
