@@ -8,14 +8,15 @@ resident in HBM: zero the tables, record loop (k_prep / k_plan / k_window / k_co
 insertion multiset reduction, per-site consensus, and the rank's consensus bytes copied to pinned host
 memory; at N > 1 additionally the all-gather that leaves the stitched consensus of ALL ranks in every
 GPU's HBM (assembling that into one host FASTA is file output, done once outside the timed region).  N > 1: one process per GPU (torchrun), reference
-positions sharded by G-space interval with no collective on the pileup path.  WEAK scaling: the
-N-GPU workload is N copies of the config's contig set (N x 5 Mbp at 500x for C3), so every rank
-owns one config-sized interval and synthesises the reads of its own interval.
+positions sharded by G-space interval with no collective on the pileup path.  N > 1 reports STRONG scaling as `value` (the
+north star's figure: ONE config-sized input cut into N work-balanced position intervals, total work fixed) and measures weak
+scaling (N copies of the config's contig set, one per rank) right after, as `other_scaling`; `--scaling weak` swaps them.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
 kernel (per-launch durations from hipEvents on the engine's stream) and, at N = 1,
-`cpu_baseline`: the C oracle (oracle/kindel_oracle.c, a port of the reference's loops) timed on
-one host core over the same batch, which doubles as a full-size bit-exactness check.
+`cpu_baseline`: the UNMODIFIED reference (kindel.kindel.parse_records + consensus_sequence) timed in this run on one host
+core over a bounded sample of the same workload; nested in it (`c_port`) the C oracle (oracle/kindel_oracle.c, a port of the
+reference's loops) over the whole batch, which doubles as the full-size bit-exactness check.
 """
 import argparse
 import hashlib
@@ -53,7 +54,7 @@ def main():
     ap.add_argument("--sweep", default="", help="extra tunings to time on the same batch: mode:window:slice,...")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; "
                     "gloo only to exercise the multi-rank path on a box with fewer GPUs than ranks)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+    ap.add_argument("--scaling", default="", choices=["", "weak", "strong"],
                     help="N > 1: weak = N copies of the config's contig set, one per rank (per-GPU work fixed); strong = ONE "
                          "config-sized input, work-balanced contiguous position intervals (whole contigs where possible), every "
                          "rank takes its reads from the one shared batch (total work fixed)")
@@ -67,6 +68,8 @@ def main():
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="time the eager submission only (no kd_step / hipGraph replay)")
     ap.add_argument("--e2e-scale", type=float, default=0.1, help="N = 1: depth scale of the live end-to-end leg (BAM file -> FASTA; 0 = skip)")
     args = ap.parse_args()
+    if not args.scaling:      # N > 1: strong scaling is the headline (BASELINE.json: one input over 1 / 2 / 4 / 8 GPUs); N = 1: the contract's word
+        args.scaling = "strong" if args.gpus > 1 else "weak"
 
     import torch
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -172,18 +175,23 @@ def main():
 
         state = {}
 
-        def step(graph=False):
-            if graph:
-                # the same work in ONE call (kd_step): a repeat of the same resident batch replays the captured hipGraph of the
-                # dispatch chain and verifies its decisions on the device's status words afterwards
-                off, state["replayed"] = eng.step_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"], pinned_np)
-            else:
+        def step(graph=False, classic=False):
+            if classic:
+                # the call sequence of rounds 1 - 3, five blocking read-backs (kept as a second, independent way to the same bytes)
                 eng.reset()
                 eng.push_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"])
                 eng.finalize()
                 eng.consensus_run(1)
-                # this rank's consensus bytes -> pinned host memory (at N = 1 that is the whole FASTA) ...
                 off = eng.consensus_fetch_all_into(pinned_np)
+            else:
+                # ONE call (kd_step): reset, record loop, insertion reduction, consensus and this rank's consensus bytes into pinned
+                # host memory (at N = 1 the whole FASTA), two host round trips.  graph=False: the eager sequence, what every new
+                # batch takes (`value`).  graph=True: the first repeat on the same resident batch is captured, later ones replay the
+                # hipGraph and verify its decisions on the device's status words (`replay_ms_per_step`).
+                if state.get("graph") != graph:
+                    eng.set_step_graph(graph)
+                    state["graph"] = graph
+                off, state["replayed"] = eng.step_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"], pinned_np)
             seqs = [pinned_np[int(off[c]): int(off[c + 1])] for c in range(n_contigs)]
             # ... and, at N > 1, the all-gather that leaves the stitched consensus in every GPU's HBM
             if world > 1:
@@ -210,7 +218,12 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         prof_dom = eng.profile()
-        dt_eager, submission = dt, "eager: one dispatch per kernel, two blocking status read-backs per step"
+        dt_eager, submission = dt, "eager (kd_step): one dispatch per kernel, two host round trips per step"
+        seqs_eager = seqs
+        # the classic five-call sequence once (untimed): the same bytes by the other way
+        seqs_c = [bytes(memoryview(x)) for x in step(classic=True)]
+        assert seqs_c == [bytes(memoryview(x)) for x in step()], "kd_step and the classic call sequence disagree"
+        dt_graph = None
         if args.graph:
             # timed region (one-launch step): the same K steps through kd_step.  The first call records + captures, so it is part
             # of the warm-up; the timed steps must all have been served by the graph, else the eager figure stands.
@@ -226,9 +239,9 @@ def main():
             barrier()
             dt_graph = time.perf_counter() - t0
             if all_replayed:
-                assert all(bytes(memoryview(a)) == bytes(memoryview(b)) for a, b in zip(seqs, seqs_g))
-                dt, seqs = dt_graph, seqs_g
-                submission = "hipGraph replay of the step's dispatch chain (kd_step), decisions verified on the device's status words after every replay"
+                assert all(bytes(memoryview(a)) == bytes(memoryview(b)) for a, b in zip(seqs_eager, seqs_g))
+            else:
+                dt_graph = None
         eng.profile_enable(1)
         eng.profile_reset()
         for _ in range(args.steps):
@@ -236,10 +249,11 @@ def main():
         barrier()
         prof = eng.profile()
         eng.profile_enable(0)
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt, dt_graph if dt_graph is not None else -1.0], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = float(tmax[0].item())
+        dt_graph = float(tmax[1].item()) if dt_graph is not None else None
         info = eng.batch_info()
         stats = eng.stats()
         if world > 1:   # host assembly of the stitched FASTA, outside the timed region (checksum only)
@@ -266,7 +280,7 @@ def main():
                 launches_per_step = rows[dom][0] / args.steps
                 a = B / world / max(launches_per_step, 1) / (rows[dom][1] * 1e-3) / 1e9
                 roofline = dict(bound="hbm", kernel=dom, achieved=round(a, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                                frac=round(a / HBM_PEAK_GBS, 5), traffic=_pmc_traffic(dom), traffic_source=_PMC_SOURCE,
+                                frac=round(a / HBM_PEAK_GBS, 5), traffic=_pmc_traffic(dom, args, world), traffic_source=_PMC_SOURCE,
                                 avg_launch_ms=round(rows[dom][1], 4),
                                 algorithmic_bytes=int(B), bytes_per_event=round(B / max(aligned_g, 1), 4),
                                 step_achieved=round(B / (dt / args.steps) / 1e9, 2),
@@ -274,7 +288,8 @@ def main():
             out = dict(
                 metric="aligned-base events/sec pileup+consensus", value=value, unit="events/s", n_gpus=world,
                 steps=args.steps, warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, submission=submission,
-                eager_ms_per_step=round(dt_eager / args.steps * 1e3, 4),
+                replay_ms_per_step=(round(dt_graph / args.steps * 1e3, 4) if dt_graph is not None else None),
+                replay_note="the same K steps through kd_step's hipGraph replay of the SAME resident batch (a repeat no real input makes: never `value`)",
                 scaling=scaling if world > 1 else "weak", vs_baseline=None, dtype="u32", data="synthetic",
                 config=dict(workload="%s: synthetic %s, %d contig(s), %d sites, depth %gx%s" % (
                     args.config, "150 bp short reads" if cfg["kind"] == "short" else "ONT-like long reads",
@@ -463,12 +478,21 @@ def _cpu_quota():
         return None
 
 
-def _pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*pmc*.json), or None."""
+def _pmc_key(args, world):
+    """The workload a committed PMC record belongs to: config, kernel mode, input order, scale, ranks."""
+    return "%s|%s|%s" % (args.config, args.mode, ("shuffle-" + args.shuffle) if args.shuffle else "sorted")
+
+
+def _pmc_traffic(kernel, args, world):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of THIS workload (profiles/pmc_traffic.json:
+    {"<config>|<mode>|<order>": {kernel: {"bytes": ...}}}), or None when no record of this workload exists (another config, a
+    scaled / overridden generator, N > 1): a figure measured on another workload is not this one's traffic."""
+    if world != 1 or args.scale != 1.0 or args.synth or args.window or args.slice:
+        return None
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(p):
         try:
-            return (json.load(open(p)).get(kernel) or {}).get("bytes")
+            return ((json.load(open(p)).get(_pmc_key(args, world)) or {}).get(kernel) or {}).get("bytes")
         except Exception:
             return None
     return None
@@ -519,11 +543,21 @@ def cpu_baseline(batch, contig_lens, gpu_seqs, sample, aligned_total):
             same = same and (seq.encode() == gpu_seqs[cid])
     dt = time.perf_counter() - t0
     from kindel_amd import _native as _N
-    return dict(value=ev / dt, unit="events/s", cores=1, kind="port", host_cores=os.cpu_count(), host_cpu_quota=_cpu_quota(), decoder_threads_default=_N.host_threads(),
+    port = dict(value=ev / dt, unit="events/s", cores=1, kind="port",
                 sample="%s of the %d reads (%d aligned-base events), all contigs, pileup + consensus; %.1f s" % (
                     "all" if frac >= 1.0 else "every %d-th" % int(round(1.0 / frac)), n, ev, dt),
-                bit_exact_vs_gpu=(same if frac >= 1.0 else None),
-                reference_python=refpy)
+                bit_exact_vs_gpu=(same if frac >= 1.0 else None))
+    host_info = dict(host_cores=os.cpu_count(), host_cpu_quota=_cpu_quota(), decoder_threads_default=_N.host_threads())
+    if refpy and "value" in refpy:
+        # the contract's baseline: the reference's own CPU path, timed beside the GPU number; the C port (the oracle) nested
+        out = dict(refpy)
+        out.update(host_info)
+        out["c_port"] = port
+        out["bit_exact_vs_gpu"] = port["bit_exact_vs_gpu"]     # (the full-size check is the port's: the Python reference walks a sample)
+        return out
+    port.update(host_info)
+    port["reference_python"] = refpy
+    return port
 
 
 if __name__ == "__main__":

@@ -201,6 +201,15 @@ int kd_changes_device(kd_ctx *ctx, void **dev_ptr);
  * if the graph served the call.  seq_out should be pinned host memory.  Errors as kd_finalize. */
 int kd_step(kd_ctx *ctx, const kd_batch *dev_batch, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out,
             uint64_t *contig_off, int *replayed);
+/* kd_set_step_graph: on = 0: kd_step always takes the eager sequence (what a new batch takes anyway); on = 1 (default): the first
+ * REPEAT of a step on the same resident batch is captured, later repeats replay the graph. */
+int kd_set_step_graph(kd_ctx *ctx, int on);
+/* kd_finish: everything behind the pushes in one call and ONE host round trip -- kd_finalize + kd_consensus_run(min_depth, no
+ * patches) + kd_consensus_fetch_all -- i.e. consensus(insertions[pos]) :420 and consensus_sequence :384-430 for all contigs, the
+ * bytes of all contigs in G-space order into seq_out (cap bytes; pinned memory makes the copy asynchronous), *len_out their number,
+ * contig_off[n_contigs + 1] (may be NULL) each contig's offset.  Errors as kd_finalize (the deferred reference exceptions).  Afterwards
+ * the context is finalized and has a consensus run: kd_get_tables / kd_get_insertions / kd_consensus_fetch / kd_changes_device work. */
+int kd_finish(kd_ctx *ctx, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint64_t *contig_off);
 /* Host-side metadata of the last run: contig_off[n_contigs+1] = byte offset of each contig in the
  * concatenated consensus (last entry = total), depth_minmax[2*n_contigs]. Either may be NULL. */
 int kd_consensus_offsets(kd_ctx *ctx, uint64_t *contig_off, uint32_t *depth_minmax);

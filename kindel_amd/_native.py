@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error "
     "kd_stream_open kd_stream_n_contigs kd_stream_contig_name kd_stream_contig_len kd_stream_next kd_stream_n_records "
     "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_write_bam kd_host_threads kd_host_inflate kd_host_crc32 "
-    "kd_bgzf_index kd_decode_open_span kd_step kd_bgzf_plan_open kd_bgzf_plan_n_contigs kd_bgzf_plan_contig_name kd_bgzf_plan_contig_len "
+    "kd_bgzf_index kd_decode_open_span kd_step kd_finish kd_set_step_graph kd_bgzf_plan_open kd_bgzf_plan_n_contigs kd_bgzf_plan_contig_name kd_bgzf_plan_contig_len "
     "kd_bgzf_plan_view kd_bgzf_plan_close kd_push_bam_gpu"
 ).split()
 
@@ -100,6 +100,8 @@ class Library:
         L.kd_consensus_offsets.argtypes = [p, p, p]
         L.kd_consensus_fetch_all.argtypes = [p, p, u64, C.POINTER(u64), p, p]
         L.kd_step.argtypes = [p, C.POINTER(kd_batch), u32, p, u64, C.POINTER(u64), p, C.POINTER(C.c_int)]
+        L.kd_finish.argtypes = [p, u32, p, u64, C.POINTER(u64), p]
+        L.kd_set_step_graph.argtypes = [p, C.c_int]
         L.kd_profile_enable.argtypes = [p, C.c_int]
         L.kd_profile_get.argtypes = [p, C.POINTER(u32), p, p, p]
         L.kd_profile_reset.argtypes = [p]
@@ -505,6 +507,19 @@ class Engine:
         self._n_patches = 0
         self._check(self.lib.dll.kd_step(self._h, C.byref(b), int(min_depth), _ptr(out), out.size, C.byref(ln), _ptr(off), C.byref(rep)), "kd_step")
         return off, bool(rep.value)
+
+    def set_step_graph(self, on):
+        """False: step_device always takes the eager sequence; True (default): a repeated step is captured and replayed."""
+        self._check(self.lib.dll.kd_set_step_graph(self._h, 1 if on else 0), "kd_set_step_graph")
+
+    def finish(self, out, min_depth=1):
+        """Everything behind the pushes in one call and one host round trip (kd_finish): insertion reduction, consensus of all
+        contigs, their bytes into `out`.  -> contig_off uint64[n_contigs + 1].  Raises like finalize()."""
+        ln = C.c_uint64(0)
+        off = np.zeros(len(self.contig_lens) + 1, np.uint64)
+        self._n_patches = 0
+        self._check(self.lib.dll.kd_finish(self._h, int(min_depth), _ptr(out), out.size, C.byref(ln), _ptr(off)), "kd_finish")
+        return off
 
     def push_stream(self, stream):
         """Every remaining batch of a Stream: decode of batch k+1 overlapped with copy + kernels of batch k.

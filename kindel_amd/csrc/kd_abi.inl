@@ -121,6 +121,15 @@ int kd_consensus_device(kd_ctx *ctx, void **dev_ptr, uint64_t *n_bytes) {
     return KD_OK;
 }
 
+int kd_finish(kd_ctx *ctx, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint64_t *contig_off) {
+    return ctx ? ctx->e.finish(min_depth, seq_out, cap, len_out, contig_off) : KD_E_ARG;
+}
+int kd_set_step_graph(kd_ctx *ctx, int on) {
+    if (!ctx) return KD_E_ARG;
+    ctx->e.step_graph = on != 0;
+    if (!on) { ctx->e.step_have = false; ctx->e.rt.graph_drop(); }
+    return KD_OK;
+}
 int kd_step(kd_ctx *ctx, const kd_batch *dev_batch, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out,
             uint64_t *contig_off, int *replayed) {
     if (!ctx || !dev_batch) return KD_E_ARG;

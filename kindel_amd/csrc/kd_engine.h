@@ -101,6 +101,7 @@ struct KdEngine {
     uint64_t step_fasta_len = 0;   // consensus bytes of the recorded step
     uint64_t step_last_sig[12] = {0};
     bool step_record_bad = false;
+    bool step_graph = true;        // kd_set_step_graph: capture a repeated step as a hipGraph
     bool step_have = false;
 
     int fail(int code, const std::string &m) { err = m; return code; }
@@ -1084,6 +1085,55 @@ struct KdEngine {
         return KD_OK;
     }
 
+    // kd_finish: everything behind the pushes -- insertion reduction, consensus, read-out -- queued back to back and collected in
+    // ONE host round trip: the status words (deferred reference exceptions, hash verification), the run's metadata and the
+    // consensus bytes -- as many as a consensus without net insertions has; the rare rest in a second copy.  (kd_finalize +
+    // kd_consensus_run + kd_consensus_fetch_all are three blocking read-backs and two more for the bytes.)
+    int finish(uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint64_t *contig_off) {
+        int rc;
+        if ((rc = finalize_launch()) || (rc = consensus_launch(min_depth, 0, nullptr, nullptr))) return rc;
+        const size_t mb = meta_bytes();
+        const uint64_t shard_sites = std::min<uint64_t>(S, g_hi) - std::min<uint64_t>(S, g_lo);
+        uint64_t guess = seq_out ? std::min<uint64_t>(std::min<uint64_t>(cap, cns_cap), shard_sites + 4096) : 0;
+        const void *meta = nullptr;
+        if (step_mode == STEP_REPLAY) {
+            // captured: the copies land when the graph runs (verified then); the host continues with the record
+            if ((rc = fetch_status())) return rc;
+            step_meta_seen.assign(mb / 8, 0);
+            if (step_meta.size() != mb / 8) return fail(KD_E_INTERNAL, "kd_step: recorded consensus metadata has another shape");
+            if (rt.d2h_async(step_meta_seen.data(), b_coff.p, mb)) return hipfail("consensus: d2h");
+            meta = step_meta.data();
+            guess = seq_out ? step_fasta_len : 0;     // (the recorded length: one exact copy)
+            if (guess && rt.d2h_async(seq_out, b_cns.p, guess)) return hipfail("consensus fetch: d2h");
+        } else {
+            uint8_t *st = (uint8_t *)rt.stage(KDS_COUNT * 8 + mb);
+            if (!st) return hipfail("kd_finish: pinned staging");
+            if (rt.d2h_async(st, d_status, KDS_COUNT * 8) || rt.d2h_async(st + KDS_COUNT * 8, b_coff.p, mb) ||
+                (guess && rt.d2h_async(seq_out, b_cns.p, guess)) || rt.sync())
+                return hipfail("kd_finish: d2h");
+            memcpy(h_status.data(), st, KDS_COUNT * 8);
+            if (step_mode == STEP_RECORD) { step_status.push_back(h_status); step_meta.assign((const uint64_t *)(st + KDS_COUNT * 8), (const uint64_t *)(st + KDS_COUNT * 8) + mb / 8); }
+            meta = st + KDS_COUNT * 8;
+        }
+        bool redone = false;
+        if ((rc = finalize_check(nullptr, &redone))) return rc;
+        if (redone) {     // a hash collision was repaired (never seen outside the tests): the consensus once more, read back on its own
+            if (step_mode == STEP_REPLAY) return fail(KD_E_INTERNAL, "kd_step: hash collision under capture");
+            step_record_bad = true;     // (no graph of this step)
+            if ((rc = consensus_run(min_depth, 0, nullptr, nullptr))) return rc;
+            guess = 0;
+        } else if ((rc = consensus_collect(meta))) return rc;
+        const uint64_t o0 = h_coff[0], o1 = h_coff[n_contigs];
+        if (len_out) *len_out = o1 - o0;
+        if (contig_off) for (uint32_t c = 0; c <= n_contigs; c++) contig_off[c] = h_coff[c] - o0;
+        if (seq_out) {
+            if (o1 - o0 > cap) return fail(KD_E_ARG, "kd_finish: buffer too small");
+            if (step_mode == STEP_RECORD) step_fasta_len = o1;
+            if (o1 > guess && rt.d2h((uint8_t *)seq_out + guess, (uint8_t *)b_cns.p + guess, o1 - guess)) return hipfail("consensus fetch: d2h");
+        }
+        return KD_OK;
+    }
+
     // One step over a device-resident batch (kd_step): see step_mode above.  *replayed = 1 when the graph did it.
     int step(const kd_batch &B, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint64_t *contig_off, int *replayed) {
         if (replayed) *replayed = 0;
@@ -1092,53 +1142,12 @@ struct KdEngine {
                                   (uint64_t)B.seq4_bytes ^ ((uint64_t)B.cigar_words << 32), (uint64_t)(uintptr_t)seq_out, cap,
                                   g_lo ^ (g_hi << 1) ^ ((uint64_t)min_depth << 56), (uint64_t)mode ^ ((uint64_t)W << 8) ^ ((uint64_t)slice_cfg << 32)};
         // The step, eager: reset, record loop, insertion reduction and consensus are queued back to back; the host waits ONCE
-        // behind k_prep (the counts that size buffers and choose kernels) and ONCE at the end, for a single round trip that
-        // brings the status words (deferred reference exceptions, hash verification), the run's metadata and the consensus
-        // bytes -- as many as a consensus without net insertions has; the rare rest in a second copy.  (Round 3: five blocking
-        // read-backs per step -- after k_prep, after the reduction, after the consensus, the FASTA, the change codes' owner.)
+        // behind k_prep (the counts that size buffers and choose kernels) and ONCE at the end (finish()).  (Round 3: five
+        // blocking read-backs per step -- after k_prep, after the reduction, after the consensus, the FASTA, the metadata.)
         auto sequence = [&]() -> int {
             int rc;
-            if ((rc = reset()) || (rc = push_device(B)) || (rc = finalize_launch()) || (rc = consensus_launch(min_depth, 0, nullptr, nullptr))) return rc;
-            const size_t mb = meta_bytes();
-            const uint64_t shard_sites = std::min<uint64_t>(S, g_hi) - std::min<uint64_t>(S, g_lo);
-            uint64_t guess = seq_out ? std::min<uint64_t>(std::min<uint64_t>(cap, cns_cap), shard_sites + 4096) : 0;
-            const void *meta = nullptr;
-            if (step_mode == STEP_REPLAY) {
-                // captured: the copies land when the graph runs (verified then); the host continues with the record
-                if ((rc = fetch_status())) return rc;
-                step_meta_seen.assign(mb / 8, 0);
-                if (step_meta.size() != mb / 8) return fail(KD_E_INTERNAL, "kd_step: recorded consensus metadata has another shape");
-                if (rt.d2h_async(step_meta_seen.data(), b_coff.p, mb)) return hipfail("consensus: d2h");
-                meta = step_meta.data();
-                guess = seq_out ? step_fasta_len : 0;     // (the recorded length: one exact copy)
-                if (guess && rt.d2h_async(seq_out, b_cns.p, guess)) return hipfail("consensus fetch: d2h");
-            } else {
-                uint8_t *st = (uint8_t *)rt.stage(KDS_COUNT * 8 + mb);
-                if (!st) return hipfail("kd_step: pinned staging");
-                if (rt.d2h_async(st, d_status, KDS_COUNT * 8) || rt.d2h_async(st + KDS_COUNT * 8, b_coff.p, mb) ||
-                    (guess && rt.d2h_async(seq_out, b_cns.p, guess)) || rt.sync())
-                    return hipfail("kd_step: d2h");
-                memcpy(h_status.data(), st, KDS_COUNT * 8);
-                if (step_mode == STEP_RECORD) { step_status.push_back(h_status); step_meta.assign((const uint64_t *)(st + KDS_COUNT * 8), (const uint64_t *)(st + KDS_COUNT * 8) + mb / 8); }
-                meta = st + KDS_COUNT * 8;
-            }
-            bool redone = false;
-            if ((rc = finalize_check(nullptr, &redone))) return rc;
-            if (redone) {     // a hash collision was repaired (never seen outside the tests): the consensus once more, read back on its own
-                if (step_mode == STEP_REPLAY) return fail(KD_E_INTERNAL, "kd_step: hash collision under capture");
-                step_record_bad = true;     // (no graph of this step)
-                if ((rc = consensus_run(min_depth, 0, nullptr, nullptr))) return rc;
-                guess = 0;
-            } else if ((rc = consensus_collect(meta))) return rc;
-            const uint64_t o0 = h_coff[0], o1 = h_coff[n_contigs];
-            if (len_out) *len_out = o1 - o0;
-            if (contig_off) for (uint32_t c = 0; c <= n_contigs; c++) contig_off[c] = h_coff[c] - o0;
-            if (seq_out) {
-                if (o1 - o0 > cap) return fail(KD_E_ARG, "kd_step: buffer too small");
-                if (step_mode == STEP_RECORD) step_fasta_len = o1;
-                if (o1 > guess && rt.d2h((uint8_t *)seq_out + guess, (uint8_t *)b_cns.p + guess, o1 - guess)) return hipfail("consensus fetch: d2h");
-            }
-            return KD_OK;
+            if ((rc = reset()) || (rc = push_device(B))) return rc;
+            return finish(min_depth, seq_out, cap, len_out, contig_off);
         };
         // the words every host decision of the sequence is made from
         static const int kDecisive[] = {KDS_ERR_READ, KDS_N_EV, KDS_POOL, KDS_B_INS_OPS, KDS_B_INS_BASES, KDS_B_MAXSPAN, KDS_B_MAXLEAD, KDS_B_MAXSEGSPAN, KDS_B_ROW_DWORDS,
@@ -1169,7 +1178,7 @@ struct KdEngine {
         // input is a new batch every time and takes the eager sequence above): capture on the first repeat
         const bool repeat = !memcmp(sig, step_last_sig, sizeof sig);
         memcpy(step_last_sig, sig, sizeof sig);
-        if (rc || !rt.graph_supported() || step_record_bad || !repeat || getenv("KD_STEP_NO_GRAPH")) return rc;
+        if (rc || !rt.graph_supported() || step_record_bad || !repeat || !step_graph) return rc;
         // the same sequence once more, captured: every host read answered from the record, nothing executes
         step_mode = STEP_REPLAY; step_pos = 0;
         int rc2 = rt.capture_begin() ? 1 : 0;

@@ -1,20 +1,50 @@
 #!/bin/bash
-# Round summary on one MI355X: parity suite, smoke, bench C3 (JSON line incl. cpu_baseline), rocprofv3 stats + PMC.
-cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; rm -rf $O/prof_c3 $O/pmc_*; mkdir -p $O
-echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-echo "== pytest gpu"; timeout 1200 python -m pytest tests -m gpu -q --maxfail=8 -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log
-echo "== bench C3"; timeout 900 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err; echo "bench rc=$?"
-echo "== rocprof stats"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python $R/bench.py --no-cpu-baseline > $O/prof_c3_bench.json 2> $O/prof_c3.err); echo "rc=$?"
-bash scripts/gpu_pmc.sh > $O/pmc_summary.txt 2>&1; grep -E "^[1-4] k_(window|prep|cold)" $O/pmc_summary.txt
-echo "== strip mode / shuffled"; bash scripts/gpu_r2.sh lib:none > /dev/null 2>&1; for m in strip; do timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --mode $m > $O/exp_$m.json 2> $O/exp_$m.err; done; timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --shuffle > $O/exp_shuf.json 2> $O/exp_shuf.err
-echo "== e2e full C3"; timeout 900 python scripts/e2e_bench.py --scale 1.0 --repeat 3 --out $O/e2e_c3_full.json > /dev/null 2> $O/e2e.err; tail -c 600 $O/e2e_c3_full.json
-echo "== multirank (gloo, one GPU)"; bash scripts/gpu_multirank.sh 2>&1 | tail -12
-echo "== FETCH_SIZE calibration"; bash scripts/gpu_calib.sh 2>&1 | tail -6
-for c in ${CONFIGS:-C2 C4 C5}; do timeout 600 python bench.py --config $c --steps 3 --warmup 1 > $O/bench_$c.json 2> $O/bench_$c.err; done
+# Round driver on one MI355X (through gpurun): `bash scripts/gpu_round.sh STAGE...`, results under gpurun_out/ (scratch; the
+# judged summaries are copied into profiles/ by scripts/harvest_profiles.py).  Stages:
+#   smoke  tests  bench  cfg  shuf  prof  pmc:<CONFIG>[:shuffle]  proj  sweep  timeline  e2e  multirank
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; mkdir -p $O
+for st in "$@"; do
+  echo "== $st"
+  case $st in
+    smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ;;
+    tests) timeout 1500 python -m pytest tests -m gpu -q --maxfail=8 -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log ;;
+    bench) timeout 900 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err; echo "bench rc=$?"; tail -2 $O/bench_c3.err ;;
+    cfg) for c in ${CONFIGS:-C2 C4 C5}; do timeout 600 python bench.py --config $c --steps 10 --warmup 3 --e2e-scale 0 > $O/bench_$c.json 2> $O/bench_$c.err; echo "$c rc=$?"; done ;;
+    shuf) timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --shuffle > $O/exp_shuf.json 2> $O/exp_shuf.err; echo "rc=$?"
+          KD_SORT_GLOBAL=1 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --shuffle > $O/exp_shuf_global.json 2> $O/exp_shuf_global.err ;;
+    prof) rm -rf $O/prof_c3; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python $R/bench.py --no-cpu-baseline > $O/prof_c3_bench.json 2> $O/prof_c3.err); echo "rc=$?" ;;
+    pmc:*) spec=${st#pmc:}; cfg=${spec%%:*}; extra=""; tag=$cfg; case $spec in *:shuffle) extra="--shuffle"; tag=${cfg}_shuffle;; esac
+           BENCH_ARGS="--config $cfg $extra" PMC_TAG=$tag bash scripts/gpu_pmc.sh 2>&1 | tail -8 ;;
+    proj) for c in ${PROJ_CONFIGS:-C3 C4}; do timeout 900 python scripts/strong_projection.py --config $c --tunings "${PROJ_TUNINGS:-0:0}" --out $O/strong_projection_$c.json > /dev/null 2> $O/proj_$c.err; echo "$c rc=$?"; done ;;
+    sweep) T="0:0,448:256,448:512,448:1024,448:2048,256:256,256:512,256:1024,192:256,192:512,192:1024,128:256,128:512,64:256,64:512"
+           timeout 600 python scripts/strong_projection.py --config C3 --ranks 8 --only-rank 3 --tunings "$T" --out $O/sweep_C3_rank3of8.json > /dev/null 2> $O/sweep_c3.err; echo "c3/8 rc=$?"
+           timeout 600 python scripts/strong_projection.py --config C4 --ranks 8 --only-rank 3 --tunings "$T" --out $O/sweep_C4_rank3of8.json > /dev/null 2> $O/sweep_c4.err; echo "c4/8 rc=$?"
+           timeout 600 python scripts/strong_projection.py --config C2 --ranks 1 --tunings "$T" --out $O/sweep_C2.json > /dev/null 2> $O/sweep_c2.err; echo "c2 rc=$?"
+           for pp in 4 8 16 32 64; do KD_PREP_PER=$pp timeout 600 python scripts/strong_projection.py --config C3 --ranks 8 --only-rank 3 --out $O/sweep_C3_rank3of8_prep$pp.json > /dev/null 2>> $O/sweep_c3.err; done ;;
+    timeline) bash scripts/gpu_timeline.sh 2>&1 | tail -3 ;;
+    e2e) timeout 900 python scripts/e2e_bench.py --scale 1.0 --repeat 3 --out $O/e2e_c3_full_phred.json > /dev/null 2> $O/e2e.err; tail -c 400 $O/e2e_c3_full_phred.json ;;
+    multirank) bash scripts/gpu_multirank.sh 2>&1 | tail -12 ;;
+    *) echo "unknown stage $st" ;;
+  esac
+done
 python - <<PY
-import json
+import json, glob, os
+O="$O"
+def line(p):
+    for l in open(p):
+        if l.startswith('{"metric'): return json.loads(l)
 for c in ["c3","C2","C4","C5"]:
+    p=os.path.join(O,"bench_%s.json"%c)
+    if not os.path.exists(p): continue
     try:
-        d=json.load(open("$O/bench_%s.json"%c)); print(c, "%.3e ev/s"%d["value"], "%.2f ms"%d["ms_per_step"], "kern %.2f"%d["kernel_ms_per_step"], {k:v["avg_ms"] for k,v in d["kernels"].items() if v["avg_ms"]>0.2}, d.get("cpu_baseline",{}).get("bit_exact_vs_gpu"))
+        d=line(p); print(c, "%.3e ev/s"%d["value"], "%.4f ms"%d["ms_per_step"], "replay", d.get("replay_ms_per_step"), "kern %.3f"%d["kernel_ms_per_step"], "frac", d["roofline"]["frac"], d["roofline"]["step_frac"],
+                         {k:v["avg_ms"] for k,v in d["kernels"].items()}, (d.get("cpu_baseline") or {}).get("bit_exact_vs_gpu"))
     except Exception as e: print(c, "failed", e)
+for p in sorted(glob.glob(os.path.join(O,"strong_projection_*.json"))+glob.glob(os.path.join(O,"sweep_*.json"))):
+    try:
+        d=json.load(open(p))
+        for r in d["rows"]:
+            print(os.path.basename(p), r["n_ranks"], r["projected_step_ms"], r.get("projected_speedup"), [(q["rank"], q["step_ms"], q["kernel_ms"], q["k_window_ms"], q["k_prep_ms"], q.get("tuning")) for q in r["per_rank"]][:8])
+            if "sweep" in p: print("   tried", r["per_rank"][0].get("tried"), r["per_rank"][0].get("kernels"))
+    except Exception as e: print(p, "failed", e)
 PY

@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ranks", default="1,2,4,8")
     ap.add_argument("--out", default="")
+    ap.add_argument("--only-rank", type=int, default=-1, help="time only this rank of every decomposition (sweeps)")
+    ap.add_argument("--tunings", default="0:0", help="window:slice[,window:slice...] -- every rank's shard is timed under each, the best stands "
+                    "(0:0 = the engine's own choice)")
     args = ap.parse_args()
     import torch
     from kindel_amd import _native as N
@@ -43,6 +46,8 @@ def main():
         ivs = shard.partition_weighted(lens, tb["contig"], tb["pos0"], tb["seq_len"], world)
         per_rank = []
         for r in range(world):
+            if args.only_rank >= 0 and r != min(args.only_rank, world - 1):
+                continue
             keep = shard.reads_of_rank(lens, g_lo, g_hi, r, world, intervals=ivs)
             sub = dict(tb)
             for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
@@ -53,31 +58,37 @@ def main():
                 eng.set_shard(*ivs[r])
             ptrs = synth.device_ptrs(sub)
 
-            def step():
-                eng.reset()
-                eng.push_device(ptrs, n, tb["seq4_bytes"], tb["cigar_words"])
-                eng.finalize()
-                eng.consensus_run(1)
-                eng.consensus_fetch_all_into(pinned)
+            eng.set_step_graph(False)      # the eager sequence: what a new batch takes (bench.py's `value`)
 
-            for _ in range(args.warmup):
-                step()
-            ms = None
-            for _ in range(3):      # best of three timed blocks: one host hiccup must not pass for a rank's step time
-                eng.sync(); torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
+            def step():
+                eng.step_device(ptrs, n, tb["seq4_bytes"], tb["cigar_words"], pinned)
+
+            ms, tuned, tried = None, None, {}
+            for spec in args.tunings.split(","):
+                w_, s_ = (int(x) for x in spec.split(":"))
+                eng.set_tuning(w_, s_)
+                for _ in range(args.warmup):
                     step()
-                eng.sync(); torch.cuda.synchronize()
-                m = (time.perf_counter() - t0) / args.steps * 1e3
-                ms = m if ms is None else min(ms, m)
+                for _ in range(3):      # best of three timed blocks: one host hiccup must not pass for a rank's step time
+                    eng.sync(); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        step()
+                    eng.sync(); torch.cuda.synchronize()
+                    m = (time.perf_counter() - t0) / args.steps * 1e3
+                    tried[spec] = round(min(tried.get(spec, 1e9), m), 4)
+                    if ms is None or m < ms:
+                        ms, tuned = m, spec
+            w_, s_ = (int(x) for x in tuned.split(":"))
+            eng.set_tuning(w_, s_)
             eng.profile_enable(1); eng.profile_reset()
             for _ in range(args.steps):
                 step()
             prof = eng.profile()
             eng.profile_enable(0)
             kern = sum(v[1] for v in prof.values()) / args.steps
-            per_rank.append(dict(rank=r, interval=[int(ivs[r][0]), int(ivs[r][1])], reads=n, step_ms=round(ms, 4), kernel_ms=round(kern, 4),
+            per_rank.append(dict(rank=r, interval=[int(ivs[r][0]), int(ivs[r][1])], reads=n, step_ms=round(ms, 4), kernel_ms=round(kern, 4), tuning=tuned, tried=tried,
+                                 kernels={k: round(v[1] / max(v[0], 1), 4) for k, v in sorted(prof.items())},
                                  k_window_ms=round(prof.get("k_window", (0, 0.0))[1] / args.steps, 4), k_prep_ms=round(prof.get("k_prep", (0, 0.0))[1] / args.steps, 4)))
             eng.close()
             del sub, keep

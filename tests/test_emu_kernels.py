@@ -365,6 +365,84 @@ def test_step_equals_the_classic_sequence(emu_lib):
         eng.close()
 
 
+def _finish_vs_classic(lib, batch, window=0, slice_reads=0, out_cap=None, n_pushes=1):
+    """kd_finish (one round trip) against kd_finalize + kd_consensus_run + kd_consensus_fetch per contig, on the same pushes."""
+    run = P.Run(lib, batch, window=window, slice_reads=slice_reads, n_pushes=n_pushes)
+    eng = N.Engine(batch["contig_lens"], lib=lib)
+    try:
+        if window or slice_reads:
+            eng.set_tuning(window, slice_reads)
+        n = len(batch["contig"])
+        cuts = np.linspace(0, n, n_pushes + 1).astype(int)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            eng.push(P.subset(batch, a, b))
+        out = np.zeros(out_cap or (int(sum(batch["contig_lens"])) * 2 + 4096), np.uint8)
+        off = eng.finish(out)
+        for cid in run.order:
+            assert out[int(off[cid]): int(off[cid + 1])].tobytes() == run.cns[cid][0]
+            assert np.array_equal(eng.tables(cid), run.tables[cid])
+            got = eng.consensus_fetch(cid)       # the context is finalized and has a run: the per-contig read-outs work
+            assert got[0] == run.cns[cid][0] and np.array_equal(got[1], run.cns[cid][1]) and tuple(got[2]) == tuple(run.cns[cid][2])
+            site, count, strings = eng.insertions(cid)
+            assert sorted((int(p_), s_, int(c_)) for p_, c_, s_ in zip(site, count, strings)) == sorted(run.ins[cid])
+    finally:
+        eng.close()
+    return run
+
+
+def test_finish_equals_finalize_consensus_fetch(emu_lib):
+    _finish_vs_classic(emu_lib, P.load_fixture("bwa_mem__1.1.sub_test"), window=256)
+    _finish_vs_classic(emu_lib, P.load_fixture("minimap2__1.1.multi"), window=128, slice_reads=64, n_pushes=3)
+    # no insertion events at all (the reduction is skipped, the run's per-contig words are still initialised on the device)
+    _finish_vs_classic(emu_lib, synth.to_numpy(synth.short_reads([3000, 900], 15, seed=5, indel_p=0.0, planted=0)))
+
+
+def test_finish_with_more_consensus_bytes_than_sites(emu_lib):
+    """The closing round trip copies as many bytes as a consensus without net insertions has; a consensus that is longer (majority
+    insertions, no deletions) gets the rest in a second copy."""
+    import random
+    rng = random.Random(11)
+    L = 300
+    ref = "".join(rng.choice("ACGT") for _ in range(L))
+    ins = "".join(rng.choice("ACGT") for _ in range(5000))     # one huge majority insertion: > 4096 bytes more than sites
+    sam = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c\tLN:%d\n" % L
+    for k in range(5):
+        sam += "r%d\t0\tc\t1\t60\t150M%dI150M\t*\t0\t0\t%s\t*\n" % (k, len(ins), ref[:150] + ins + ref[150:])
+    batch = P.sam_to_batch(sam)
+    run = _finish_vs_classic(emu_lib, batch, out_cap=16384)
+    assert len(run.cns[0][0]) == L + len(ins)
+    P.assert_matches_oracle(run)
+
+
+def test_finish_raises_the_reference_exception(emu_lib):
+    # a base outside A,C,G,T,N in an aligned segment: KeyError through the one-round-trip path too
+    sam = "@HD\tVN:1.6\n@SQ\tSN:c\tLN:50\nr1\t0\tc\t1\t60\t10M\t*\t0\t0\tACGTRACGTA\t*\nr2\t0\tc\t3\t60\t10M\t*\t0\t0\tACGTAACGTA\t*\n"
+    batch = P.sam_to_batch(sam)
+    eng = N.Engine(batch["contig_lens"], lib=emu_lib)
+    try:
+        eng.push(batch)
+        with pytest.raises(KeyError):
+            eng.finish(np.zeros(4096, np.uint8))
+    finally:
+        eng.close()
+
+
+def test_finish_through_a_forced_hash_collision(emu_lib, monkeypatch):
+    batch = synth.to_numpy(synth.short_reads([6000], 40, seed=21, indel_p=0.5))
+    monkeypatch.setenv("KD_TEST_INS_COLLIDE", "1")
+    P.assert_matches_oracle(_finish_vs_classic(emu_lib, batch, window=512))
+
+
+def test_deep_windows_are_shared_through_the_hot_list(emu_lib):
+    """A deep small genome: every window holds many slices, so every workgroup but the ticket holders works as a helper off the
+    hot list (kd_window.h: KdWq); slices of 64 reads, windows of 64 - 448 sites."""
+    tb = synth.to_numpy(synth.short_reads([700], 900, seed=31))
+    for window, sl in ((64, 64), (448, 64), (128, 300)):
+        run = P.Run(emu_lib, tb, window=window, slice_reads=sl)
+        assert run.info["work_items"] > 3 * ((700 + window) // window + 1)
+        P.assert_matches_oracle(run)
+
+
 def test_scan_cigar_matches_its_reference_statement(emu_lib):
     """k_prep's kd_scan_cigar (32-bit, branch-free per op) against the 64-bit branch-per-kind statement of the same rules
     (tests/emu/scan_ref.h) on random CIGARs: op lengths up to 2^28, reads at / across / behind the contig's end, negative

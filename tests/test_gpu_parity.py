@@ -422,7 +422,8 @@ def test_streamed_ingest_many_small_batches(hip_lib, tmp_path, key, chunk):
 
 
 def test_step_graph_replay_is_verified(hip_lib):
-    """kd_step: the first call runs the eager sequence and captures it, repeats replay the hipGraph.  Same batch -> same bytes;
+    """kd_step: the first call runs the eager sequence, the first REPEAT on the same resident batch runs it again and captures it,
+    later repeats replay the hipGraph.  Same batch -> same bytes;
     bases changed in place (no host decision depends on them) -> the replay is still exact for the NEW data; a CIGAR changed in
     place so that the event counts move -> the verification notices and the eager sequence runs.  Each time vs the oracle."""
     import torch
@@ -443,7 +444,13 @@ def test_step_graph_replay_is_verified(hip_lib):
 
     try:
         check(False)
+        check(False)
         check(True)
+        check(True)
+        eng.set_step_graph(False)       # the eager sequence only (what bench.py times as `value`)
+        check(False)
+        eng.set_step_graph(True)
+        check(False)
         check(True)
         # new bases under the same pointers: the replay runs the right kernels on the new data, but what it hands back from its
         # record (offsets, depth ranges) may no longer be true -- the verification compares them with the device's and decides;
