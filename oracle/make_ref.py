@@ -10,7 +10,12 @@ sourceless bytecode oracle/_ref/kindel/*.pyc.  oracle/_ref/ is git-ignored (no r
 history) and is NOT in .gpurunignore, so the bytecode travels to the GPU box like the built .so files do.  Both boxes run
 the same image (CPython 3.10): the bytecode's magic number is checked at import.
 
-Only oracle/refrun.py imports the result, and only tests/, smoke() and bench.py's cpu_baseline leg use refrun.
+The same recipe stages the reference's own INPUT files -- the 15 htslib-written BAMs and 3 SAMs of /root/reference/tests/data_* --
+into oracle/_ref/fixtures/ (git-ignored, travels): the `-m gpu` suite then runs the device-side ingest (k_gpu_inflate, k_bam_*) on
+third-party files ON the MI355X, not only on BAMs this repo's own writer produced.  Inputs only; what the reference's tests
+compare the outputs with is committed as tests/golden/reference_fasta.json.
+
+Only oracle/refrun.py imports the bytecode, and only tests/, smoke() and bench.py's cpu_baseline leg use refrun.
 """
 import os
 import py_compile
@@ -20,6 +25,8 @@ REF_PKG = "/root/reference/kindel"
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_ref", "kindel")
 FILES = ("__init__.py", "kindel.py", "cli.py")
+REF_TESTS = "/root/reference/tests"
+FIXTURES = os.path.join(HERE, "_ref", "fixtures")
 
 
 def available():
@@ -40,10 +47,44 @@ def build(force=False):
         if force or not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src):
             # dfile: the path tracebacks show -- the reference's own, so that file:line citations stay meaningful
             py_compile.compile(src, cfile=dst, dfile=src, doraise=True)
+    stage_fixtures()
     with open(os.path.join(os.path.dirname(OUT), "README"), "w") as fh:
         fh.write("Build product of oracle/make_ref.py: sourceless bytecode of the unmodified reference (%s), CPython %s.\n"
                  "Git-ignored; test / measurement infrastructure only.\n" % (REF_PKG, sys.version.split()[0]))
     return os.path.dirname(OUT)
+
+
+def stage_fixtures():
+    """The reference's test INPUTS (*.bam, *.sam) -> oracle/_ref/fixtures/<data_dir>/ (byte-identical copies, git-ignored)."""
+    import glob
+    import shutil
+    n = 0
+    for src in sorted(glob.glob(os.path.join(REF_TESTS, "data_*", "*.bam")) + glob.glob(os.path.join(REF_TESTS, "data_*", "*.sam"))):
+        dst = os.path.join(FIXTURES, os.path.basename(os.path.dirname(src)), os.path.basename(src))
+        if not os.path.exists(dst) or os.path.getsize(dst) != os.path.getsize(src) or os.path.getmtime(dst) < os.path.getmtime(src):
+            os.makedirs(os.path.dirname(dst), exist_ok=True)
+            shutil.copyfile(src, dst)
+        n += 1
+    return n
+
+
+def fixture(rel):
+    """Path of a staged reference input, e.g. fixture("data_bwa_mem/1.1.sub_test.bam"): the reference tree's own file where that
+    exists, the staged copy elsewhere (the GPU box), None if neither."""
+    for root in (REF_TESTS, FIXTURES):
+        p = os.path.join(root, rel)
+        if os.path.isfile(p):
+            return p
+    return None
+
+
+def fixtures(pattern="*.bam"):
+    import glob
+    for root in (REF_TESTS, FIXTURES):
+        got = sorted(glob.glob(os.path.join(root, "data_*", pattern)))
+        if got:
+            return got
+    return []
 
 
 if __name__ == "__main__":

@@ -18,6 +18,14 @@ FASTA_CASES = [(k, tag) for k in sorted(REF_FASTA) for tag in sorted(REF_FASTA[k
 FEATURE_KEYS = ["bwa_mem__1.1.sub_test", "ext__3.issue23.bc75", "ext__1.issue23.debug"]
 
 
+def reference_input(key):
+    """The reference's own file behind fixture key "<dir>__<stem>" (data_<dir>/<stem>.bam or .sam), from /root/reference or its
+    staged copy (oracle/make_ref.py); None when neither is on this box."""
+    from oracle import make_ref
+    d, stem = key.split("__", 1)
+    return make_ref.fixture("data_%s/%s.bam" % (d, stem)) or make_ref.fixture("data_%s/%s.sam" % (d, stem))
+
+
 def bam_of(tmp_path, key):
     p = str(tmp_path / (key + ".bam"))
     if not os.path.exists(p):
@@ -25,10 +33,10 @@ def bam_of(tmp_path, key):
     return p
 
 
-def check_reference_fasta(K, tmp_path, key, tag):
+def check_reference_fasta(K, tmp_path, key, tag, path=None):
     """What the reference's CLI tests assert: same record names, sequences equal ignoring case (cli.py defaults:
     min_overlap 7)."""
-    res = K.bam_to_consensus(bam_of(tmp_path, key), realign=(tag == "realign"), min_overlap=7)
+    res = K.bam_to_consensus(path or bam_of(tmp_path, key), realign=(tag == "realign"), min_overlap=7)
     got = {c.name: c.sequence for c in res.consensuses}
     want = REF_FASTA[key][tag]
     assert set(want) <= set(got), (key, tag, sorted(want), sorted(got))

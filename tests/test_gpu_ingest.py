@@ -228,6 +228,62 @@ def test_gpu_ingest_api_consensus_on_the_gpu(hip_lib, tmp_path, monkeypatch):
     assert gpu.refs_reports == host.refs_reports and gpu.refs_changes == host.refs_changes
 
 
+@pytest.mark.gpu
+def test_reference_bams_on_the_gpu(hip_lib):
+    """The reference's own htslib-written BAM files (aux tags, real read names, bwa / minimap2 / segemehl record layouts, the 6.1 Mbp
+    bact.tiny) through k_gpu_inflate + k_bgzf_crc + k_bam_* ON the MI355X vs the host decoder feeding the same engine: every
+    table of every contig, insertion dicts, first-appearance order, record counts.  (Staged by oracle/make_ref.py.)"""
+    from oracle import make_ref
+    paths = make_ref.fixtures("*.bam")
+    assert len(paths) >= 15, "oracle/_ref/fixtures is missing: run __graft_entry__.build() where /root/reference exists"
+    for p in paths:
+        info = both_ways(hip_lib, p)
+        assert info["records"] > 0, p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key,tag", __import__("tests.refcheck", fromlist=["x"]).FASTA_CASES)
+def test_reference_fasta_through_the_device_side_ingest_on_the_gpu(hip_lib, tmp_path, monkeypatch, key, tag):
+    """The reference's 21 golden FASTA files (default and -r) from the reference's OWN input files with KINDEL_INGEST=gpu on the
+    MI355X (/root/reference/tests/test_kindel.py:114-278).  BAM inputs must really take the device-side path; the three SAM
+    inputs are text and go to the host decoder."""
+    from kindel_amd import kindel as K
+    from tests import refcheck as RC
+    path = RC.reference_input(key)
+    assert path, "oracle/_ref/fixtures is missing: run __graft_entry__.build() where /root/reference exists"
+    monkeypatch.setenv("KINDEL_INGEST", "gpu")
+    took = K.pileup_file(path).ingest.get("path")
+    assert took == ("gpu" if path.endswith(".bam") else took) and (path.endswith(".bam") or took != "gpu")
+    RC.check_reference_fasta(K, tmp_path, key, tag, path=path)
+
+
+@pytest.mark.gpu
+def test_full_size_c3_through_the_device_side_ingest(hip_lib, tmp_path):
+    """BASELINE.json's headline config as a FILE: 16.7 M reads, 2 GB of BGZF with Phred-like qualities -> device-side ingest -> pileup
+    -> consensus, against the oracle's consensus of the same reads and the host decoder's record count."""
+    import torch
+    from kindel_amd import kindel as K
+    from oracle import oracle as ko
+    tb = synth.make("C3", device="cuda:0")
+    batch = synth.to_numpy(tb)
+    del tb
+    torch.cuda.empty_cache()
+    p = str(tmp_path / "c3_full.bam")
+    os.environ["KD_WRITE_BAM_QUAL"] = "phred"
+    try:
+        N.write_bam(p, batch, lib=hip_lib)
+    finally:
+        os.environ.pop("KD_WRITE_BAM_QUAL", None)
+    pl = K.pileup_file(p, ingest="gpu")
+    assert pl.ingest["path"] == "gpu" and pl.ingest["kept"] == len(batch["contig"])
+    done = K._device_consensus_all(pl, {c: None for c in pl.order}, False, 1, False)
+    oa = ko.parse_records(batch, 0)
+    assert done[pl.order[0]][0] == oa.consensus_sequence()[0]
+    t = np.asarray(pl.tables(pl.order[0]))
+    assert np.array_equal(t[0:5, :oa.L].T, oa.weights) and np.array_equal(t[5], oa.deletions) and np.array_equal(t[18], oa.ins_totals)
+    pl.engine.close()
+
+
 def test_a_file_too_big_for_the_device_goes_to_the_host_decoder(emu_lib, api_on_emu, tmp_path, monkeypatch):
     # file + inflated stream + batch are resident at once on the device-side path: what does not fit takes the streamed host decoder
     from kindel_amd import kindel

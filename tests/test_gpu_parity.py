@@ -127,6 +127,30 @@ def test_full_size_config_device_resident(hip_lib, cfg, mode):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("cfg,layout,sort", [("C3-mid", "records", "lds"), ("C3-mid", "index", "lds"), ("C3-mid", "records", "global"),
+                                             ("C3-mid", "index", "global"), ("C3", "records", "lds"), ("C3", "index", "global")])
+def test_unsorted_input_at_scale(hip_lib, monkeypatch, cfg, layout, sort):
+    """Unsorted input on the hardware, at sizes where every stage of the bucket sort has more than one unit of work: the
+    LDS-bin counting sort with 512 sort workgroups (16 scan segments of the column scan) and the global-counter fall-back
+    (the path of a genome whose bin table exceeds the LDS), both batch layouts (payload in record order = what a decoder hands
+    over for an unsorted file; payload left in place), C3-mid and FULL C3: every table of every contig, the insertion dicts, the
+    consensus and change codes vs the oracle (sums are order independent: the oracle walks the same shuffled batch)."""
+    import torch
+    if sort == "global":
+        monkeypatch.setenv("KD_SORT_GLOBAL", "1")
+    tb = synth.make("C3", device="cuda:0") if cfg == "C3" else SYN[cfg]("cuda:0")
+    sh = synth.shuffled(tb, mode=layout, seed=7)
+    del tb
+    eng = N.Engine(sh["contig_lens"], lib=hip_lib)
+    eng.push_device(synth.device_ptrs(sh), sh["contig"].numel(), sh["seq4_bytes"], sh["cigar_words"])
+    info = eng.batch_info()
+    eng.close()
+    assert info["windowed"] == 1 and info["unsorted"] > 0
+    _check_device_resident(hip_lib, sh, N.KD_MODE_AUTO, "%s shuffled (%s, %s sort)" % (cfg, layout, sort))
+    del sh
+    torch.cuda.empty_cache()
+
+
 def test_host_push_equals_device_push(hip_lib):
     tb = synth.short_reads([200_000], 40, seed=12, device="cuda:0")
     host = synth.to_numpy(tb)
