@@ -989,7 +989,9 @@ struct Stream {
             size_t used = 0;
             auto tt1 = tt0;
             bool final;
-            const bool unfused = getenv("KD_DECODE_UNFUSED") != nullptr;   // (tests / measurements: the two-phase path)
+            // (tests / measurements: the two-phase path.  Never for a SPAN -- kd_decode_open_span: only the fused branch knows where a
+            // span begins inside its first block and where it must end)
+            const bool unfused = getenv("KD_DECODE_UNFUSED") != nullptr && span_end == ~(size_t)0 && span_skip == 0;
             if (header_done && !unfused) {
                 // Records only: every worker inflates a run of whole blocks and walks the records in them straight away
                 // (RangePlan); what a worker cannot judge at the end of its run is walked by the hand-off pass.

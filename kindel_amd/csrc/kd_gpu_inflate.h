@@ -31,11 +31,14 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 #define GI_LOAD_FAR(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-// Before a far match reads flushed output back: its bytes left the ring >= 28 flushes (one store instruction each) ago, stores
-// complete in the order issued, so "at most 8 vector memory operations outstanding" means they have reached the L2 (which the sc1
-// loads read).  A release fence here waits for the NEWEST flush as well: 8 us per far match measured, 44 % of a quality-less file's
-// inflate time.
-#define GI_DRAIN_STORES() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+// Before a far match reads flushed output back: its newest source byte lies at least GI_NEAR - 257 bytes behind `pos` and `flushed` is
+// at most 255 bytes behind `pos`, so at least (GI_NEAR - 513) / 256 flushes (one store instruction each) were issued AFTER the one
+// that carried the byte; memory operations of a wavefront complete in the order issued, so "at most that many vector memory
+// operations outstanding" means the byte has reached the L2 (which the sc1 loads read).  The count follows from the ring's
+// geometry (GI_FAR_VMCNT below: 3 for the 2 KiB ring -- round 3 shipped vmcnt(8), derived for the 8 KiB ring it had first, with
+// which the newest source byte's store could still be in flight: a timing-dependent stale read).  A release fence here waits for
+// the NEWEST flush as well and writes the L2 back: 8 us per far match measured, 44 % of a quality-less file's inflate time.
+#define GI_DRAIN_STORES() asm volatile(GI_FAR_WAIT ::: "memory")
 __device__ __forceinline__ uint32_t gi_readlane(uint32_t v, uint32_t lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)lane));
 }
@@ -59,6 +62,20 @@ static inline uint32_t gi_uni(uint32_t v) { return v; }
 #endif
 #define GI_RING_MASK (GI_RING - 1u)
 #define GI_NEAR (GI_RING - 512u)      // a match at most this far back is copied inside the ring
+// vector memory operations that may still be outstanding when a far match reads its source back (GI_DRAIN_STORES)
+#define GI_FAR_VMCNT ((GI_NEAR - 513u) / 256u)
+#if GI_RING < 1024u
+#error "GI_RING: a power of two >= 1024 (a far match's source must have left the ring at least one flush ago)"
+#elif (GI_RING - 512u - 513u) / 256u >= 8u
+#define GI_FAR_WAIT "s_waitcnt vmcnt(8)"
+#elif (GI_RING - 512u - 513u) / 256u >= 3u
+#define GI_FAR_WAIT "s_waitcnt vmcnt(3)"
+#elif (GI_RING - 512u - 513u) / 256u >= 1u
+#define GI_FAR_WAIT "s_waitcnt vmcnt(1)"
+#else
+#define GI_FAR_WAIT "s_waitcnt vmcnt(0)"
+#endif
+static_assert((GI_RING & (GI_RING - 1u)) == 0u && GI_NEAR + 258u <= GI_RING, "k_gpu_inflate: a near match (source and the bytes it writes) must fit the ring");
 #define GI_LIT_BITS 10
 #define GI_DIST_BITS 8
 #define GI_CL_BITS 7
@@ -165,6 +182,7 @@ __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const G
     s.cur = gi_load_dw(s, lane); s.nxt = gi_load_dw(s, 64u + lane);
     const GiCode c_lit{t_lit, cnt_lit, srt_lit, GI_LIT_BITS}, c_dist{t_dist, cnt_dist, srt_dist, GI_DIST_BITS}, c_cl{t_cl, cnt_cl, srt_cl, GI_CL_BITS};
     uint32_t pos = 0, flushed = 0, err = GI_OK;
+    uint32_t in_rem = B.in_len;   // bytes of the block's input from s.in on (a stored block restarts the window behind its bytes)
     bool dirty = false;      // flushed bytes whose stores may still be on their way
 #ifdef GI_CLOCKS             // profiling build (scripts/gpu_inflate_proto.py --clocks): where the wavefront's clocks go
     long long gc_mark = clock64(), gc_build = 0, gc_sym = 0, gc_near = 0, gc_far = 0, gc_flush = 0, gc_other = 0;
@@ -209,7 +227,7 @@ __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const G
             if (pos + len > B.out_len) { err = GI_E_SIZE; break; }
             // the bit buffer holds whole bytes now: the next unread input byte is
             const unsigned long long at = 4ull * s.idx - s.bc / 8u;
-            if (at + len > B.in_len) { err = GI_E_INPUT; break; }
+            if (at + len > in_rem) { err = GI_E_INPUT; break; }    // (against what is LEFT of the block: a second stored block must not read on)
             for (uint32_t done = 0; done < len;) {      // through the ring like everything else, 256 bytes at a time
                 const uint32_t step = len - done < 256u ? len - done : 256u;
                 GI_WAVE_SYNC();
@@ -220,7 +238,8 @@ __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const G
             }
             // restart the input window behind the stored bytes
             const unsigned long long next = at + len;
-            s.in += next; s.n_dw = (uint32_t)((B.in_len - next + 3u) / 4u + 1u);
+            in_rem -= (uint32_t)next;
+            s.in += next; s.n_dw = (in_rem + 3u) / 4u + 1u;
             s.idx = 0; s.bb = 0; s.bc = 0;
             s.cur = gi_load_dw(s, lane); s.nxt = gi_load_dw(s, 64u + lane);
             continue;
@@ -322,7 +341,7 @@ __global__ void __launch_bounds__(64) k_gpu_inflate(const uint8_t *comp, const G
             if (pos - flushed >= 256u) flush();
         }
         // consumed more than the block holds?
-        if (err == GI_OK && 32ull * s.idx - s.bc > 8ull * ((const uint8_t *)comp + B.in_off + B.in_len - s.in)) err = GI_E_INPUT;
+        if (err == GI_OK && 32ull * s.idx - s.bc > 8ull * in_rem) err = GI_E_INPUT;
     }
     if (err == GI_OK && pos != B.out_len) err = GI_E_SIZE;
     // the tail of the ring, byte by byte

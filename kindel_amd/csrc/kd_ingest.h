@@ -159,11 +159,16 @@ k_bam_count(KdBam B, const kd_u64 *start, const uint32_t *inflate_status, kd_u64
             q += 4 + (kd_u64)R.bs;
         }
         // the walk ended on the first record that starts behind this block: the part that begins there must have guessed it
-        if (q < B.n) {
-            const uint32_t nb = kd_bam_block_of(B, q);
-            if (start[nb] != q) { atomicOr(status, KD_INGEST_CHAIN); atomicMax((kd_u64 *)(status + 2), ((kd_u64)(b + 1) << 32) | (nb + 1)); }   // (diagnosis: which hand-off)
+        // -- and a block that a record longer than a block skips whole (b < c < nb) must have guessed NOTHING: a start found there
+        // (record-shaped bytes inside a long record's qualities or auxiliary data) would be walked as phantom reads that neither the
+        // host decoder nor the reference ever sees.  Either way the file goes to the host decoder (KD_INGEST_CHAIN).
+        if (q > B.n) atomicOr(status, KD_INGEST_RECORD);
+        else {
+            const uint32_t nb = q < B.n ? kd_bam_block_of(B, q) : B.n_blocks;
+            bool chain_ok = q == B.n || start[nb] == q;
+            for (uint32_t c = b + 1; c < nb && chain_ok; c++) chain_ok = start[c] == KD_BAM_NONE;
+            if (!chain_ok) { atomicOr(status, KD_INGEST_CHAIN); atomicMax((kd_u64 *)(status + 2), ((kd_u64)(b + 1) << 32) | (nb + 1)); }   // (diagnosis: which hand-off)
         }
-        else if (q > B.n) atomicOr(status, KD_INGEST_RECORD);
     }
     cnt_rec[b] = kept; cnt_seq[b] = sb; cnt_cig[b] = cw;
     if (seen) atomicAdd(n_seen, seen);

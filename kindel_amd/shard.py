@@ -358,8 +358,9 @@ def ingest_sharded(path, rank, world, device="cpu", group=None, threads=0, lib=N
         size = __import__("os").path.getsize(path)
         blocks = [0] + [int(np.searchsorted(off, size * p // world)) for p in range(1, world)] + [len(off)]
         own = N.decode_span(path, blocks[rank], blocks[rank + 1], threads=threads, lib=lib)
-    except OSError:
-        ok = 0          # not BGZF (SAM text, plain gzip) or a span that does not close
+    except Exception:   # noqa: BLE001 -- ANY failure of this rank's share must reach the collective below, or the others wait for it
+        own, ok = None, 0   # not BGZF (SAM text, plain gzip), a span that does not close, an RNAME without @SQ line, no memory:
+        #                     every rank then reads the whole file (and a real error is raised by all of them alike)
     n = len(own["contig"]) if own is not None else 0
     first = last = -1
     is_sorted, reach, lead, s0, s1 = 1, 0, 0, 0, 0
@@ -407,38 +408,47 @@ def ingest_sharded(path, rank, world, device="cpu", group=None, threads=0, lib=N
     lo, hi = ivs[rank]
     M, Lmax = int(rows[:, 5].max()), int(rows[:, 6].max())
     pieces, extra = [own], 0
-    if hi > lo:
-        # reads of EARLIER shares that reach into [lo, ...): they start after lo - M
-        if rank > 0 and lo > 0:
-            b_hi, step, back = blocks[rank], 1, []
-            while b_hi > 0:
-                b_lo = max(0, b_hi - step)
-                sp = N.decode_span(path, b_lo, b_hi, threads=threads, lib=lib)
-                back.insert(0, sp)
-                b_hi, step = b_lo, step * 2
-                if len(sp["contig"]) and int(_start_keys(base, sp)[0]) + M <= lo:
-                    break
-            pieces = back + pieces
-            extra += sum(len(b["contig"]) for b in back)
-        # reads of LATER shares that touch the halo site hi (or reach back over it with a leading clip): they start by hi + Lmax
-        if rank + 1 < world and hi < S:
-            b_lo, step, fwd = blocks[rank + 1], 1, []
-            nblk = blocks[world]
-            while b_lo < nblk:
-                b_hi = min(nblk, b_lo + step)
-                sp = N.decode_span(path, b_lo, b_hi, threads=threads, lib=lib)
-                fwd.append(sp)
-                b_lo, step = b_hi, step * 2
-                if len(sp["contig"]) and int(_start_keys(base, sp)[-1]) > hi + Lmax:
-                    break
-            pieces = pieces + fwd
-            extra += sum(len(b["contig"]) for b in fwd)
+    fail = None     # an exception of this rank's neighbour decode: carried through the closing collective, raised by every rank
+    try:
+        if hi > lo:
+            # reads of EARLIER shares that reach into [lo, ...): they start after lo - M
+            if rank > 0 and lo > 0:
+                b_hi, step, back = blocks[rank], 1, []
+                while b_hi > 0:
+                    b_lo = max(0, b_hi - step)
+                    sp = N.decode_span(path, b_lo, b_hi, threads=threads, lib=lib)
+                    back.insert(0, sp)
+                    b_hi, step = b_lo, step * 2
+                    if len(sp["contig"]) and int(_start_keys(base, sp)[0]) + M <= lo:
+                        break
+                pieces = back + pieces
+                extra += sum(len(b["contig"]) for b in back)
+            # reads of LATER shares that touch the halo site hi (or reach back over it with a leading clip): they start by hi + Lmax
+            if rank + 1 < world and hi < S:
+                b_lo, step, fwd = blocks[rank + 1], 1, []
+                nblk = blocks[world]
+                while b_lo < nblk:
+                    b_hi = min(nblk, b_lo + step)
+                    sp = N.decode_span(path, b_lo, b_hi, threads=threads, lib=lib)
+                    fwd.append(sp)
+                    b_lo, step = b_hi, step * 2
+                    if len(sp["contig"]) and int(_start_keys(base, sp)[-1]) > hi + Lmax:
+                        break
+                pieces = pieces + fwd
+                extra += sum(len(b["contig"]) for b in fwd)
+    except Exception as e:   # noqa: BLE001
+        fail = (type(e).__name__, str(e))
+        pieces = [own]
     batch = concat_batches(pieces) if hi > lo else None
     if batch is not None:
         g_lo, g_hi = footprints(lens, batch)
         batch = _subset(batch, (g_hi > lo) & (g_lo <= hi))
-    used = gather_obj(np.unique(np.asarray(own["contig"])).tolist())              # (a handful of ints per rank; same collective round)
-    order = sorted(set(c for u in used for c in u))      # coordinate-sorted file: first appearance = ascending contig id
+    used = gather_obj((np.unique(np.asarray(own["contig"])).tolist(), fail))      # (a handful of ints per rank; same collective round)
+    failed = next((f for _, f in used if f), None)
+    if failed:          # the lowest failing rank's exception, on every rank
+        raise {"KeyError": KeyError, "IndexError": IndexError, "MemoryError": MemoryError, "OSError": OSError}.get(failed[0], RuntimeError)(
+            "rank-sharded ingest: " + failed[1])
+    order = sorted(set(c for u, _ in used for c in u))   # coordinate-sorted file: first appearance = ascending contig id
     return dict(batch=batch, interval=(lo, hi), intervals=ivs, names=[str(x) for x in own["contig_names"]], lens=lens, order=order,
                 mode="sharded", stats=dict(decoded_records=n, neighbour_records=extra, blocks=(blocks[rank], blocks[rank + 1])))
 
@@ -454,12 +464,12 @@ def pileup_consensus_sharded(path, rank, world, device="cpu", dev_index=0, group
     eng = N.Engine(ing["lens"], device=dev_index, lib=lib)
     err = None
     try:
-        eng.set_shard(*ing["interval"])
-        if ing["batch"] is not None and len(ing["batch"]["contig"]):
-            eng.push(ing["batch"])
-        try:
+        try:        # ANY exception of this rank (a reference exception, no device memory, a native error) goes through the gather
+            eng.set_shard(*ing["interval"])
+            if ing["batch"] is not None and len(ing["batch"]["contig"]):
+                eng.push(ing["batch"])
             eng.finalize()
-        except (KeyError, IndexError, RuntimeError) as e:
+        except Exception as e:   # noqa: BLE001
             err = (type(e).__name__, str(e))
         if world > 1:
             errs = [None] * world
@@ -468,7 +478,7 @@ def pileup_consensus_sharded(path, rank, world, device="cpu", dev_index=0, group
             errs = [err]
         first_err = next((e for e in errs if e), None)
         if first_err:     # (the lowest rank's = the earliest position's, for a sorted file the reference's own choice)
-            raise {"KeyError": KeyError, "IndexError": IndexError, "RuntimeError": RuntimeError}[first_err[0]](first_err[1])
+            raise {"KeyError": KeyError, "IndexError": IndexError, "MemoryError": MemoryError, "OSError": OSError}.get(first_err[0], RuntimeError)(first_err[1])
         eng.consensus_run(min_depth)
         seqs, changes, minmax = stitch(eng, ing["interval"], device, group, intervals=ing["intervals"])
     finally:

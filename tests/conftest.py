@@ -25,7 +25,8 @@ def hip_lib():
     """The product library on a real GPU."""
     import torch
     from kindel_amd import _native as N
-    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    if not torch.cuda.is_available():
+        pytest.skip("needs a real MI355X (the -m gpu suite runs through gpurun)")
     return N.default_library()
 
 

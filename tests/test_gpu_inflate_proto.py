@@ -188,3 +188,25 @@ def test_block_crc_kernel_against_zlib(proto):
         obuf[int(blocks[8].out_off) + 4321] ^= 0x10
         assert proto.gi_crc_blocks(cbuf.ctypes.data, C.addressof(blocks), len(datas), obuf.ctypes.data, bad.ctypes.data, grid) == 0
         assert int(bad[0]) == 1, grid
+
+
+def test_a_second_stored_block_is_bounded_by_what_is_left_of_the_input(proto):
+    """stored(300 bytes) followed by a stored block that CLAIMS 200 bytes while only 10 are left of the BGZF block's input: the length
+    check must be made against the remaining input, not against the whole block's (the window restarts behind a stored block) --
+    else the kernel reads on into the next block's compressed bytes and reports success (round 3's review)."""
+    import struct
+    first = bytes(range(256)) + bytes(44)
+    good = b"\x00" + struct.pack("<HH", 300, 300 ^ 0xffff) + first
+    lying = good + b"\x01" + struct.pack("<HH", 200, 200 ^ 0xffff) + b"Z" * 10
+    follower = raw_deflate(b"the next block's bytes " * 40, 6, zlib.Z_DEFAULT_STRATEGY)
+    outs, status = inflate_blocks(proto, [lying, follower], [500, 23 * 40])
+    assert status[0] == 7, int(status[0])            # GI_E_INPUT
+    assert status[1] == 0 and outs[1] == b"the next block's bytes " * 40
+    # the honest version of the same shape: two stored blocks, the second one complete
+    honest = good + b"\x01" + struct.pack("<HH", 10, 10 ^ 0xffff) + b"Z" * 10
+    outs, status = inflate_blocks(proto, [honest, follower], [310, 23 * 40])
+    assert status[0] == 0 and outs[0] == first + b"Z" * 10 and status[1] == 0
+    # ... and a dynamic block behind a stored one whose code words run past the block's end is still caught by the closing check
+    cut = good + follower[:len(follower) // 2]
+    outs, status = inflate_blocks(proto, [cut, follower], [300 + 23 * 40, 23 * 40])
+    assert status[0] != 0 and status[1] == 0
