@@ -91,6 +91,17 @@ __device__ __forceinline__ unsigned long long kd_ld_acquire(const unsigned long 
 __device__ __forceinline__ void kd_spin_pause() { __builtin_amdgcn_s_sleep(8); }
 #endif
 
+// Profiling hooks of k_window (where its wavefronts spend their clocks).  EMPTY in the product; a profiling build force-includes
+// scripts/exp/kd_phase_clocks.h (hipcc -include ...), which defines them and KD_PHASE_CLOCKS (eight more status words).  The
+// product headers hold no measurement-only code paths: the wrong-on-purpose attribution builds of rounds 2 - 3 (packed bases
+// from cache, flush skipped, ...) are recorded in profiles/ and gone from the tree.
+#ifndef KD_PHASE_DECL
+#define KD_PHASE_DECL
+#define KD_MARK(acc)
+#define KD_PHASE_COMMIT(status, rows)
+#define KD_PHASE_REPORT(h)
+#endif
+
 #define KD_WAVE 64
 #define KD_BLOCK 256
 #define KD_WAVES_PER_BLOCK (KD_BLOCK / KD_WAVE)
@@ -147,6 +158,8 @@ enum {
     KDO_B_N_IRREG,      // per batch: entries in the irregular list
     KDO_B_N_LONG,       // per batch: entries in the long-CIGAR list
     KDO_B_N_REG,        // per batch: regular reads
+    KDO_B_FILL,         // per batch: entries of k_window's boundary table written by gap fills (k_prep's budget)
+    KDO_WQ_LEFT,        // k_window's work queue: hot windows that still have slices nobody has taken
     KDO_WQ_TICKET,      // k_window's self-planned work queue (kd_window.h): window tickets handed out,
     KDO_WQ_PUB,         //   windows whose owner has published its slice count,
     KDO_WQ_HOT,         //   entries of the list of windows with more than one slice
@@ -181,6 +194,8 @@ enum {
 #define KDS_B_N_IRREG (KDO_B_N_IRREG * KDS_STRIDE)
 #define KDS_B_N_LONG (KDO_B_N_LONG * KDS_STRIDE)
 #define KDS_B_N_REG (KDO_B_N_REG * KDS_STRIDE)
+#define KDS_B_FILL (KDO_B_FILL * KDS_STRIDE)
+#define KDS_WQ_LEFT (KDO_WQ_LEFT * KDS_STRIDE)
 #define KDS_WQ_TICKET (KDO_WQ_TICKET * KDS_STRIDE)
 #define KDS_WQ_PUB (KDO_WQ_PUB * KDS_STRIDE)
 #define KDS_WQ_HOT (KDO_WQ_HOT * KDS_STRIDE)

@@ -344,18 +344,13 @@ k_window_coop(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
                     else l_cplx[atomicAdd(&s_cnt[1], 1u)] = (uint16_t)t;
                 }
             }
-#ifndef KD_EXP_COOP_NOLOAD2
             if (it + 1 >= 0 && it + 1 < n_tiles) {
                 // second level for tile it + 1: the bases and CIGAR words of the read whose footprint / offsets arrived (unconditional
                 // loads with clamped offsets: a chunk or word behind the read's end repeats its last one and is never used)
                 b_ri = a_ri;
                 const uint32_t nby = ((a_ri.pad & 0xffffffu) + 1u) >> 1, nc = a_ri.pad >> 24;
                 const uint32_t last_chunk = nby ? ((nby - 1u) >> 4) : 0u;
-#ifdef KD_EXP_NOSEQ
-                const uint8_t *sp = rd.seq4 + (a_so & 0xff0u);
-#else
                 const uint8_t *sp = rd.seq4 + a_so;
-#endif
 #pragma unroll
                 for (int u = 0; u < KD_CPRE; u++)
                     b_ch[u] = *reinterpret_cast<const KdChunk *>(sp + 16u * ((uint32_t)u < last_chunk ? (uint32_t)u : last_chunk));
@@ -363,9 +358,6 @@ k_window_coop(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
                 const uint32_t lw = nc ? nc - 1u : 0u;
                 b_cw[0] = cg[0]; b_cw[1] = cg[1u < lw ? 1u : lw]; b_cw[2] = cg[2u < lw ? 2u : lw]; b_cw[3] = cg[3u < lw ? 3u : lw];
             }
-#else
-            if (it + 1 >= 0 && it + 1 < n_tiles) { b_ri = a_ri; b_cw[0] = (b_ri.pad & 0xffffffu) << 4; }
-#endif
             if (it + 2 < n_tiles) {
                 // first level for tile it + 2
                 const kd_u64 j = first + (kd_u64)(it + 2) * KD_CT + t;
@@ -386,15 +378,9 @@ k_window_coop(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
                 const uint32_t rows_p = (np + KD_CGROUPS - 1) / KD_CGROUPS, rows_c = (ncx + KD_CGROUPS - 1) / KD_CGROUPS;
                 const uint32_t w_c = (wave + KD_WAVES_PER_BLOCK - rows_p % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK;
                 const uint32_t w_g = (wave + 2 * KD_WAVES_PER_BLOCK - (rows_p + rows_c) % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK;
-#ifndef KD_EXP_COOP_NOWALK      // (measurement-only builds, exp/: results wrong on purpose -- see kd_window.h)
-#ifndef KD_EXP_COOP_NOPLAIN
                 kd_coop_list_plain(hb, S, l_a, np, wave, Wi, PB, k, grp, bad);
-#endif
-#ifndef KD_EXP_COOP_NOCPLX
                 kd_coop_list_complex(hb, S, l_cplx, ncx, w_c, Wi, PB, k, grp, bad);
-#endif
                 kd_coop_list_general(hb, rd, S, order, l_a + KD_CT - 1, ng, w_g, tb, Wi, PB, k, grp, bad);
-#endif
                 __syncthreads();
             }
         }
@@ -407,9 +393,6 @@ k_window_coop(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T,
             const uint32_t *hrow = hist + KD_CPAD + row * (uint32_t)P;
             for (uint32_t xw = t; xw < W / 2; xw += KD_BLOCK) {
                 const uint32_t v = hrow[xw];
-#ifdef KD_EXP_NOFLUSH
-                if (v != 0x7fff7fffu) continue;
-#endif
                 if (!v) continue;
                 if (tch == 0xffu) { bad = true; continue; }
                 const kd_u64 g0 = wlo + 2 * (kd_u64)xw;   // even: 8-byte aligned in the channel row

@@ -277,10 +277,10 @@ struct KdEngine {
         int rc;
         // reads per lane of k_prep (one wavefront per workgroup): 64 keep its per-wavefront atomics few (one per counter and 4096
         // reads), but a small batch (a shard of a strong-scaling run, a deep small genome) then launches fewer wavefronts than the
-        // chip has slots: halve until ~8 wavefronts per CU are there
+        // chip has slots: halve until ~4 wavefronts per CU are there
         uint32_t prep_per = KD_PREP_PER_THREAD;
         if (const char *e = getenv("KD_PREP_PER")) prep_per = (uint32_t)std::min(KD_PREP_PER_THREAD, std::max(KD_PREP_UNROLL, atoi(e) / KD_PREP_UNROLL * KD_PREP_UNROLL));   // (knob: measurement)
-        else while (prep_per > KD_PREP_UNROLL && n / ((uint64_t)KD_PREP_BLOCK * prep_per) < (uint64_t)8 * rt.n_cus()) prep_per /= 2;
+        else while (prep_per > KD_PREP_UNROLL && n / ((uint64_t)KD_PREP_BLOCK * prep_per) < (uint64_t)4 * rt.n_cus()) prep_per /= 2;   // (1/8 of C3, 2.08 M reads: 4 / 8 / 16 / 32 / 64 reads per lane = 0.157 / 0.103 / 0.076 / 0.088 / 0.114 ms)
         const uint32_t prep_chunk = KD_PREP_BLOCK * prep_per, cold_region = KD_WAVE * prep_per;
         const unsigned prep_grid = (unsigned)((n + prep_chunk - 1) / prep_chunk);
         const unsigned prep_regions = prep_grid;     // one region of compact cold-read records per wavefront of k_prep
@@ -478,8 +478,8 @@ struct KdEngine {
                 }
                 if (!use_coop) {
                     // k_window: self-planned queue -- nothing but the list of windows with more than one slice to allocate
-                    if ((rc2 = ensure(b_hot, (size_t)n_win * 8))) return rc2;
-                    Q.hot = (uint32_t *)b_hot.p;
+                    if ((rc2 = ensure(b_hot, (size_t)n_win * sizeof(KdHot)))) return rc2;
+                    Q.hot = (KdHot *)b_hot.p;
                     const uint32_t Wh = (W + H + 2 * KD_HALO) / 2;   // dwords per channel row
                     const size_t lds = KD_WINDOW_LDS_BYTES(Wh);
                     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
@@ -815,16 +815,7 @@ struct KdEngine {
     int finalize_check(uint64_t *err_read, bool *redone = nullptr) {
         int rc;
         if (h_status[KDS_INTERNAL]) return fail(KD_E_INTERNAL, "insertion event buffers overran (internal error)");
-#ifdef KD_PHASE_CLOCKS   // profiling build (exp/: hipcc -DKD_PHASE_CLOCKS): where k_window's wavefronts spend their clocks
-        {
-            const char *nm[8] = {"dequeue", "zero", "classify", "plain", "complex", "barrier-wait", "flush", "waves"};
-            double tot = 0;
-            for (int k = 0; k < 7; k++) tot += (double)h_status[KDS_DBG0 + k * KDS_STRIDE];
-            fprintf(stderr, "k_window phase clocks (sum over wavefronts):");
-            for (int k = 0; k < 8; k++) fprintf(stderr, " %s=%.3g(%.1f%%)", nm[k], (double)h_status[KDS_DBG0 + k * KDS_STRIDE], 100.0 * h_status[KDS_DBG0 + k * KDS_STRIDE] / tot);
-            fprintf(stderr, "\n");
-        }
-#endif
+        KD_PHASE_REPORT(h_status)
         if (h_status[KDS_ERR_READ] != ~0ULL) {
             // the reference raises for the first failing read of the earliest-appearing contig (kindel.py:150-151)
             std::vector<kd_u64> fi(n_contigs), ef(n_contigs);

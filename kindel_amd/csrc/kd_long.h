@@ -365,18 +365,12 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
                 if (e >= ins.ev_cap || po + nb > ins.pool_cap) {
                     atomicAdd(&status[KDS_INTERNAL], 1ULL);
                 } else if (kd_commit(T, g)) {
-#ifndef KD_EXP_LONG_NOEV     // (measurement-only builds, exp/: wrong results on purpose)
                     ins.ev_site[e] = (uint32_t)g; ins.ev_len[e] = nb; ins.ev_off[e] = po;
-#endif
                     const uint32_t q0 = (int64_t)q_op < sl ? q_op : (uint32_t)sl;
                     for (uint32_t x0 = 0; x0 < nb; x0 += 8u) {       // 8 bases per fetch, one base code per pool byte
                         const uint32_t qq = q0 + x0;
                         uint32_t z = staged ? kd_fetch8_lin_lds(s_seq, (qq >> 1) - (qb >> 1), qq & 1u) : kd_fetch8_lin(seq, qq);
-#ifndef KD_EXP_LONG_NOEV
                         for (uint32_t x = x0; x < nb && x < x0 + 8u; x++, z >>= 4) ins.pool[po + x] = (uint8_t)(z & 15u);
-#else
-                        if (z == 0x12345678u) ins.pool[po] = 1;
-#endif
                     }
                     if (dup) atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g], 1u);     // (its site's "+ins" flag is taken)
                 } else {
@@ -397,11 +391,7 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
         }
         // ---- the tile's pieces, 64 at a time ----
         uint32_t op_in = 0;                    // 1 + the op the chunk's first piece continues (0: it starts an op)
-#ifdef KD_EXP_LONG_NOWALK
-        const uint32_t n_chunks_pieces = 0;
-#else
         const uint32_t n_chunks_pieces = n_pieces;
-#endif
         for (uint32_t p0 = 0; p0 < n_chunks_pieces; p0 += KD_WAVE) {
             s_pt[lane] = 0; s_out[lane] = 0; s_insb[lane] = 0;
             KD_WAVE_SYNC();
@@ -435,9 +425,6 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
             const uint32_t jf = kd_readfirstlane(j);
             if (cj != 0xffffffffu && cj != jf) {            // the carried dword is complete
                 if (lane == 0) {
-#ifdef KD_EXP_LONG_NOROW
-                    if (cval == 0x12345678u)
-#endif
                     row[cj] = KD_ROW_FINISH(cval, cins);
                 }
                 cval = 0; cins = 0;
@@ -452,9 +439,6 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
             uint32_t v = s_out[lane], vb = s_insb[lane];
             if (lane == 0) { v |= cval; vb |= cins; }
             if (jf + lane < jl) {
-#ifdef KD_EXP_LONG_NOROW
-                if (v == 0x12345678u)
-#endif
                 row[jf + lane] = KD_ROW_FINISH(v, vb);
             }
             cj = jl;

@@ -72,7 +72,7 @@ k_sort_scan(uint32_t *bin_cnt, kd_u64 *bin_off, uint32_t n_bins, kd_u64 *status)
     __shared__ kd_u64 s_wave[KD_SCAN_WIDE / KD_WAVE];
     const uint32_t t = threadIdx.x;
     // (a bucket-sorted pass follows: k_window's work queue starts empty -- a batch's second pass finds the first one's counts)
-    if (t == 0) { status[KDS_WQ_TICKET] = 0; status[KDS_WQ_PUB] = 0; status[KDS_WQ_HOT] = 0; }
+    if (t == 0) { status[KDS_WQ_TICKET] = 0; status[KDS_WQ_PUB] = 0; status[KDS_WQ_HOT] = 0; status[KDS_WQ_LEFT] = 0; }
     const uint32_t per = (n_bins + KD_SCAN_WIDE - 1) / KD_SCAN_WIDE;
     const uint32_t b0 = t * per < n_bins ? t * per : n_bins, b1 = b0 + per < n_bins ? b0 + per : n_bins;
     kd_u64 mine = 0;

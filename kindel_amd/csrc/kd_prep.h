@@ -172,6 +172,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
     uint32_t w_ev_total = 0;
     kd_u64 w_pool_total = 0;
     const bool tail_wave = chunk0 < rd.n && chunk0 + (kd_u64)KD_PREP_BLOCK * per_thread >= rd.n;
+    bool fill_on = true;                                         // this wavefront still writes k_window's boundary table
     uint32_t c_cached = 0xffffffffu;                             // one-entry cache of the contig table
     uint32_t cb_cached = 0, L_cached = 0;                         // (G-space fits 32 bits)
     for (int it0 = 0; it0 < (int)per_thread; it0 += KD_PREP_UNROLL) {
@@ -225,11 +226,15 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
                 // k_window's BOUNDARY TABLE (kd_window.h: KdWq): bound[j] = first read that starts at or behind site 64 j.  A read in
                 // a later granule than its predecessor fills the granules in between (the batch's first read: from granule 0) --
                 // by itself when that is one or two entries (deep coverage: every granule holds reads), the whole wavefront
-                // together when it is a gap in the coverage.  Meaningless for an unsorted batch (which is bucket-sorted instead).
+                // together when it is a gap in the coverage.  Meaningless for an unsorted batch (which is bucket-sorted instead,
+                // the table unused) -- and there every forward jump would look like a gap to fill: a wavefront that sees ONE read
+                // start in front of its predecessor stops filling for good (random order: the first 64 reads it looks at), and
+                // fills of more than 64 entries draw on a budget of 4 x the table (a sorted batch fills every entry once).
                 if (bound) {
+                    if (kd_ballot(ok && pk > gkey)) fill_on = false;          // (wave-uniform)
                     const uint32_t kj = gkey >> 6;
                     const uint32_t b0 = i == 0 ? 0u : (pk >> 6) + 1u;         // first granule to fill
-                    uint32_t cnt = (ok && kj >= b0) ? kj - b0 + 1u : 0u;
+                    uint32_t cnt = (fill_on && ok && kj >= b0) ? kj - b0 + 1u : 0u;
                     if (cnt <= 2u) {
                         if (cnt) bound[b0] = (uint32_t)i;
                         if (cnt == 2u) bound[b0 + 1u] = (uint32_t)i;
@@ -238,6 +243,11 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
                     for (unsigned long long m = kd_ballot(cnt != 0); m; m &= m - 1) {
                         const uint32_t l = (uint32_t)__builtin_ctzll(m);
                         const uint32_t f0 = kd_shfl(b0, l), fn = kd_shfl(cnt, l), fv = kd_shfl((uint32_t)i, l);
+                        if (fn > 64u) {
+                            kd_u64 spent = 0;
+                            if (t == 0) spent = atomicAdd(&status[KDS_B_FILL], (kd_u64)fn);
+                            if (kd_shfl64(spent, 0) > 4ull * nb) { fill_on = false; break; }
+                        }
                         for (uint32_t x = t; x < fn; x += KD_WAVE) bound[f0 + x] = fv;
                     }
                     // behind the batch's last read: "none" = the number of reads

@@ -42,19 +42,7 @@
 // masked path below is only needed at the ends of a run.
 // Counter of (channel ch, window-relative site s in [-KD_HALO, W + KD_HALO)) = half (s & 1) of hist0[(s >> 1) * 19 + ch],
 // hist0 = hist + (KD_HALO / 2) * 19; Wh = (W + 2 * KD_HALO) / 2 pairs.
-// MEASUREMENT-ONLY builds (exp/, never the product: their results are wrong on purpose), used to attribute k_window's HBM
-// traffic to its sources under `rocprofv3 --pmc FETCH_SIZE` (scripts/gpu_attrib.sh):
-//   -DKD_EXP_NOSEQ    every read takes its packed bases from the first 4 KiB of the batch (cache hits)
-//   -DKD_EXP_NOFLUSH  the LDS histogram is built but never added to the tables
-//   -DKD_EXP_PAIRADD  cost model of a joint (two-base) histogram: a whole dword of a run issues 4 LDS atomics, each with the
-//                     address / half-word arithmetic a 16-bit joint counter needs, instead of 8 (same LDS footprint:
-//                     an optimistic bound, the real thing needs 36 counters per site pair)
-//   -DKD_WINDOW_OCC=7 __launch_bounds__ for 7 workgroups per CU (<= 72 VGPRs); run with a window of <= 448 sites
-#ifdef KD_EXP_NOSEQ
-#define KD_SEQ_AT(rd, i) ((rd).seq4 + (KD_SOFF(rd, i) & 0xff0u))
-#else
 #define KD_SEQ_AT(rd, i) ((rd).seq4 + KD_SOFF(rd, i))
-#endif
 #define KD_HALO 8
 #define KD_HPITCH 19
 #define KD_HPITCHB (4 * KD_HPITCH)
@@ -88,22 +76,12 @@ __device__ __forceinline__ void kd_add8_full(uint32_t *hist0, uint32_t v, int32_
     const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
     uint32_t rh, rl;
     kd_codes8<ROWS>(v, rh, rl);
-#ifdef KD_EXP_PAIRADD
-    const uint32_t jj = rh + rl;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t jb = (jj >> (8 * k)) & 0xffu;
-        unsigned char *a = (p ? hq : h) + (jb & 0xfcu) + KD_HPITCHB * k;
-        atomicAdd(reinterpret_cast<uint32_t *>(a), (vp | vq) << ((jb & 2u) << 3));
-    }
-#else
 #pragma unroll
     for (int b = 0; b < 8; b++) {
         const uint32_t code = (((b & 1) ? rl : rh) >> (8 * (b >> 1))) & 0xffu;
         unsigned char *a = ((b & 1) ? hq : h) + code + KD_HPITCHB * (b >> 1);
         atomicAdd(reinterpret_cast<uint32_t *>(a), (b & 1) ? vq : vp);
     }
-#endif
 }
 // only bases [blo, bhi) belong to the run
 template <bool ROWS = false>
@@ -469,16 +447,11 @@ __device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const
 #undef KD_INNER_STAGE
 }
 
-#ifndef KD_LANE_GROUP
-#define KD_LANE_GROUP 1   // 1, 2, 4, .. 64 (a divisor of the wavefront size)
-#endif
 #define KD_TILE 1024   // reads classified together (a multiple of KD_BLOCK)
 #define KD_TILE_PER_THREAD (KD_TILE / KD_BLOCK)
 #define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)2 * KD_TILE * 2)   // Wh = site pairs, halos included
 
-#ifndef KD_WINDOW_OCC
-#define KD_WINDOW_OCC 5
-#endif
+#define KD_WINDOW_OCC 5   // workgroups per CU the register budget is set for (= what the LDS footprint allows; 6 / 7 measured: slower, scratch)
 // k_window's WORK QUEUE (round 4: the kernel plans for itself).  Rounds 1 - 3 planned in two kernels of their own -- a binary
 // search per window for its candidate range (k_plan_ranges, 24 us on C3: 24 dependent loads), a one-workgroup scan of the
 // per-window item counts that also wrote an item -> window table (k_plan_scan, 29 us) -- a twentieth of the step on C3 and
@@ -491,12 +464,13 @@ __device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const
 //     its owner keeps taking slices from the counter, and workgroups that find the tickets gone wait until every ticket holder
 //     has published (a count: owners publish right after the dequeue, before they tally) and then help with the hot windows.
 //     No scan, no item table, nothing sized by an upper bound on the items.
+struct alignas(16) KdHot { uint32_t w, next, K, pad; kd_u64 lo, hi; };   // a window with K > 1 slices: next slice to take, its candidate range
 struct KdWq {
     const uint32_t *bound32;   // k_prep's table (gran 64), or NULL:
     const kd_u64 *bound64;     //   the bin offsets of the bucket sort (entry b * reps = first slot of bin b)
     uint32_t gran, reps;
     uint32_t nb;               // last valid index of the table (= its entry for "behind the last site")
-    uint32_t *hot;             // [2 * n_win]: window, next slice
+    KdHot *hot;                // [n_win]
     uint32_t n_win, span_slot;
 };
 __device__ __forceinline__ kd_u64 kd_wq_bound(const KdWq &Q, kd_u64 j) {
@@ -548,22 +522,13 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
     const uint32_t nh = (uint32_t)KD_HCH * (uint32_t)Wh;   // histogram dwords
     const int32_t Wi = (int32_t)W, We = (int32_t)(W + H);     // the window / the histogram's reach, in sites
     uint32_t *hist_early = hist0 + (H / 2) * KD_HPITCH;       // pair of site wlo + H: origin of the early entries' walk (H is even)
-#ifdef KD_PHASE_CLOCKS
-#ifndef KD_PHASE_CLOCKS_ROWS_ONLY
-#define KD_PHASE_CLOCKS_ROWS_ONLY 0   // 1: only the row pass (k_window<true>) adds its clocks
-#endif
-    long long c_zero = 0, c_cls = 0, c_plain = 0, c_cplx = 0, c_wait = 0, c_flush = 0, c_deq = 0, c_mark;
-#define KD_MARK(acc) { const long long n_ = clock64(); acc += n_ - c_mark; c_mark = n_; }
-    c_mark = clock64();
-#else
-#define KD_MARK(acc)
-#endif
+    KD_PHASE_DECL      // (profiling hooks, empty in the product: kd_common.h)
     // thread 0's view of the queue, kept across items -- in LDS, not in registers: every lane would carry them, and the walk
     // needs its 96
-    const uint32_t NONE = 0xffffffffu;
+    const uint32_t NONE = 0xffffffffu, SCAN = 0xfffffffeu;
     __shared__ uint32_t q_hot_w, q_hot_j, q_hot_K;      // the hot window this workgroup is taking slices from
     __shared__ kd_u64 q_hot_lo, q_hot_hi;
-    __shared__ uint32_t q_state, q_scan, q_nhot;        // q_state: 0 window tickets may be left, 1 none left, 2 helping
+    __shared__ uint32_t q_state, q_nhot, s_found;       // q_state: 0 window tickets may be left, 1 none left, 2 helping
     if (t == 0) { q_hot_w = NONE; q_state = 0; }
     for (;;) {
         if (t == 0) {
@@ -571,7 +536,8 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
             kd_u64 lo = 0, hi = 0;
             for (;;) {
                 if (q_hot_w != NONE) {                   // a window with several slices: the next one nobody has taken
-                    k = atomicAdd(&Q.hot[2 * q_hot_j + 1], 1u);
+                    k = atomicAdd(&Q.hot[q_hot_j].next, 1u);
+                    if (k + 1u == q_hot_K) atomicAdd(&status[KDS_WQ_LEFT], ~0ULL);     // the window's last slice is taken
                     if (k < q_hot_K) { w = q_hot_w; lo = q_hot_lo; hi = q_hot_hi; break; }
                     q_hot_w = NONE;
                     continue;
@@ -583,9 +549,11 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                     const kd_u64 K = (hi - lo + slice - 1) / slice;
                     if (K > 1) {                         // publish the window for helpers; slice 0 is this workgroup's
                         const uint32_t j = (uint32_t)atomicAdd(&status[KDS_WQ_HOT], 1ULL);
-                        Q.hot[2 * j] = (uint32_t)tk; Q.hot[2 * j + 1] = 1u;
-                        q_hot_w = (uint32_t)tk; q_hot_j = j; q_hot_K = (uint32_t)(K < 0xffffffffULL ? K : 0xffffffffULL);
-                        q_hot_lo = lo; q_hot_hi = hi;
+                        KdHot e;
+                        e.w = (uint32_t)tk; e.next = 1u; e.K = (uint32_t)(K < 0xfffffff0ULL ? K : 0xfffffff0ULL); e.pad = 0; e.lo = lo; e.hi = hi;
+                        Q.hot[j] = e;
+                        q_hot_w = e.w; q_hot_j = j; q_hot_K = e.K; q_hot_lo = lo; q_hot_hi = hi;
+                        atomicAdd(&status[KDS_WQ_LEFT], 1ULL);
                         atomicAdd(&status[KDS_TOTAL_ITEMS], K - 1);      // (statistics: kd_get_batch_info)
                         __threadfence();
                     }
@@ -597,22 +565,44 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                 if (q_state == 1) {                      // every ticket is taken: wait until their holders have published
                     while (kd_ld_acquire(&status[KDS_WQ_PUB]) < (kd_u64)Q.n_win) kd_spin_pause();
                     q_nhot = (uint32_t)kd_ld_acquire(&status[KDS_WQ_HOT]);
-                    q_state = 2; q_scan = 0;
+                    q_state = 2;
                 }
-                if (q_scan >= q_nhot) break;             // w == NONE: done
-                // (workgroups start at different entries of the list and go round)
-                const uint32_t j = (blockIdx.x + q_scan) % q_nhot;
-                q_scan++;
-                kd_u64 hlo, hhi;
-                const uint32_t hw = Q.hot[2 * j];
-                kd_wq_range(Q, status, w0, hw, W, H, hlo, hhi);
-                const kd_u64 K = (hhi - hlo + slice - 1) / slice;
-                q_hot_w = hw; q_hot_j = j; q_hot_K = (uint32_t)(K < 0xffffffffULL ? K : 0xffffffffULL); q_hot_lo = hlo; q_hot_hi = hhi;
+                // helping: as long as some hot window has slices nobody has taken, look for one (all threads: below)
+                if (q_nhot != 0 && kd_ld_acquire(&status[KDS_WQ_LEFT]) != 0) w = SCAN;
+                break;                                   // (w == NONE: done)
             }
             s_win = w;
             s_first = lo + (kd_u64)k * slice;
             s_last = lo + (kd_u64)k * slice + slice < hi ? lo + (kd_u64)k * slice + slice : hi;
             s_cnt[0][0] = 0; s_cnt[0][1] = 0; s_cnt[0][2] = 0; s_cnt[0][3] = 0;
+            s_found = NONE;
+        }
+        __syncthreads();
+        if (s_win == SCAN) {
+            // the hot list, KD_BLOCK entries at a time (workgroups start at different entries and go round): the first one with a
+            // slice left; thread 0 then takes slices from it like its owner does
+            const uint32_t nhot = q_nhot;
+            for (uint32_t base = 0; base < nhot; base += KD_BLOCK) {      // (uniform trip count; two barriers per round)
+                const uint32_t x = base + t;
+                if (x < nhot) {
+                    const KdHot *e = &Q.hot[(blockIdx.x + x) % nhot];
+                    if (*(volatile const uint32_t *)&e->next < *(volatile const uint32_t *)&e->K) atomicMin(&s_found, x);
+                }
+                __syncthreads();
+                const bool hit = s_found != NONE;
+                __syncthreads();
+                if (hit) break;
+            }
+            if (t == 0) {
+                if (s_found == NONE) q_nhot = 0;         // nothing left anywhere: the next look at the queue says "done"
+                else {
+                    const uint32_t j = (blockIdx.x + s_found) % nhot;
+                    const KdHot e = Q.hot[j];
+                    q_hot_w = e.w; q_hot_j = j; q_hot_K = e.K; q_hot_lo = e.lo; q_hot_hi = e.hi;
+                }
+            }
+            __syncthreads();
+            continue;
         }
         __syncthreads();
         const uint32_t w = s_win;
@@ -676,16 +666,9 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
             // homogeneous wavefronts: first the plain reads, then the complex ones.  Lane l of a wavefront takes
             // list entries l*rows + r: neighbours in a wavefront are `rows` reads apart in the sorted batch,
             // which keeps them off the same LDS counters in the same instruction.
-            // lanes take the list in GROUPS of KD_LANE_GROUP neighbouring entries (neighbours in the sorted batch: their
-            // rinfo / seq_off / packed bases share cache lines, one fetch serves the group), the groups of a wavefront
-            // lie rows apart (different sites: fewer same-counter collisions in one LDS instruction)
-            const uint32_t ngi = (ni + KD_LANE_GROUP - 1) / KD_LANE_GROUP, ngp = (np + KD_LANE_GROUP - 1) / KD_LANE_GROUP,
-                           ngc = (ncx + KD_LANE_GROUP - 1) / KD_LANE_GROUP;
-            const uint32_t rows_i = (ngi + KD_WAVE / KD_LANE_GROUP - 1) / (KD_WAVE / KD_LANE_GROUP);
-            const uint32_t rows_p = (ngp + KD_WAVE / KD_LANE_GROUP - 1) / (KD_WAVE / KD_LANE_GROUP);
-            const uint32_t rows_c = (ngc + KD_WAVE / KD_LANE_GROUP - 1) / (KD_WAVE / KD_LANE_GROUP);
+            const uint32_t rows_i = (ni + KD_WAVE - 1) / KD_WAVE, rows_p = (np + KD_WAVE - 1) / KD_WAVE, rows_c = (ncx + KD_WAVE - 1) / KD_WAVE;
             for (uint32_t r = wave; r < rows_i; r += KD_WAVES_PER_BLOCK) {
-                const uint32_t e = ((lane / KD_LANE_GROUP) * rows_i + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
+                const uint32_t e = lane * rows_i + r;
                 if (e < ni) {
                     const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
                     if (ROWS) kd_walk_row(rd, i, KD_RI(rinfo, rd, i), wlo, Wi, lane + 17u * r, hist0);
@@ -696,7 +679,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
             // (each list's rows start at the wavefront after the one that took the last row of the list before)
             for (uint32_t r = (wave + KD_WAVES_PER_BLOCK - rows_i % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK; r < rows_p;
                  r += KD_WAVES_PER_BLOCK) {
-                const uint32_t e = ((lane / KD_LANE_GROUP) * rows_p + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
+                const uint32_t e = lane * rows_p + r;
                 if (e < np) {
                     const kd_u64 j = tb + l_plain[KD_TILE - 1u - e], i = order ? (kd_u64)order[j] : j;
                     kd_walk_plain(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0);
@@ -706,7 +689,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
             // the complex rows start at the wavefront after the one that took the last plain row
             for (uint32_t r = (wave + 2 * KD_WAVES_PER_BLOCK - (rows_i + rows_p) % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK; r < rows_c;
                  r += KD_WAVES_PER_BLOCK) {
-                const uint32_t e = ((lane / KD_LANE_GROUP) * rows_c + r) * KD_LANE_GROUP + lane % KD_LANE_GROUP;
+                const uint32_t e = lane * rows_c + r;
                 if (e < ncx) {
                     const kd_u64 j = tb + l_cplx[e], i = order ? (kd_u64)order[j] : j;
                     const KdRInfo ri = KD_RI(rinfo, rd, i);
@@ -760,9 +743,6 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
             uint32_t *row2 = T.tab + (kd_u64)(tch2 == 0xffu ? 0u : tch2) * T.stride;
             for (uint32_t xw = t; xw < (uint32_t)Wh; xw += KD_BLOCK) {
                 const uint32_t v = hist[xw * KD_HPITCH + ch];
-#ifdef KD_EXP_NOFLUSH
-                if (v != 0x7fff7fffu) continue;
-#endif
                 if (!v) continue;
                 // the word holds window-relative sites s (low half) and s + 1 (high half); halo sites are dropped
                 const int32_t sw = 2 * (int32_t)xw - KD_HALO;
@@ -794,12 +774,5 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
         __syncthreads();
         KD_MARK(c_wait)
     }
-#ifdef KD_PHASE_CLOCKS
-    if ((t & 63u) == 0 && (ROWS || !KD_PHASE_CLOCKS_ROWS_ONLY)) {   // lane 0 of every wavefront
-        atomicAdd(&status[KDS_DBG0], (kd_u64)c_deq); atomicAdd(&status[KDS_DBG1], (kd_u64)c_zero);
-        atomicAdd(&status[KDS_DBG2], (kd_u64)c_cls); atomicAdd(&status[KDS_DBG3], (kd_u64)c_plain);
-        atomicAdd(&status[KDS_DBG4], (kd_u64)c_cplx); atomicAdd(&status[KDS_DBG5], (kd_u64)c_wait);
-        atomicAdd(&status[KDS_DBG6], (kd_u64)c_flush); atomicAdd(&status[KDS_DBG7], 1ULL);
-    }
-#endif
+    KD_PHASE_COMMIT(status, ROWS)
 }

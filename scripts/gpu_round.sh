@@ -16,11 +16,12 @@ for st in "$@"; do
     pmc:*) spec=${st#pmc:}; cfg=${spec%%:*}; extra=""; tag=$cfg; case $spec in *:shuffle) extra="--shuffle"; tag=${cfg}_shuffle;; esac
            BENCH_ARGS="--config $cfg $extra" PMC_TAG=$tag bash scripts/gpu_pmc.sh 2>&1 | tail -8 ;;
     proj) for c in ${PROJ_CONFIGS:-C3 C4}; do timeout 900 python scripts/strong_projection.py --config $c --tunings "${PROJ_TUNINGS:-0:0}" --out $O/strong_projection_$c.json > /dev/null 2> $O/proj_$c.err; echo "$c rc=$?"; done ;;
-    sweep) T="0:0,448:256,448:512,448:1024,448:2048,256:256,256:512,256:1024,192:256,192:512,192:1024,128:256,128:512,64:256,64:512"
+    sweep) T="${SWEEP_TUNINGS:-0:0,448:512,448:1024,448:2048,448:4096,256:512,256:1024,256:2048,192:512,192:1024,192:2048,128:512,128:1024,128:4096,64:1024}"
            timeout 600 python scripts/strong_projection.py --config C3 --ranks 8 --only-rank 3 --tunings "$T" --out $O/sweep_C3_rank3of8.json > /dev/null 2> $O/sweep_c3.err; echo "c3/8 rc=$?"
            timeout 600 python scripts/strong_projection.py --config C4 --ranks 8 --only-rank 3 --tunings "$T" --out $O/sweep_C4_rank3of8.json > /dev/null 2> $O/sweep_c4.err; echo "c4/8 rc=$?"
            timeout 600 python scripts/strong_projection.py --config C2 --ranks 1 --tunings "$T" --out $O/sweep_C2.json > /dev/null 2> $O/sweep_c2.err; echo "c2 rc=$?"
-           for pp in 4 8 16 32 64; do KD_PREP_PER=$pp timeout 600 python scripts/strong_projection.py --config C3 --ranks 8 --only-rank 3 --out $O/sweep_C3_rank3of8_prep$pp.json > /dev/null 2>> $O/sweep_c3.err; done ;;
+           timeout 600 python scripts/strong_projection.py --config C5 --ranks 1 --tunings "$T" --out $O/sweep_C5.json > /dev/null 2> $O/sweep_c5.err; echo "c5 rc=$?" ;;
+    sweep_prep) for pp in 4 8 16 32 64; do KD_PREP_PER=$pp timeout 600 python scripts/strong_projection.py --config C3 --ranks 8 --only-rank 3 --out $O/sweep_C3_rank3of8_prep$pp.json > /dev/null 2>> $O/sweep_c3.err; done ;;
     timeline) bash scripts/gpu_timeline.sh 2>&1 | tail -3 ;;
     e2e) timeout 900 python scripts/e2e_bench.py --scale 1.0 --repeat 3 --out $O/e2e_c3_full_phred.json > /dev/null 2> $O/e2e.err; tail -c 400 $O/e2e_c3_full_phred.json ;;
     multirank) bash scripts/gpu_multirank.sh 2>&1 | tail -12 ;;

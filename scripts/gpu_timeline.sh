@@ -1,7 +1,7 @@
 #!/bin/bash
 # one bench step as a dispatch timeline (rocprofv3 --kernel-trace): kernel, start offset, duration, idle gap before it
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; mkdir -p $O; rm -rf $O/tl
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/tl -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > $O/tl_bench.json 2> $O/tl.err)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/tl -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} --no-graph --e2e-scale 0 > $O/tl_bench.json 2> $O/tl.err)
 python - <<PY
 import csv, glob
 rows=[]
