@@ -277,10 +277,6 @@ int kd_bgzf_plan_view(const kd_bgzf_plan *p, const uint8_t **file, uint64_t *fil
 void kd_bgzf_plan_close(kd_bgzf_plan *p);
 int kd_push_bam_gpu(kd_ctx *ctx, const kd_bgzf_plan *plan, uint64_t stats[8]);
 
-/* ---- tool: write a host batch as a BGZF-compressed BAM (synthetic inputs for end-to-end runs; parallel deflate) ---- */
-int kd_write_bam(const char *path, const kd_batch *host_batch, uint32_t n_contigs, const char *const *names,
-                 const uint32_t *lens, const char *sort_order, int n_threads, int level);
-
 /* ---- streaming ingest: the record iteration of parse_bam (kindel.py:143-145) without holding the whole file -------- */
 
 typedef struct kd_stream kd_stream;

@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "kd_profile_enable kd_profile_get kd_profile_reset kd_decode_open kd_decode_batch kd_decode_n_contigs "
     "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error "
     "kd_stream_open kd_stream_n_contigs kd_stream_contig_name kd_stream_contig_len kd_stream_next kd_stream_n_records "
-    "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_write_bam kd_host_threads kd_host_inflate kd_host_crc32 "
+    "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_host_threads kd_host_inflate kd_host_crc32 "
     "kd_bgzf_index kd_decode_open_span kd_step kd_finish kd_set_step_graph kd_bgzf_plan_open kd_bgzf_plan_n_contigs kd_bgzf_plan_contig_name kd_bgzf_plan_contig_len "
     "kd_bgzf_plan_view kd_bgzf_plan_close kd_push_bam_gpu"
 ).split()
@@ -149,7 +149,6 @@ class Library:
         L.kd_push_stream.argtypes = [p, p, C.POINTER(u64)]
         L.kd_decode_push_file.argtypes = [p, C.c_char_p, C.c_int, u64, C.POINTER(u64)]
         L.kd_get_contig_first.argtypes = [p, p]
-        L.kd_write_bam.argtypes = [C.c_char_p, C.POINTER(kd_batch), u32, C.POINTER(C.c_char_p), p, C.c_char_p, C.c_int, C.c_int]
         if L.kd_abi_version() != 1:
             raise ImportError("kindel_amd: ABI version mismatch in %s" % path)
 
@@ -237,9 +236,26 @@ class Stream:
     __del__ = close
 
 
+_tools = None
+
+
+def tools_library():
+    """TEST / BENCH TOOLS (tools/libkindel_tools.so: the BAM writer), built by __graft_entry__.build(); not the product library."""
+    global _tools
+    if _tools is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "libkindel_tools.so")
+        if not os.path.exists(path):
+            raise ImportError("%s not built: python -c 'import __graft_entry__ as g; g.build()'" % path)
+        _tools = C.CDLL(path)
+        _tools.kd_write_bam.argtypes = [C.c_char_p, C.POINTER(kd_batch), C.c_uint32, C.POINTER(C.c_char_p), C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+        _tools.kd_tools_last_error.restype = C.c_char_p
+    return _tools
+
+
 def write_bam(path, batch, names=None, sort_order="coordinate", threads=0, level=1, lib=None):
-    """Host batch (dict of numpy arrays) -> BGZF-compressed BAM through the native writer (parallel deflate)."""
-    lib = lib or default_library()
+    """Host batch (dict of numpy arrays) -> BGZF-compressed BAM through the native writer of the TOOLS library (parallel deflate;
+    test / bench inputs).  `lib` is ignored (kept for the callers that pass the product / emulator library around)."""
+    dll = tools_library()
     arrs = {name: np.ascontiguousarray(batch[name], dt) for name, dt in _BATCH_FIELDS}
     b = kd_batch()
     b.n_reads = len(arrs["contig"])
@@ -249,9 +265,9 @@ def write_bam(path, batch, names=None, sort_order="coordinate", threads=0, level
     lens = np.ascontiguousarray(batch["contig_lens"], np.uint32)
     names = [str(x) for x in (names if names is not None else batch.get("contig_names", ["ctg%d" % i for i in range(len(lens))]))]
     cnames = (C.c_char_p * max(len(names), 1))(*[n.encode() for n in names])
-    rc = lib.dll.kd_write_bam(os.fsencode(str(path)), C.byref(b), len(lens), cnames, _ptr(lens), sort_order.encode(), int(threads), int(level))
+    rc = dll.kd_write_bam(os.fsencode(str(path)), C.byref(b), len(lens), cnames, _ptr(lens), sort_order.encode(), int(threads), int(level))
     if rc:
-        raise _EXC.get(rc, KindelNativeError)("%s: %s" % (path, lib.dll.kd_decode_last_error().decode()))
+        raise _EXC.get(rc, KindelNativeError)("%s: %s" % (path, dll.kd_tools_last_error().decode()))
 
 
 def host_threads(lib=None):

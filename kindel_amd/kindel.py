@@ -15,6 +15,14 @@ Same function names, arguments, defaults, return shapes and exceptions as
 
 The record loop and the per-site loop run in kindel_amd/csrc/kd_kernels.h on the GPU through
 the C-ABI (kindel_amd/_native.py).  There is no CPU implementation of either loop here.
+
+Attribution.  This module is an interface mirror of bede/kindel (GPLv3, (c) Bede Constantinides).  Most of it is a new
+implementation behind the same names (the CDR / --realign scans are vectorised numpy re-derivations, the tables come from
+the device).  Three small pieces necessarily follow the reference line by line, because their OUTPUT must be identical to the
+byte or to the float and so leaves no room to differ: ``consensus()`` (:369-381, six lines), the REPORT text of
+``_report`` / ``build_report`` (:437-485, its wording, field order and separators), and the pandas tail of ``weights()``
+(:586-630: column names, their order, the rounding and the Jeffreys-interval call).  The warning text of ``merge_cdrps`` is the
+reference's for the same reason.  Those lines are derived from the GPLv3 reference and are marked where they stand.
 """
 import logging
 import os
@@ -418,7 +426,7 @@ def merge_cdrps(cdrps, min_overlap):
 # --------------------------------------------------------------------------------------
 # consensus
 # --------------------------------------------------------------------------------------
-def consensus(weight):
+def consensus(weight):   # (follows kindel.py:369-381 line by line: see the module header)
     """Returns tuple of consensus base, weight and flag indicating a tie for consensus (kindel.py:369-381)"""
     base, frequency = max(weight.items(), key=lambda x: x[1]) if sum(weight.values()) else ("N", 0)
     weight_sans_consensus = {k: d for k, d in weight.items() if k != base}
