@@ -127,7 +127,10 @@ int kd_set_shard(kd_ctx *ctx, uint64_t g_lo, uint64_t g_hi);
 int kd_push_batch(kd_ctx *ctx, const kd_batch *host_batch);
 /* Same, but every pointer in *dev_batch is a DEVICE pointer on ctx's GPU (inputs already
  * resident in HBM); the arrays must stay valid until the next kd_sync/kd_finalize.  seq4 must be
- * 16-byte aligned with 16 readable bytes past seq4_bytes (the kernels stage bases with 16-byte loads). */
+ * 16-byte aligned with 16 readable bytes past seq4_bytes (the kernels stage bases with 16-byte loads).
+ * The library launches on a stream of its own: whatever produces the arrays (another stream's kernels or
+ * copies) must have COMPLETED when the call is made (hipStreamSynchronize / torch.cuda.synchronize) --
+ * the kernels follow cig_off / seq_off as they find them. */
 int kd_push_batch_device(kd_ctx *ctx, const kd_batch *dev_batch);
 int kd_sync(kd_ctx *ctx);
 

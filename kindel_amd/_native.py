@@ -507,7 +507,8 @@ class Engine:
         self._check(self.lib.dll.kd_push_batch(self._h, C.byref(b)), "kd_push_batch")
 
     def push_device(self, ptrs, n_reads, seq4_bytes, cigar_words):
-        """Device-resident batch: ptrs maps field name -> device address (e.g. tensor.data_ptr())."""
+        """Device-resident batch: ptrs maps field name -> device address (e.g. tensor.data_ptr()).  The library runs on its own
+        stream: the arrays must be complete (torch.cuda.synchronize() after the kernels that wrote them) when this is called."""
         b = self._struct(ptrs, n_reads)
         b.seq4_bytes, b.cigar_words = seq4_bytes, cigar_words
         self._check(self.lib.dll.kd_push_batch_device(self._h, C.byref(b)), "kd_push_batch_device")

@@ -393,20 +393,32 @@ struct KdEngine {
                 const bool use_coop = want_coop && KD_COOP_LDS_BYTES(KD_COOP_PITCH(W)) <= (size_t)160 * 1024 - 1024;
                 uint32_t w0;
                 const uint32_t n_win = windows_of(W, w0);
-                uint32_t slice = slice_cfg;
-                if (!slice) {  // aim for a few thousand work items, slices big enough to amortise the LDS flush
-                    uint64_t s = ne / 4096;
-                    slice = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(256, s));
-                }
-                slice = std::min<uint32_t>(slice, 32768u);   // u16 LDS counters: an item may not tally more reads than that
-                const uint32_t *order = nullptr;
-                const KdRInfo *walk_info = info;      // what k_window walks: the entries themselves, or their window-sorted copy
-                KdReads walk_R = R;
                 // the histogram reaches H sites past the window: an entry is tallied whole by the window it starts in (kd_window.h:
                 // OWNERSHIP); H = the longest footprint of this pass's entries, up to 256 sites (longer ones leave a remainder)
                 // (a row is thousands of sites long: every window tallies its own part of it, H = 0)
                 uint32_t H = (use_coop || rows) ? 0u : (uint32_t)std::min<uint64_t>(256, (h_status[span_slot] + 63) & ~uint64_t(63));
                 while (H && KD_WINDOW_LDS_BYTES((W + H + 2 * KD_HALO) / 2) > (size_t)160 * 1024 - 1024) H -= 64;   // (a hand-picked window near the LDS limit)
+                const uint32_t Wh = (W + H + 2 * KD_HALO) / 2;   // dwords per channel row
+                const size_t win_lds = KD_WINDOW_LDS_BYTES(Wh);
+                const unsigned win_grid = std::max(1u, (unsigned)rt.n_cus() * (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (win_lds + 64))));
+                uint32_t slice = slice_cfg;
+                if (!slice && use_coop) slice = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(256, ne / 4096));   // (planned queue: a few thousand items)
+                if (!slice) {
+                    // A work item = one zeroing + one flush of the window's histogram, whatever it tallies in between: every slice
+                    // a window is cut into repeats both (measured, 1/8 of C3: 3 - 4 slices per window 1.00 ms, one 0.19 ms).  So: a
+                    // window is ONE item unless it holds several times the average (a hot spot: cut, so that helpers can share it)
+                    // -- except when there are several resident workgroups per window (a deep small genome: C2 is 23 windows of
+                    // 29 000 reads): then the windows are cut into about one item per workgroup.
+                    const uint64_t avg = rows ? 0 : ne / std::max<uint32_t>(n_win, 1u) + 1;     // (rows: an entry is a candidate of many windows; their depth is what matters: 4096)
+                    const uint64_t cut = win_grid / std::max<uint32_t>(n_win, 1u);     // workgroups per window (rounded down: 1.5 is not worth a second flush)
+                    if (rows) slice = 4096u;
+                    else if (cut <= 1) slice = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(1024, 4 * avg));
+                    else slice = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(256, avg / cut));
+                }
+                slice = std::min<uint32_t>(slice, 32768u);   // u16 LDS counters: an item may not tally more reads than that
+                const uint32_t *order = nullptr;
+                const KdRInfo *walk_info = info;      // what k_window walks: the entries themselves, or their window-sorted copy
+                KdReads walk_R = R;
                 KdWq Q;       // k_window plans for itself (kd_window.h): the boundary table its ranges come from
                 Q.bound32 = (const uint32_t *)b_bound.p; Q.bound64 = nullptr; Q.gran = 64u; Q.reps = 1u; Q.nb = (uint32_t)(S / 64);
                 Q.n_win = n_win; Q.span_slot = span_slot; Q.hot = nullptr;
@@ -480,10 +492,8 @@ struct KdEngine {
                     // k_window: self-planned queue -- nothing but the list of windows with more than one slice to allocate
                     if ((rc2 = ensure(b_hot, (size_t)n_win * sizeof(KdHot)))) return rc2;
                     Q.hot = (KdHot *)b_hot.p;
-                    const uint32_t Wh = (W + H + 2 * KD_HALO) / 2;   // dwords per channel row
-                    const size_t lds = KD_WINDOW_LDS_BYTES(Wh);
-                    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (lds + 64)));
-                    const unsigned grid = std::max(1u, (unsigned)rt.n_cus() * per_cu);
+                    const size_t lds = win_lds;
+                    const unsigned grid = win_grid;
                     if (rows) {
                         walk_R.seq4 = (const uint8_t *)b_rows.p; walk_R.seq_off = (const kd_u64 *)b_rowoff.p;
                         walk_R.cig_off = nullptr; walk_R.n_cig = nullptr; walk_R.osh = 0;

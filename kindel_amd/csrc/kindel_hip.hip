@@ -185,8 +185,11 @@ struct HipRt {
             if (bad(hipEventCreate(&p.a)) || bad(hipEventCreate(&p.b))) return 1;
             if (bad(hipEventRecord(p.a, stream))) return 1;
         }
+        static const bool trace = getenv("KD_LAUNCH_TRACE") != nullptr;   // (knob: fault localisation -- name, geometry, then wait for the kernel)
+        if (trace && !capturing) fprintf(stderr, "[kd] %s grid %u block %u lds %zu\n", name, grid, block, shmem);
         k<<<dim3(grid), dim3(block), shmem, stream>>>(args...);
         if (bad(hipGetLastError())) return 1;
+        if (trace && !capturing && bad(hipStreamSynchronize(stream))) return 1;
         if (timed) {
             if (bad(hipEventRecord(p.b, stream))) return 1;
             p.name = name;

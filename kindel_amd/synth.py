@@ -346,7 +346,10 @@ def to_numpy(batch):
 
 
 def device_ptrs(batch):
-    """field -> device address, for kd_push_batch_device"""
+    """field -> device address, for kd_push_batch_device.  The library launches on its own stream (include/kindel_hip.h): the
+    torch kernels that wrote the arrays are waited for here, so that what the addresses point at is complete."""
+    if batch["contig"].is_cuda:
+        torch.cuda.synchronize(batch["contig"].device)
     return {k: batch[k].data_ptr() for k in FIELDS}
 
 

@@ -1,13 +1,14 @@
 #!/bin/bash
 # Round driver on one MI355X (through gpurun): `bash scripts/gpu_round.sh STAGE...`, results under gpurun_out/ (scratch; the
 # judged summaries are copied into profiles/ by scripts/harvest_profiles.py).  Stages:
-#   smoke  tests  bench  cfg  shuf  prof  pmc:<CONFIG>[:shuffle]  proj  sweep  timeline  e2e  multirank
+#   smoke  tests  test1 (TEST1_ARGS: one selection, output shown)  bench  cfg  shuf  prof  pmc:<CONFIG>[:shuffle]  proj  sweep  timeline  e2e  multirank
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; mkdir -p $O
 for st in "$@"; do
   echo "== $st"
   case $st in
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ;;
     tests) timeout 1500 python -m pytest tests -m gpu -q --maxfail=8 -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log ;;
+    test1) timeout ${TEST1_TIMEOUT:-600} python -m pytest tests -m gpu -q -x -s -p no:cacheprovider ${TEST1_ARGS:-} > $O/pytest_test1.log 2>&1; echo "test1 rc=$?"; tail -${TEST1_TAIL:-30} $O/pytest_test1.log | cut -c1-400 ;;
     bench) timeout 900 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err; echo "bench rc=$?"; tail -2 $O/bench_c3.err ;;
     cfg) for c in ${CONFIGS:-C2 C4 C5}; do timeout 600 python bench.py --config $c --steps 10 --warmup 3 --e2e-scale 0 > $O/bench_$c.json 2> $O/bench_$c.err; echo "$c rc=$?"; done ;;
     shuf) timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --shuffle > $O/exp_shuf.json 2> $O/exp_shuf.err; echo "rc=$?"

@@ -141,6 +141,7 @@ def test_unsorted_input_at_scale(hip_lib, monkeypatch, cfg, layout, sort):
     tb = synth.make("C3", device="cuda:0") if cfg == "C3" else SYN[cfg]("cuda:0")
     sh = synth.shuffled(tb, mode=layout, seed=7)
     del tb
+    torch.cuda.synchronize()     # (the library launches on its own stream: the permuted arrays must be complete, include/kindel_hip.h)
     eng = N.Engine(sh["contig_lens"], lib=hip_lib)
     eng.push_device(synth.device_ptrs(sh), sh["contig"].numel(), sh["seq4_bytes"], sh["cigar_words"])
     info = eng.batch_info()
