@@ -355,7 +355,7 @@ struct RangePlan {
 // Does d[q, n) begin with a well-formed BAM record (block_size, refID, pos, l_read_name, the lengths adding up, the read name
 // NUL-terminated)?  -> the offset of the record behind it, 0 if not, or KD_REC_UNKNOWN when too little of the record lies in front of n
 // to tell.  The speculative record starts of the parallel walk (below) and of a span of a file (kd_decode_open_span) use it.
-constexpr size_t KD_REC_EDGE = 4 + 32 + 255 + 8, KD_REC_UNKNOWN = ~(size_t)0;
+constexpr size_t KD_REC_UNKNOWN = ~(size_t)0;
 constexpr int KD_SPEC_CHAIN = 16;
 inline size_t bam_record_plausible(const uint8_t *d, size_t n, size_t q, uint32_t n_ref) {
     if (q + 36 > n) return KD_REC_UNKNOWN;

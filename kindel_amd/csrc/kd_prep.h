@@ -287,7 +287,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
             // regular: decided by the sums, footprint and length within what the window kernels index with
             const uint32_t reg = (scanned && inside && s.span <= 0x07ffffffULL && sl < KD_COLD_MAX_SEQ) ? 1u : 0u;
             const uint32_t defer = (scanned && !inside) ? 1u : 0u;                     // the exact scan decides, behind the loop
-            const uint32_t irr = star | (scanned & (reg | defer) ^ scanned);            // scanned, inside, but too long / too wide
+            const uint32_t irr = star | ((scanned & (reg | defer)) ^ scanned);            // scanned, inside, but too long / too wide
             const uint32_t counted = scanned & (defer ^ 1u);                           // its counts are the sums'
             a_reads += (skip ^ 1u) & (defer ^ 1u);
             a_aligned += counted ? s.aligned : 0ULL; a_walked += counted ? s.walked : 0ULL;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round driver on one MI355X (through gpurun): `bash scripts/gpu_round.sh STAGE...`, results under gpurun_out/ (scratch; the
 # judged summaries are copied into profiles/ by scripts/harvest_profiles.py).  Stages:
-#   smoke  tests  test1 (TEST1_ARGS: one selection, output shown)  bench  cfg  shuf  prof  pmc:<CONFIG>[:shuffle]  proj  sweep  timeline  e2e  multirank
+#   smoke  tests  test1 (TEST1_ARGS: one selection, output shown)  variants  fetch  bench  cfg  shuf  prof  pmc:<CONFIG>[:shuffle]  proj  sweep  timeline  e2e  multirank
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; mkdir -p $O
 for st in "$@"; do
   echo "== $st"
@@ -9,6 +9,26 @@ for st in "$@"; do
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ;;
     tests) timeout 1500 python -m pytest tests -m gpu -q --maxfail=8 -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log ;;
     test1) timeout ${TEST1_TIMEOUT:-600} python -m pytest tests -m gpu -q -x -s -p no:cacheprovider ${TEST1_ARGS:-} > $O/pytest_test1.log 2>&1; echo "test1 rc=$?"; tail -${TEST1_TAIL:-30} $O/pytest_test1.log | cut -c1-400 ;;
+    variants) # VARIANTS="name ..." (exp/libkd_<name>.so; "-" = the product), VARIANT_ARGS = bench arguments: k_window / step time of each
+          for v in ${VARIANTS:--}; do lib=""; [ "$v" != "-" ] && lib=$R/exp/libkd_$v.so
+            KD_BENCH_LIB=$lib timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --e2e-scale 0 ${VARIANT_ARGS:-} > $O/var_$v.json 2> $O/var_$v.err
+            python -c "import json,sys; d=[json.loads(l) for l in open('$O/var_$v.json') if l.startswith('{\"metric')][-1]; print('$v', '%.4f ms'%d['ms_per_step'], {k: x['avg_ms'] for k, x in d['kernels'].items() if k in ('k_window','k_prep','k_cold_lane','k_window_rows','k_long_expand')}, d.get('fasta_sha256','')[:12])" || tail -3 $O/var_$v.err
+          done ;;
+    fetch) # FETCH_SIZE / WRITE_SIZE per launch of the same variants (one rocprofv3 --pmc pass each)
+          for v in ${VARIANTS:--}; do lib=""; [ "$v" != "-" ] && lib=$R/exp/libkd_$v.so
+            for c in FETCH_SIZE WRITE_SIZE; do rm -rf $O/fetch_${v}_$c
+              (cd /tmp && KD_BENCH_LIB=$lib timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/fetch_${v}_$c -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --e2e-scale 0 ${VARIANT_ARGS:-} > /dev/null 2> $O/fetch_${v}_$c.err)
+              python - <<PY
+import csv, glob, collections
+fs = glob.glob("$O/fetch_${v}_$c/**/*counter_collection.csv", recursive=True)
+acc = collections.defaultdict(float); ids = collections.defaultdict(set)
+for f in fs:
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:24]
+        if k.startswith("k_"): acc[k] += float(r["Counter_Value"]); ids[k].add(r["Dispatch_Id"])
+print("$v $c", {k: "%.4g" % (acc[k] / len(ids[k])) for k in sorted(acc, key=lambda k: -acc[k])[:5]})
+PY
+            done; done ;;
     bench) timeout 900 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err; echo "bench rc=$?"; tail -2 $O/bench_c3.err ;;
     cfg) for c in ${CONFIGS:-C2 C4 C5}; do timeout 600 python bench.py --config $c --steps 10 --warmup 3 --e2e-scale 0 > $O/bench_$c.json 2> $O/bench_$c.err; echo "$c rc=$?"; done ;;
     shuf) timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --shuffle > $O/exp_shuf.json 2> $O/exp_shuf.err; echo "rc=$?"

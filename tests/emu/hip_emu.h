@@ -184,13 +184,19 @@ static inline uint32_t kd_wave_scan_max(uint32_t v) {   // running maximum over 
     emu_wave_meet();
     return r;
 }
-// v_perm_b32: byte i of the result = byte sel.byte[i] of {hi (bytes 4-7), lo (bytes 0-3)} (selectors 0-7 only)
+// v_perm_b32: byte i of the result = byte sel.byte[i] of {hi (bytes 4-7), lo (bytes 0-3)} for selectors 0-7; selector 0x0c = the
+// constant 0x00, 0x0d and above = 0xff (the sign-replicating selectors 8-11 are not used by the kernels)
 static inline uint32_t kd_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
     const unsigned long long src = ((unsigned long long)hi << 32) | lo;
     uint32_t r = 0;
-    for (int i = 0; i < 4; i++) r |= (uint32_t)((src >> (8 * ((sel >> (8 * i)) & 7u))) & 0xffu) << (8 * i);
+    for (int i = 0; i < 4; i++) {
+        const uint32_t sb = (sel >> (8 * i)) & 0xffu;
+        const uint32_t byte = sb < 8u ? (uint32_t)((src >> (8 * sb)) & 0xffu) : sb == 0x0cu ? 0u : sb > 0x0cu ? 0xffu : (abort(), 0u);
+        r |= byte << (8 * i);
+    }
     return r;
 }
+static inline uint32_t kd_opaque(uint32_t x) { return x; }
 // v_alignbyte_b32: ({hi, lo} >> 8 * (sh & 3)) [31:0]
 static inline uint32_t kd_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
     return (uint32_t)(((((unsigned long long)hi) << 32) | lo) >> (8 * (sh & 3u)));
