@@ -401,19 +401,21 @@ struct KdEngine {
                 const uint32_t Wh = (W + H + 2 * KD_HALO) / 2;   // dwords per channel row
                 const size_t win_lds = KD_WINDOW_LDS_BYTES(Wh);
                 const unsigned win_grid = std::max(1u, (unsigned)rt.n_cus() * (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (win_lds + 64))));
-                uint32_t slice = slice_cfg;
+                uint32_t slice = slice_cfg, static_cut = 0;
                 if (!slice && use_coop) slice = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(256, ne / 4096));   // (planned queue: a few thousand items)
+                // A work item = one zeroing + one flush of the window's histogram, whatever it tallies in between: every slice
+                // a window is cut into repeats both (measured, 1/8 of C3: 3 - 4 slices per window 1.00 ms, one 0.19 ms).  So: a
+                // window is ONE item unless it holds several times the average (a hot spot: cut, so that helpers can share it)
+                // -- except when there are several resident workgroups per window (a deep small genome: C2 is 23 windows of
+                // 29 000 reads): then every workgroup takes an equal part of its window (the STATIC queue of kd_window.h: parts of
+                // 256 reads or more, tallied in pieces of `slice`: the u16 counters' limit, i.e. one piece unless a test asks).
+                const uint64_t avg = rows ? 0 : ne / std::max<uint32_t>(n_win, 1u) + 1;     // (rows: an entry is a candidate of many windows; their depth is what matters: 4096)
+                const uint64_t cut = win_grid / std::max<uint32_t>(n_win, 1u);     // workgroups per window (rounded down: 1.5 is not worth a second flush)
+                if (!rows && !use_coop && cut >= 2) static_cut = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cut, avg / 256));
                 if (!slice) {
-                    // A work item = one zeroing + one flush of the window's histogram, whatever it tallies in between: every slice
-                    // a window is cut into repeats both (measured, 1/8 of C3: 3 - 4 slices per window 1.00 ms, one 0.19 ms).  So: a
-                    // window is ONE item unless it holds several times the average (a hot spot: cut, so that helpers can share it)
-                    // -- except when there are several resident workgroups per window (a deep small genome: C2 is 23 windows of
-                    // 29 000 reads): then the windows are cut into about one item per workgroup.
-                    const uint64_t avg = rows ? 0 : ne / std::max<uint32_t>(n_win, 1u) + 1;     // (rows: an entry is a candidate of many windows; their depth is what matters: 4096)
-                    const uint64_t cut = win_grid / std::max<uint32_t>(n_win, 1u);     // workgroups per window (rounded down: 1.5 is not worth a second flush)
                     if (rows) slice = 4096u;
                     else if (cut <= 1) slice = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(1024, 4 * avg));
-                    else slice = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(256, avg / cut));
+                    else slice = 32768u;
                 }
                 slice = std::min<uint32_t>(slice, 32768u);   // u16 LDS counters: an item may not tally more reads than that
                 const uint32_t *order = nullptr;
@@ -421,7 +423,7 @@ struct KdEngine {
                 KdReads walk_R = R;
                 KdWq Q;       // k_window plans for itself (kd_window.h): the boundary table its ranges come from
                 Q.bound32 = (const uint32_t *)b_bound.p; Q.bound64 = nullptr; Q.gran = 64u; Q.reps = 1u; Q.nb = (uint32_t)(S / 64);
-                Q.n_win = n_win; Q.span_slot = span_slot; Q.hot = nullptr;
+                Q.n_win = n_win; Q.span_slot = span_slot; Q.hot = nullptr; Q.cut = static_cut >= 2 ? static_cut : 0u;
                 if (in_order) {
                     if (use_coop && rt.launch("k_plan_ranges", k_plan_ranges, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, info, (kd_u64)ne, w0,
                                   n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status, span_slot == (uint32_t)KDS_B_MAXSPAN ? H : 0u))

@@ -472,6 +472,7 @@ struct KdWq {
     uint32_t nb;               // last valid index of the table (= its entry for "behind the last site")
     KdHot *hot;                // [n_win]
     uint32_t n_win, span_slot;
+    uint32_t cut;              // > 0: STATIC queue -- workgroup b tallies part (b mod cut) of window (b / cut), see k_window
 };
 __device__ __forceinline__ kd_u64 kd_wq_bound(const KdWq &Q, kd_u64 j) {
     j = j < Q.nb ? j : Q.nb;
@@ -534,6 +535,29 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
         if (t == 0) {
             uint32_t w = NONE, k = 0;
             kd_u64 lo = 0, hi = 0;
+            if (Q.cut) {
+                // STATIC queue (round 4): few windows, many workgroups (a deep small genome: C2 is 23 windows of 29 000 reads on
+                // 1280 workgroups).  The hot list below served it -- and its wavefronts spent 47 % of their clocks in this loop
+                // (phase clocks, profiles/r04_kwindow_experiments.json): 1280 tickets for 23 windows, everybody polling the
+                // publication count, one contended counter per window.  With `cut` workgroups per window nothing needs to be
+                // negotiated: workgroup b takes part (b mod cut) of window (b / cut) -- its candidate range from the boundary
+                // table, cut evenly -- in pieces of at most `slice` (u16 counters), and leaves.
+                if (q_state == 0) {
+                    q_state = 3;
+                    const uint32_t b = blockIdx.x;
+                    if (b < Q.n_win * Q.cut) {
+                        kd_wq_range(Q, status, w0, b / Q.cut, W, H, lo, hi);
+                        const kd_u64 part = (((hi - lo + Q.cut - 1) / Q.cut) + 63) & ~(kd_u64)63;
+                        const kd_u64 a = lo + (kd_u64)(b % Q.cut) * part;
+                        q_hot_w = b / Q.cut; q_hot_lo = a < hi ? a : hi; q_hot_hi = a + part < hi ? a + part : hi;
+                        if (b == 0) atomicAdd(&status[KDS_TOTAL_ITEMS], (kd_u64)Q.n_win * (Q.cut - 1u));      // (statistics: kd_get_batch_info)
+                    }
+                }
+                if (q_hot_w != NONE && q_hot_lo < q_hot_hi) {
+                    w = q_hot_w; lo = q_hot_lo; hi = q_hot_hi; k = 0;    // [lo, min(lo + slice, hi)) now, the rest on the next visit
+                    q_hot_lo = lo + slice < hi ? lo + slice : hi;
+                }
+            } else
             for (;;) {
                 if (q_hot_w != NONE) {                   // a window with several slices: the next one nobody has taken
                     k = atomicAdd(&Q.hot[q_hot_j].next, 1u);

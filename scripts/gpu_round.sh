@@ -28,12 +28,14 @@ for f in fs:
         if k.startswith("k_"): acc[k] += float(r["Counter_Value"]); ids[k].add(r["Dispatch_Id"])
 print("$v $c", {k: "%.4g" % (acc[k] / len(ids[k])) for k in sorted(acc, key=lambda k: -acc[k])[:5]})
 PY
+              rm -rf $O/fetch_${v}_$c
             done; done ;;
     bench) timeout 900 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err; echo "bench rc=$?"; tail -2 $O/bench_c3.err ;;
     cfg) for c in ${CONFIGS:-C2 C4 C5}; do timeout 600 python bench.py --config $c --steps 10 --warmup 3 --e2e-scale 0 > $O/bench_$c.json 2> $O/bench_$c.err; echo "$c rc=$?"; done ;;
     shuf) timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --shuffle > $O/exp_shuf.json 2> $O/exp_shuf.err; echo "rc=$?"
           KD_SORT_GLOBAL=1 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --shuffle > $O/exp_shuf_global.json 2> $O/exp_shuf_global.err ;;
-    prof) rm -rf $O/prof_c3; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python $R/bench.py --no-cpu-baseline > $O/prof_c3_bench.json 2> $O/prof_c3.err); echo "rc=$?" ;;
+    prof) rm -rf $O/prof_c3; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python $R/bench.py --no-cpu-baseline > $O/prof_c3_bench.json 2> $O/prof_c3.err); echo "rc=$?"
+          find $O/prof_c3 -type f ! -name "*kernel_stats.csv" -delete ;;      # (the per-dispatch trace is tens of MB: the merge back is capped at 64 MiB)
     pmc:*) spec=${st#pmc:}; cfg=${spec%%:*}; extra=""; tag=$cfg; case $spec in *:shuffle) extra="--shuffle"; tag=${cfg}_shuffle;; esac
            BENCH_ARGS="--config $cfg $extra" PMC_TAG=$tag bash scripts/gpu_pmc.sh 2>&1 | tail -8 ;;
     proj) for c in ${PROJ_CONFIGS:-C3 C4}; do timeout 900 python scripts/strong_projection.py --config $c --tunings "${PROJ_TUNINGS:-0:0}" --out $O/strong_projection_$c.json > /dev/null 2> $O/proj_$c.err; echo "$c rc=$?"; done ;;

@@ -2,7 +2,7 @@
 # one bench step as a dispatch timeline (rocprofv3 --kernel-trace): kernel, start offset, duration, idle gap before it
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; mkdir -p $O; rm -rf $O/tl
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/tl -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} --no-graph --e2e-scale 0 > $O/tl_bench.json 2> $O/tl.err)
-python - <<PY
+python - <<PY | tee $O/step_timeline.txt
 import csv, glob
 rows=[]
 for f in glob.glob("$O/tl/**/*kernel_trace.csv", recursive=True):
@@ -25,3 +25,4 @@ for s,e,n in rows[j:]:
     prev=max(prev or e,e); tot_busy+=(e-s)/1e3
 print("span %.1f us busy %.1f us"%((prev-t0)/1e3,tot_busy))
 PY
+rm -rf $O/tl

@@ -20,6 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+# files older than this many hours are another round's leftovers (gpurun_out/ is merged into, never cleaned)
+newer_than = __import__("time").time() - 3600.0 * float(sys.argv[2] if len(sys.argv) > 2 else 6)
 
 
 def first_json_line(path):
@@ -44,39 +46,57 @@ for src, dst in (("bench_c3.json", "%s_c3_bench.json"), ("prof_c3_bench.json", "
                  ("bench_C2.json", "%s_C2_bench.json"), ("bench_C4.json", "%s_C4_bench.json"), ("bench_C5.json", "%s_C5_bench.json"),
                  ("exp_strip.json", "%s_c3_bench_mode_strip.json"), ("exp_shuf.json", "%s_c3_bench_shuffled.json")):
     p = os.path.join(O, src)
-    if os.path.exists(p):
+    if os.path.exists(p) and os.path.getmtime(p) > newer_than:
         json.dump(first_json_line(p), open(os.path.join(P, dst % tag), "w"), indent=1, sort_keys=True)
 
-acc = collections.defaultdict(lambda: collections.defaultdict(float))
-ndisp = collections.defaultdict(set)
-for i in (1, 2, 3, 4):
-    for f in sorted(glob.glob(os.path.join(O, "pmc_%d" % i, "**", "*counter_collection.csv"), recursive=True),
-                    key=os.path.getmtime, reverse=True)[:1]:   # the newest run only (gpurun merges, it does not delete)
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
-            k = k[5:] if k.startswith("void ") else k          # templated kernels: "void k_window<false>(...)"
-            k = {"k_window<false>": "k_window", "k_window<true>": "k_window_rows"}.get(k, k.split("<")[0])
-            if not k.startswith("k_"):
-                continue
-            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            ndisp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
-per = {k: {c: v / max(len(ndisp[(k, c)]), 1) for c, v in cs.items()} for k, cs in acc.items()}
-if per:
-    json.dump(per, open(os.path.join(P, "%s_c3_pmc_per_dispatch.json" % tag), "w"), indent=1, sort_keys=True)
-    note = ("(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch.  The factors are calibrated on this GPU in the kernels' own access patterns "
-            "(profiles/fetch_calibration.json, scripts/fetch_calib.hip: a 2 GiB buffer touched exactly once): FETCH_SIZE counts half "
-            "the bytes (x2.00 for coalesced 8- and 16-byte streams; k_window's per-lane unaligned 16-byte loads over 75-byte records "
-            "fetch 1.30x their unique bytes, which this figure includes as real traffic), WRITE_SIZE x1.00 for stores and for atomics "
-            "(whose read half is not counted).  raw_bytes = (FETCH_SIZE + WRITE_SIZE)*1024, uncorrected")
-    traffic = {k: dict(bytes=int((2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024),
-                       raw_bytes=int((c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024), note=note)
-               for k, c in per.items() if "FETCH_SIZE" in c}
-    json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+def pmc_per_dispatch(tagname):
+    """counters of one workload averaged per launch, as scripts/gpu_pmc.sh left them on the GPU box (pmc_<tag>_summary.json)"""
+    p = os.path.join(O, "pmc_%s_summary.json" % tagname)
+    if not os.path.exists(p) or os.path.getmtime(p) < newer_than:
+        return {}
+    return json.load(open(p))
+
+
+# profiles/pmc_traffic.json: {"<config>|<mode>|<order>": {kernel: {"bytes", "raw_bytes"}}, "_note": ...} -- bench.py looks its
+# workload up by that key and reports null when no record of it exists
+note = ("(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch.  The factors are calibrated on this GPU in the kernels' own access patterns "
+        "(profiles/fetch_calibration.json, scripts/fetch_calib.hip: a 2 GiB buffer touched exactly once): FETCH_SIZE counts half "
+        "the bytes (x2.00 for coalesced 8- and 16-byte streams; k_window's per-lane unaligned 16-byte loads over 75-byte records "
+        "fetch 1.30x their unique bytes, which this figure includes as real traffic), WRITE_SIZE x1.00 for stores and for atomics "
+        "(whose read half is not counted).  raw_bytes = (FETCH_SIZE + WRITE_SIZE)*1024, uncorrected")
+tp = os.path.join(P, "pmc_traffic.json")
+traffic = {}
+if os.path.exists(tp):
+    old = json.load(open(tp))
+    traffic = {k: v for k, v in old.items() if "|" in k}       # (a pre-round-4 file was keyed by kernel: dropped)
+for tagname, key in (("C3", "C3|auto|sorted"), ("C2", "C2|auto|sorted"), ("C4", "C4|auto|sorted"), ("C5", "C5|auto|sorted"),
+                     ("C3_shuffle", "C3|auto|shuffle-records")):
+    per = pmc_per_dispatch(tagname)
+    if not per:
+        continue
+    json.dump(per, open(os.path.join(P, "%s_%s_pmc_per_dispatch.json" % (tag, tagname if tagname != "C3" else "c3")), "w"), indent=1, sort_keys=True)
+    rec = {k: dict(bytes=int((2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024),
+                   raw_bytes=int((c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024))
+           for k, c in per.items() if "FETCH_SIZE" in c and "WRITE_SIZE" in c}
+    if rec:
+        rec["_measured"] = tag
+        traffic[key] = rec
+if traffic:
+    traffic["_note"] = note
+    json.dump(traffic, open(tp, "w"), indent=1, sort_keys=True)
 for src, dst in (("e2e_c3_full.json", "e2e_c3_full.json"), ("fetch_calibration.json", "fetch_calibration.json"),
                  ("e2e_sweep.txt", "%s_e2e_thread_chunk_sweep.txt" % tag)):
     p = os.path.join(O, src)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(P, dst))
+for src, dst in (("strong_projection_C3.json", "%s_strong_scaling_projection_C3.json"), ("strong_projection_C4.json", "%s_strong_scaling_projection_C4.json"),
+                 ("e2e_c3_full_phred.json", "%s_e2e_c3_full_phred.json"), ("step_timeline.txt", "%s_c3_step_timeline.txt")):
+    p = os.path.join(O, src)
+    if os.path.exists(p) and os.path.getmtime(p) > newer_than:
+        shutil.copy(p, os.path.join(P, dst % tag))
+p = os.path.join(O, "exp_shuf_global.json")
+if os.path.exists(p) and os.path.getmtime(p) > newer_than:
+    json.dump(first_json_line(p), open(os.path.join(P, "%s_c3_bench_shuffled_global_counters.json" % tag), "w"), indent=1, sort_keys=True)
 mr = {}
 for f in sorted(glob.glob(os.path.join(O, "multirank_*.clean.json"))):
     d = json.load(open(f))

@@ -103,6 +103,20 @@ def test_unsorted_batch_sorted_by_more_workgroups_than_one_scan_segment(emu_lib,
     P.assert_matches_oracle(run)
 
 
+def test_few_deep_windows_take_the_static_queue(emu_lib):
+    """k_window's STATIC queue (kd_window.h: several resident workgroups per window -- a deep small genome): workgroup b tallies part
+    (b mod cut) of window (b / cut).  Default tuning (one piece per part), a forced piece size (a part in many pieces: the u16
+    counters' limit at test scale), two contigs (windows of a plan that do not start at site 0) -- every table against the oracle."""
+    deep = synth.to_numpy(synth.short_reads([1400], 3000, seed=5))
+    run = P.Run(emu_lib, deep)
+    assert run.info["windowed"] == 1 and run.info["work_items"] > 4      # 4 windows of 448 sites, more parts than windows
+    P.assert_matches_oracle(run)
+    P.assert_matches_oracle(P.Run(emu_lib, deep, slice_reads=100))
+    two = synth.to_numpy(synth.short_reads([700, 500], 2000, seed=9, planted=False))
+    P.assert_matches_oracle(P.Run(emu_lib, two))
+    P.assert_matches_oracle(P.Run(emu_lib, two, window=256, slice_reads=64))
+
+
 def test_multiple_pushes_accumulate(emu_lib):
     b = P.subset(P.load_fixture("segemehl__2.1.sub_test"), 100, 700)
     P.assert_matches_oracle(P.Run(emu_lib, b, window=256, n_pushes=3))
@@ -436,10 +450,10 @@ def test_finish_through_a_forced_hash_collision(emu_lib, monkeypatch):
 def test_deep_windows_are_shared_through_the_hot_list(emu_lib):
     """A deep small genome: every window holds many slices, so every workgroup but the ticket holders works as a helper off the
     hot list (kd_window.h: KdWq); slices of 64 reads, windows of 64 - 448 sites."""
-    tb = synth.to_numpy(synth.short_reads([700], 900, seed=31))
+    tb = synth.to_numpy(synth.short_reads([3200], 900, seed=31))    # (more windows than half the emulator's 10 workgroups: fewer take the static queue)
     for window, sl in ((64, 64), (448, 64), (128, 300)):
         run = P.Run(emu_lib, tb, window=window, slice_reads=sl)
-        assert run.info["work_items"] > 3 * ((700 + window) // window + 1)
+        assert run.info["work_items"] > 3 * ((3200 + window) // window + 1)
         P.assert_matches_oracle(run)
 
 
