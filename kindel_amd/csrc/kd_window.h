@@ -411,42 +411,54 @@ __device__ __forceinline__ void kd_add8_ptr(unsigned char *h, unsigned char *hq,
 // A plain read that lies INSIDE the window (k_window's first list): no window clipping, and for a read of up to 160 bases no
 // loop either -- its (up to) five chunks are requested together, every chunk before the last is four whole dwords whose
 // counters sit at compile-time offsets from one pointer computed per read.
+// ROT (a DEEP tile: dozens of reads start on every site, so the lanes of a wavefront -- `rows` reads apart -- still sit on the same
+// handful of sites and in step would add to the same counters in every instruction; same-address LDS atomics serialise): a read
+// of four whole chunks (129 - 160 bases: every short-read library) is walked from chunk `rot & 3` round, the partial fifth chunk
+// last, so that lanes of different `rot` are 32 sites apart.  Costs a pointer computation per chunk: only where it pays.
+template <bool ROT>
 __device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const KdRInfo ri, kd_u64 wlo, int32_t Wi,
-                                              int32_t Wh, uint32_t *hist0) {
+                                              int32_t Wh, uint32_t *hist0, uint32_t rot) {
     const int32_t len = (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
     const int32_t cb = (len - 1) >> 5;
     if (cb > 4) { kd_walk_plain(rd, i, ri, wlo, Wi, Wh, hist0); return; }
     const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);   // 0 <= grel, grel + len <= W
     const KdChunk *src = reinterpret_cast<const KdChunk *>(KD_SEQ_AT(rd, i));
-    KdChunk k0 = src[0], k1 = k0, k2 = k0, k3 = k0, k4 = k0;
-    if (cb >= 1) k1 = src[1];
-    if (cb >= 2) k2 = src[2];
-    if (cb >= 3) k3 = src[3];
+    const uint32_t r4 = (ROT && cb == 4) ? rot & 3u : 0u;        // slot c holds chunk (c + r4) & 3 (slots 0-3 of a read with a fifth chunk)
+    const uint32_t c0 = r4, c1 = ROT ? (1u + r4) & 3u : 1u, c2 = ROT ? (2u + r4) & 3u : 2u, c3 = ROT ? (3u + r4) & 3u : 3u;
+    KdChunk k0 = src[c0], k1 = k0, k2 = k0, k3 = k0, k4 = k0;
+    if (cb >= 1) k1 = src[c1];
+    if (cb >= 2) k2 = src[c2];
+    if (cb >= 3) k3 = src[c3];
     if (cb >= 4) k4 = src[4];
     const int32_t p = grel & 1;
     unsigned char *h = reinterpret_cast<unsigned char *>(hist0) + KD_MUL24S(grel >> 1, KD_HPITCHB);
     unsigned char *hq = h + KD_HPITCHB * p;
     const uint32_t vp = 1u << (16 * p), vq = 0x10000u >> (16 * p);
-#define KD_INNER_STAGE(kc, c)                                                                            \
+#define KD_INNER_STAGE(kc, c, cc)                                                                        \
     if ((c) < cb) {                                                                                      \
-        kd_add8_ptr(h + 16 * (c) * KD_HPITCHB, hq + 16 * (c) * KD_HPITCHB, kc.x, vp, vq);               \
-        kd_add8_ptr(h + (16 * (c) + 4) * KD_HPITCHB, hq + (16 * (c) + 4) * KD_HPITCHB, kc.y, vp, vq);   \
-        kd_add8_ptr(h + (16 * (c) + 8) * KD_HPITCHB, hq + (16 * (c) + 8) * KD_HPITCHB, kc.z, vp, vq);   \
-        kd_add8_ptr(h + (16 * (c) + 12) * KD_HPITCHB, hq + (16 * (c) + 12) * KD_HPITCHB, kc.w, vp, vq); \
+        unsigned char *hc = ROT ? h + KD_MUL24((cc), 16 * KD_HPITCHB) : h + 16 * (c) * KD_HPITCHB;       \
+        unsigned char *hqc = ROT ? hq + KD_MUL24((cc), 16 * KD_HPITCHB) : hq + 16 * (c) * KD_HPITCHB;    \
+        kd_add8_ptr(hc, hqc, kc.x, vp, vq);                                                              \
+        kd_add8_ptr(hc + 4 * KD_HPITCHB, hqc + 4 * KD_HPITCHB, kc.y, vp, vq);                            \
+        kd_add8_ptr(hc + 8 * KD_HPITCHB, hqc + 8 * KD_HPITCHB, kc.z, vp, vq);                            \
+        kd_add8_ptr(hc + 12 * KD_HPITCHB, hqc + 12 * KD_HPITCHB, kc.w, vp, vq);                          \
     } else if ((c) == cb) {                                                                              \
         kd_add_dword(hist0, kc.x, 32 * (c), 0, len, 0, len, grel, 0u);                                   \
         kd_add_dword(hist0, kc.y, 32 * (c) + 8, 0, len, 0, len, grel, 0u);                               \
         kd_add_dword(hist0, kc.z, 32 * (c) + 16, 0, len, 0, len, grel, 0u);                              \
         kd_add_dword(hist0, kc.w, 32 * (c) + 24, 0, len, 0, len, grel, 0u);                              \
     }
-    KD_INNER_STAGE(k0, 0)
-    KD_INNER_STAGE(k1, 1)
-    KD_INNER_STAGE(k2, 2)
-    KD_INNER_STAGE(k3, 3)
-    KD_INNER_STAGE(k4, 4)
+    KD_INNER_STAGE(k0, 0, c0)
+    KD_INNER_STAGE(k1, 1, c1)
+    KD_INNER_STAGE(k2, 2, c2)
+    KD_INNER_STAGE(k3, 3, c3)
+    KD_INNER_STAGE(k4, 4, 4u)
 #undef KD_INNER_STAGE
 }
 
+#ifndef KD_DEEP_READS_PER_SITE
+#define KD_DEEP_READS_PER_SITE 12u   // a tile is DEEP when it holds this many candidates per start site
+#endif
 #define KD_TILE 1024   // reads classified together (a multiple of KD_BLOCK)
 #define KD_TILE_PER_THREAD (KD_TILE / KD_BLOCK)
 #define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)2 * KD_TILE * 2)   // Wh = site pairs, halos included
@@ -518,6 +530,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
     // [tile parity][list]: 0 own plain entries that end inside the histogram (l_plain from the front), 1 own plain entries cut by
     // its end (l_plain from the back), 2 own complex entries (l_cplx from the front), 3 early / late entries (l_cplx from the back)
     __shared__ uint32_t s_cnt[2][4];
+    __shared__ uint32_t s_gfirst[2], s_glast[2];   // G-starts of the tile's first and last candidate (a DEEP tile: see kd_walk_inner<true>)
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
     const uint32_t nh = (uint32_t)KD_HCH * (uint32_t)Wh;   // histogram dwords
@@ -657,6 +670,11 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
 #pragma unroll
             for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
                 const kd_u64 gs = p_gs[u], span = p_sc[u] >> KD_SPAN_SHIFT;
+                if (!ROWS) {
+                    const kd_u64 j = tb + u * KD_BLOCK + t;
+                    if (j == tb) s_gfirst[par] = (uint32_t)gs;
+                    if (j + 1 == (tb + KD_TILE < last ? tb + KD_TILE : last)) s_glast[par] = (uint32_t)gs;
+                }
                 if (ROWS) {
                     if ((p_sc[u] & 3u) == KD_CLS_REG && gs < whi && gs + span > wlo)
                         l_plain[atomicAdd(&s_cnt[par][0], 1u)] = (uint16_t)(u * KD_BLOCK + t);
@@ -677,6 +695,10 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
             __syncthreads();
             KD_MARK(c_cls)
             const uint32_t ni = s_cnt[par][0], np = s_cnt[par][1], ncx = s_cnt[par][2], nx = s_cnt[par][3];
+            // DEEP tile (a sorted batch: the tile's first and last candidates bracket its start sites): KD_DEEP_READS_PER_SITE or more
+            // reads per start site -- the plain reads are walked from different chunks
+            const kd_u64 tile_n = (tb + KD_TILE < last ? tb + KD_TILE : last) - tb;
+            const bool deep = !ROWS && !order && rd.osh == 0 && (kd_u64)(s_glast[par] - s_gfirst[par] + 1u) * KD_DEEP_READS_PER_SITE <= tile_n;
             if (t == 0) { s_cnt[par ^ 1u][0] = 0; s_cnt[par ^ 1u][1] = 0; s_cnt[par ^ 1u][2] = 0; s_cnt[par ^ 1u][3] = 0; }   // next tile's counters (idle until its classify)
 #pragma unroll
             for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
@@ -696,7 +718,8 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                 if (e < ni) {
                     const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
                     if (ROWS) kd_walk_row(rd, i, KD_RI(rinfo, rd, i), wlo, Wi, lane + 17u * r, hist0);
-                    else kd_walk_inner(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0);
+                    else if (deep) kd_walk_inner<true>(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0, lane);
+                    else kd_walk_inner<false>(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0, 0u);
                 }
             }
             if (!ROWS) {
