@@ -46,7 +46,8 @@ PY
            timeout 600 python scripts/strong_projection.py --config C5 --ranks 1 --tunings "$T" --out $O/sweep_C5.json > /dev/null 2> $O/sweep_c5.err; echo "c5 rc=$?" ;;
     sweep_prep) for pp in 4 8 16 32 64; do KD_PREP_PER=$pp timeout 600 python scripts/strong_projection.py --config C3 --ranks 8 --only-rank 3 --out $O/sweep_C3_rank3of8_prep$pp.json > /dev/null 2>> $O/sweep_c3.err; done ;;
     timeline) bash scripts/gpu_timeline.sh 2>&1 | tail -3 ;;
-    e2e) timeout 900 python scripts/e2e_bench.py --scale 1.0 --repeat 3 --out $O/e2e_c3_full_phred.json > /dev/null 2> $O/e2e.err; tail -c 400 $O/e2e_c3_full_phred.json ;;
+    e2e) timeout 900 python scripts/e2e_bench.py --scale 1.0 --repeat 3 --qual phred --out $O/e2e_c3_full_phred.json > /dev/null 2> $O/e2e.err; tail -c 400 $O/e2e_c3_full_phred.json; echo
+         timeout 900 python scripts/e2e_bench.py --scale 1.0 --repeat 3 --out $O/e2e_c3_full.json > /dev/null 2>> $O/e2e.err; tail -c 400 $O/e2e_c3_full.json ;;
     multirank) bash scripts/gpu_multirank.sh 2>&1 | tail -12 ;;
     *) echo "unknown stage $st" ;;
   esac
