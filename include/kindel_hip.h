@@ -292,6 +292,11 @@ uint32_t kd_stream_contig_len(const kd_stream *s, uint32_t i);
 /* Next batch, or *batch = NULL at the end of the file.  Two batches are kept: a batch stays valid until the call AFTER the
  * next one, so one thread can decode batch k+1 while another still reads batch k. */
 int kd_stream_next(kd_stream *s, const kd_batch **batch);
+/* Records come out with contig = map[refID] from the next kd_stream_next on (map: one entry per @SQ line; 0xffffffff = "no record
+ * may lie here": KD_E_ARG if one does; n = 0 restores the identity).  For a header far larger than what the records touch (a
+ * human-genome @SQ table, reads on one small contig): the reference lays out only the RNAMEs it sees (kindel.py:143-151) -- the
+ * caller scans the file once for the contigs in use, creates its context over those, and streams with this map. */
+int kd_stream_set_contig_map(kd_stream *s, const uint32_t *map, uint32_t n);
 uint64_t kd_stream_n_records(const kd_stream *s); /* records seen so far, incl. dropped RNAME '*' */
 const char *kd_stream_last_error(const kd_stream *s);
 void kd_stream_close(kd_stream *s);

@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "kd_profile_enable kd_profile_get kd_profile_reset kd_decode_open kd_decode_batch kd_decode_n_contigs "
     "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error "
     "kd_stream_open kd_stream_n_contigs kd_stream_contig_name kd_stream_contig_len kd_stream_next kd_stream_n_records "
-    "kd_stream_last_error kd_stream_close kd_push_stream kd_decode_push_file kd_get_contig_first kd_host_threads kd_host_inflate kd_host_crc32 "
+    "kd_stream_last_error kd_stream_close kd_stream_set_contig_map kd_push_stream kd_decode_push_file kd_get_contig_first kd_host_threads kd_host_inflate kd_host_crc32 "
     "kd_bgzf_index kd_decode_open_span kd_step kd_finish kd_set_step_graph kd_bgzf_plan_open kd_bgzf_plan_n_contigs kd_bgzf_plan_contig_name kd_bgzf_plan_contig_len "
     "kd_bgzf_plan_view kd_bgzf_plan_close kd_push_bam_gpu"
 ).split()
@@ -145,6 +145,7 @@ class Library:
         L.kd_stream_last_error.argtypes = [p]
         L.kd_stream_last_error.restype = C.c_char_p
         L.kd_stream_close.argtypes = [p]
+        L.kd_stream_set_contig_map.argtypes = [p, p, u32]
         L.kd_stream_close.restype = None
         L.kd_push_stream.argtypes = [p, p, C.POINTER(u64)]
         L.kd_decode_push_file.argtypes = [p, C.c_char_p, C.c_int, u64, C.POINTER(u64)]
@@ -224,6 +225,14 @@ class Stream:
         out["contig_names"] = np.asarray(self.contig_names)
         out["contig_lens"] = self.contig_lens
         return out
+
+    def set_contig_map(self, mapping):
+        """Records come out with contig = mapping[refID] from the next batch on (uint32 per @SQ line, 0xffffffff = no record may
+        lie there); None restores the identity.  kd_stream_set_contig_map."""
+        m = np.zeros(0, np.uint32) if mapping is None else np.ascontiguousarray(mapping, np.uint32)
+        rc = self.lib.dll.kd_stream_set_contig_map(self._h, _ptr(m) if len(m) else None, len(m))
+        if rc:
+            self._raise(rc)
 
     def n_records(self):
         return int(self.lib.dll.kd_stream_n_records(self._h))

@@ -1298,6 +1298,7 @@ struct kd_stream {
     File slot[2];
     int cur = 0;
     std::string err;
+    std::vector<uint32_t> cmap;     // kd_stream_set_contig_map: file refID -> the caller's contig id (empty: identity)
 };
 
 int kd_stream_open(kd_stream **out, const char *path, int n_threads, uint64_t chunk_bytes) {
@@ -1326,8 +1327,25 @@ int kd_stream_next(kd_stream *s, const kd_batch **batch) {
     if (s->st.names.size() != names.size()) { s->st.names = names; s->st.lens = lens; }
     if (rc) { s->err = g_decode_error; return rc; }
     if (!got) return KD_OK;
+    if (!s->cmap.empty()) {
+        for (size_t i = 0; i < f.contig.size(); i++) {
+            uint32_t &c = f.contig.data()[i];
+            const uint32_t m = c < s->cmap.size() ? s->cmap[c] : 0xffffffffu;
+            if (m == 0xffffffffu) {
+                s->err = "kd_stream_set_contig_map: a record lies on @SQ entry " + std::to_string(c) + ", which the map leaves out";
+                return KD_E_ARG;
+            }
+            c = m;
+        }
+    }
     finish_view(f);
     *batch = &f.view;
+    return KD_OK;
+}
+int kd_stream_set_contig_map(kd_stream *s, const uint32_t *map, uint32_t n) {
+    if (!s || (n && !map)) return KD_E_ARG;
+    if (n && n != s->st.names.size()) { s->err = "kd_stream_set_contig_map: the map must have one entry per @SQ line"; return KD_E_ARG; }
+    s->cmap.assign(map, map + n);
     return KD_OK;
 }
 const char *kd_stream_last_error(const kd_stream *s) { return s ? s->err.c_str() : g_decode_error.c_str(); }

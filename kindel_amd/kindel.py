@@ -199,15 +199,32 @@ def pileup_batch(batch, bam_path=None, device=0, lib=None, mode=N.KD_MODE_AUTO, 
     return Pileup(eng, names, lens, _first_appearance(np.asarray(sub["contig"])), bam_path)
 
 
-#: a header whose contigs add up to at most this many sites is laid out whole and the file is STREAMED (decode of batch
-#: k+1 overlapped with copy + kernels of batch k); a larger header (a human genome's) goes through the whole-file decode,
-#: which lays out only the contigs that have records
-STREAM_MAX_SITES = 1 << 26      # 67 M sites = 5 GB of tables at 76 B/site (the streamed path lays out every @SQ contig)
+#: a header whose contigs add up to at most this many sites is laid out whole and the file is streamed at once (decode of batch
+#: k+1 overlapped with copy + kernels of batch k); a larger header (a human genome's) is first SCANNED for the contigs that have
+#: records (one streamed decode pass, nothing kept), then streamed over those alone -- the reference lays out per RNAME seen
+#: (kindel.py:143-151) -- so that neither the header nor the file has to fit anywhere
+STREAM_MAX_SITES = 1 << 26      # 67 M sites = 5 GB of tables at 76 B/site
+
+
+def _contigs_in_use(bam_path, threads, chunk_bytes, lib):
+    """One streamed pass over the file: the @SQ entries that have records, in file order of the header."""
+    st = N.Stream(bam_path, threads=threads, chunk_bytes=chunk_bytes, lib=lib)
+    try:
+        seen = np.zeros(len(st.contig_lens), bool)
+        while True:
+            b = st.next_batch()
+            if b is None:
+                break
+            seen[np.unique(b["contig"])] = True
+        return np.flatnonzero(seen)
+    finally:
+        st.close()
 
 
 def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=None, ingest=None):
-    """Decode + device record loop of one SAM / BAM file -> Pileup.  stream: True / False forces the path, None decides by
-    the size of the header (see STREAM_MAX_SITES).  ingest: "host" (default: the native host decoder feeds the GPU) or "gpu"
+    """Decode + device record loop of one SAM / BAM file -> Pileup.  stream: False = the whole file decoded as ONE batch (only the
+    contigs with records laid out); True = streamed over the whole header, whatever its size; None (default) = streamed, a header
+    beyond STREAM_MAX_SITES scanned first for the contigs in use.  ingest: "host" (default: the native host decoder feeds the GPU) or "gpu"
     (opt-in, also KINDEL_INGEST=gpu: the BGZF blocks are inflated and the BAM records walked ON the GPU, kd_push_bam_gpu; a file
     that path cannot read -- SAM text, plain gzip, CG-tag CIGARs, a header larger than STREAM_MAX_SITES -- takes the host path)."""
     if (ingest or os.environ.get("KINDEL_INGEST", "host")) == "gpu" and stream is not False:
@@ -234,20 +251,33 @@ def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=N
         st = N.Stream(bam_path, threads=threads, chunk_bytes=chunk_bytes, lib=lib)
         try:
             total = int(st.contig_lens.astype(np.uint64).sum())
-            if stream or (len(st.contig_lens) and total <= STREAM_MAX_SITES):
-                if len(st.contig_lens) == 0:
-                    if st.next_batch() is not None:
-                        raise KeyError("no @SQ lines in header")
+            if len(st.contig_lens) == 0:
+                if st.next_batch() is not None:
+                    raise KeyError("no @SQ lines in header")
+                return Pileup(None, [], np.zeros(0, np.uint32), [], bam_path)
+            names, lens = list(st.contig_names), st.contig_lens
+            if total > STREAM_MAX_SITES and not stream:
+                # a header far larger than what the records touch: lay out the contigs in use only
+                keep = _contigs_in_use(bam_path, threads, chunk_bytes, lib)
+                if len(keep) == 0:
                     return Pileup(None, [], np.zeros(0, np.uint32), [], bam_path)
-                eng = N.Engine(st.contig_lens, device=device, lib=lib)
+                cmap = np.full(len(lens), 0xFFFFFFFF, np.uint32)
+                cmap[keep] = np.arange(len(keep), dtype=np.uint32)
+                st.set_contig_map(cmap)
+                names, lens = [names[int(i)] for i in keep], lens[keep]
+            eng = N.Engine(lens, device=device, lib=lib)
+            try:
                 info = eng.push_stream(st)
-                eng.finalize()
-                first = eng.contig_first()
-                used = np.flatnonzero(first != np.uint64(0xFFFFFFFFFFFFFFFF))
-                order = [int(c) for c in used[np.argsort(first[used], kind="stable")]]   # first appearance, kindel.py:143-151
-                pl = Pileup(eng, list(st.contig_names), st.contig_lens, order, bam_path)
-                pl.ingest = info
-                return pl
+            except BaseException:
+                eng.close()
+                raise
+            eng.finalize()
+            first = eng.contig_first()
+            used = np.flatnonzero(first != np.uint64(0xFFFFFFFFFFFFFFFF))
+            order = [int(c) for c in used[np.argsort(first[used], kind="stable")]]   # first appearance, kindel.py:143-151
+            pl = Pileup(eng, names, lens, order, bam_path)
+            pl.ingest = info
+            return pl
         finally:
             st.close()
     return pileup_batch(N.decode_file(bam_path, threads=threads, lib=lib), bam_path=bam_path, device=device, lib=lib)

@@ -92,6 +92,38 @@ def test_unknown_rname_is_a_keyerror(api_on_emu, tmp_path):
     assert ei.value.args[0] == "zzz"
 
 
+def test_large_header_is_scanned_then_streamed(api_on_emu, tmp_path):
+    """A header beyond STREAM_MAX_SITES (a human genome's @SQ table, reads on two small contigs in between): the file is scanned once
+    for the contigs in use and then STREAMED over those alone -- several chunks, a contig map inside the decoder
+    (kd_stream_set_contig_map) -- instead of being decoded whole; same tables, order and FASTA as the one-batch path."""
+    from kindel_amd import kindel as K
+    small = synth.to_numpy(synth.short_reads([3000, 2000], 40, seed=21, planted=False))
+    batch = dict(small)
+    batch["contig"] = np.where(small["contig"] == 0, 1, 3).astype(np.uint32)            # header slots 1 and 3 of five
+    batch["contig_lens"] = np.asarray([2_100_000_000, 3000, 1_900_000_000, 2000, 50_000_000], np.uint32)
+    names = ["chr1", "virusA", "chr2", "virusB", "chrUn"]
+    p = str(tmp_path / "big_header.bam")
+    synth.write_bam(p, batch, names=names, block_bytes=4000)
+    pl = K.pileup_file(p, chunk_bytes=20000)                                             # many chunks: the map applies to every batch
+    assert pl.names == ["virusA", "virusB"] and list(pl.lens) == [3000, 2000] and pl.ingest["batches"] > 3
+    ref = K.pileup_file(p, stream=False)
+    assert ref.names == pl.names and pl.order == ref.order
+    for cid in pl.order:
+        assert np.array_equal(pl.engine.tables(cid), ref.engine.tables(cid))
+    a, b = K.bam_to_consensus(p), K.bam_to_consensus(p, min_depth=2)
+    assert [c.name for c in a.consensuses] == ["virusA_cns", "virusB_cns"] and len(b.consensuses) == 2
+    want = K.pileup_batch(small)
+    for cid in (0, 1):
+        assert np.array_equal(pl.engine.tables(cid), want.engine.tables(cid))
+    # a record on an @SQ entry the map leaves out is refused by the decoder, not mis-filed
+    st = N.Stream(p)
+    st.set_contig_map(np.asarray([0xFFFFFFFF, 0, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF], np.uint32))
+    with pytest.raises(N.KindelNativeError, match="which the map leaves out"):
+        while st.next_batch() is not None:
+            pass
+    st.close()
+
+
 def test_sam_insertion_outside_the_bam_alphabet_is_refused(api_on_emu, tmp_path):
     """4-bit base codes cannot hold e.g. 'U'.  In M / clip context that is a KeyError like in the reference; inside an
     insertion the reference would keep the text verbatim (kindel.py:55-58): refused loudly instead of emitting '='."""
