@@ -391,16 +391,30 @@ struct KdEngine {
                 int rc2;
                 // 16 lanes per read, row-major histogram (kd_coop.h) -- unless a hand-picked window is too wide for its 33 rows
                 const bool use_coop = want_coop && KD_COOP_LDS_BYTES(KD_COOP_PITCH(W)) <= (size_t)160 * 1024 - 1024;
-                uint32_t w0;
-                const uint32_t n_win = windows_of(W, w0);
                 // the histogram reaches H sites past the window: an entry is tallied whole by the window it starts in (kd_window.h:
                 // OWNERSHIP); H = the longest footprint of this pass's entries, up to 256 sites (longer ones leave a remainder)
                 // (a row is thousands of sites long: every window tallies its own part of it, H = 0)
                 uint32_t H = (use_coop || rows) ? 0u : (uint32_t)std::min<uint64_t>(256, (h_status[span_slot] + 63) & ~uint64_t(63));
                 while (H && KD_WINDOW_LDS_BYTES((W + H + 2 * KD_HALO) / 2) > (size_t)160 * 1024 - 1024) H -= 64;   // (a hand-picked window near the LDS limit)
+                auto grid_of = [&](uint32_t Wx) {
+                    const size_t l = KD_WINDOW_LDS_BYTES((Wx + H + 2 * KD_HALO) / 2);
+                    return std::max(1u, (unsigned)rt.n_cus() * (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (l + 64))));
+                };
+                uint32_t w0;
+                if (!this->W && !use_coop && !rows) {
+                    // A SMALL shard (1/8 of C3 on one of eight GPUs: 1395 windows of 448 sites on 1280 resident workgroups): a few windows
+                    // left over for a second, thin round cost a window's whole latency.  A wider window that puts every window into
+                    // the FIRST round is taken when there is one (measured on that shard: k_window 0.21 -> 0.18 ms, step -7 %).
+                    uint32_t d0;
+                    const uint32_t n0 = windows_of(W, d0), g0 = grid_of(W);
+                    if (n0 > g0 && n0 < 2 * g0)
+                        for (uint32_t Wx = W + 64; Wx <= W + 256; Wx += 64)
+                            if (windows_of(Wx, d0) <= grid_of(Wx)) { W = Wx; break; }
+                }
+                const uint32_t n_win = windows_of(W, w0);
                 const uint32_t Wh = (W + H + 2 * KD_HALO) / 2;   // dwords per channel row
                 const size_t win_lds = KD_WINDOW_LDS_BYTES(Wh);
-                const unsigned win_grid = std::max(1u, (unsigned)rt.n_cus() * (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (win_lds + 64))));
+                const unsigned win_grid = grid_of(W);
                 uint32_t slice = slice_cfg, static_cut = 0;
                 if (!slice && use_coop) slice = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(256, ne / 4096));   // (planned queue: a few thousand items)
                 // A work item = one zeroing + one flush of the window's histogram, whatever it tallies in between: every slice
