@@ -459,6 +459,9 @@ __device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const
 #ifndef KD_DEEP_READS_PER_SITE
 #define KD_DEEP_READS_PER_SITE 12u   // a tile is DEEP when it holds this many candidates per start site
 #endif
+#ifndef KD_DYN_ROWS
+#define KD_DYN_ROWS 1  // rows of a tile handed out from a counter (0: every fourth row of every list)
+#endif
 #define KD_TILE 1024   // reads classified together (a multiple of KD_BLOCK)
 #define KD_TILE_PER_THREAD (KD_TILE / KD_BLOCK)
 #define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)2 * KD_TILE * 2)   // Wh = site pairs, halos included
@@ -530,6 +533,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
     // [tile parity][list]: 0 own plain entries that end inside the histogram (l_plain from the front), 1 own plain entries cut by
     // its end (l_plain from the back), 2 own complex entries (l_cplx from the front), 3 early / late entries (l_cplx from the back)
     __shared__ uint32_t s_cnt[2][4];
+    __shared__ uint32_t s_row[2];       // KD_DYN_ROWS: next row of the tile to hand out
     __shared__ uint32_t s_gfirst[2], s_glast[2];   // G-starts of the tile's first and last candidate (a DEEP tile: see kd_walk_inner<true>)
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
@@ -611,7 +615,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
             s_win = w;
             s_first = lo + (kd_u64)k * slice;
             s_last = lo + (kd_u64)k * slice + slice < hi ? lo + (kd_u64)k * slice + slice : hi;
-            s_cnt[0][0] = 0; s_cnt[0][1] = 0; s_cnt[0][2] = 0; s_cnt[0][3] = 0;
+            s_cnt[0][0] = 0; s_cnt[0][1] = 0; s_cnt[0][2] = 0; s_cnt[0][3] = 0; s_row[0] = 0;
             s_found = NONE;
         }
         __syncthreads();
@@ -699,7 +703,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
             // reads per start site -- the plain reads are walked from different chunks
             const kd_u64 tile_n = (tb + KD_TILE < last ? tb + KD_TILE : last) - tb;
             const bool deep = !ROWS && !order && rd.osh == 0 && (kd_u64)(s_glast[par] - s_gfirst[par] + 1u) * KD_DEEP_READS_PER_SITE <= tile_n;
-            if (t == 0) { s_cnt[par ^ 1u][0] = 0; s_cnt[par ^ 1u][1] = 0; s_cnt[par ^ 1u][2] = 0; s_cnt[par ^ 1u][3] = 0; }   // next tile's counters (idle until its classify)
+            if (t == 0) { s_cnt[par ^ 1u][0] = 0; s_cnt[par ^ 1u][1] = 0; s_cnt[par ^ 1u][2] = 0; s_cnt[par ^ 1u][3] = 0; s_row[par ^ 1u] = 0; }   // next tile's counters (idle until its classify)
 #pragma unroll
             for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
                 const kd_u64 j = tb + KD_TILE + u * KD_BLOCK + t;
@@ -713,6 +717,70 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
             // list entries l*rows + r: neighbours in a wavefront are `rows` reads apart in the sorted batch,
             // which keeps them off the same LDS counters in the same instruction.
             const uint32_t rows_i = (ni + KD_WAVE - 1) / KD_WAVE, rows_p = (np + KD_WAVE - 1) / KD_WAVE, rows_c = (ncx + KD_WAVE - 1) / KD_WAVE;
+#if KD_DYN_ROWS
+            // ROWS HANDED OUT: a wavefront takes the next row of the tile from a counter -- the complex rows first (the longest), then
+            // the plain rows inside the histogram, those cut by its end, the early / late ones -- instead of every fourth row of
+            // every list: a wavefront whose rows waited longer for their bases takes fewer of them.
+            const uint32_t rows_x = ROWS ? 0u : (nx + KD_WAVE - 1) / KD_WAVE;
+            const uint32_t rows_all = (ROWS ? 0u : rows_c + rows_p + rows_x) + rows_i;
+            for (;;) {
+                uint32_t rr = 0;
+                if (lane == 0) rr = atomicAdd(&s_row[par], 1u);
+                rr = kd_readfirstlane(rr);
+                if (rr >= rows_all) break;
+                if (!ROWS && rr < rows_c) {
+                    const uint32_t r = rr, e = lane * rows_c + r;
+                    if (e < ncx) {
+                        const kd_u64 j = tb + l_cplx[e], i = order ? (kd_u64)order[j] : j;
+                        const KdRInfo ri = KD_RI(rinfo, rd, i);
+                        const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);
+                        const int32_t foot_end = grel + (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
+                        if (!kd_walk_short(rd, i, ri, wlo, We, Wh, hist0)) {   // more than three segments: general walk
+                            kd_walk_ops(rd, i, ri.pad >> 24, 0u, ri.pad >> 24, grel, 0, (int32_t)ri.lead, foot_end, We, Wh, hist0);
+                        }
+                    }
+                    continue;
+                }
+                if (!ROWS) rr -= rows_c;
+                if (rr < rows_i) {
+                    const uint32_t r = rr, e = lane * rows_i + r;
+                    if (e < ni) {
+                        const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
+                        if (ROWS) kd_walk_row(rd, i, KD_RI(rinfo, rd, i), wlo, Wi, lane + 17u * r, hist0);
+                        else if (deep) kd_walk_inner<true>(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0, lane);
+                        else kd_walk_inner<false>(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0, 0u);
+                    }
+                    continue;
+                }
+                rr -= rows_i;
+                if (rr < rows_p) {
+                    const uint32_t r = rr, e = lane * rows_p + r;
+                    if (e < np) {
+                        const kd_u64 j = tb + l_plain[KD_TILE - 1u - e], i = order ? (kd_u64)order[j] : j;
+                        kd_walk_plain(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0);
+                    }
+                    continue;
+                }
+                rr -= rows_p;
+                {   // early / late entries (rare: an entry longer than the histogram's reach, a leading clip across the window's left
+                    // edge): the general walk, early ones against the origin wlo + H over W sites, late ones against [wlo, whi)
+                    const uint32_t e = rr * KD_WAVE + lane;
+                    if (e < nx) {
+                        const uint32_t code = l_cplx[KD_TILE - 1u - e];
+                        const bool early = (code & 0x8000u) != 0;
+                        const kd_u64 j = tb + (code & 0x3fffu), i = order ? (kd_u64)order[j] : j;
+                        const KdRInfo ri = KD_RI(rinfo, rd, i);
+                        const bool shifted = early && w != 0;          // early entry of a window that has windows in front
+                        const kd_u64 org = shifted ? wlo + H : wlo;
+                        uint32_t *h0 = shifted ? hist_early : hist0;
+                        const int32_t Wx = (early && !shifted) ? We : Wi;
+                        const int32_t grel = (int32_t)(ri.gstart - (uint32_t)org);
+                        const int32_t foot_end = grel + (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
+                        kd_walk_ops(rd, i, ri.pad >> 24, 0u, ri.pad >> 24, grel, 0, (int32_t)ri.lead, foot_end, Wx, Wh, h0);
+                    }
+                }
+            }
+#else
             for (uint32_t r = wave; r < rows_i; r += KD_WAVES_PER_BLOCK) {
                 const uint32_t e = lane * rows_i + r;
                 if (e < ni) {
@@ -767,6 +835,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                 }
             }
             }   // !ROWS
+#endif
             KD_MARK(c_cplx)
             __syncthreads();
             KD_MARK(c_wait)
