@@ -847,39 +847,47 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
             __syncthreads();
             KD_MARK(c_wait)
         }
-        // flush: channel by channel, lane = site pair: consecutive lanes -> consecutive dwords of one HBM channel row (the LDS
-        // reads are 19 dwords apart: conflict free); zeros are skipped.
+        // flush: lane = site pair.  A pair's 19 counters are consecutive in LDS: the thread requests them all at once (19 reads in
+        // flight instead of one per loop turn), then walks the channels with the channel -> table-row mapping a compile-time
+        // matter of the unrolled loop -- for a fixed channel consecutive lanes hit consecutive 8-byte words of one HBM row; zeros
+        // are skipped.  (Rounds 1 - 3 looped channel by channel with the pair inside: 38 dependent LDS reads per thread, 9 % of
+        // the wavefront clocks.)
         // LDS channel -> table channel (KD_CH_*): weights 0-4, deletions 5, csw 6-10, cew 11-15; 0xff = bad slot
         bool bad = false;
-        for (uint32_t ch = 0; ch < KD_HCH; ch++) {
-            uint32_t tch, tch2 = 0xffu;
-            if (ROWS) {   // row symbols (kd_common.h): 0 nothing, 1-5 A,T,G,C,N, 6 deleted; 7-13 the same with an insertion in front
-                if (ch == KD_ROW_SKIP || ch > KD_ROW_DEL + KD_ROW_INS) continue;
-                const uint32_t sym = ch >= KD_ROW_INS ? ch - KD_ROW_INS : ch;
-                tch = sym == KD_ROW_SKIP ? (uint32_t)KDC_INS_TOTAL : sym == KD_ROW_DEL ? (uint32_t)KDC_DEL : sym - 1u;
-                if (ch >= KD_ROW_INS && sym != KD_ROW_SKIP) tch2 = KDC_INS_TOTAL;
-            } else {
-                tch = ch < 5 ? ch : ch == KD_HCH_DEL ? (uint32_t)KDC_DEL
-                    : (ch >= 7 && ch < 12) ? ch - 1 : (ch >= 13 && ch < 18) ? ch - 2 : 0xffu;
-            }
-            uint32_t *row = T.tab + (kd_u64)(tch == 0xffu ? 0u : tch) * T.stride;
-            uint32_t *row2 = T.tab + (kd_u64)(tch2 == 0xffu ? 0u : tch2) * T.stride;
-            for (uint32_t xw = t; xw < (uint32_t)Wh; xw += KD_BLOCK) {
-                const uint32_t v = hist[xw * KD_HPITCH + ch];
-                if (!v) continue;
-                // the word holds window-relative sites s (low half) and s + 1 (high half); halo sites are dropped
-                const int32_t sw = 2 * (int32_t)xw - KD_HALO;
-                const kd_u64 g0 = wlo + (kd_u64)sw;   // even: W, the halo and the G-space rows are all even / 8-byte aligned
-                if (tch != 0xffu && sw >= 0 && sw + 1 < We && g0 + 1 < T.sites && kd_commit(T, g0) && kd_commit(T, g0 + 1)) {
+        for (uint32_t xw = t; xw < (uint32_t)Wh; xw += KD_BLOCK) {
+            uint32_t v[KD_HCH];
+#pragma unroll
+            for (uint32_t ch = 0; ch < KD_HCH; ch++) v[ch] = hist[xw * KD_HPITCH + ch];
+            // the words hold window-relative sites s (low half) and s + 1 (high half); halo sites are dropped
+            const int32_t sw = 2 * (int32_t)xw - KD_HALO;
+            const kd_u64 g0 = wlo + (kd_u64)sw;   // even: W, the halo and the G-space rows are all even / 8-byte aligned
+            const bool whole = sw >= 0 && sw + 1 < We && g0 + 1 < T.sites && kd_commit(T, g0) && kd_commit(T, g0 + 1);
+#pragma unroll
+            for (uint32_t ch = 0; ch < KD_HCH; ch++) {
+                uint32_t tch, tch2 = 0xffu;
+                if (ROWS) {   // row symbols (kd_common.h): 0 nothing, 1-5 A,T,G,C,N, 6 deleted; 7-13 the same with an insertion in front
+                    if (ch == KD_ROW_SKIP || ch > KD_ROW_DEL + KD_ROW_INS) continue;
+                    const uint32_t sym = ch >= KD_ROW_INS ? ch - KD_ROW_INS : ch;
+                    tch = sym == KD_ROW_SKIP ? (uint32_t)KDC_INS_TOTAL : sym == KD_ROW_DEL ? (uint32_t)KDC_DEL : sym - 1u;
+                    if (ch >= KD_ROW_INS && sym != KD_ROW_SKIP) tch2 = KDC_INS_TOTAL;
+                } else {
+                    tch = ch < 5 ? ch : ch == KD_HCH_DEL ? (uint32_t)KDC_DEL
+                        : (ch >= 7 && ch < 12) ? ch - 1 : (ch >= 13 && ch < 18) ? ch - 2 : 0xffu;
+                }
+                const uint32_t x = v[ch];
+                if (!x) continue;
+                uint32_t *row = T.tab + (kd_u64)(tch == 0xffu ? 0u : tch) * T.stride;
+                uint32_t *row2 = T.tab + (kd_u64)(tch2 == 0xffu ? 0u : tch2) * T.stride;
+                if (tch != 0xffu && whole) {
                     // both sites of the word live: ONE 64-bit add on the two adjacent u32 counters (the low counter
                     // cannot carry into the high one: a u32 table counter never wraps)
-                    atomicAdd(reinterpret_cast<kd_u64 *>(row + g0), (kd_u64)(v & 0xffffu) | ((kd_u64)(v >> 16) << 32));
+                    atomicAdd(reinterpret_cast<kd_u64 *>(row + g0), (kd_u64)(x & 0xffffu) | ((kd_u64)(x >> 16) << 32));
                     if (ROWS && tch2 != 0xffu)
-                        atomicAdd(reinterpret_cast<kd_u64 *>(row2 + g0), (kd_u64)(v & 0xffffu) | ((kd_u64)(v >> 16) << 32));
+                        atomicAdd(reinterpret_cast<kd_u64 *>(row2 + g0), (kd_u64)(x & 0xffffu) | ((kd_u64)(x >> 16) << 32));
                     continue;
                 }
                 for (int hlf = 0; hlf < 2; hlf++) {
-                    const uint32_t cnt = hlf ? v >> 16 : v & 0xffffu;
+                    const uint32_t cnt = hlf ? x >> 16 : x & 0xffffu;
                     const int32_t sw2 = sw + hlf;
                     if (!cnt || sw2 < 0 || sw2 >= We) continue;
                     const kd_u64 g = wlo + (kd_u64)sw2;
