@@ -735,11 +735,11 @@ struct KdEngine {
         if (!n) return KD_OK;
         const size_t bytes[9] = {n * 4, n * 4, n * 4, n * 8, n * 4, n * 8, n * 4, (size_t)seq_bytes + 64, (size_t)cig_words * 4 + 8};
         for (int k = 0; k < 9; k++) if ((rc = ensure(b_stage[k], bytes[k]))) return rc;
-        if ((rc = ensure(b_gi_recat, n * 8))) return rc;
+        if ((rc = ensure(b_gi_recat, n * 16))) return rc;
         KdBamOut O;
         O.contig = (uint32_t *)b_stage[0].p; O.pos0 = (int32_t *)b_stage[1].p; O.flag = (uint32_t *)b_stage[2].p; O.seq_off = (kd_u64 *)b_stage[3].p;
         O.seq_len = (uint32_t *)b_stage[4].p; O.cig_off = (kd_u64 *)b_stage[5].p; O.n_cig = (uint32_t *)b_stage[6].p;
-        O.seq4 = (uint8_t *)b_stage[7].p; O.cigar = (uint32_t *)b_stage[8].p; O.rec_at = (kd_u64 *)b_gi_recat.p;
+        O.seq4 = (uint8_t *)b_stage[7].p; O.cigar = (uint32_t *)b_stage[8].p; O.rec_at = (kd_u64 *)b_gi_recat.p; O.cig_at = (kd_u64 *)b_gi_recat.p + n;
         if (rt.memset((uint8_t *)b_stage[7].p + seq_bytes, 0, 64) ||
             rt.launch("k_bam_fields", k_bam_fields, gb, KD_BLOCK, 0, Bm, (const kd_u64 *)start, (const kd_u64 *)c_rec, (const kd_u64 *)c_seq, (const kd_u64 *)c_cig, O) ||
             rt.launch("k_bam_payload", k_bam_payload, (unsigned)((n + KD_WAVE - 1) / KD_WAVE), KD_WAVE, 0, Bm, (kd_u64)n, O, (kd_u64)seq_bytes, (kd_u64)cig_words))

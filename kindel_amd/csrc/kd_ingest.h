@@ -10,8 +10,8 @@
 // the first offset in the block from which KD_BAM_CHAIN consecutive records look well-formed (k_bam_starts: 64 candidates per step
 // and wavefront); a walk must END exactly on the start the next part guessed (k_bam_count), otherwise the ingest reports
 // KD_INGEST_CHAIN and the caller decodes on the host.  Records of unmapped reads (refID < 0) are dropped, as the host decoder
-// drops them; a CIGAR placeholder with a CG:B,I tag (> 65535 operations, SAMv1 4.2.2) sends the file to the host decoder
-// (KD_INGEST_HOST), which spells the tag out.
+// drops them; a CIGAR placeholder with a CG:B,I tag (> 65535 operations, SAMv1 4.2.2) is followed to the tag's array
+// (kd_bam_real_cigar, round 4; rounds 1 - 3 sent such a file to the host decoder).
 //
 //   k_bam_starts   wavefront per block   -> start[b]                      (first record that starts in block b, or NONE)
 //   k_bam_count    thread per block      -> kept records / packed-base bytes / CIGAR words of block b's part, chain check
@@ -28,7 +28,7 @@
 #define KD_INGEST_INFLATE 1u   // a block did not inflate
 #define KD_INGEST_RECORD 2u    // a malformed / truncated record on a walked chain
 #define KD_INGEST_CHAIN 4u     // a walk did not end on the next part's start (a start was guessed wrong)
-#define KD_INGEST_HOST 8u      // CG-tag CIGAR: the host decoder's business
+#define KD_INGEST_HOST 8u      // (unused since round 4: CG-tag CIGARs are read here)
 
 struct KdBam {
     const uint8_t *d;        // the inflated stream
@@ -134,6 +134,38 @@ __device__ __forceinline__ bool kd_bam_read(const KdBam &B, kd_u64 q, KdBamRec &
     return true;
 }
 
+// The CIGAR of the record at q (R = its fixed fields): count and absolute offset of its words.  A read with more than 65535
+// operations is stored with the placeholder <l_seq>S<ref_len>N in the record and the real CIGAR in a CG:B,I tag (SAMv1 4.2.2): the
+// auxiliary fields are walked for it (the host decoder's rule, kd_decode.cpp: real_cigar); without the tag the placeholder stands.
+__device__ __forceinline__ uint32_t kd_bam_real_cigar(const KdBam &B, kd_u64 q, const KdBamRec &R, kd_u64 &at) {
+    const uint8_t *r = B.d + q + 4;
+    at = q + 4 + 32 + R.l_rn;
+    if (R.n_cig != 2) return R.n_cig;
+    const uint32_t c0 = kd_rd32(r + 32 + R.l_rn), c1 = kd_rd32(r + 32 + R.l_rn + 4);
+    if ((c0 & 15u) != 4u || (c0 >> 4) != R.l_seq || (c1 & 15u) != 3u) return R.n_cig;
+    const kd_u64 bs = R.bs;
+    kd_u64 a = 32ull + R.l_rn + 8ull + ((kd_u64)R.l_seq + 1) / 2 + (kd_u64)R.l_seq;
+    while (a + 3 <= bs) {
+        const uint8_t t0 = r[a], t1 = r[a + 1], ty = r[a + 2];
+        a += 3;
+        kd_u64 len = 0;
+        if (ty == 'A' || ty == 'c' || ty == 'C') len = 1;
+        else if (ty == 's' || ty == 'S') len = 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
+        else if (ty == 'Z' || ty == 'H') { while (a + len < bs && r[a + len]) len++; len++; }
+        else if (ty == 'B') {
+            if (a + 5 > bs) return R.n_cig;
+            const uint8_t sub = r[a];
+            const uint32_t cnt = kd_rd32(r + a + 1);
+            const kd_u64 es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            if (t0 == 'C' && t1 == 'G' && sub == 'I' && a + 5 + 4ull * cnt <= bs) { at = q + 4 + a + 5; return cnt; }
+            len = 5 + es * (kd_u64)cnt;
+        } else return R.n_cig;   // unknown type: cannot skip it
+        a += len;
+    }
+    return R.n_cig;
+}
+
 __global__ void __launch_bounds__(KD_BLOCK)
 k_bam_count(KdBam B, const kd_u64 *start, const uint32_t *inflate_status, kd_u64 *cnt_rec, kd_u64 *cnt_seq, kd_u64 *cnt_cig, kd_u64 *n_seen,
             uint32_t *status) {
@@ -149,12 +181,8 @@ k_bam_count(KdBam B, const kd_u64 *start, const uint32_t *inflate_status, kd_u64
             if (!kd_bam_read(B, q, R)) { atomicOr(status, KD_INGEST_RECORD); q = B.n; break; }
             seen++;
             if (R.refid >= 0) {
-                kept++; sb += ((kd_u64)R.l_seq + 1) / 2; cw += R.n_cig;
-                if (R.n_cig == 2) {      // <l_seq>S<ref_len>N: the real CIGAR may sit in a CG:B,I tag (the host decoder looks)
-                    const uint8_t *cg = B.d + q + 4 + 32 + R.l_rn;
-                    const uint32_t c0 = kd_rd32(cg), c1 = kd_rd32(cg + 4);
-                    if ((c0 & 15u) == 4u && (c0 >> 4) == R.l_seq && (c1 & 15u) == 3u) atomicOr(status, KD_INGEST_HOST);
-                }
+                kd_u64 cg_at;
+                kept++; sb += ((kd_u64)R.l_seq + 1) / 2; cw += kd_bam_real_cigar(B, q, R, cg_at);
             }
             q += 4 + (kd_u64)R.bs;
         }
@@ -195,7 +223,8 @@ k_bam_scan(kd_u64 *a0, kd_u64 *a1, kd_u64 *a2, uint32_t n, kd_u64 *tot) {
 struct KdBamOut {
     uint32_t *contig; int32_t *pos0; uint32_t *flag; kd_u64 *seq_off; uint32_t *seq_len; kd_u64 *cig_off; uint32_t *n_cig;
     uint8_t *seq4; uint32_t *cigar;
-    kd_u64 *rec_at;          // scratch: offset of every kept record's body in the stream
+    kd_u64 *rec_at;          // scratch: offset of every kept record's packed bases in the stream,
+    kd_u64 *cig_at;          //   and of its CIGAR words (in the record, or the array of its CG:B,I tag)
 };
 
 __global__ void __launch_bounds__(KD_BLOCK)
@@ -209,9 +238,11 @@ k_bam_fields(KdBam B, const kd_u64 *start, const kd_u64 *rec_base, const kd_u64 
         KdBamRec R;
         if (!kd_bam_read(B, q, R)) return;       // (k_bam_count has reported it)
         if (R.refid >= 0) {
-            O.contig[k] = (uint32_t)R.refid; O.pos0[k] = R.pos; O.flag[k] = R.flag; O.seq_len[k] = R.l_seq; O.n_cig[k] = R.n_cig;
-            O.seq_off[k] = so; O.cig_off[k] = co; O.rec_at[k] = q + 4;
-            k++; so += ((kd_u64)R.l_seq + 1) / 2; co += R.n_cig;
+            kd_u64 cg_at;
+            const uint32_t nc = kd_bam_real_cigar(B, q, R, cg_at);
+            O.contig[k] = (uint32_t)R.refid; O.pos0[k] = R.pos; O.flag[k] = R.flag; O.seq_len[k] = R.l_seq; O.n_cig[k] = nc;
+            O.seq_off[k] = so; O.cig_off[k] = co; O.rec_at[k] = q + 4 + 32 + R.l_rn + 4ull * R.n_cig; O.cig_at[k] = cg_at;
+            k++; so += ((kd_u64)R.l_seq + 1) / 2; co += nc;
         }
         q += 4 + (kd_u64)R.bs;
     }
@@ -222,16 +253,15 @@ k_bam_fields(KdBam B, const kd_u64 *start, const kd_u64 *rec_base, const kd_u64 
 // the 64 records' output offsets (LDS).
 __global__ void __launch_bounds__(KD_WAVE)
 k_bam_payload(KdBam B, kd_u64 n_rec, KdBamOut O, kd_u64 seq_total, kd_u64 cig_total) {
-    __shared__ kd_u64 s_so[KD_WAVE + 1], s_co[KD_WAVE + 1], s_src[KD_WAVE];
+    __shared__ kd_u64 s_so[KD_WAVE + 1], s_co[KD_WAVE + 1], s_src[KD_WAVE], s_csrc[KD_WAVE];
     __shared__ uint32_t s_odd[KD_WAVE];
     const uint32_t lane = threadIdx.x;
     const kd_u64 i0 = (kd_u64)blockIdx.x * KD_WAVE, i = i0 + lane;
     const uint32_t cnt = (uint32_t)(n_rec - i0 < KD_WAVE ? n_rec - i0 : KD_WAVE);
     if (lane < cnt) {
         s_so[lane] = O.seq_off[i]; s_co[lane] = O.cig_off[i];
-        const kd_u64 at = O.rec_at[i];
-        const uint32_t l_rn = kd_rd32(B.d + at + 8) & 0xffu;
-        s_src[lane] = at + 32 + l_rn;                 // the record's CIGAR words; its bases follow them
+        s_src[lane] = O.rec_at[i];                    // the record's packed bases
+        s_csrc[lane] = O.cig_at[i];                   // its CIGAR words
         s_odd[lane] = O.seq_len[i] & 1u;
     }
     if (lane == 0) {   // the end of the wavefront's output ranges
@@ -246,12 +276,11 @@ k_bam_payload(KdBam B, kd_u64 n_rec, KdBamOut O, kd_u64 seq_total, kd_u64 cig_to
     };
     for (kd_u64 x = s_co[0] + lane; x < s_co[cnt]; x += KD_WAVE) {
         const uint32_t j = find(s_co, x);
-        O.cigar[x] = kd_rd32(B.d + s_src[j] + 4 * (x - s_co[j]));
+        O.cigar[x] = kd_rd32(B.d + s_csrc[j] + 4 * (x - s_co[j]));
     }
     for (kd_u64 x = s_so[0] + lane; x < s_so[cnt]; x += KD_WAVE) {
         const uint32_t j = find(s_so, x);
-        const kd_u64 n_cw = s_co[j + 1] - s_co[j];
-        uint8_t v = B.d[s_src[j] + 4 * n_cw + (x - s_so[j])];
+        uint8_t v = B.d[s_src[j] + (x - s_so[j])];
         if (s_odd[j] && x + 1 == s_so[j + 1]) v &= 0xf0u;      // the unused low nibble behind an odd-length read
         O.seq4[x] = v;
     }

@@ -459,9 +459,6 @@ __device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const
 #ifndef KD_DEEP_READS_PER_SITE
 #define KD_DEEP_READS_PER_SITE 12u   // a tile is DEEP when it holds this many candidates per start site
 #endif
-#ifndef KD_DYN_ROWS
-#define KD_DYN_ROWS 1  // rows of a tile handed out from a counter (0: every fourth row of every list)
-#endif
 #define KD_TILE 1024   // reads classified together (a multiple of KD_BLOCK)
 #define KD_TILE_PER_THREAD (KD_TILE / KD_BLOCK)
 #define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)2 * KD_TILE * 2)   // Wh = site pairs, halos included
@@ -534,10 +531,10 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
     // [tile parity][list]: 0 own plain entries that end inside the histogram (l_plain from the front), 1 own plain entries cut by
     // its end (l_plain from the back), 2 own complex entries (l_cplx from the front), 3 early / late entries (l_cplx from the back)
     __shared__ uint32_t s_cnt[2][4];
-    __shared__ uint32_t s_row[2];       // KD_DYN_ROWS: next row of the tile to hand out
+    __shared__ uint32_t s_row[2];       // next row of the tile to hand out
     __shared__ uint32_t s_gfirst[2], s_glast[2];   // G-starts of the tile's first and last candidate (a DEEP tile: see kd_walk_inner<true>)
     const uint32_t t = threadIdx.x;
-    const uint32_t lane = t & (KD_WAVE - 1), wave = t / KD_WAVE;
+    const uint32_t lane = t & (KD_WAVE - 1);
     const uint32_t nh = (uint32_t)KD_HCH * (uint32_t)Wh;   // histogram dwords
     const int32_t Wi = (int32_t)W, We = (int32_t)(W + H);     // the window / the histogram's reach, in sites
     uint32_t *hist_early = hist0 + (H / 2) * KD_HPITCH;       // pair of site wlo + H: origin of the early entries' walk (H is even)
@@ -724,7 +721,6 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
             // list entries l*rows + r: neighbours in a wavefront are `rows` reads apart in the sorted batch,
             // which keeps them off the same LDS counters in the same instruction.
             const uint32_t rows_i = (ni + KD_WAVE - 1) / KD_WAVE, rows_p = (np + KD_WAVE - 1) / KD_WAVE, rows_c = (ncx + KD_WAVE - 1) / KD_WAVE;
-#if KD_DYN_ROWS
             // ROWS HANDED OUT: a wavefront takes the next row of the tile from a counter -- the complex rows first (the longest), then
             // the plain rows inside the histogram, those cut by its end, the early / late ones -- instead of every fourth row of
             // every list: a wavefront whose rows waited longer for their bases takes fewer of them.
@@ -787,62 +783,6 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                     }
                 }
             }
-#else
-            for (uint32_t r = wave; r < rows_i; r += KD_WAVES_PER_BLOCK) {
-                const uint32_t e = lane * rows_i + r;
-                if (e < ni) {
-                    const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
-                    if (ROWS) kd_walk_row(rd, i, KD_RI(rinfo, rd, i), wlo, Wi, lane + 17u * r, hist0);
-                    else if (deep) kd_walk_inner<true>(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0, lane);
-                    else kd_walk_inner<false>(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0, 0u);
-                }
-            }
-            if (!ROWS) {
-            // (each list's rows start at the wavefront after the one that took the last row of the list before)
-            for (uint32_t r = (wave + KD_WAVES_PER_BLOCK - rows_i % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK; r < rows_p;
-                 r += KD_WAVES_PER_BLOCK) {
-                const uint32_t e = lane * rows_p + r;
-                if (e < np) {
-                    const kd_u64 j = tb + l_plain[KD_TILE - 1u - e], i = order ? (kd_u64)order[j] : j;
-                    kd_walk_plain(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0);
-                }
-            }
-            KD_MARK(c_plain)
-            // the complex rows start at the wavefront after the one that took the last plain row
-            for (uint32_t r = (wave + 2 * KD_WAVES_PER_BLOCK - (rows_i + rows_p) % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK; r < rows_c;
-                 r += KD_WAVES_PER_BLOCK) {
-                const uint32_t e = lane * rows_c + r;
-                if (e < ncx) {
-                    const kd_u64 j = tb + l_cplx[e], i = order ? (kd_u64)order[j] : j;
-                    const KdRInfo ri = KD_RI(rinfo, rd, i);
-                    const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);
-                    const int32_t foot_end = grel + (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
-                    if (!kd_walk_short(rd, i, ri, wlo, We, Wh, hist0)) {   // more than three segments: general walk
-                        kd_walk_ops(rd, i, ri.pad >> 24, 0u, ri.pad >> 24, grel, 0, (int32_t)ri.lead, foot_end, We, Wh, hist0);
-                    }
-                }
-            }
-            // early / late entries (rare: an entry longer than the histogram's reach, a leading clip across the window's left
-            // edge): the general walk, early ones against the origin wlo + H over W sites, late ones against [wlo, whi)
-            for (uint32_t r = (wave + 3 * KD_WAVES_PER_BLOCK - (rows_i + rows_p + rows_c) % KD_WAVES_PER_BLOCK) % KD_WAVES_PER_BLOCK;
-                 r * KD_WAVE < nx; r += KD_WAVES_PER_BLOCK) {
-                const uint32_t e = r * KD_WAVE + lane;
-                if (e < nx) {
-                    const uint32_t code = l_cplx[KD_TILE - 1u - e];
-                    const bool early = (code & 0x8000u) != 0;
-                    const kd_u64 j = tb + (code & 0x3fffu), i = order ? (kd_u64)order[j] : j;
-                    const KdRInfo ri = KD_RI(rinfo, rd, i);
-                    const bool shifted = early && w != 0;          // early entry of a window that has windows in front
-                    const kd_u64 org = shifted ? wlo + H : wlo;
-                    uint32_t *h0 = shifted ? hist_early : hist0;
-                    const int32_t Wx = (early && !shifted) ? We : Wi;
-                    const int32_t grel = (int32_t)(ri.gstart - (uint32_t)org);
-                    const int32_t foot_end = grel + (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
-                    kd_walk_ops(rd, i, ri.pad >> 24, 0u, ri.pad >> 24, grel, 0, (int32_t)ri.lead, foot_end, Wx, Wh, h0);
-                }
-            }
-            }   // !ROWS
-#endif
             KD_MARK(c_cplx)
             __syncthreads();
             KD_MARK(c_wait)

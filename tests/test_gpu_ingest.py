@@ -121,7 +121,7 @@ def test_files_for_the_host_decoder(emu_lib, api_on_emu, tmp_path, monkeypatch):
     open(sam, "w").write("@HD\tVN:1.6\n@SQ\tSN:c\tLN:100\nr1\t0\tc\t5\t60\t10M\t*\t0\t0\tACGTACGTAC\t*\n")
     with pytest.raises(N.UnsupportedByGpuIngest):
         N.BgzfPlan(sam, lib=emu_lib)
-    # a CIGAR of more than 65535 operations travels in a CG:B,I tag: the device walk sees the placeholder and says so
+    # a CIGAR of more than 65535 operations travels in a CG:B,I tag: the device walk follows the placeholder to the tag's array
     n_ops = 66000
     cig = np.empty(n_ops, np.uint32)
     cig[0::2] = (1 << 4) | 0
@@ -133,14 +133,10 @@ def test_files_for_the_host_decoder(emu_lib, api_on_emu, tmp_path, monkeypatch):
                  contig_lens=np.asarray([200000], np.uint32), contig_names=np.asarray(["c"]))
     p = str(tmp_path / "cg.bam")
     synth.write_bam(p, batch)
-    with N.BgzfPlan(p, lib=emu_lib) as plan:
-        eng = N.Engine(plan.contig_lens, lib=emu_lib)
-        with pytest.raises(N.UnsupportedByGpuIngest):
-            eng.push_bam_gpu(plan)
-        eng.close()
-    monkeypatch.setenv("KINDEL_INGEST", "gpu")        # ... and the API falls back to the host decoder, which spells the tag out
+    both_ways(emu_lib, p)                             # (the same batch, tables and insertions as the host decoder's)
+    monkeypatch.setenv("KINDEL_INGEST", "gpu")
     pl = kindel.pileup_file(p)
-    assert getattr(pl, "ingest", {}).get("path") != "gpu"
+    assert getattr(pl, "ingest", {}).get("path") == "gpu"
     assert int(np.asarray(pl.tables(0))[:5].sum()) == sl        # every base of the one read tallied (A / deleted site alternating)
 
 
