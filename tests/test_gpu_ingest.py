@@ -208,6 +208,19 @@ def test_gpu_ingest_on_the_gpu(hip_lib, tmp_path):
     q = str(tmp_path / "long.bam")
     synth.write_bam(q, lb, block_bytes=3000)
     both_ways(hip_lib, q)
+    # a read of 66 000 CIGAR operations: the placeholder in the record, the CIGAR in a CG:B,I tag (kd_bam_real_cigar on the device)
+    n_ops = 66000
+    cig = np.empty(n_ops, np.uint32)
+    cig[0::2] = (1 << 4) | 0
+    cig[1::2] = (1 << 4) | 2
+    sl = n_ops // 2
+    one = dict(contig=np.zeros(1, np.uint32), pos0=np.zeros(1, np.int32), flag=np.zeros(1, np.uint32), seq_off=np.zeros(1, np.uint64),
+               seq_len=np.asarray([sl], np.uint32), cig_off=np.zeros(1, np.uint64), n_cig=np.asarray([n_ops], np.uint32),
+               seq4=np.full((sl + 1) // 2 + 8, 0x11, np.uint8), cigar=np.concatenate([cig, np.zeros(2, np.uint32)]),
+               contig_lens=np.asarray([200000], np.uint32), contig_names=np.asarray(["c"]))
+    r = str(tmp_path / "cg.bam")
+    synth.write_bam(r, one)
+    assert both_ways(hip_lib, r)["kept"] == 1
 
 
 @pytest.mark.gpu
