@@ -201,7 +201,9 @@ int kd_changes_device(kd_ctx *ctx, void **dev_ptr);
  * calls that repeat the same batch (same pointers, sizes, seq_out, shard, tuning) replay the graph -- one launch instead of ~20
  * dispatches and two blocking read-backs -- and then verify on the device's status words and consensus offsets that the replay
  * took exactly the decisions the eager sequence would have taken (else the eager sequence runs).  *replayed (may be NULL): 1
- * if the graph served the call.  seq_out should be pinned host memory.  Errors as kd_finalize. */
+ * if the graph served the call.  seq_out should be pinned host memory (hipHostMalloc / hipHostRegister): with a pageable seq_out the
+ * step is never captured -- a graph's copy nodes may only point at page-locked memory -- and every call takes the eager sequence.
+ * Errors as kd_finalize. */
 int kd_step(kd_ctx *ctx, const kd_batch *dev_batch, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out,
             uint64_t *contig_off, int *replayed);
 /* kd_set_step_graph: on = 0: kd_step always takes the eager sequence (what a new batch takes anyway); on = 1 (default): the first

@@ -96,7 +96,9 @@ struct KdEngine {
     int step_mode = STEP_OFF;
     std::vector<std::vector<kd_u64>> step_status;   // the status read-backs of the recorded step, in order
     size_t step_pos = 0;
-    std::vector<uint64_t> step_meta, step_meta_seen, step_meta_up;   // consensus metadata: recorded / copied back by the graph / uploaded
+    std::vector<uint64_t> step_meta, step_meta_up;   // consensus metadata: recorded / uploaded
+    uint64_t *step_meta_pin = nullptr;               //   ... / copied back by the graph on every replay: PINNED (Runtime::graph_stage)
+    size_t step_meta_pin_bytes = 0;
     uint64_t step_sig[12] = {0};
     uint64_t step_fasta_len = 0;   // consensus bytes of the recorded step
     uint64_t step_last_sig[12] = {0};
@@ -1116,12 +1118,15 @@ struct KdEngine {
         if (step_mode == STEP_REPLAY) {
             // captured: the copies land when the graph runs (verified then); the host continues with the record
             if ((rc = fetch_status())) return rc;
-            step_meta_seen.assign(mb / 8, 0);
             if (step_meta.size() != mb / 8) return fail(KD_E_INTERNAL, "kd_step: recorded consensus metadata has another shape");
-            if (rt.d2h_async(step_meta_seen.data(), b_coff.p, mb)) return hipfail("consensus: d2h");
+            if (!step_meta_pin || step_meta_pin_bytes != mb) return fail(KD_E_INTERNAL, "kd_step: no pinned buffer for the replay's metadata");
+            // The two copies of a replay -- the run's metadata into pinned memory, the FASTA at its recorded length -- are NOT nodes of
+            // the graph: replay_copies() queues them behind every graph launch.  (With them inside, a graph that had been replayed
+            // fine faulted -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION -- on its next launch after ANOTHER user of the runtime had
+            // made a small pageable copy: torch's .cpu() between two steps, MI355X / ROCm 7.2; kernel and memset nodes are not affected.)
+            if (!step_in_capture) { int rcc = replay_copies(seq_out); if (rcc) return rcc; }
             meta = step_meta.data();
             guess = seq_out ? step_fasta_len : 0;     // (the recorded length: one exact copy)
-            if (guess && rt.d2h_async(seq_out, b_cns.p, guess)) return hipfail("consensus fetch: d2h");
         } else {
             uint8_t *st = (uint8_t *)rt.stage(KDS_COUNT * 8 + mb);
             if (!st) return hipfail("kd_finish: pinned staging");
@@ -1151,6 +1156,14 @@ struct KdEngine {
         return KD_OK;
     }
 
+    bool step_in_capture = false;
+    int replay_copies(uint8_t *seq_out) {
+        const size_t mb = meta_bytes();
+        if (rt.d2h_async(step_meta_pin, b_coff.p, mb)) return hipfail("consensus: d2h");      // (pinned: see Runtime::graph_stage)
+        if (seq_out && step_fasta_len && rt.d2h_async(seq_out, b_cns.p, step_fasta_len)) return hipfail("consensus fetch: d2h");
+        return KD_OK;
+    }
+
     // One step over a device-resident batch (kd_step): see step_mode above.  *replayed = 1 when the graph did it.
     int step(const kd_batch &B, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint64_t *contig_off, int *replayed) {
         if (replayed) *replayed = 0;
@@ -1171,9 +1184,20 @@ struct KdEngine {
                                         KDS_B_UNSORTED, KDS_B_N_COLD, KDS_B_N_IRREG, KDS_B_N_LONG, KDS_B_N_REG, KDS_INS_COLLISION, KDS_INTERNAL,
                                         KDS_BAD_BASE};
         if (step_have && rt.has_graph() && !memcmp(sig, step_sig, sizeof sig) && !step_status.empty()) {
-            if (!rt.graph_launch() && !rt.sync()) {
+            // (knob, fault localisation: KD_STEP_REPLAY_EAGER=1 submits the recorded sequence kernel by kernel -- the same launches with the
+            // same recorded host decisions as the graph holds, but visible to KD_LAUNCH_TRACE -- instead of launching the graph)
+            static const bool replay_eager = getenv("KD_STEP_REPLAY_EAGER") != nullptr;
+            bool ran = false;
+            if (replay_eager) {
+                step_mode = STEP_REPLAY; step_pos = 0;
+                const int rce = sequence();
+                step_mode = STEP_OFF;
+                ran = rce == KD_OK && !rt.sync();
+            } else ran = !rt.graph_launch() && replay_copies(seq_out) == KD_OK && !rt.sync();
+            if (ran) {
                 std::vector<kd_u64> now(KDS_COUNT, 0);
-                bool same = !rt.d2h_small(now.data(), d_status, KDS_COUNT * 8) && step_meta_seen == step_meta;
+                bool same = !rt.d2h_small(now.data(), d_status, KDS_COUNT * 8) && step_meta_pin && step_meta_pin_bytes == step_meta.size() * 8 &&
+                            !memcmp(step_meta_pin, step_meta.data(), step_meta_pin_bytes);
                 for (int w : kDecisive) same = same && now[w] == step_status.back()[w];
                 if (same) {
                     // host state as the recorded sequence left it (the capture pass ran the same host code)
@@ -1196,11 +1220,17 @@ struct KdEngine {
         const bool repeat = !memcmp(sig, step_last_sig, sizeof sig);
         memcpy(step_last_sig, sig, sizeof sig);
         if (rc || !rt.graph_supported() || step_record_bad || !repeat || !step_graph) return rc;
+        if (!rt.is_pinned(seq_out)) return rc;      // the graph's copy nodes must point at page-locked memory (Runtime::graph_stage): a pageable `seq_out` keeps the step eager
         // the same sequence once more, captured: every host read answered from the record, nothing executes
+        step_meta_pin_bytes = meta_bytes();
+        step_meta_pin = (uint64_t *)rt.graph_stage(step_meta_pin_bytes);      // (allocated in front of the capture, not inside it)
+        if (!step_meta_pin) return KD_OK;                                      // no pinned memory: no graph, the step stays eager
         step_mode = STEP_REPLAY; step_pos = 0;
         int rc2 = rt.capture_begin() ? 1 : 0;
         if (!rc2) {
+            step_in_capture = true;
             rc2 = sequence();
+            step_in_capture = false;
             if (rt.capture_end(rc2 == KD_OK && step_pos == step_status.size())) rc2 = rc2 ? rc2 : 1;
         }
         step_mode = STEP_OFF;

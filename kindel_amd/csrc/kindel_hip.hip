@@ -47,6 +47,7 @@ struct HipRt {
         graph_drop();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; }
         if (stage_buf) { (void)hipHostFree(stage_buf); stage_buf = nullptr; stage_cap = 0; }
+        if (graph_pin) { (void)hipHostFree(graph_pin); graph_pin = nullptr; graph_pin_cap = 0; }
         for (int k = 0; k < 2; k++) { if (up_pin[k]) { (void)hipHostFree(up_pin[k]); up_pin[k] = nullptr; } if (up_ev[k]) { (void)hipEventDestroy(up_ev[k]); up_ev[k] = nullptr; } }
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
         if (ev_copy) { (void)hipEventDestroy(ev_copy); ev_copy = nullptr; }
@@ -144,6 +145,30 @@ struct HipRt {
         if (bad(hipHostMalloc(&stage_buf, n, hipHostMallocDefault))) { stage_buf = nullptr; return nullptr; }
         stage_cap = n;
         return stage_buf;
+    }
+
+    // a second pinned buffer, for what a captured graph copies back on every replay (the run's metadata): a memcpy node whose
+    // destination is PAGEABLE host memory goes through the runtime's staging, which other users of the runtime (a torch .cpu()
+    // between two replays) can pull from under it -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on the next launch, seen on MI355X
+    void *graph_pin = nullptr;
+    size_t graph_pin_cap = 0;
+    void *graph_stage(size_t bytes) {
+        if (bytes <= graph_pin_cap) return graph_pin;
+        if (bad(hipSetDevice(dev))) return nullptr;
+        if (graph_pin) { (void)hipStreamSynchronize(stream); (void)hipHostFree(graph_pin); graph_pin = nullptr; graph_pin_cap = 0; }
+        const size_t n = (bytes + 65535) & ~(size_t)65535;
+        if (bad(hipHostMalloc(&graph_pin, n, hipHostMallocDefault))) { graph_pin = nullptr; return nullptr; }
+        graph_pin_cap = n;
+        return graph_pin;
+    }
+
+    // is p page-locked host memory the runtime knows (hipHostMalloc / hipHostRegister; torch's pin_memory)?  A graph's copy node
+    // may only point at such memory (above).
+    bool is_pinned(const void *p) {
+        if (!p) return true;
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeHost;
     }
 
     // small readbacks (the status words, one cache line each: 4 KiB, 5 KiB in a profiling build) go through a pinned bounce buffer:

@@ -46,6 +46,9 @@ struct EmuRt {
     int sync() { return 0; }
     std::vector<unsigned char> stage_buf;
     void *stage(size_t bytes) { if (stage_buf.size() < bytes) stage_buf.resize(bytes); return stage_buf.data(); }
+    bool is_pinned(const void *) { return true; }
+    std::vector<unsigned char> graph_buf;
+    void *graph_stage(size_t bytes) { if (graph_buf.size() < bytes) graph_buf.resize(bytes); return graph_buf.data(); }
     int d2h_async(void *h, const void *d, size_t n) { ::memcpy(h, d, n); return 0; }
     // (no graphs here: kd_step always takes the eager path on the emulator)
     bool graph_supported() const { return false; }
