@@ -461,7 +461,10 @@ __device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const
 #endif
 #define KD_TILE 1024   // reads classified together (a multiple of KD_BLOCK)
 #define KD_TILE_PER_THREAD (KD_TILE / KD_BLOCK)
-#define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)2 * KD_TILE * 2)   // Wh = site pairs, halos included
+#ifndef KD_LIST_CARRY
+#define KD_LIST_CARRY 1   // list 0 carries every entry's window-relative start and length (no second fetch of its footprint record)
+#endif
+#define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)KD_TILE * 4 + (size_t)KD_TILE * 2)   // Wh = site pairs, halos included; lists: u32 + u16 per tile slot
 
 #define KD_WINDOW_OCC 5   // workgroups per CU the register budget is set for (= what the LDS footprint allows; 6 / 7 measured: slower, scratch)
 // k_window's WORK QUEUE (round 4: the kernel plans for itself).  Rounds 1 - 3 planned in two kernels of their own -- a binary
@@ -524,8 +527,11 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
     KD_DYN_SHARED(uint32_t, hist);
     const int32_t Wh = (int32_t)Wh_;   // dwords per channel row (two u16 counters each, halos included; >= (W + 2*KD_HALO)/2)
     uint32_t *hist0 = hist + (KD_HALO / 2) * KD_HPITCH;   // pair of window-relative site 0
-    uint16_t *l_plain = reinterpret_cast<uint16_t *>(hist + (size_t)KD_HCH * Wh);  // tile-relative read indices
-    uint16_t *l_cplx = l_plain + KD_TILE;
+    // list entries: tile-relative read indices; list 0 (plain reads inside the histogram) also carries the read's window-relative
+    // start (bits 10-19) and length (bits 20-31), which the classification has in registers: the walker does not fetch the
+    // footprint record a second time
+    uint32_t *l_plain = hist + (size_t)KD_HCH * Wh;
+    uint16_t *l_cplx = reinterpret_cast<uint16_t *>(l_plain + KD_TILE);
     __shared__ kd_u64 s_first, s_last;
     __shared__ uint32_t s_win;
     // [tile parity][list]: 0 own plain entries that end inside the histogram (l_plain from the front), 1 own plain entries cut by
@@ -685,13 +691,13 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                 }
                 if (ROWS) {
                     if ((p_sc[u] & 3u) == KD_CLS_REG && gs < whi && gs + span > wlo)
-                        l_plain[atomicAdd(&s_cnt[par][0], 1u)] = (uint16_t)(u * KD_BLOCK + t);
+                        l_plain[atomicAdd(&s_cnt[par][0], 1u)] = u * KD_BLOCK + t;
                 } else if ((p_sc[u] & 3u) == KD_CLS_REG) {
                     const uint32_t rel = u * KD_BLOCK + t;
                     if (gs >= wlo && gs < whi) {             // starts here: this window's own
                         if (!(p_sc[u] & KD_INFO_PLAIN)) l_cplx[atomicAdd(&s_cnt[par][2], 1u)] = (uint16_t)rel;
-                        else if (gs + span <= whi + H) l_plain[atomicAdd(&s_cnt[par][0], 1u)] = (uint16_t)rel;
-                        else l_plain[KD_TILE - 1u - atomicAdd(&s_cnt[par][1], 1u)] = (uint16_t)rel;
+                        else if (gs + span <= whi + H) l_plain[atomicAdd(&s_cnt[par][0], 1u)] = rel | (uint32_t)(gs - wlo) << 10 | (uint32_t)span << 20;
+                        else l_plain[KD_TILE - 1u - atomicAdd(&s_cnt[par][1], 1u)] = rel;
                     } else if (gs < wlo) {                   // starts in a window in front: what its owner(s) left of it for this one
                         // (the FIRST window of a shard's plan has no window in front: it takes such entries from its own first site)
                         if (gs + span > wlo + (w ? H : 0u)) l_cplx[KD_TILE - 1u - atomicAdd(&s_cnt[par][3], 1u)] = (uint16_t)(rel | 0x8000u);
@@ -748,10 +754,14 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                 if (rr < rows_i) {
                     const uint32_t r = rr, e = lane * rows_i + r;
                     if (e < ni) {
-                        const kd_u64 j = tb + l_plain[e], i = order ? (kd_u64)order[j] : j;
-                        if (ROWS) kd_walk_row(rd, i, KD_RI(rinfo, rd, i), wlo, Wi, lane + 17u * r, hist0);
-                        else if (deep) kd_walk_inner<true>(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0, lane);
-                        else kd_walk_inner<false>(rd, i, KD_RI(rinfo, rd, i), wlo, We, Wh, hist0, 0u);
+                        const uint32_t le = l_plain[e];
+                        const kd_u64 j = tb + (le & 1023u), i = order ? (kd_u64)order[j] : j;
+                        KdRInfo ri;
+                        if (ROWS || !KD_LIST_CARRY) ri = KD_RI(rinfo, rd, i);
+                        else { ri.gstart = (uint32_t)wlo + ((le >> 10) & 1023u); ri.span_cls = (le >> 20) << KD_SPAN_SHIFT; ri.lead = 0; ri.pad = 0; }
+                        if (ROWS) kd_walk_row(rd, i, ri, wlo, Wi, lane + 17u * r, hist0);
+                        else if (deep) kd_walk_inner<true>(rd, i, ri, wlo, We, Wh, hist0, lane);
+                        else kd_walk_inner<false>(rd, i, ri, wlo, We, Wh, hist0, 0u);
                     }
                     continue;
                 }
