@@ -403,6 +403,9 @@ struct KdEngine {
                     return std::max(1u, (unsigned)rt.n_cus() * (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (l + 64))));
                 };
                 uint32_t w0;
+                // the default window keeps window + reach at 640 sites (448 + 192 for 150-base reads, 384 + 256 for 250-base ones, 512 + 128
+                // for 100-base ones): the LDS footprint that lets five workgroups share a CU
+                if (!this->W && !use_coop && !rows && H) W = 640u - H;
                 if (!this->W && !use_coop && !rows) {
                     // A SMALL shard (1/8 of C3 on one of eight GPUs: 1395 windows of 448 sites on 1280 resident workgroups): a few windows
                     // left over for a second, thin round cost a window's whole latency.  A wider window that puts every window into

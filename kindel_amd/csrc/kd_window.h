@@ -464,7 +464,8 @@ __device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const
 #ifndef KD_LIST_CARRY
 #define KD_LIST_CARRY 1   // list 0 carries every entry's window-relative start and length (no second fetch of its footprint record)
 #endif
-#define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)KD_TILE * 4 + (size_t)KD_TILE * 2)   // Wh = site pairs, halos included; lists: u32 + u16 per tile slot
+#define KD_CMETA 352u    // complex entries whose footprint the list carries too (what the LDS of five workgroups per CU has room for)
+#define KD_WINDOW_LDS_BYTES(Wh) ((size_t)KD_HCH * (Wh) * 4 + (size_t)KD_TILE * 4 + (size_t)KD_TILE * 2 + (size_t)KD_CMETA * 4)   // Wh = site pairs, halos included; lists: u32 + u16 per tile slot + the complex entries' footprints
 
 #define KD_WINDOW_OCC 5   // workgroups per CU the register budget is set for (= what the LDS footprint allows; 6 / 7 measured: slower, scratch)
 // k_window's WORK QUEUE (round 4: the kernel plans for itself).  Rounds 1 - 3 planned in two kernels of their own -- a binary
@@ -532,6 +533,9 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
     // footprint record a second time
     uint32_t *l_plain = hist + (size_t)KD_HCH * Wh;
     uint16_t *l_cplx = reinterpret_cast<uint16_t *>(l_plain + KD_TILE);
+    // the first KD_CMETA complex entries' footprints: window-relative start (bits 0-9), span (10-19), leading clip's reach (20-26),
+    // CIGAR words (27-31); ~0: does not fit, the walker fetches the record
+    uint32_t *l_cmeta = reinterpret_cast<uint32_t *>(l_cplx + KD_TILE);
     __shared__ kd_u64 s_first, s_last;
     __shared__ uint32_t s_win;
     // [tile parity][list]: 0 own plain entries that end inside the histogram (l_plain from the front), 1 own plain entries cut by
@@ -663,14 +667,14 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
         const kd_u64 first = s_first, last = s_last;
         // The classification keys (start, span | flags, lead) of a tile are fetched ONE TILE AHEAD into registers:
         // the loads of tile k + 1 are in flight while tile k is walked.  `order`: bucket-sorted permutation.
-        uint32_t p_gs[KD_TILE_PER_THREAD], p_sc[KD_TILE_PER_THREAD], p_ld[KD_TILE_PER_THREAD];
+        uint32_t p_gs[KD_TILE_PER_THREAD], p_sc[KD_TILE_PER_THREAD], p_ld[KD_TILE_PER_THREAD];   // (p_ld: the leading clip's reach, the CIGAR word count in its top byte)
 #pragma unroll
         for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
             const kd_u64 j = first + u * KD_BLOCK + t;
             p_sc[u] = KD_CLS_SKIP; p_gs[u] = 0; p_ld[u] = 0;
             if (j < last) {
                 const KdRInfo ri = KD_RI(rinfo, rd, order ? (kd_u64)order[j] : j);
-                p_gs[u] = ri.gstart; p_sc[u] = ri.span_cls; p_ld[u] = ri.lead;
+                p_gs[u] = ri.gstart; p_sc[u] = ri.span_cls; p_ld[u] = (ri.lead & 0xffffffu) | (ri.pad & 0xff000000u);
             }
         }
         {   // Wh is a multiple of 4 (W is a multiple of 64): zero with 16-byte stores
@@ -695,13 +699,23 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                 } else if ((p_sc[u] & 3u) == KD_CLS_REG) {
                     const uint32_t rel = u * KD_BLOCK + t;
                     if (gs >= wlo && gs < whi) {             // starts here: this window's own
-                        if (!(p_sc[u] & KD_INFO_PLAIN)) l_cplx[atomicAdd(&s_cnt[par][2], 1u)] = (uint16_t)rel;
+                        if (!(p_sc[u] & KD_INFO_PLAIN)) {
+                            const uint32_t slot = atomicAdd(&s_cnt[par][2], 1u);
+                            l_cplx[slot] = (uint16_t)rel;
+#if KD_LIST_CARRY
+                            if (slot < KD_CMETA) {
+                                const uint32_t nc = p_ld[u] >> 24, ld = p_ld[u] & 0xffffffu;
+                                l_cmeta[slot] = (span < 1024u && ld < 128u && nc < 32u)
+                                                    ? (uint32_t)(gs - wlo) | (uint32_t)span << 10 | ld << 20 | nc << 27 : 0xffffffffu;
+                            }
+#endif
+                        }
                         else if (gs + span <= whi + H) l_plain[atomicAdd(&s_cnt[par][0], 1u)] = rel | (uint32_t)(gs - wlo) << 10 | (uint32_t)span << 20;
                         else l_plain[KD_TILE - 1u - atomicAdd(&s_cnt[par][1], 1u)] = rel;
                     } else if (gs < wlo) {                   // starts in a window in front: what its owner(s) left of it for this one
                         // (the FIRST window of a shard's plan has no window in front: it takes such entries from its own first site)
                         if (gs + span > wlo + (w ? H : 0u)) l_cplx[KD_TILE - 1u - atomicAdd(&s_cnt[par][3], 1u)] = (uint16_t)(rel | 0x8000u);
-                    } else if (gs - p_ld[u] < whi) {         // starts behind: its leading clip reaches back into this window
+                    } else if (gs - (p_ld[u] & 0xffffffu) < whi) {         // starts behind: its leading clip reaches back into this window
                         l_cplx[KD_TILE - 1u - atomicAdd(&s_cnt[par][3], 1u)] = (uint16_t)(rel | 0x4000u);
                     }
                 }
@@ -720,7 +734,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                 p_sc[u] = KD_CLS_SKIP;
                 if (j < last) {
                     const KdRInfo ri = KD_RI(rinfo, rd, order ? (kd_u64)order[j] : j);
-                    p_gs[u] = ri.gstart; p_sc[u] = ri.span_cls; p_ld[u] = ri.lead;
+                    p_gs[u] = ri.gstart; p_sc[u] = ri.span_cls; p_ld[u] = (ri.lead & 0xffffffu) | (ri.pad & 0xff000000u);
                 }
             }
             // homogeneous wavefronts: first the plain reads, then the complex ones.  Lane l of a wavefront takes
@@ -741,7 +755,10 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                     const uint32_t r = rr, e = lane * rows_c + r;
                     if (e < ncx) {
                         const kd_u64 j = tb + l_cplx[e], i = order ? (kd_u64)order[j] : j;
-                        const KdRInfo ri = KD_RI(rinfo, rd, i);
+                        KdRInfo ri;
+                        const uint32_t cm = (KD_LIST_CARRY && e < KD_CMETA) ? l_cmeta[e] : 0xffffffffu;
+                        if (cm == 0xffffffffu) ri = KD_RI(rinfo, rd, i);
+                        else { ri.gstart = (uint32_t)wlo + (cm & 1023u); ri.span_cls = ((cm >> 10) & 1023u) << KD_SPAN_SHIFT; ri.lead = (cm >> 20) & 127u; ri.pad = (cm >> 27) << 24; }
                         const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);
                         const int32_t foot_end = grel + (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
                         if (!kd_walk_short(rd, i, ri, wlo, We, Wh, hist0)) {   // more than three segments: general walk
