@@ -459,7 +459,9 @@ __device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const
 #ifndef KD_DEEP_READS_PER_SITE
 #define KD_DEEP_READS_PER_SITE 12u   // a tile is DEEP when it holds this many candidates per start site
 #endif
+#ifndef KD_TILE
 #define KD_TILE 1024   // reads classified together (a multiple of KD_BLOCK)
+#endif
 #define KD_TILE_PER_THREAD (KD_TILE / KD_BLOCK)
 #ifndef KD_LIST_CARRY
 #define KD_LIST_CARRY 1   // list 0 carries every entry's window-relative start and length (no second fetch of its footprint record)
