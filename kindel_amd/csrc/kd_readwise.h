@@ -160,7 +160,9 @@ k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const KdColdRec *rec, const uint32_
     // offset): the kernel is a chain of dependent round trips otherwise
     const uint32_t *cg = rd.cigar + cr.cig_off;
     const KdChunk pre = kd_load_cigar4(cg, 0u, nc);
-    const uint8_t *seq = rd.seq4 + rd.seq_off[i];
+    // (the packed bases are only read for insertions: a read that is merely clipped does not ask where they lie -- one request to
+    // a line of its own less for half of the records)
+    const uint8_t *seq = rd.seq4 + ((cr.len_ops & KD_COLD_HAS_INS) ? rd.seq_off[i] : 0ULL);
     kd_u64 ev_next = ev_base + cr.ev_rel, pool_next = pool_base + cr.pool_rel;   // (unused by a read without insertions)
     const int64_t L = T.contig_len[c];
     const kd_u64 cb = T.contig_base[c];
