@@ -398,6 +398,7 @@ struct KdEngine {
                 // (a row is thousands of sites long: every window tallies its own part of it, H = 0)
                 uint32_t H = (use_coop || rows) ? 0u : (uint32_t)std::min<uint64_t>(256, (h_status[span_slot] + 63) & ~uint64_t(63));
                 while (H && KD_WINDOW_LDS_BYTES((W + H + 2 * KD_HALO) / 2) > (size_t)160 * 1024 - 1024) H -= 64;   // (a hand-picked window near the LDS limit)
+                while (!use_coop && W > 64 && KD_WINDOW_LDS_BYTES((W + H + 2 * KD_HALO) / 2) > (size_t)160 * 1024 - 1024) W -= 64;   // (... or beyond it)
                 auto grid_of = [&](uint32_t Wx) {
                     const size_t l = KD_WINDOW_LDS_BYTES((Wx + H + 2 * KD_HALO) / 2);
                     return std::max(1u, (unsigned)rt.n_cus() * (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024 - 512) / (l + 64))));

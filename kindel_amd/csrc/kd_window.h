@@ -707,12 +707,13 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
 #if KD_LIST_CARRY
                             if (slot < KD_CMETA) {
                                 const uint32_t nc = p_ld[u] >> 24, ld = p_ld[u] & 0xffffffu;
-                                l_cmeta[slot] = (span < 1024u && ld < 128u && nc < 32u)
+                                l_cmeta[slot] = (gs - wlo < 1024u && span < 1024u && ld < 128u && nc < 32u)
                                                     ? (uint32_t)(gs - wlo) | (uint32_t)span << 10 | ld << 20 | nc << 27 : 0xffffffffu;
                             }
 #endif
                         }
-                        else if (gs + span <= whi + H) l_plain[atomicAdd(&s_cnt[par][0], 1u)] = rel | (uint32_t)(gs - wlo) << 10 | (uint32_t)span << 20;
+                        else if (gs + span <= whi + H)      // (a start or a length beyond the fields -- a hand-picked window of more than 1024 sites -- is not carried: length 0)
+                            l_plain[atomicAdd(&s_cnt[par][0], 1u)] = (gs - wlo < 1024u && span < 4096u) ? rel | (uint32_t)(gs - wlo) << 10 | (uint32_t)span << 20 : rel;
                         else l_plain[KD_TILE - 1u - atomicAdd(&s_cnt[par][1], 1u)] = rel;
                     } else if (gs < wlo) {                   // starts in a window in front: what its owner(s) left of it for this one
                         // (the FIRST window of a shard's plan has no window in front: it takes such entries from its own first site)
@@ -776,7 +777,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                         const uint32_t le = l_plain[e];
                         const kd_u64 j = tb + (le & 1023u), i = order ? (kd_u64)order[j] : j;
                         KdRInfo ri;
-                        if (ROWS || !KD_LIST_CARRY) ri = KD_RI(rinfo, rd, i);
+                        if (ROWS || !KD_LIST_CARRY || (le >> 20) == 0u) ri = KD_RI(rinfo, rd, i);
                         else { ri.gstart = (uint32_t)wlo + ((le >> 10) & 1023u); ri.span_cls = (le >> 20) << KD_SPAN_SHIFT; ri.lead = 0; ri.pad = 0; }
                         if (ROWS) kd_walk_row(rd, i, ri, wlo, Wi, lane + 17u * r, hist0);
                         else if (deep) kd_walk_inner<true>(rd, i, ri, wlo, We, Wh, hist0, lane);

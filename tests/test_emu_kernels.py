@@ -117,6 +117,16 @@ def test_few_deep_windows_take_the_static_queue(emu_lib):
     P.assert_matches_oracle(P.Run(emu_lib, two, window=256, slice_reads=64))
 
 
+def test_hand_picked_windows_beyond_the_list_fields(emu_lib):
+    """k_window's lists carry a read's window-relative start in 10 bits (kd_window.h): with a hand-picked window of more than 1024 sites
+    the entries that do not fit are not carried (the walker fetches the footprint record), and a window too wide for the LDS is cut
+    down by the engine -- every table against the oracle."""
+    b = synth.to_numpy(synth.short_reads([7000], 40, seed=44))
+    for window in (1024, 2048, 4096):
+        P.assert_matches_oracle(P.Run(emu_lib, b, window=window))
+        P.assert_matches_oracle(P.Run(emu_lib, b, window=window, slice_reads=300))
+
+
 def test_multiple_pushes_accumulate(emu_lib):
     b = P.subset(P.load_fixture("segemehl__2.1.sub_test"), 100, 700)
     P.assert_matches_oracle(P.Run(emu_lib, b, window=256, n_pushes=3))
