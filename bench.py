@@ -174,6 +174,9 @@ def main():
         pinned_np = pinned.numpy()
 
         state = {}
+        # N > 1: the exchange row is registered with the engine (kd_set_exchange): kd_step leaves this rank's row -- header, contig
+        # offsets, depth ranges, change codes, consensus bytes -- in device memory on its way, the step's collective is all that follows
+        exch = shard.Exchange(eng, interval, dev, intervals=intervals).attach() if world > 1 else None
 
         def step(graph=False, classic=False):
             if classic:
@@ -194,8 +197,8 @@ def main():
                 off, state["replayed"] = eng.step_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"], pinned_np)
             seqs = [pinned_np[int(off[c]): int(off[c + 1])] for c in range(n_contigs)]
             # ... and, at N > 1, the all-gather that leaves the stitched consensus in every GPU's HBM
-            if world > 1:
-                state["gathered"] = shard.gather(eng, interval, dev, intervals=intervals)[0]   # one fixed-size all-gather (RCCL over xGMI)
+            if world > 1:   # one fixed-size all-gather (RCCL over xGMI); the classic call sequence does not fill the row: on demand there
+                state["gathered"] = exch.run() if classic else exch.collect()
             return seqs
 
         def barrier():
@@ -257,6 +260,7 @@ def main():
         info = eng.batch_info()
         stats = eng.stats()
         if world > 1:   # host assembly of the stitched FASTA, outside the timed region (checksum only)
+            assert exch.need(state["gathered"]) <= exch.pad, "an exchange row did not fit its agreed size"
             rows = np.ascontiguousarray(state["gathered"].cpu().numpy())
             seqs, _, _ = shard.assemble(rows, contig_lens, world, intervals=intervals)
         seqs = [bytes(memoryview(x)) for x in seqs]

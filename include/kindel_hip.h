@@ -195,6 +195,18 @@ int kd_consensus_device(kd_ctx *ctx, void **dev_ptr, uint64_t *n_bytes);
 /* Same for the per-site change codes: *dev_ptr + g = the change code of G-space site g, valid for the sites of the context's
  * interval [g_lo, g_hi) only (the array is shard-local like the tables; the pointer is biased to G-space indexing). */
 int kd_changes_device(kd_ctx *ctx, void **dev_ptr);
+/* The EXCHANGE ROW of this context's shard -- what the multi-GPU all-gather moves (kindel_amd/shard.py; the stitch of the
+ * per-contig loop kindel.py:515-551 across ranks) -- written by the context into a caller's DEVICE buffer of cap bytes:
+ *   u64 row_bytes | u64 0 | contig_off u64[n_contigs + 1] | depth min / max u32[2 n_contigs] | change codes of the shard's
+ *   sites [g_lo, g_hi) | consensus bytes (kd_consensus_device's)
+ * row_bytes > cap: the row did not fit, only its 16-byte header is there (every rank reads that in the gathered rows and the
+ * gather is repeated with the announced size).  kd_exchange_row: on demand after kd_consensus_run / kd_finish / kd_step;
+ * complete when it returns.  kd_set_exchange: registers a row that kd_finish and kd_step then fill on their way -- the two
+ * device-to-device copies queued behind the consensus kernels, the header with the run's collected metadata -- so that a
+ * multi-GPU step is kd_step + ONE collective; complete when kd_finish / kd_step return.  dev_row = NULL unregisters.  A step
+ * with a registered row always takes the eager sequence (no hipGraph).  cap >= 16. */
+int kd_exchange_row(kd_ctx *ctx, void *dev_row, uint64_t cap, uint64_t *row_bytes);
+int kd_set_exchange(kd_ctx *ctx, void *dev_row, uint64_t cap);
 /* One whole step over a DEVICE-resident batch in one call: kd_reset + kd_push_batch_device + kd_finalize + kd_consensus_run (no
  * patches) + kd_consensus_fetch_all(seq_out ...), i.e. parse_records' loop and consensus_sequence's loop (kindel.py:40-81,
  * :384-430) for every contig of the batch.  The first call with a given batch runs that sequence and captures it as a hipGraph;

@@ -27,7 +27,7 @@ KD_MODE_AUTO, KD_MODE_GLOBAL, KD_MODE_WINDOW, KD_MODE_STRIP, KD_MODE_COOP = 0, 1
 ABI_SYMBOLS = (
     "kd_abi_version kd_create kd_destroy kd_last_error kd_reset kd_set_mode kd_set_tuning kd_get_tuning kd_contig_base "
     "kd_total_sites kd_set_shard kd_push_batch kd_push_batch_device kd_sync kd_finalize kd_get_stats "
-    "kd_get_batch_info kd_get_tables kd_get_insertions kd_consensus_run kd_consensus_fetch kd_consensus_fetch_all kd_consensus_device kd_changes_device kd_consensus_offsets "
+    "kd_get_batch_info kd_get_tables kd_get_insertions kd_consensus_run kd_consensus_fetch kd_consensus_fetch_all kd_consensus_device kd_changes_device kd_consensus_offsets kd_exchange_row kd_set_exchange "
     "kd_profile_enable kd_profile_get kd_profile_reset kd_decode_open kd_decode_batch kd_decode_n_contigs "
     "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error "
     "kd_stream_open kd_stream_n_contigs kd_stream_contig_name kd_stream_contig_len kd_stream_next kd_stream_n_records "
@@ -97,6 +97,8 @@ class Library:
         L.kd_consensus_fetch.argtypes = [p, u32, p, u64, C.POINTER(u64), p, p, p]
         L.kd_consensus_device.argtypes = [p, C.POINTER(p), C.POINTER(u64)]
         L.kd_changes_device.argtypes = [p, C.POINTER(p)]
+        L.kd_exchange_row.argtypes = [p, p, u64, C.POINTER(u64)]
+        L.kd_set_exchange.argtypes = [p, p, u64]
         L.kd_consensus_offsets.argtypes = [p, p, p]
         L.kd_consensus_fetch_all.argtypes = [p, p, u64, C.POINTER(u64), p, p]
         L.kd_step.argtypes = [p, C.POINTER(kd_batch), u32, p, u64, C.POINTER(u64), p, C.POINTER(C.c_int)]
@@ -488,6 +490,11 @@ class Engine:
 
     def set_shard(self, g_lo, g_hi):
         self._check(self.lib.dll.kd_set_shard(self._h, g_lo, g_hi), "kd_set_shard")
+        self._shard = (int(g_lo), int(g_hi))
+
+    def shard_interval(self):
+        """The emit interval [g_lo, g_hi) of this context (all of G-space unless set_shard was called)."""
+        return getattr(self, "_shard", None) or (0, self.total_sites())
 
     def reset(self):
         self._check(self.lib.dll.kd_reset(self._h), "kd_reset")
@@ -680,6 +687,17 @@ class Engine:
         p = C.c_void_p()
         self._check(self.lib.dll.kd_changes_device(self._h, C.byref(p)), "kd_changes_device")
         return p.value
+
+    def exchange_row(self, dev_ptr, cap):
+        """This shard's exchange row (kindel_hip.h: kd_exchange_row) into `cap` bytes of device memory at dev_ptr -> row bytes
+        (> cap: it did not fit, only the header was written)."""
+        n = C.c_uint64(0)
+        self._check(self.lib.dll.kd_exchange_row(self._h, C.c_void_p(dev_ptr), cap, C.byref(n)), "kd_exchange_row")
+        return n.value
+
+    def set_exchange(self, dev_ptr, cap):
+        """Register (dev_ptr = 0 / None: unregister) the device buffer kd_finish / kd_step leave the exchange row in."""
+        self._check(self.lib.dll.kd_set_exchange(self._h, C.c_void_p(dev_ptr or None), cap if dev_ptr else 0), "kd_set_exchange")
 
     def consensus_offsets(self):
         """-> (contig_off uint64[n+1], depth_minmax uint32[n,2]) of the last consensus_run"""

@@ -143,6 +143,16 @@ int kd_changes_device(kd_ctx *ctx, void **dev_ptr) {
     *dev_ptr = (uint8_t *)ctx->e.b_changes.p - ctx->e.alloc_lo;
     return KD_OK;
 }
+int kd_set_exchange(kd_ctx *ctx, void *dev_row, uint64_t cap) {
+    if (!ctx || (dev_row && cap < 16)) return KD_E_ARG;
+    ctx->e.exch_row = (uint8_t *)dev_row; ctx->e.exch_cap = dev_row ? cap : 0;
+    if (dev_row) { ctx->e.step_have = false; ctx->e.rt.graph_drop(); }     // (a step with a row is never a graph: kd_step)
+    return KD_OK;
+}
+int kd_exchange_row(kd_ctx *ctx, void *dev_row, uint64_t cap, uint64_t *row_bytes) {
+    if (!ctx) return KD_E_ARG;
+    return ctx->e.exchange_row((uint8_t *)dev_row, cap, row_bytes);
+}
 int kd_consensus_offsets(kd_ctx *ctx, uint64_t *contig_off, uint32_t *depth_minmax) {
     if (!ctx) return KD_E_ARG;
     if (!ctx->e.have_cns) return ctx->e.fail(KD_E_ARG, "kd_consensus_offsets: call kd_consensus_run first");

@@ -251,3 +251,28 @@ k_cns_emit(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, const kd_u64 *tile_s
     }
     (void)n_contigs;
 }
+
+// k_exchange_head: header + metadata of a shard's EXCHANGE ROW (kd_engine.h: exchange_queue; include/kindel_hip.h: kd_exchange_row)
+//   row[0] = row bytes, row[1] = 0, then contig_off u64[n_contigs + 1] | depth min / max u32[2 n_contigs]
+// from the run's metadata block as the device holds it, with what consensus_collect does to the host's copy: a contig whose first
+// site lies outside the processed tiles [t_lo, t_hi) was not visited by k_cns_emit -- it has no bytes (offset 0 in front of the
+// tiles, the total behind them).  One workgroup, queued behind k_cns_emit: the row is complete without a host round trip of its own.
+// A row too small for its metadata gets the 16-byte header only (row bytes > cap says so).
+__global__ void __launch_bounds__(KD_BLOCK)
+k_exchange_head(const kd_u64 *contig_off, const uint32_t *minmax, const kd_u64 *contig_base, uint32_t n_contigs, kd_u64 t_lo, kd_u64 t_hi,
+                kd_u64 fixed, kd_u64 cap, kd_u64 *row) {
+    const kd_u64 total = contig_off[n_contigs];
+    if (threadIdx.x == 0) { row[0] = fixed + total; row[1] = 0; }
+    if (16ULL + ((kd_u64)n_contigs + 1) * 8 + (kd_u64)n_contigs * 8 > cap) return;
+    for (uint32_t c = threadIdx.x; c <= n_contigs; c += KD_BLOCK) {
+        kd_u64 v = contig_off[c];
+        if (c < n_contigs) {
+            const kd_u64 b = contig_base[c];
+            if (b < t_lo) v = 0;
+            else if (b >= t_hi) v = total;
+        }
+        row[2 + c] = v;
+    }
+    const kd_u64 *mm = reinterpret_cast<const kd_u64 *>(minmax);     // (the block is u64 contig_off[n + 1] | u32 minmax[2 n]: 8-byte aligned)
+    for (uint32_t c = threadIdx.x; c < n_contigs; c += KD_BLOCK) row[2 + n_contigs + 1 + c] = mm[c];
+}

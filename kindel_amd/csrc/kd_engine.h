@@ -1108,6 +1108,53 @@ struct KdEngine {
         return KD_OK;
     }
 
+    // ---- the exchange row (multi-GPU, kindel_amd/shard.py: the ONE all-gather that stitches the FASTA) ----
+    //   u64 row bytes | u64 0 | contig_off u64[n_contigs + 1] | depth min / max u32[2 n_contigs] | change codes of [g_lo, g_hi) | consensus bytes
+    // written into a caller's DEVICE buffer by the context itself: two device-to-device copies and a one-workgroup kernel for the header
+    // and the run's metadata, queued behind k_cns_emit (by kd_finish / kd_step when a row is registered: kd_set_exchange) -- the row is
+    // complete when the step's last read-back returns, no host round trip of its own.  (Before: the Python side built the row with eight
+    // torch operations, two pageable uploads and a blocking .item() per step: +0.10 ms on a 1/8 shard's 0.38 ms step, measured;
+    // scripts/exp/exchange_ab.py.)  A row that does not fit gets its header only: row bytes > cap tells every rank so after the gather.
+    uint8_t *exch_row = nullptr;
+    uint64_t exch_cap = 0, exch_cns_queued = 0;
+    uint64_t exch_sites() const { return std::min<uint64_t>(S, g_hi) - std::min<uint64_t>(S, g_lo); }
+    uint64_t exch_fixed() const { return 16 + meta_bytes() + exch_sites(); }
+    // queued behind k_cns_emit: the change codes, the first cns_bytes of the consensus (its length is not known yet: a guess) and
+    // k_exchange_head (header + metadata, from the device's copy of the run's metadata block)
+    int exchange_queue(uint8_t *row, uint64_t cap, uint64_t cns_bytes) {
+        exch_cns_queued = 0;
+        if (cap < 16 || (reinterpret_cast<uintptr_t>(row) & 7u)) return fail(KD_E_ARG, "exchange row: at least 16 bytes, 8-byte aligned");
+        const uint64_t fixed = exch_fixed(), sites = exch_sites();
+        if (fixed <= cap) {
+            if (sites && rt.d2d(row + (fixed - sites), (const uint8_t *)b_changes.p + (std::min<uint64_t>(S, g_lo) - alloc_lo), (size_t)sites)) return hipfail("exchange: d2d");
+            const uint64_t n = std::min<uint64_t>(cns_bytes, cap - fixed);
+            if (n && rt.d2d(row + fixed, b_cns.p, (size_t)n)) return hipfail("exchange: d2d");
+            exch_cns_queued = n;
+        }
+        if (rt.launch("k_exchange_head", k_exchange_head, 1u, KD_BLOCK, 0, (const kd_u64 *)meta_coff(), (const uint32_t *)meta_mm(), (const kd_u64 *)d_cbase, n_contigs,
+                      (kd_u64)(cns_tile_first * KD_CNS_TILE), (kd_u64)((cns_tile_first + cns_tiles) * KD_CNS_TILE), (kd_u64)fixed, (kd_u64)cap, (kd_u64 *)row))
+            return hipfail("k_exchange_head");
+        return KD_OK;
+    }
+    // after consensus_collect: the consensus bytes the guess did not cover (net insertions beyond it: rare); waits for the row
+    int exchange_rest(uint8_t *row, uint64_t cap, uint64_t *row_bytes) {
+        const uint64_t total = h_coff[n_contigs], fixed = exch_fixed(), need = fixed + total;
+        if (need <= cap && total > exch_cns_queued &&
+            rt.d2d(row + fixed + exch_cns_queued, (const uint8_t *)b_cns.p + exch_cns_queued, (size_t)(total - exch_cns_queued)))
+            return hipfail("exchange: d2d");
+        if (rt.sync()) return hipfail("exchange: sync");
+        if (row_bytes) *row_bytes = need;
+        return KD_OK;
+    }
+    // on demand, after any consensus run (kd_exchange_row)
+    int exchange_row(uint8_t *row, uint64_t cap, uint64_t *row_bytes) {
+        if (!have_cns) return fail(KD_E_ARG, "kd_exchange_row: call kd_consensus_run first");
+        if (!row) return fail(KD_E_ARG, "kd_exchange_row: no row");
+        int rc;
+        if ((rc = exchange_queue(row, cap, h_coff[n_contigs]))) return rc;
+        return exchange_rest(row, cap, row_bytes);
+    }
+
     // kd_finish: everything behind the pushes -- insertion reduction, consensus, read-out -- queued back to back and collected in
     // ONE host round trip: the status words (deferred reference exceptions, hash verification), the run's metadata and the
     // consensus bytes -- as many as a consensus without net insertions has; the rare rest in a second copy.  (kd_finalize +
@@ -1134,6 +1181,7 @@ struct KdEngine {
         } else {
             uint8_t *st = (uint8_t *)rt.stage(KDS_COUNT * 8 + mb);
             if (!st) return hipfail("kd_finish: pinned staging");
+            if (exch_row && (rc = exchange_queue(exch_row, exch_cap, std::min<uint64_t>(cns_cap, shard_sites + 4096)))) return rc;
             if (rt.d2h_async(st, d_status, KDS_COUNT * 8) || rt.d2h_async(st + KDS_COUNT * 8, b_coff.p, mb) ||
                 (guess && rt.d2h_async(seq_out, b_cns.p, guess)) || rt.sync())
                 return hipfail("kd_finish: d2h");
@@ -1148,7 +1196,9 @@ struct KdEngine {
             step_record_bad = true;     // (no graph of this step)
             if ((rc = consensus_run(min_depth, 0, nullptr, nullptr))) return rc;
             guess = 0;
+            if (exch_row && ((rc = exchange_queue(exch_row, exch_cap, h_coff[n_contigs])) || (rc = exchange_rest(exch_row, exch_cap, nullptr)))) return rc;     // (the row once more)
         } else if ((rc = consensus_collect(meta))) return rc;
+        else if (exch_row && step_mode != STEP_REPLAY && h_coff[n_contigs] > exch_cns_queued && (rc = exchange_rest(exch_row, exch_cap, nullptr))) return rc;
         const uint64_t o0 = h_coff[0], o1 = h_coff[n_contigs];
         if (len_out) *len_out = o1 - o0;
         if (contig_off) for (uint32_t c = 0; c <= n_contigs; c++) contig_off[c] = h_coff[c] - o0;
@@ -1187,6 +1237,7 @@ struct KdEngine {
         static const int kDecisive[] = {KDS_ERR_READ, KDS_N_EV, KDS_POOL, KDS_B_INS_OPS, KDS_B_INS_BASES, KDS_B_MAXSPAN, KDS_B_MAXLEAD, KDS_B_MAXSEGSPAN, KDS_B_ROW_DWORDS,
                                         KDS_B_UNSORTED, KDS_B_N_COLD, KDS_B_N_IRREG, KDS_B_N_LONG, KDS_B_N_REG, KDS_INS_COLLISION, KDS_INTERNAL,
                                         KDS_BAD_BASE};
+        if (exch_row) { step_have = false; step_mode = STEP_OFF; return sequence(); }     // (a registered exchange row: its tail may need the run's host values -- always eager)
         if (step_have && rt.has_graph() && !memcmp(sig, step_sig, sizeof sig) && !step_status.empty()) {
             // (knob, fault localisation: KD_STEP_REPLAY_EAGER=1 submits the recorded sequence kernel by kernel -- the same launches with the
             // same recorded host decisions as the graph holds, but visible to KD_LAUNCH_TRACE -- instead of launching the graph)

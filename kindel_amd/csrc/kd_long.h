@@ -263,7 +263,10 @@ __device__ __forceinline__ uint32_t kd_zero_nibbles(uint32_t x) {
 //   * a second insertion at the SAME site of one read (I ops with nothing but N / P between them) cannot be a flag: it is
 //     added to ins_total directly.
 // Behind the tiles: the soft clips' weight tallies and clip_starts / clip_ends counters (atomics to HBM: two clips per read).
-__global__ void __launch_bounds__(KD_BLOCK)
+#ifndef KD_LONG_OCC
+#define KD_LONG_OCC 5      // wavefronts per SIMD the register budget is set for (96 registers; measured on C5: 4 / 5 / 6 = 0.676 / 0.610 / 0.651 ms, 6 spills 9 registers)
+#endif
+__global__ void __launch_bounds__(KD_BLOCK, KD_LONG_OCC)
 k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint32_t *long_list, uint32_t n_long,
               const KdLongAcc *long_acc, const kd_u64 *row_off, uint8_t *rows, kd_u64 *status) {
     // per wavefront: the tile's ops (reference start, query start, CIGAR word, first piece), the chunk's piece -> op table

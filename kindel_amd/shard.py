@@ -188,51 +188,83 @@ def _as_tensor(ptr, n, device):
 _HDR = 16   # payload header: u64 payload bytes, u64 spare
 
 
-def gather(engine, interval, device, group=None, pad=None, intervals=None):
-    """The exchange step: ONE all-gather of fixed-size payloads -- header (payload bytes) + contig offsets + depth min/max +
-    change codes + consensus bytes; RCCL over xGMI when the backend is "nccl".  The row size `pad` is agreed without
-    communication: every rank derives the same upper bound from the shard geometry (the largest interval of `intervals`,
-    or of the equal-sites split when none are given, twice: change codes + one byte per site, plus room for inserted bases).  Should a rank's consensus not fit (an insertion-heavy
-    shard), its header says so, every rank reads that in the gathered rows and all of them repeat the gather with the
-    announced size -- a second collective only in that case.  Call after engine.consensus_run(); everything stays on
-    `device`.  -> (gathered uint8 tensor [world, pad], world)."""
-    import torch
-    import torch.distributed as dist
-
+def row_pad(engine, interval, world, intervals=None):
+    """The row size every rank derives WITHOUT communication from the shard geometry: the widest interval of `intervals` (or of the
+    equal-sites split) twice -- change codes + one byte per site -- plus room for inserted bases."""
+    n = len(engine.contig_lens)
+    head = (n + 1) * 8 + n * 8
     lo, hi = interval
-    coff, mm = engine.consensus_offsets()
-    cptr, cbytes = engine.consensus_device()
-    chptr = engine.changes_device()
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    head = np.concatenate([coff.view(np.uint8), mm.reshape(-1).view(np.uint8)])
-    my_size = _HDR + head.size + (hi - lo) + cbytes
-    if pad is None:
-        if intervals is not None:      # every rank holds the same list: the widest interval bounds every rank's payload
-            widest = max(1, max(b - a for a, b in intervals))
-        else:
-            widest = max(1, -(-engine.total_sites() // max(world, 1)) + 4096) if world > 1 else hi - lo
-        pad = _HDR + head.size + 2 * widest + widest // 4 + 65536
-        pad = max(pad, my_size) if world == 1 else pad
+    if intervals is not None:      # every rank holds the same list: the widest interval bounds every rank's payload
+        widest = max(1, max(b - a for a, b in intervals))
+    else:
+        widest = max(1, -(-engine.total_sites() // max(world, 1)) + 4096) if world > 1 else hi - lo
+    return _HDR + head + 2 * widest + widest // 4 + 65536
+
+
+class Exchange:
+    """The exchange step with its buffers kept across steps.  The ENGINE writes this rank's row -- header (row bytes) + contig
+    offsets + depth min/max + change codes + consensus bytes, kindel_hip.h: kd_exchange_row -- into `row` (device memory): on
+    demand (run()), or on the way of kd_finish / kd_step once attach()ed, so that a multi-GPU step is kd_step + ONE collective
+    (RCCL over xGMI when the backend is "nccl") and no torch kernel, upload or read-back besides.  Everything stays on `device`."""
+
+    def __init__(self, engine, interval, device, group=None, pad=None, intervals=None):
+        import torch
+        import torch.distributed as dist
+        self.engine, self.interval, self.device, self.group = engine, interval, device, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.pad = int(pad) if pad is not None else row_pad(engine, interval, self.world, intervals)
+        self.row = torch.empty(self.pad, dtype=torch.uint8, device=device)
+        self.rows = torch.empty(self.world * self.pad, dtype=torch.uint8, device=device) if self.world > 1 else self.row
+        self.attached = False
+        self._cuda = torch.device(device).type == "cuda"
+
+    def attach(self):
+        """From now on kd_finish / kd_step (Engine.finish / step_device) leave the row behind: collect() is the collective alone."""
+        self.engine.set_exchange(self.row.data_ptr(), self.pad)
+        self.attached = True
+        return self
+
+    def detach(self):
+        if self.attached:
+            self.engine.set_exchange(0, 0)
+            self.attached = False
+
+    def collect(self):
+        """The ONE data collective over rows the engines have already written -> uint8 tensor [world, pad] (on `device`)."""
+        import torch
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.rows, self.row, group=self.group)
+            if self._cuda:
+                torch.cuda.current_stream().synchronize()     # the step ends when every rank's consensus is in this GPU's HBM
+        return self.rows.view(self.world, self.pad)
+
+    def run(self):
+        """Row on demand (after Engine.consensus_run / finish) + the collective."""
+        self.engine.exchange_row(self.row.data_ptr(), self.pad)
+        return self.collect()
+
+    def need(self, rows):
+        """The largest row any rank announced (every rank reads the same headers: the same decision everywhere)."""
+        import torch
+        return int(rows[:, :8].contiguous().view(torch.int64).max().item())
+
+
+def gather(engine, interval, device, group=None, pad=None, intervals=None):
+    """The exchange step, one-shot: ONE all-gather of fixed-size rows (Exchange).  The row size `pad` is agreed without
+    communication (row_pad).  Should a rank's consensus not fit (an insertion-heavy shard), its header says so, every rank
+    reads that in the gathered rows and all of them repeat the gather with the announced size -- a second collective only
+    in that case.  Call after engine.consensus_run() / finish(); everything stays on `device`.
+    -> (gathered uint8 tensor [world, pad], world)."""
+    lo, hi = interval
+    if (lo, hi) != tuple(engine.shard_interval()):
+        raise ValueError("shard.gather: interval %r is not the engine's shard %r" % ((lo, hi), tuple(engine.shard_interval())))
     for _ in range(2):
-        payload = torch.zeros(pad, dtype=torch.uint8, device=device)
-        hdr = np.asarray([my_size, 0], np.uint64).view(np.uint8)
-        payload[:_HDR] = torch.from_numpy(hdr).to(device)
-        if my_size <= pad:
-            o = _HDR
-            payload[o: o + head.size] = torch.from_numpy(head).to(device)
-            o += head.size
-            payload[o: o + (hi - lo)] = _as_tensor(chptr + lo, hi - lo, device)
-            o += hi - lo
-            payload[o: o + cbytes] = _as_tensor(cptr, cbytes, device)
-        if world > 1:
-            gathered = torch.empty(world * pad, dtype=torch.uint8, device=device)
-            dist.all_gather_into_tensor(gathered, payload, group=group)  # the one data collective
-        else:
-            gathered = payload
-        rows = gathered.view(world, pad)
-        need = int(rows[:, :8].contiguous().view(torch.int64).max().item())   # every rank sees the same sizes
-        if need <= pad:
-            return rows, world
+        ex = Exchange(engine, interval, device, group=group, pad=pad, intervals=intervals)
+        rows = ex.run()
+        need = ex.need(rows)
+        if need <= ex.pad:
+            return rows, ex.world
         pad = need
     raise RuntimeError("shard.gather: payload sizes changed between two gathers")
 

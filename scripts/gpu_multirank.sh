@@ -15,10 +15,17 @@ try:
 except Exception as e: print("   failed", e)
 PY
 }
-run c3x2 2 --scale 0.2
-run c3x4 4 --scale 0.2 --scaling strong --one-scaling
-run c4x4 4 --config C4 --scale 0.1 --scaling strong --one-scaling
-run c4x8 8 --config C4 --scale 0.05 --scaling strong --one-scaling
-for c in "C3 0.2" "C4 0.1" "C4 0.05"; do set -- $c
+if [ -n "${MR_QUICK:-}" ]; then      # (two of the four shapes: a short check of the N > 1 path)
+  run c3x2 2 --scale 0.2
+  run c4x4 4 --config C4 --scale 0.1 --scaling strong --one-scaling
+  SINGLES=("C3 0.2" "C4 0.1")
+else
+  run c3x2 2 --scale 0.2
+  run c3x4 4 --scale 0.2 --scaling strong --one-scaling
+  run c4x4 4 --config C4 --scale 0.1 --scaling strong --one-scaling
+  run c4x8 8 --config C4 --scale 0.05 --scaling strong --one-scaling
+  SINGLES=("C3 0.2" "C4 0.1" "C4 0.05")
+fi
+for c in "${SINGLES[@]}"; do set -- $c
   timeout 300 python bench.py --config $1 --scale $2 --steps 3 --warmup 1 --no-cpu-baseline | python -c "import json,sys; d=json.load(sys.stdin); print('single $1 x$2', '%.3g'%d['value'], d['fasta_sha256'][:12], d['consensus_len'])"
 done

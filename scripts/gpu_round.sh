@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round driver on one MI355X (through gpurun): `bash scripts/gpu_round.sh STAGE...`, results under gpurun_out/ (scratch; the
 # judged summaries are copied into profiles/ by scripts/harvest_profiles.py).  Stages:
-#   smoke  tests  test1 (TEST1_ARGS: one selection, output shown)  variants  fetch  bench  cfg  shuf  prof  pmc:<CONFIG>[:shuffle]  proj  sweep  timeline  e2e  multirank
+#   smoke  tests  test1 (TEST1_ARGS: one selection, output shown)  variants  envruns  psweep  exch  fetch  bench  cfg  shuf  prof  pmc:<CONFIG>[:shuffle]  proj  sweep  timeline  e2e  multirank
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; mkdir -p $O
 for st in "$@"; do
   echo "== $st"
@@ -14,6 +14,17 @@ for st in "$@"; do
             KD_BENCH_LIB=$lib timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --e2e-scale 0 ${VARIANT_ARGS:-} > $O/var_$v.json 2> $O/var_$v.err
             python -c "import json,sys; d=[json.loads(l) for l in open('$O/var_$v.json') if l.startswith('{\"metric')][-1]; print('$v', '%.4f ms'%d['ms_per_step'], {k: x['avg_ms'] for k, x in d['kernels'].items() if k in ('k_window','k_prep','k_cold_lane','k_window_rows','k_long_expand')}, d.get('fasta_sha256','')[:12])" || tail -3 $O/var_$v.err
           done ;;
+    envruns) # ENVRUNS="KNOB=value ..." (measurement knobs the engine reads from the environment): the product library under each
+          for e in ${ENVRUNS:-}; do
+            env $e timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --e2e-scale 0 ${VARIANT_ARGS:-} > $O/env_$e.json 2> $O/env_$e.err
+            python -c "import json,sys; d=[json.loads(l) for l in open('$O/env_$e.json') if l.startswith('{\"metric')][-1]; print('$e', '%.4f ms'%d['ms_per_step'], {k: x['avg_ms'] for k, x in d['kernels'].items() if k in ('k_window','k_prep','k_cold_lane')}, d.get('fasta_sha256','')[:12])" || tail -3 $O/env_$e.err
+          done ;;
+    psweep) # one rank's shard of the strong decomposition under each library variant (VARIANTS) and tuning (SWEEP_TUNINGS)
+          for v in ${VARIANTS:--}; do lib=""; [ "$v" != "-" ] && lib=$R/exp/libkd_$v.so
+            KD_BENCH_LIB=$lib timeout 300 python scripts/strong_projection.py --config ${PSWEEP_CONFIG:-C3} --ranks ${PSWEEP_RANKS:-8} --only-rank 3 --tunings "${SWEEP_TUNINGS:-0:0}" --out $O/psweep_$v.json > /dev/null 2> $O/psweep_$v.err; echo "$v rc=$?"
+            python -c "import json; d=json.load(open('$O/psweep_$v.json')); [print('$v', r['n_ranks'], {t: round(x, 4) for t, x in pr.get('tried', {}).items()}, {k: round(x, 4) for k, x in pr.get('kernels', {}).items() if k in ('k_window', 'k_prep', 'k_cold_lane')}) for r in d['rows'] for pr in r['per_rank']]" || tail -3 $O/psweep_$v.err
+          done ;;
+    exch) timeout 300 python scripts/exp/exchange_ab.py --out $O/exchange_ab.json 2> $O/exchange_ab.err | cut -c1-600; tail -2 $O/exchange_ab.err ;;
     fetch) # FETCH_SIZE / WRITE_SIZE per launch of the same variants (one rocprofv3 --pmc pass each)
           for v in ${VARIANTS:--}; do lib=""; [ "$v" != "-" ] && lib=$R/exp/libkd_$v.so
             for c in FETCH_SIZE WRITE_SIZE; do rm -rf $O/fetch_${v}_$c

@@ -34,6 +34,8 @@ def main():
     from kindel_amd import _native as N
     from kindel_amd import shard, synth
 
+    if os.environ.get("KD_BENCH_LIB"):   # a differently built library (A/B of a variant, scripts/README.md): never the default
+        N._default = N.Library(os.environ["KD_BENCH_LIB"])
     dev = "cuda:0"
     tb = synth.make(args.config, device=dev)
     lens = tb["contig_lens"]

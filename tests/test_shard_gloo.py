@@ -75,6 +75,80 @@ def _worker_routed(rank, world, port, emu_path, lens, depth, seed, pad, q):
     eng.close()
 
 
+def _worker_attached(rank, world, port, emu_path, lens, depth, seed, pad, q):
+    """The per-step shape of bench.py --gpus N: the exchange row registered with the engine (kd_set_exchange), filled on the way
+    of kd_finish, the collective alone behind it -- twice, as two steps of a timed loop are."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kindel_amd import _native as N
+    from kindel_amd import shard, synth
+    lib = N.Library(emu_path)
+    full = synth.to_numpy(synth.short_reads(lens, depth, seed=seed))
+    ivs = shard.partition_weighted(lens, full["contig"], full["pos0"], full["seq_len"], world)
+    keep = shard.reads_of_rank(lens, *shard.footprints(lens, full), rank, world, intervals=ivs)
+    sub = dict(full)
+    for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+        sub[k] = full[k][keep]
+    eng = N.Engine(np.asarray(lens, np.uint32), lib=lib)
+    eng.set_tuning(256, 0)
+    eng.set_shard(*ivs[rank])
+    ex = shard.Exchange(eng, ivs[rank], "cpu", intervals=ivs, pad=pad).attach()
+    out = np.zeros(sum(lens) * 2 + 4096, np.uint8)
+    needs = []
+    for _ in range(2):
+        eng.reset()
+        eng.push(sub)
+        eng.finish(out)
+        rows = ex.collect()
+        needs.append(ex.need(rows))
+    if needs[-1] > ex.pad:       # the announced size: every rank takes the same decision from the same headers
+        ex.detach()
+        ex = shard.Exchange(eng, ivs[rank], "cpu", intervals=ivs, pad=needs[-1])
+        rows = ex.run()
+    on_demand = shard.gather(eng, ivs[rank], "cpu", intervals=ivs, pad=ex.pad)[0]
+    sizes = rows[:, :8].contiguous().view(torch.int64).reshape(-1).tolist()      # (behind a row's own bytes: whatever the buffer held)
+    same = rows.shape == on_demand.shape and all(bool((rows[r, :n] == on_demand[r, :n]).all()) for r, n in enumerate(sizes))
+    seqs, changes, minmax = shard.assemble(np.ascontiguousarray(rows.numpy()), lens, world, ivs[rank], intervals=ivs)
+    q.put((rank, seqs, [c.tobytes() for c in changes], minmax, needs, same))
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+@pytest.mark.parametrize("world,lens,depth,pad", [
+    (2, [6000, 5000], 8, None),
+    (4, [30000], 6, None),
+    (2, [6000, 5000], 8, 200),          # rows that are too small: headers only, the sizes announced
+])
+def test_attached_exchange_row(emu_lib, world, lens, depth, pad):
+    from kindel_amd import synth
+    from oracle import oracle as ko
+    seed = 37
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_attached, args=(r, world, port, emu_lib.path, lens, depth, seed, pad, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = synth.to_numpy(synth.short_reads(lens, depth, seed=seed))
+    for rank, seqs, changes, minmax, needs, same in results:
+        assert needs[0] == needs[1] == results[0][4][0]            # both steps, every rank: the same announced size
+        assert (needs[0] > pad) if pad else True
+        assert same                                                 # the row left by kd_finish == the row on demand
+        for cid in range(len(lens)):
+            oa = ko.parse_records(full, cid)
+            oseq, och = oa.consensus_sequence()
+            assert seqs[cid].decode() == oseq, (rank, cid)
+            assert [None if c == 0 else chr(c) for c in changes[cid]] == och
+            assert minmax[cid] == oa.depth_minmax()
+
+
 @pytest.mark.parametrize("world,lens,depth,pad", [
     (4, [2500] * 12, 8, None),          # many contigs (config 4 in miniature): cuts land on contig boundaries
     (8, [2000] * 20, 6, None),
