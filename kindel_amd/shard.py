@@ -190,7 +190,9 @@ _HDR = 16   # payload header: u64 payload bytes, u64 spare
 
 def row_pad(engine, interval, world, intervals=None):
     """The row size every rank derives WITHOUT communication from the shard geometry: the widest interval of `intervals` (or of the
-    equal-sites split) twice -- change codes + one byte per site -- plus room for inserted bases."""
+    equal-sites split) twice -- change codes + one byte per site -- plus room for inserted bases (1/16 of the sites + 16 KB: the
+    all-gather moves the agreed size whatever a row holds, and a rank with more net insertions than that announces its size:
+    gather() / stitch() repeat the collective exactly sized)."""
     n = len(engine.contig_lens)
     head = (n + 1) * 8 + n * 8
     lo, hi = interval
@@ -198,7 +200,7 @@ def row_pad(engine, interval, world, intervals=None):
         widest = max(1, max(b - a for a, b in intervals))
     else:
         widest = max(1, -(-engine.total_sites() // max(world, 1)) + 4096) if world > 1 else hi - lo
-    return _HDR + head + 2 * widest + widest // 4 + 65536
+    return -(-(_HDR + head + 2 * widest + widest // 16 + 16384) // 64) * 64
 
 
 class Exchange:
@@ -284,6 +286,9 @@ def assemble(rows, contig_lens, world, interval=None, intervals=None):
     mins = np.full(n, 0xFFFFFFFF, np.uint64)
     maxs = np.zeros(n, np.uint64)
     for r in range(world):
+        announced = int(np.asarray(rows[r][:8]).view(np.uint64)[0])
+        if announced > len(rows[r]):      # (gather() / stitch() never hand such rows over: they repeat the collective exactly sized)
+            raise ValueError("shard.assemble: rank %d's row did not fit (%d bytes announced, rows of %d)" % (r, announced, len(rows[r])))
         row = rows[r][_HDR:]
         rcoff = row[: (n + 1) * 8].view(np.uint64)
         rmm = row[(n + 1) * 8: (n + 1) * 8 + n * 8].view(np.uint32).reshape(n, 2)

@@ -90,7 +90,8 @@ for src, dst in (("e2e_c3_full.json", "e2e_c3_full.json"), ("fetch_calibration.j
     if os.path.exists(p):
         shutil.copy(p, os.path.join(P, dst))
 for src, dst in (("strong_projection_C3.json", "%s_strong_scaling_projection_C3.json"), ("strong_projection_C4.json", "%s_strong_scaling_projection_C4.json"),
-                 ("e2e_c3_full_phred.json", "%s_e2e_c3_full_phred.json"), ("step_timeline.txt", "%s_c3_step_timeline.txt")):
+                 ("e2e_c3_full_phred.json", "%s_e2e_c3_full_phred.json"), ("step_timeline.txt", "%s_c3_step_timeline.txt"),
+                 ("exchange_ab.json", "%s_exchange_host_side_ab.json")):
     p = os.path.join(O, src)
     if os.path.exists(p) and os.path.getmtime(p) > newer_than:
         shutil.copy(p, os.path.join(P, dst % tag))
