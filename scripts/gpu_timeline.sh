@@ -1,8 +1,9 @@
 #!/bin/bash
 # one bench step as a dispatch timeline (rocprofv3 --kernel-trace): kernel, start offset, duration, idle gap before it
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; mkdir -p $O; rm -rf $O/tl
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/tl -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} --no-graph --e2e-scale 0 > $O/tl_bench.json 2> $O/tl.err)
-python - <<PY | tee $O/step_timeline.txt
+# TL_CMD: another command whose last step is wanted (e.g. a 1/8 shard: "scripts/strong_projection.py --ranks 8 --only-rank 3 --steps 3 --warmup 1 --no-profile"), TL_OUT its file
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/tl -- python $R/${TL_CMD:-bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} --no-graph --e2e-scale 0} > $O/tl_bench.json 2> $O/tl.err)
+python - <<PY | tee $O/${TL_OUT:-step_timeline.txt}
 import csv, glob
 rows=[]
 for f in glob.glob("$O/tl/**/*kernel_trace.csv", recursive=True):

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--ranks", default="1,2,4,8")
     ap.add_argument("--out", default="")
     ap.add_argument("--only-rank", type=int, default=-1, help="time only this rank of every decomposition (sweeps)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel pass (hipEvents around every launch): for a dispatch timeline of the timed steps")
     ap.add_argument("--tunings", default="0:0", help="window:slice[,window:slice...] -- every rank's shard is timed under each, the best stands "
                     "(0:0 = the engine's own choice)")
     args = ap.parse_args()
@@ -62,8 +63,14 @@ def main():
 
             eng.set_step_graph(False)      # the eager sequence: what a new batch takes (bench.py's `value`)
 
+            # N > 1: the rank's exchange row registered with the engine, as bench.py --gpus N does (kd_set_exchange): the projected step
+            # contains the row's copies and k_exchange_head -- everything of an N-GPU step but the collective itself
+            ex = shard.Exchange(eng, ivs[r], dev, pad=shard.row_pad(eng, ivs[r], world, ivs)).attach() if world > 1 else None
+
             def step():
                 eng.step_device(ptrs, n, tb["seq4_bytes"], tb["cigar_words"], pinned)
+                if ex is not None:
+                    ex.collect()
 
             ms, tuned, tried = None, None, {}
             for spec in args.tunings.split(","):
@@ -83,11 +90,13 @@ def main():
                         ms, tuned = m, spec
             w_, s_ = (int(x) for x in tuned.split(":"))
             eng.set_tuning(w_, s_)
-            eng.profile_enable(1); eng.profile_reset()
-            for _ in range(args.steps):
-                step()
-            prof = eng.profile()
-            eng.profile_enable(0)
+            prof = {}
+            if not args.no_profile:
+                eng.profile_enable(1); eng.profile_reset()
+                for _ in range(args.steps):
+                    step()
+                prof = eng.profile()
+                eng.profile_enable(0)
             kern = sum(v[1] for v in prof.values()) / args.steps
             per_rank.append(dict(rank=r, interval=[int(ivs[r][0]), int(ivs[r][1])], reads=n, step_ms=round(ms, 4), kernel_ms=round(kern, 4), tuning=tuned, tried=tried,
                                  kernels={k: round(v[1] / max(v[0], 1), 4) for k, v in sorted(prof.items())},
@@ -102,7 +111,7 @@ def main():
     # the fixed part of a step: what does not shrink with the shard (dispatch chain, read-backs, the final copy): from the two ends
     # of the curve, t(N) = fixed + work / N
     out = dict(kind="PROJECTION from one GPU: each rank's shard of the strong-scaling decomposition timed alone; projected N-GPU step = "
-                    "max over ranks (the one all-gather of <= 5 MB is not included); NOT a measurement on N GPUs",
+                    "max over ranks (every rank writes its exchange row as bench.py --gpus N does; the one all-gather of <= 5 MB itself is not included); NOT a measurement on N GPUs",
                config=args.config, reads=n_all, aligned_events=aligned, steps=args.steps,
                rows=[dict(r, projected_speedup=round(t1 / r["projected_step_ms"], 3),
                           projected_events_per_s=aligned / (r["projected_step_ms"] * 1e-3)) for r in rows])

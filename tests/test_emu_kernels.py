@@ -401,7 +401,20 @@ def _finish_vs_classic(lib, batch, window=0, slice_reads=0, out_cap=None, n_push
         for a, b in zip(cuts[:-1], cuts[1:]):
             eng.push(P.subset(batch, a, b))
         out = np.zeros(out_cap or (int(sum(batch["contig_lens"])) * 2 + 4096), np.uint8)
+        # the exchange row (multi-GPU stitch) registered with the engine: kd_finish leaves it behind on its way -- here through the
+        # same paths as the bytes (a consensus longer than the first copy's guess, a repaired hash collision) -- and it must be the
+        # row kd_exchange_row writes on demand, and assemble to the same consensus
+        iv = (0, int(shard.g_layout(batch["contig_lens"])[1]))
+        ex = shard.Exchange(eng, iv, "cpu", pad=shard.row_pad(eng, iv, 1) + 8192).attach()
         off = eng.finish(out)
+        left = ex.collect().clone()
+        ex.detach()
+        on_demand = shard.Exchange(eng, iv, "cpu", pad=ex.pad).run()
+        n_row = ex.need(left)
+        assert n_row <= ex.pad and n_row == ex.need(on_demand) and bool((left[0, :n_row] == on_demand[0, :n_row]).all())
+        seqs, changes, minmax = shard.assemble(left.numpy(), batch["contig_lens"], 1, iv)
+        for cid in run.order:
+            assert seqs[cid] == run.cns[cid][0] and np.array_equal(changes[cid], run.cns[cid][1]) and tuple(minmax[cid]) == tuple(run.cns[cid][2])
         for cid in run.order:
             assert out[int(off[cid]): int(off[cid + 1])].tobytes() == run.cns[cid][0]
             assert np.array_equal(eng.tables(cid), run.tables[cid])
