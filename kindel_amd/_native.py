@@ -69,6 +69,8 @@ class Library:
         except OSError as e:
             raise ImportError("kindel_amd: cannot load %s: %s" % (path, e))
         self.path = path
+        # where the contexts' "device" memory lives: the test emulator (tests/emu, the kernels as host code) keeps it in host memory
+        self.emulated = hasattr(self.dll, "emu_switch")
         L, p, u32, u64 = self.dll, C.c_void_p, C.c_uint32, C.c_uint64
         L.kd_abi_version.restype = C.c_int
         L.kd_create.argtypes = [C.POINTER(p), C.c_int, u32, p, p]
@@ -446,6 +448,7 @@ class Engine:
     def __init__(self, contig_lens, device=0, stream=None, lib=None, mode=KD_MODE_AUTO):
         self.lib = lib or default_library()
         self.contig_lens = np.ascontiguousarray(contig_lens, np.uint32)
+        self.device_index = int(device)
         self._h = C.c_void_p()
         rc = self.lib.dll.kd_create(C.byref(self._h), int(device), len(self.contig_lens), _ptr(self.contig_lens),
                                     C.c_void_p(stream) if stream else None)
@@ -491,6 +494,11 @@ class Engine:
     def set_shard(self, g_lo, g_hi):
         self._check(self.lib.dll.kd_set_shard(self._h, g_lo, g_hi), "kd_set_shard")
         self._shard = (int(g_lo), int(g_hi))
+
+    @property
+    def memory_device(self):
+        """torch device string of the memory this context's device pointers point into ("cuda:<index>"; "cpu" under the test emulator)."""
+        return "cpu" if self.lib.emulated else "cuda:%d" % self.device_index
 
     def shard_interval(self):
         """The emit interval [g_lo, g_hi) of this context (all of G-space unless set_shard was called)."""

@@ -215,10 +215,16 @@ class Exchange:
         self.engine, self.interval, self.device, self.group = engine, interval, device, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.pad = int(pad) if pad is not None else row_pad(engine, interval, self.world, intervals)
-        self.row = torch.empty(self.pad, dtype=torch.uint8, device=device)
+        # the row lives where the ENGINE's memory is (it writes it with device-to-device copies and a kernel); the collective runs on
+        # `device`: the same memory under RCCL, host tensors under gloo (a CLI run with KINDEL_DIST_BACKEND=gloo, the CPU tests) --
+        # then the row is copied over in front of the collective
+        mem = engine.memory_device
+        self.row = torch.empty(self.pad, dtype=torch.uint8, device=mem)
+        self.staged = self.world > 1 and torch.empty(0, device=mem).device != torch.empty(0, device=device).device
+        self.row_coll = torch.empty(self.pad, dtype=torch.uint8, device=device) if self.staged else self.row
         self.rows = torch.empty(self.world * self.pad, dtype=torch.uint8, device=device) if self.world > 1 else self.row
         self.attached = False
-        self._cuda = torch.device(device).type == "cuda"
+        self._cuda = self.world > 1 and torch.device(device).type == "cuda"
 
     def attach(self):
         """From now on kd_finish / kd_step (Engine.finish / step_device) leave the row behind: collect() is the collective alone."""
@@ -236,7 +242,9 @@ class Exchange:
         import torch
         import torch.distributed as dist
         if self.world > 1:
-            dist.all_gather_into_tensor(self.rows, self.row, group=self.group)
+            if self.staged:
+                self.row_coll.copy_(self.row)
+            dist.all_gather_into_tensor(self.rows, self.row_coll, group=self.group)
             if self._cuda:
                 torch.cuda.current_stream().synchronize()     # the step ends when every rank's consensus is in this GPU's HBM
         return self.rows.view(self.world, self.pad)
