@@ -229,12 +229,14 @@ class Exchange:
     def attach(self):
         """From now on kd_finish / kd_step (Engine.finish / step_device) leave the row behind: collect() is the collective alone."""
         self.engine.set_exchange(self.row.data_ptr(), self.pad)
+        self.engine._exchange_keep = self.row      # (the context holds the raw pointer: the tensor lives as long as the registration)
         self.attached = True
         return self
 
     def detach(self):
         if self.attached:
             self.engine.set_exchange(0, 0)
+            self.engine._exchange_keep = None
             self.attached = False
 
     def collect(self):
