@@ -66,6 +66,63 @@ def random_batch(rng, n_reads, contig_lens=(37, 90), wild=0.15, sort=False, long
     return b
 
 
+def mixed_batch(rng, L, n_reads, piled=False):
+    """VALID reads of very mixed shapes on one contig of L sites, coordinate-sorted, at whatever depth n_reads gives: plain reads of
+    2 .. 400 bases and a few of 3000 .. 6000, leading clips of up to 260 bases, CIGARs of up to 16 ops with deletions of up to 5000
+    sites and N skips -- the shapes k_window's tile lists carry or do not carry (kd_window.h: window-relative start, length, reach
+    of the leading clip and CIGAR word count have bounded fields), at depths where its deep-tile and queue regimes switch.
+    piled: all reads start in the first eighth of the contig."""
+    contig, pos0, flag, seq_off, seq_len, cig_off, n_cig = [], [], [], [], [], [], []
+    seq4, cigar = bytearray(), []
+    starts = np.sort(rng.integers(0, max(1, L // 8) if piled else L, n_reads))
+    for i in range(n_reads):
+        r = rng.random()
+        if r < 0.55:
+            ops = [(int(rng.integers(2, 400)) if rng.random() < 0.97 else int(rng.integers(3000, 6000)), 0)]
+        elif r < 0.75:
+            lead = int(rng.integers(1, 30)) if rng.random() < 0.8 else int(rng.integers(120, 260))
+            ops = [(lead, 4), (int(rng.integers(5, 300)), 0)]
+            if rng.random() < 0.5:
+                ops.append((int(rng.integers(1, 40)), 4))
+        else:
+            ops, k = [], int(rng.integers(2, 9))
+            for j in range(k):
+                ops.append((int(rng.integers(1, 120)), [0, 7, 8][int(rng.integers(0, 3))]))
+                t = rng.random()
+                if j < k - 1:
+                    if t < 0.4:
+                        ops.append((int(rng.integers(1, 6)), 1))
+                    elif t < 0.8:
+                        ops.append((int(rng.integers(1, 30)) if rng.random() < 0.9 else int(rng.integers(1000, 5000)), 2))
+                    elif t < 0.9:
+                        ops.append((int(rng.integers(1, 200)), 3))
+            ops = ops[:16]
+            if ops[-1][1] in (1, 2, 3):
+                ops[-1] = (int(rng.integers(1, 50)), 0)
+        qlen = sum(ln for ln, op in ops if op in (0, 1, 4, 7, 8))
+        rlen = sum(ln for ln, op in ops if op in (0, 2, 3, 7, 8))
+        p = int(starts[i])
+        if rlen > L:
+            ops, qlen, rlen, p = [(min(L, 50), 0)], min(L, 50), min(L, 50), 0
+        if p + rlen > L:
+            p = L - rlen
+        nib = rng.choice([1, 2, 4, 8, 15], qlen, p=[0.24, 0.24, 0.24, 0.24, 0.04])
+        contig.append(0); pos0.append(p); flag.append(0)
+        seq_off.append(len(seq4)); seq_len.append(qlen); cig_off.append(len(cigar)); n_cig.append(len(ops))
+        nn = [int(x) for x in nib] + [0] * (qlen & 1)
+        seq4.extend((nn[k] << 4) | nn[k + 1] for k in range(0, len(nn), 2))
+        cigar.extend((ln << 4) | op for ln, op in ops)
+    b = dict(contig=np.asarray(contig, np.uint32), pos0=np.asarray(pos0, np.int32), flag=np.asarray(flag, np.uint32),
+             seq_off=np.asarray(seq_off, np.uint64), seq_len=np.asarray(seq_len, np.uint32),
+             cig_off=np.asarray(cig_off, np.uint64), n_cig=np.asarray(n_cig, np.uint32),
+             seq4=np.frombuffer(bytes(seq4) + b"\0" * 32, np.uint8).copy(), cigar=np.asarray(cigar + [0, 0], np.uint32),
+             contig_names=np.asarray(["f0"]), contig_lens=np.asarray([L], np.uint32))
+    o = np.argsort(np.maximum(b["pos0"].astype(np.int64), 0), kind="stable")
+    for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+        b[k] = b[k][o]
+    return b
+
+
 def oracle_outcome(batch):
     """-> ("ok", {cid: OracleAln}) or ("raise", ExceptionType) following the reference's contig-major order"""
     from oracle import oracle as ko

@@ -55,6 +55,26 @@ def test_fuzz_long_cigars_emulated(emu_lib):
     assert _long_campaign(emu_lib, range(300, 304), n_reads=40) >= 6
 
 
+def _mixed_campaign(lib, seeds, sizes):
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        L, n_reads = sizes[seed % len(sizes)]
+        batch = fuzz.mixed_batch(rng, L, n_reads, piled=bool(seed & 1))
+        window, slice_reads = [0, 0, 64, 256, 448, 1024, 2048][seed % 7], [0, 0, 64, 300, 2000][seed % 5]
+        assert fuzz.check_engine(lib, batch, N.KD_MODE_AUTO, window=window, slice_reads=slice_reads) == "ok", (seed, L, n_reads, window, slice_reads)
+
+
+def test_fuzz_mixed_shapes_at_depth_emulated(emu_lib):
+    """What k_window's tile lists carry and what they do not (long plain reads, long leading clips, long deletions), at depths where its
+    queue regimes and the deep-tile walk switch; a few thousand such batches ran clean as a local campaign, these seeds stay."""
+    _mixed_campaign(emu_lib, range(900, 935), [(700, 1500), (1500, 4000), (4000, 9000), (9000, 300), (20000, 4000)])
+
+
+@pytest.mark.gpu
+def test_fuzz_mixed_shapes_at_depth_gpu(hip_lib):
+    _mixed_campaign(hip_lib, range(900, 914), [(700, 6000), (4000, 30000), (60000, 20000), (300000, 40000)])
+
+
 def test_oracle_fuzz_is_deterministic():
     a = fuzz.random_batch(np.random.default_rng(5), 30)
     b = fuzz.random_batch(np.random.default_rng(5), 30)
