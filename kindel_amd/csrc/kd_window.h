@@ -463,6 +463,7 @@ __device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const
 #define KD_TILE 1024   // reads classified together (a multiple of KD_BLOCK)
 #endif
 #define KD_TILE_PER_THREAD (KD_TILE / KD_BLOCK)
+static_assert(KD_TILE % KD_BLOCK == 0 && KD_TILE <= 1024, "a list entry holds the tile-relative index of a read in 10 bits (the complex list: 14, two flag bits above)");
 #ifndef KD_LIST_CARRY
 #define KD_LIST_CARRY 1   // list 0 carries every entry's window-relative start and length (no second fetch of its footprint record)
 #endif
