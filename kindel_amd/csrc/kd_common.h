@@ -100,6 +100,10 @@ __device__ __forceinline__ void kd_spin_pause() { __builtin_amdgcn_s_sleep(8); }
 #define KD_MARK(acc)
 #define KD_PHASE_COMMIT(status, rows)
 #define KD_PHASE_REPORT(h)
+// ... and of k_prep (when its wavefronts start, leave their loop and end: what a small batch's floor is made of)
+#define KD_PREP_CLK_DECL
+#define KD_PREP_CLK_LOOP_END
+#define KD_PREP_CLK_COMMIT(status)
 #endif
 
 #define KD_WAVE 64
@@ -172,6 +176,7 @@ enum {
     KDO_QUEUE7 = KDO_QUEUE0 + 7,
 #ifdef KD_PHASE_CLOCKS
     KDO_DBG0, KDO_DBG1, KDO_DBG2, KDO_DBG3, KDO_DBG4, KDO_DBG5, KDO_DBG6, KDO_DBG7,   // phase clocks (profiling build only)
+    KDO_DBG8, KDO_DBG9, KDO_DBG10, KDO_DBG11, KDO_DBG12, KDO_DBG13,                   // k_prep's wavefront times (the same)
 #endif
     KDO_COUNT
 };

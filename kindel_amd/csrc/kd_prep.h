@@ -155,6 +155,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
        uint32_t *irreg_list, uint32_t *long_list,
        uint32_t *read_ev, kd_u64 *read_pool, kd_u64 *status, uint32_t per_thread, uint32_t *bound, uint32_t nb) {
     // per_thread: reads per lane, a multiple of KD_PREP_UNROLL up to KD_PREP_PER_THREAD (= 64: the bits of the list masks)
+    KD_PREP_CLK_DECL      // (profiling hooks, empty in the product: kd_common.h)
     const uint32_t t = threadIdx.x;                      // = the lane
     const kd_u64 chunk0 = (kd_u64)blockIdx.x * KD_PREP_BLOCK * per_thread;
     uint32_t a_reads = 0, a_ins = 0, a_reg = 0, a_unsorted = 0, a_ins_tail = 0;    // (counts over <= 64 reads of <= 16 ops)
@@ -341,6 +342,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
             if (ok) rinfo[i] = ri;
         }
     }
+    KD_PREP_CLK_LOOP_END
     // The reads the sums could not decide (rare: at a contig's end, CIGAR and read length at odds, POS 0): the exact scan counts
     // them -- an irregular read's insertion slots are reserved from its counts -- and they take the general walk.
     for (kd_u64 todo = m_defer; todo; todo &= todo - 1) {
@@ -410,6 +412,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
             if (m_long & bit) long_list[w_long++] = (uint32_t)i;
         }
     }
+    KD_PREP_CLK_COMMIT(status)
 }
 
 // (long-CIGAR reads -- k_prep_long, k_long_reduce, k_long_expand -- live in kd_long.h)

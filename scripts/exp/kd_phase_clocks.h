@@ -30,3 +30,32 @@
             fprintf(stderr, " %s=%.3g(%.1f%%)", nm_[k_], (double)(h)[KDS_DBG0 + k_ * KDS_STRIDE], 100.0 * (h)[KDS_DBG0 + k_ * KDS_STRIDE] / tot_); \
         fprintf(stderr, "\n");                                                                                     \
     }
+// k_prep: every wavefront's start, loop end and end on the constant-rate clock (wall_clock64: 100 MHz) -- sums of the loop and
+// the tail, the longest wavefront, the first start and the last end (the kernel's span as its wavefronts see it).
+#define KD_PREP_CLK_DECL const unsigned long long pc_t0 = wall_clock64(); unsigned long long pc_t1 = pc_t0;
+#define KD_PREP_CLK_LOOP_END pc_t1 = wall_clock64();
+#define KD_PREP_CLK_COMMIT(status)                                                                                 \
+    {                                                                                                              \
+        const unsigned long long pc_t2 = wall_clock64();                                                           \
+        if (threadIdx.x == 0) {                                                                                    \
+            atomicAdd(&status[KDS_DBG0 + 8 * KDS_STRIDE], pc_t1 - pc_t0); atomicAdd(&status[KDS_DBG0 + 9 * KDS_STRIDE], pc_t2 - pc_t1);   \
+            atomicMax(&status[KDS_DBG0 + 10 * KDS_STRIDE], pc_t2 - pc_t0); atomicMax(&status[KDS_DBG0 + 11 * KDS_STRIDE], ~pc_t0);        \
+            atomicMax(&status[KDS_DBG0 + 12 * KDS_STRIDE], pc_t2); atomicAdd(&status[KDS_DBG0 + 13 * KDS_STRIDE], 1ULL);                  \
+        }                                                                                                          \
+    }
+#undef KD_PHASE_REPORT
+#define KD_PHASE_REPORT(h)                                                                                         \
+    {                                                                                                              \
+        const char *nm_[8] = {"dequeue", "zero", "classify", "plain", "complex", "barrier-wait", "flush", "waves"}; \
+        double tot_ = 0;                                                                                           \
+        for (int k_ = 0; k_ < 7; k_++) tot_ += (double)(h)[KDS_DBG0 + k_ * KDS_STRIDE];                            \
+        fprintf(stderr, "k_window phase clocks (sum over wavefronts):");                                           \
+        for (int k_ = 0; k_ < 8; k_++)                                                                             \
+            fprintf(stderr, " %s=%.3g(%.1f%%)", nm_[k_], (double)(h)[KDS_DBG0 + k_ * KDS_STRIDE], 100.0 * (h)[KDS_DBG0 + k_ * KDS_STRIDE] / tot_); \
+        fprintf(stderr, "\n");                                                                                     \
+        const double nw_ = (double)(h)[KDS_DBG0 + 13 * KDS_STRIDE];                                                \
+        if (nw_ > 0)                                                                                               \
+            fprintf(stderr, "k_prep wavefronts (last batch; 100 MHz ticks as us): %.0f waves, loop avg %.2f us, tail avg %.2f us, longest %.2f us, first start -> last end %.2f us\n", \
+                    nw_, (h)[KDS_DBG0 + 8 * KDS_STRIDE] / nw_ / 100.0, (h)[KDS_DBG0 + 9 * KDS_STRIDE] / nw_ / 100.0, (h)[KDS_DBG0 + 10 * KDS_STRIDE] / 100.0, \
+                    ((double)(h)[KDS_DBG0 + 12 * KDS_STRIDE] - (double)(~(h)[KDS_DBG0 + 11 * KDS_STRIDE])) / 100.0);    \
+    }
