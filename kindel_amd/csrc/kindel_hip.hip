@@ -173,7 +173,7 @@ struct HipRt {
 
     // small readbacks (the status words, one cache line each: 4 KiB, 5 KiB in a profiling build) go through a pinned bounce buffer:
     // no pageable staging in the runtime
-    static constexpr size_t KD_SMALL_COPY = 16384;
+    static constexpr size_t KD_SMALL_COPY = KDS_COUNT * 8 > 16384 ? (size_t)KDS_COUNT * 8 : 16384;      // (the status words are the largest of the small read-backs, whatever their spacing)
     void *pin = nullptr;
     int d2h_small(void *h, const void *d, size_t n) {
         if (!pin && bad(hipHostMalloc(&pin, KD_SMALL_COPY, hipHostMallocDefault))) return 1;

@@ -29,7 +29,7 @@ struct EmuRt {
     int d2d(void *d, const void *s, size_t n) { ::memcpy(d, s, n); return 0; }
     int d2h(void *h, const void *d, size_t n) { ::memcpy(h, d, n); return 0; }
     int d2h_small(void *h, const void *d, size_t n) { ::memcpy(h, d, n); return 0; }
-    unsigned char small[16384];
+    unsigned char small[KDS_COUNT * 8 > 16384 ? (size_t)KDS_COUNT * 8 : 16384];
     int d2h_small_begin(const void *d, size_t n) { if (n > sizeof small) return 1; ::memcpy(small, d, n); return 0; }
     int d2h_small_end(void *h, size_t n) { ::memcpy(h, small, n); return 0; }
     template <class F>
