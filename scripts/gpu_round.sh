@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round driver on one MI355X (through gpurun): `bash scripts/gpu_round.sh STAGE...`, results under gpurun_out/ (scratch; the
 # judged summaries are copied into profiles/ by scripts/harvest_profiles.py).  Stages:
-#   smoke  tests  test1 (TEST1_ARGS: one selection, output shown)  variants  envruns  psweep  exch  fetch  bench  cfg  shuf  prof  pmc:<CONFIG>[:shuffle]  proj  sweep  timeline  e2e  multirank
+#   smoke  tests  test1 (TEST1_ARGS: one selection, output shown)  variants  envruns  psweep  exch  pending  fetch  bench  cfg  shuf  prof  pmc:<CONFIG>[:shuffle]  proj  sweep  timeline  e2e  multirank
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; mkdir -p $O
 for st in "$@"; do
   echo "== $st"
@@ -24,6 +24,11 @@ for st in "$@"; do
             KD_BENCH_LIB=$lib timeout 300 python scripts/strong_projection.py --config ${PSWEEP_CONFIG:-C3} --ranks ${PSWEEP_RANKS:-8} --only-rank 3 --tunings "${SWEEP_TUNINGS:-0:0}" --out $O/psweep_$v.json > /dev/null 2> $O/psweep_$v.err; echo "$v rc=$?"
             python -c "import json; d=json.load(open('$O/psweep_$v.json')); [print('$v', r['n_ranks'], {t: round(x, 4) for t, x in pr.get('tried', {}).items()}, {k: round(x, 4) for k, x in pr.get('kernels', {}).items() if k in ('k_window', 'k_prep', 'k_cold_lane')}) for r in d['rows'] for pr in r['per_rank']]" || tail -3 $O/psweep_$v.err
           done ;;
+    pending) # what round 4 left to be measured first: status words 4 KB apart; k_prep's wavefront times on a 1/8 shard
+          [ -f $R/exp/libkd_stride512.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-function -DKDS_STRIDE=512 kindel_amd/csrc/kindel_hip.hip kindel_amd/csrc/kd_decode.cpp -lz -o $R/exp/libkd_stride512.so
+          [ -f $R/exp/libkd_phase.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-function -include scripts/exp/kd_phase_clocks.h kindel_amd/csrc/kindel_hip.hip kindel_amd/csrc/kd_decode.cpp -lz -o $R/exp/libkd_phase.so
+          VARIANTS="- stride512" bash $R/scripts/gpu_round.sh variants psweep 2>&1 | grep "^- \|^stride512"
+          KD_BENCH_LIB=$R/exp/libkd_phase.so timeout 300 python scripts/strong_projection.py --config C3 --ranks 8 --only-rank 3 --steps 5 --warmup 2 --no-profile 2>&1 >/dev/null | grep "k_prep wavefronts\|k_window phase" | tail -2 ;;
     exch) timeout 300 python scripts/exp/exchange_ab.py --out $O/exchange_ab.json 2> $O/exchange_ab.err | cut -c1-600; tail -2 $O/exchange_ab.err ;;
     fetch) # FETCH_SIZE / WRITE_SIZE per launch of the same variants (one rocprofv3 --pmc pass each)
           for v in ${VARIANTS:--}; do lib=""; [ "$v" != "-" ] && lib=$R/exp/libkd_$v.so
