@@ -19,6 +19,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cerrno>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -176,16 +177,19 @@ struct File {
 inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | p[1] << 8); }
 
-bool read_all(const char *path, Arr<uint8_t> &out) {
-    FILE *f = fopen(path, "rb");
-    if (!f) return false;
-    fseek(f, 0, SEEK_END);
-    long n = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    out.resize(n > 0 ? (size_t)n : 0);
-    size_t got = out.size() ? fread(out.data(), 1, out.size(), f) : 0;
-    fclose(f);
-    return got == out.size();
+// Everything the descriptor still holds, up to its end: also for an input without a size (a pipe, /dev/stdin), which can be
+// opened and read only ONCE.
+bool read_all(int fd, Arr<uint8_t> &out) {
+    size_t have = 0;
+    if (!out.resize((size_t)1 << 20)) return false;
+    for (;;) {
+        if (have == out.size() && !out.resize(out.size() * 2)) return false;
+        const ssize_t got = ::read(fd, out.data() + have, out.size() - have);
+        if (got < 0) { if (errno == EINTR) continue; return false; }
+        if (got == 0) break;
+        have += (size_t)got;
+    }
+    return out.resize(have);
 }
 
 struct Block { size_t in_off, in_len, out_off, out_len; };
@@ -833,8 +837,9 @@ struct RawView {   // the compressed file: mapped read-only (the workers fault i
                 return true;
             }
         }
+        const bool ok = read_all(fd, own);   // (the SAME descriptor: a pipe's writer sees its reader leave only once)
         ::close(fd);
-        if (!read_all(path, own)) return false;
+        if (!ok) return false;
         p = own.data(); n = own.size();
         return true;
     }

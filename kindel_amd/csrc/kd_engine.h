@@ -1237,6 +1237,10 @@ struct KdEngine {
         static const int kDecisive[] = {KDS_ERR_READ, KDS_N_EV, KDS_POOL, KDS_B_INS_OPS, KDS_B_INS_BASES, KDS_B_MAXSPAN, KDS_B_MAXLEAD, KDS_B_MAXSEGSPAN, KDS_B_ROW_DWORDS,
                                         KDS_B_UNSORTED, KDS_B_N_COLD, KDS_B_N_IRREG, KDS_B_N_LONG, KDS_B_N_REG, KDS_INS_COLLISION, KDS_INTERNAL,
                                         KDS_BAD_BASE};
+        static const bool step_trace = getenv("KD_STEP_TRACE") != nullptr;      // (knob, fault localisation: the step's path and the addresses a fault report can be matched with)
+        if (step_trace)
+            fprintf(stderr, "[kd] step: have_graph %d status %p tab %p cns %p coff %p seq_out %p meta_pin %p reads %p..%p\n", (int)(step_have && rt.has_graph()),
+                    (void *)d_status, (void *)d_tab, b_cns.p, b_coff.p, (void *)seq_out, (void *)step_meta_pin, (const void *)B.contig, (const void *)B.seq4);
         if (exch_row) { step_have = false; step_mode = STEP_OFF; return sequence(); }     // (a registered exchange row: its tail may need the run's host values -- always eager)
         if (step_have && rt.has_graph() && !memcmp(sig, step_sig, sizeof sig) && !step_status.empty()) {
             // (knob, fault localisation: KD_STEP_REPLAY_EAGER=1 submits the recorded sequence kernel by kernel -- the same launches with the

@@ -233,8 +233,11 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
                 // fills of more than 64 entries draw on a budget of 4 x the table (a sorted batch fills every entry once).
                 if (bound) {
                     if (kd_ballot(ok && pk > gkey)) fill_on = false;          // (wave-uniform)
-                    const uint32_t kj = gkey >> 6;
-                    const uint32_t b0 = i == 0 ? 0u : (pk >> 6) + 1u;         // first granule to fill
+                    // (a POS behind the last contig's end -- the read is an IndexError further down -- must not index past the
+                    // table's nb + 1 entries: both granules are clamped to nb, which leaves such a read nothing to fill)
+                    const uint32_t kj = (gkey >> 6) < nb ? (gkey >> 6) : nb;
+                    const uint32_t pj = (pk >> 6) < nb ? (pk >> 6) : nb;
+                    const uint32_t b0 = i == 0 ? 0u : pj + 1u;                // first granule to fill
                     uint32_t cnt = (fill_on && ok && kj >= b0) ? kj - b0 + 1u : 0u;
                     if (cnt <= 2u) {
                         if (cnt) bound[b0] = (uint32_t)i;
@@ -247,7 +250,7 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
                         if (fn > 64u) {
                             kd_u64 spent = 0;
                             if (t == 0) spent = atomicAdd(&status[KDS_B_FILL], (kd_u64)fn);
-                            if (kd_shfl64(spent, 0) > 4ull * nb) { fill_on = false; break; }
+                            if (kd_shfl64(spent, 0) + fn > 4ull * nb) { fill_on = false; break; }   // (spent BEFORE this fill + this fill)
                         }
                         for (uint32_t x = t; x < fn; x += KD_WAVE) bound[f0 + x] = fv;
                     }

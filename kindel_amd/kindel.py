@@ -26,6 +26,7 @@ reference's for the same reason.  Those lines are derived from the GPLv3 referen
 """
 import logging
 import os
+import stat
 from collections import OrderedDict, namedtuple
 
 import numpy as np
@@ -206,6 +207,13 @@ def pileup_batch(batch, bam_path=None, device=0, lib=None, mode=N.KD_MODE_AUTO, 
 STREAM_MAX_SITES = 1 << 26      # 67 M sites = 5 GB of tables at 76 B/site
 
 
+def _is_regular_file(path):
+    try:
+        return stat.S_ISREG(os.stat(path).st_mode)
+    except OSError:
+        return True      # (let the decoder report what is wrong with the path)
+
+
 def _contigs_in_use(bam_path, threads, chunk_bytes, lib):
     """One streamed pass over the file: the @SQ entries that have records, in file order of the header."""
     st = N.Stream(bam_path, threads=threads, chunk_bytes=chunk_bytes, lib=lib)
@@ -235,11 +243,11 @@ def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=N
                     eng = N.Engine(plan.contig_lens, device=device, lib=lib)
                     try:
                         info = eng.push_bam_gpu(plan)
+                        eng.finalize()            # (the reference's deferred exceptions surface here: the tables go with them)
+                        first = eng.contig_first()
                     except BaseException:
                         eng.close()
                         raise
-                    eng.finalize()
-                    first = eng.contig_first()
                     used = np.flatnonzero(first != np.uint64(0xFFFFFFFFFFFFFFFF))
                     order = [int(c) for c in used[np.argsort(first[used], kind="stable")]]   # first appearance, kindel.py:143-151
                     pl = Pileup(eng, list(plan.contig_names), plan.contig_lens, order, bam_path)
@@ -247,6 +255,10 @@ def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=N
                     return pl
         except N.UnsupportedByGpuIngest:
             pass
+    if stream is None and not _is_regular_file(bam_path):
+        # the default route may open the file a second time (a large header: _contigs_in_use); an input that can be read only
+        # once (a pipe, /dev/stdin) is decoded in ONE pass as a whole, like the reference reads it (kindel.py:136-145)
+        stream = False
     if stream is not False:
         st = N.Stream(bam_path, threads=threads, chunk_bytes=chunk_bytes, lib=lib)
         try:
@@ -257,7 +269,8 @@ def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=N
                 return Pileup(None, [], np.zeros(0, np.uint32), [], bam_path)
             names, lens = list(st.contig_names), st.contig_lens
             if total > STREAM_MAX_SITES and not stream:
-                # a header far larger than what the records touch: lay out the contigs in use only
+                # a header far larger than what the records touch: lay out the contigs in use only (a second pass over the
+                # file: regular files only, see above)
                 keep = _contigs_in_use(bam_path, threads, chunk_bytes, lib)
                 if len(keep) == 0:
                     return Pileup(None, [], np.zeros(0, np.uint32), [], bam_path)
@@ -268,11 +281,11 @@ def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=N
             eng = N.Engine(lens, device=device, lib=lib)
             try:
                 info = eng.push_stream(st)
+                eng.finalize()                    # (the reference's deferred exceptions surface here: the tables go with them)
+                first = eng.contig_first()
             except BaseException:
                 eng.close()
                 raise
-            eng.finalize()
-            first = eng.contig_first()
             used = np.flatnonzero(first != np.uint64(0xFFFFFFFFFFFFFFFF))
             order = [int(c) for c in used[np.argsort(first[used], kind="stable")]]   # first appearance, kindel.py:143-151
             pl = Pileup(eng, names, lens, order, bam_path)

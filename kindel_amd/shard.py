@@ -429,7 +429,12 @@ def ingest_sharded(path, rank, world, device="cpu", group=None, threads=0, lib=N
         good = good and all(rows[a, 3] <= rows[b, 2] for a, b in zip(filled, filled[1:]))   # shares ordered by position
     if not good:
         # premises broken: every rank reads the whole file and takes its share of an equal-work partition (same results)
-        full = N.decode_file(path, threads=threads, lib=lib)
+        try:
+            full = N.decode_file(path, threads=threads, lib=lib)
+        except Exception as e:   # noqa: BLE001 -- one rank alone failing here (no memory) would leave the others in the next collective:
+            #                      the failure travels in the result and pileup_consensus_sharded's gather raises it on every rank
+            return dict(batch=None, interval=(0, 0), intervals=[(0, 0)] * world, names=[], lens=np.zeros(0, np.uint32), order=[],
+                        mode="whole-file", stats={}, fail=(type(e).__name__, str(e)))
         lens = full["contig_lens"]
         ivs = partition_weighted(lens, full["contig"], full["pos0"], full["seq_len"], world) if len(full["contig"]) else partition(lens, world)
         batch = None
@@ -508,14 +513,17 @@ def pileup_consensus_sharded(path, rank, world, device="cpu", dev_index=0, group
     import torch.distributed as dist
     from . import _native as N
     ing = ingest_sharded(path, rank, world, device=device, group=group, threads=threads, lib=lib)
-    eng = N.Engine(ing["lens"], device=dev_index, lib=lib)
-    err = None
+    eng = None
+    err = ing.get("fail")       # (the whole-file fallback's decode failed on this rank)
     try:
-        try:        # ANY exception of this rank (a reference exception, no device memory, a native error) goes through the gather
-            eng.set_shard(*ing["interval"])
-            if ing["batch"] is not None and len(ing["batch"]["contig"]):
-                eng.push(ing["batch"])
-            eng.finalize()
+        try:        # ANY exception of this rank (a reference exception, no device memory -- also for the tables themselves --, a native
+            #         error) goes through the gather
+            if err is None:
+                eng = N.Engine(ing["lens"], device=dev_index, lib=lib)
+                eng.set_shard(*ing["interval"])
+                if ing["batch"] is not None and len(ing["batch"]["contig"]):
+                    eng.push(ing["batch"])
+                eng.finalize()
         except Exception as e:   # noqa: BLE001
             err = (type(e).__name__, str(e))
         if world > 1:
@@ -529,6 +537,7 @@ def pileup_consensus_sharded(path, rank, world, device="cpu", dev_index=0, group
         eng.consensus_run(min_depth)
         seqs, changes, minmax = stitch(eng, ing["interval"], device, group, intervals=ing["intervals"])
     finally:
-        eng.close()
+        if eng is not None:
+            eng.close()
     return dict(seqs=seqs, changes=changes, minmax=minmax, names=ing["names"], lens=ing["lens"], order=ing["order"], mode=ing["mode"],
                 stats=ing["stats"])

@@ -12,6 +12,33 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
 
 
+def _gpu_run(config):
+    return "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or "")
+
+
+def pytest_runtest_logstart(nodeid, location):
+    """On a GPU run the log names the test that is running BEFORE it runs (flushed): a HIP abort takes the
+    whole interpreter down, and the last line of the log must say where.  (-p no:faulthandler in pyproject.toml
+    keeps CPython's 5 KB extension-module dump from burying that line.)"""
+    if _GPU_RUN:
+        sys.__stdout__.write("\n[gpu-test] %s " % nodeid)
+        sys.__stdout__.flush()
+
+
+_GPU_RUN = False
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU runs: tests that start other processes, replay graphs or exchange between ranks go last, so a fault
+    in the riskiest part of the runtime cannot erase the parity results in front of it."""
+    global _GPU_RUN
+    _GPU_RUN = _gpu_run(config)
+    if not _GPU_RUN:
+        return
+    risky = ("two_ranks", "executable", "subprocess", "graph", "multirank", "test_packaging", "integration_stub", "test_cli")
+    items.sort(key=lambda it: any(w in it.nodeid.lower() for w in risky))
+
+
 @pytest.fixture(scope="session")
 def emu_lib():
     """TEST INFRASTRUCTURE: the C-ABI compiled against the CPU kernel emulator (tests/emu)."""

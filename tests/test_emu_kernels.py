@@ -530,3 +530,24 @@ def test_scan_cigar_matches_its_reference_statement(emu_lib):
     # the sums-only scan (kd_scan_cigar_inside) decided a good share of them itself -- only ever "regular" -- and left the
     # reads at / over the contig's or the query's end, and those that write behind a trailing clip, to the exact scan
     assert n_inside > 3000 and n_inside_irreg == 0 and n_inside < 38000, (n_inside, n_inside_irreg)
+
+
+@pytest.mark.parametrize("mode", [N.KD_MODE_AUTO, N.KD_MODE_GLOBAL])
+@pytest.mark.parametrize("far", [200000, 50_000_000, 0x7fffff00])
+def test_pos_far_behind_the_last_contig_is_an_index_error_not_a_wild_write(emu_lib, mode, far):
+    """A read whose POS lies (far) behind the end of the LAST contig: kindel.py:51 raises IndexError.  k_prep's boundary table for
+    k_window has S / 64 + 1 entries and the read's granule used to index it unclamped (an out-of-bounds device write of up to
+    ~128 MB reachable from a malformed BAM through the default path); the window path must answer like the general one."""
+    sam = "@SQ\tSN:c\tLN:1000\n" + "".join(
+        "r%d\t0\tc\t%d\t60\t20M\t*\t0\t0\t%s\t*\n" % (k, p, "ACGT" * 5) for k, p in enumerate((10, 20, far)))
+    batch = P.sam_to_batch(sam)
+    with pytest.raises(IndexError):
+        P.Run(emu_lib, batch, mode=mode)
+    # the same with enough reads in front that the far one is not in the batch's first wavefront, and sorted in front of it
+    sam2 = "@SQ\tSN:c\tLN:1000\n" + "".join(
+        "r%d\t0\tc\t%d\t60\t20M\t*\t0\t0\t%s\t*\n" % (k, 1 + (k * 3) % 900, "ACGT" * 5) for k in range(300))
+    lines = sam2.rstrip("\n").split("\n")
+    body = sorted(lines[1:], key=lambda l: int(l.split("\t")[3]))
+    body.append("far\t0\tc\t%d\t60\t20M\t*\t0\t0\t%s\t*" % (far, "ACGT" * 5))
+    with pytest.raises(IndexError):
+        P.Run(emu_lib, P.sam_to_batch("\n".join([lines[0]] + body) + "\n"), mode=mode)

@@ -457,6 +457,7 @@ def test_step_graph_replay_is_verified(hip_lib):
     out = torch.empty(400_000, dtype=torch.uint8, pin_memory=True).numpy()
 
     def check(expect_replay):
+        print("  [graph test] step, expecting replay =", expect_replay, flush=True)      # (a GPU fault takes the interpreter down: the log says which step)
         off, replayed = eng.step_device(synth.device_ptrs(tb), tb["contig"].numel(), tb["seq4_bytes"], tb["cigar_words"], out)
         assert expect_replay is None or replayed == expect_replay
         host = synth.to_numpy(tb)

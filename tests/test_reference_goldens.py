@@ -124,6 +124,32 @@ def test_large_header_is_scanned_then_streamed(api_on_emu, tmp_path):
     st.close()
 
 
+def test_large_header_through_a_pipe_is_read_once(api_on_emu, tmp_path):
+    """The same large header arriving through a FIFO (kindel consensus /dev/stdin): the default route must not open the input a
+    second time -- the second pass would find an empty or blocked pipe -- and decodes it whole in one pass, like the reference."""
+    import threading
+    from kindel_amd import kindel as K
+    small = synth.to_numpy(synth.short_reads([3000, 2000], 20, seed=22, planted=False))
+    batch = dict(small)
+    batch["contig"] = np.where(small["contig"] == 0, 1, 3).astype(np.uint32)
+    batch["contig_lens"] = np.asarray([2_100_000_000, 3000, 1_900_000_000, 2000, 50_000_000], np.uint32)
+    p = str(tmp_path / "big_header.bam")
+    synth.write_bam(p, batch, names=["chr1", "virusA", "chr2", "virusB", "chrUn"], block_bytes=4000)
+    want = K.bam_to_consensus(p)
+    fifo = str(tmp_path / "in.fifo")
+    os.mkfifo(fifo)
+
+    def feed():
+        with open(fifo, "wb") as out, open(p, "rb") as src:       # ONE writer, closed at the end: a second open would block
+            out.write(src.read())
+    th = threading.Thread(target=feed, daemon=True)
+    th.start()
+    got = K.bam_to_consensus(fifo)
+    th.join(timeout=30)
+    assert not th.is_alive()
+    assert [(c.name, c.sequence) for c in got.consensuses] == [(c.name, c.sequence) for c in want.consensuses]
+
+
 def test_sam_insertion_outside_the_bam_alphabet_is_refused(api_on_emu, tmp_path):
     """4-bit base codes cannot hold e.g. 'U'.  In M / clip context that is a KeyError like in the reference; inside an
     insertion the reference would keep the text verbatim (kindel.py:55-58): refused loudly instead of emitting '='."""

@@ -346,3 +346,55 @@ def _run_file_ranks_expect_error(emu_lib, path, world):
         p.join(timeout=60)
         assert p.exitcode == 0
     return results
+
+
+def _worker_one_rank_fails(rank, world, port, emu_path, path, what, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kindel_amd import _native as N
+    from kindel_amd import kindel as K
+    lib = N.Library(emu_path)
+    if rank == 1:      # this rank ALONE runs out of memory: in the whole-file fallback's decode, or when it allocates its tables
+        def boom(*a, **k):
+            raise MemoryError("rank 1 has no memory for " + what)
+        if what == "decode":
+            N.decode_file = boom
+        else:
+            N.Engine = boom
+    try:
+        K.bam_to_consensus_sharded(path, rank, world, device="cpu", lib=lib)
+        q.put("no error")
+    except Exception as e:       # noqa: BLE001
+        q.put(type(e).__name__ + ": " + str(e))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("what", ["decode", "engine"])
+def test_a_failure_of_one_rank_alone_reaches_every_rank(emu_lib, tmp_path, what):
+    """One rank failing where the others do not -- the whole-file fallback's decode (a SAM text file: no BGZF spans), the engine's
+    tables -- must not leave the others waiting in the next collective: the failure travels through the gather."""
+    from kindel_amd import synth
+    batch = synth.to_numpy(synth.short_reads([4000], 8, seed=44))
+    bam = str(tmp_path / "ok.bam")
+    synth.write_bam(bam, batch, sort_order="coordinate", block_bytes=1500)
+    path = bam
+    if what == "decode":      # the fallback is taken by a file that has no BGZF blocks to share out
+        import gzip
+        path = str(tmp_path / "plain.bam")
+        from kindel_amd import _native as N   # (the BGZF members concatenated = one valid gzip stream; rewritten as ONE member)
+        with gzip.open(bam, "rb") as src, gzip.open(path, "wb") as dst:
+            dst.write(src.read())
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_one_rank_fails, args=(r, 3, port, emu_lib.path, path, what, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r.startswith("MemoryError") and "rank 1 has no memory" in r for r in results), results
