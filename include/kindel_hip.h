@@ -209,17 +209,18 @@ int kd_exchange_row(kd_ctx *ctx, void *dev_row, uint64_t cap, uint64_t *row_byte
 int kd_set_exchange(kd_ctx *ctx, void *dev_row, uint64_t cap);
 /* One whole step over a DEVICE-resident batch in one call: kd_reset + kd_push_batch_device + kd_finalize + kd_consensus_run (no
  * patches) + kd_consensus_fetch_all(seq_out ...), i.e. parse_records' loop and consensus_sequence's loop (kindel.py:40-81,
- * :384-430) for every contig of the batch.  The first call with a given batch runs that sequence and captures it as a hipGraph;
- * calls that repeat the same batch (same pointers, sizes, seq_out, shard, tuning) replay the graph -- one launch instead of ~20
- * dispatches and two blocking read-backs -- and then verify on the device's status words and consensus offsets that the replay
- * took exactly the decisions the eager sequence would have taken (else the eager sequence runs).  *replayed (may be NULL): 1
- * if the graph served the call.  seq_out should be pinned host memory (hipHostMalloc / hipHostRegister): with a pageable seq_out the
- * step is never captured -- a graph's copy nodes may only point at page-locked memory -- and every call takes the eager sequence.
- * Errors as kd_finalize. */
+ * :384-430) for every contig of the batch, queued back to back with two host round trips (the EAGER sequence: what every call
+ * takes by default, and what a new batch takes in any case).  With kd_set_step_graph(ctx, 1) -- opt-in, experimental -- the first
+ * repeat of a step on the same resident batch (same pointers, sizes, seq_out, shard, tuning) is also captured as a hipGraph and
+ * later repeats replay it -- one launch instead of ~20 dispatches -- and then verify on the device's status words and consensus
+ * offsets that the replay took exactly the decisions the eager sequence would have taken (else the eager sequence runs).
+ * *replayed (may be NULL): 1 if a graph served the call.  seq_out should be pinned host memory (hipHostMalloc / hipHostRegister;
+ * pinned memory makes the closing copy asynchronous, and a pageable seq_out is never captured).  Errors as kd_finalize. */
 int kd_step(kd_ctx *ctx, const kd_batch *dev_batch, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out,
             uint64_t *contig_off, int *replayed);
-/* kd_set_step_graph: on = 0: kd_step always takes the eager sequence (what a new batch takes anyway); on = 1 (default): the first
- * REPEAT of a step on the same resident batch is captured, later repeats replay the graph. */
+/* kd_set_step_graph: on = 0 (default since round 5): kd_step always takes the eager sequence; on = 1: the first REPEAT of a step
+ * on the same resident batch is captured, later repeats replay the graph.  Experimental: on ROCm 7.2 / MI355X a replay on changed
+ * inputs faulted in a long-lived process where the same launches submitted one by one did not. */
 int kd_set_step_graph(kd_ctx *ctx, int on);
 /* kd_finish: everything behind the pushes in one call and ONE host round trip -- kd_finalize + kd_consensus_run(min_depth, no
  * patches) + kd_consensus_fetch_all -- i.e. consensus(insertions[pos]) :420 and consensus_sequence :384-430 for all contigs, the

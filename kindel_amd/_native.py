@@ -539,7 +539,7 @@ class Engine:
 
     def step_device(self, ptrs, n_reads, seq4_bytes, cigar_words, out, min_depth=1):
         """One whole step over a device-resident batch (kd_step: reset + record loop + insertion reduction + consensus + all
-        contigs' consensus bytes into `out`, ideally pinned).  Repeating the same batch replays a captured hipGraph.
+        contigs' consensus bytes into `out`, ideally pinned).  After set_step_graph(True) repeating the same batch replays a captured hipGraph.
         -> (contig_off uint64[n_contigs + 1], replayed bool)"""
         b = self._struct(ptrs, n_reads)
         b.seq4_bytes, b.cigar_words = seq4_bytes, cigar_words
@@ -550,7 +550,8 @@ class Engine:
         return off, bool(rep.value)
 
     def set_step_graph(self, on):
-        """False: step_device always takes the eager sequence; True (default): a repeated step is captured and replayed."""
+        """False (default): step_device always takes the eager sequence; True (opt-in, experimental): a repeated step is captured as a
+        hipGraph and replayed."""
         self._check(self.lib.dll.kd_set_step_graph(self._h, 1 if on else 0), "kd_set_step_graph")
 
     def finish(self, out, min_depth=1):

@@ -103,7 +103,9 @@ struct KdEngine {
     uint64_t step_fasta_len = 0;   // consensus bytes of the recorded step
     uint64_t step_last_sig[12] = {0};
     bool step_record_bad = false;
-    bool step_graph = true;        // kd_set_step_graph: capture a repeated step as a hipGraph
+    bool step_graph = false;       // kd_set_step_graph: capture a repeated step as a hipGraph.  OPT-IN since round 5: on this stack (ROCm 7.2,
+                                   // MI355X) a replay faulted twice where the same launches, submitted one by one with the same recorded
+                                   // decisions, ran clean ("hipGraph replay") -- the eager sequence is the product path
     bool step_have = false;
 
     int fail(int code, const std::string &m) { err = m; return code; }
@@ -143,6 +145,7 @@ struct KdEngine {
     int create(int device, uint32_t n, const uint32_t *lens, void *stream) {
         if (!n || !lens) return fail(KD_E_ARG, "kd_create: no contigs");
         if (rt.init(device, stream)) return hipfail("kd_create: device init");
+        knob_step_trace = getenv("KD_STEP_TRACE") != nullptr; knob_replay_eager = getenv("KD_STEP_REPLAY_EAGER") != nullptr;
         n_contigs = n;
         clen.assign(lens, lens + n);
         cbase.resize(n);
@@ -202,7 +205,8 @@ struct KdEngine {
     }
 
     // (re)allocate the tables for the current shard and zero them
-    int prepare_tables() {
+    // side: the zeroing goes onto the runtime's side stream (next to what the main stream queues until rt.join_side())
+    int prepare_tables(bool side = false) {
         const uint64_t lo = g_lo / KD_CNS_TILE * KD_CNS_TILE;
         const uint64_t hi = std::min<uint64_t>(S, (g_hi + 1 + KD_CNS_TILE - 1) / KD_CNS_TILE * KD_CNS_TILE);
         if (!d_tab || lo != alloc_lo || hi != alloc_hi) {
@@ -212,7 +216,7 @@ struct KdEngine {
             if (!d_tab)
                 return fail(KD_E_NOMEM, "device allocation of the tables failed (" + std::to_string((size_t)KDC_NCH * pitch * 4) + " bytes): " + rt.err());
         }
-        if (rt.memset(d_tab, 0, (size_t)KDC_NCH * pitch * 4)) return hipfail("memset tables");
+        if (side ? rt.memset_side(d_tab, 0, (size_t)KDC_NCH * pitch * 4) : rt.memset(d_tab, 0, (size_t)KDC_NCH * pitch * 4)) return hipfail("memset tables");
         tables_ready = true;
         return KD_OK;
     }
@@ -314,16 +318,17 @@ struct KdEngine {
         const bool self_planned = mode != KD_MODE_GLOBAL && mode != KD_MODE_STRIP;
         const uint32_t nb = (uint32_t)(S / 64);
         if (self_planned && (rc = ensure(b_bound, ((size_t)nb + 1) * 4))) return rc;
-        if (rt.launch("k_prep", k_prep, prep_grid, KD_PREP_BLOCK, 0, R, T, rinfo, cold, (uint32_t *)b_coldcnt.p, (kd_u64 *)b_coldev.p, (kd_u64 *)b_coldpool.p, irreg, lng, (uint32_t *)b_readev.p,
-                      (kd_u64 *)b_readpool.p, d_status, prep_per, self_planned ? (uint32_t *)b_bound.p : (uint32_t *)nullptr, nb))
-            return hipfail("k_prep");
-        // k_prep touches no table: the first batch's table zeroing is queued BEHIND it and behind the status copy, so that
-        // the host's wait for the copy (a round trip of ~30 us) passes while the memset runs
-        if (step_mode != STEP_REPLAY && rt.d2h_small_begin(d_status, KDS_COUNT * 8)) return hipfail("status d2h");
+        // k_prep touches no table: the first batch's table zeroing (360 MB at full size) runs NEXT to it, on the side stream
+        // (round 5; rounds 3 - 4 queued it behind k_prep's status copy, where it hid the host's wait for the copy but not itself).
+        // The status copy waits for k_prep alone; what is queued behind the join (everything that touches the tables) for both.
         if (!tables_ready) {
-            if ((rc = prepare_tables())) return rc;
-            T = tabs();      // (the tables may just have been allocated: k_prep only used the contig geometry of T)
+            if ((rc = prepare_tables(true))) return rc;
+            T = tabs();      // (the tables may just have been allocated: k_prep only uses the contig geometry of T)
         }
+        const int rc_prep = rt.launch("k_prep", k_prep, prep_grid, KD_PREP_BLOCK, 0, R, T, rinfo, cold, (uint32_t *)b_coldcnt.p, (kd_u64 *)b_coldev.p, (kd_u64 *)b_coldpool.p, irreg, lng, (uint32_t *)b_readev.p,
+                                  (kd_u64 *)b_readpool.p, d_status, prep_per, self_planned ? (uint32_t *)b_bound.p : (uint32_t *)nullptr, nb);
+        const int rc_copy = (!rc_prep && step_mode != STEP_REPLAY) ? rt.d2h_small_begin(d_status, KDS_COUNT * 8) : 0;
+        if (rt.join_side() || rc_prep || rc_copy) return hipfail(rc_prep ? "k_prep" : rc_copy ? "status d2h" : "push: join");      // (the join on every way out)
         if (step_mode == STEP_REPLAY) { if ((rc = fetch_status())) return rc; }
         else {
             if (rt.d2h_small_end(h_status.data(), KDS_COUNT * 8)) return hipfail("status d2h");
@@ -1211,6 +1216,8 @@ struct KdEngine {
     }
 
     bool step_in_capture = false;
+    // fault-localisation knobs, read when the context is created (create())
+    bool knob_step_trace = false, knob_replay_eager = false;
     int replay_copies(uint8_t *seq_out) {
         const size_t mb = meta_bytes();
         if (rt.d2h_async(step_meta_pin, b_coff.p, mb)) return hipfail("consensus: d2h");      // (pinned: see Runtime::graph_stage)
@@ -1237,7 +1244,7 @@ struct KdEngine {
         static const int kDecisive[] = {KDS_ERR_READ, KDS_N_EV, KDS_POOL, KDS_B_INS_OPS, KDS_B_INS_BASES, KDS_B_MAXSPAN, KDS_B_MAXLEAD, KDS_B_MAXSEGSPAN, KDS_B_ROW_DWORDS,
                                         KDS_B_UNSORTED, KDS_B_N_COLD, KDS_B_N_IRREG, KDS_B_N_LONG, KDS_B_N_REG, KDS_INS_COLLISION, KDS_INTERNAL,
                                         KDS_BAD_BASE};
-        static const bool step_trace = getenv("KD_STEP_TRACE") != nullptr;      // (knob, fault localisation: the step's path and the addresses a fault report can be matched with)
+        const bool step_trace = knob_step_trace;      // (knob, fault localisation: the step's path and the addresses a fault report can be matched with)
         if (step_trace)
             fprintf(stderr, "[kd] step: have_graph %d status %p tab %p cns %p coff %p seq_out %p meta_pin %p reads %p..%p\n", (int)(step_have && rt.has_graph()),
                     (void *)d_status, (void *)d_tab, b_cns.p, b_coff.p, (void *)seq_out, (void *)step_meta_pin, (const void *)B.contig, (const void *)B.seq4);
@@ -1245,7 +1252,7 @@ struct KdEngine {
         if (step_have && rt.has_graph() && !memcmp(sig, step_sig, sizeof sig) && !step_status.empty()) {
             // (knob, fault localisation: KD_STEP_REPLAY_EAGER=1 submits the recorded sequence kernel by kernel -- the same launches with the
             // same recorded host decisions as the graph holds, but visible to KD_LAUNCH_TRACE -- instead of launching the graph)
-            static const bool replay_eager = getenv("KD_STEP_REPLAY_EAGER") != nullptr;
+            const bool replay_eager = knob_replay_eager;
             bool ran = false;
             if (replay_eager) {
                 step_mode = STEP_REPLAY; step_pos = 0;

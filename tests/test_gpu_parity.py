@@ -429,6 +429,34 @@ def test_cli_two_ranks_on_one_gpu(hip_lib, tmp_path):
     assert one.stderr.strip() and one.stderr.strip() in two.stderr     # the same report (the CLI's own defaults, e.g. min_overlap 7)
 
 
+def test_bench_two_ranks_on_one_gpu_same_fasta():
+    """bench.py's N > 1 product path on hardware as far as one GPU allows: `bench.py --gpus 2` under torch.distributed.run (the
+    driver's launch line, gloo instead of RCCL because both ranks share the GPU) -- one input cut into two work-balanced position
+    intervals, shard-local tables, the engine-written exchange row, ONE all-gather -- leaves the same FASTA (sha256 over all
+    contigs) as the single-GPU run of the same workload; weak scaling (two config-sized intervals) measured in the same call."""
+    import json
+    import socket
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    common = ["--steps", "2", "--warmup", "1", "--scale", "0.05", "--no-cpu-baseline", "--e2e-scale", "0", "--no-graph"]
+    one = subprocess.run([sys.executable, "bench.py"] + common, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), "bench.py", "--gpus", "2", "--backend", "gloo", "--scaling", "strong"] + common,
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["scaling"] == "strong"
+    assert b["fasta_sha256"] == a["fasta_sha256"] and b["consensus_len"] == a["consensus_len"]
+    assert b["config"]["aligned_events"] == a["config"]["aligned_events"]        # the ONE input, every read counted once
+    assert b["other_scaling"]["scaling"] == "weak" and b["other_scaling"]["value"] > 0
+
+
 @pytest.mark.parametrize("key,chunk", [("bwa_mem__2.1.sub_test", 5000), ("minimap2__1.1.multi", 900), ("ext__1.issue23.debug", 30000)])
 def test_streamed_ingest_many_small_batches(hip_lib, tmp_path, key, chunk):
     """kd_push_stream on the GPU with chunks small enough that batch boundaries cut windows (decode thread + pushing thread,
@@ -446,20 +474,23 @@ def test_streamed_ingest_many_small_batches(hip_lib, tmp_path, key, chunk):
     assert [c.sequence for c in ra.consensuses] == [g["consensus"] for g in GOLD[key]["contigs"]]
 
 
-def test_step_graph_replay_is_verified(hip_lib):
-    """kd_step: the first call runs the eager sequence, the first REPEAT on the same resident batch runs it again and captures it,
-    later repeats replay the hipGraph.  Same batch -> same bytes;
-    bases changed in place (no host decision depends on them) -> the replay is still exact for the NEW data; a CIGAR changed in
-    place so that the event counts move -> the verification notices and the eager sequence runs.  Each time vs the oracle."""
+def _step_sequence(lib, graph):
+    """kd_step over one resident batch, step after step, every step's consensus and tables against the oracle: the same batch
+    again, bases changed in place under the same pointers, a CIGAR changed in place so that the event counts move.  graph=False:
+    the eager sequence every time (the product's default).  graph=True (kd_set_step_graph(1), opt-in): the first REPEAT on the same
+    resident batch is also captured, later repeats replay the hipGraph; changed bases (no host decision depends on them) -> the
+    replay must still be exact for the NEW data or the verification must notice; changed event counts -> the verification notices
+    and the eager sequence runs."""
     import torch
     tb = synth.short_reads([120_000, 30_000], 40, seed=31, device="cuda:0")
-    eng = N.Engine(tb["contig_lens"], lib=hip_lib)
+    eng = N.Engine(tb["contig_lens"], lib=lib)
+    eng.set_step_graph(graph)
     out = torch.empty(400_000, dtype=torch.uint8, pin_memory=True).numpy()
 
     def check(expect_replay):
-        print("  [graph test] step, expecting replay =", expect_replay, flush=True)      # (a GPU fault takes the interpreter down: the log says which step)
+        print("  [step test] graph =", graph, "expecting replay =", expect_replay, flush=True)      # (a GPU fault takes the interpreter down: the log says which step)
         off, replayed = eng.step_device(synth.device_ptrs(tb), tb["contig"].numel(), tb["seq4_bytes"], tb["cigar_words"], out)
-        assert expect_replay is None or replayed == expect_replay
+        assert expect_replay is None or replayed == (expect_replay and graph)
         host = synth.to_numpy(tb)
         for cid in ko.contig_order(host):
             oa = ko.parse_records(host, cid)
@@ -475,10 +506,10 @@ def test_step_graph_replay_is_verified(hip_lib):
         check(True)
         eng.set_step_graph(False)       # the eager sequence only (what bench.py times as `value`)
         check(False)
-        eng.set_step_graph(True)
+        eng.set_step_graph(graph)
         check(False)
         check(True)
-        # new bases under the same pointers: the replay runs the right kernels on the new data, but what it hands back from its
+        # new bases under the same pointers: a replay runs the right kernels on the new data, but what it hands back from its
         # record (offsets, depth ranges) may no longer be true -- the verification compares them with the device's and decides;
         # either way the results must be those of the NEW data, and the step after is a replay again
         nib = torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device="cuda:0")
@@ -486,18 +517,33 @@ def test_step_graph_replay_is_verified(hip_lib):
         tb["seq4"][: tb["seq4_bytes"]] = (nib[r] << 4) | nib[(r + 1) % 4]
         check(None)
         check(True)
-        # one more insertion (an M op of a 1-op read becomes M I M): the event count changes -> eager, then captured again
+        # one insertion less (the I of a 5-op read S M I M S becomes an M): the event count changes -> eager, then captured again
         ncig = tb["n_cig"].cpu().numpy()
         i = int(np.flatnonzero(ncig == 5)[0]) if (ncig == 5).any() else None
-        if i is not None:       # a 5-op read S M I|D M S: turn its middle op into the other kind
+        if i is not None:
             co = int(tb["cig_off"][i])
             w = int(tb["cigar"][co + 2])
             ln, op = w >> 4, w & 15
-            if op == 2:         # deletion -> insertion of the same length: the read's query no longer adds up -> irregular; skip
-                pass
-            else:               # insertion -> match: fewer events
+            if op != 2:         # (a deletion -> insertion of the same length would leave a read whose query no longer adds up: skipped)
                 tb["cigar"][co + 2] = (ln << 4) | 0
                 check(False)
                 check(True)
     finally:
         eng.close()
+
+
+def test_step_repeats_and_inputs_changed_in_place(hip_lib):
+    """kd_step, the product's default (eager) sequence: see _step_sequence."""
+    _step_sequence(hip_lib, graph=False)
+
+
+def test_step_graph_replay_is_verified_in_a_fresh_process():
+    """kd_step with the opt-in hipGraph replay (kd_set_step_graph(1)): see _step_sequence.  In a process of its own: on this stack
+    (ROCm 7.2, MI355X) a replay on changed inputs died with a GPU memory fault at the end of a long-lived process -- this suite --
+    where the same launches submitted one by one (KD_STEP_REPLAY_EAGER=1) ran clean, and a GPU fault takes the whole interpreter
+    down (gpurun_out/graph_hunt of round 5); which is why the replay is opt-in and the eager sequence the default."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", "from tests import test_gpu_parity as T; from kindel_amd import _native as N; "
+                        "T._step_sequence(N.default_library(), graph=True); print('GRAPH-REPLAY-OK')"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "GRAPH-REPLAY-OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
