@@ -205,8 +205,7 @@ struct KdEngine {
     }
 
     // (re)allocate the tables for the current shard and zero them
-    // side: the zeroing goes onto the runtime's side stream (next to what the main stream queues until rt.join_side())
-    int prepare_tables(bool side = false) {
+    int prepare_tables() {
         const uint64_t lo = g_lo / KD_CNS_TILE * KD_CNS_TILE;
         const uint64_t hi = std::min<uint64_t>(S, (g_hi + 1 + KD_CNS_TILE - 1) / KD_CNS_TILE * KD_CNS_TILE);
         if (!d_tab || lo != alloc_lo || hi != alloc_hi) {
@@ -216,7 +215,7 @@ struct KdEngine {
             if (!d_tab)
                 return fail(KD_E_NOMEM, "device allocation of the tables failed (" + std::to_string((size_t)KDC_NCH * pitch * 4) + " bytes): " + rt.err());
         }
-        if (side ? rt.memset_side(d_tab, 0, (size_t)KDC_NCH * pitch * 4) : rt.memset(d_tab, 0, (size_t)KDC_NCH * pitch * 4)) return hipfail("memset tables");
+        if (rt.memset(d_tab, 0, (size_t)KDC_NCH * pitch * 4)) return hipfail("memset tables");
         tables_ready = true;
         return KD_OK;
     }
@@ -318,17 +317,18 @@ struct KdEngine {
         const bool self_planned = mode != KD_MODE_GLOBAL && mode != KD_MODE_STRIP;
         const uint32_t nb = (uint32_t)(S / 64);
         if (self_planned && (rc = ensure(b_bound, ((size_t)nb + 1) * 4))) return rc;
-        // k_prep touches no table: the first batch's table zeroing (360 MB at full size) runs NEXT to it, on the side stream
-        // (round 5; rounds 3 - 4 queued it behind k_prep's status copy, where it hid the host's wait for the copy but not itself).
-        // The status copy waits for k_prep alone; what is queued behind the join (everything that touches the tables) for both.
+        if (rt.launch("k_prep", k_prep, prep_grid, KD_PREP_BLOCK, 0, R, T, rinfo, cold, (uint32_t *)b_coldcnt.p, (kd_u64 *)b_coldev.p, (kd_u64 *)b_coldpool.p, irreg, lng, (uint32_t *)b_readev.p,
+                      (kd_u64 *)b_readpool.p, d_status, prep_per, self_planned ? (uint32_t *)b_bound.p : (uint32_t *)nullptr, nb))
+            return hipfail("k_prep");
+        // k_prep touches no table: the first batch's table zeroing is queued BEHIND it and behind the status copy, so that
+        // the host's wait for the copy (a round trip of ~30 us) passes while the memset runs.  (Round 5 measured the zeroing NEXT
+        // to k_prep instead, on a side stream joined in front of k_window: C3 1.593 ms against 1.598 with the zeroing in front of
+        // k_prep on the main stream and 1.52 - 1.56 this way -- the two kernels share the memory system, nothing is gained: dropped.)
+        if (step_mode != STEP_REPLAY && rt.d2h_small_begin(d_status, KDS_COUNT * 8)) return hipfail("status d2h");
         if (!tables_ready) {
-            if ((rc = prepare_tables(true))) return rc;
-            T = tabs();      // (the tables may just have been allocated: k_prep only uses the contig geometry of T)
+            if ((rc = prepare_tables())) return rc;
+            T = tabs();      // (the tables may just have been allocated: k_prep only used the contig geometry of T)
         }
-        const int rc_prep = rt.launch("k_prep", k_prep, prep_grid, KD_PREP_BLOCK, 0, R, T, rinfo, cold, (uint32_t *)b_coldcnt.p, (kd_u64 *)b_coldev.p, (kd_u64 *)b_coldpool.p, irreg, lng, (uint32_t *)b_readev.p,
-                                  (kd_u64 *)b_readpool.p, d_status, prep_per, self_planned ? (uint32_t *)b_bound.p : (uint32_t *)nullptr, nb);
-        const int rc_copy = (!rc_prep && step_mode != STEP_REPLAY) ? rt.d2h_small_begin(d_status, KDS_COUNT * 8) : 0;
-        if (rt.join_side() || rc_prep || rc_copy) return hipfail(rc_prep ? "k_prep" : rc_copy ? "status d2h" : "push: join");      // (the join on every way out)
         if (step_mode == STEP_REPLAY) { if ((rc = fetch_status())) return rc; }
         else {
             if (rt.d2h_small_end(h_status.data(), KDS_COUNT * 8)) return hipfail("status d2h");

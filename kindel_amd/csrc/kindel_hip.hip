@@ -29,10 +29,10 @@ struct HipRt {
     }
     const char *err() const { return e.c_str(); }
 
-    bool trace = false;     // KD_LAUNCH_TRACE (knob, read when the context is created: fault localisation -- name, geometry, then wait for the kernel)
+    int trace = 0;          // KD_LAUNCH_TRACE (knob, read when the context is created: fault localisation -- 1: name, geometry, then wait for the kernel; 2: print only)
     int init(int device, void *s) {
         int n = 0;
-        trace = getenv("KD_LAUNCH_TRACE") != nullptr;
+        trace = getenv("KD_LAUNCH_TRACE") ? std::max(1, atoi(getenv("KD_LAUNCH_TRACE"))) : 0;
         if (bad(hipGetDeviceCount(&n))) return 1;
         if (device < 0 || device >= n) { e = "no such HIP device (" + std::to_string(n) + " visible)"; return 1; }
         dev = device;
@@ -53,7 +53,6 @@ struct HipRt {
         for (int k = 0; k < 2; k++) { if (up_pin[k]) { (void)hipHostFree(up_pin[k]); up_pin[k] = nullptr; } if (up_ev[k]) { (void)hipEventDestroy(up_ev[k]); up_ev[k] = nullptr; } }
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
         if (ev_copy) { (void)hipEventDestroy(ev_copy); ev_copy = nullptr; }
-        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); side = nullptr; (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); ev_fork = ev_join = nullptr; side_pending = false; }
         if (own_stream && stream) { (void)hipSetDevice(dev); (void)hipStreamDestroy(stream); }
         stream = nullptr;
     }
@@ -67,31 +66,6 @@ struct HipRt {
     }
     void free(void *p) { (void)hipSetDevice(dev); (void)hipFree(p); }
     int memset(void *p, int v, size_t n) { return n ? bad(hipMemsetAsync(p, v, n, stream)) : 0; }
-    // A memset on a SIDE stream, ordered behind everything queued on the main stream so far; what the main stream queues from
-    // now on runs next to it until join_side() orders the main stream behind it.  (The zeroing of the tables -- 360 MB at full
-    // size, 48 us -- next to k_prep, which touches no table and is bound by its requests, not by bytes.)  Captured steps: the
-    // side stream joins the capture through the fork event and leaves it through the join.
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool side_pending = false;
-    int memset_side(void *p, int v, size_t n) {
-        if (!n) return 0;
-        if (bad(hipSetDevice(dev))) return 1;
-        if (!side && (bad(hipStreamCreateWithFlags(&side, hipStreamNonBlocking)) || bad(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)) ||
-                      bad(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming))))
-            return 1;
-        if (side_pending && join_side()) return 1;
-        if (bad(hipEventRecord(ev_fork, stream)) || bad(hipStreamWaitEvent(side, ev_fork, 0)) || bad(hipMemsetAsync(p, v, n, side)) ||
-            bad(hipEventRecord(ev_join, side)))
-            return 1;
-        side_pending = true;
-        return 0;
-    }
-    int join_side() {
-        if (!side_pending) return 0;
-        side_pending = false;
-        return bad(hipStreamWaitEvent(stream, ev_join, 0));
-    }
     int memset2d(void *p, size_t pitch, int v, size_t width, size_t height) {
         return (width && height) ? bad(hipMemset2DAsync(p, pitch, v, width, height, stream)) : 0;
     }
@@ -101,7 +75,7 @@ struct HipRt {
         if (n && bad(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream))) return 1;
         return bad(hipStreamSynchronize(stream));
     }
-    int sync() { if (side_pending && join_side()) return 1; return bad(hipStreamSynchronize(stream)); }
+    int sync() { return bad(hipStreamSynchronize(stream)); }
     int d2h_async(void *h, const void *d, size_t n) { return n ? bad(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream)) : 0; }
     // ---- one-launch step (kd_step): the dispatch chain of a step captured into a hipGraph and replayed ----
     hipGraphExec_t graph_exec = nullptr;
@@ -241,7 +215,7 @@ struct HipRt {
         if (trace && !capturing) fprintf(stderr, "[kd] %s grid %u block %u lds %zu\n", name, grid, block, shmem);
         k<<<dim3(grid), dim3(block), shmem, stream>>>(args...);
         if (bad(hipGetLastError())) return 1;
-        if (trace && !capturing && bad(hipStreamSynchronize(stream))) return 1;
+        if (trace == 1 && !capturing && bad(hipStreamSynchronize(stream))) return 1;
         if (timed) {
             if (bad(hipEventRecord(p.b, stream))) return 1;
             p.name = name;

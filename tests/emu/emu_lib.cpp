@@ -21,8 +21,6 @@ struct EmuRt {
     void *alloc(size_t bytes) { return aligned_alloc(256, (bytes + 255) & ~size_t(255)); }
     void free(void *p) { ::free(p); }
     int memset(void *p, int v, size_t n) { ::memset(p, v, n); return 0; }
-    int memset_side(void *p, int v, size_t n) { ::memset(p, v, n); return 0; }     // (one queue here: nothing runs next to anything)
-    int join_side() { return 0; }
     int memset2d(void *p, size_t pitch, int v, size_t width, size_t height) {
         for (size_t r = 0; r < height; r++) ::memset((char *)p + r * pitch, v, width);
         return 0;
