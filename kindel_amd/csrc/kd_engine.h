@@ -68,7 +68,7 @@ struct KdEngine {
     // what the last insertion reduction left behind (k_ins_cleanup undoes it before the event buffers are reused)
     uint64_t ins_dirty_ev = 0, ins_dirty_bias = 0;   // (bias: alloc_lo when the reduction ran -- best_a[] / best_b[] are shard-local)
     KdInsTab ins_dirty_tab;
-    Buf b_cns, b_changes, b_tilesum, b_tilemm, b_tileoff, b_coff;
+    Buf b_cns, b_changes, b_tilesum, b_tilemm, b_tileoff;
 
     uint64_t reads_pushed = 0;
     uint64_t last_windowed = 0, last_nwin = 0;   // (kd_batch_info: the last batch took the window path; windows it planned)
@@ -160,7 +160,9 @@ struct KdEngine {
         d_clen = (uint32_t *)rt.alloc((size_t)n * 4);
         d_cbase = (kd_u64 *)rt.alloc((size_t)n * 8);
         d_seg = (uint32_t *)rt.alloc((size_t)(S / 64) * 4);
-        d_status = (kd_u64 *)rt.alloc(KDS_COUNT * 8);
+        // the status words and, right behind them, the consensus run's metadata block (per-contig output offsets and depth ranges,
+        // meta_coff() / meta_mm()): what a step hands back to the host is ONE copy (round 5; it was two, 6 us apart)
+        d_status = (kd_u64 *)rt.alloc(KDS_COUNT * 8 + meta_bytes());
         d_first_idx = (kd_u64 *)rt.alloc((size_t)n * 8);
         d_err_first = (kd_u64 *)rt.alloc((size_t)n * 8);
         d_err_code = (uint32_t *)rt.alloc((size_t)n * 4);
@@ -181,7 +183,7 @@ struct KdEngine {
     void destroy() {
         Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_itemwin, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_rows, &b_rowinfo, &b_rowoff, &b_longacc, &b_coldcnt, &b_coldev, &b_coldpool, &b_ev_site, &b_ev_len,
                       &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_best2, &b_flag, &b_bound, &b_hot, &b_patch, &b_cns, &b_changes,
-                      &b_tilesum, &b_tilemm, &b_tileoff, &b_coff};
+                      &b_tilesum, &b_tilemm, &b_tileoff};
         for (Buf *b : all) release(*b);
         for (Buf &b : b_stage) release(b);
         release(b_srec); release(b_smallcig); release(b_sortrows); release(b_sortseg);
@@ -773,8 +775,8 @@ struct KdEngine {
     bool fin_launched = false;      // the hash reduction ran (there were insertion events)
     bool cns_meta_fresh = false;    // k_ins_flag has just left the consensus run's per-contig words initialised
     KdInsTab fin_H;
-    kd_u64 *meta_coff() const { return (kd_u64 *)b_coff.p; }
-    uint32_t *meta_mm() const { return reinterpret_cast<uint32_t *>((kd_u64 *)b_coff.p + n_contigs + 1); }
+    kd_u64 *meta_coff() const { return d_status + KDS_COUNT; }
+    uint32_t *meta_mm() const { return reinterpret_cast<uint32_t *>(d_status + KDS_COUNT + n_contigs + 1); }
     size_t meta_bytes() const { return ((size_t)n_contigs + 1) * 8 + (size_t)n_contigs * 8; }
 
     int reduce_insertions(int attempt) {
@@ -813,7 +815,6 @@ struct KdEngine {
             if ((rc = ensure(b_best, n_local * 8)) || (rc = ensure(b_best2, n_local * 8))) return rc;
             if (rt.memset(b_best.p, 0, b_best.cap) || rt.memset(b_best2.p, 0, b_best2.cap)) return hipfail("finalize: memset best");
         }
-        if ((rc = ensure(b_coff, meta_bytes()))) return rc;
         // the event counts are exact as of the last push (k_prep reserves the slots, push_device reads them back)
         const uint64_t n_ev = h_status[KDS_N_EV];
         fin_launched = false;
@@ -994,7 +995,7 @@ struct KdEngine {
 
     // ---- consensus ----
     // consensus_launch() queues the kernels; consensus_collect() takes what they left in the run's metadata block
-    //   u64 contig_off[n_contigs + 1] | u32 minmax[2 n_contigs]        (b_coff; initialised on the device by k_ins_flag)
+    //   u64 contig_off[n_contigs + 1] | u32 minmax[2 n_contigs]        (behind the status words; initialised on the device by k_ins_flag)
     //   u64 patch_off[np] | patch_start[np] | patch_end[np]            (b_patch; only with CDR patches: --realign)
     // once the caller has copied it back (consensus_run: its own copy; kd_step: together with the status words and the FASTA).
     uint64_t cns_tile_first = 0, cns_tiles = 0, cns_cap = 0;
@@ -1008,7 +1009,7 @@ struct KdEngine {
         if ((rc = ensure(b_changes, (size_t)(alloc_hi - alloc_lo) + 64))) return rc;   // shard-local (read back through copy_changes)
         const bool self_scan = n_tiles <= KD_CNS_SELF_SCAN;
         if ((rc = ensure(b_cns, cap)) || (rc = ensure(b_tilesum, n_tiles * 8)) || (rc = ensure(b_tilemm, n_tiles * sizeof(KdTileMM))) ||
-            (!self_scan && (rc = ensure(b_tileoff, (n_tiles + 1) * 8))) || (rc = ensure(b_coff, meta_bytes())))
+            (!self_scan && (rc = ensure(b_tileoff, (n_tiles + 1) * 8))))
             return rc;
         KdTabs T = tabs();
         KdIns I = insdesc();
@@ -1065,7 +1066,7 @@ struct KdEngine {
         int rc;
         if ((rc = consensus_launch(min_depth, n_patches, ps, pe))) return rc;
         std::vector<uint64_t> down(meta_bytes() / 8, 0);
-        if (rt.d2h(down.data(), b_coff.p, meta_bytes())) return hipfail("consensus: d2h");
+        if (rt.d2h(down.data(), meta_coff(), meta_bytes())) return hipfail("consensus: d2h");
         if (n_patches && rt.d2h(h_poff.data(), b_patch.p, (size_t)n_patches * 8)) return hipfail("consensus: d2h");
         return consensus_collect(down.data());
     }
@@ -1187,7 +1188,7 @@ struct KdEngine {
             uint8_t *st = (uint8_t *)rt.stage(KDS_COUNT * 8 + mb);
             if (!st) return hipfail("kd_finish: pinned staging");
             if (exch_row && (rc = exchange_queue(exch_row, exch_cap, std::min<uint64_t>(cns_cap, shard_sites + 4096)))) return rc;
-            if (rt.d2h_async(st, d_status, KDS_COUNT * 8) || rt.d2h_async(st + KDS_COUNT * 8, b_coff.p, mb) ||
+            if (rt.d2h_async(st, d_status, KDS_COUNT * 8 + mb) ||      // (status words | metadata: adjacent in device memory)
                 (guess && rt.d2h_async(seq_out, b_cns.p, guess)) || rt.sync())
                 return hipfail("kd_finish: d2h");
             memcpy(h_status.data(), st, KDS_COUNT * 8);
@@ -1220,7 +1221,7 @@ struct KdEngine {
     bool knob_step_trace = false, knob_replay_eager = false;
     int replay_copies(uint8_t *seq_out) {
         const size_t mb = meta_bytes();
-        if (rt.d2h_async(step_meta_pin, b_coff.p, mb)) return hipfail("consensus: d2h");      // (pinned: see Runtime::graph_stage)
+        if (rt.d2h_async(step_meta_pin, meta_coff(), mb)) return hipfail("consensus: d2h");      // (pinned: see Runtime::graph_stage)
         if (seq_out && step_fasta_len && rt.d2h_async(seq_out, b_cns.p, step_fasta_len)) return hipfail("consensus fetch: d2h");
         return KD_OK;
     }
@@ -1247,7 +1248,7 @@ struct KdEngine {
         const bool step_trace = knob_step_trace;      // (knob, fault localisation: the step's path and the addresses a fault report can be matched with)
         if (step_trace)
             fprintf(stderr, "[kd] step: have_graph %d status %p tab %p cns %p coff %p seq_out %p meta_pin %p reads %p..%p\n", (int)(step_have && rt.has_graph()),
-                    (void *)d_status, (void *)d_tab, b_cns.p, b_coff.p, (void *)seq_out, (void *)step_meta_pin, (const void *)B.contig, (const void *)B.seq4);
+                    (void *)d_status, (void *)d_tab, b_cns.p, meta_coff(), (void *)seq_out, (void *)step_meta_pin, (const void *)B.contig, (const void *)B.seq4);
         if (exch_row) { step_have = false; step_mode = STEP_OFF; return sequence(); }     // (a registered exchange row: its tail may need the run's host values -- always eager)
         if (step_have && rt.has_graph() && !memcmp(sig, step_sig, sizeof sig) && !step_status.empty()) {
             // (knob, fault localisation: KD_STEP_REPLAY_EAGER=1 submits the recorded sequence kernel by kernel -- the same launches with the

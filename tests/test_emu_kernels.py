@@ -551,3 +551,26 @@ def test_pos_far_behind_the_last_contig_is_an_index_error_not_a_wild_write(emu_l
     body.append("far\t0\tc\t%d\t60\t20M\t*\t0\t0\t%s\t*" % (far, "ACGT" * 5))
     with pytest.raises(IndexError):
         P.Run(emu_lib, P.sam_to_batch("\n".join([lines[0]] + body) + "\n"), mode=mode)
+
+
+def test_consensus_over_hundreds_of_tiles_run_after_run(emu_lib):
+    """The consensus over several hundred 1024-site tiles: sites that emit nothing (majority deletions), more than one byte
+    (majority insertions), contigs that start inside tiles; run after run on the same tables with another min_depth -- every
+    consensus, change code, depth range and contig offset against the oracle.  (Written for round 5's single-pass consensus with a
+    decoupled look-back, scripts/exp/kd_cns_one.h: bit-exact but 7 x slower than the two passes, not adopted; the case stays.)"""
+    batch = synth.to_numpy(synth.short_reads([150_000, 70_001, 130_500], 3, seed=12))
+    run = P.Run(emu_lib, batch)
+    assert sum(int(l) for l in batch["contig_lens"]) // 1024 > 300
+    P.assert_matches_oracle(run)
+    eng = N.Engine(batch["contig_lens"], lib=emu_lib)
+    try:
+        eng.push(batch)
+        eng.finalize()
+        for md in (1, 3, 0, 1):      # run after run on the same tables
+            eng.consensus_run(md)
+            for cid in ko.contig_order(batch):
+                oseq, och = ko.parse_records(batch, cid).consensus_sequence(min_depth=md)
+                seq, ch, mm, _ = eng.consensus_fetch(cid)
+                assert seq.decode() == oseq and [None if c == 0 else chr(c) for c in ch] == och, (md, cid)
+    finally:
+        eng.close()
