@@ -41,7 +41,6 @@ __device__ __forceinline__ void kd_block_scan_incl2(kd_u64 &a, kd_u64 &b, kd_u64
 // An op of 2^23 bases or more makes the read irregular (k_pileup_wave walks it exactly): a tile's advances then fit 32 bits.
 #define KD_LONG_MAX_OP (1u << 23)
 #define KD_LONG_SEQ_LDS 4096u   // bytes of query bases k_long_expand copies into LDS per wavefront and tile (8192 bases)
-#define KD_LONG_TILE 128u       // ops per tile of k_long_expand: two per lane
 
 // reference / query advance of one CIGAR word as the scans see it (a non-first S moves nothing here: for a regular read it
 // is the last op that touches r, and its own reach is kept apart as the trailing clip)
@@ -271,11 +270,9 @@ __global__ void __launch_bounds__(KD_BLOCK, KD_LONG_OCC)
 k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint32_t *long_list, uint32_t n_long,
               const KdLongAcc *long_acc, const kd_u64 *row_off, uint8_t *rows, kd_u64 *status) {
     // per wavefront: the tile's ops (reference start, query start, CIGAR word, first piece), the chunk's piece -> op table
-    // and dwords, a copy of the query bases the tile consumes.  A TILE is KD_LONG_TILE = 128 ops, two per lane (round 5; 64 until
-    // round 4): with an op every ~7 bases a 64-op tile is ~92 pieces -- one full chunk of 64 lanes and one 44 % full -- and the
-    // chunk loop is where the kernel's instructions go; 128 ops are ~184 pieces = three chunks, 96 % full.
-    __shared__ uint32_t s_r_[KD_WAVES_PER_BLOCK][KD_LONG_TILE], s_q_[KD_WAVES_PER_BLOCK][KD_LONG_TILE], s_w_[KD_WAVES_PER_BLOCK][KD_LONG_TILE],
-        s_pb_[KD_WAVES_PER_BLOCK][KD_LONG_TILE], s_pt_[KD_WAVES_PER_BLOCK][KD_WAVE], s_out_[KD_WAVES_PER_BLOCK][KD_WAVE],
+    // and dwords, a copy of the query bases the tile consumes
+    __shared__ uint32_t s_r_[KD_WAVES_PER_BLOCK][KD_WAVE], s_q_[KD_WAVES_PER_BLOCK][KD_WAVE], s_w_[KD_WAVES_PER_BLOCK][KD_WAVE],
+        s_pb_[KD_WAVES_PER_BLOCK][KD_WAVE], s_pt_[KD_WAVES_PER_BLOCK][KD_WAVE], s_out_[KD_WAVES_PER_BLOCK][KD_WAVE],
         s_insb_[KD_WAVES_PER_BLOCK][KD_WAVE];
     __shared__ uint32_t s_seq_[KD_WAVES_PER_BLOCK][KD_LONG_SEQ_LDS / 4 + 4];
     const uint32_t lane = threadIdx.x & (KD_WAVE - 1), wave = threadIdx.x / KD_WAVE;
@@ -303,57 +300,48 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
     if (has_ins) { e_base = ins.read_ev[i]; p_base = ins.read_pool[i]; }
     uint32_t *tab = T.tab;
     const kd_u64 S = T.stride;
-    uint32_t c_r = 0, c_q = 0;                 // coordinates in front of the half tile at hand (r relative to pos0)
+    uint32_t c_r = 0, c_q = 0;                 // coordinates in front of the tile (r relative to pos0)
     uint32_t last_ins = 0;                     // 1 + r of the last I op seen (0: none)
     uint32_t trail_r = 0, trail_q = 0;         // the trailing clip's coordinates (its lane)
     bool bad = false, trail = false;
     // the row dword under construction: carried from chunk to chunk, tile to tile
     uint32_t cj = 0xffffffffu, cval = 0, cins = 0;
 #define KD_ROW_FINISH(v, ib) ((((v) + (ib) * KD_ROW_INS) & 0x0f0f0f0fu) << 4 | ((((v) + (ib) * KD_ROW_INS) >> 4) & 0x0f0f0f0fu))   /* "+ins" twins, BAM nibble order */
-    // (the next tile's CIGAR words and the first 256 bytes of its query bases: in flight while a tile is worked on)
-    uint32_t w_nxt[2] = {lane < nc ? cg[lane] : 15u, lane + KD_WAVE < nc ? cg[lane + KD_WAVE] : 15u};     // (op 15, length 0: moves nothing)
+    // (CIGAR words two tiles ahead, the first 256 bytes of the next tile's query bases one tile ahead: in flight while a tile is worked on)
+    uint32_t w_nxt = lane < nc ? cg[lane] : 15u, w_nxt2 = lane + KD_WAVE < nc ? cg[lane + KD_WAVE] : 15u;
     uint32_t sq_pre = 4u * lane < (uint32_t)((sl + 1) >> 1) + 8u ? reinterpret_cast<const KdU32u *>(seq + 4u * lane)->v : 0u;
-    for (uint32_t base = 0; base <= nc; base += KD_LONG_TILE) {   // (<=: the terminator behind the last op is a piece too)
-        const uint32_t w2[2] = {w_nxt[0], w_nxt[1]};
-#pragma unroll
-        for (uint32_t h = 0; h < 2; h++) { const uint32_t kn = base + KD_LONG_TILE + h * KD_WAVE + lane; w_nxt[h] = kn < nc ? cg[kn] : 15u; }
-        const uint32_t q_tile = c_q;           // the query cursor in front of the tile
-        uint32_t cnt2[2], pb2[2];              // this lane's two ops: pieces, first piece (tile-relative)
-        uint32_t n_pieces = 0;
-        KD_WAVE_SYNC();                        // (the last tile's pieces are done with the arrays)
-#pragma unroll
-        for (uint32_t h = 0; h < 2; h++) {     // ---- the ops, 64 at a time: lane = op ----
-            const uint32_t k = base + h * KD_WAVE + lane;
-            const uint32_t w = w2[h];
-            const uint32_t op = w & 15u;
-            const KdAdv adv = kd_op_advance(w, k);
-            const uint32_t ra = adv.r, qa = adv.q;
-            const uint32_t ir = kd_wave_scan_add(ra), iq = kd_wave_scan_add(qa);
-            const uint32_t r_op = c_r + ir - ra, q_op = c_q + iq - qa;
-            // pieces: an M / D run touches the dwords of its first to its last site; an I op and the terminator are one each
-            const bool is_run = ra != 0, is_ins = op == 1 && k < nc;
-            bool dup = false, insf = false;    // insf: an insertion sits in front of this run's first site (or of the terminator)
-            if (has_ins) {   // (wave-uniform) a second I op on the same site: the nearest I op before it has the same r
-                const uint32_t m = kd_wave_scan_max(is_ins ? r_op + 1u : 0u);
-                uint32_t prev = kd_shfl_up(m, 1u);
-                if (lane == 0) prev = 0;
-                prev = prev > last_ins ? prev : last_ins;
-                dup = is_ins && prev == r_op + 1u;
-                insf = (is_run || k == nc) && prev == r_op + 1u;
-                const uint32_t tile_last = kd_readlane(m, KD_WAVE - 1);
-                last_ins = tile_last > last_ins ? tile_last : last_ins;
-            }
-            const uint32_t cnt = is_run ? ((r_op + ra - 1u) >> 3) - (r_op >> 3) + 1u : k == nc ? 1u : 0u;
-            const uint32_t ipb = kd_wave_scan_add(cnt);
-            cnt2[h] = cnt; pb2[h] = n_pieces + ipb - cnt;
-            const uint32_t x = h * KD_WAVE + lane;
-            s_r[x] = r_op; s_q[x] = q_op; s_w[x] = k < nc ? w : 15u; s_pb[x] = pb2[h] | (insf ? 0x80000000u : 0u) | (dup ? 0x40000000u : 0u);
-            n_pieces += kd_readlane(ipb, KD_WAVE - 1);
-            c_r += kd_readlane(ir, KD_WAVE - 1); c_q += kd_readlane(iq, KD_WAVE - 1);
+    for (uint32_t base = 0; base <= nc; base += KD_WAVE) {   // (<=: the terminator behind the last op is a piece too)
+        const uint32_t k = base + lane;
+        const uint32_t w = w_nxt;
+        w_nxt = w_nxt2;
+        { const uint32_t kn = k + 2u * KD_WAVE; w_nxt2 = kn < nc ? cg[kn] : 15u; }
+        const uint32_t len = w >> 4, op = w & 15u;
+        const KdAdv adv = kd_op_advance(w, k);
+        const uint32_t ra = adv.r, qa = adv.q;
+        const uint32_t ir = kd_wave_scan_add(ra), iq = kd_wave_scan_add(qa);
+        const uint32_t r_op = c_r + ir - ra, q_op = c_q + iq - qa;
+        const uint32_t tot_q = kd_readlane(iq, KD_WAVE - 1);
+        // pieces: an M / D run touches the dwords of its first to its last site; an I op and the terminator are one each
+        const bool is_run = ra != 0, is_ins = op == 1 && k < nc;
+        bool dup = false, insf = false;        // insf: an insertion sits in front of this run's first site (or of the terminator)
+        if (has_ins) {   // (wave-uniform) a second I op on the same site: the nearest I op before it has the same r
+            const uint32_t m = kd_wave_scan_max(is_ins ? r_op + 1u : 0u);
+            uint32_t prev = kd_shfl_up(m, 1u);
+            if (lane == 0) prev = 0;
+            prev = prev > last_ins ? prev : last_ins;
+            dup = is_ins && prev == r_op + 1u;
+            insf = (is_run || k == nc) && prev == r_op + 1u;
+            const uint32_t tile_last = kd_readlane(m, KD_WAVE - 1);
+            last_ins = tile_last > last_ins ? tile_last : last_ins;
         }
+        const uint32_t cnt = is_run ? ((r_op + ra - 1u) >> 3) - (r_op >> 3) + 1u : k == nc ? 1u : 0u;
+        const uint32_t ipb = kd_wave_scan_add(cnt);
+        const uint32_t n_pieces = kd_readlane(ipb, KD_WAVE - 1);
+        KD_WAVE_SYNC();                        // (the last tile's pieces are done with the arrays)
+        s_r[lane] = r_op; s_q[lane] = q_op; s_w[lane] = w; s_pb[lane] = (ipb - cnt) | (insf ? 0x80000000u : 0u);
         // the query bases of the tile (+ the 8-base fetch window): copied when they fit
-        const uint32_t qb = q_tile & ~7u;                                   // first copied base: a dword boundary of the read's bytes
-        uint32_t q_end = c_q;
+        const uint32_t qb = c_q & ~7u;                                      // first copied base: a dword boundary of the read's bytes
+        uint32_t q_end = c_q + tot_q;
         q_end = (int64_t)q_end < sl ? q_end : (uint32_t)sl;
         const uint32_t need = q_end > qb ? ((q_end - qb + 1u) >> 1) + 8u : 0u;   // bytes
         const bool staged = need <= KD_LONG_SEQ_LDS;
@@ -363,61 +351,54 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
                 s_seq[o >> 2] = reinterpret_cast<const KdU32u *>(seq + (qb >> 1) + o)->v;
         }
         {   // the next tile's copy starts at the dword of its first base
-            const uint32_t ob = (c_q & ~7u) >> 1;
+            const uint32_t ob = ((c_q + tot_q) & ~7u) >> 1;
             sq_pre = ob + 4u * lane < (uint32_t)((sl + 1) >> 1) + 8u ? reinterpret_cast<const KdU32u *>(seq + ob + 4u * lane)->v : 0u;
         }
         KD_WAVE_SYNC();                        // the tile's arrays are written
-#pragma unroll
-        for (uint32_t h = 0; h < 2; h++) {     // ---- insertion events and clip counters of the ops, 64 at a time ----
-            const uint32_t k = base + h * KD_WAVE + lane, x = h * KD_WAVE + lane;
-            const uint32_t w = s_w[x], len = w >> 4, op = w & 15u, r_op = s_r[x], q_op = s_q[x];
-            const bool is_ins = op == 1 && k < nc, dup = (s_pb[x] & 0x40000000u) != 0;
-            if (has_ins) {   // (wave-uniform) event / pool slots of the I ops
-                uint32_t ni = 0, nb = 0;
-                if (is_ins) {
-                    const int64_t q0 = (int64_t)q_op < sl ? (int64_t)q_op : sl, q1 = (int64_t)q_op + len < sl ? (int64_t)q_op + len : sl;
-                    ni = 1; nb = (uint32_t)(q1 - q0);
-                }
-                const uint32_t i_ni = kd_wave_scan_add(ni), i_nb = kd_wave_scan_add(nb);
-                if (is_ins) {
-                    const kd_u64 e = e_base + i_ni - 1, po = p_base + i_nb - nb;
-                    const kd_u64 g = g0 + r_op;
-                    if (e >= ins.ev_cap || po + nb > ins.pool_cap) {
-                        atomicAdd(&status[KDS_INTERNAL], 1ULL);
-                    } else if (kd_commit(T, g)) {
-                        ins.ev_site[e] = (uint32_t)g; ins.ev_len[e] = nb; ins.ev_off[e] = po;
-                        const uint32_t q0 = (int64_t)q_op < sl ? q_op : (uint32_t)sl;
-                        for (uint32_t x0 = 0; x0 < nb; x0 += 8u) {       // 8 bases per fetch, one base code per pool byte
-                            const uint32_t qq = q0 + x0;
-                            uint32_t z = staged ? kd_fetch8_lin_lds(s_seq, (qq >> 1) - (qb >> 1), qq & 1u) : kd_fetch8_lin(seq, qq);
-                            for (uint32_t xx = x0; xx < nb && xx < x0 + 8u; xx++, z >>= 4) ins.pool[po + xx] = (uint8_t)(z & 15u);
-                        }
-                        if (dup) atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g], 1u);     // (its site's "+ins" flag is taken)
-                    } else {
-                        ins.ev_site[e] = KD_EV_DROPPED; ins.ev_len[e] = 0; ins.ev_off[e] = po;
-                    }
-                }
-                e_base += kd_readlane(i_ni, KD_WAVE - 1); p_base += kd_readlane(i_nb, KD_WAVE - 1);
+        if (has_ins) {   // (wave-uniform) event / pool slots of the tile's I ops
+            uint32_t ni = 0, nb = 0;
+            if (is_ins) {
+                const int64_t q0 = (int64_t)q_op < sl ? (int64_t)q_op : sl, q1 = (int64_t)q_op + len < sl ? (int64_t)q_op + len : sl;
+                ni = 1; nb = (uint32_t)(q1 - q0);
             }
-            if (op == 4 && k < nc) {
-                if (k == 0) {      // leading clip, kindel.py:64-73: clip_ends[r]
-                    if (kd_commit(T, g0)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g0], 1u);
-                } else {           // non-first clip, kindel.py:74-81: clip_starts[r - 1] (index -1 wraps to the last slot)
-                    const int64_t xr = (int64_t)pos0 + r_op - 1;
-                    const kd_u64 g = cb + (kd_u64)(xr < 0 ? xr + L + 1 : xr);
-                    if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
-                    trail = true; trail_r = r_op; trail_q = q_op;
+            const uint32_t i_ni = kd_wave_scan_add(ni), i_nb = kd_wave_scan_add(nb);
+            if (is_ins) {
+                const kd_u64 e = e_base + i_ni - 1, po = p_base + i_nb - nb;
+                const kd_u64 g = g0 + r_op;
+                if (e >= ins.ev_cap || po + nb > ins.pool_cap) {
+                    atomicAdd(&status[KDS_INTERNAL], 1ULL);
+                } else if (kd_commit(T, g)) {
+                    ins.ev_site[e] = (uint32_t)g; ins.ev_len[e] = nb; ins.ev_off[e] = po;
+                    const uint32_t q0 = (int64_t)q_op < sl ? q_op : (uint32_t)sl;
+                    for (uint32_t x0 = 0; x0 < nb; x0 += 8u) {       // 8 bases per fetch, one base code per pool byte
+                        const uint32_t qq = q0 + x0;
+                        uint32_t z = staged ? kd_fetch8_lin_lds(s_seq, (qq >> 1) - (qb >> 1), qq & 1u) : kd_fetch8_lin(seq, qq);
+                        for (uint32_t x = x0; x < nb && x < x0 + 8u; x++, z >>= 4) ins.pool[po + x] = (uint8_t)(z & 15u);
+                    }
+                    if (dup) atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g], 1u);     // (its site's "+ins" flag is taken)
+                } else {
+                    ins.ev_site[e] = KD_EV_DROPPED; ins.ev_len[e] = 0; ins.ev_off[e] = po;
                 }
+            }
+            e_base += kd_readlane(i_ni, KD_WAVE - 1); p_base += kd_readlane(i_nb, KD_WAVE - 1);
+        }
+        if (op == 4 && k < nc) {
+            if (k == 0) {      // leading clip, kindel.py:64-73: clip_ends[r]
+                if (kd_commit(T, g0)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g0], 1u);
+            } else {           // non-first clip, kindel.py:74-81: clip_starts[r - 1] (index -1 wraps to the last slot)
+                const int64_t x = (int64_t)pos0 + r_op - 1;
+                const kd_u64 g = cb + (kd_u64)(x < 0 ? x + L + 1 : x);
+                if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
+                trail = true; trail_r = r_op; trail_q = q_op;
             }
         }
         // ---- the tile's pieces, 64 at a time ----
         uint32_t op_in = 0;                    // 1 + the op the chunk's first piece continues (0: it starts an op)
-        for (uint32_t p0 = 0; p0 < n_pieces; p0 += KD_WAVE) {
+        const uint32_t n_chunks_pieces = n_pieces;
+        for (uint32_t p0 = 0; p0 < n_chunks_pieces; p0 += KD_WAVE) {
             s_pt[lane] = 0; s_out[lane] = 0; s_insb[lane] = 0;
             KD_WAVE_SYNC();
-#pragma unroll
-            for (uint32_t h = 0; h < 2; h++)
-                if (cnt2[h] && pb2[h] >= p0 && pb2[h] < p0 + KD_WAVE) s_pt[pb2[h] - p0] = h * KD_WAVE + lane + 1u;
+            { const uint32_t pb = ipb - cnt; if (cnt && pb >= p0 && pb < p0 + KD_WAVE) s_pt[pb - p0] = lane + 1u; }
             KD_WAVE_SYNC();
             uint32_t oi = kd_wave_scan_max(s_pt[lane]);
             oi = oi > op_in ? oi : op_in;      // (op indices grow with the piece number)
@@ -427,7 +408,7 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
             const uint32_t ko = oi - 1u;       // (a live piece always has its op: piece 0 starts one)
             uint32_t j = 0, val = 0, ib = 0;
             if (live) {
-                const uint32_t r_k = s_r[ko], w_k = s_w[ko], pbf = s_pb[ko], idx = p - (pbf & 0x3fffffffu);
+                const uint32_t r_k = s_r[ko], w_k = s_w[ko], pbf = s_pb[ko], idx = p - (pbf & 0x7fffffffu);
                 if (idx == 0 && (pbf >> 31)) ib = 1u << (4u * (r_k & 7u));   // "+ins" flag of the run's first site
                 const uint32_t ln = w_k >> 4, o = w_k & 15u;
                 j = (r_k >> 3) + idx;
@@ -466,6 +447,7 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
             cj = jl;
             cval = kd_readlane(v, jl - jf); cins = kd_readlane(vb, jl - jf);
         }
+        c_r += kd_readlane(ir, KD_WAVE - 1); c_q += tot_q;
     }
     if (cj != 0xffffffffu && lane == 0) row[cj] = KD_ROW_FINISH(cval, cins);
 #undef KD_ROW_FINISH
