@@ -343,8 +343,8 @@ struct KdEngine {
             if ((rc = ensure(b_rowinfo, (size_t)n_long * sizeof(KdRInfo))) || (rc = ensure(b_rowoff, (size_t)n_long * 8)) ||
                 (rc = ensure(b_longacc, (size_t)n_long * sizeof(KdLongAcc))))
                 return rc;
-            const unsigned long_grid = (unsigned)((n_long + KD_WAVES_PER_BLOCK - 1) / KD_WAVES_PER_BLOCK);   // a wavefront per long read
-            if (rt.launch("k_prep_long", k_prep_long, long_grid, KD_BLOCK, 0, R, T, rinfo,
+            const unsigned long_grid = (unsigned)((n_long + KD_LONG_WAVES - 1) / KD_LONG_WAVES);   // a wavefront per long read, a workgroup per wavefront
+            if (rt.launch("k_prep_long", k_prep_long, long_grid, KD_LONG_BLOCK, 0, R, T, rinfo,
                           (const uint32_t *)lng, (uint32_t)n_long, (KdLongAcc *)b_longacc.p))
                 return hipfail("k_prep_long");
             if (rt.launch("k_long_reduce", k_long_reduce, (unsigned)((n_long + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, (const KdLongAcc *)b_longacc.p,
@@ -372,7 +372,7 @@ struct KdEngine {
         }
         KdIns I = insdesc();
         if (n_long && mode != KD_MODE_GLOBAL &&
-            rt.launch("k_long_expand", k_long_expand, (unsigned)((n_long + KD_WAVES_PER_BLOCK - 1) / KD_WAVES_PER_BLOCK), KD_BLOCK, 0, R, T, I,
+            rt.launch("k_long_expand", k_long_expand, (unsigned)((n_long + KD_LONG_WAVES - 1) / KD_LONG_WAVES), KD_LONG_BLOCK, 0, R, T, I,
                       (const KdRInfo *)rinfo, (const uint32_t *)lng, (uint32_t)n_long, (const KdLongAcc *)b_longacc.p, (const kd_u64 *)b_rowoff.p, (uint8_t *)b_rows.p, d_status))
             return hipfail("k_long_expand");
         const uint64_t n_reg = h_status[KDS_B_N_REG], n_cold = h_status[KDS_B_N_COLD], n_irreg = h_status[KDS_B_N_IRREG];

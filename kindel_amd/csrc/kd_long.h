@@ -58,11 +58,16 @@ __device__ __forceinline__ KdAdv kd_op_advance(uint32_t w, uint32_t k) {
 // k_prep_long: the regularity rules of kd_scan_cigar (kd_prep.h) applied op-parallel: every op checks itself against its own
 // start coordinates; what the read leaves behind is ONE record (KdLongAcc) and its footprint entry -- k_long_reduce turns the
 // records into slots.
-__global__ void __launch_bounds__(KD_BLOCK)
+// (round 5: ONE wavefront per workgroup here and in k_long_expand -- KD_LONG_BLOCK.  A workgroup of four wavefronts = four reads
+// keeps its slots until its LONGEST read is done, and long reads are anything from 2 to 30 kilobases: the maximum of four
+// lengths is 1.6 x their mean, three of four wavefront slots idle for the difference.  Neither kernel has a workgroup barrier.)
+#define KD_LONG_BLOCK KD_WAVE
+#define KD_LONG_WAVES (KD_LONG_BLOCK / KD_WAVE)
+__global__ void __launch_bounds__(KD_LONG_BLOCK)
 k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uint32_t n_long, KdLongAcc *long_acc) {
-    __shared__ kd_u64 s_acc[KD_WAVES_PER_BLOCK][4];       // aligned, walked, n_ins, ins_bases
+    __shared__ kd_u64 s_acc[KD_LONG_WAVES][4];       // aligned, walked, n_ins, ins_bases
     const uint32_t lane = threadIdx.x & (KD_WAVE - 1), wave = threadIdx.x / KD_WAVE;
-    const uint32_t b = blockIdx.x * KD_WAVES_PER_BLOCK + wave;
+    const uint32_t b = blockIdx.x * KD_LONG_WAVES + wave;
     if (b >= n_long) return;
     const kd_u64 i = long_list[b];
     const uint32_t c = rd.contig[i];
@@ -266,17 +271,17 @@ __device__ __forceinline__ uint32_t kd_zero_nibbles(uint32_t x) {
 #ifndef KD_LONG_OCC
 #define KD_LONG_OCC 5      // wavefronts per SIMD the register budget is set for (96 registers; measured on C5: 4 / 5 / 6 = 0.676 / 0.610 / 0.651 ms, 6 spills 9 registers)
 #endif
-__global__ void __launch_bounds__(KD_BLOCK, KD_LONG_OCC)
+__global__ void __launch_bounds__(KD_LONG_BLOCK, KD_LONG_OCC)
 k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint32_t *long_list, uint32_t n_long,
               const KdLongAcc *long_acc, const kd_u64 *row_off, uint8_t *rows, kd_u64 *status) {
     // per wavefront: the tile's ops (reference start, query start, CIGAR word, first piece), the chunk's piece -> op table
     // and dwords, a copy of the query bases the tile consumes
-    __shared__ uint32_t s_r_[KD_WAVES_PER_BLOCK][KD_WAVE], s_q_[KD_WAVES_PER_BLOCK][KD_WAVE], s_w_[KD_WAVES_PER_BLOCK][KD_WAVE],
-        s_pb_[KD_WAVES_PER_BLOCK][KD_WAVE], s_pt_[KD_WAVES_PER_BLOCK][KD_WAVE], s_out_[KD_WAVES_PER_BLOCK][KD_WAVE],
-        s_insb_[KD_WAVES_PER_BLOCK][KD_WAVE];
-    __shared__ uint32_t s_seq_[KD_WAVES_PER_BLOCK][KD_LONG_SEQ_LDS / 4 + 4];
+    __shared__ uint32_t s_r_[KD_LONG_WAVES][KD_WAVE], s_q_[KD_LONG_WAVES][KD_WAVE], s_w_[KD_LONG_WAVES][KD_WAVE],
+        s_pb_[KD_LONG_WAVES][KD_WAVE], s_pt_[KD_LONG_WAVES][KD_WAVE], s_out_[KD_LONG_WAVES][KD_WAVE],
+        s_insb_[KD_LONG_WAVES][KD_WAVE];
+    __shared__ uint32_t s_seq_[KD_LONG_WAVES][KD_LONG_SEQ_LDS / 4 + 4];
     const uint32_t lane = threadIdx.x & (KD_WAVE - 1), wave = threadIdx.x / KD_WAVE;
-    const uint32_t b = blockIdx.x * KD_WAVES_PER_BLOCK + wave;
+    const uint32_t b = blockIdx.x * KD_LONG_WAVES + wave;
     if (b >= n_long) return;
     const kd_u64 i = long_list[b];
     const uint32_t sc = rinfo[i].span_cls;
