@@ -53,6 +53,8 @@ struct KdEngine {
         void *p = nullptr;
         size_t cap = 0;
     };
+    Buf b_longorder;      // k_long_order: the long reads longest first
+    bool long_ordered = false;
     Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_rows, b_rowinfo, b_rowoff, b_longacc, b_coldcnt, b_coldev, b_coldpool;
     Buf b_stage[9];
     Buf b_gi_file, b_gi_blocks, b_gi_out, b_gi_bstat, b_gi_start, b_gi_cnt, b_gi_tot, b_gi_recat;   // device-side ingest (kd_ingest.h)
@@ -186,7 +188,7 @@ struct KdEngine {
                       &b_tilesum, &b_tilemm, &b_tileoff};
         for (Buf *b : all) release(*b);
         for (Buf &b : b_stage) release(b);
-        release(b_srec); release(b_smallcig); release(b_sortrows); release(b_sortseg);
+        release(b_srec); release(b_smallcig); release(b_sortrows); release(b_sortseg); release(b_longorder);
         for (Buf *g : {&b_gi_file, &b_gi_blocks, &b_gi_out, &b_gi_bstat, &b_gi_start, &b_gi_cnt, &b_gi_tot, &b_gi_recat}) release(*g);
         if (d_tab) rt.free(d_tab);
         if (d_clen) rt.free(d_clen);
@@ -351,6 +353,13 @@ struct KdEngine {
                           (const uint32_t *)lng, (uint32_t)n_long, (const KdRInfo *)rinfo, irreg, (uint32_t *)b_readev.p, (kd_u64 *)b_readpool.p,
                           (KdRInfo *)b_rowinfo.p, (kd_u64 *)b_rowoff.p, d_status))
                 return hipfail("k_long_reduce");
+            // k_long_expand starts the longest reads first (k_long_order; queued in front of the read-back: it runs while the host waits)
+            long_ordered = n_long > 1 && n_long <= KD_LONG_ORDER_MAX && mode != KD_MODE_GLOBAL;
+            if (long_ordered) {
+                if ((rc = ensure(b_longorder, (size_t)n_long * 4))) return rc;
+                if (rt.launch("k_long_order", k_long_order, 1u, KD_LONG_ORDER_BLOCK, 0, (const KdLongAcc *)b_longacc.p, (uint32_t)n_long, (uint32_t *)b_longorder.p))
+                    return hipfail("k_long_order");
+            }
             if ((rc = fetch_status())) return rc;
             if ((rc = ensure(b_rows, (size_t)h_status[KDS_B_ROW_DWORDS] * 4 + 64))) return rc;   // (+ 64: the walk loads 16-byte chunks)
         }
@@ -373,7 +382,8 @@ struct KdEngine {
         KdIns I = insdesc();
         if (n_long && mode != KD_MODE_GLOBAL &&
             rt.launch("k_long_expand", k_long_expand, (unsigned)((n_long + KD_LONG_WAVES - 1) / KD_LONG_WAVES), KD_LONG_BLOCK, 0, R, T, I,
-                      (const KdRInfo *)rinfo, (const uint32_t *)lng, (uint32_t)n_long, (const KdLongAcc *)b_longacc.p, (const kd_u64 *)b_rowoff.p, (uint8_t *)b_rows.p, d_status))
+                      (const KdRInfo *)rinfo, (const uint32_t *)lng, (uint32_t)n_long, (const KdLongAcc *)b_longacc.p, (const kd_u64 *)b_rowoff.p, (uint8_t *)b_rows.p, d_status,
+                      long_ordered ? (const uint32_t *)b_longorder.p : (const uint32_t *)nullptr))
             return hipfail("k_long_expand");
         const uint64_t n_reg = h_status[KDS_B_N_REG], n_cold = h_status[KDS_B_N_COLD], n_irreg = h_status[KDS_B_N_IRREG];
         const bool windowed = (mode != KD_MODE_GLOBAL) && n_reg > 0;
