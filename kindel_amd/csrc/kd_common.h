@@ -163,7 +163,6 @@ enum {
     KDO_B_N_LONG,       // per batch: entries in the long-CIGAR list
     KDO_B_N_REG,        // per batch: regular reads
     KDO_B_FILL,         // per batch: entries of k_window's boundary table written by gap fills (k_prep's budget)
-    KDO_B_LONG_SEGS,    // per batch: segments (KD_LONG_SEG_OPS CIGAR words each) of the long reads (k_long_plan): k_long_expand's wavefronts
     KDO_WQ_LEFT,        // k_window's work queue: hot windows that still have slices nobody has taken
     KDO_WQ_TICKET,      // k_window's self-planned work queue (kd_window.h): window tickets handed out,
     KDO_WQ_PUB,         //   windows whose owner has published its slice count,
@@ -201,7 +200,6 @@ enum {
 #define KDS_B_N_LONG (KDO_B_N_LONG * KDS_STRIDE)
 #define KDS_B_N_REG (KDO_B_N_REG * KDS_STRIDE)
 #define KDS_B_FILL (KDO_B_FILL * KDS_STRIDE)
-#define KDS_B_LONG_SEGS (KDO_B_LONG_SEGS * KDS_STRIDE)
 #define KDS_WQ_LEFT (KDO_WQ_LEFT * KDS_STRIDE)
 #define KDS_WQ_TICKET (KDO_WQ_TICKET * KDS_STRIDE)
 #define KDS_WQ_PUB (KDO_WQ_PUB * KDS_STRIDE)
@@ -294,9 +292,6 @@ struct alignas(16) KdColdRec {
 
 // What k_prep_long learned about one long read (one workgroup each): summed into the status words and turned into event /
 // pool / irregular-list slots by ONE small kernel (k_long_reduce) instead of ten same-address atomics per workgroup.
-// a long read's state in front of one of its SEGMENTS (k_prep_long -> k_long_expand): reference / query cursor relative to the
-// read's start, insertion events and inserted bases in front of it, 1 + the reference cursor of the last I op (0: none)
-struct KdLongCk { uint32_t c_r, c_q, ev, pool, last_ins, pad; };
 struct KdLongAcc {
     kd_u64 aligned, walked, insb;
     uint32_t n_ins;

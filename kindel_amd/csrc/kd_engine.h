@@ -53,8 +53,8 @@ struct KdEngine {
         void *p = nullptr;
         size_t cap = 0;
     };
-    Buf b_longsegfirst, b_longsegowner, b_longck;      // the long reads' segments (k_long_plan, k_prep_long's checkpoints)
-    uint64_t long_seg_cap = 0;
+    Buf b_longorder;      // k_long_order: the long reads longest first
+    bool long_ordered = false;
     Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_rows, b_rowinfo, b_rowoff, b_longacc, b_coldcnt, b_coldev, b_coldpool;
     Buf b_stage[9];
     Buf b_gi_file, b_gi_blocks, b_gi_out, b_gi_bstat, b_gi_start, b_gi_cnt, b_gi_tot, b_gi_recat;   // device-side ingest (kd_ingest.h)
@@ -188,7 +188,7 @@ struct KdEngine {
                       &b_tilesum, &b_tilemm, &b_tileoff};
         for (Buf *b : all) release(*b);
         for (Buf &b : b_stage) release(b);
-        release(b_srec); release(b_smallcig); release(b_sortrows); release(b_sortseg); release(b_longsegfirst); release(b_longsegowner); release(b_longck);
+        release(b_srec); release(b_smallcig); release(b_sortrows); release(b_sortseg); release(b_longorder);
         for (Buf *g : {&b_gi_file, &b_gi_blocks, &b_gi_out, &b_gi_bstat, &b_gi_start, &b_gi_cnt, &b_gi_tot, &b_gi_recat}) release(*g);
         if (d_tab) rt.free(d_tab);
         if (d_clen) rt.free(d_clen);
@@ -345,30 +345,23 @@ struct KdEngine {
             if ((rc = ensure(b_rowinfo, (size_t)n_long * sizeof(KdRInfo))) || (rc = ensure(b_rowoff, (size_t)n_long * 8)) ||
                 (rc = ensure(b_longacc, (size_t)n_long * sizeof(KdLongAcc))))
                 return rc;
-            // k_long_expand's unit of work is a SEGMENT of a read (KD_LONG_SEG_OPS CIGAR words; kd_long.h): k_long_plan numbers them, k_prep_long
-            // leaves the read's state in front of each.  Their number is bounded by what the host knows: a read of nc words has nc / 512 + 1.
-            long_seg_cap = n_long + R.n_cigar / KD_LONG_SEG_OPS + 2;
-            if (long_seg_cap >= 0xfffffff0ULL) return fail(KD_E_NOMEM, "too many long-read segments");
-            if ((rc = ensure(b_longsegfirst, (size_t)n_long * 4)) || (rc = ensure(b_longsegowner, (size_t)long_seg_cap * 4)) ||
-                (rc = ensure(b_longck, (size_t)long_seg_cap * sizeof(KdLongCk))))
-                return rc;
-            if (rt.launch("k_long_plan", k_long_plan, (unsigned)((n_long + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, R, (const uint32_t *)lng, (uint32_t)n_long,
-                          (uint32_t *)b_longsegfirst.p, (uint32_t *)b_longsegowner.p, (uint32_t)long_seg_cap, d_status))
-                return hipfail("k_long_plan");
             const unsigned long_grid = (unsigned)((n_long + KD_LONG_WAVES - 1) / KD_LONG_WAVES);   // a wavefront per long read, a workgroup per wavefront
             if (rt.launch("k_prep_long", k_prep_long, long_grid, KD_LONG_BLOCK, 0, R, T, rinfo,
-                          (const uint32_t *)lng, (uint32_t)n_long, (KdLongAcc *)b_longacc.p, (const uint32_t *)b_longsegfirst.p, (KdLongCk *)b_longck.p,
-                          (uint32_t)long_seg_cap))
+                          (const uint32_t *)lng, (uint32_t)n_long, (KdLongAcc *)b_longacc.p))
                 return hipfail("k_prep_long");
             if (rt.launch("k_long_reduce", k_long_reduce, (unsigned)((n_long + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, (const KdLongAcc *)b_longacc.p,
                           (const uint32_t *)lng, (uint32_t)n_long, (const KdRInfo *)rinfo, irreg, (uint32_t *)b_readev.p, (kd_u64 *)b_readpool.p,
                           (KdRInfo *)b_rowinfo.p, (kd_u64 *)b_rowoff.p, d_status))
                 return hipfail("k_long_reduce");
+            // k_long_expand starts the longest reads first (k_long_order; queued in front of the read-back: it runs while the host waits)
+            long_ordered = n_long > 1 && n_long <= KD_LONG_ORDER_MAX && mode != KD_MODE_GLOBAL;
+            if (long_ordered) {
+                if ((rc = ensure(b_longorder, (size_t)n_long * 4))) return rc;
+                if (rt.launch("k_long_order", k_long_order, 1u, KD_LONG_ORDER_BLOCK, 0, (const KdLongAcc *)b_longacc.p, (uint32_t)n_long, (uint32_t *)b_longorder.p))
+                    return hipfail("k_long_order");
+            }
             if ((rc = fetch_status())) return rc;
             if ((rc = ensure(b_rows, (size_t)h_status[KDS_B_ROW_DWORDS] * 4 + 64))) return rc;   // (+ 64: the walk loads 16-byte chunks)
-            // zeroed: two neighbouring segments of a read may meet inside one row dword and OR their parts in
-            if (mode != KD_MODE_GLOBAL && rt.memset(b_rows.p, 0, (size_t)h_status[KDS_B_ROW_DWORDS] * 4)) return hipfail("push: memset rows");
-            if (h_status[KDS_B_LONG_SEGS] > long_seg_cap) return fail(KD_E_INTERNAL, "more long-read segments than their bound");
         }
         // size the insertion event buffers from the exact counts of this batch
         // k_prep / k_prep_long have already reserved this batch's slots in KDS_N_EV / KDS_POOL
@@ -387,11 +380,10 @@ struct KdEngine {
             pool_cap = ncap;
         }
         KdIns I = insdesc();
-        const uint64_t n_long_segs = n_long ? h_status[KDS_B_LONG_SEGS] : 0;      // a wavefront per segment, a workgroup per wavefront
-        if (n_long_segs && mode != KD_MODE_GLOBAL &&
-            rt.launch("k_long_expand", k_long_expand, (unsigned)((n_long_segs + KD_LONG_WAVES - 1) / KD_LONG_WAVES), KD_LONG_BLOCK, 0, R, T, I,
+        if (n_long && mode != KD_MODE_GLOBAL &&
+            rt.launch("k_long_expand", k_long_expand, (unsigned)((n_long + KD_LONG_WAVES - 1) / KD_LONG_WAVES), KD_LONG_BLOCK, 0, R, T, I,
                       (const KdRInfo *)rinfo, (const uint32_t *)lng, (uint32_t)n_long, (const KdLongAcc *)b_longacc.p, (const kd_u64 *)b_rowoff.p, (uint8_t *)b_rows.p, d_status,
-                      (const uint32_t *)b_longsegfirst.p, (const uint32_t *)b_longsegowner.p, (const KdLongCk *)b_longck.p, (uint32_t)n_long_segs))
+                      long_ordered ? (const uint32_t *)b_longorder.p : (const uint32_t *)nullptr))
             return hipfail("k_long_expand");
         const uint64_t n_reg = h_status[KDS_B_N_REG], n_cold = h_status[KDS_B_N_COLD], n_irreg = h_status[KDS_B_N_IRREG];
         const bool windowed = (mode != KD_MODE_GLOBAL) && n_reg > 0;

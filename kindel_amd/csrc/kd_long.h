@@ -63,35 +63,8 @@ __device__ __forceinline__ KdAdv kd_op_advance(uint32_t w, uint32_t k) {
 // lengths is 1.6 x their mean, three of four wavefront slots idle for the difference.  Neither kernel has a workgroup barrier.)
 #define KD_LONG_BLOCK KD_WAVE
 #define KD_LONG_WAVES (KD_LONG_BLOCK / KD_WAVE)
-// SEGMENTS (round 5).  k_long_expand's wavefronts used to take a whole read each, and a read is anything from 2 to 30 kilobases
-// on a long-read run: the launch lasted as long as its longest read (longest first: 0.54 -> 0.40 ms on C5, and no further).  Now a
-// wavefront takes KD_LONG_SEG_OPS = 512 CIGAR words of a read: k_long_plan numbers the segments (a thread per read: prefix sums,
-// segment -> read table), k_prep_long -- which walks every read front to back anyway -- leaves the read's state in front of each
-// segment (KdLongCk), and a segment's wavefront starts from it.  Two neighbouring segments may meet inside one row dword: the
-// rows are zeroed and a segment ORs its first and its last dword in (every site's nibble comes from one segment only).
-#define KD_LONG_SEG_OPS 512u
-static_assert(KD_LONG_SEG_OPS % KD_WAVE == 0, "a segment is whole tiles");
-__global__ void __launch_bounds__(KD_BLOCK)
-k_long_plan(KdReads rd, const uint32_t *long_list, uint32_t n_long, uint32_t *seg_first, uint32_t *seg_owner, uint32_t seg_cap, kd_u64 *status) {
-    __shared__ kd_u64 s_wave[KD_WAVES_PER_BLOCK];
-    __shared__ kd_u64 s_base;
-    const uint32_t t = threadIdx.x, b = blockIdx.x * KD_BLOCK + t;
-    // tiles 0 .. nc / 64 (the terminator behind the last op is a piece too): segments 0 .. nc / KD_LONG_SEG_OPS
-    const kd_u64 n_seg = b < n_long ? (kd_u64)(rd.n_cig[long_list[b]] / KD_LONG_SEG_OPS) + 1ULL : 0ULL;
-    kd_u64 total;
-    const kd_u64 incl = kd_block_scan_incl(n_seg, s_wave, total);
-    if (t == 0) s_base = total ? atomicAdd(&status[KDS_B_LONG_SEGS], total) : 0ULL;
-    __syncthreads();
-    if (b < n_long) {
-        const kd_u64 first = s_base + incl - n_seg;
-        seg_first[b] = (uint32_t)first;
-        for (kd_u64 x = 0; x < n_seg && first + x < seg_cap; x++) seg_owner[first + x] = b;     // (seg_cap: the engine's bound, never reached)
-    }
-}
-
 __global__ void __launch_bounds__(KD_LONG_BLOCK)
-k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uint32_t n_long, KdLongAcc *long_acc,
-            const uint32_t *seg_first, KdLongCk *ck, uint32_t seg_cap) {
+k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uint32_t n_long, KdLongAcc *long_acc) {
     __shared__ kd_u64 s_acc[KD_LONG_WAVES][4];       // aligned, walked, n_ins, ins_bases
     const uint32_t lane = threadIdx.x & (KD_WAVE - 1), wave = threadIdx.x / KD_WAVE;
     const uint32_t b = blockIdx.x * KD_LONG_WAVES + wave;
@@ -108,20 +81,8 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
     bool bad = false, cold = false;
     uint32_t first_nfs = 0xffffffffu, last_rel = 0;
     int64_t c_r = pos0, c_q = 0;      // coordinates in front of the tile
-    uint32_t lane_last = 0;           // 1 + the (read-relative) reference cursor of the last I op this lane has seen
-    const uint32_t seg0 = seg_first ? seg_first[b] : 0u;
-    // the read's state in front of segment `sg` (all lanes call it: cross-lane sums)
-    auto checkpoint = [&](uint32_t sg) {
-        const uint32_t ev = kd_wave_sum((uint32_t)n_ins), pool = kd_wave_sum((uint32_t)insb), li = kd_wave_max(lane_last);
-        if (lane == 0 && ck && seg0 + sg < seg_cap) {
-            KdLongCk x;
-            x.c_r = (uint32_t)(c_r - pos0); x.c_q = (uint32_t)c_q; x.ev = ev; x.pool = pool; x.last_ins = li; x.pad = 0;
-            ck[seg0 + sg] = x;
-        }
-    };
     uint32_t w_nxt = lane < nc ? cg[lane] : 15u, w_nxt2 = lane + KD_WAVE < nc ? cg[lane + KD_WAVE] : 15u;      // (op 15, length 0: moves nothing)
     for (uint32_t base = 0; base < nc; base += KD_WAVE) {
-        if (base % KD_LONG_SEG_OPS == 0) checkpoint(base / KD_LONG_SEG_OPS);      // (wave-uniform)
         const uint32_t k = base + lane;
         const uint32_t w = w_nxt;
         w_nxt = w_nxt2;
@@ -141,7 +102,6 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
             if (r > L) bad = true;
             const int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
             n_ins++; insb += (kd_u64)(q1 - q0); walked += (kd_u64)len; last_rel = k;
-            { const uint32_t x = (uint32_t)(r - pos0) + 1u; lane_last = x > lane_last ? x : lane_last; }
         } else if (op == 2) {
             if (r + len > L + 1) bad = true;
             walked += (kd_u64)len; last_rel = k;
@@ -158,7 +118,6 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
         }
         c_r += (int64_t)kd_readlane(ir, KD_WAVE - 1); c_q += (int64_t)kd_readlane(iq, KD_WAVE - 1);
     }
-    if (nc % KD_LONG_SEG_OPS == 0) checkpoint(nc / KD_LONG_SEG_OPS);     // (the segment that holds the terminator alone)
     KD_WAVE_SYNC();
     if (aligned) atomicAdd(&s_acc[wave][0], aligned);
     if (walked) atomicAdd(&s_acc[wave][1], walked);
@@ -255,6 +214,33 @@ k_long_reduce(const KdLongAcc *long_acc, const uint32_t *long_list, uint32_t n_l
     }
 }
 
+// k_long_order: the long reads LONGEST FIRST (round 5) -- order[x] = the x-th read k_long_expand starts.  Its wavefronts each
+// expand one read, 2 to 30 kilobases on a long-read run, and the launch ends with its last read: in list order a 30-kilobase
+// read that starts late is the kernel's tail; longest first the long ones start at once and the short ones fill the gaps
+// (longest-processing-time-first list scheduling).  One workgroup: a counting sort over 128 length classes (walked events, two
+// mantissa bits per power of two), descending; reads of one class keep their list order.
+#define KD_LONG_ORDER_BLOCK 1024
+#define KD_LONG_ORDER_MAX (1u << 20)     // (more long reads than this: list order -- a tail of one read no longer shows)
+__global__ void __launch_bounds__(KD_LONG_ORDER_BLOCK)
+k_long_order(const KdLongAcc *long_acc, uint32_t n_long, uint32_t *order) {
+    __shared__ uint32_t s_cnt[128];
+    const uint32_t t = threadIdx.x;
+    if (t < 128) s_cnt[t] = 0;
+    __syncthreads();
+    auto cls = [](kd_u64 walked) -> uint32_t {
+        const uint32_t v = walked < 0xffffffffULL ? (uint32_t)walked : 0xffffffffu;
+        if (v < 4u) return 127u - v;
+        const uint32_t lg = 31u - (uint32_t)__builtin_clz(v);
+        return 127u - ((lg << 2) | ((v >> (lg - 2u)) & 3u));      // 0 = the longest class
+    };
+    for (uint32_t b = t; b < n_long; b += KD_LONG_ORDER_BLOCK) atomicAdd(&s_cnt[cls(long_acc[b].walked)], 1u);
+    __syncthreads();
+    if (t == 0) { uint32_t run = 0; for (uint32_t k = 0; k < 128; k++) { const uint32_t v = s_cnt[k]; s_cnt[k] = run; run += v; } }
+    __syncthreads();
+    // (slots of a class are handed out in any order: which of two reads of one length class starts first does not matter)
+    for (uint32_t b = t; b < n_long; b += KD_LONG_ORDER_BLOCK) order[atomicAdd(&s_cnt[cls(long_acc[b].walked)], 1u)] = b;
+}
+
 // 8 query bases from base q on as LINEAR nibbles (base q + i at bits 4i .. 4i+3): BAM packs the even base into the HIGH
 // nibble of a byte, so the nibbles of every byte are swapped before the (q & 1) shift.  Reads 8 bytes from byte q / 2.
 struct __attribute__((packed, aligned(1))) KdU64u { kd_u64 v; };
@@ -314,8 +300,7 @@ __device__ __forceinline__ uint32_t kd_zero_nibbles(uint32_t x) {
 #endif
 __global__ void __launch_bounds__(KD_LONG_BLOCK, KD_LONG_OCC)
 k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint32_t *long_list, uint32_t n_long,
-              const KdLongAcc *long_acc, const kd_u64 *row_off, uint8_t *rows, kd_u64 *status,
-              const uint32_t *seg_first, const uint32_t *seg_owner, const KdLongCk *cks, uint32_t n_segs) {
+              const KdLongAcc *long_acc, const kd_u64 *row_off, uint8_t *rows, kd_u64 *status, const uint32_t *order) {
     // per wavefront: the tile's ops (reference start, query start, CIGAR word, first piece), the chunk's piece -> op table
     // and dwords, a copy of the query bases the tile consumes
     __shared__ uint32_t s_r_[KD_LONG_WAVES][KD_WAVE], s_q_[KD_LONG_WAVES][KD_WAVE], s_w_[KD_LONG_WAVES][KD_WAVE],
@@ -323,11 +308,9 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
         s_insb_[KD_LONG_WAVES][KD_WAVE];
     __shared__ uint32_t s_seq_[KD_LONG_WAVES][KD_LONG_SEQ_LDS / 4 + 4];
     const uint32_t lane = threadIdx.x & (KD_WAVE - 1), wave = threadIdx.x / KD_WAVE;
-    const uint32_t x = blockIdx.x * KD_LONG_WAVES + wave;      // the segment
-    if (x >= n_segs) return;
-    const uint32_t b = seg_owner[x];                           // its read
-    if (b >= n_long) return;
-    const uint32_t sg = x - seg_first[b];
+    const uint32_t x = blockIdx.x * KD_LONG_WAVES + wave;
+    if (x >= n_long) return;
+    const uint32_t b = order ? order[x] : x;        // (k_long_order: longest first)
     const kd_u64 i = long_list[b];
     const uint32_t sc = rinfo[i].span_cls;
     if ((sc & 3u) != KD_CLS_LONG) return;   // LONG after k_prep_long = regular long read
@@ -346,26 +329,21 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
     uint32_t *row = reinterpret_cast<uint32_t *>(rows + row_off[b]);
     // (acc.row_span - 1 = M / D footprint F: symbols 0 .. F-1 are its sites, symbol F takes trailing insertions)
     const bool has_ins = (sc & KD_INFO_INS) != 0;
-    const KdLongCk ck = cks[x];                // the read's state in front of this segment (k_prep_long)
     kd_u64 e_base = 0, p_base = 0;
-    if (has_ins) { e_base = (kd_u64)ins.read_ev[i] + ck.ev; p_base = ins.read_pool[i] + ck.pool; }
+    if (has_ins) { e_base = ins.read_ev[i]; p_base = ins.read_pool[i]; }
     uint32_t *tab = T.tab;
     const kd_u64 S = T.stride;
-    uint32_t c_r = ck.c_r, c_q = ck.c_q;       // coordinates in front of the tile (r relative to pos0)
-    uint32_t last_ins = ck.last_ins;           // 1 + r of the last I op seen (0: none)
+    uint32_t c_r = 0, c_q = 0;                 // coordinates in front of the tile (r relative to pos0)
+    uint32_t last_ins = 0;                     // 1 + r of the last I op seen (0: none)
     uint32_t trail_r = 0, trail_q = 0;         // the trailing clip's coordinates (its lane)
     bool bad = false, trail = false;
     // the row dword under construction: carried from chunk to chunk, tile to tile
     uint32_t cj = 0xffffffffu, cval = 0, cins = 0;
-    // the segment's FIRST row dword (the one in front of it may end in the same dword) is OR-ed into the zeroed row, like its last
-    uint32_t first_dw = 0xffffffffu;
 #define KD_ROW_FINISH(v, ib) ((((v) + (ib) * KD_ROW_INS) & 0x0f0f0f0fu) << 4 | ((((v) + (ib) * KD_ROW_INS) >> 4) & 0x0f0f0f0fu))   /* "+ins" twins, BAM nibble order */
     // (CIGAR words two tiles ahead, the first 256 bytes of the next tile's query bases one tile ahead: in flight while a tile is worked on)
-    const uint32_t base0 = sg * KD_LONG_SEG_OPS;
-    uint32_t w_nxt = base0 + lane < nc ? cg[base0 + lane] : 15u, w_nxt2 = base0 + lane + KD_WAVE < nc ? cg[base0 + lane + KD_WAVE] : 15u;
-    uint32_t sq_pre;
-    { const uint32_t ob = (c_q & ~7u) >> 1; sq_pre = ob + 4u * lane < (uint32_t)((sl + 1) >> 1) + 8u ? reinterpret_cast<const KdU32u *>(seq + ob + 4u * lane)->v : 0u; }
-    for (uint32_t base = base0; base <= nc && base < base0 + KD_LONG_SEG_OPS; base += KD_WAVE) {   // (<= nc: the terminator behind the last op is a piece too)
+    uint32_t w_nxt = lane < nc ? cg[lane] : 15u, w_nxt2 = lane + KD_WAVE < nc ? cg[lane + KD_WAVE] : 15u;
+    uint32_t sq_pre = 4u * lane < (uint32_t)((sl + 1) >> 1) + 8u ? reinterpret_cast<const KdU32u *>(seq + 4u * lane)->v : 0u;
+    for (uint32_t base = 0; base <= nc; base += KD_WAVE) {   // (<=: the terminator behind the last op is a piece too)
         const uint32_t k = base + lane;
         const uint32_t w = w_nxt;
         w_nxt = w_nxt2;
@@ -481,11 +459,9 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
                 }                                           // (else: the terminator: the slot behind the last site exists)
             }
             const uint32_t jf = kd_readfirstlane(j);
-            if (first_dw == 0xffffffffu) first_dw = jf;
             if (cj != 0xffffffffu && cj != jf) {            // the carried dword is complete
                 if (lane == 0) {
-                    if (cj == first_dw) atomicOr(&row[cj], KD_ROW_FINISH(cval, cins));
-                    else row[cj] = KD_ROW_FINISH(cval, cins);
+                    row[cj] = KD_ROW_FINISH(cval, cins);
                 }
                 cval = 0; cins = 0;
             } else if (cj == 0xffffffffu) { cval = 0; cins = 0; }
@@ -499,18 +475,17 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
             uint32_t v = s_out[lane], vb = s_insb[lane];
             if (lane == 0) { v |= cval; vb |= cins; }
             if (jf + lane < jl) {
-                if (jf + lane == first_dw) atomicOr(&row[jf + lane], KD_ROW_FINISH(v, vb));
-                else row[jf + lane] = KD_ROW_FINISH(v, vb);
+                row[jf + lane] = KD_ROW_FINISH(v, vb);
             }
             cj = jl;
             cval = kd_readlane(v, jl - jf); cins = kd_readlane(vb, jl - jf);
         }
         c_r += kd_readlane(ir, KD_WAVE - 1); c_q += tot_q;
     }
-    if (cj != 0xffffffffu && lane == 0) atomicOr(&row[cj], KD_ROW_FINISH(cval, cins));     // (the segment behind may begin in this dword)
+    if (cj != 0xffffffffu && lane == 0) row[cj] = KD_ROW_FINISH(cval, cins);
 #undef KD_ROW_FINISH
     // ---- soft clips: weights of the clipped bases (clip_end_weights in front of the read, clip_start_weights behind it) ----
-    if (sg == 0 && (cg[0] & 15u) == 4u && acc.lead) {
+    if ((cg[0] & 15u) == 4u && acc.lead) {
         const uint32_t len0 = cg[0] >> 4;
         for (uint32_t x = lane; x < acc.lead; x += KD_WAVE) {       // base len0 - lead + x -> site pos0 - lead + x
             const uint32_t ch = kd_chan(kd_nib(seq, (int64_t)(len0 - acc.lead + x)));
