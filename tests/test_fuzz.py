@@ -39,13 +39,13 @@ def test_fuzz_batch_sizes_around_the_prep_block_emulated(emu_lib, n_reads):
         assert fuzz.check_engine(emu_lib, batch, mode, window=[64, 256, 640][n_reads % 3], slice_reads=[0, 16][n_reads % 2]) in ("ok", "raise")
 
 
-def _long_campaign(lib, seeds, n_reads):
+def _long_campaign(lib, seeds, n_reads, long_ops=(17, 700), contig_lens=(6000, 2500)):
     """Reads with hundreds of ops (clips at both ends, indels, N/H/P) on contigs that hold them: the long-read
     path (k_prep_long, k_long_expand's rows, k_window's row pass), sorted and unsorted, two window sizes."""
     n_ok = 0
     for seed in seeds:
         rng = np.random.default_rng(seed)
-        batch = fuzz.random_batch(rng, n_reads, contig_lens=(6000, 2500), wild=0.0, sort=bool(seed & 1), long_ops=(17, 700))
+        batch = fuzz.random_batch(rng, n_reads, contig_lens=contig_lens, wild=0.0, sort=bool(seed & 1), long_ops=long_ops)
         for mode in MODES:
             n_ok += fuzz.check_engine(lib, batch, mode, window=[64, 256][seed % 2], slice_reads=[0, 16][(seed >> 1) % 2]) == "ok"
     return n_ok
@@ -53,6 +53,13 @@ def _long_campaign(lib, seeds, n_reads):
 
 def test_fuzz_long_cigars_emulated(emu_lib):
     assert _long_campaign(emu_lib, range(300, 304), n_reads=40) >= 6
+
+
+def test_fuzz_long_cigars_of_several_segments_emulated(emu_lib):
+    """Round 5: k_long_expand takes a read in SEGMENTS of 512 CIGAR words, each from the state k_prep_long left in front of it --
+    reads of up to 2 600 words: segment boundaries inside insertion runs, deletions, in front of the trailing clip; neighbouring
+    segments meeting inside one row dword."""
+    assert _long_campaign(emu_lib, range(310, 316), n_reads=30, long_ops=(480, 2600), contig_lens=(30000, 14000)) >= 8
 
 
 def _mixed_campaign(lib, seeds, sizes):
