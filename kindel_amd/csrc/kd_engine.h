@@ -345,21 +345,21 @@ struct KdEngine {
             if ((rc = ensure(b_rowinfo, (size_t)n_long * sizeof(KdRInfo))) || (rc = ensure(b_rowoff, (size_t)n_long * 8)) ||
                 (rc = ensure(b_longacc, (size_t)n_long * sizeof(KdLongAcc))))
                 return rc;
+            // k_prep_long and k_long_expand start the longest reads first (k_long_order)
+            long_ordered = n_long > 1 && n_long <= KD_LONG_ORDER_MAX;
+            if (long_ordered) {
+                if ((rc = ensure(b_longorder, (size_t)n_long * 4))) return rc;
+                if (rt.launch("k_long_order", k_long_order, 1u, KD_LONG_ORDER_BLOCK, 0, R, (const uint32_t *)lng, (uint32_t)n_long, (uint32_t *)b_longorder.p))
+                    return hipfail("k_long_order");
+            }
             const unsigned long_grid = (unsigned)((n_long + KD_LONG_WAVES - 1) / KD_LONG_WAVES);   // a wavefront per long read, a workgroup per wavefront
             if (rt.launch("k_prep_long", k_prep_long, long_grid, KD_LONG_BLOCK, 0, R, T, rinfo,
-                          (const uint32_t *)lng, (uint32_t)n_long, (KdLongAcc *)b_longacc.p))
+                          (const uint32_t *)lng, (uint32_t)n_long, (KdLongAcc *)b_longacc.p, long_ordered ? (const uint32_t *)b_longorder.p : (const uint32_t *)nullptr))
                 return hipfail("k_prep_long");
             if (rt.launch("k_long_reduce", k_long_reduce, (unsigned)((n_long + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, (const KdLongAcc *)b_longacc.p,
                           (const uint32_t *)lng, (uint32_t)n_long, (const KdRInfo *)rinfo, irreg, (uint32_t *)b_readev.p, (kd_u64 *)b_readpool.p,
                           (KdRInfo *)b_rowinfo.p, (kd_u64 *)b_rowoff.p, d_status))
                 return hipfail("k_long_reduce");
-            // k_long_expand starts the longest reads first (k_long_order; queued in front of the read-back: it runs while the host waits)
-            long_ordered = n_long > 1 && n_long <= KD_LONG_ORDER_MAX && mode != KD_MODE_GLOBAL;
-            if (long_ordered) {
-                if ((rc = ensure(b_longorder, (size_t)n_long * 4))) return rc;
-                if (rt.launch("k_long_order", k_long_order, 1u, KD_LONG_ORDER_BLOCK, 0, (const KdLongAcc *)b_longacc.p, (uint32_t)n_long, (uint32_t *)b_longorder.p))
-                    return hipfail("k_long_order");
-            }
             if ((rc = fetch_status())) return rc;
             if ((rc = ensure(b_rows, (size_t)h_status[KDS_B_ROW_DWORDS] * 4 + 64))) return rc;   // (+ 64: the walk loads 16-byte chunks)
         }

@@ -55,6 +55,32 @@ __device__ __forceinline__ KdAdv kd_op_advance(uint32_t w, uint32_t k) {
     return a;
 }
 
+// k_long_order: the long reads LONGEST FIRST (round 5) -- order[x] = the x-th read k_prep_long and k_long_expand start.  Their
+// wavefronts each take one read, 2 to 30 kilobases on a long-read run, and a launch ends with its last read: in list order a
+// 30-kilobase read that starts late is the kernel's tail; longest first the long ones start at once and the short ones fill the
+// gaps (longest-processing-time-first list scheduling).  One workgroup: a counting sort over 128 length classes (CIGAR words, two
+// mantissa bits per power of two), descending.
+#define KD_LONG_ORDER_BLOCK 1024
+#define KD_LONG_ORDER_MAX (1u << 20)     // (more long reads than this: list order -- a tail of one read no longer shows)
+__global__ void __launch_bounds__(KD_LONG_ORDER_BLOCK)
+k_long_order(KdReads rd, const uint32_t *long_list, uint32_t n_long, uint32_t *order) {
+    __shared__ uint32_t s_cnt[128];
+    const uint32_t t = threadIdx.x;
+    if (t < 128) s_cnt[t] = 0;
+    __syncthreads();
+    auto cls = [](uint32_t v) -> uint32_t {
+        if (v < 4u) return 127u - v;
+        const uint32_t lg = 31u - (uint32_t)__builtin_clz(v);
+        return 127u - ((lg << 2) | ((v >> (lg - 2u)) & 3u));      // 0 = the longest class
+    };
+    for (uint32_t b = t; b < n_long; b += KD_LONG_ORDER_BLOCK) atomicAdd(&s_cnt[cls(rd.n_cig[long_list[b]])], 1u);
+    __syncthreads();
+    if (t == 0) { uint32_t run = 0; for (uint32_t k = 0; k < 128; k++) { const uint32_t v = s_cnt[k]; s_cnt[k] = run; run += v; } }
+    __syncthreads();
+    // (slots of a class are handed out in any order: which of two reads of one length class starts first does not matter)
+    for (uint32_t b = t; b < n_long; b += KD_LONG_ORDER_BLOCK) order[atomicAdd(&s_cnt[cls(rd.n_cig[long_list[b]])], 1u)] = b;
+}
+
 // k_prep_long: the regularity rules of kd_scan_cigar (kd_prep.h) applied op-parallel: every op checks itself against its own
 // start coordinates; what the read leaves behind is ONE record (KdLongAcc) and its footprint entry -- k_long_reduce turns the
 // records into slots.
@@ -64,11 +90,12 @@ __device__ __forceinline__ KdAdv kd_op_advance(uint32_t w, uint32_t k) {
 #define KD_LONG_BLOCK KD_WAVE
 #define KD_LONG_WAVES (KD_LONG_BLOCK / KD_WAVE)
 __global__ void __launch_bounds__(KD_LONG_BLOCK)
-k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uint32_t n_long, KdLongAcc *long_acc) {
+k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uint32_t n_long, KdLongAcc *long_acc, const uint32_t *order) {
     __shared__ kd_u64 s_acc[KD_LONG_WAVES][4];       // aligned, walked, n_ins, ins_bases
     const uint32_t lane = threadIdx.x & (KD_WAVE - 1), wave = threadIdx.x / KD_WAVE;
-    const uint32_t b = blockIdx.x * KD_LONG_WAVES + wave;
-    if (b >= n_long) return;
+    const uint32_t x = blockIdx.x * KD_LONG_WAVES + wave;
+    if (x >= n_long) return;
+    const uint32_t b = order ? order[x] : x;         // (k_long_order: longest first)
     const kd_u64 i = long_list[b];
     const uint32_t c = rd.contig[i];
     const int64_t L = T.contig_len[c];
@@ -214,33 +241,6 @@ k_long_reduce(const KdLongAcc *long_acc, const uint32_t *long_list, uint32_t n_l
     }
 }
 
-// k_long_order: the long reads LONGEST FIRST (round 5) -- order[x] = the x-th read k_long_expand starts.  Its wavefronts each
-// expand one read, 2 to 30 kilobases on a long-read run, and the launch ends with its last read: in list order a 30-kilobase
-// read that starts late is the kernel's tail; longest first the long ones start at once and the short ones fill the gaps
-// (longest-processing-time-first list scheduling).  One workgroup: a counting sort over 128 length classes (walked events, two
-// mantissa bits per power of two), descending; reads of one class keep their list order.
-#define KD_LONG_ORDER_BLOCK 1024
-#define KD_LONG_ORDER_MAX (1u << 20)     // (more long reads than this: list order -- a tail of one read no longer shows)
-__global__ void __launch_bounds__(KD_LONG_ORDER_BLOCK)
-k_long_order(const KdLongAcc *long_acc, uint32_t n_long, uint32_t *order) {
-    __shared__ uint32_t s_cnt[128];
-    const uint32_t t = threadIdx.x;
-    if (t < 128) s_cnt[t] = 0;
-    __syncthreads();
-    auto cls = [](kd_u64 walked) -> uint32_t {
-        const uint32_t v = walked < 0xffffffffULL ? (uint32_t)walked : 0xffffffffu;
-        if (v < 4u) return 127u - v;
-        const uint32_t lg = 31u - (uint32_t)__builtin_clz(v);
-        return 127u - ((lg << 2) | ((v >> (lg - 2u)) & 3u));      // 0 = the longest class
-    };
-    for (uint32_t b = t; b < n_long; b += KD_LONG_ORDER_BLOCK) atomicAdd(&s_cnt[cls(long_acc[b].walked)], 1u);
-    __syncthreads();
-    if (t == 0) { uint32_t run = 0; for (uint32_t k = 0; k < 128; k++) { const uint32_t v = s_cnt[k]; s_cnt[k] = run; run += v; } }
-    __syncthreads();
-    // (slots of a class are handed out in any order: which of two reads of one length class starts first does not matter)
-    for (uint32_t b = t; b < n_long; b += KD_LONG_ORDER_BLOCK) order[atomicAdd(&s_cnt[cls(long_acc[b].walked)], 1u)] = b;
-}
-
 // 8 query bases from base q on as LINEAR nibbles (base q + i at bits 4i .. 4i+3): BAM packs the even base into the HIGH
 // nibble of a byte, so the nibbles of every byte are swapped before the (q & 1) shift.  Reads 8 bytes from byte q / 2.
 struct __attribute__((packed, aligned(1))) KdU64u { kd_u64 v; };
@@ -296,7 +296,7 @@ __device__ __forceinline__ uint32_t kd_zero_nibbles(uint32_t x) {
 //     added to ins_total directly.
 // Behind the tiles: the soft clips' weight tallies and clip_starts / clip_ends counters (atomics to HBM: two clips per read).
 #ifndef KD_LONG_OCC
-#define KD_LONG_OCC 5      // wavefronts per SIMD the register budget is set for (96 registers; measured on C5: 4 / 5 / 6 = 0.676 / 0.610 / 0.651 ms, 6 spills 9 registers)
+#define KD_LONG_OCC 6      // wavefronts per SIMD the register budget is set for (round 5, one wavefront per workgroup, longest reads first: 4 / 5 / 6 / 8 = 0.406 / 0.400 / 0.373 / 0.405 ms on C5; round 4, four reads per workgroup: 0.676 / 0.610 / 0.651)
 #endif
 __global__ void __launch_bounds__(KD_LONG_BLOCK, KD_LONG_OCC)
 k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint32_t *long_list, uint32_t n_long,
