@@ -348,7 +348,7 @@ struct KdEngine {
             // k_prep_long and k_long_expand start the longest reads first (k_long_order)
             long_ordered = n_long > 1 && n_long <= KD_LONG_ORDER_MAX;
             if (long_ordered) {
-                if ((rc = ensure(b_longorder, (size_t)n_long * 4))) return rc;
+                if ((rc = ensure(b_longorder, (size_t)n_long * 8))) return rc;      // (the order | the reads' length classes)
                 if (rt.launch("k_long_order", k_long_order, 1u, KD_LONG_ORDER_BLOCK, 0, R, (const uint32_t *)lng, (uint32_t)n_long, (uint32_t *)b_longorder.p))
                     return hipfail("k_long_order");
             }

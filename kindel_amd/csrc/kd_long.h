@@ -73,12 +73,26 @@ k_long_order(KdReads rd, const uint32_t *long_list, uint32_t n_long, uint32_t *o
         const uint32_t lg = 31u - (uint32_t)__builtin_clz(v);
         return 127u - ((lg << 2) | ((v >> (lg - 2u)) & 3u));      // 0 = the longest class
     };
-    for (uint32_t b = t; b < n_long; b += KD_LONG_ORDER_BLOCK) atomicAdd(&s_cnt[cls(rd.n_cig[long_list[b]])], 1u);
+    // pass 1: a read's class from its CIGAR word count (two dependent loads per read: four reads per turn in flight), kept in the
+    // second half of `order` (2 x n_long words) for pass 2
+    uint32_t *cl = order + n_long;
+    for (uint32_t b0 = t; b0 < n_long; b0 += 4u * KD_LONG_ORDER_BLOCK) {
+        uint32_t i4[4], n4[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) { const uint32_t b = b0 + u * KD_LONG_ORDER_BLOCK; i4[u] = b < n_long ? long_list[b] : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) { const uint32_t b = b0 + u * KD_LONG_ORDER_BLOCK; n4[u] = b < n_long ? rd.n_cig[i4[u]] : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t b = b0 + u * KD_LONG_ORDER_BLOCK;
+            if (b < n_long) { const uint32_t c = cls(n4[u]); cl[b] = c; atomicAdd(&s_cnt[c], 1u); }
+        }
+    }
     __syncthreads();
     if (t == 0) { uint32_t run = 0; for (uint32_t k = 0; k < 128; k++) { const uint32_t v = s_cnt[k]; s_cnt[k] = run; run += v; } }
     __syncthreads();
     // (slots of a class are handed out in any order: which of two reads of one length class starts first does not matter)
-    for (uint32_t b = t; b < n_long; b += KD_LONG_ORDER_BLOCK) order[atomicAdd(&s_cnt[cls(rd.n_cig[long_list[b]])], 1u)] = b;
+    for (uint32_t b = t; b < n_long; b += KD_LONG_ORDER_BLOCK) order[atomicAdd(&s_cnt[cl[b]], 1u)] = b;
 }
 
 // k_prep_long: the regularity rules of kd_scan_cigar (kd_prep.h) applied op-parallel: every op checks itself against its own
