@@ -313,6 +313,7 @@ def main():
                     "/".join(sorted(prof_dom)) or "none", args.steps),
                 kernel_ms_per_step=round(kernel_ms_per_step, 4),
                 fasta_sha256=fasta_sha, consensus_len=sum(len(s) for s in seqs), gen_seconds=round(t_gen, 1),
+                library_sha256=_library_sha(N),
                 engine_stats=stats,
             )
         return dict(out=out, eng=eng, batch=batch, contig_lens=contig_lens, seqs=seqs, aligned_g=aligned_g, step=step, barrier=barrier)
@@ -488,6 +489,16 @@ def _cpu_quota():
 def _pmc_key(args, world):
     """The workload a committed PMC record belongs to: config, kernel mode, input order, scale, ranks."""
     return "%s|%s|%s" % (args.config, args.mode, ("shuffle-" + args.shuffle) if args.shuffle else "sorted")
+
+
+def _library_sha(N):
+    """sha256 (16 hex digits) of the libkindel_hip.so this run loaded: records of different builds must not be mixed
+    (scripts/harvest_profiles.py refuses a counter pass whose library differs from the bench file's)"""
+    try:
+        with open(N.default_library().path, "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest()[:16]
+    except Exception:
+        return None
 
 
 def _pmc_traffic(kernel, args, world):

@@ -38,7 +38,14 @@ per = {k: {c: v / max(len(ids[(k, c)]), 1) for c, v in cs.items()} for k, cs in 
 out = "$O/pmc_%s_summary.json" % tag
 old = json.load(open(out)) if os.path.exists(out) else {}
 for k, cs in per.items(): old.setdefault(k, {}).update(cs)        # (a traffic-only rerun keeps the other counters)
+# the library these passes ran (bench.py prints it on its JSON line): harvest_profiles.py compares it with the bench files'
+try:
+    lines = [l for i in [int(x) for x in "${PMC_SETS:-1 2 3 4}".split()] for l in open("$O/pmc_%s_%d.out" % (tag, i)) if l.startswith('{"metric')]
+    libs = sorted(set(json.loads(l).get("library_sha256") for l in lines))
+    old["_library_sha256"] = libs[0] if len(libs) == 1 else libs
+except Exception as e:
+    old["_library_sha256"] = None
 json.dump(old, open(out, "w"), indent=1, sort_keys=True)
-for k in sorted(per, key=lambda k: -per[k].get("FETCH_SIZE", per[k].get("SQ_BUSY_CYCLES", 0)))[:4]:
+for k in sorted((k for k in per if not k.startswith("_")), key=lambda k: -per[k].get("FETCH_SIZE", per[k].get("SQ_BUSY_CYCLES", 0)))[:4]:
     print(tag, k, {c: "%.4g" % v for c, v in sorted(per[k].items())})
 PY

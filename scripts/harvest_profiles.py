@@ -69,17 +69,34 @@ traffic = {}
 if os.path.exists(tp):
     old = json.load(open(tp))
     traffic = {k: v for k, v in old.items() if "|" in k}       # (a pre-round-4 file was keyed by kernel: dropped)
+def bench_library(tagname):
+    """library_sha256 of this round's bench file of the same workload (None: no such file, or written by a bench.py without it)"""
+    src = {"C3": "bench_c3.json", "C2": "bench_C2.json", "C4": "bench_C4.json", "C5": "bench_C5.json", "C3_shuffle": "exp_shuf.json"}[tagname]
+    p = os.path.join(O, src)
+    if not os.path.exists(p) or os.path.getmtime(p) < newer_than:
+        return None
+    return first_json_line(p).get("library_sha256")
+
+
 for tagname, key in (("C3", "C3|auto|sorted"), ("C2", "C2|auto|sorted"), ("C4", "C4|auto|sorted"), ("C5", "C5|auto|sorted"),
                      ("C3_shuffle", "C3|auto|shuffle-records")):
     per = pmc_per_dispatch(tagname)
     if not per:
         continue
+    # records that agree with each other: a counter pass taken with ANOTHER build of the library than the bench file of the same
+    # workload is refused (round 4 committed a C4 bench file quoting 8.91 GB next to a PMC table with 6.08 GB)
+    lib_pmc, lib_bench = per.pop("_library_sha256", None), bench_library(tagname)
+    if lib_bench is not None and lib_pmc != lib_bench:
+        print("REFUSED: the PMC pass of %s ran library %s, its bench file %s -- rerun both on one build" % (tagname, lib_pmc, lib_bench))
+        continue
+    per = {k: c for k, c in per.items() if not k.startswith("_")}
     json.dump(per, open(os.path.join(P, "%s_%s_pmc_per_dispatch.json" % (tag, tagname if tagname != "C3" else "c3")), "w"), indent=1, sort_keys=True)
     rec = {k: dict(bytes=int((2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024),
                    raw_bytes=int((c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024))
            for k, c in per.items() if "FETCH_SIZE" in c and "WRITE_SIZE" in c}
     if rec:
         rec["_measured"] = tag
+        rec["_library_sha256"] = lib_pmc
         traffic[key] = rec
 if traffic:
     traffic["_note"] = note
