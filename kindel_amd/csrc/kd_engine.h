@@ -148,6 +148,7 @@ struct KdEngine {
         if (!n || !lens) return fail(KD_E_ARG, "kd_create: no contigs");
         if (rt.init(device, stream)) return hipfail("kd_create: device init");
         knob_step_trace = getenv("KD_STEP_TRACE") != nullptr; knob_replay_eager = getenv("KD_STEP_REPLAY_EAGER") != nullptr;
+        if (const char *e = getenv("KD_COLD_TAIL")) knob_cold_tail = atoi(e) != 0;
         n_contigs = n;
         clen.assign(lens, lens + n);
         cbase.resize(n);
@@ -395,6 +396,8 @@ struct KdEngine {
             const uint64_t g_end = std::min<uint64_t>(S, g_hi + 1);
             auto windows_of = [&](uint32_t Wx, uint32_t &first) { first = (uint32_t)(g_lo / Wx); return (uint32_t)((g_end + Wx - 1) / Wx) - first; };
             const bool coop = coop_mode();
+            bool cold_fused = false;      // the cold records' workgroups rode in k_window's launch (kd_window.h: KdColdTail)
+            const bool cold_tail_on = knob_cold_tail;
             const uint32_t W_first = window_sites(coop), W_seg = window_sites(false);
             uint32_t ws0, dummy0;
             const uint32_t ns_win = windows_of(KD_STRIP, ws0);
@@ -538,8 +541,18 @@ struct KdEngine {
                         walk_R.cig_off = nullptr; walk_R.n_cig = nullptr; walk_R.osh = 0;
                     }
                     last_nwin += n_win;
-                    if (rows ? rt.launch("k_window_rows", k_window<true>, grid, KD_BLOCK, lds, walk_R, walk_info, order, T, Q, w0, W, H, Wh, slice, d_status)
-                             : rt.launch("k_window", k_window<false>, grid, KD_BLOCK, lds, walk_R, walk_info, order, T, Q, w0, W, H, Wh, slice, d_status))
+                    // the first pass carries the cold records' workgroups behind its persistent ones (kd_window.h: KdColdTail) -- when
+                    // the reads it walks are the batch's own arrays (an unsorted batch's window-ordered copy has another layout)
+                    KdColdTail tail;
+                    tail.rec = nullptr; tail.cnt = nullptr; tail.evbase = tail.poolbase = nullptr; tail.ins = I;
+                    tail.region_slots = 0; tail.n_regions = 0; tail.first_block = grid;
+                    if (!rows && n_cold && walk_R.osh == 0 && cold_tail_on) {
+                        tail.rec = (const KdColdRec *)cold; tail.cnt = (const uint32_t *)b_coldcnt.p; tail.evbase = (const kd_u64 *)b_coldev.p;
+                        tail.poolbase = (const kd_u64 *)b_coldpool.p; tail.region_slots = cold_region; tail.n_regions = prep_regions;
+                        cold_fused = true;
+                    }
+                    if (rows ? rt.launch("k_window_rows", k_window<true>, grid, KD_BLOCK, lds, walk_R, walk_info, order, T, Q, w0, W, H, Wh, slice, d_status, tail)
+                             : rt.launch("k_window", k_window<false>, grid + tail.n_regions, KD_BLOCK, lds, walk_R, walk_info, order, T, Q, w0, W, H, Wh, slice, d_status, tail))
                         return hipfail("k_window");
                     return KD_OK;
                 }
@@ -632,7 +645,7 @@ struct KdEngine {
                 return hipfail("k_pileup_wave_irreg");
             // the batch's last kernel: the clip counters / insertion events of the clipped and inserted regular reads, and -- its
             // last workgroup -- the error classification (kd_errors.h: leaves at once when nothing was flagged)
-            if (n_cold ? rt.launch("k_cold_lane", k_cold_lane, prep_regions + 1u, KD_BLOCK, 0, R, T, I, (const KdColdRec *)cold,
+            if (n_cold && !cold_fused ? rt.launch("k_cold_lane", k_cold_lane, prep_regions + 1u, KD_BLOCK, 0, R, T, I, (const KdColdRec *)cold,
                                    (const uint32_t *)b_coldcnt.p, (const kd_u64 *)b_coldev.p, (const kd_u64 *)b_coldpool.p, cold_region, d_status,
                                    (const KdRInfo *)rinfo, n_contigs)
                        : rt.launch("k_errors", k_errors, 1u, KD_BLOCK, 0, R, T, (const KdRInfo *)rinfo, n_contigs, d_status, 1u))
@@ -1229,6 +1242,7 @@ struct KdEngine {
     bool step_in_capture = false;
     // fault-localisation knobs, read when the context is created (create())
     bool knob_step_trace = false, knob_replay_eager = false;
+    bool knob_cold_tail = true;       // KD_COLD_TAIL=0 (measurement): k_cold_lane as a launch of its own behind the window passes, as until round 4
     int replay_copies(uint8_t *seq_out) {
         const size_t mb = meta_bytes();
         if (rt.d2h_async(step_meta_pin, meta_coff(), mb)) return hipfail("consensus: d2h");      // (pinned: see Runtime::graph_stage)

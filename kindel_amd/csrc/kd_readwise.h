@@ -140,14 +140,16 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
 // list.  Regular reads cannot raise and never wrap (k_prep checked), so this is plain G-space arithmetic.
 // The workgroup behind the last record region is the batch's error classification (kd_errors.h): the other kernels of the
 // batch have finished, this kernel flags nothing.
-__global__ void __launch_bounds__(KD_BLOCK)
-k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const KdColdRec *rec, const uint32_t *cold_cnt, const kd_u64 *cold_evbase,
-            const kd_u64 *cold_poolbase, uint32_t region_slots, kd_u64 *status, const KdRInfo *rinfo, uint32_t n_contigs) {
-    if (blockIdx.x + 1 == gridDim.x) { kd_errors(rd, T, rinfo, n_contigs, status, true); return; }
+// kd_cold_region: the records of ONE region (= of one wavefront of k_prep), all threads of a 256-thread workgroup.  Called by
+// k_cold_lane (a workgroup per region) and -- round 5 -- by the workgroups k_window's launch carries behind its persistent ones
+// (kd_window.h: KdColdTail): the work fills the chip while the last windows are still being tallied.
+__device__ __forceinline__ void kd_cold_region(uint32_t region, const KdReads &rd, const KdTabs &T, const KdIns &ins, const KdColdRec *rec,
+                                               const uint32_t *cold_cnt, const kd_u64 *cold_evbase, const kd_u64 *cold_poolbase,
+                                               uint32_t region_slots, kd_u64 *status) {
     // one workgroup per record region (= per wavefront of k_prep): cnt records, usually fewer than 256
-    const uint32_t cnt = cold_cnt[blockIdx.x];
-    const KdColdRec *reg = rec + (kd_u64)blockIdx.x * region_slots;
-    const kd_u64 ev_base = cold_evbase[blockIdx.x], pool_base = cold_poolbase[blockIdx.x];   // the region's insertion slots
+    const uint32_t cnt = cold_cnt[region];
+    const KdColdRec *reg = rec + (kd_u64)region * region_slots;
+    const kd_u64 ev_base = cold_evbase[region], pool_base = cold_poolbase[region];   // the region's insertion slots
   for (uint32_t k0 = 0; k0 < cnt; k0 += KD_BLOCK) {     // (uniform trip count: the wavefront meets again behind each walk)
     const uint32_t slot = k0 + threadIdx.x;
     const bool live = slot < cnt;
@@ -222,6 +224,12 @@ k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const KdColdRec *rec, const uint32_
     if ((n = kd_run_heads(g_cs != NONE, g_cs, hl))) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g_cs], n);
     if ((n = kd_run_heads(g_in != NONE, g_in, hl))) atomicAdd(&tab[(kd_u64)KDC_INS_TOTAL * S + g_in], n);
   }
+}
+__global__ void __launch_bounds__(KD_BLOCK)
+k_cold_lane(KdReads rd, KdTabs T, KdIns ins, const KdColdRec *rec, const uint32_t *cold_cnt, const kd_u64 *cold_evbase,
+            const kd_u64 *cold_poolbase, uint32_t region_slots, kd_u64 *status, const KdRInfo *rinfo, uint32_t n_contigs) {
+    if (blockIdx.x + 1 == gridDim.x) { kd_errors(rd, T, rinfo, n_contigs, status, true); return; }
+    kd_cold_region(blockIdx.x, rd, T, ins, rec, cold_cnt, cold_evbase, cold_poolbase, region_slots, status);
 }
 
 // k_cold_slots: the same records -> read_ev[] / read_pool[] of the reads with insertions.  Only for the paths that walk regular

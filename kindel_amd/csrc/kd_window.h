@@ -510,10 +510,26 @@ __device__ __forceinline__ void kd_wq_range(const KdWq &Q, kd_u64 maxspan, kd_u6
     if (hi < lo) hi = lo;      // (an unsorted batch's table is meaningless -- and unused; never a negative range)
 }
 
+// THE COLD TAIL (round 5).  The launch's persistent workgroups leave one by one as the window tickets run out, each after its last
+// window (~0.1 ms of work at full size): for half a window's time on average a workgroup slot idles until the launch ends.  The
+// clip counters and insertion events of the clipped / inserted reads (k_cold_lane: 0.12 ms of memory-bound work that needs
+// nothing k_window produces) ride in the same launch as workgroups BEHIND the persistent ones -- `n_regions` more, one per
+// record region: the dispatcher hands them out as slots come free, they fill the tail, and k_cold_lane's own launch is gone.
+// (They hold no ticket and nobody waits for them; a slot taken by one before every persistent workgroup is resident delays that
+// workgroup, nothing else.)  The batch's error classification, which must see every kernel's flags, is a launch of its own then.
+struct KdColdTail {
+    const KdColdRec *rec; const uint32_t *cnt; const kd_u64 *evbase, *poolbase;
+    KdIns ins;
+    uint32_t region_slots, n_regions, first_block;     // n_regions = 0: no tail; first_block = the persistent workgroups
+};
 template <bool ROWS>
 __global__ void __launch_bounds__(KD_BLOCK, KD_WINDOW_OCC)   // 5 wavefronts per SIMD = the 5 workgroups per CU the LDS footprint allows
 k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq Q, uint32_t w0,
-         uint32_t W, uint32_t H, uint32_t Wh_, uint32_t slice, kd_u64 *status) {
+         uint32_t W, uint32_t H, uint32_t Wh_, uint32_t slice, kd_u64 *status, KdColdTail tail) {
+    if (!ROWS && tail.n_regions && blockIdx.x >= tail.first_block) {     // (uniform over the workgroup)
+        kd_cold_region(blockIdx.x - tail.first_block, rd, T, tail.ins, tail.rec, tail.cnt, tail.evbase, tail.poolbase, tail.region_slots, status);
+        return;
+    }
     // OWNERSHIP (round 3).  The histogram of window w covers the sites [wlo, whi + H): H sites more than the window.  An entry
     // is tallied by the window its START lies in, over [start, min(end, whi + H)) -- with H >= the longest footprint of the
     // batch that is the whole read, once, on the loop-free walk, whatever window edge it crosses (before, every read that
