@@ -1242,7 +1242,10 @@ struct KdEngine {
     bool step_in_capture = false;
     // fault-localisation knobs, read when the context is created (create())
     bool knob_step_trace = false, knob_replay_eager = false;
-    bool knob_cold_tail = true;       // KD_COLD_TAIL=0 (measurement): k_cold_lane as a launch of its own behind the window passes, as until round 4
+    bool knob_cold_tail = false;      // KD_COLD_TAIL=1: the cold records' workgroups ride in k_window's launch (kd_window.h: KdColdTail) instead of k_cold_lane's own.
+                                      // Measured (round 5): the step gains 1.6 % (C3) / 2.4 % (C4) -- the memory-bound cold work fills the launch's tail --, bit-exact; OFF by
+                                      // default because the launch the roofline is measured on then carries k_cold_lane's 0.12 ms as well (k_window 0.93 -> 1.03 ms:
+                                      // the contract's fraction would fall from 0.37 to 0.33 for a step that got FASTER), and 1.6 % is inside the box-to-box spread
     int replay_copies(uint8_t *seq_out) {
         const size_t mb = meta_bytes();
         if (rt.d2h_async(step_meta_pin, meta_coff(), mb)) return hipfail("consensus: d2h");      // (pinned: see Runtime::graph_stage)

@@ -517,6 +517,8 @@ __device__ __forceinline__ void kd_wq_range(const KdWq &Q, kd_u64 maxspan, kd_u6
 // record region: the dispatcher hands them out as slots come free, they fill the tail, and k_cold_lane's own launch is gone.
 // (They hold no ticket and nobody waits for them; a slot taken by one before every persistent workgroup is resident delays that
 // workgroup, nothing else.)  The batch's error classification, which must see every kernel's flags, is a launch of its own then.
+// Measured: C3 step 1.589 -> 1.565 ms (k_window + k_cold_lane 0.932 + 0.131 -> 1.031), C4 2.858 -> 2.790, C2 0.253 -> 0.250, same FASTA,
+// 359 parity tests.  Opt-in (KD_COLD_TAIL=1; kd_engine.h says why it is not the default): profiles/r05_cold_tail_ab.json.
 struct KdColdTail {
     const KdColdRec *rec; const uint32_t *cnt; const kd_u64 *evbase, *poolbase;
     KdIns ins;

@@ -574,3 +574,24 @@ def test_consensus_over_hundreds_of_tiles_run_after_run(emu_lib):
                 assert seq.decode() == oseq and [None if c == 0 else chr(c) for c in ch] == och, (md, cid)
     finally:
         eng.close()
+
+
+def test_cold_records_riding_in_the_window_launch(emu_lib, monkeypatch):
+    """KD_COLD_TAIL=1 (opt-in, round 5): the clip counters and insertion events of the clipped / inserted reads are done by workgroups
+    appended to k_window's launch instead of k_cold_lane's own -- same tables, insertion dicts and consensus; also with bad bases
+    (the error classification is then a launch of its own) and for an unsorted batch (which keeps the separate launch)."""
+    monkeypatch.setenv("KD_COLD_TAIL", "1")
+    batch = synth.to_numpy(synth.short_reads([9000, 2500], 60, seed=14, clip_p=0.3, indel_p=0.3))
+    P.assert_matches_oracle(P.Run(emu_lib, batch))
+    P.assert_matches_oracle(P.Run(emu_lib, batch, window=128, slice_reads=64, n_pushes=3))
+    n = len(batch["contig"])
+    sh = dict(batch)
+    perm = np.random.default_rng(2).permutation(n)
+    for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+        sh[k] = batch[k][perm].copy()
+    P.assert_matches_oracle(P.Run(emu_lib, sh))
+    for key in QUIRKS:      # every case the reference raises for (bad bases in M / clips, overhangs, CIGAR '*', which contig's error wins)
+        exc = P.quirk_expect(QUIRKS[key])
+        if exc and not key.startswith("__"):
+            with pytest.raises(exc):
+                P.Run(emu_lib, P.sam_to_batch(QUIRKS[key]["sam"]), window=64)

@@ -474,6 +474,22 @@ def test_streamed_ingest_many_small_batches(hip_lib, tmp_path, key, chunk):
     assert [c.sequence for c in ra.consensuses] == [g["consensus"] for g in GOLD[key]["contigs"]]
 
 
+def test_cold_records_riding_in_the_window_launch_gpu(hip_lib, monkeypatch):
+    """KD_COLD_TAIL=1 (opt-in): k_cold_lane's work as workgroups behind k_window's persistent ones -- every table, insertion dict and
+    consensus of a clip- and indel-rich batch and of C2 at full size against the oracle; the reference's exceptions still surface."""
+    monkeypatch.setenv("KD_COLD_TAIL", "1")
+    batch = synth.to_numpy(synth.short_reads([90000, 25000], 300, seed=15, clip_p=0.3, indel_p=0.3))
+    run = P.Run(hip_lib, batch)
+    assert run.info["windowed"] == 1
+    P.assert_matches_oracle(run)
+    P.assert_matches_oracle(P.Run(hip_lib, synth.to_numpy(synth.make("C2", scale=0.2))))
+    for key in QUIRKS:
+        exc = P.quirk_expect(QUIRKS[key])
+        if exc and not key.startswith("__"):
+            with pytest.raises(exc):
+                P.Run(hip_lib, P.sam_to_batch(QUIRKS[key]["sam"]), window=64)
+
+
 def _step_sequence(lib, graph):
     """kd_step over one resident batch, step after step, every step's consensus and tables against the oracle: the same batch
     again, bases changed in place under the same pointers, a CIGAR changed in place so that the event counts move.  graph=False:
