@@ -74,17 +74,43 @@ __device__ __forceinline__ kd_u64 kd_mix64(kd_u64 x) {
 // NULL (the re-seeded repeat after a hash collision): ev_slot holds KD_EV_TAKE / KD_EV_DROPPED from the first attempt.
 // (events of one deep site sit next to each other in event order and carry the same insertion: neighbouring lanes with
 //  the same 64-bit key probe once and add their number, kd_run_heads)
+// Round 5: the SITE TEST is made here, per event, from the tables themselves (ten 4-byte loads for the event's site and the one
+// behind it) -- k_ins_flag's pass over every site of the shard (0.022 ms on C3 and a dependent launch: 0.03 ms of every step, a
+// tenth of C2's) is gone from a batch that has events; with it this kernel took over the words a consensus run starts from (the
+// collision counter, the per-contig depth ranges and output offsets).  `first` = the first attempt of a reduction: decide and
+// record the decision in ev_slot; else (the re-seeded repeat after a hash collision) ev_slot holds KD_EV_TAKE / KD_EV_DROPPED.
+__device__ __forceinline__ bool kd_ins_site_emits(const KdTabs &T, kd_u64 g) {
+    const uint32_t it = T.tab[(kd_u64)KDC_INS_TOTAL * T.stride + g];
+    if (!it) return false;
+    kd_u64 ad = 0, adn = 0;
+    const int chs[4] = {KDC_A, KDC_T, KDC_G, KDC_C};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t *row = T.tab + (kd_u64)chs[c] * T.stride;
+        ad += row[g];
+        adn += g + 1 < T.sites ? row[g + 1] : 0u;      // (0 behind a contig's last site: its slot L holds no weights)
+    }
+    return 2ULL * it > (ad < adn ? ad : adn);
+}
 __global__ void __launch_bounds__(KD_BLOCK)
-k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev, const uint8_t *flag) {
+k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev, KdTabs T, uint32_t first, kd_u64 *status, kd_u64 *contig_off, uint32_t *depth_minmax,
+             uint32_t n_contigs) {
     const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
+    if (first) {     // (what k_ins_flag left for the kernels behind it)
+        if (e == 0) { status[KDS_INS_COLLISION] = 0ULL; }
+        for (kd_u64 c = e; c <= n_contigs; c += (kd_u64)gridDim.x * KD_BLOCK) {
+            contig_off[c] = 0ULL;
+            if (c < n_contigs) { depth_minmax[2 * c] = 0xffffffffu; depth_minmax[2 * c + 1] = 0u; }
+        }
+    }
     bool take = false;
     uint32_t site = 0, len = 0;
     if (e < n_ev) {
-        if (flag) {
+        if (first) {
             site = ins.ev_site[e]; len = ins.ev_len[e];
             // a reserved slot that was never written (its read raised a reference exception half way: the batch is rejected by
             // kd_finalize anyway) holds stale data: keep it out unless it is at least in bounds
-            take = site != KD_EV_DROPPED && site < H.sites && ins.ev_off[e] + len <= ins.pool_cap && flag[site];
+            take = site != KD_EV_DROPPED && site < H.sites && ins.ev_off[e] + len <= ins.pool_cap && kd_commit(T, site) && kd_ins_site_emits(T, site);
             if (!take) H.ev_slot[e] = KD_EV_DROPPED;
         } else {
             take = H.ev_slot[e] == KD_EV_TAKE;
