@@ -63,7 +63,8 @@ struct KdEngine {
     Buf b_srec;   // an unsorted batch's regular reads in window order: KdSortRec[] (k_sort_scatter_reads)
     Buf b_ev_site, b_ev_len, b_ev_off, b_pool;
     uint64_t ev_cap = 0, pool_cap = 0;
-    Buf b_hkey, b_hcnt, b_hrep, b_evslot, b_best, b_best2;   // b_best / b_best2: the per-site maxima best_a / best_b (kd_ins.h)
+    Buf b_hkey, b_hcnt, b_hrep, b_evslot, b_best, b_best2, b_flag;   // b_best / b_best2: the per-site maxima best_a / best_b (kd_ins.h); b_flag: k_ins_flag's site bytes
+    bool ins_site_flags = false;      // this reduction's site test was made by k_ins_flag (else per event by k_ins_insert)
     Buf b_bound, b_hot;   // k_window's work queue: k_prep's boundary table, the hot-window list (kd_window.h: KdWq)
     Buf b_patch;          // consensus_run with CDR patches: patch_off | patch_start | patch_end
     uint64_t hash_cap = 0;
@@ -185,7 +186,7 @@ struct KdEngine {
 
     void destroy() {
         Buf *all[] = {&b_rinfo, &b_cold, &b_irreg, &b_long, &b_winlo, &b_winhi, &b_itemoff, &b_itemwin, &b_readev, &b_readpool, &b_order, &b_bincnt, &b_binoff, &b_rows, &b_rowinfo, &b_rowoff, &b_longacc, &b_coldcnt, &b_coldev, &b_coldpool, &b_ev_site, &b_ev_len,
-                      &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_best2, &b_bound, &b_hot, &b_patch, &b_cns, &b_changes,
+                      &b_ev_off, &b_pool, &b_hkey, &b_hcnt, &b_hrep, &b_evslot, &b_best, &b_best2, &b_flag, &b_bound, &b_hot, &b_patch, &b_cns, &b_changes,
                       &b_tilesum, &b_tilemm, &b_tileoff};
         for (Buf *b : all) release(*b);
         for (Buf &b : b_stage) release(b);
@@ -815,7 +816,8 @@ struct KdEngine {
         const unsigned ge = (unsigned)((n_ev + KD_BLOCK - 1) / KD_BLOCK), g4 = (unsigned)((n_ev + KD_INS_CHUNK - 1) / KD_INS_CHUNK);
         // (attempt 0: k_ins_insert zeroes the collision counter and marks the events itself)
         if (attempt && rt.memset(d_status + KDS_INS_COLLISION, 0, 8)) return hipfail("finalize: memset status");
-        if (rt.launch("k_ins_insert", k_ins_insert, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev, tabs(), attempt ? 0u : 1u, d_status, meta_coff(), meta_mm(), n_contigs))
+        if (rt.launch("k_ins_insert", k_ins_insert, ge, KD_BLOCK, 0, I, H, (kd_u64)n_ev, tabs(), attempt ? 0u : 1u, d_status, meta_coff(), meta_mm(), n_contigs,
+                      ins_site_flags ? (const uint8_t *)b_flag.p - alloc_lo : (const uint8_t *)nullptr))
             return hipfail("k_ins_insert");
         if (rt.launch("k_ins_verify_max", k_ins_verify_max, g4, KD_BLOCK, 0, I, H, (kd_u64)n_ev, (kd_u64 *)b_best.p - alloc_lo,
                       (kd_u64 *)b_best2.p - alloc_lo, d_status))
@@ -851,7 +853,9 @@ struct KdEngine {
                 if ((rc = ensure(b_hkey, cap * 8)) || (rc = ensure(b_hcnt, cap * 4)) || (rc = ensure(b_hrep, cap * 4))) return rc;
                 if (rt.memset(b_hkey.p, 0, b_hkey.cap) || rt.memset(b_hcnt.p, 0, b_hcnt.cap)) return hipfail("finalize: memset hash");
             }
-            if ((rc = ensure(b_evslot, n_ev * 4))) return rc;
+            // the site test: per event in k_ins_insert, or -- more events than a quarter of the shard's sites -- once per site (k_ins_flag)
+            ins_site_flags = n_ev * 4 > (uint64_t)(alloc_hi - alloc_lo);
+            if ((rc = ensure(b_evslot, n_ev * 4)) || (ins_site_flags && (rc = ensure(b_flag, n_local)))) return rc;
             hash_cap = cap;
             H.key = (kd_u64 *)b_hkey.p; H.cnt = (uint32_t *)b_hcnt.p; H.rep = (uint32_t *)b_hrep.p;
             H.ev_slot = (uint32_t *)b_evslot.p; H.cap = cap; H.sites = S;
@@ -859,8 +863,11 @@ struct KdEngine {
         // the words the reduction's verification and the consensus run start from: left by k_ins_insert on its way (round 5: it also
         // decides per event whether its site can emit an insertion at all -- rounds 2 - 4 flagged every site of the shard first); a
         // batch without insertion events has no k_ins_insert: k_ins_flag's minimal grid writes them
-        if (!n_ev && rt.launch("k_ins_flag", k_ins_flag, (unsigned)((std::min<uint64_t>((uint64_t)n_contigs + 1, 65536) + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, T,
-                               (kd_u64)alloc_lo, (kd_u64)alloc_hi, (uint8_t *)nullptr, d_status, meta_coff(), meta_mm(), n_contigs))
+        if (!n_ev) ins_site_flags = false;
+        const uint64_t flag_threads = ins_site_flags ? (alloc_hi - alloc_lo) / 4 : std::min<uint64_t>((uint64_t)n_contigs + 1, 65536);
+        if ((!n_ev || ins_site_flags) &&
+            rt.launch("k_ins_flag", k_ins_flag, (unsigned)((flag_threads + KD_BLOCK - 1) / KD_BLOCK), KD_BLOCK, 0, T, (kd_u64)alloc_lo, (kd_u64)alloc_hi,
+                      ins_site_flags ? (uint8_t *)b_flag.p - alloc_lo : (uint8_t *)nullptr, d_status, meta_coff(), meta_mm(), n_contigs))
             return hipfail("k_ins_flag");
         cns_meta_fresh = true;
         if (n_ev) {

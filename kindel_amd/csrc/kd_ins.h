@@ -74,10 +74,12 @@ __device__ __forceinline__ kd_u64 kd_mix64(kd_u64 x) {
 // NULL (the re-seeded repeat after a hash collision): ev_slot holds KD_EV_TAKE / KD_EV_DROPPED from the first attempt.
 // (events of one deep site sit next to each other in event order and carry the same insertion: neighbouring lanes with
 //  the same 64-bit key probe once and add their number, kd_run_heads)
-// Round 5: the SITE TEST is made here, per event, from the tables themselves (ten 4-byte loads for the event's site and the one
-// behind it) -- k_ins_flag's pass over every site of the shard (0.022 ms on C3 and a dependent launch: 0.03 ms of every step, a
-// tenth of C2's) is gone from a batch that has events; with it this kernel took over the words a consensus run starts from (the
-// collision counter, the per-contig depth ranges and output offsets).  `first` = the first attempt of a reduction: decide and
+// Round 5: where a batch has FEW events for its sites (short reads: C3 has 1.3 M events on 5 M sites) the SITE TEST is made here, per
+// event, from the tables themselves (ten 4-byte loads for the event's site and the one behind it) -- k_ins_flag's pass over
+// every site of the shard (0.022 ms on C3 and a dependent launch: 0.03 ms of every step, a tenth of C2's) is gone, and this
+// kernel leaves the words a consensus run starts from (the collision counter, the per-contig depth ranges and output offsets).
+// With MORE events than a quarter of the sites (long reads: C5 has 10 M events on 1 M sites; measured 0.172 against 0.042 + 0.008 ms)
+// k_ins_flag tests every site once and the events look their site's byte up, as in rounds 2 - 4.  `first` = the first attempt of a reduction: decide and
 // record the decision in ev_slot; else (the re-seeded repeat after a hash collision) ev_slot holds KD_EV_TAKE / KD_EV_DROPPED.
 __device__ __forceinline__ bool kd_ins_site_emits(const KdTabs &T, kd_u64 g) {
     const uint32_t it = T.tab[(kd_u64)KDC_INS_TOTAL * T.stride + g];
@@ -94,9 +96,9 @@ __device__ __forceinline__ bool kd_ins_site_emits(const KdTabs &T, kd_u64 g) {
 }
 __global__ void __launch_bounds__(KD_BLOCK)
 k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev, KdTabs T, uint32_t first, kd_u64 *status, kd_u64 *contig_off, uint32_t *depth_minmax,
-             uint32_t n_contigs) {
+             uint32_t n_contigs, const uint8_t *flag) {     // flag != NULL: k_ins_flag has tested the sites (a batch with more events than a quarter of its sites)
     const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
-    if (first) {     // (what k_ins_flag left for the kernels behind it)
+    if (first && !flag) {     // (what k_ins_flag leaves for the kernels behind it)
         if (e == 0) { status[KDS_INS_COLLISION] = 0ULL; }
         for (kd_u64 c = e; c <= n_contigs; c += (kd_u64)gridDim.x * KD_BLOCK) {
             contig_off[c] = 0ULL;
@@ -110,7 +112,8 @@ k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev, KdTabs T, uint32_t first, kd_u6
             site = ins.ev_site[e]; len = ins.ev_len[e];
             // a reserved slot that was never written (its read raised a reference exception half way: the batch is rejected by
             // kd_finalize anyway) holds stale data: keep it out unless it is at least in bounds
-            take = site != KD_EV_DROPPED && site < H.sites && ins.ev_off[e] + len <= ins.pool_cap && kd_commit(T, site) && kd_ins_site_emits(T, site);
+            take = site != KD_EV_DROPPED && site < H.sites && ins.ev_off[e] + len <= ins.pool_cap &&
+                   (flag ? flag[site] != 0 : (kd_commit(T, site) && kd_ins_site_emits(T, site)));
             if (!take) H.ev_slot[e] = KD_EV_DROPPED;
         } else {
             take = H.ev_slot[e] == KD_EV_TAKE;
