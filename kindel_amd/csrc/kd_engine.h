@@ -150,6 +150,7 @@ struct KdEngine {
         if (rt.init(device, stream)) return hipfail("kd_create: device init");
         knob_step_trace = getenv("KD_STEP_TRACE") != nullptr; knob_replay_eager = getenv("KD_STEP_REPLAY_EAGER") != nullptr;
         if (const char *e = getenv("KD_COLD_TAIL")) knob_cold_tail = atoi(e) != 0;
+        if (const char *e = getenv("KD_INS_SITE_FLAGS")) knob_ins_site_flags = atoi(e) != 0;
         n_contigs = n;
         clen.assign(lens, lens + n);
         cbase.resize(n);
@@ -853,8 +854,9 @@ struct KdEngine {
                 if ((rc = ensure(b_hkey, cap * 8)) || (rc = ensure(b_hcnt, cap * 4)) || (rc = ensure(b_hrep, cap * 4))) return rc;
                 if (rt.memset(b_hkey.p, 0, b_hkey.cap) || rt.memset(b_hcnt.p, 0, b_hcnt.cap)) return hipfail("finalize: memset hash");
             }
-            // the site test: per event in k_ins_insert, or -- more events than a quarter of the shard's sites -- once per site (k_ins_flag)
-            ins_site_flags = n_ev * 4 > (uint64_t)(alloc_hi - alloc_lo);
+            // the site test: per event in k_ins_insert (measured: +11 us per million events), or once per site by k_ins_flag (a dependent
+            // launch, ~10 us, + 4.4 us per million sites) where the events are many for the sites -- long reads: C5 has 10 M events on 1 M sites
+            ins_site_flags = knob_ins_site_flags >= 0 ? knob_ins_site_flags != 0 : n_ev > 1000000ULL + (uint64_t)(alloc_hi - alloc_lo) * 2 / 5;
             if ((rc = ensure(b_evslot, n_ev * 4)) || (ins_site_flags && (rc = ensure(b_flag, n_local)))) return rc;
             hash_cap = cap;
             H.key = (kd_u64 *)b_hkey.p; H.cnt = (uint32_t *)b_hcnt.p; H.rep = (uint32_t *)b_hrep.p;
@@ -1247,6 +1249,7 @@ struct KdEngine {
     bool step_in_capture = false;
     // fault-localisation knobs, read when the context is created (create())
     bool knob_step_trace = false, knob_replay_eager = false;
+    int knob_ins_site_flags = -1;     // KD_INS_SITE_FLAGS=0 / 1 (tests, measurement): the insertion reduction's site test per event / once per site, whatever the counts
     bool knob_cold_tail = false;      // KD_COLD_TAIL=1: the cold records' workgroups ride in k_window's launch (kd_window.h: KdColdTail) instead of k_cold_lane's own.
                                       // Measured (round 5): the step gains 1.6 % (C3) / 2.4 % (C4) -- the memory-bound cold work fills the launch's tail --, bit-exact; OFF by
                                       // default because the launch the roofline is measured on then carries k_cold_lane's 0.12 ms as well (k_window 0.93 -> 1.03 ms:

@@ -78,7 +78,7 @@ __device__ __forceinline__ kd_u64 kd_mix64(kd_u64 x) {
 // event, from the tables themselves (ten 4-byte loads for the event's site and the one behind it) -- k_ins_flag's pass over
 // every site of the shard (0.022 ms on C3 and a dependent launch: 0.03 ms of every step, a tenth of C2's) is gone, and this
 // kernel leaves the words a consensus run starts from (the collision counter, the per-contig depth ranges and output offsets).
-// With MORE events than a quarter of the sites (long reads: C5 has 10 M events on 1 M sites; measured 0.172 against 0.042 + 0.008 ms)
+// With many events for the sites (long reads: C5 has 10 M events on 1 M sites; measured 0.172 against 0.042 + 0.008 ms)
 // k_ins_flag tests every site once and the events look their site's byte up, as in rounds 2 - 4.  `first` = the first attempt of a reduction: decide and
 // record the decision in ev_slot; else (the re-seeded repeat after a hash collision) ev_slot holds KD_EV_TAKE / KD_EV_DROPPED.
 __device__ __forceinline__ bool kd_ins_site_emits(const KdTabs &T, kd_u64 g) {
@@ -96,7 +96,7 @@ __device__ __forceinline__ bool kd_ins_site_emits(const KdTabs &T, kd_u64 g) {
 }
 __global__ void __launch_bounds__(KD_BLOCK)
 k_ins_insert(KdIns ins, KdInsTab H, kd_u64 n_ev, KdTabs T, uint32_t first, kd_u64 *status, kd_u64 *contig_off, uint32_t *depth_minmax,
-             uint32_t n_contigs, const uint8_t *flag) {     // flag != NULL: k_ins_flag has tested the sites (a batch with more events than a quarter of its sites)
+             uint32_t n_contigs, const uint8_t *flag) {     // flag != NULL: k_ins_flag has tested the sites (a batch with many events for its sites: kd_engine.h)
     const kd_u64 e = (kd_u64)blockIdx.x * KD_BLOCK + threadIdx.x;
     if (first && !flag) {     // (what k_ins_flag leaves for the kernels behind it)
         if (e == 0) { status[KDS_INS_COLLISION] = 0ULL; }

@@ -595,3 +595,18 @@ def test_cold_records_riding_in_the_window_launch(emu_lib, monkeypatch):
         if exc and not key.startswith("__"):
             with pytest.raises(exc):
                 P.Run(emu_lib, P.sam_to_batch(QUIRKS[key]["sam"]), window=64)
+
+
+@pytest.mark.parametrize("site_flags", ["0", "1"])
+def test_insertion_site_test_per_event_and_per_site(emu_lib, monkeypatch, site_flags):
+    """The insertion reduction tests 'can this site emit an insertion at all' (kindel.py:411-412, :419) either per event inside
+    k_ins_insert (few events for the sites: short reads) or once per site in k_ins_flag (many: long reads); the engine picks by
+    the counts, KD_INS_SITE_FLAGS forces one: both against the oracle on batches with planted majority insertions, ties and a
+    second consensus run on the same tables (the run's words are left by whichever kernel made the test)."""
+    monkeypatch.setenv("KD_INS_SITE_FLAGS", site_flags)
+    batch = synth.to_numpy(synth.short_reads([9000, 2500], 60, seed=16, indel_p=0.3))
+    P.assert_matches_oracle(P.Run(emu_lib, batch))
+    P.assert_matches_oracle(P.Run(emu_lib, batch, min_depth=3), min_depth=3)
+    lb = synth.to_numpy(synth.long_reads([60000], 6, seed=3))
+    P.assert_matches_oracle(P.Run(emu_lib, lb))
+    _finish_vs_classic(emu_lib, batch)
