@@ -131,6 +131,8 @@ if os.path.exists(p) and os.path.getmtime(p) > newer_than:
     json.dump(first_json_line(p), open(os.path.join(P, "%s_c3_bench_shuffled_global_counters.json" % tag), "w"), indent=1, sort_keys=True)
 mr = {}
 for f in sorted(glob.glob(os.path.join(O, "multirank_*.clean.json"))):
+    if os.path.getmtime(f) < newer_than:      # (another round's leftovers)
+        continue
     d = json.load(open(f))
     mr[os.path.basename(f)[len("multirank_"):-len(".clean.json")]] = {k: d.get(k) for k in (
         "n_gpus", "scaling", "value", "ms_per_step", "fasta_sha256", "config", "other_scaling")}
