@@ -108,7 +108,9 @@ k_pileup_wave(KdReads rd, KdTabs T, KdIns ins, const uint32_t *list, kd_u64 n_li
                 const int64_t x = r - 1;
                 if (x > L || x < -(L + 1)) { if (lane == 0) kd_flag_error(T, status, c, gidx); return; }
                 const int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
-                if (n_adv > sl - q || (len > n_adv && q + n_adv >= sl) || (n_adv > 0 && r < -L)) {
+                // (the reference looks seq[q_pos] up in EVERY one of the op's `len` turns, also when r_pos has reached the contig's end --
+                // and in none when len is 0: a "0S" behind a query cursor that an insertion carried past the read's end is legal)
+                if (len > 0 && (n_adv > sl - q || (len > n_adv && q + n_adv >= sl) || (n_adv > 0 && r < -L))) {
                     if (lane == 0) kd_flag_error(T, status, c, gidx);
                     return;
                 }

@@ -109,6 +109,11 @@ CASES = {
     "ERR_order_first_contig_wins_KeyError": _mk(_HDR2, ("a", 0, "c2", 3, "4M", "ACGT"), ("b", 0, "c1", 28, "6M", "ACGTAC"),
                                                 ("c", 0, "c2", 3, "4M", "ACRT")),
     "ERR_order_within_contig_file_order": _mk(_HDR2, ("a", 0, "c1", 28, "6M", "ACGTAC"), ("b", 0, "c1", 3, "4M", "ACRT")),
+    # round 5 (found by a fuzz campaign): a non-first S of length 0 looks nothing up (kindel.py:77 loops over range(0)) -- also when an
+    # insertion has carried the query cursor past the read's end (an I only slices); with length >= 1 the same cursor is an IndexError
+    "zero_length_S_behind_an_overshooting_I": _mk(_HDR1, ("a", 0, "c1", 2, "6M9I0S", A10), ("b", 0, "c1", 2, "10M", A10)),
+    "zero_length_S_then_more_ops": _mk(_HDR1, ("a", 0, "c1", 2, "6M9I0S2D0S1P", A10), ("b", 0, "c1", 4, "8M", "ACGTACGT")),
+    "ERR_one_base_S_behind_an_overshooting_I": _mk(_HDR1, ("a", 0, "c1", 2, "6M9I1S", A10)),
 }
 
 #: option sets every non-error case is run with: (min_depth, trim_ends, uppercase)
