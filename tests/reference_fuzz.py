@@ -1,0 +1,100 @@
+"""TEST INFRASTRUCTURE: end-to-end differential fuzz against the UNMODIFIED reference (round 5).  Random SAM files -> the
+reference's bam_to_consensus (oracle/refrun.py: /root/reference, or its bytecode under oracle/_ref) vs
+kindel_amd.kindel.bam_to_consensus: record names, sequences, change lists, report text, or the exception type -- default and
+realign=True (the CDR path, a host port), several min_depth / min_overlap / clip_decay_threshold / mask_ends / trim / uppercase
+settings.  `python -m tests.reference_fuzz N SEED0` runs a local campaign on the kernel emulator (2 500 files ran clean in round 5);
+tests/test_reference_fuzz.py keeps a few dozen seeds in the CPU suite."""
+import os
+import random
+import tempfile
+
+
+def rand_sam(rng, n_contigs, realistic):
+    lens = [rng.randint(60, 400) for _ in range(n_contigs)]
+    refs = ["".join(rng.choice("ACGT") for _ in range(L)) for L in lens]
+    txt = "@HD\tVN:1.6\tSO:unsorted\n" + "".join("@SQ\tSN:c%d\tLN:%d\n" % (i, L) for i, L in enumerate(lens))
+    n_reads = rng.randint(5, 400)
+    hot = [(rng.randrange(n_contigs), rng.randint(10, 50)) for _ in range(3)]    # places where many reads clip (CDRs for realign)
+    for n in range(n_reads):
+        c = rng.randrange(n_contigs); L = lens[c]
+        rl = rng.randint(20, 90)
+        pos = rng.randint(0, max(0, L - rl))
+        ops = []; seq = []; r = pos; left = rl
+        if rng.random() < 0.35:      # leading clip
+            k = rng.randint(1, 25); ops.append("%dS" % k); seq.append("".join(rng.choice("ACGT") for _ in range(k)))
+        while left > 0 and r < L:
+            m = min(left, rng.randint(3, 40), L - r)
+            if m <= 0: break
+            s = list(refs[c][r:r + m])
+            for j in range(len(s)):
+                if rng.random() < 0.04: s[j] = rng.choice("ACGTN")
+            ops.append("%d%s" % (m, rng.choice("M=X") if not realistic else "M")); seq.append("".join(s)); r += m; left -= m
+            u = rng.random()
+            if u < 0.15 and r < L - 3:
+                k = rng.randint(1, 4); ops.append("%dI" % k); seq.append("".join(rng.choice("ACGT") for _ in range(k)))
+            elif u < 0.3 and r < L - 6:
+                k = rng.randint(1, 5); ops.append("%dD" % k); r += k
+            elif u < 0.33: ops.append("%dN" % rng.randint(1, 9))
+        if rng.random() < 0.35:      # trailing clip
+            k = rng.randint(1, 25); ops.append("%dS" % k); seq.append("".join(rng.choice("ACGT") for _ in range(k)))
+        s = "".join(seq)
+        if len(s) < 2: continue
+        flag = rng.choice([0, 16, 0, 0, 256, 2048, 4 if rng.random() < 0.3 else 0])
+        txt += "r%d\t%d\tc%d\t%d\t60\t%s\t*\t0\t0\t%s\t*\n" % (n, flag, c, pos + 1, "".join(ops), s)
+    return txt
+
+def outcome(fn, path, kw):
+    try:
+        res = fn(path, **kw)
+        return ("ok", [(c.name, c.sequence) for c in res.consensuses], {k: list(v) for k, v in res.refs_changes.items()}, dict(res.refs_reports))
+    except Exception as e:      # noqa: BLE001 -- the exception TYPE is what is compared
+        return ("raise", type(e).__name__)
+
+
+def settings(rng, seed):
+    return (dict(), dict(realign=True),
+            dict(realign=True, min_depth=2, min_overlap=rng.choice([5, 7, 9]), clip_decay_threshold=rng.choice([0.1, 0.2, 0.05]),
+                 mask_ends=rng.choice([0, 5, 50]), trim_ends=True, uppercase=True),
+            dict(min_depth=rng.choice([0, 2, 5]), trim_ends=bool(seed & 2), uppercase=bool(seed & 4)))
+
+
+def check_seed(R, K, seed, keep_dir=None):
+    """One random file through both implementations under four settings -> None, or a description of the first difference."""
+    rng = random.Random(seed)
+    txt = rand_sam(rng, rng.randint(1, 3), realistic=bool(seed & 1))
+    with tempfile.NamedTemporaryFile("w", suffix=".sam", delete=False) as fh:
+        fh.write(txt)
+        path = fh.name
+    try:
+        for kw in settings(rng, seed):
+            a, b = outcome(R.bam_to_consensus, path, kw), outcome(K.bam_to_consensus, path, kw)
+            if a != b:
+                if keep_dir:
+                    open(os.path.join(keep_dir, "reference_fuzz_fail_%d.sam" % seed), "w").write(txt)
+                what = "outcome"
+                if a[0] == "ok" and b[0] == "ok":
+                    what = "sequences" if a[1] != b[1] else "changes" if a[2] != b[2] else "report"
+                return "seed %d %r: %s differ (reference %s, kindel_amd %s)" % (seed, kw, what, a[0] if a[0] == "ok" else a, b[0] if b[0] == "ok" else b)
+    finally:
+        os.unlink(path)
+    return None
+
+
+if __name__ == "__main__":
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    from kindel_amd import _native as N
+    N._default = N.Library(g.build_emu())
+    from kindel_amd import kindel as K
+    from oracle import refrun
+    R = refrun.load_reference()
+    n, s0 = (int(sys.argv[1]) if len(sys.argv) > 1 else 300), (int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = 0
+    for seed in range(s0, s0 + n):
+        d = check_seed(R, K, seed, keep_dir=tempfile.gettempdir())
+        if d:
+            bad += 1
+            print("DIFF", d, flush=True)
+    print("reference fuzz done:", n, "files, differences:", bad, flush=True)

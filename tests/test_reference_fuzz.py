@@ -1,0 +1,22 @@
+"""The unmodified reference against kindel_amd on random SAM files, end to end (tests/reference_fuzz.py): default and --realign."""
+import pytest
+
+from oracle import refrun
+from tests import reference_fuzz as RF
+
+pytestmark = pytest.mark.skipif(not refrun.reference_available(), reason="the reference (or its bytecode, oracle/make_ref.py) is not on this box")
+
+
+def test_random_files_through_reference_and_emulated_engine(api_on_emu):
+    from kindel_amd import kindel as K
+    R = refrun.load_reference()
+    diffs = [d for d in (RF.check_seed(R, K, seed) for seed in range(400, 430)) if d]
+    assert not diffs, diffs
+
+
+@pytest.mark.gpu
+def test_random_files_through_reference_and_the_gpu(hip_lib):
+    from kindel_amd import kindel as K
+    R = refrun.load_reference()
+    diffs = [d for d in (RF.check_seed(R, K, seed) for seed in range(500, 540)) if d]
+    assert not diffs, diffs
