@@ -80,6 +80,80 @@ def check_seed(R, K, seed, keep_dir=None):
     return None
 
 
+def _df_diff(a, b):
+    import numpy as np
+    if list(a.columns) != list(b.columns) or len(a) != len(b):
+        return "shape / columns"
+    for c in a.columns:
+        x, y = a[c].to_numpy(), b[c].to_numpy()
+        if x.dtype.kind == "f" or y.dtype.kind == "f":
+            ok = np.allclose(x.astype(float), y.astype(float), rtol=0, atol=1e-12, equal_nan=True)     # (float columns: 1e-12 absolute)
+        elif x.dtype == object or y.dtype == object:
+            ok = (x.astype(str) == y.astype(str)).all()
+        else:
+            ok = np.array_equal(x, y)
+        if not ok:
+            return "column %s" % c
+    return None
+
+
+def check_api_seed(R, K, seed):
+    """The rest of the Python API on one random file: weights() (three option sets; integer columns exact, float columns to 1e-12),
+    features() (single-contig files: the reference's handles no more), parse_bam()'s alignment fields -> None or the first difference."""
+    import numpy as np
+    rng = random.Random(seed)
+    single = bool(seed % 3)
+    txt = rand_sam(rng, 1 if single else rng.randint(1, 3), realistic=bool(seed & 1))
+    with tempfile.NamedTemporaryFile("w", suffix=".sam", delete=False) as fh:
+        fh.write(txt)
+        path = fh.name
+
+    def both(name, *a, **kw):
+        out = []
+        for M in (R, K):
+            try:
+                out.append(("ok", getattr(M, name)(*a, **kw)))
+            except Exception as e:      # noqa: BLE001
+                out.append(("raise", type(e).__name__))
+        return out
+    try:
+        for kw in (dict(), dict(relative=True), dict(confidence=False)):
+            a, b = both("weights", path, **kw)
+            if a[0] != b[0] or (a[0] == "raise" and a != b):
+                return "seed %d weights %r: %s vs %s" % (seed, kw, a[:2] if a[0] == "raise" else "ok", b[:2] if b[0] == "raise" else "ok")
+            if a[0] == "ok":
+                d = _df_diff(a[1], b[1])
+                if d:
+                    return "seed %d weights %r: %s" % (seed, kw, d)
+        if single:
+            a, b = both("features", path)
+            if a[0] != b[0] or (a[0] == "raise" and a != b):
+                return "seed %d features: outcomes differ" % seed
+            if a[0] == "ok" and _df_diff(a[1], b[1]):
+                return "seed %d features: %s" % (seed, _df_diff(a[1], b[1]))
+        a, b = both("parse_bam", path)
+        if a[0] != b[0] or (a[0] == "raise" and a != b):
+            return "seed %d parse_bam: outcomes differ" % seed
+        if a[0] == "ok":
+            if list(a[1]) != list(b[1]):
+                return "seed %d parse_bam: contigs %r vs %r" % (seed, list(a[1]), list(b[1]))
+            for cid in a[1]:
+                x, y = a[1][cid], b[1][cid]
+                for f in x._fields:
+                    u, v = getattr(x, f), getattr(y, f)
+                    if f == "ref_id":
+                        same = u == v
+                    elif f in ("weights", "clip_start_weights", "clip_end_weights", "insertions"):
+                        same = [dict(d) for d in u] == [dict(d) for d in v]
+                    else:
+                        same = np.asarray(u).tolist() == np.asarray(v).tolist()
+                    if not same:
+                        return "seed %d parse_bam %s.%s differs" % (seed, cid, f)
+    finally:
+        os.unlink(path)
+    return None
+
+
 if __name__ == "__main__":
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -14,6 +14,18 @@ def test_random_files_through_reference_and_emulated_engine(api_on_emu):
     assert not diffs, diffs
 
 
+def test_weights_features_parse_bam_against_the_reference(api_on_emu):
+    """weights() incl. its float columns (no value assertions in the reference's own tests: pinned here by running it side by side),
+    features(), the alignment namedtuple of parse_bam() -- on random files."""
+    import warnings
+    from kindel_amd import kindel as K
+    R = refrun.load_reference()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        diffs = [d for d in (RF.check_api_seed(R, K, seed) for seed in range(600, 612)) if d]
+    assert not diffs, diffs
+
+
 @pytest.mark.gpu
 def test_random_files_through_reference_and_the_gpu(hip_lib):
     from kindel_amd import kindel as K
