@@ -43,6 +43,46 @@ def rand_sam(rng, n_contigs, realistic):
         txt += "r%d\t%d\tc%d\t%d\t60\t%s\t*\t0\t0\t%s\t*\n" % (n, flag, c, pos + 1, "".join(ops), s)
     return txt
 
+def wild_sam(rng):
+    nc = rng.randint(1, 3)
+    lens = [rng.randint(40, 120) for _ in range(nc)]
+    txt = "@HD\tVN:1.6\tSO:unsorted\n" + "".join("@SQ\tSN:c%d\tLN:%d\n" % (i, L) for i, L in enumerate(lens))
+    wildness = rng.choice([0.0, 0.0, 0.02, 0.1])
+    for n in range(rng.randint(1, 40)):
+        c = rng.randrange(nc); L = lens[c]
+        ops = []
+        for _ in range(rng.randint(1, 7)):
+            ops.append((rng.choice([0, 1, 1, 2, 3, 5, 8]), rng.choice("MMMMMIDSHNP=X")))
+        q = sum(l for l, o in ops if o in "MIS=X")
+        cigar = "".join("%d%s" % x for x in ops) if rng.random() > wildness * 0.3 else "*"
+        qlen = q if rng.random() > wildness else rng.randint(0, 30)
+        seq = "".join(rng.choice("ACGTNacgtRY=") if rng.random() < wildness * 0.3 else rng.choice("ACGT") for _ in range(qlen)) or "*"
+        pos = rng.randint(1, max(1, L - 30)) if rng.random() > wildness else rng.choice([0, 1, L, L + 1, L + 5, rng.randint(1, L)])
+        flag = rng.choice([0, 0, 0, 16, 4, 256, 2048])
+        rname = "c%d" % c if rng.random() > wildness * 0.3 else "*"
+        txt += "r%d\t%d\t%s\t%d\t60\t%s\t*\t0\t0\t%s\t*\n" % (n, flag, rname, pos, cigar, seq)
+    return txt
+
+
+def check_wild_seed(R, K, seed):
+    """One WILD file (ops of length 0, H / N / P anywhere, clips in the middle, POS 0 / at and behind the contig's end, SEQ shorter or
+    longer than the CIGAR, '*' CIGARs and RNAMEs, IUPAC and '=' bases) under three settings: the same result or the same exception type.
+    The one documented divergence is tolerated: an insertion with a letter outside the BAM alphabet is refused (OSError)."""
+    rng = random.Random(seed)
+    txt = wild_sam(rng)
+    with tempfile.NamedTemporaryFile("w", suffix=".sam", delete=False) as fh:
+        fh.write(txt)
+        path = fh.name
+    try:
+        for kw in (dict(), dict(min_depth=2, trim_ends=True), dict(realign=True, mask_ends=rng.choice([0, 3, 50]), min_overlap=rng.choice([3, 7]))):
+            a, b = outcome(R.bam_to_consensus, path, kw), outcome(K.bam_to_consensus, path, kw)
+            if a != b and not (b == ("raise", "OSError") and a[0] == "ok"):
+                return "seed %d %r: reference %s, kindel_amd %s" % (seed, kw, a if a[0] == "raise" else "ok", b if b[0] == "raise" else "ok")
+    finally:
+        os.unlink(path)
+    return None
+
+
 def outcome(fn, path, kw):
     try:
         res = fn(path, **kw)
