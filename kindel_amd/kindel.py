@@ -653,14 +653,13 @@ def bam_to_consensus_sharded(bam_path, rank, world, device="cpu", dev_index=0, g
                              clip_decay_threshold=0.1, mask_ends=50, trim_ends=False, uppercase=False, threads=0, lib=None):
     """bam_to_consensus (kindel.py:488-555) with the per-contig loop (:143-151, :501-551) spread over `world` ranks, one GPU
     each (kindel_amd/shard.py: sharded ingest, shard-local pileup, one all-gather).  Call on every rank of an initialised
-    torch.distributed group; every rank returns the same result tuple.  --realign needs whole-contig clip tables on one host
-    and is not distributed: use one GPU for it."""
+    torch.distributed group; every rank returns the same result tuple.  realign=True (round 5): the clip-dominant regions are
+    found on whole-contig tables summed over the shards (shard.realign_patches: one all-reduce per contig), every rank patches
+    its part."""
     from . import shard
-    if realign:
-        raise NotImplementedError("kindel_amd: realign=True is a single-GPU path (clip-dominant regions are found on whole-contig "
-                                  "tables); run without --gpus")
     out = shard.pileup_consensus_sharded(bam_path, rank, world, device=device, dev_index=dev_index, group=group, min_depth=min_depth,
-                                         threads=threads, lib=lib)
+                                         threads=threads, lib=lib,
+                                         realign=dict(min_overlap=min_overlap, clip_decay_threshold=clip_decay_threshold, mask_ends=mask_ends) if realign else None)
     consensuses, refs_changes, refs_reports = [], {}, {}
     for cid in out["order"]:
         ref_id = out["names"][cid]
@@ -671,7 +670,7 @@ def bam_to_consensus_sharded(bam_path, rank, world, device="cpu", dev_index=0, g
             seq = seq.upper()           # kindel.py:427-428
         ch = out["changes"][cid]
         consensuses.append(consensus_seqrecord(seq, ref_id))
-        refs_reports[ref_id] = _report(ref_id, out["minmax"][cid], ch, None, bam_path, realign, min_depth, min_overlap,
+        refs_reports[ref_id] = _report(ref_id, out["minmax"][cid], ch, (out.get("patches") or {}).get(cid), bam_path, realign, min_depth, min_overlap,
                                        clip_decay_threshold, trim_ends, uppercase)
         refs_changes[ref_id] = _changes_list(ch)
     result = namedtuple("result", ["consensuses", "refs_changes", "refs_reports"])

@@ -281,9 +281,10 @@ def gather(engine, interval, device, group=None, pad=None, intervals=None):
     raise RuntimeError("shard.gather: payload sizes changed between two gathers")
 
 
-def assemble(rows, contig_lens, world, interval=None, intervals=None):
+def assemble(rows, contig_lens, world, interval=None, intervals=None, with_parts=False):
     """Host side: per-rank payload rows (uint8 numpy [world, pad]) -> (seqs, changes, minmax) per contig.
-    intervals: the per-rank G-space intervals (default: partition(contig_lens, world))."""
+    intervals: the per-rank G-space intervals (default: partition(contig_lens, world)).
+    with_parts: a fourth result, part_lens[c][r] = bytes rank r contributed to contig c (realign splices its patches by them)."""
     lens = np.asarray(contig_lens, np.uint32)
     n = len(lens)
     base, S = g_layout(lens)
@@ -292,6 +293,7 @@ def assemble(rows, contig_lens, world, interval=None, intervals=None):
     else:   # every rank lays contigs out identically, so the equal-sites intervals are recomputable locally
         ivs = partition(lens, world) if world > 1 else [interval if interval is not None else (0, S)]
     seq_parts = [[] for _ in range(n)]
+    part_lens = [[0] * world for _ in range(n)]
     changes_g = np.zeros(S, np.uint8)
     mins = np.full(n, 0xFFFFFFFF, np.uint64)
     maxs = np.zeros(n, np.uint64)
@@ -309,20 +311,23 @@ def assemble(rows, contig_lens, world, interval=None, intervals=None):
         for c in range(n):
             if rcoff[c + 1] > rcoff[c]:
                 seq_parts[c].append(row[o + int(rcoff[c]): o + int(rcoff[c + 1])].tobytes())
+                part_lens[c][r] = int(rcoff[c + 1]) - int(rcoff[c])
         mins = np.minimum(mins, rmm[:, 0])
         maxs = np.maximum(maxs, rmm[:, 1])
     seqs = [b"".join(p) for p in seq_parts]
     changes = [changes_g[int(base[c]): int(base[c]) + int(lens[c])] for c in range(n)]
     minmax = [(int(mins[c]), int(maxs[c])) for c in range(n)]
+    if with_parts:
+        return seqs, changes, minmax, part_lens
     return seqs, changes, minmax
 
 
-def stitch(engine, interval, device, group=None, intervals=None, pad=None):
-    """gather() + host assembly: -> (seqs, changes, minmax), identical on every rank.
+def stitch(engine, interval, device, group=None, intervals=None, pad=None, with_parts=False):
+    """gather() + host assembly: -> (seqs, changes, minmax[, part_lens]), identical on every rank.
     seqs[c] = bytes of contig c's consensus, changes[c] = uint8[L_c], minmax[c] = (min, max) ACGT depth."""
     gathered, world = gather(engine, interval, device, group, pad=pad, intervals=intervals)
     rows = np.ascontiguousarray(gathered.cpu().numpy())
-    return assemble(rows, engine.contig_lens, world, interval, intervals=intervals)
+    return assemble(rows, engine.contig_lens, world, interval, intervals=intervals, with_parts=with_parts)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -505,10 +510,55 @@ def ingest_sharded(path, rank, world, device="cpu", group=None, threads=0, lib=N
                 mode="sharded", stats=dict(decoded_records=n, neighbour_records=extra, blocks=(blocks[rank], blocks[rank + 1])))
 
 
-def pileup_consensus_sharded(path, rank, world, device="cpu", dev_index=0, group=None, min_depth=1, threads=0, lib=None):
-    """ingest_sharded + shard-local pileup + consensus + stitch.  -> dict(seqs, changes, minmax, names, lens, order, mode, stats),
-    identical on every rank.  A reference exception raised by any rank's reads (KeyError / IndexError / RuntimeError,
-    kindel.py:47-81) is agreed on by all ranks and raised everywhere."""
+def _full_tables(eng, cid, interval, device, group, world, channels=None):
+    """Contig cid's tables over ALL shards.  A context commits the sites of its interval [g_lo, g_hi) AND the halo site g_hi (the
+    consensus of site g_hi - 1 looks one site ahead), which the next rank commits too: each rank keeps the columns of its own
+    interval only, then the sum over the ranks is the whole contig's table.  One all-reduce (counts as int64: a sum of uint32)."""
+    import torch
+    import torch.distributed as dist
+    t = eng.tables(cid, channels)
+    if world == 1:
+        return t
+    b = eng.contig_base(cid)
+    lo, hi = max(0, min(t.shape[1], int(interval[0]) - b)), max(0, min(t.shape[1], int(interval[1]) - b))
+    t[:, :lo] = 0
+    t[:, hi:] = 0
+    x = torch.from_numpy(t.astype(np.int64)).to(device)
+    dist.all_reduce(x, group=group)
+    return x.cpu().numpy().astype(np.uint32)
+
+
+def realign_patches(eng, order, lens, interval, device, group, world, min_overlap, clip_decay_threshold, mask_ends, keep=None):
+    """--realign across ranks (round 5; kindel.py:502-513): the clip-dominant regions of a contig are found on its WHOLE tables, so
+    every rank sums the shards' tables (_full_tables: one all-reduce per contig that has records) and runs the same host scans on
+    the same numbers -- identical patches everywhere, no broadcast.  -> {cid: merged patches (kindel.merge_cdrps)}
+    (This is the one place a table crosses the links: 16 channels x 8 bytes per site, off by default like --realign itself, and
+    small beside the host scans it feeds -- the reference's own Python loops over every site.)"""
+    from . import _native as N
+    from . import kindel as K
+    patches = {}
+    for cid in order:
+        t = _full_tables(eng, cid, interval, device, group, world)
+        if keep is not None:
+            keep[cid] = t
+        L = int(lens[cid])
+        W = np.ascontiguousarray(t[0:5, :L].T)
+        S = np.ascontiguousarray(t[N.KD_CH_CSW:N.KD_CH_CSW + 5, :L].T)
+        E = np.ascontiguousarray(t[N.KD_CH_CEW:N.KD_CH_CEW + 5, :L].T)
+        csd = (S[:, 0] + S[:, 1] + S[:, 2] + S[:, 3]).astype(np.int64).tolist()      # A,T,G,C without N (kindel.py:90-95)
+        ced = (E[:, 0] + E[:, 1] + E[:, 2] + E[:, 3]).astype(np.int64).tolist()
+        cdrps = K.cdrp_consensuses(K.SiteDicts(W), t[N.KD_CH_DEL].astype(np.int64).tolist(), K.SiteDicts(S), K.SiteDicts(E), csd, ced,
+                                   clip_decay_threshold, mask_ends)
+        patches[cid] = K.merge_cdrps(cdrps, min_overlap)
+    return patches
+
+
+def pileup_consensus_sharded(path, rank, world, device="cpu", dev_index=0, group=None, min_depth=1, threads=0, lib=None, realign=None):
+    """ingest_sharded + shard-local pileup + consensus + stitch.  -> dict(seqs, changes, minmax, names, lens, order, mode, stats
+    [, patches]), identical on every rank.  A reference exception raised by any rank's reads (KeyError / IndexError / RuntimeError,
+    kindel.py:47-81) is agreed on by all ranks and raised everywhere.
+    realign: None, or dict(min_overlap, clip_decay_threshold, mask_ends): clip-dominant regions are patched (realign_patches); every
+    rank's consensus run skips the patched sites of its shard and the patch texts are spliced into the stitched contigs."""
     import torch
     import torch.distributed as dist
     from . import _native as N
@@ -534,10 +584,55 @@ def pileup_consensus_sharded(path, rank, world, device="cpu", dev_index=0, group
         first_err = next((e for e in errs if e), None)
         if first_err:     # (the lowest rank's = the earliest position's, for a sorted file the reference's own choice)
             raise {"KeyError": KeyError, "IndexError": IndexError, "MemoryError": MemoryError, "OSError": OSError}.get(first_err[0], RuntimeError)(first_err[1])
-        eng.consensus_run(min_depth)
-        seqs, changes, minmax = stitch(eng, ing["interval"], device, group, intervals=ing["intervals"])
+        patches = None
+        if realign is None:
+            eng.consensus_run(min_depth)
+            seqs, changes, minmax = stitch(eng, ing["interval"], device, group, intervals=ing["intervals"])
+        else:
+            from . import kindel as K
+            kept = {} if realign.get("keep_tables") else None
+            patches = realign_patches(eng, ing["order"], ing["lens"], ing["interval"], device, group, world, realign["min_overlap"],
+                                      realign["clip_decay_threshold"], realign["mask_ends"], keep=kept)
+            plans = {cid: K._patch_plan(int(ing["lens"][cid]), patches.get(cid)) for cid in ing["order"]}
+            flat, owner = [], []
+            for cid in ing["order"]:
+                b = eng.contig_base(cid)
+                for s_, e_, _ in plans[cid]:
+                    flat.append((b + s_, b + e_)); owner.append(cid)
+            eng.consensus_run(min_depth, flat)
+            seqs, changes, minmax, part_lens = stitch(eng, ing["interval"], device, group, intervals=ing["intervals"], with_parts=True)
+            if flat:
+                # where a patch's text goes: the offset its OWNER (the rank whose interval holds the patch's first site) recorded,
+                # relative to its part of the contig, behind the parts of the ranks in front
+                local = np.full(len(flat), -1, np.int64)
+                for cid in set(owner):
+                    po = eng.consensus_meta(cid)[2]
+                    for k, c in enumerate(owner):
+                        if c == cid and po[k] != np.uint64(0xFFFFFFFFFFFFFFFF):
+                            local[k] = int(po[k])
+                if world > 1:
+                    x = torch.from_numpy(local).to(device)
+                    allx = torch.empty(world * len(flat), dtype=torch.int64, device=device)
+                    dist.all_gather_into_tensor(allx, x, group=group)
+                    local_all = allx.cpu().numpy().reshape(world, len(flat))
+                else:
+                    local_all = local.reshape(1, -1)
+                ivs = ing["intervals"]
+                seqs = list(seqs)
+                for cid in set(owner):
+                    raw, parts, prev = seqs[cid], [], 0
+                    ks = [k for k, c in enumerate(owner) if c == cid]
+                    for (s_, e_, text), k in zip(plans[cid], ks):
+                        g = flat[k][0]
+                        r = next(r for r in range(world) if ivs[r][0] <= g < ivs[r][1])
+                        if local_all[r][k] < 0:
+                            raise RuntimeError("realign across ranks: rank %d did not record the offset of the patch at site %d" % (r, g))
+                        o = sum(part_lens[cid][:r]) + int(local_all[r][k])
+                        parts.append(raw[prev:o]); parts.append(text.encode()); prev = o
+                    parts.append(raw[prev:])
+                    seqs[cid] = b"".join(parts)
     finally:
         if eng is not None:
             eng.close()
     return dict(seqs=seqs, changes=changes, minmax=minmax, names=ing["names"], lens=ing["lens"], order=ing["order"], mode=ing["mode"],
-                stats=ing["stats"])
+                stats=ing["stats"], patches=patches, tables=kept if realign else None)

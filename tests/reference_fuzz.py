@@ -43,6 +43,73 @@ def rand_sam(rng, n_contigs, realistic):
         txt += "r%d\t%d\tc%d\t%d\t60\t%s\t*\t0\t0\t%s\t*\n" % (n, flag, c, pos + 1, "".join(ops), s)
     return txt
 
+def structured_sam(rng, n_contigs=None, sort=True):
+    """Files on which --realign DOES something: each contig's sample carries one to three novel segments (an insertion or a
+    replacement of 0 - 60 reference bases by 15 - 90 new ones); reads tile the SAMPLE, and a read across a junction is aligned by
+    its larger flank with the rest soft-clipped, as a local aligner reports it -- clip-dominant regions with overlapping
+    clip consensuses from both sides (kindel.py:283-478)."""
+    n_contigs = n_contigs or rng.randint(1, 3)
+    txt_sq, recs = "", []
+    for c in range(n_contigs):
+        L = rng.randint(600, 5000)
+        ref = "".join(rng.choice("ACGT") for _ in range(L))
+        txt_sq += "@SQ\tSN:c%d\tLN:%d\n" % (c, L)
+        # sample = list of (sample_start, length, ref_start or None)
+        cuts = sorted(rng.sample(range(150, L - 150), rng.randint(1, 3)))
+        cuts = [p for i, p in enumerate(cuts) if i == 0 or p - cuts[i - 1] > 250]
+        segs, sample, r = [], [], 0
+        for p in cuts:
+            segs.append((len(sample), p - r, r)); sample.extend(ref[r:p])
+            m = rng.randint(15, 90)
+            segs.append((len(sample), m, None)); sample.extend(rng.choice("ACGT") for _ in range(m))
+            r = p + rng.choice([0, 0, rng.randint(1, 60)])
+        segs.append((len(sample), L - r, r)); sample.extend(ref[r:])
+        sample = "".join(sample)
+        depth, rl = rng.randint(8, 40), rng.randint(60, 150)
+        n_reads = max(5, len(sample) * depth // rl)
+        for n in range(n_reads):
+            a = rng.randint(0, max(0, len(sample) - rl)); b = min(len(sample), a + rl)
+            parts = []          # (length, ref_start or None) of the read's pieces
+            for s0, ln, rs in segs:
+                lo, hi = max(a, s0), min(b, s0 + ln)
+                if lo < hi:
+                    parts.append((hi - lo, None if rs is None else rs + lo - s0))
+            best = max((k for k in range(len(parts)) if parts[k][1] is not None), key=lambda k: parts[k][0], default=None)
+            if best is None or parts[best][0] < 12:
+                continue
+            lead = sum(x for x, _ in parts[:best]); trail = sum(x for x, _ in parts[best + 1:])
+            seq = list(sample[a:b])
+            for j in range(len(seq)):
+                if rng.random() < 0.01: seq[j] = rng.choice("ACGT")
+            cigar = ("%dS" % lead if lead else "") + "%dM" % parts[best][0] + ("%dS" % trail if trail else "")
+            recs.append((c, parts[best][1], "r%d_%d\t0\tc%d\t%d\t60\t%s\t*\t0\t0\t%s\t*\n" % (c, n, c, parts[best][1] + 1, cigar, "".join(seq))))
+    if sort:
+        recs.sort(key=lambda t: (t[0], t[1]))
+    else:
+        rng.shuffle(recs)
+    return "@HD\tVN:1.6\tSO:%s\n" % ("coordinate" if sort else "unsorted") + txt_sq + "".join(t[2] for t in recs)
+
+
+def check_structured_seed(R, K, seed):
+    """structured_sam through the reference and kindel_amd with realign=True (and the default) -> None or the first difference;
+    also says whether realign changed the sequence (so a campaign can count the files that exercised the patches)."""
+    rng = random.Random(seed)
+    txt = structured_sam(rng, sort=bool(seed % 3))
+    with tempfile.NamedTemporaryFile("w", suffix=".sam", delete=False) as fh:
+        fh.write(txt)
+        path = fh.name
+    try:
+        outs = []
+        for kw in (dict(), dict(realign=True), dict(realign=True, min_overlap=rng.choice([5, 9, 12]), clip_decay_threshold=rng.choice([0.1, 0.05]), mask_ends=rng.choice([0, 50]))):
+            a, b = outcome(R.bam_to_consensus, path, kw), outcome(K.bam_to_consensus, path, kw)
+            if a != b:
+                return "seed %d %r: differ (reference %s, kindel_amd %s)" % (seed, kw, a[0] if a[0] == "ok" else a, b[0] if b[0] == "ok" else b), False
+            outs.append(a)
+        return None, outs[0][0] == "ok" and outs[1][0] == "ok" and outs[0][1] != outs[1][1]
+    finally:
+        os.unlink(path)
+
+
 def wild_sam(rng):
     nc = rng.randint(1, 3)
     lens = [rng.randint(40, 120) for _ in range(nc)]
@@ -206,6 +273,18 @@ if __name__ == "__main__":
     R = refrun.load_reference()
     n, s0 = (int(sys.argv[1]) if len(sys.argv) > 1 else 300), (int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     bad = 0
+    if len(sys.argv) > 3 and sys.argv[3] == "structured":
+        import logging
+        logging.disable(logging.WARNING)
+        patched = 0
+        for seed in range(s0, s0 + n):
+            d, did = check_structured_seed(R, K, seed)
+            patched += bool(did)
+            if d:
+                bad += 1
+                print("DIFF", d, flush=True)
+        print("structured reference fuzz done:", n, "files,", patched, "changed by realign, differences:", bad, flush=True)
+        sys.exit(0)
     for seed in range(s0, s0 + n):
         d = check_seed(R, K, seed, keep_dir=tempfile.gettempdir())
         if d:

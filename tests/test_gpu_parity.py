@@ -429,6 +429,27 @@ def test_cli_two_ranks_on_one_gpu(hip_lib, tmp_path):
     assert one.stderr.strip() and one.stderr.strip() in two.stderr     # the same report (the CLI's own defaults, e.g. min_overlap 7)
 
 
+def test_cli_two_ranks_realign_on_one_gpu(hip_lib, tmp_path):
+    """`kindel consensus --realign --gpus 2` on the real library (round 5): the shards' tables summed over the two ranks, the same
+    clip-dominant regions found by both, each patching its part -- stdout is the FASTA the unmodified reference wrote with
+    realign=True (a fixture whose consensus realign changes), the report on stderr lists the region."""
+    key = "bwa_mem__1.1.sub_test"
+    g = GOLD[key]["contigs"][0]
+    assert g["realign_consensus"] != g["consensus"]
+    path = str(tmp_path / "x.bam")
+    synth.write_bam(path, P.load_fixture(key), sort_order="unknown", block_bytes=3000)
+    env = dict(os.environ, KINDEL_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    two = subprocess.run([sys.executable, "-m", "kindel_amd", "consensus", "--realign", "--gpus", "2", path], capture_output=True, text=True,
+                         timeout=900, env=env, cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-2000:]
+    out = two.stdout[two.stdout.index(">"):] if ">" in two.stdout else two.stdout
+    assert out == ">%s_cns\n%s\n" % (g["name"], g["realign_consensus"])
+    region = [l for l in g["realign_report"].split("\n") if l.startswith("- clip-dominant regions")][0]
+    assert region.split(": ", 1)[1] and region in two.stderr
+
+
 def test_bench_two_ranks_on_one_gpu_same_fasta():
     """bench.py's N > 1 product path on hardware as far as one GPU allows: `bench.py --gpus 2` under torch.distributed.run (the
     driver's launch line, gloo instead of RCCL because both ranks share the GPU) -- one input cut into two work-balanced position

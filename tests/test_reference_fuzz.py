@@ -14,6 +14,21 @@ def test_random_files_through_reference_and_emulated_engine(api_on_emu):
     assert not diffs, diffs
 
 
+def test_files_with_clip_dominant_regions_through_realign(api_on_emu):
+    """reference_fuzz.structured_sam: novel segments in the sample, reads soft-clipped at the junctions -- files on which --realign
+    patches something (the random files above rarely do).  Default and two realign settings, reference vs kindel_amd."""
+    import logging
+    from kindel_amd import kindel as K
+    R = refrun.load_reference()
+    logging.disable(logging.WARNING)
+    try:
+        res = [RF.check_structured_seed(R, K, seed) for seed in range(2000, 2012)]
+    finally:
+        logging.disable(logging.NOTSET)
+    assert not [d for d, _ in res if d], [d for d, _ in res if d]
+    assert sum(bool(did) for _, did in res) >= 5      # realign changed the consensus of these files
+
+
 def test_wild_files_same_result_or_same_exception(api_on_emu):
     """6 000 such files ran clean as a local campaign (round 5); these seeds stay."""
     from kindel_amd import kindel as K

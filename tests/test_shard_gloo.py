@@ -215,7 +215,7 @@ def test_two_rank_stitch_matches_oracle(emu_lib):
             assert minmax[cid] == oa.depth_minmax()
 
 
-def _worker_file(rank, world, port, emu_path, path, q):
+def _worker_file(rank, world, port, emu_path, path, q, kw=None):
     """The product's multi-GPU entry on CPU: every rank decodes its share of ONE file (gloo, emulated kernels)."""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -228,7 +228,7 @@ def _worker_file(rank, world, port, emu_path, path, q):
     N._default = lib
     out = shard.pileup_consensus_sharded(path, rank, world, device="cpu", lib=lib)
     try:
-        res = K.bam_to_consensus_sharded(path, rank, world, device="cpu", lib=lib)
+        res = K.bam_to_consensus_sharded(path, rank, world, device="cpu", lib=lib, **(kw or {}))
         res = ([(c.name, c.sequence) for c in res.consensuses], res.refs_reports, {k: "".join("." if c is None else c for c in v) for k, v in res.refs_changes.items()})
     except Exception as e:       # noqa: BLE001 -- handed to the parent
         res = repr(e)
@@ -237,11 +237,11 @@ def _worker_file(rank, world, port, emu_path, path, q):
     dist.destroy_process_group()
 
 
-def _run_file_ranks(emu_lib, path, world):
+def _run_file_ranks(emu_lib, path, world, kw=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_file, args=(r, world, port, emu_lib.path, path, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_file, args=(r, world, port, emu_lib.path, path, q, kw)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted(q.get(timeout=900) for _ in range(world))
@@ -281,6 +281,82 @@ def test_one_file_across_ranks_matches_the_reference_golden(emu_lib, tmp_path, k
         for g in gold:
             assert reports[g["name"]] == g["report"].replace("{bam_path}", path)
             assert changes[g["name"]] == g["changes"]
+
+
+@pytest.mark.parametrize("key,world,block_bytes", [
+    ("bwa_mem__1.1.sub_test", 2, 900),
+    ("bwa_mem__1.1.sub_test", 5, 400),                   # cuts inside and next to the clip-dominant regions
+    ("segemehl__2.1.sub_test", 3, 1500),
+    ("ext__1.issue23.debug", 4, 700),                    # the reference's --realign regression fixture (issue 23)
+    ("minimap2__hxb2-gp120-mutated", 2, 1200),           # unsorted: whole-file fallback, then the same realign
+    ("minimap2__1.1.multi", 3, 800),                     # three contigs
+])
+def test_realign_across_ranks_matches_the_reference_golden(emu_lib, tmp_path, key, world, block_bytes):
+    """`kindel consensus --realign --gpus N` (round 5): the clip tables of the shards are summed (one all-reduce per contig), every rank
+    finds the same clip-dominant regions and patches its part -- the consensus and the report (with its region list) equal what
+    the unmodified reference printed for the fixture with realign=True, on every rank."""
+    from kindel_amd import synth
+    from tests import parity as P
+    gold = [g for g in P.golden_outputs()[key]["contigs"] if "realign_consensus" in g]
+    assert gold
+    path = str(tmp_path / (key + ".bam"))
+    synth.write_bam(path, P.load_fixture(key), sort_order="unknown", block_bytes=block_bytes)
+    results = _run_file_ranks(emu_lib, path, world, dict(realign=True, min_overlap=7))
+    for rank, mode, stats, order, res in results:
+        assert not isinstance(res, str), res
+        recs, reports, changes = res
+        seqs = dict(recs)
+        for g in gold:
+            assert seqs[g["name"] + "_cns"] == g["realign_consensus"], (rank, g["name"])
+            assert reports[g["name"]] == g["realign_report"].replace("{bam_path}", path)
+
+
+def _worker_tables(rank, world, port, emu_path, path, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kindel_amd import _native as N
+    from kindel_amd import shard
+    lib = N.Library(emu_path)
+    N._default = lib
+    out = shard.pileup_consensus_sharded(path, rank, world, device="cpu", lib=lib,
+                                         realign=dict(min_overlap=7, clip_decay_threshold=0.1, mask_ends=50, keep_tables=True))
+    q.put((rank, {c: t.tobytes() for c, t in out["tables"].items()}, out["intervals"] if "intervals" in out else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_tables_summed_over_the_shards_equal_the_whole_file_tables(emu_lib, tmp_path, world):
+    """What --realign across ranks scans (shard._full_tables): every channel of every contig, summed over the ranks' own columns,
+    equals the single-process tables -- also at the cut sites, which two neighbouring contexts both commit (the halo site)."""
+    from kindel_amd import synth, _native as N
+    from kindel_amd import kindel as K
+    batch = synth.to_numpy(synth.short_reads([3000, 1500, 2200], 25, seed=77, clip_p=0.5))
+    path = str(tmp_path / "t.bam")
+    synth.write_bam(path, batch, sort_order="coordinate", block_bytes=900)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_tables, args=(r, world, port, emu_lib.path, path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    N._default = emu_lib
+    pl = K.pileup_file(path)
+    try:
+        for rank, tabs, _ in results:
+            assert sorted(tabs) == sorted(pl.order)
+            for cid in pl.order:
+                want = pl.engine.tables(cid)
+                got = np.frombuffer(tabs[cid], np.uint32).reshape(want.shape)
+                assert np.array_equal(got, want), (rank, cid, np.argwhere(got != want)[:5])
+    finally:
+        pl.engine.close()
 
 
 def test_one_file_across_ranks_synthetic_multi_contig(emu_lib, tmp_path):
@@ -407,3 +483,17 @@ def test_random_files_across_three_ranks_equal_the_single_process_result(emu_lib
     from tests import shard_fuzz
     files, diffs = shard_fuzz.run_campaign(25, 90000, 3, emu_lib.path)
     assert len(files) >= 20 and not diffs, diffs
+
+
+def test_files_with_clip_dominant_regions_realigned_across_four_ranks(emu_lib):
+    """--realign across ranks on files that HAVE clip-dominant regions (reference_fuzz.structured_sam; tiny BGZF blocks, sorted and
+    unsorted): every rank's sequences, change codes and reports (with the region lists) equal the single-process realign run's --
+    which tests/test_reference_fuzz.py holds against the unmodified reference on files of the same generator."""
+    import logging
+    from tests import shard_fuzz
+    logging.disable(logging.WARNING)
+    try:
+        files, diffs = shard_fuzz.run_campaign(12, 95000, 4, emu_lib.path, kw=dict(realign=True, min_overlap=7), structured=True)
+    finally:
+        logging.disable(logging.NOTSET)
+    assert len(files) == 12 and not diffs, diffs
