@@ -538,7 +538,8 @@ def realign_patches(eng, order, lens, interval, device, group, world, min_overla
     from . import kindel as K
     patches = {}
     for cid in order:
-        t = _full_tables(eng, cid, interval, device, group, world)
+        t = _full_tables(eng, cid, interval, device, group, world,
+                         channels=np.arange(N.KD_CH_CLIP_STARTS, dtype=np.uint32))    # weights, deletions, clip start / end weights: what the scans read
         if keep is not None:
             keep[cid] = t
         L = int(lens[cid])

@@ -352,7 +352,7 @@ def test_tables_summed_over_the_shards_equal_the_whole_file_tables(emu_lib, tmp_
         for rank, tabs, _ in results:
             assert sorted(tabs) == sorted(pl.order)
             for cid in pl.order:
-                want = pl.engine.tables(cid)
+                want = pl.engine.tables(cid)[:N.KD_CH_CLIP_STARTS]      # the 16 channels the CDR scans read
                 got = np.frombuffer(tabs[cid], np.uint32).reshape(want.shape)
                 assert np.array_equal(got, want), (rank, cid, np.argwhere(got != want)[:5])
     finally:
