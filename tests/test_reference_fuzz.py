@@ -55,3 +55,18 @@ def test_random_files_through_reference_and_the_gpu(hip_lib):
     R = refrun.load_reference()
     diffs = [d for d in (RF.check_seed(R, K, seed) for seed in range(500, 540)) if d]
     assert not diffs, diffs
+
+
+@pytest.mark.gpu
+def test_files_with_clip_dominant_regions_through_realign_on_the_gpu(hip_lib):
+    """The structured files (clip-dominant regions that realign patches) through the reference and the HIP path."""
+    import logging
+    from kindel_amd import kindel as K
+    R = refrun.load_reference()
+    logging.disable(logging.WARNING)
+    try:
+        res = [RF.check_structured_seed(R, K, seed) for seed in range(2100, 2110)]
+    finally:
+        logging.disable(logging.NOTSET)
+    assert not [d for d, _ in res if d], [d for d, _ in res if d]
+    assert sum(bool(did) for _, did in res) >= 4
