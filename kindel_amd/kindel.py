@@ -627,16 +627,21 @@ def bam_to_consensus(bam_path, realign=False, min_depth=1, min_overlap=9, clip_d
     """bam_to_consensus of kindel.py:488-555: same arguments, same result tuple."""
     consensuses, refs_changes, refs_reports = [], {}, {}
     pl = pileup_file(bam_path)
-    patches = {}
-    for cid in pl.order:
-        if realign:
-            aln = pl.alignment(cid)
-            cdrps = cdrp_consensuses(aln.weights, aln.deletions, aln.clip_start_weights, aln.clip_end_weights,
-                                     aln.clip_start_depth, aln.clip_end_depth, clip_decay_threshold, mask_ends)
-            patches[cid] = merge_cdrps(cdrps, min_overlap)
-        else:
-            patches[cid] = None
-    done = _device_consensus_all(pl, patches, trim_ends, min_depth, uppercase)
+    try:
+        patches = {}
+        for cid in pl.order:
+            if realign:
+                aln = pl.alignment(cid)
+                cdrps = cdrp_consensuses(aln.weights, aln.deletions, aln.clip_start_weights, aln.clip_end_weights,
+                                         aln.clip_start_depth, aln.clip_end_depth, clip_decay_threshold, mask_ends)
+                patches[cid] = merge_cdrps(cdrps, min_overlap)
+            else:
+                patches[cid] = None
+        done = _device_consensus_all(pl, patches, trim_ends, min_depth, uppercase)
+    finally:
+        # everything below is host data.  With realign the alignment objects refer back to the Pileup (a cycle): without this the
+        # context -- tables, stream, pinned buffers -- would live until Python's cycle collector happens to run
+        pl.engine.close()
     for cid in pl.order:
         ref_id = pl.names[cid]
         seq, ch, mm = done[cid]

@@ -44,7 +44,8 @@ def emu_lib():
     """TEST INFRASTRUCTURE: the C-ABI compiled against the CPU kernel emulator (tests/emu)."""
     import __graft_entry__ as g
     from kindel_amd import _native as N
-    return N.Library(g.build_emu())
+    # KD_EMU_LIB: another build of the same emulator library (scripts/exp/asan_emu.sh: AddressSanitizer + garbage-filled allocations)
+    return N.Library(os.environ.get("KD_EMU_LIB") or g.build_emu())
 
 
 @pytest.fixture(scope="session")

@@ -16,7 +16,7 @@ struct EmuRt {
     const char *err() const { return e.c_str(); }
     int init(int, void *) { return 0; }
     void shutdown() {}
-    int n_cus() const { return 2; }
+    int n_cus() const { if (const char *e = getenv("KD_EMU_CUS")) return std::max(1, atoi(e)); return 2; }   // (256 = the launch geometry of an MI355X: idle workgroups, long grids)
     size_t free_bytes() { if (const char *e = getenv("KD_EMU_FREE_BYTES")) return (size_t)strtoull(e, nullptr, 10); return (size_t)1 << 40; }
     void *alloc(size_t bytes) { return aligned_alloc(256, (bytes + 255) & ~size_t(255)); }
     void free(void *p) { ::free(p); }

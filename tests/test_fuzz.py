@@ -77,6 +77,18 @@ def test_fuzz_mixed_shapes_at_depth_emulated(emu_lib):
     _mixed_campaign(emu_lib, range(900, 935), [(700, 1500), (1500, 4000), (4000, 9000), (9000, 300), (20000, 4000)])
 
 
+def test_fuzz_with_the_launch_geometry_of_the_gpu_emulated(emu_lib, monkeypatch):
+    """The emulator sizes its grids for 2 CUs by default; an MI355X launches persistent kernels with 256 x k workgroups, most of them
+    idle on small inputs (k_window: 1280 workgroups for a 600-site contig) -- KD_EMU_CUS=256 gives the emulator that geometry
+    (round 5, after a fault on hardware that no emulated run showed): the same campaigns, fewer seeds."""
+    monkeypatch.setenv("KD_EMU_CUS", "256")
+    out = _campaign(emu_lib, range(100, 104), n_reads=60, wild=0.0)
+    assert out["ok"] >= 3
+    out = _campaign(emu_lib, range(200, 204), n_reads=12, wild=0.3)
+    assert out["ok"] + out["raise"] == 16
+    _mixed_campaign(emu_lib, range(900, 907), [(700, 1500), (1500, 4000), (4000, 9000), (9000, 300), (20000, 4000)])
+
+
 @pytest.mark.gpu
 def test_fuzz_mixed_shapes_at_depth_gpu(hip_lib):
     _mixed_campaign(hip_lib, range(900, 914), [(700, 6000), (4000, 30000), (60000, 20000), (300000, 40000)])
