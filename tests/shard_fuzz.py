@@ -1,5 +1,5 @@
-"""TEST INFRASTRUCTURE (round 5).  `python -m tests.shard_fuzz N SEED0 WORLD`: a local campaign -- 1 500 files over 2, 3, 4, 5 and 8 ranks ran
-clean; tests/test_shard_gloo.py keeps 25 files on three ranks.  The N-rank one-file entry (bam_to_consensus_sharded over gloo, emulated kernels) on random BAM files with tiny
+"""TEST INFRASTRUCTURE (round 5).  `python -m tests.shard_fuzz N SEED0 WORLD [realign MIN_OVERLAP]`: a local campaign -- 1 500 files over 2, 3, 4, 5 and 8 ranks ran
+clean, and 1 510 files with clip-dominant regions under --realign over 2 - 8 ranks; tests/test_shard_gloo.py keeps 25 files on three ranks.  The N-rank one-file entry (bam_to_consensus_sharded over gloo, emulated kernels) on random BAM files with tiny
 BGZF blocks against the single-process result of the same file -- sorted files (rank-sharded ingest, neighbour decodes, cuts) and
 unsorted ones (whole-file fallback)."""
 import os, sys, random, tempfile
