@@ -65,10 +65,7 @@ def main():
                          "are permuted, every read's bases / CIGAR stay where the sorted batch had them (rounds 1 - 2; a layout no file produces)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=0.0, help="fraction of reads for the CPU baseline (0 = auto)")
-    ap.add_argument("--graph", dest="graph", action="store_true", default=False,
-                    help="also time K steps through kd_step's opt-in hipGraph replay of the same resident batch (`replay_ms_per_step`; never `value`). "
-                         "Off by default since round 5: a replay faulted on this stack where the eager submission of the same launches did not (DESIGN section 3)")
-    ap.add_argument("--no-graph", dest="graph", action="store_false", help="(the default; kept for older command lines)")
+    ap.add_argument("--no-graph", action="store_true", help="(accepted and ignored: older command lines; the hipGraph replay of rounds 3 - 5 is gone)")
     ap.add_argument("--e2e-scale", type=float, default=0.1, help="N = 1: depth scale of the live end-to-end leg (BAM file -> FASTA; 0 = skip)")
     args = ap.parse_args()
     if not args.scaling:      # N > 1: strong scaling is the headline (BASELINE.json: one input over 1 / 2 / 4 / 8 GPUs); N = 1: the contract's word
@@ -181,7 +178,7 @@ def main():
         # offsets, depth ranges, change codes, consensus bytes -- in device memory on its way, the step's collective is all that follows
         exch = shard.Exchange(eng, interval, dev, intervals=intervals).attach() if world > 1 else None
 
-        def step(graph=False, classic=False):
+        def step(classic=False):
             if classic:
                 # the call sequence of rounds 1 - 3, five blocking read-backs (kept as a second, independent way to the same bytes)
                 eng.reset()
@@ -191,13 +188,8 @@ def main():
                 off = eng.consensus_fetch_all_into(pinned_np)
             else:
                 # ONE call (kd_step): reset, record loop, insertion reduction, consensus and this rank's consensus bytes into pinned
-                # host memory (at N = 1 the whole FASTA), two host round trips.  graph=False: the eager sequence, what every new
-                # batch takes (`value`).  graph=True: the first repeat on the same resident batch is captured, later ones replay the
-                # hipGraph and verify its decisions on the device's status words (`replay_ms_per_step`).
-                if state.get("graph") != graph:
-                    eng.set_step_graph(graph)
-                    state["graph"] = graph
-                off, state["replayed"] = eng.step_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"], pinned_np)
+                # host memory (at N = 1 the whole FASTA), two host round trips
+                off = eng.step_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"], pinned_np)
             seqs = [pinned_np[int(off[c]): int(off[c + 1])] for c in range(n_contigs)]
             # ... and, at N > 1, the all-gather that leaves the stitched consensus in every GPU's HBM
             if world > 1:   # one fixed-size all-gather (RCCL over xGMI); the classic call sequence does not fill the row: on demand there
@@ -229,25 +221,6 @@ def main():
         # the classic five-call sequence once (untimed): the same bytes by the other way
         seqs_c = [bytes(memoryview(x)) for x in step(classic=True)]
         assert seqs_c == [bytes(memoryview(x)) for x in step()], "kd_step and the classic call sequence disagree"
-        dt_graph = None
-        if args.graph:
-            # timed region (one-launch step): the same K steps through kd_step.  The first call records + captures, so it is part
-            # of the warm-up; the timed steps must all have been served by the graph, else the eager figure stands.
-            eng.profile_enable(0)
-            for _ in range(max(2, args.warmup)):
-                seqs_g = step(graph=True)
-            barrier()
-            t0 = time.perf_counter()
-            all_replayed = True
-            for _ in range(args.steps):
-                seqs_g = step(graph=True)
-                all_replayed = all_replayed and state.get("replayed", False)
-            barrier()
-            dt_graph = time.perf_counter() - t0
-            if all_replayed:
-                assert all(bytes(memoryview(a)) == bytes(memoryview(b)) for a, b in zip(seqs_eager, seqs_g))
-            else:
-                dt_graph = None
         eng.profile_enable(1)
         eng.profile_reset()
         for _ in range(args.steps):
@@ -255,11 +228,10 @@ def main():
         barrier()
         prof = eng.profile()
         eng.profile_enable(0)
-        tmax = torch.tensor([dt, dt_graph if dt_graph is not None else -1.0], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0].item())
-        dt_graph = float(tmax[1].item()) if dt_graph is not None else None
         info = eng.batch_info()
         stats = eng.stats()
         if world > 1:   # host assembly of the stitched FASTA, outside the timed region (checksum only)
@@ -295,8 +267,6 @@ def main():
             out = dict(
                 metric="aligned-base events/sec pileup+consensus", value=value, unit="events/s", n_gpus=world,
                 steps=args.steps, warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, submission=submission,
-                replay_ms_per_step=(round(dt_graph / args.steps * 1e3, 4) if dt_graph is not None else None),
-                replay_note="the same K steps through kd_step's hipGraph replay of the SAME resident batch (a repeat no real input makes: never `value`)",
                 scaling=scaling if world > 1 else "weak", vs_baseline=None, dtype="u32", data="synthetic",
                 config=dict(workload="%s: synthetic %s, %d contig(s), %d sites, depth %gx%s" % (
                     args.config, "150 bp short reads" if cfg["kind"] == "short" else "ONT-like long reads",

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KD_ABI_VERSION 1
+#define KD_ABI_VERSION 2
 
 /* error codes; the Python mirror re-raises the exception the reference would raise */
 #define KD_OK 0
@@ -203,25 +203,17 @@ int kd_changes_device(kd_ctx *ctx, void **dev_ptr);
  * gather is repeated with the announced size).  kd_exchange_row: on demand after kd_consensus_run / kd_finish / kd_step;
  * complete when it returns.  kd_set_exchange: registers a row that kd_finish and kd_step then fill on their way -- the two
  * device-to-device copies queued behind the consensus kernels, the header with the run's collected metadata -- so that a
- * multi-GPU step is kd_step + ONE collective; complete when kd_finish / kd_step return.  dev_row = NULL unregisters.  A step
- * with a registered row always takes the eager sequence (no hipGraph).  cap >= 16. */
+ * multi-GPU step is kd_step + ONE collective; complete when kd_finish / kd_step return.  dev_row = NULL unregisters.  cap >= 16. */
 int kd_exchange_row(kd_ctx *ctx, void *dev_row, uint64_t cap, uint64_t *row_bytes);
 int kd_set_exchange(kd_ctx *ctx, void *dev_row, uint64_t cap);
 /* One whole step over a DEVICE-resident batch in one call: kd_reset + kd_push_batch_device + kd_finalize + kd_consensus_run (no
  * patches) + kd_consensus_fetch_all(seq_out ...), i.e. parse_records' loop and consensus_sequence's loop (kindel.py:40-81,
- * :384-430) for every contig of the batch, queued back to back with two host round trips (the EAGER sequence: what every call
- * takes by default, and what a new batch takes in any case).  With kd_set_step_graph(ctx, 1) -- opt-in, experimental -- the first
- * repeat of a step on the same resident batch (same pointers, sizes, seq_out, shard, tuning) is also captured as a hipGraph and
- * later repeats replay it -- one launch instead of ~20 dispatches -- and then verify on the device's status words and consensus
- * offsets that the replay took exactly the decisions the eager sequence would have taken (else the eager sequence runs).
- * *replayed (may be NULL): 1 if a graph served the call.  seq_out should be pinned host memory (hipHostMalloc / hipHostRegister;
- * pinned memory makes the closing copy asynchronous, and a pageable seq_out is never captured).  Errors as kd_finalize. */
+ * :384-430) for every contig of the batch, queued back to back with two host round trips.  seq_out should be pinned host memory
+ * (hipHostMalloc / hipHostRegister: pinned memory makes the closing copy asynchronous).  Errors as kd_finalize.
+ * (ABI 1 had an opt-in hipGraph replay of a repeated step -- kd_set_step_graph, an int *replayed here -- removed in
+ * ABI 2: it measured nothing over the eager sequence and was the one path that faulted on hardware) */
 int kd_step(kd_ctx *ctx, const kd_batch *dev_batch, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out,
-            uint64_t *contig_off, int *replayed);
-/* kd_set_step_graph: on = 0 (default since round 5): kd_step always takes the eager sequence; on = 1: the first REPEAT of a step
- * on the same resident batch is captured, later repeats replay the graph.  Experimental: on ROCm 7.2 / MI355X a replay on changed
- * inputs faulted in a long-lived process where the same launches submitted one by one did not. */
-int kd_set_step_graph(kd_ctx *ctx, int on);
+            uint64_t *contig_off);
 /* kd_finish: everything behind the pushes in one call and ONE host round trip -- kd_finalize + kd_consensus_run(min_depth, no
  * patches) + kd_consensus_fetch_all -- i.e. consensus(insertions[pos]) :420 and consensus_sequence :384-430 for all contigs, the
  * bytes of all contigs in G-space order into seq_out (cap bytes; pinned memory makes the copy asynchronous), *len_out their number,

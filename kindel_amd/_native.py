@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "kd_decode_contig_name kd_decode_contig_len kd_decode_n_records kd_decode_close kd_decode_last_error "
     "kd_stream_open kd_stream_n_contigs kd_stream_contig_name kd_stream_contig_len kd_stream_next kd_stream_n_records "
     "kd_stream_last_error kd_stream_close kd_stream_set_contig_map kd_push_stream kd_decode_push_file kd_get_contig_first kd_host_threads kd_host_inflate kd_host_crc32 "
-    "kd_bgzf_index kd_decode_open_span kd_step kd_finish kd_set_step_graph kd_bgzf_plan_open kd_bgzf_plan_n_contigs kd_bgzf_plan_contig_name kd_bgzf_plan_contig_len "
+    "kd_bgzf_index kd_decode_open_span kd_step kd_finish kd_bgzf_plan_open kd_bgzf_plan_n_contigs kd_bgzf_plan_contig_name kd_bgzf_plan_contig_len "
     "kd_bgzf_plan_view kd_bgzf_plan_close kd_push_bam_gpu"
 ).split()
 
@@ -103,9 +103,8 @@ class Library:
         L.kd_set_exchange.argtypes = [p, p, u64]
         L.kd_consensus_offsets.argtypes = [p, p, p]
         L.kd_consensus_fetch_all.argtypes = [p, p, u64, C.POINTER(u64), p, p]
-        L.kd_step.argtypes = [p, C.POINTER(kd_batch), u32, p, u64, C.POINTER(u64), p, C.POINTER(C.c_int)]
+        L.kd_step.argtypes = [p, C.POINTER(kd_batch), u32, p, u64, C.POINTER(u64), p]
         L.kd_finish.argtypes = [p, u32, p, u64, C.POINTER(u64), p]
-        L.kd_set_step_graph.argtypes = [p, C.c_int]
         L.kd_profile_enable.argtypes = [p, C.c_int]
         L.kd_profile_get.argtypes = [p, C.POINTER(u32), p, p, p]
         L.kd_profile_reset.argtypes = [p]
@@ -154,7 +153,7 @@ class Library:
         L.kd_push_stream.argtypes = [p, p, C.POINTER(u64)]
         L.kd_decode_push_file.argtypes = [p, C.c_char_p, C.c_int, u64, C.POINTER(u64)]
         L.kd_get_contig_first.argtypes = [p, p]
-        if L.kd_abi_version() != 1:
+        if L.kd_abi_version() != 2:
             raise ImportError("kindel_amd: ABI version mismatch in %s" % path)
 
 
@@ -539,20 +538,14 @@ class Engine:
 
     def step_device(self, ptrs, n_reads, seq4_bytes, cigar_words, out, min_depth=1):
         """One whole step over a device-resident batch (kd_step: reset + record loop + insertion reduction + consensus + all
-        contigs' consensus bytes into `out`, ideally pinned).  After set_step_graph(True) repeating the same batch replays a captured hipGraph.
-        -> (contig_off uint64[n_contigs + 1], replayed bool)"""
+        contigs' consensus bytes into `out`, ideally pinned).  -> contig_off uint64[n_contigs + 1]"""
         b = self._struct(ptrs, n_reads)
         b.seq4_bytes, b.cigar_words = seq4_bytes, cigar_words
-        ln, rep = C.c_uint64(0), C.c_int(0)
+        ln = C.c_uint64(0)
         off = np.zeros(len(self.contig_lens) + 1, np.uint64)
         self._n_patches = 0
-        self._check(self.lib.dll.kd_step(self._h, C.byref(b), int(min_depth), _ptr(out), out.size, C.byref(ln), _ptr(off), C.byref(rep)), "kd_step")
-        return off, bool(rep.value)
-
-    def set_step_graph(self, on):
-        """False (default): step_device always takes the eager sequence; True (opt-in, experimental): a repeated step is captured as a
-        hipGraph and replayed."""
-        self._check(self.lib.dll.kd_set_step_graph(self._h, 1 if on else 0), "kd_set_step_graph")
+        self._check(self.lib.dll.kd_step(self._h, C.byref(b), int(min_depth), _ptr(out), out.size, C.byref(ln), _ptr(off)), "kd_step")
+        return off
 
     def finish(self, out, min_depth=1):
         """Everything behind the pushes in one call and one host round trip (kd_finish): insertion reduction, consensus of all

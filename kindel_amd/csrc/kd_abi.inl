@@ -124,16 +124,10 @@ int kd_consensus_device(kd_ctx *ctx, void **dev_ptr, uint64_t *n_bytes) {
 int kd_finish(kd_ctx *ctx, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint64_t *contig_off) {
     return ctx ? ctx->e.finish(min_depth, seq_out, cap, len_out, contig_off) : KD_E_ARG;
 }
-int kd_set_step_graph(kd_ctx *ctx, int on) {
-    if (!ctx) return KD_E_ARG;
-    ctx->e.step_graph = on != 0;
-    if (!on) { ctx->e.step_have = false; ctx->e.rt.graph_drop(); }
-    return KD_OK;
-}
 int kd_step(kd_ctx *ctx, const kd_batch *dev_batch, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out,
-            uint64_t *contig_off, int *replayed) {
+            uint64_t *contig_off) {
     if (!ctx || !dev_batch) return KD_E_ARG;
-    return ctx->e.step(*dev_batch, min_depth, seq_out, cap, len_out, contig_off, replayed);
+    return ctx->e.step(*dev_batch, min_depth, seq_out, cap, len_out, contig_off);
 }
 
 int kd_changes_device(kd_ctx *ctx, void **dev_ptr) {
@@ -146,7 +140,6 @@ int kd_changes_device(kd_ctx *ctx, void **dev_ptr) {
 int kd_set_exchange(kd_ctx *ctx, void *dev_row, uint64_t cap) {
     if (!ctx || (dev_row && cap < 16)) return KD_E_ARG;
     ctx->e.exch_row = (uint8_t *)dev_row; ctx->e.exch_cap = dev_row ? cap : 0;
-    if (dev_row) { ctx->e.step_have = false; ctx->e.rt.graph_drop(); }     // (a step with a row is never a graph: kd_step)
     return KD_OK;
 }
 int kd_exchange_row(kd_ctx *ctx, void *dev_row, uint64_t cap, uint64_t *row_bytes) {

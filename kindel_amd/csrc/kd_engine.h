@@ -87,38 +87,16 @@ struct KdEngine {
     std::vector<uint8_t> h_insbytes;
     bool have_inskeys = false;
 
-    // ---- kd_step: one call = reset + record loop + insertion reduction + consensus + read-out.  The first call with a given
-    // (device-resident) batch runs the usual sequence and RECORDS what the host read back on the way (the status words that
-    // size buffers and choose paths, the consensus offsets); it then runs the sequence once more under stream capture with
-    // every host read answered from the record -- no synchronisation -- and keeps the hipGraph.  Later calls with the same batch
-    // REPLAY the graph (one launch instead of ~20 dispatches, two blocking read-backs and four copies) and then verify that the
-    // device's status words and offsets are the recorded ones -- every host decision of the eager sequence is a function of
-    // those, so equality means the graph did exactly what the eager sequence would have done; otherwise it is dropped and the
-    // eager sequence runs.
-    enum { STEP_OFF = 0, STEP_RECORD, STEP_REPLAY };
-    int step_mode = STEP_OFF;
-    std::vector<std::vector<kd_u64>> step_status;   // the status read-backs of the recorded step, in order
-    size_t step_pos = 0;
-    std::vector<uint64_t> step_meta, step_meta_up;   // consensus metadata: recorded / uploaded
-    uint64_t *step_meta_pin = nullptr;               //   ... / copied back by the graph on every replay: PINNED (Runtime::graph_stage)
-    size_t step_meta_pin_bytes = 0;
-    uint64_t step_sig[12] = {0};
-    uint64_t step_fasta_len = 0;   // consensus bytes of the recorded step
-    uint64_t step_last_sig[12] = {0};
-    bool step_record_bad = false;
-    bool step_graph = false;       // kd_set_step_graph: capture a repeated step as a hipGraph.  OPT-IN since round 5: on this stack (ROCm 7.2,
-                                   // MI355X) a replay faulted twice where the same launches, submitted one by one with the same recorded
-                                   // decisions, ran clean ("hipGraph replay") -- the eager sequence is the product path
-    bool step_have = false;
-
     int fail(int code, const std::string &m) { err = m; return code; }
     int hipfail(const char *what) { return fail(KD_E_HIP, std::string(what) + ": " + rt.err()); }
 
-    int ensure(Buf &b, size_t bytes, bool keep = false, size_t keep_bytes = 0) {
+    // (the macro below passes the buffer's name on: what KD_GUARD's allocation table and fault report call it)
+    int ensure_(const char *tag, Buf &b, size_t bytes, bool keep = false, size_t keep_bytes = 0) {
         if (bytes <= b.cap) return KD_OK;
         size_t ncap = std::max(bytes, b.cap + b.cap / 2);
         ncap = (ncap + 255) & ~size_t(255);
-        void *np = rt.alloc(ncap);
+        if (rt.exact_sizes()) ncap = (bytes + 15) & ~size_t(15);      // KD_GUARD: no head-room -- an access past what was asked for must fault
+        void *np = rt.alloc(ncap, tag);
         if (!np) return fail(KD_E_NOMEM, "device allocation of " + std::to_string(ncap) + " bytes failed: " + rt.err());
         if (keep && b.p && keep_bytes) {
             if (rt.d2d(np, b.p, keep_bytes)) return hipfail("d2d");
@@ -128,6 +106,7 @@ struct KdEngine {
         b.p = np; b.cap = ncap;
         return KD_OK;
     }
+#define ensure(b, ...) ensure_(#b, b, __VA_ARGS__)
     void release(Buf &b) { if (b.p) rt.free(b.p); b.p = nullptr; b.cap = 0; }
 
     KdTabs tabs() const {
@@ -148,7 +127,6 @@ struct KdEngine {
     int create(int device, uint32_t n, const uint32_t *lens, void *stream) {
         if (!n || !lens) return fail(KD_E_ARG, "kd_create: no contigs");
         if (rt.init(device, stream)) return hipfail("kd_create: device init");
-        knob_step_trace = getenv("KD_STEP_TRACE") != nullptr; knob_replay_eager = getenv("KD_STEP_REPLAY_EAGER") != nullptr;
         if (const char *e = getenv("KD_COLD_TAIL")) knob_cold_tail = atoi(e) != 0;
         if (const char *e = getenv("KD_INS_SITE_FLAGS")) knob_ins_site_flags = atoi(e) != 0;
         n_contigs = n;
@@ -162,15 +140,15 @@ struct KdEngine {
         S = (g + KD_CNS_TILE - 1) / KD_CNS_TILE * KD_CNS_TILE;
         if (S >= 0xfffffff0ULL) return fail(KD_E_ARG, "kd_create: more than 2^32 reference sites");
         g_lo = 0; g_hi = S;
-        d_clen = (uint32_t *)rt.alloc((size_t)n * 4);
-        d_cbase = (kd_u64 *)rt.alloc((size_t)n * 8);
-        d_seg = (uint32_t *)rt.alloc((size_t)(S / 64) * 4);
+        d_clen = (uint32_t *)rt.alloc((size_t)n * 4, "d_clen");
+        d_cbase = (kd_u64 *)rt.alloc((size_t)n * 8, "d_cbase");
+        d_seg = (uint32_t *)rt.alloc((size_t)(S / 64) * 4, "d_seg");
         // the status words and, right behind them, the consensus run's metadata block (per-contig output offsets and depth ranges,
         // meta_coff() / meta_mm()): what a step hands back to the host is ONE copy (round 5; it was two, 6 us apart)
-        d_status = (kd_u64 *)rt.alloc(KDS_COUNT * 8 + meta_bytes());
-        d_first_idx = (kd_u64 *)rt.alloc((size_t)n * 8);
-        d_err_first = (kd_u64 *)rt.alloc((size_t)n * 8);
-        d_err_code = (uint32_t *)rt.alloc((size_t)n * 4);
+        d_status = (kd_u64 *)rt.alloc(KDS_COUNT * 8 + meta_bytes(), "d_status");
+        d_first_idx = (kd_u64 *)rt.alloc((size_t)n * 8, "d_first_idx");
+        d_err_first = (kd_u64 *)rt.alloc((size_t)n * 8, "d_err_first");
+        d_err_code = (uint32_t *)rt.alloc((size_t)n * 4, "d_err_code");
         if (!d_clen || !d_cbase || !d_seg || !d_status || !d_first_idx || !d_err_first || !d_err_code)
             return fail(KD_E_NOMEM, std::string("kd_create: device allocation failed: ") + rt.err());
         std::vector<uint32_t> seg(S / 64, n - 1);
@@ -191,6 +169,7 @@ struct KdEngine {
                       &b_tilesum, &b_tilemm, &b_tileoff};
         for (Buf *b : all) release(*b);
         for (Buf &b : b_stage) release(b);
+        for (Buf &b : b_gin) release(b);
         release(b_srec); release(b_smallcig); release(b_sortrows); release(b_sortseg); release(b_longorder);
         for (Buf *g : {&b_gi_file, &b_gi_blocks, &b_gi_out, &b_gi_bstat, &b_gi_start, &b_gi_cnt, &b_gi_tot, &b_gi_recat}) release(*g);
         if (d_tab) rt.free(d_tab);
@@ -218,7 +197,7 @@ struct KdEngine {
         if (!d_tab || lo != alloc_lo || hi != alloc_hi) {
             if (d_tab) { if (rt.sync()) return hipfail("sync"); rt.free(d_tab); d_tab = nullptr; }
             alloc_lo = lo; alloc_hi = hi; pitch = (hi - lo) + 64;   // slack: the consensus reads one site past its last tile
-            d_tab = (uint32_t *)rt.alloc((size_t)KDC_NCH * pitch * 4);
+            d_tab = (uint32_t *)rt.alloc((size_t)KDC_NCH * pitch * 4, "d_tab");
             if (!d_tab)
                 return fail(KD_E_NOMEM, "device allocation of the tables failed (" + std::to_string((size_t)KDC_NCH * pitch * 4) + " bytes): " + rt.err());
         }
@@ -270,20 +249,33 @@ struct KdEngine {
     }
 
     int fetch_status() {
-        if (step_mode == STEP_REPLAY) {
-            if (step_pos >= step_status.size()) return fail(KD_E_INTERNAL, "kd_step: replay asked for more read-backs than were recorded");
-            h_status = step_status[step_pos++];
-            return KD_OK;
-        }
         if (rt.d2h_small(h_status.data(), d_status, KDS_COUNT * 8)) return hipfail("status d2h");
-        if (step_mode == STEP_RECORD) step_status.push_back(h_status);
         return KD_OK;
     }
 
     // ---- pileup ----
-    int push_device(const kd_batch &B) {
+    Buf b_gin[9];      // KD_GUARD: the caller's device batch, copied into fenced buffers of exactly the promised sizes
+    int push_device(const kd_batch &B_in) {
+        kd_batch B = B_in;
         const uint64_t n = B.n_reads;
         if (!n) return KD_OK;
+        if (rt.exact_sizes()) {
+            // include/kindel_hip.h: n entries per read array, cigar_words words, seq4_bytes + 16 readable bytes of packed bases --
+            // a kernel that reads more than that faults on the copy's fence
+            const void *src[9] = {B.contig, B.pos0, B.flag, B.seq_off, B.seq_len, B.cig_off, B.n_cig, B.seq4, B.cigar};
+            const size_t bytes[9] = {n * 4, n * 4, n * 4, n * 8, n * 4, n * 8, n * 4, (size_t)B.seq4_bytes + 16, (size_t)B.cigar_words * 4};
+            if (rt.sync()) return hipfail("push: sync");      // (an earlier batch's kernels may still read the last copies)
+            for (int k = 0; k < 9; k++) {
+                release(b_gin[k]);                          // exact size every time: a smaller batch must not inherit a larger one's room
+                int rcg = ensure(b_gin[k], std::max<size_t>(bytes[k], 16));
+                if (rcg) return rcg;
+                const size_t have = k == 7 ? (size_t)B.seq4_bytes : bytes[k];      // (the 16 bytes behind the packed bases: readable, not meaningful)
+                if ((k == 7 && rt.memset((uint8_t *)b_gin[k].p + have, 0, 16)) || (have && rt.d2d(b_gin[k].p, src[k], have))) return hipfail("push: d2d");
+            }
+            B.contig = (const uint32_t *)b_gin[0].p; B.pos0 = (const int32_t *)b_gin[1].p; B.flag = (const uint32_t *)b_gin[2].p;
+            B.seq_off = (const uint64_t *)b_gin[3].p; B.seq_len = (const uint32_t *)b_gin[4].p; B.cig_off = (const uint64_t *)b_gin[5].p;
+            B.n_cig = (const uint32_t *)b_gin[6].p; B.seq4 = (const uint8_t *)b_gin[7].p; B.cigar = (const uint32_t *)b_gin[8].p;
+        }
         if (n >= 0xffffffffULL) return fail(KD_E_ARG, "kd_push_batch: more than 2^32-1 reads in one batch");
         if (reinterpret_cast<uintptr_t>(B.seq4) & 15u) return fail(KD_E_ARG, "kd_push_batch_device: seq4 must be 16-byte aligned");
         int rc;
@@ -331,16 +323,12 @@ struct KdEngine {
         // the host's wait for the copy (a round trip of ~30 us) passes while the memset runs.  (Round 5 measured the zeroing NEXT
         // to k_prep instead, on a side stream joined in front of k_window: C3 1.593 ms against 1.598 with the zeroing in front of
         // k_prep on the main stream and 1.52 - 1.56 this way -- the two kernels share the memory system, nothing is gained: dropped.)
-        if (step_mode != STEP_REPLAY && rt.d2h_small_begin(d_status, KDS_COUNT * 8)) return hipfail("status d2h");
+        if (rt.d2h_small_begin(d_status, KDS_COUNT * 8)) return hipfail("status d2h");
         if (!tables_ready) {
             if ((rc = prepare_tables())) return rc;
             T = tabs();      // (the tables may just have been allocated: k_prep only used the contig geometry of T)
         }
-        if (step_mode == STEP_REPLAY) { if ((rc = fetch_status())) return rc; }
-        else {
-            if (rt.d2h_small_end(h_status.data(), KDS_COUNT * 8)) return hipfail("status d2h");
-            if (step_mode == STEP_RECORD) step_status.push_back(h_status);
-        }
+        if (rt.d2h_small_end(h_status.data(), KDS_COUNT * 8)) return hipfail("status d2h");
         const uint64_t n_long = h_status[KDS_B_N_LONG];
         const uint64_t n_reg_short = h_status[KDS_B_N_REG];   // (k_long_reduce adds the regular long reads: their rows are the second pass)
         if (n_long) {
@@ -1201,143 +1189,45 @@ struct KdEngine {
         const size_t mb = meta_bytes();
         const uint64_t shard_sites = std::min<uint64_t>(S, g_hi) - std::min<uint64_t>(S, g_lo);
         uint64_t guess = seq_out ? std::min<uint64_t>(std::min<uint64_t>(cap, cns_cap), shard_sites + 4096) : 0;
-        const void *meta = nullptr;
-        if (step_mode == STEP_REPLAY) {
-            // captured: the copies land when the graph runs (verified then); the host continues with the record
-            if ((rc = fetch_status())) return rc;
-            if (step_meta.size() != mb / 8) return fail(KD_E_INTERNAL, "kd_step: recorded consensus metadata has another shape");
-            if (!step_meta_pin || step_meta_pin_bytes != mb) return fail(KD_E_INTERNAL, "kd_step: no pinned buffer for the replay's metadata");
-            // The two copies of a replay -- the run's metadata into pinned memory, the FASTA at its recorded length -- are NOT nodes of
-            // the graph: replay_copies() queues them behind every graph launch.  (With them inside, a graph that had been replayed
-            // fine faulted -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION -- on its next launch after ANOTHER user of the runtime had
-            // made a small pageable copy: torch's .cpu() between two steps, MI355X / ROCm 7.2; kernel and memset nodes are not affected.)
-            if (!step_in_capture) { int rcc = replay_copies(seq_out); if (rcc) return rcc; }
-            meta = step_meta.data();
-            guess = seq_out ? step_fasta_len : 0;     // (the recorded length: one exact copy)
-        } else {
-            uint8_t *st = (uint8_t *)rt.stage(KDS_COUNT * 8 + mb);
-            if (!st) return hipfail("kd_finish: pinned staging");
-            if (exch_row && (rc = exchange_queue(exch_row, exch_cap, std::min<uint64_t>(cns_cap, shard_sites + 4096)))) return rc;
-            if (rt.d2h_async(st, d_status, KDS_COUNT * 8 + mb) ||      // (status words | metadata: adjacent in device memory)
-                (guess && rt.d2h_async(seq_out, b_cns.p, guess)) || rt.sync())
-                return hipfail("kd_finish: d2h");
-            memcpy(h_status.data(), st, KDS_COUNT * 8);
-            if (step_mode == STEP_RECORD) { step_status.push_back(h_status); step_meta.assign((const uint64_t *)(st + KDS_COUNT * 8), (const uint64_t *)(st + KDS_COUNT * 8) + mb / 8); }
-            meta = st + KDS_COUNT * 8;
-        }
+        uint8_t *st = (uint8_t *)rt.stage(KDS_COUNT * 8 + mb);
+        if (!st) return hipfail("kd_finish: pinned staging");
+        if (exch_row && (rc = exchange_queue(exch_row, exch_cap, std::min<uint64_t>(cns_cap, shard_sites + 4096)))) return rc;
+        if (rt.d2h_async(st, d_status, KDS_COUNT * 8 + mb) ||      // (status words | metadata: adjacent in device memory)
+            (guess && rt.d2h_async(seq_out, b_cns.p, guess)) || rt.sync())
+            return hipfail("kd_finish: d2h");
+        memcpy(h_status.data(), st, KDS_COUNT * 8);
+        const void *meta = st + KDS_COUNT * 8;
         bool redone = false;
         if ((rc = finalize_check(nullptr, &redone))) return rc;
         if (redone) {     // a hash collision was repaired (never seen outside the tests): the consensus once more, read back on its own
-            if (step_mode == STEP_REPLAY) return fail(KD_E_INTERNAL, "kd_step: hash collision under capture");
-            step_record_bad = true;     // (no graph of this step)
             if ((rc = consensus_run(min_depth, 0, nullptr, nullptr))) return rc;
             guess = 0;
             if (exch_row && ((rc = exchange_queue(exch_row, exch_cap, h_coff[n_contigs])) || (rc = exchange_rest(exch_row, exch_cap, nullptr)))) return rc;     // (the row once more)
         } else if ((rc = consensus_collect(meta))) return rc;
-        else if (exch_row && step_mode != STEP_REPLAY && h_coff[n_contigs] > exch_cns_queued && (rc = exchange_rest(exch_row, exch_cap, nullptr))) return rc;
+        else if (exch_row && h_coff[n_contigs] > exch_cns_queued && (rc = exchange_rest(exch_row, exch_cap, nullptr))) return rc;
         const uint64_t o0 = h_coff[0], o1 = h_coff[n_contigs];
         if (len_out) *len_out = o1 - o0;
         if (contig_off) for (uint32_t c = 0; c <= n_contigs; c++) contig_off[c] = h_coff[c] - o0;
         if (seq_out) {
             if (o1 - o0 > cap) return fail(KD_E_ARG, "kd_finish: buffer too small");
-            if (step_mode == STEP_RECORD) step_fasta_len = o1;
             if (o1 > guess && rt.d2h((uint8_t *)seq_out + guess, (uint8_t *)b_cns.p + guess, o1 - guess)) return hipfail("consensus fetch: d2h");
         }
         return KD_OK;
     }
 
-    bool step_in_capture = false;
-    // fault-localisation knobs, read when the context is created (create())
-    bool knob_step_trace = false, knob_replay_eager = false;
     int knob_ins_site_flags = -1;     // KD_INS_SITE_FLAGS=0 / 1 (tests, measurement): the insertion reduction's site test per event / once per site, whatever the counts
-    bool knob_cold_tail = false;      // KD_COLD_TAIL=1: the cold records' workgroups ride in k_window's launch (kd_window.h: KdColdTail) instead of k_cold_lane's own.
-                                      // Measured (round 5): the step gains 1.6 % (C3) / 2.4 % (C4) -- the memory-bound cold work fills the launch's tail --, bit-exact; OFF by
-                                      // default because the launch the roofline is measured on then carries k_cold_lane's 0.12 ms as well (k_window 0.93 -> 1.03 ms:
-                                      // the contract's fraction would fall from 0.37 to 0.33 for a step that got FASTER), and 1.6 % is inside the box-to-box spread
-    int replay_copies(uint8_t *seq_out) {
-        const size_t mb = meta_bytes();
-        if (rt.d2h_async(step_meta_pin, meta_coff(), mb)) return hipfail("consensus: d2h");      // (pinned: see Runtime::graph_stage)
-        if (seq_out && step_fasta_len && rt.d2h_async(seq_out, b_cns.p, step_fasta_len)) return hipfail("consensus fetch: d2h");
-        return KD_OK;
-    }
+    bool knob_cold_tail = true;       // the cold records' workgroups ride in k_window's launch (kd_window.h: KdColdTail) instead of k_cold_lane's own: the memory-bound
+                                      // cold work fills the launch's tail (round 5: step -1.6 % on C3, -2.4 % on C4, bit-exact; default since round 6).  KD_COLD_TAIL=0:
+                                      // k_cold_lane as a launch of its own (tests keep both branches covered)
 
-    // One step over a device-resident batch (kd_step): see step_mode above.  *replayed = 1 when the graph did it.
-    int step(const kd_batch &B, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint64_t *contig_off, int *replayed) {
-        if (replayed) *replayed = 0;
-        const uint64_t sig[12] = {(uint64_t)B.n_reads, (uint64_t)(uintptr_t)B.contig, (uint64_t)(uintptr_t)B.pos0, (uint64_t)(uintptr_t)B.seq_off,
-                                  (uint64_t)(uintptr_t)B.cig_off, (uint64_t)(uintptr_t)B.seq4, (uint64_t)(uintptr_t)B.cigar,
-                                  (uint64_t)B.seq4_bytes ^ ((uint64_t)B.cigar_words << 32), (uint64_t)(uintptr_t)seq_out, cap,
-                                  g_lo ^ (g_hi << 1) ^ ((uint64_t)min_depth << 56), (uint64_t)mode ^ ((uint64_t)W << 8) ^ ((uint64_t)slice_cfg << 32)};
-        // The step, eager: reset, record loop, insertion reduction and consensus are queued back to back; the host waits ONCE
-        // behind k_prep (the counts that size buffers and choose kernels) and ONCE at the end (finish()).  (Round 3: five
-        // blocking read-backs per step -- after k_prep, after the reduction, after the consensus, the FASTA, the metadata.)
-        auto sequence = [&]() -> int {
-            int rc;
-            if ((rc = reset()) || (rc = push_device(B))) return rc;
-            return finish(min_depth, seq_out, cap, len_out, contig_off);
-        };
-        // the words every host decision of the sequence is made from
-        static const int kDecisive[] = {KDS_ERR_READ, KDS_N_EV, KDS_POOL, KDS_B_INS_OPS, KDS_B_INS_BASES, KDS_B_MAXSPAN, KDS_B_MAXLEAD, KDS_B_MAXSEGSPAN, KDS_B_ROW_DWORDS,
-                                        KDS_B_UNSORTED, KDS_B_N_COLD, KDS_B_N_IRREG, KDS_B_N_LONG, KDS_B_N_REG, KDS_INS_COLLISION, KDS_INTERNAL,
-                                        KDS_BAD_BASE};
-        const bool step_trace = knob_step_trace;      // (knob, fault localisation: the step's path and the addresses a fault report can be matched with)
-        if (step_trace)
-            fprintf(stderr, "[kd] step: have_graph %d status %p tab %p cns %p coff %p seq_out %p meta_pin %p reads %p..%p\n", (int)(step_have && rt.has_graph()),
-                    (void *)d_status, (void *)d_tab, b_cns.p, meta_coff(), (void *)seq_out, (void *)step_meta_pin, (const void *)B.contig, (const void *)B.seq4);
-        if (exch_row) { step_have = false; step_mode = STEP_OFF; return sequence(); }     // (a registered exchange row: its tail may need the run's host values -- always eager)
-        if (step_have && rt.has_graph() && !memcmp(sig, step_sig, sizeof sig) && !step_status.empty()) {
-            // (knob, fault localisation: KD_STEP_REPLAY_EAGER=1 submits the recorded sequence kernel by kernel -- the same launches with the
-            // same recorded host decisions as the graph holds, but visible to KD_LAUNCH_TRACE -- instead of launching the graph)
-            const bool replay_eager = knob_replay_eager;
-            bool ran = false;
-            if (replay_eager) {
-                step_mode = STEP_REPLAY; step_pos = 0;
-                const int rce = sequence();
-                step_mode = STEP_OFF;
-                ran = rce == KD_OK && !rt.sync();
-            } else ran = !rt.graph_launch() && replay_copies(seq_out) == KD_OK && !rt.sync();
-            if (ran) {
-                std::vector<kd_u64> now(KDS_COUNT, 0);
-                bool same = !rt.d2h_small(now.data(), d_status, KDS_COUNT * 8) && step_meta_pin && step_meta_pin_bytes == step_meta.size() * 8 &&
-                            !memcmp(step_meta_pin, step_meta.data(), step_meta_pin_bytes);
-                for (int w : kDecisive) same = same && now[w] == step_status.back()[w];
-                if (same) {
-                    // host state as the recorded sequence left it (the capture pass ran the same host code)
-                    h_status = step_status.back();
-                    if (len_out) *len_out = h_coff[n_contigs] - h_coff[0];
-                    if (contig_off) for (uint32_t c = 0; c <= n_contigs; c++) contig_off[c] = h_coff[c] - h_coff[0];
-                    if (replayed) *replayed = 1;
-                    return KD_OK;
-                }
-            }
-            step_have = false;      // the input changed under the same pointers (or the launch failed): back to the eager sequence
-            rt.graph_drop();
-        }
-        step_have = false;
-        step_mode = STEP_RECORD; step_status.clear(); step_meta.clear(); step_record_bad = false;
-        int rc = sequence();
-        step_mode = STEP_OFF;
-        // a graph is only worth its capture when the SAME resident batch is stepped again (a benchmark's timed loop; a real
-        // input is a new batch every time and takes the eager sequence above): capture on the first repeat
-        const bool repeat = !memcmp(sig, step_last_sig, sizeof sig);
-        memcpy(step_last_sig, sig, sizeof sig);
-        if (rc || !rt.graph_supported() || step_record_bad || !repeat || !step_graph) return rc;
-        if (!rt.is_pinned(seq_out)) return rc;      // the graph's copy nodes must point at page-locked memory (Runtime::graph_stage): a pageable `seq_out` keeps the step eager
-        // the same sequence once more, captured: every host read answered from the record, nothing executes
-        step_meta_pin_bytes = meta_bytes();
-        step_meta_pin = (uint64_t *)rt.graph_stage(step_meta_pin_bytes);      // (allocated in front of the capture, not inside it)
-        if (!step_meta_pin) return KD_OK;                                      // no pinned memory: no graph, the step stays eager
-        step_mode = STEP_REPLAY; step_pos = 0;
-        int rc2 = rt.capture_begin() ? 1 : 0;
-        if (!rc2) {
-            step_in_capture = true;
-            rc2 = sequence();
-            step_in_capture = false;
-            if (rt.capture_end(rc2 == KD_OK && step_pos == step_status.size())) rc2 = rc2 ? rc2 : 1;
-        }
-        step_mode = STEP_OFF;
-        if (rc2 == KD_OK && rt.has_graph()) { memcpy(step_sig, sig, sizeof sig); step_have = true; }
-        else { rt.graph_drop(); err.clear(); }     // no graph: the next call is eager again (and tries again)
-        return KD_OK;
+    // One step over a device-resident batch (kd_step): reset, record loop, insertion reduction and consensus queued back to back;
+    // the host waits ONCE behind k_prep (the counts that size buffers and choose kernels) and ONCE at the end (finish()).  (Round 3:
+    // five blocking read-backs per step.  Rounds 3 - 5 could also capture a repeated step as a hipGraph and replay it; with two host
+    // round trips left per step the replay measured nothing -- C3 1.573 vs 1.576 ms -- and it was the one path that faulted on
+    // hardware: removed in round 6)
+    int step(const kd_batch &B, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint64_t *contig_off) {
+        int rc;
+        if ((rc = reset()) || (rc = push_device(B))) return rc;
+        return finish(min_depth, seq_out, cap, len_out, contig_off);
     }
 };

@@ -4,7 +4,9 @@
 // fallback: without a usable GPU kd_create() fails with KD_E_HIP.
 #include <hip/hip_runtime.h>
 
+#include <csignal>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -33,6 +35,11 @@ struct HipRt {
     int init(int device, void *s) {
         int n = 0;
         trace = getenv("KD_LAUNCH_TRACE") ? std::max(1, atoi(getenv("KD_LAUNCH_TRACE"))) : 0;
+        guard = getenv("KD_GUARD") ? atoi(getenv("KD_GUARD")) : 0;
+        if (guard) {
+            static std::once_flag once;
+            std::call_once(once, [] { signal(SIGABRT, guard_dump); fprintf(stderr, "[kd guard] on: fenced device allocations, a wait behind every launch\n"); });
+        }
         if (bad(hipGetDeviceCount(&n))) return 1;
         if (device < 0 || device >= n) { e = "no such HIP device (" + std::to_string(n) + " visible)"; return 1; }
         dev = device;
@@ -46,10 +53,8 @@ struct HipRt {
     }
     void shutdown() {
         profile_reset();
-        graph_drop();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; }
         if (stage_buf) { (void)hipHostFree(stage_buf); stage_buf = nullptr; stage_cap = 0; }
-        if (graph_pin) { (void)hipHostFree(graph_pin); graph_pin = nullptr; graph_pin_cap = 0; }
         for (int k = 0; k < 2; k++) { if (up_pin[k]) { (void)hipHostFree(up_pin[k]); up_pin[k] = nullptr; } if (up_ev[k]) { (void)hipEventDestroy(up_ev[k]); up_ev[k] = nullptr; } }
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
         if (ev_copy) { (void)hipEventDestroy(ev_copy); ev_copy = nullptr; }
@@ -58,13 +63,93 @@ struct HipRt {
     }
     int n_cus() const { return cus; }
     size_t free_bytes() { size_t f = 0, t = 0; if (bad(hipSetDevice(dev)) || bad(hipMemGetInfo(&f, &t))) return 0; return f; }
-    void *alloc(size_t bytes) {
+    // ---- KD_GUARD: a device-side "electric fence" (debug knob, round 6; off in the product's default run) ----
+    // KD_GUARD=1: every device allocation is mapped by itself (hipMemAddressReserve / hipMemCreate / hipMemMap) so that its LAST
+    // byte (16-byte granularity) is the last mapped byte of its address range: the first access past its end -- read or write --
+    // is a GPU memory fault at once, whatever the neighbouring allocations are, at an address that names the buffer.  KD_GUARD=2:
+    // the allocation's FIRST byte is the first mapped byte instead (underruns, negative offsets).  The slack at the other end is
+    // filled with a canary that kd_free checks.  Every launch is followed by a wait (the last kernel named is the one that
+    // faulted), buffers are allocated at their exact sizes (kd_engine.h: ensure), a caller's device batch is copied into fenced
+    // buffers of exactly the sizes the header promises (kd_engine.h: push_device), and SIGABRT -- what the runtime raises on a
+    // GPU fault -- prints the live allocations of every context in the process with their tags.
+    int guard = 0;
+    struct GuardRec { void *va; size_t va_bytes; void *map_at; size_t map_bytes; hipMemGenericAllocationHandle_t h; size_t bytes; char tag[24]; int dev; };
+    static std::map<uintptr_t, GuardRec> &guard_table() { static std::map<uintptr_t, GuardRec> t; return t; }
+    static std::mutex &guard_mutex() { static std::mutex m; return m; }
+    static const char *&guard_last_kernel() { static const char *k = "(none)"; return k; }
+    static void guard_dump(int) {
+        fprintf(stderr, "[kd guard] SIGABRT; last kernel launched: %s; live device allocations:\n", guard_last_kernel());
+        for (auto &kv : guard_table())
+            fprintf(stderr, "[kd guard]   %-12s [%p, %p) %zu bytes (mapped [%p, %p))\n", kv.second.tag, (void *)kv.first, (void *)(kv.first + kv.second.bytes), kv.second.bytes,
+                    kv.second.map_at, (void *)((uintptr_t)kv.second.map_at + kv.second.map_bytes));
+        fflush(stderr);
+        signal(SIGABRT, SIG_DFL);
+        abort();
+    }
+    static constexpr size_t GUARD_ALIGN = 16, GUARD_CANARY = 4096;
+    void *guard_alloc(size_t bytes, const char *tag) {
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+        size_t gran = 0;
+        if (bad(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) || !gran) { e = "KD_GUARD: hipMemGetAllocationGranularity: " + e; return nullptr; }
+        const size_t need = (bytes + GUARD_ALIGN - 1) / GUARD_ALIGN * GUARD_ALIGN;
+        GuardRec r = {};
+        r.bytes = bytes; r.dev = dev;
+        snprintf(r.tag, sizeof r.tag, "%s", tag ? tag : "");
+        r.map_bytes = (need + GUARD_CANARY + gran - 1) / gran * gran;
+        r.va_bytes = r.map_bytes + gran;      // one granule of the range stays unmapped: the fence
+        if (bad(hipMemAddressReserve(&r.va, r.va_bytes, gran, nullptr, 0))) { e = "KD_GUARD: hipMemAddressReserve: " + e; return nullptr; }
+        r.map_at = guard == 2 ? (void *)((uintptr_t)r.va + gran) : r.va;
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+        if (bad(hipMemCreate(&r.h, r.map_bytes, &prop, 0)) || bad(hipMemMap(r.map_at, r.map_bytes, 0, r.h, 0)) || bad(hipMemSetAccess(r.map_at, r.map_bytes, &acc, 1))) {
+            e = "KD_GUARD: hipMemCreate / hipMemMap / hipMemSetAccess: " + e;
+            return nullptr;
+        }
+        void *user = guard == 2 ? r.map_at : (void *)((uintptr_t)r.map_at + r.map_bytes - need);
+        // the canary: everything mapped that is not the allocation
+        if (bad(hipMemset(r.map_at, 0xA5, r.map_bytes)) || bad(hipDeviceSynchronize())) return nullptr;
+        std::lock_guard<std::mutex> lk(guard_mutex());
+        guard_table()[(uintptr_t)user] = r;
+        return user;
+    }
+    void guard_free(void *p) {
+        GuardRec r;
+        {
+            std::lock_guard<std::mutex> lk(guard_mutex());
+            auto it = guard_table().find((uintptr_t)p);
+            if (it == guard_table().end()) { fprintf(stderr, "[kd guard] free of an unknown pointer %p\n", p); abort(); }
+            r = it->second;
+            guard_table().erase(it);
+        }
+        (void)hipDeviceSynchronize();
+        // the canary next to the allocation (GUARD_CANARY bytes of it: the rest of a granule is not worth the copy)
+        const size_t need = (r.bytes + GUARD_ALIGN - 1) / GUARD_ALIGN * GUARD_ALIGN;
+        std::vector<unsigned char> c(GUARD_CANARY);
+        const void *at = guard == 2 ? (const void *)((uintptr_t)p + need) : (const void *)((uintptr_t)p - GUARD_CANARY);
+        if (hipMemcpy(c.data(), at, GUARD_CANARY, hipMemcpyDeviceToHost) == hipSuccess) {
+            for (size_t k = 0; k < GUARD_CANARY; k++)
+                if (c[k] != 0xA5) {
+                    fprintf(stderr, "[kd guard] CANARY of %s [%p, +%zu) damaged %s it, at byte %zd (value 0x%02x); last kernel launched: %s\n", r.tag, p, r.bytes,
+                            guard == 2 ? "behind" : "in front of", guard == 2 ? (ssize_t)k : (ssize_t)k - (ssize_t)GUARD_CANARY, c[k], guard_last_kernel());
+                    abort();
+                }
+        }
+        (void)hipMemUnmap(r.map_at, r.map_bytes); (void)hipMemRelease(r.h); (void)hipMemAddressFree(r.va, r.va_bytes);
+    }
+    bool exact_sizes() const { return guard != 0; }
+    void *alloc(size_t bytes, const char *tag = "") {
         void *p = nullptr;
         if (bad(hipSetDevice(dev))) return nullptr;
+        if (guard) return guard_alloc(bytes ? bytes : 1, tag);
         if (bad(hipMalloc(&p, bytes ? bytes : 1))) return nullptr;
         return p;
     }
-    void free(void *p) { (void)hipSetDevice(dev); (void)hipFree(p); }
+    void free(void *p) {
+        (void)hipSetDevice(dev);
+        if (guard) { guard_free(p); return; }
+        (void)hipFree(p);
+    }
     int memset(void *p, int v, size_t n) { return n ? bad(hipMemsetAsync(p, v, n, stream)) : 0; }
     int memset2d(void *p, size_t pitch, int v, size_t width, size_t height) {
         return (width && height) ? bad(hipMemset2DAsync(p, pitch, v, width, height, stream)) : 0;
@@ -77,28 +162,6 @@ struct HipRt {
     }
     int sync() { return bad(hipStreamSynchronize(stream)); }
     int d2h_async(void *h, const void *d, size_t n) { return n ? bad(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream)) : 0; }
-    // ---- one-launch step (kd_step): the dispatch chain of a step captured into a hipGraph and replayed ----
-    hipGraphExec_t graph_exec = nullptr;
-    bool capturing = false;
-    bool graph_supported() const { return true; }
-    bool has_graph() const { return graph_exec != nullptr; }
-    void graph_drop() { if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; } }
-    int capture_begin() {
-        graph_drop();
-        if (bad(hipSetDevice(dev)) || bad(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed))) return 1;
-        capturing = true;
-        return 0;
-    }
-    int capture_end(bool keep) {
-        hipGraph_t g = nullptr;
-        capturing = false;
-        if (bad(hipStreamEndCapture(stream, &g)) || !g) return 1;
-        int rc = 0;
-        if (keep && bad(hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0))) { graph_exec = nullptr; rc = 1; }
-        (void)hipGraphDestroy(g);
-        return rc;
-    }
-    int graph_launch() { return bad(hipSetDevice(dev)) || bad(hipGraphLaunch(graph_exec, stream)); }
     // ---- a large host buffer (pageable: a mapped file) -> device, PIPELINED: worker threads copy 32 MiB pieces into two pinned
     // buffers, a copy stream moves them on (hipMemcpyAsync from pageable memory stages through one thread of the runtime: 8 GB/s
     // measured on the GPU node, 40 % of the device-side ingest), and after every piece `after(bytes_there)` may launch work on the
@@ -149,30 +212,6 @@ struct HipRt {
         return stage_buf;
     }
 
-    // a second pinned buffer, for what a captured graph copies back on every replay (the run's metadata): a memcpy node whose
-    // destination is PAGEABLE host memory goes through the runtime's staging, which other users of the runtime (a torch .cpu()
-    // between two replays) can pull from under it -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on the next launch, seen on MI355X
-    void *graph_pin = nullptr;
-    size_t graph_pin_cap = 0;
-    void *graph_stage(size_t bytes) {
-        if (bytes <= graph_pin_cap) return graph_pin;
-        if (bad(hipSetDevice(dev))) return nullptr;
-        if (graph_pin) { (void)hipStreamSynchronize(stream); (void)hipHostFree(graph_pin); graph_pin = nullptr; graph_pin_cap = 0; }
-        const size_t n = (bytes + 65535) & ~(size_t)65535;
-        if (bad(hipHostMalloc(&graph_pin, n, hipHostMallocDefault))) { graph_pin = nullptr; return nullptr; }
-        graph_pin_cap = n;
-        return graph_pin;
-    }
-
-    // is p page-locked host memory the runtime knows (hipHostMalloc / hipHostRegister; torch's pin_memory)?  A graph's copy node
-    // may only point at such memory (above).
-    bool is_pinned(const void *p) {
-        if (!p) return true;
-        hipPointerAttribute_t a;
-        if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-        return a.type == hipMemoryTypeHost;
-    }
-
     // small readbacks (the status words, one cache line each: 4 KiB, 5 KiB in a profiling build) go through a pinned bounce buffer:
     // no pageable staging in the runtime
     static constexpr size_t KD_SMALL_COPY = KDS_COUNT * 8 > 16384 ? (size_t)KDS_COUNT * 8 : 16384;      // (the status words are the largest of the small read-backs, whatever their spacing)
@@ -203,19 +242,20 @@ struct HipRt {
     template <class K, class... A>
     int launch(const char *name, K k, unsigned grid, unsigned block, size_t shmem, A... args) {
         if (bad(hipSetDevice(dev))) return 1;
-        if (shmem > 48 * 1024 && !capturing &&
+        if (shmem > 48 * 1024 &&
             bad(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)))
             return 1;
         Pending p;
-        const bool timed = !capturing && (prof == 1 || (prof == 2 && (!strcmp(name, "k_window") || !strcmp(name, "k_strip"))));
+        const bool timed = (prof == 1 || (prof == 2 && (!strcmp(name, "k_window") || !strcmp(name, "k_strip"))));
         if (timed) {
             if (bad(hipEventCreate(&p.a)) || bad(hipEventCreate(&p.b))) return 1;
             if (bad(hipEventRecord(p.a, stream))) return 1;
         }
-        if (trace && !capturing) fprintf(stderr, "[kd] %s grid %u block %u lds %zu\n", name, grid, block, shmem);
+        if (trace) fprintf(stderr, "[kd] %s grid %u block %u lds %zu\n", name, grid, block, shmem);
+        if (guard) guard_last_kernel() = name;
         k<<<dim3(grid), dim3(block), shmem, stream>>>(args...);
         if (bad(hipGetLastError())) return 1;
-        if (trace == 1 && !capturing && bad(hipStreamSynchronize(stream))) return 1;
+        if ((trace == 1 || guard) && bad(hipStreamSynchronize(stream))) return 1;
         if (timed) {
             if (bad(hipEventRecord(p.b, stream))) return 1;
             p.name = name;

@@ -125,7 +125,18 @@ class Pileup:
     def __init__(self, engine, names, lens, order, bam_path=None):
         self.engine, self.names, self.lens, self.order, self.bam_path = engine, names, lens, order, bam_path
         self._tables = {}
-        self._alns = {}
+
+    def close(self):
+        """Release the context (device tables, stream, pinned buffers) NOW.  The host copies already fetched stay usable; whatever
+        needs the device afterwards raises.  A Pileup without records has no context (engine None)."""
+        if self.engine is not None:
+            self.engine.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
     def tables(self, cid):
         """uint32 [KD_NCH, L+1] of contig cid (cached host copy)."""
@@ -134,8 +145,9 @@ class Pileup:
         return self._tables[cid]
 
     def alignment(self, cid):
-        if cid in self._alns:
-            return self._alns[cid]
+        # (not cached here: the views refer back to this Pileup -- consensus_sequence() needs the device tables behind them --
+        # and a cache would close the cycle Pileup -> alignment -> Pileup, leaving the context to the cycle collector instead of
+        # to the reference count of the last alignment alive)
         t = self.tables(cid)
         L = int(self.lens[cid])
         W = np.ascontiguousarray(t[0:5, :L].T)
@@ -159,7 +171,6 @@ class Pileup:
             (csd + ced).tolist(),                       # kindel.py:96
             W.max(axis=1).astype(np.int64) if L else np.zeros(0, np.int64),  # aligned - discordant, :83-89
         )
-        self._alns[cid] = aln
         return aln
 
 
@@ -235,6 +246,11 @@ def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=N
     beyond STREAM_MAX_SITES scanned first for the contigs in use.  ingest: "host" (default: the native host decoder feeds the GPU) or "gpu"
     (opt-in, also KINDEL_INGEST=gpu: the BGZF blocks are inflated and the BAM records walked ON the GPU, kd_push_bam_gpu; a file
     that path cannot read -- SAM text, plain gzip, CG-tag CIGARs, a header larger than STREAM_MAX_SITES -- takes the host path)."""
+    if stream is None and not _is_regular_file(bam_path):
+        # the default route may open the file a second time (a large header: _contigs_in_use; the opt-in device-side ingest falling
+        # back to the host decoder); an input that can be read only once (a pipe, /dev/stdin) is decoded in ONE pass as a whole,
+        # like the reference reads it (kindel.py:136-145)
+        stream = False
     if (ingest or os.environ.get("KINDEL_INGEST", "host")) == "gpu" and stream is not False:
         try:
             with N.BgzfPlan(bam_path, lib=lib) as plan:
@@ -255,10 +271,6 @@ def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=N
                     return pl
         except N.UnsupportedByGpuIngest:
             pass
-    if stream is None and not _is_regular_file(bam_path):
-        # the default route may open the file a second time (a large header: _contigs_in_use); an input that can be read only
-        # once (a pipe, /dev/stdin) is decoded in ONE pass as a whole, like the reference reads it (kindel.py:136-145)
-        stream = False
     if stream is not False:
         st = N.Stream(bam_path, threads=threads, chunk_bytes=chunk_bytes, lib=lib)
         try:
@@ -639,9 +651,7 @@ def bam_to_consensus(bam_path, realign=False, min_depth=1, min_overlap=9, clip_d
                 patches[cid] = None
         done = _device_consensus_all(pl, patches, trim_ends, min_depth, uppercase)
     finally:
-        # everything below is host data.  With realign the alignment objects refer back to the Pileup (a cycle): without this the
-        # context -- tables, stream, pinned buffers -- would live until Python's cycle collector happens to run
-        pl.engine.close()
+        pl.close()      # everything below is host data: the context -- tables, stream, pinned buffers -- goes now (no context: no records)
     for cid in pl.order:
         ref_id = pl.names[cid]
         seq, ch, mm = done[cid]
@@ -692,6 +702,11 @@ def weights(bam_path, relative=False, confidence=True, confidence_alpha=0.01):
     import scipy.stats
 
     pl = pileup_file(bam_path)
+    try:
+        for cid in pl.order:
+            pl.tables(cid)      # (host copies)
+    finally:
+        pl.close()              # the rest is host arithmetic: the context goes now
     frames = []
     for cid in pl.order:
         t = pl.tables(cid).astype(np.int64)
@@ -740,6 +755,11 @@ def features(bam_path):
     import scipy.stats
 
     pl = pileup_file(bam_path)
+    try:
+        for cid in pl.order:
+            pl.tables(cid)      # (host copies)
+    finally:
+        pl.close()
     frames = []
     for cid in pl.order:
         t = pl.tables(cid).astype(np.int64)
@@ -774,6 +794,13 @@ def variants(bam_path, abs_threshold=1, rel_threshold=0.01, only_variants=True, 
     import pandas as pd
 
     pl = pileup_file(bam_path)
+    ins_of = {}
+    try:
+        for cid in pl.order:
+            pl.tables(cid)      # (host copies)
+            ins_of[cid] = pl.engine.insertions(cid)
+    finally:
+        pl.close()
     frames = []
     for cid in pl.order:
         t = pl.tables(cid).astype(np.int64)
@@ -805,7 +832,7 @@ def variants(bam_path, abs_threshold=1, rel_threshold=0.01, only_variants=True, 
         c = t[N.KD_CH_DEL, :L]
         sites = np.flatnonzero((c >= max(abs_threshold, 1)) & (c >= rel_threshold * safe))
         frames.append(rows(sites, np.full(len(sites), "-", dtype=object), "del", c[sites]))
-        site, count, strings = pl.engine.insertions(cid)
+        site, count, strings = ins_of[cid]
         site, count = np.asarray(site, np.int64), np.asarray(count, np.int64)
         ok = site < L                                            # slot L is never emitted (kindel.py:390)
         ok &= (count >= max(abs_threshold, 1)) & (count >= rel_threshold * safe[np.minimum(site, L - 1)])
@@ -828,9 +855,9 @@ def plotly_clips(bam_path):
     import plotly.graph_objs as go
     import plotly.offline as py
 
-    pl = pileup_file(bam_path)
-    aln = pl.alignment(pl.order[0])
-    t = pl.tables(pl.order[0]).astype(np.int64)
+    with pileup_file(bam_path) as pl:
+        aln = pl.alignment(pl.order[0])
+        t = pl.tables(pl.order[0]).astype(np.int64)
     aligned_depth = t[0:5, :-1].sum(axis=0).tolist()
     ins = t[N.KD_CH_INS_TOTAL].tolist()
     x_axis = list(range(1, len(aligned_depth) + 1))

@@ -194,9 +194,9 @@ def long_cases():
         if o[-1] in "M":
             qi += int(o[:-1])
     add("odd_base_inside_an_insertion_is_fine", 60, ops, None, s[:qi] + "N" + s[qi + 1:])
-    # k_long_expand takes a read in SEGMENTS of 512 CIGAR words, each from the state k_prep_long leaves in front of it (round 5):
-    # what may sit on a segment's edge -- insertions on one site on both sides of it, an insertion in front of the next segment's
-    # first run, deletions, the trailing clip as a segment's first op, a last segment that holds the terminator alone
+    # CIGARs of more than 512 words with something awkward around word 512 (round 5 expanded long reads by 512-word segments; that
+    # design was measured slower and dropped, the cases stay as long-CIGAR coverage): insertions on one site on both sides of the
+    # mark, an insertion in front of the run behind it, deletions across it, the trailing clip right behind it
     add("ins_pair_across_a_segment", 3, filler(511, random.Random(21)) + ["2I", "1P", "1I"] + filler(41, random.Random(22)))
     add("segment_ends_on_ins", 3, filler(511, random.Random(23)) + ["3I"] + filler(40, random.Random(24)))
     add("deletions_across_a_segment", 3, filler(510, random.Random(25)) + ["5D", "4D", "3M"] + filler(41, random.Random(26)))

@@ -65,7 +65,6 @@ def main():
     pinned = torch.empty(sum(int(l) + int(l) // 8 for l in lens) + 4096, dtype=torch.uint8, pin_memory=True).numpy()
     eng = N.Engine(lens, device=0)
     eng.set_shard(*ivs[r])
-    eng.set_step_graph(False)
     ptrs = synth.device_ptrs(sub)
     pad = shard.row_pad(eng, ivs[r], args.ranks, ivs)
 

@@ -61,7 +61,6 @@ def main():
                 eng.set_shard(*ivs[r])
             ptrs = synth.device_ptrs(sub)
 
-            eng.set_step_graph(False)      # the eager sequence: what a new batch takes (bench.py's `value`)
 
             # N > 1: the rank's exchange row registered with the engine, as bench.py --gpus N does (kd_set_exchange): the projected step
             # contains the row's copies and k_exchange_head -- everything of an N-GPU step but the collective itself

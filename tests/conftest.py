@@ -18,8 +18,9 @@ def _gpu_run(config):
 
 def pytest_runtest_logstart(nodeid, location):
     """On a GPU run the log names the test that is running BEFORE it runs (flushed): a HIP abort takes the
-    whole interpreter down, and the last line of the log must say where.  (-p no:faulthandler in pyproject.toml
-    keeps CPython's 5 KB extension-module dump from burying that line.)"""
+    whole interpreter down, and the last line of the log must say where.  (faulthandler is switched off for GPU runs only --
+    pytest_collection_modifyitems -- so that CPython's 5 KB extension-module dump does not bury that line; CPU runs keep it: a
+    native crash in the emulator or the decoder leaves its Python traceback.)"""
     if _GPU_RUN:
         sys.__stdout__.write("\n[gpu-test] %s " % nodeid)
         sys.__stdout__.flush()
@@ -29,12 +30,14 @@ _GPU_RUN = False
 
 
 def pytest_collection_modifyitems(config, items):
-    """GPU runs: tests that start other processes, replay graphs or exchange between ranks go last, so a fault
+    """GPU runs: tests that start other processes, or exchange between ranks go last, so a fault
     in the riskiest part of the runtime cannot erase the parity results in front of it."""
     global _GPU_RUN
     _GPU_RUN = _gpu_run(config)
     if not _GPU_RUN:
         return
+    import faulthandler
+    faulthandler.disable()
     risky = ("two_ranks", "executable", "subprocess", "graph", "multirank", "test_packaging", "integration_stub", "test_cli")
     items.sort(key=lambda it: any(w in it.nodeid.lower() for w in risky))
 

@@ -18,7 +18,12 @@ struct EmuRt {
     void shutdown() {}
     int n_cus() const { if (const char *e = getenv("KD_EMU_CUS")) return std::max(1, atoi(e)); return 2; }   // (256 = the launch geometry of an MI355X: idle workgroups, long grids)
     size_t free_bytes() { if (const char *e = getenv("KD_EMU_FREE_BYTES")) return (size_t)strtoull(e, nullptr, 10); return (size_t)1 << 40; }
-    void *alloc(size_t bytes) { return aligned_alloc(256, (bytes + 255) & ~size_t(255)); }
+    // KD_EMU_EXACT=1 (with the AddressSanitizer build, scripts/exp/asan_emu.sh): every "device" allocation has exactly the size asked
+    // for and the engine asks for exactly what it needs (kd_engine.h: ensure, push_device) -- the CPU counterpart of the product's
+    // KD_GUARD: an access past a buffer's end lands in the sanitizer's red zone instead of in head-room
+    bool exact = getenv("KD_EMU_EXACT") != nullptr;
+    void *alloc(size_t bytes, const char * = "") { return exact ? malloc(bytes ? bytes : 1) : aligned_alloc(256, (bytes + 255) & ~size_t(255)); }
+    bool exact_sizes() const { return exact; }
     void free(void *p) { ::free(p); }
     int memset(void *p, int v, size_t n) { ::memset(p, v, n); return 0; }
     int memset2d(void *p, size_t pitch, int v, size_t width, size_t height) {
@@ -46,17 +51,7 @@ struct EmuRt {
     int sync() { return 0; }
     std::vector<unsigned char> stage_buf;
     void *stage(size_t bytes) { if (stage_buf.size() < bytes) stage_buf.resize(bytes); return stage_buf.data(); }
-    bool is_pinned(const void *) { return true; }
-    std::vector<unsigned char> graph_buf;
-    void *graph_stage(size_t bytes) { if (graph_buf.size() < bytes) graph_buf.resize(bytes); return graph_buf.data(); }
     int d2h_async(void *h, const void *d, size_t n) { ::memcpy(h, d, n); return 0; }
-    // (no graphs here: kd_step always takes the eager path on the emulator)
-    bool graph_supported() const { return false; }
-    bool has_graph() const { return false; }
-    void graph_drop() {}
-    int capture_begin() { return 1; }
-    int capture_end(bool) { return 1; }
-    int graph_launch() { return 1; }
     template <class K, class... A>
     int launch(const char *name, K k, unsigned grid, unsigned block, size_t shmem, A... args) {
         static const bool trace = getenv("KD_EMU_TRACE") != nullptr;

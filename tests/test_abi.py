@@ -24,7 +24,7 @@ def test_library_exports_every_symbol():
     lib = N.default_library()
     for sym in header_symbols():
         assert hasattr(lib.dll, sym), sym
-    assert lib.dll.kd_abi_version() == 1
+    assert lib.dll.kd_abi_version() == 2
 
 
 def test_emulator_library_exports_the_same_abi(emu_lib):

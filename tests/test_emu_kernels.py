@@ -370,8 +370,7 @@ def test_config_as_virtual_shards_through_gather_and_assemble(emu_lib, lens, dep
 
 
 def test_step_equals_the_classic_sequence(emu_lib):
-    """kd_step = kd_reset + kd_push_batch_device + kd_finalize + kd_consensus_run + kd_consensus_fetch_all in one call (the
-    emulator has no graphs: always the eager sequence; the GPU suite checks the replay)."""
+    """kd_step = kd_reset + kd_push_batch_device + kd_finalize + kd_consensus_run + kd_consensus_fetch_all in one call."""
     batch = synth.to_numpy(synth.short_reads([4000, 1500], 20, seed=23))
     run = P.Run(emu_lib, batch)
     eng = N.Engine(batch["contig_lens"], lib=emu_lib)
@@ -380,8 +379,7 @@ def test_step_equals_the_classic_sequence(emu_lib):
         ptrs = {k: v.ctypes.data for k, v in arrs.items()}       # (on the emulator "device" memory is host memory)
         out = np.zeros(8192, np.uint8)
         for _ in range(2):
-            off, replayed = eng.step_device(ptrs, len(arrs["contig"]), arrs["seq4"].size, arrs["cigar"].size, out)
-            assert not replayed
+            off = eng.step_device(ptrs, len(arrs["contig"]), arrs["seq4"].size, arrs["cigar"].size, out)
             for cid in run.order:
                 assert out[int(off[cid]): int(off[cid + 1])].tobytes() == run.cns[cid][0]
                 assert np.array_equal(eng.tables(cid), run.tables[cid])
@@ -576,11 +574,13 @@ def test_consensus_over_hundreds_of_tiles_run_after_run(emu_lib):
         eng.close()
 
 
-def test_cold_records_riding_in_the_window_launch(emu_lib, monkeypatch):
-    """KD_COLD_TAIL=1 (opt-in, round 5): the clip counters and insertion events of the clipped / inserted reads are done by workgroups
-    appended to k_window's launch instead of k_cold_lane's own -- same tables, insertion dicts and consensus; also with bad bases
-    (the error classification is then a launch of its own) and for an unsorted batch (which keeps the separate launch)."""
-    monkeypatch.setenv("KD_COLD_TAIL", "1")
+@pytest.mark.parametrize("cold_tail", ["1", "0"])
+def test_cold_records_riding_in_the_window_launch(emu_lib, monkeypatch, cold_tail):
+    """KD_COLD_TAIL (default 1 since round 6): the clip counters and insertion events of the clipped / inserted reads are done by
+    workgroups appended to k_window's launch -- or, with 0, by k_cold_lane's own launch: same tables, insertion dicts and consensus
+    either way; also with bad bases (with the tail the error classification is a launch of its own) and for an unsorted batch
+    (which always keeps the separate launch)."""
+    monkeypatch.setenv("KD_COLD_TAIL", cold_tail)
     batch = synth.to_numpy(synth.short_reads([9000, 2500], 60, seed=14, clip_p=0.3, indel_p=0.3))
     P.assert_matches_oracle(P.Run(emu_lib, batch))
     P.assert_matches_oracle(P.Run(emu_lib, batch, window=128, slice_reads=64, n_pushes=3))

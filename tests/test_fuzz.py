@@ -56,9 +56,9 @@ def test_fuzz_long_cigars_emulated(emu_lib):
 
 
 def test_fuzz_long_cigars_of_several_segments_emulated(emu_lib):
-    """Round 5: k_long_expand takes a read in SEGMENTS of 512 CIGAR words, each from the state k_prep_long left in front of it --
-    reads of up to 2 600 words: segment boundaries inside insertion runs, deletions, in front of the trailing clip; neighbouring
-    segments meeting inside one row dword."""
+    """Very long CIGARs (480 - 2 600 words: dozens of k_long_expand's 64-op tiles per read) with insertion runs, deletions and the
+    trailing clip anywhere in them.  (Written for round 5's expansion by 512-word segments, which was measured slower and dropped --
+    profiles/r05_long_expand_segments_nogo.json; kept as long-CIGAR coverage: kd_long.h has no segments.)"""
     assert _long_campaign(emu_lib, range(310, 316), n_reads=30, long_ops=(480, 2600), contig_lens=(30000, 14000)) >= 8
 
 

@@ -463,7 +463,7 @@ def test_bench_two_ranks_on_one_gpu_same_fasta():
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    common = ["--steps", "2", "--warmup", "1", "--scale", "0.05", "--no-cpu-baseline", "--e2e-scale", "0", "--no-graph"]
+    common = ["--steps", "2", "--warmup", "1", "--scale", "0.05", "--no-cpu-baseline", "--e2e-scale", "0"]
     one = subprocess.run([sys.executable, "bench.py"] + common, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -495,10 +495,12 @@ def test_streamed_ingest_many_small_batches(hip_lib, tmp_path, key, chunk):
     assert [c.sequence for c in ra.consensuses] == [g["consensus"] for g in GOLD[key]["contigs"]]
 
 
-def test_cold_records_riding_in_the_window_launch_gpu(hip_lib, monkeypatch):
-    """KD_COLD_TAIL=1 (opt-in): k_cold_lane's work as workgroups behind k_window's persistent ones -- every table, insertion dict and
-    consensus of a clip- and indel-rich batch and of C2 at full size against the oracle; the reference's exceptions still surface."""
-    monkeypatch.setenv("KD_COLD_TAIL", "1")
+@pytest.mark.parametrize("cold_tail", ["1", "0"])
+def test_cold_records_riding_in_the_window_launch_gpu(hip_lib, monkeypatch, cold_tail):
+    """KD_COLD_TAIL (default 1 since round 6): k_cold_lane's work as workgroups behind k_window's persistent ones, or (0) as a launch
+    of its own -- every table, insertion dict and consensus of a clip- and indel-rich batch and of C2 against the oracle either
+    way; the reference's exceptions still surface."""
+    monkeypatch.setenv("KD_COLD_TAIL", cold_tail)
     batch = synth.to_numpy(synth.short_reads([90000, 25000], 300, seed=15, clip_p=0.3, indel_p=0.3))
     run = P.Run(hip_lib, batch)
     assert run.info["windowed"] == 1
@@ -511,23 +513,17 @@ def test_cold_records_riding_in_the_window_launch_gpu(hip_lib, monkeypatch):
                 P.Run(hip_lib, P.sam_to_batch(QUIRKS[key]["sam"]), window=64)
 
 
-def _step_sequence(lib, graph):
+def _step_sequence(lib):
     """kd_step over one resident batch, step after step, every step's consensus and tables against the oracle: the same batch
-    again, bases changed in place under the same pointers, a CIGAR changed in place so that the event counts move.  graph=False:
-    the eager sequence every time (the product's default).  graph=True (kd_set_step_graph(1), opt-in): the first REPEAT on the same
-    resident batch is also captured, later repeats replay the hipGraph; changed bases (no host decision depends on them) -> the
-    replay must still be exact for the NEW data or the verification must notice; changed event counts -> the verification notices
-    and the eager sequence runs."""
+    again, bases changed in place under the same pointers, a CIGAR changed in place so that the event counts move."""
     import torch
     tb = synth.short_reads([120_000, 30_000], 40, seed=31, device="cuda:0")
     eng = N.Engine(tb["contig_lens"], lib=lib)
-    eng.set_step_graph(graph)
     out = torch.empty(400_000, dtype=torch.uint8, pin_memory=True).numpy()
 
-    def check(expect_replay):
-        print("  [step test] graph =", graph, "expecting replay =", expect_replay, flush=True)      # (a GPU fault takes the interpreter down: the log says which step)
-        off, replayed = eng.step_device(synth.device_ptrs(tb), tb["contig"].numel(), tb["seq4_bytes"], tb["cigar_words"], out)
-        assert expect_replay is None or replayed == (expect_replay and graph)
+    def check():
+        torch.cuda.synchronize()      # (the library runs on its own stream: torch's writes to the batch must have landed)
+        off = eng.step_device(synth.device_ptrs(tb), tb["contig"].numel(), tb["seq4_bytes"], tb["cigar_words"], out)
         host = synth.to_numpy(tb)
         for cid in ko.contig_order(host):
             oa = ko.parse_records(host, cid)
@@ -537,24 +533,15 @@ def _step_sequence(lib, graph):
         return off
 
     try:
-        check(False)
-        check(False)
-        check(True)
-        check(True)
-        eng.set_step_graph(False)       # the eager sequence only (what bench.py times as `value`)
-        check(False)
-        eng.set_step_graph(graph)
-        check(False)
-        check(True)
-        # new bases under the same pointers: a replay runs the right kernels on the new data, but what it hands back from its
-        # record (offsets, depth ranges) may no longer be true -- the verification compares them with the device's and decides;
-        # either way the results must be those of the NEW data, and the step after is a replay again
+        for _ in range(4):
+            check()
+        # new bases under the same pointers
         nib = torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device="cuda:0")
         r = torch.randint(0, 4, (tb["seq4_bytes"],), device="cuda:0")
         tb["seq4"][: tb["seq4_bytes"]] = (nib[r] << 4) | nib[(r + 1) % 4]
-        check(None)
-        check(True)
-        # one insertion less (the I of a 5-op read S M I M S becomes an M): the event count changes -> eager, then captured again
+        check()
+        check()
+        # one insertion less (the I of a 5-op read S M I M S becomes an M): the event count changes
         ncig = tb["n_cig"].cpu().numpy()
         i = int(np.flatnonzero(ncig == 5)[0]) if (ncig == 5).any() else None
         if i is not None:
@@ -563,24 +550,13 @@ def _step_sequence(lib, graph):
             ln, op = w >> 4, w & 15
             if op != 2:         # (a deletion -> insertion of the same length would leave a read whose query no longer adds up: skipped)
                 tb["cigar"][co + 2] = (ln << 4) | 0
-                check(False)
-                check(True)
+                check()
+                check()
     finally:
         eng.close()
 
 
 def test_step_repeats_and_inputs_changed_in_place(hip_lib):
-    """kd_step, the product's default (eager) sequence: see _step_sequence."""
-    _step_sequence(hip_lib, graph=False)
-
-
-def test_step_graph_replay_is_verified_in_a_fresh_process():
-    """kd_step with the opt-in hipGraph replay (kd_set_step_graph(1)): see _step_sequence.  In a process of its own: on this stack
-    (ROCm 7.2, MI355X) a replay on changed inputs died with a GPU memory fault at the end of a long-lived process -- this suite --
-    where the same launches submitted one by one (KD_STEP_REPLAY_EAGER=1) ran clean, and a GPU fault takes the whole interpreter
-    down (gpurun_out/graph_hunt of round 5); which is why the replay is opt-in and the eager sequence the default."""
-    env = dict(os.environ, PYTHONPATH=ROOT)
-    r = subprocess.run([sys.executable, "-c", "from tests import test_gpu_parity as T; from kindel_amd import _native as N; "
-                        "T._step_sequence(N.default_library(), graph=True); print('GRAPH-REPLAY-OK')"],
-                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert r.returncode == 0 and "GRAPH-REPLAY-OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    """kd_step: see _step_sequence.  (Rounds 3 - 5 also had an opt-in hipGraph replay of a repeated step and its test here; removed in
+    round 6 with the replay: DESIGN section 3.)"""
+    _step_sequence(hip_lib)

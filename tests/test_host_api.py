@@ -217,3 +217,63 @@ def test_cli_refuses_more_ranks_than_gpus(tmp_path):
     p = subprocess.run([sys.executable, "-m", "kindel_amd", "consensus", "--gpus", str(max(n, 2)), str(tmp_path / "x.bam")],
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert p.returncode == 2 and p.stdout == "" and "GPU(s) visible" in p.stderr
+
+
+@pytest.mark.parametrize("header", ["@SQ\tSN:a\tLN:30\n@SQ\tSN:b\tLN:12\n", "@HD\tVN:1.6\n"])
+def test_header_only_input_gives_an_empty_result(api_on_emu, tmp_path, header):
+    """A header and no records (with and without @SQ lines), as a file and through a pipe: parse_bam returns {} (kindel.py:143-152) and
+    bam_to_consensus an empty result -- there is no context to close (round 5's `finally: pl.engine.close()` raised AttributeError
+    here), and weights() / variants() hand back empty frames."""
+    import threading
+    from kindel_amd import kindel as K
+    p = tmp_path / "h.sam"
+    p.write_text(header)
+    for realign in (False, True):
+        r = K.bam_to_consensus(str(p), realign=realign)
+        assert r.consensuses == [] and r.refs_changes == {} and r.refs_reports == {}
+    assert K.parse_bam(str(p)) == {}
+    assert len(K.weights(str(p))) == 0 and len(K.variants(str(p))) == 0
+    fifo = str(tmp_path / "in.fifo")
+    os.mkfifo(fifo)
+
+    def feed():
+        with open(fifo, "w") as out:
+            out.write(header)
+    th = threading.Thread(target=feed, daemon=True)
+    th.start()
+    r = K.bam_to_consensus(fifo)
+    th.join(timeout=30)
+    assert not th.is_alive() and r.consensuses == []
+
+
+def test_contexts_are_released_without_the_cycle_collector(api_on_emu, tmp_path):
+    """weights() / features() / variants() / bam_to_consensus() close their context before they return; parse_bam()'s alignments keep
+    theirs alive exactly as long as one of them lives -- by reference count, no cycle for the collector to find (round 5: the
+    alignments referred back to a Pileup that cached them)."""
+    import gc
+    import weakref
+    from kindel_amd import kindel as K
+    from kindel_amd import _native as N
+    p = _bam(tmp_path, "bwa_mem__1.1.sub_test", 400)
+    made = []
+    real_init = N.Engine.__init__
+
+    def spy(self, *a, **k):
+        real_init(self, *a, **k)
+        made.append(weakref.ref(self))
+    N.Engine.__init__ = spy
+    gc.disable()
+    try:
+        K.weights(p); K.features(p); K.variants(p); K.bam_to_consensus(p, realign=True)
+        assert len(made) == 4 and all(r() is None or r()._h is None for r in made)      # closed (or gone) on return
+        alns = K.parse_bam(p)
+        eng = made[-1]()
+        assert eng is not None and eng._h is not None
+        one = next(iter(alns.values()))
+        seq, _ = K.consensus_sequence(one.weights, one.insertions, one.deletions, None, False, 1, False)     # needs the device tables
+        assert len(seq) > 0
+        del eng, one, alns
+        assert made[-1]() is None                                                       # freed by reference count alone
+    finally:
+        gc.enable()
+        N.Engine.__init__ = real_init
