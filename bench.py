@@ -65,6 +65,10 @@ def main():
                          "are permuted, every read's bases / CIGAR stay where the sorted batch had them (rounds 1 - 2; a layout no file produces)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=0.0, help="fraction of reads for the CPU baseline (0 = auto)")
+    ap.add_argument("--rccl-at-1", action="store_true",
+                    help="N = 1 only: initialise torch.distributed with backend nccl (= RCCL) at world size 1, register the exchange row and run the step's "
+                         "all-gather on it every step -- the N-GPU code path (kd_set_exchange + ncclAllGather on device rows) on the one GPU a gpurun box "
+                         "has; the FASTA of the line is the one assembled from the gathered row")
     ap.add_argument("--no-graph", action="store_true", help="(accepted and ignored: older command lines; the hipGraph replay of rounds 3 - 5 is gone)")
     ap.add_argument("--e2e-scale", type=float, default=0.1, help="N = 1: depth scale of the live end-to-end leg (BAM file -> FASTA; 0 = skip)")
     args = ap.parse_args()
@@ -84,8 +88,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev_index = local_rank % max(1, torch.cuda.device_count())   # == local_rank on a node with >= N GPUs
-    if world > 1:
+    coll = world > 1 or args.rccl_at_1      # the step ends with the exchange collective
+    if args.rccl_at_1 and (world != 1 or args.backend != "nccl"):
+        raise SystemExit("bench.py: --rccl-at-1 is for N = 1 with the nccl backend")
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
@@ -160,7 +168,7 @@ def main():
         eng = N.Engine(np.asarray(contig_lens, np.uint32), device=dev_index, mode=mode)
         if args.window or args.slice:
             eng.set_tuning(args.window, args.slice)
-        if world > 1 and intervals is None:
+        if coll and intervals is None:
             intervals = shard.partition(contig_lens, world)
         interval = intervals[rank] if world > 1 else (0, eng.total_sites())
         ptrs = synth.device_ptrs(batch)
@@ -176,7 +184,7 @@ def main():
         state = {}
         # N > 1: the exchange row is registered with the engine (kd_set_exchange): kd_step leaves this rank's row -- header, contig
         # offsets, depth ranges, change codes, consensus bytes -- in device memory on its way, the step's collective is all that follows
-        exch = shard.Exchange(eng, interval, dev, intervals=intervals).attach() if world > 1 else None
+        exch = shard.Exchange(eng, interval, dev, intervals=intervals, force_collective=args.rccl_at_1).attach() if coll else None
 
         def step(classic=False):
             if classic:
@@ -192,7 +200,7 @@ def main():
                 off = eng.step_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"], pinned_np)
             seqs = [pinned_np[int(off[c]): int(off[c + 1])] for c in range(n_contigs)]
             # ... and, at N > 1, the all-gather that leaves the stitched consensus in every GPU's HBM
-            if world > 1:   # one fixed-size all-gather (RCCL over xGMI); the classic call sequence does not fill the row: on demand there
+            if coll:   # one fixed-size all-gather (RCCL over xGMI); the classic call sequence does not fill the row: on demand there
                 state["gathered"] = exch.run() if classic else exch.collect()
             return seqs
 
@@ -234,7 +242,7 @@ def main():
         dt = float(tmax[0].item())
         info = eng.batch_info()
         stats = eng.stats()
-        if world > 1:   # host assembly of the stitched FASTA, outside the timed region (checksum only)
+        if coll:   # host assembly of the stitched FASTA, outside the timed region (checksum only)
             assert exch.need(state["gathered"]) <= exch.pad, "an exchange row did not fit its agreed size"
             rows = np.ascontiguousarray(state["gathered"].cpu().numpy())
             seqs, _, _ = shard.assemble(rows, contig_lens, world, intervals=intervals)
@@ -266,6 +274,7 @@ def main():
                                 step_frac=round(B / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5))
             out = dict(
                 metric="aligned-base events/sec pileup+consensus", value=value, unit="events/s", n_gpus=world,
+                **(dict(rccl_at_1="every step ended with ncclAllGather (RCCL, world size 1) on the engine-written exchange row; this line's FASTA is assembled from the gathered row") if args.rccl_at_1 else {}),
                 steps=args.steps, warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, submission=submission,
                 scaling=scaling if world > 1 else "weak", vs_baseline=None, dtype="u32", data="synthetic",
                 config=dict(workload="%s: synthetic %s, %d contig(s), %d sites, depth %gx%s" % (
@@ -349,12 +358,9 @@ def main():
         print(json.dumps(out))
     if eng is not None:
         eng.close()
-    if world > 1:
+    if coll:
         dist.destroy_process_group()
     return
-    eng.close()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 def e2e_leg(config, scale):

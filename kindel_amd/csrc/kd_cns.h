@@ -202,10 +202,19 @@ __device__ __forceinline__ void kd_cns_fold_mm(const KdTileMM *tile_mm, kd_u64 n
 // depth ranges into the per-contig ranges on the way; k_cns_scan (one workgroup, 19 us on C3 for a prefix sum of 4 883 numbers,
 // most of it the dispatch and its dependent round trips) is only launched beyond that, where the quadratic sum would cost more.
 #define KD_CNS_SELF_SCAN 16384u
+// Round 6: the tile's bytes are STAGED in LDS and leave the workgroup as whole dwords -- to the device buffer and, when the caller's
+// output buffer is pinned host memory the device can address (host_out != NULL: kd_step / kd_finish), straight into it as well:
+// 64 lanes x 4 bytes = 256 contiguous bytes per store instruction, full lines on the host link, written WHILE the kernel runs.
+// The step's closing device-to-host copy of the FASTA (5 MB at C3: 90 us on the critical path behind a 44 us kernel) is gone;
+// bytes a thread used to store one by one (4 instructions touching the same 256 bytes) now cost one LDS write each.
+// A tile whose bytes do not fit the stage (insertions of thousands of bases) takes the byte-by-byte path, both destinations.
+#define KD_CNS_STAGE 2048u      // bytes of LDS staging per workgroup: a tile is 1024 sites + its insertion texts
 __global__ void __launch_bounds__(KD_BLOCK)
 k_cns_emit(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, const kd_u64 *tile_sum, const kd_u64 *tile_off, const KdTileMM *tile_mm,
-           uint32_t *depth_minmax, uint8_t *out, uint8_t *changes, kd_u64 *contig_off, uint32_t n_contigs, kd_u64 *patch_off) {
+           uint32_t *depth_minmax, uint8_t *out, uint8_t *changes, kd_u64 *contig_off, uint32_t n_contigs, kd_u64 *patch_off,
+           uint8_t *host_out, kd_u64 host_cap) {
     __shared__ kd_u64 s_wave[KD_WAVES_PER_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[KD_CNS_STAGE];
     const uint32_t t = threadIdx.x;
     const kd_u64 tile0 = (tile_first + blockIdx.x) * KD_CNS_TILE;
     const kd_u64 g0 = tile0 + (kd_u64)t * KD_CNS_PER_THREAD;
@@ -226,8 +235,16 @@ k_cns_emit(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, const kd_u64 *tile_s
     kd_u64 tile_total;
     const kd_u64 incl = kd_block_scan_incl((kd_u64)sum, s_wave, tile_total);   // __shfl_up scans, two barriers
     if (blockIdx.x == gridDim.x - 1 && t == 0) contig_off[n_contigs] = base + tile_total;   // total length, next to the per-contig offsets
+    const bool staged = tile_total <= KD_CNS_STAGE;      // (uniform over the workgroup)
     kd_u64 o = base + incl - sum;
     const char lower[17] = "=acmgrsvtwyhkdbn";
+    // one output byte: into the stage (tile-relative) or, for a tile too long for it, to its final places
+#define KD_CNS_PUT(off, v)                                                                         \
+    {                                                                                              \
+        const kd_u64 off_ = (off); const uint8_t v_ = (uint8_t)(v);                                \
+        if (staged) s_stage[(uint32_t)(off_ - base)] = v_;                                         \
+        else { out[off_] = v_; if (host_out && off_ < host_cap) host_out[off_] = v_; }             \
+    }
     // the thread's four change codes as one store (g0 is a multiple of 4, S a multiple of 1024, the array 4-byte aligned)
     if (g0 < T.sites)
         *reinterpret_cast<uint32_t *>(changes + g0) = (uint32_t)s[0].change | (uint32_t)s[1].change << 8 | (uint32_t)s[2].change << 16 | (uint32_t)s[3].change << 24;
@@ -242,12 +259,31 @@ k_cns_emit(KdTabs T, KdCns C, KdIns ins, kd_u64 tile_first, const kd_u64 *tile_s
         for (uint32_t pk = 0; pk < C.n_patches; pk++) if (C.patch_start[pk] == g) patch_off[pk] = o;
         if (s[k].ins == 1) {
             const uint8_t *p = ins.pool + ins.ev_off[s[k].ins_ev];
-            for (uint32_t b = 0; b < s[k].ins_len; b++) out[o + b] = (uint8_t)lower[p[b] & 15];  // .lower(), :421
+            for (uint32_t b = 0; b < s[k].ins_len; b++) KD_CNS_PUT(o + b, lower[p[b] & 15])  // .lower(), :421
             o += s[k].ins_len;
         } else if (s[k].ins == 2) {
-            out[o++] = 'N';
+            KD_CNS_PUT(o, 'N')
+            o++;
         }
-        if (s[k].has_base) out[o++] = s[k].base;
+        if (s[k].has_base) { KD_CNS_PUT(o, s[k].base) o++; }
+    }
+#undef KD_CNS_PUT
+    if (!staged) return;      // (uniform)
+    __syncthreads();
+    // the stage -> [base, base + tile_total) of both destinations: bytes up to the first 4-byte boundary of the DESTINATION and behind the
+    // last one singly, whole dwords in between (a dword of the stage sits at any byte offset: four LDS byte reads)
+    const uint32_t n = (uint32_t)tile_total;
+    const uint32_t head = (uint32_t)((4u - (uint32_t)(base & 3u)) & 3u) < n ? (uint32_t)((4u - (uint32_t)(base & 3u)) & 3u) : n;
+    const uint32_t n_dw = (n - head) >> 2, tail0 = head + 4u * n_dw;
+    if (t < head) { out[base + t] = s_stage[t]; if (host_out && base + t < host_cap) host_out[base + t] = s_stage[t]; }
+    if (t < n - tail0) { const kd_u64 a = base + tail0 + t; out[a] = s_stage[tail0 + t]; if (host_out && a < host_cap) host_out[a] = s_stage[tail0 + t]; }
+    for (uint32_t j = t; j < n_dw; j += KD_BLOCK) {
+        const uint32_t so = head + 4u * j;
+        const uint32_t v = (uint32_t)s_stage[so] | (uint32_t)s_stage[so + 1] << 8 | (uint32_t)s_stage[so + 2] << 16 | (uint32_t)s_stage[so + 3] << 24;
+        const kd_u64 a = base + so;
+        *reinterpret_cast<uint32_t *>(out + a) = v;
+        if (host_out && a + 4 <= host_cap) *reinterpret_cast<uint32_t *>(host_out + a) = v;
+        else if (host_out) for (uint32_t b = 0; b < 4 && a + b < host_cap; b++) host_out[a + b] = (uint8_t)(v >> (8 * b));
     }
     (void)n_contigs;
 }

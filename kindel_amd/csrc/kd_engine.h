@@ -129,6 +129,7 @@ struct KdEngine {
         if (rt.init(device, stream)) return hipfail("kd_create: device init");
         if (const char *e = getenv("KD_COLD_TAIL")) knob_cold_tail = atoi(e) != 0;
         if (const char *e = getenv("KD_INS_SITE_FLAGS")) knob_ins_site_flags = atoi(e) != 0;
+        if (const char *e = getenv("KD_ZERO_COPY")) knob_zero_copy = atoi(e) != 0;
         n_contigs = n;
         clen.assign(lens, lens + n);
         cbase.resize(n);
@@ -1018,7 +1019,9 @@ struct KdEngine {
     // once the caller has copied it back (consensus_run: its own copy; kd_step: together with the status words and the FASTA).
     uint64_t cns_tile_first = 0, cns_tiles = 0, cns_cap = 0;
     uint32_t cns_patches = 0;
-    int consensus_launch(uint32_t min_depth, uint32_t n_patches, const uint64_t *ps, const uint64_t *pe) {
+    // host_out (may be NULL): the caller's output buffer as the DEVICE addresses it (pinned host memory, Rt::device_view): k_cns_emit
+    // then stores the consensus bytes there as well, as it emits them (kd_cns.h) -- no device-to-host copy behind the kernel
+    int consensus_launch(uint32_t min_depth, uint32_t n_patches, const uint64_t *ps, const uint64_t *pe, uint8_t *host_out = nullptr, uint64_t host_cap = 0) {
         int rc;
         const uint64_t tile_first = g_lo / KD_CNS_TILE;
         const uint64_t n_tiles = std::max<uint64_t>(1, (std::min<uint64_t>(S, g_hi) + KD_CNS_TILE - 1) / KD_CNS_TILE - tile_first);
@@ -1058,7 +1061,7 @@ struct KdEngine {
             return hipfail("k_cns_scan");
         if (rt.launch("k_cns_emit", k_cns_emit, (unsigned)n_tiles, KD_BLOCK, 0, T, C, I, (kd_u64)tile_first, (const kd_u64 *)b_tilesum.p,
                       self_scan ? (const kd_u64 *)nullptr : (const kd_u64 *)b_tileoff.p, (const KdTileMM *)b_tilemm.p, meta_mm(),
-                      (uint8_t *)b_cns.p, (uint8_t *)b_changes.p - alloc_lo, meta_coff(), n_contigs, d_poff))
+                      (uint8_t *)b_cns.p, (uint8_t *)b_changes.p - alloc_lo, meta_coff(), n_contigs, d_poff, host_out, (kd_u64)host_cap))
             return hipfail("k_cns_emit");
         h_pstart.assign(ps, ps + n_patches);
         h_poff.assign(n_patches, ~0ULL);
@@ -1185,10 +1188,13 @@ struct KdEngine {
     // kd_consensus_run + kd_consensus_fetch_all are three blocking read-backs and two more for the bytes.)
     int finish(uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint64_t *contig_off) {
         int rc;
-        if ((rc = finalize_launch()) || (rc = consensus_launch(min_depth, 0, nullptr, nullptr))) return rc;
+        // a pinned seq_out the device can address: the consensus kernel writes the bytes there itself (round 6; the copy behind the
+        // kernel was 90 us of C3's step).  Pageable memory (a numpy array of the API path) keeps the copy.
+        uint8_t *zc = (seq_out && knob_zero_copy && !(reinterpret_cast<uintptr_t>(seq_out) & 3u)) ? (uint8_t *)rt.device_view(seq_out) : nullptr;
+        if ((rc = finalize_launch()) || (rc = consensus_launch(min_depth, 0, nullptr, nullptr, zc, cap))) return rc;
         const size_t mb = meta_bytes();
         const uint64_t shard_sites = std::min<uint64_t>(S, g_hi) - std::min<uint64_t>(S, g_lo);
-        uint64_t guess = seq_out ? std::min<uint64_t>(std::min<uint64_t>(cap, cns_cap), shard_sites + 4096) : 0;
+        uint64_t guess = (seq_out && !zc) ? std::min<uint64_t>(std::min<uint64_t>(cap, cns_cap), shard_sites + 4096) : 0;
         uint8_t *st = (uint8_t *)rt.stage(KDS_COUNT * 8 + mb);
         if (!st) return hipfail("kd_finish: pinned staging");
         if (exch_row && (rc = exchange_queue(exch_row, exch_cap, std::min<uint64_t>(cns_cap, shard_sites + 4096)))) return rc;
@@ -1201,7 +1207,7 @@ struct KdEngine {
         if ((rc = finalize_check(nullptr, &redone))) return rc;
         if (redone) {     // a hash collision was repaired (never seen outside the tests): the consensus once more, read back on its own
             if ((rc = consensus_run(min_depth, 0, nullptr, nullptr))) return rc;
-            guess = 0;
+            guess = 0; zc = nullptr;
             if (exch_row && ((rc = exchange_queue(exch_row, exch_cap, h_coff[n_contigs])) || (rc = exchange_rest(exch_row, exch_cap, nullptr)))) return rc;     // (the row once more)
         } else if ((rc = consensus_collect(meta))) return rc;
         else if (exch_row && h_coff[n_contigs] > exch_cns_queued && (rc = exchange_rest(exch_row, exch_cap, nullptr))) return rc;
@@ -1210,11 +1216,12 @@ struct KdEngine {
         if (contig_off) for (uint32_t c = 0; c <= n_contigs; c++) contig_off[c] = h_coff[c] - o0;
         if (seq_out) {
             if (o1 - o0 > cap) return fail(KD_E_ARG, "kd_finish: buffer too small");
-            if (o1 > guess && rt.d2h((uint8_t *)seq_out + guess, (uint8_t *)b_cns.p + guess, o1 - guess)) return hipfail("consensus fetch: d2h");
+            if (!zc && o1 > guess && rt.d2h((uint8_t *)seq_out + guess, (uint8_t *)b_cns.p + guess, o1 - guess)) return hipfail("consensus fetch: d2h");
         }
         return KD_OK;
     }
 
+    bool knob_zero_copy = true;       // KD_ZERO_COPY=0 (tests, measurement): kd_step / kd_finish copy the FASTA behind the consensus kernel even into pinned memory
     int knob_ins_site_flags = -1;     // KD_INS_SITE_FLAGS=0 / 1 (tests, measurement): the insertion reduction's site test per event / once per site, whatever the counts
     bool knob_cold_tail = true;       // the cold records' workgroups ride in k_window's launch (kd_window.h: KdColdTail) instead of k_cold_lane's own: the memory-bound
                                       // cold work fills the launch's tail (round 5: step -1.6 % on C3, -2.4 % on C4, bit-exact; default since round 6).  KD_COLD_TAIL=0:

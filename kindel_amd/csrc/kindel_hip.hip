@@ -135,7 +135,12 @@ struct HipRt {
                     abort();
                 }
         }
-        (void)hipMemUnmap(r.map_at, r.map_bytes); (void)hipMemRelease(r.h); (void)hipMemAddressFree(r.va, r.va_bytes);
+        // The memory goes back, the ADDRESS RANGE does not (no hipMemAddressFree): on this stack (ROCm 7.2, MI355X) a range that is
+        // reserved, mapped, unmapped, freed and handed out again shows kernels the wrong pages -- scripts/exp/vmm_tlb_check.hip: stale
+        // reads in 299 of 300 rounds with hipMemMap, none with hipMalloc / hipFree (profiles/r06_guard_vmm_address_reuse.txt); KD_GUARD's
+        // first version "caught" exactly that.  A range that stays reserved and unmapped also turns every use of a freed buffer into a
+        // fault.  (47 bits of address space: a test run reserves a few hundred GB of it.)
+        (void)hipMemUnmap(r.map_at, r.map_bytes); (void)hipMemRelease(r.h);
     }
     bool exact_sizes() const { return guard != 0; }
     void *alloc(size_t bytes, const char *tag = "") {
@@ -210,6 +215,18 @@ struct HipRt {
         if (bad(hipHostMalloc(&stage_buf, n, hipHostMallocDefault))) { stage_buf = nullptr; return nullptr; }
         stage_cap = n;
         return stage_buf;
+    }
+
+    // host memory as the device addresses it: pinned memory the runtime knows (hipHostMalloc / hipHostRegister; torch's pin_memory) -> its
+    // device pointer, anything else (pageable) -> NULL
+    void *device_view(void *host) {
+        if (!host || bad(hipSetDevice(dev))) return nullptr;
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (a.type != hipMemoryTypeHost) return nullptr;
+        void *d = nullptr;
+        if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return d;
     }
 
     // small readbacks (the status words, one cache line each: 4 KiB, 5 KiB in a profiling build) go through a pinned bounce buffer:

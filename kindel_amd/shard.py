@@ -209,22 +209,25 @@ class Exchange:
     demand (run()), or on the way of kd_finish / kd_step once attach()ed, so that a multi-GPU step is kd_step + ONE collective
     (RCCL over xGMI when the backend is "nccl") and no torch kernel, upload or read-back besides.  Everything stays on `device`."""
 
-    def __init__(self, engine, interval, device, group=None, pad=None, intervals=None):
+    def __init__(self, engine, interval, device, group=None, pad=None, intervals=None, force_collective=False):
         import torch
         import torch.distributed as dist
         self.engine, self.interval, self.device, self.group = engine, interval, device, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force_collective: run the all-gather even in a group of ONE rank (bench.py --rccl-at-1, the GPU suite: the RCCL call on a
+        # device row on the one GPU a test box has)
+        self.collective = self.world > 1 or (bool(force_collective) and dist.is_initialized())
         self.pad = int(pad) if pad is not None else row_pad(engine, interval, self.world, intervals)
         # the row lives where the ENGINE's memory is (it writes it with device-to-device copies and a kernel); the collective runs on
         # `device`: the same memory under RCCL, host tensors under gloo (a CLI run with KINDEL_DIST_BACKEND=gloo, the CPU tests) --
         # then the row is copied over in front of the collective
         mem = engine.memory_device
         self.row = torch.empty(self.pad, dtype=torch.uint8, device=mem)
-        self.staged = self.world > 1 and torch.empty(0, device=mem).device != torch.empty(0, device=device).device
+        self.staged = self.collective and torch.empty(0, device=mem).device != torch.empty(0, device=device).device
         self.row_coll = torch.empty(self.pad, dtype=torch.uint8, device=device) if self.staged else self.row
-        self.rows = torch.empty(self.world * self.pad, dtype=torch.uint8, device=device) if self.world > 1 else self.row
+        self.rows = torch.empty(self.world * self.pad, dtype=torch.uint8, device=device) if self.collective else self.row
         self.attached = False
-        self._cuda = self.world > 1 and torch.device(device).type == "cuda"
+        self._cuda = self.collective and torch.device(device).type == "cuda"
 
     def attach(self):
         """From now on kd_finish / kd_step (Engine.finish / step_device) leave the row behind: collect() is the collective alone."""
@@ -243,7 +246,7 @@ class Exchange:
         """The ONE data collective over rows the engines have already written -> uint8 tensor [world, pad] (on `device`)."""
         import torch
         import torch.distributed as dist
-        if self.world > 1:
+        if self.collective:
             if self.staged:
                 self.row_coll.copy_(self.row)
             dist.all_gather_into_tensor(self.rows, self.row_coll, group=self.group)

@@ -52,6 +52,7 @@ struct EmuRt {
     std::vector<unsigned char> stage_buf;
     void *stage(size_t bytes) { if (stage_buf.size() < bytes) stage_buf.resize(bytes); return stage_buf.data(); }
     int d2h_async(void *h, const void *d, size_t n) { ::memcpy(h, d, n); return 0; }
+    void *device_view(void *host) { return getenv("KD_EMU_NO_PINNED") ? nullptr : host; }      // (every host buffer is "pinned" here: the zero-copy path of kd_step / kd_finish runs in the CPU tests)
     template <class K, class... A>
     int launch(const char *name, K k, unsigned grid, unsigned block, size_t shmem, A... args) {
         static const bool trace = getenv("KD_EMU_TRACE") != nullptr;

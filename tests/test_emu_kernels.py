@@ -610,3 +610,35 @@ def test_insertion_site_test_per_event_and_per_site(emu_lib, monkeypatch, site_f
     lb = synth.to_numpy(synth.long_reads([60000], 6, seed=3))
     P.assert_matches_oracle(P.Run(emu_lib, lb))
     _finish_vs_classic(emu_lib, batch)
+
+
+@pytest.mark.parametrize("zero_copy", ["1", "0"])
+def test_finish_writes_the_fasta_itself_or_copies_it(emu_lib, monkeypatch, zero_copy):
+    """Round 6: with a pinned output buffer (on the emulator every host buffer counts as pinned) k_cns_emit stores the consensus bytes
+    straight into it -- staged per tile in LDS, whole dwords -- and kd_finish / kd_step copy nothing behind the kernel; KD_ZERO_COPY=0
+    (and any pageable buffer on the GPU) keeps the copy.  Same bytes either way: reference fixtures, many small tiles' worth of
+    contigs, an insertion longer than the stage, and a buffer that is too small (refused, nothing written past its end)."""
+    import random
+    monkeypatch.setenv("KD_ZERO_COPY", zero_copy)
+    _finish_vs_classic(emu_lib, P.load_fixture("bwa_mem__1.1.sub_test"), window=256)
+    _finish_vs_classic(emu_lib, P.load_fixture("minimap2__1.1.multi"), window=128, slice_reads=64, n_pushes=3)
+    P.assert_matches_oracle(_finish_vs_classic(emu_lib, synth.to_numpy(synth.short_reads([5000, 1023, 1025, 400, 3000], 30, seed=9, indel_p=0.4))))
+    rng = random.Random(12)
+    L = 2100
+    ref = "".join(rng.choice("ACGT") for _ in range(L))
+    ins = "".join(rng.choice("ACGT") for _ in range(2500))     # > KD_CNS_STAGE: its tile takes the byte-by-byte path
+    sam = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c\tLN:%d\n" % L
+    for k in range(5):
+        sam += "r%d\t0\tc\t1001\t60\t150M%dI150M\t*\t0\t0\t%s\t*\n" % (k, len(ins), ref[1000:1150] + ins + ref[1150:1300])
+    batch = P.sam_to_batch(sam)
+    run = _finish_vs_classic(emu_lib, batch)
+    assert len(run.cns[0][0]) == L + len(ins)
+    eng = N.Engine(batch["contig_lens"], lib=emu_lib)
+    try:
+        eng.push(batch)
+        out = np.full(4096 + 64, 0xEE, np.uint8)
+        with pytest.raises(N.KindelNativeError, match="buffer too small"):
+            eng.finish(out[:4096])
+        assert bool((out[4096:] == 0xEE).all())
+    finally:
+        eng.close()

@@ -560,3 +560,26 @@ def test_step_repeats_and_inputs_changed_in_place(hip_lib):
     """kd_step: see _step_sequence.  (Rounds 3 - 5 also had an opt-in hipGraph replay of a repeated step and its test here; removed in
     round 6 with the replay: DESIGN section 3.)"""
     _step_sequence(hip_lib)
+
+
+def test_bench_step_through_rccl_at_world_size_one():
+    """The N-GPU step on the one GPU a box has: `bench.py --gpus 1 --rccl-at-1` initialises torch.distributed with backend nccl (= RCCL)
+    at world size 1, registers the exchange row with the engine (kd_set_exchange) and ends every step with
+    dist.all_gather_into_tensor on that device row (shard.Exchange.collect) -- the collective of kindel_amd/shard.py executed by RCCL on
+    an MI355X, its result assembled into the same FASTA (sha256) as the plain single-GPU run."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--steps", "3", "--warmup", "1", "--scale", "0.05", "--no-cpu-baseline", "--e2e-scale", "0"]
+    one = subprocess.run([sys.executable, "bench.py"] + common, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env["NCCL_DEBUG"] = "INFO"
+    two = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--rccl-at-1"] + common, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-3000:]
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 1 and "rccl_at_1" in b and "rccl_at_1" not in a
+    assert b["fasta_sha256"] == a["fasta_sha256"] and b["consensus_len"] == a["consensus_len"]
+    log = two.stdout + two.stderr
+    assert "NCCL INFO" in log and ("RCCL" in log or "rccl" in log or "nranks 1" in log), log[-1500:]      # the library that ran is RCCL
