@@ -58,6 +58,7 @@ struct KdEngine {
     Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_rows, b_rowinfo, b_rowoff, b_longacc, b_coldcnt, b_coldev, b_coldpool;
     Buf b_stage[9];
     Buf b_gi_file, b_gi_blocks, b_gi_out, b_gi_bstat, b_gi_start, b_gi_cnt, b_gi_tot, b_gi_recat;   // device-side ingest (kd_ingest.h)
+    Buf b_gi_tok, b_gi_ntok;   // the two-pass inflate's token lists and their lengths (kd_gpu_inflate2.h)
     Buf b_sortrows, b_sortseg;   // unsorted input: per-workgroup bin counts / starts and their segment totals (kd_plan.h)
     Buf b_smallcig;   // a batch with fewer than 4 CIGAR words: its padded copy
     Buf b_srec;   // an unsorted batch's regular reads in window order: KdSortRec[] (k_sort_scatter_reads)
@@ -130,6 +131,7 @@ struct KdEngine {
         if (const char *e = getenv("KD_COLD_TAIL")) knob_cold_tail = atoi(e) != 0;
         if (const char *e = getenv("KD_INS_SITE_FLAGS")) knob_ins_site_flags = atoi(e) != 0;
         if (const char *e = getenv("KD_ZERO_COPY")) knob_zero_copy = atoi(e) != 0;
+        if (const char *e = getenv("KD_INFLATE")) knob_inflate = atoi(e) == 2 ? 2 : 1;
         n_contigs = n;
         clen.assign(lens, lens + n);
         cbase.resize(n);
@@ -172,7 +174,7 @@ struct KdEngine {
         for (Buf &b : b_stage) release(b);
         for (Buf &b : b_gin) release(b);
         release(b_srec); release(b_smallcig); release(b_sortrows); release(b_sortseg); release(b_longorder);
-        for (Buf *g : {&b_gi_file, &b_gi_blocks, &b_gi_out, &b_gi_bstat, &b_gi_start, &b_gi_cnt, &b_gi_tot, &b_gi_recat}) release(*g);
+        for (Buf *g : {&b_gi_file, &b_gi_blocks, &b_gi_out, &b_gi_bstat, &b_gi_start, &b_gi_cnt, &b_gi_tot, &b_gi_recat, &b_gi_tok, &b_gi_ntok}) release(*g);
         if (d_tab) rt.free(d_tab);
         if (d_clen) rt.free(d_clen);
         if (d_cbase) rt.free(d_cbase);
@@ -696,12 +698,17 @@ struct KdEngine {
         if (rt.sync()) return hipfail("ingest: sync");              // (the previous batch's kernels read the staging buffers)
         {   // the file, its inflated stream and the batch are all resident at once on this path: a file too big for that is the
             // streamed host decoder's (chunks of 64 MiB)
-            const uint64_t have = b_gi_file.cap + b_gi_out.cap, need = file_bytes + 2 * total_out;
+            const uint64_t have = b_gi_file.cap + b_gi_out.cap + b_gi_tok.cap, need = file_bytes + 2 * total_out + (knob_inflate == 2 ? 4 * (uint64_t)gi2_tok_off(total_out, n_blocks) : 0);
             const uint64_t free_now = rt.free_bytes();
             if (need > have && need - have > free_now / 10 * 8)
                 return fail(KD_E_UNSUPPORTED, "the file (" + std::to_string(file_bytes >> 20) + " MiB, " + std::to_string(total_out >> 20) +
                                                   " MiB inflated) does not fit the GPU's free memory at once: the streamed host decoder reads it");
         }
+        // KD_INFLATE=2 (round 6): the two-pass inflate (kd_gpu_inflate2.h: a LANE per block records the matches, a wavefront per block
+        // resolves them); 1: the one-pass kernel of rounds 3 - 5 (a wavefront per block).  The token lists: 4 / 3 of the inflated size
+        const bool two_pass = knob_inflate == 2;
+        const size_t tok_words = two_pass ? (size_t)gi2_tok_off(total_out, n_blocks) + 16 : 0;
+        if (two_pass && ((rc = ensure(b_gi_tok, tok_words * 4)) || (rc = ensure(b_gi_ntok, (size_t)n_blocks * 4)))) return rc;
         if ((rc = ensure(b_gi_file, file_bytes + 64)) || (rc = ensure(b_gi_blocks, (size_t)n_blocks * sizeof(GiBlock))) ||
             (rc = ensure(b_gi_out, total_out + 64)) || (rc = ensure(b_gi_bstat, (size_t)n_blocks * 4)) || (rc = ensure(b_gi_start, (size_t)n_blocks * 8)) ||
             (rc = ensure(b_gi_cnt, (size_t)n_blocks * 8 * 3)) || (rc = ensure(b_gi_tot, 64)))
@@ -723,8 +730,14 @@ struct KdEngine {
                 // one wavefront works ~20 ms on a block and launches on one stream run one after the other: a launch of fewer blocks
                 // than two rounds of the chip's slots (26 wavefronts per CU) leaves most of it idle for that long
                 if (e == next_block || (e < n_blocks && e - next_block < 52u * (uint32_t)rt.n_cus() && !getenv("KD_UPLOAD_CHUNK"))) return 0;
-                const int bad = rt.launch("k_gpu_inflate", k_gpu_inflate, e - next_block, KD_WAVE, 0, (const uint8_t *)b_gi_file.p, d_blocks + next_block, e - next_block,
-                                          (uint8_t *)b_gi_out.p, bstat + next_block);
+                const uint32_t cnt = e - next_block;
+                const int bad = two_pass
+                    ? (rt.launch("k_inflate_tokens", k_inflate_tokens, (cnt + 63u) / 64u, KD_WAVE, 0, (const uint8_t *)b_gi_file.p, d_blocks + next_block, cnt,
+                                 (uint8_t *)b_gi_out.p, (uint32_t *)b_gi_tok.p, (uint32_t *)b_gi_ntok.p + next_block, bstat + next_block, next_block) ||
+                       rt.launch("k_inflate_resolve", k_inflate_resolve, cnt, KD_WAVE, 0, d_blocks + next_block, cnt, (uint8_t *)b_gi_out.p,
+                                 (const uint32_t *)b_gi_tok.p, (const uint32_t *)b_gi_ntok.p + next_block, (const uint32_t *)(bstat + next_block), next_block))
+                    : rt.launch("k_gpu_inflate", k_gpu_inflate, cnt, KD_WAVE, 0, (const uint8_t *)b_gi_file.p, d_blocks + next_block, cnt,
+                                (uint8_t *)b_gi_out.p, bstat + next_block);
                 next_block = e;
                 return bad;
             };
@@ -1221,6 +1234,7 @@ struct KdEngine {
         return KD_OK;
     }
 
+    int knob_inflate = 1;             // KD_INFLATE=1 / 2: which GPU inflate the device-side ingest uses (ingest_bam)
     bool knob_zero_copy = true;       // KD_ZERO_COPY=0 (tests, measurement): kd_step / kd_finish copy the FASTA behind the consensus kernel even into pinned memory
     int knob_ins_site_flags = -1;     // KD_INS_SITE_FLAGS=0 / 1 (tests, measurement): the insertion reduction's site test per event / once per site, whatever the counts
     bool knob_cold_tail = true;       // the cold records' workgroups ride in k_window's launch (kd_window.h: KdColdTail) instead of k_cold_lane's own: the memory-bound

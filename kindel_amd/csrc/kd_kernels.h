@@ -27,8 +27,9 @@
 //   kd_errors.h   k_errors: which read / which reference exception (rare path; rides as k_cold_lane's last workgroup)
 //   kd_ins.h      k_ins_*: insertion events -> open-addressing hash multiset -> per-site unique max
 //   kd_cns.h      k_cns_*: per-site argmax / tie / indel rules, exclusive scan, byte emission
-//   kd_gpu_inflate.h, kd_ingest.h   the device-side ingest (opt-in): k_gpu_inflate (raw DEFLATE of BGZF blocks, one wavefront each),
-//                 k_bam_*: the BAM record chain walked from speculative, verified starts -> the kd_batch arrays in HBM
+//   kd_gpu_inflate.h, kd_gpu_inflate2.h, kd_ingest.h   the device-side ingest (opt-in): k_gpu_inflate (raw DEFLATE of BGZF blocks, one
+//                 wavefront each) or k_inflate_tokens + k_inflate_resolve (round 6: a lane per block records the matches, a wavefront per
+//                 block resolves them), k_bam_*: the BAM record chain walked from speculative, verified starts -> the kd_batch arrays in HBM
 //
 // The file has no host API calls and only uses __syncthreads + atomics across lanes, so
 // tests/emu/ can execute the same source on the CPU for logic checks (test infrastructure).
@@ -45,3 +46,4 @@
 #include "kd_ins.h"
 #include "kd_cns.h"
 #include "kd_ingest.h"
+#include "kd_gpu_inflate2.h"

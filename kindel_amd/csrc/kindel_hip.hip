@@ -87,7 +87,21 @@ struct HipRt {
         abort();
     }
     static constexpr size_t GUARD_ALIGN = 16, GUARD_CANARY = 4096;
+    static constexpr size_t GUARD_BIG = (size_t)256 << 20, GUARD_BIG_CANARY = (size_t)64 << 10;
     void *guard_alloc(size_t bytes, const char *tag) {
+        if (bytes > GUARD_BIG) {
+            // a mapping of a gigabyte in 4 KiB pieces faulted inside the runtime's own fill on this stack (round 6: the full-size C4 batch,
+            // profiles/r06_guard_campaign.txt): the few buffers of that size get hipMalloc + a canary on both sides instead of a fence
+            GuardRec r = {};
+            r.bytes = bytes; r.dev = dev; r.map_bytes = bytes + 2 * GUARD_BIG_CANARY;
+            snprintf(r.tag, sizeof r.tag, "%s", tag ? tag : "");
+            if (bad(hipMalloc(&r.map_at, r.map_bytes))) return nullptr;
+            if (bad(hipMemset(r.map_at, 0xA5, r.map_bytes)) || bad(hipDeviceSynchronize())) return nullptr;
+            void *user = (void *)((uintptr_t)r.map_at + GUARD_BIG_CANARY);
+            std::lock_guard<std::mutex> lk(guard_mutex());
+            guard_table()[(uintptr_t)user] = r;
+            return user;
+        }
         hipMemAllocationProp prop = {};
         prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
         size_t gran = 0;
@@ -123,6 +137,21 @@ struct HipRt {
             guard_table().erase(it);
         }
         (void)hipDeviceSynchronize();
+        if (!r.va) {      // a big buffer (hipMalloc + canaries on both sides)
+            std::vector<unsigned char> c(GUARD_BIG_CANARY);
+            for (int side = 0; side < 2; side++) {
+                const void *at = side ? (const void *)((uintptr_t)p + r.bytes) : r.map_at;
+                if (hipMemcpy(c.data(), at, GUARD_BIG_CANARY, hipMemcpyDeviceToHost) != hipSuccess) continue;
+                for (size_t k = 0; k < GUARD_BIG_CANARY; k++)
+                    if (c[k] != 0xA5) {
+                        fprintf(stderr, "[kd guard] CANARY of %s [%p, +%zu) damaged %s it, at byte %zu (value 0x%02x); last kernel launched: %s\n", r.tag, p, r.bytes,
+                                side ? "behind" : "in front of", k, c[k], guard_last_kernel());
+                        abort();
+                    }
+            }
+            (void)hipFree(r.map_at);
+            return;
+        }
         // the canary next to the allocation (GUARD_CANARY bytes of it: the rest of a granule is not worth the copy)
         const size_t need = (r.bytes + GUARD_ALIGN - 1) / GUARD_ALIGN * GUARD_ALIGN;
         std::vector<unsigned char> c(GUARD_CANARY);

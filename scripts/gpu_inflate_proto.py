@@ -28,7 +28,8 @@ SRC = os.path.join(ROOT, "scripts", "gpu_inflate_proto.hip")
 
 
 def build():
-    deps = [SRC, os.path.join(ROOT, "scripts", "gpu_inflate_proto.h")]
+    deps = [SRC, os.path.join(ROOT, "scripts", "gpu_inflate_proto.h"), os.path.join(ROOT, "kindel_amd", "csrc", "kd_gpu_inflate.h"),
+            os.path.join(ROOT, "kindel_amd", "csrc", "kd_gpu_inflate2.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC, "-o", LIB])
@@ -61,6 +62,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--lib", default="", help="a prebuilt variant of exp/libgpu_inflate_proto.so")
     ap.add_argument("--clocks", action="store_true", help="the library was built with -DGI_CLOCKS: print where the wavefronts' clocks went")
+    ap.add_argument("--two-pass", action="store_true", help="round 6: time kd_gpu_inflate2.h (a lane per block records the matches, a wavefront per block resolves them)")
     ap.add_argument("--no-verify", action="store_true", help="skip the zlib comparison and the host decoder (variants: timing only)")
     a = ap.parse_args()
     import torch
@@ -68,6 +70,8 @@ def main():
     dll = C.CDLL(a.lib or build())
     dll.gi_inflate_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     dll.gi_inflate_blocks.restype = C.c_int
+    dll.gi_inflate_blocks2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_uint64]
+    dll.gi_inflate_blocks2.restype = C.c_int
     batch = synth.to_numpy(synth.make(a.config, scale=a.scale, device="cuda:0"))
     res = {"_what": "PROTOTYPE: raw DEFLATE of BGZF blocks on the GPU, one wavefront per block (scripts/gpu_inflate_proto.h), vs the host decoder "
                     "on the same file in the same run; every block's bytes compared with zlib",
@@ -92,9 +96,13 @@ def main():
         d_out = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
         d_status = torch.zeros(nb + 64, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
-        ms = C.c_float(0)
-        rc = dll.gi_inflate_blocks(d_comp.data_ptr(), d_blocks.data_ptr(), nb, d_out.data_ptr(), d_status.data_ptr(), 1 if a.clocks else 5, C.byref(ms))
+        ms2 = (C.c_float * 2)(0, 0)
+        if a.two_pass:
+            rc = dll.gi_inflate_blocks2(d_comp.data_ptr(), d_blocks.data_ptr(), nb, d_out.data_ptr(), d_status.data_ptr(), 5, ms2, total)
+        else:
+            rc = dll.gi_inflate_blocks(d_comp.data_ptr(), d_blocks.data_ptr(), nb, d_out.data_ptr(), d_status.data_ptr(), 1 if a.clocks else 5, ms2)
         assert rc == 0, rc
+        ms = C.c_float(ms2[0])
         status = d_status.cpu().numpy()
         if a.clocks:
             dbg = status[(nb + 1) & ~1:][:22].view(np.uint64)
@@ -106,7 +114,7 @@ def main():
         status = status[:nb]
         out = d_out.cpu().numpy()
         if a.no_verify:
-            print(qual, "gpu_ms %.3f GBps_out %.1f blocks_ok %d / %d" % (ms.value, total / ms.value * 1e-6, int((status == 0).sum()), nb), flush=True)
+            print(qual, "gpu_ms %.3f (pass 1 %.3f) GBps_out %.1f blocks_ok %d / %d" % (ms.value, ms2[1], total / ms.value * 1e-6, int((status == 0).sum()), nb), flush=True)
             os.remove(path)
             continue
         t0 = time.perf_counter()
@@ -126,6 +134,8 @@ def main():
         del d
         res["runs"][qual] = {
             "file_bytes": len(raw), "inflated_bytes": total, "compression": round(total / len(raw), 2), "blocks": nb,
+            "kernel": "two-pass (k_inflate_tokens + k_inflate_resolve)" if a.two_pass else "one-pass (k_gpu_inflate)",
+            **({"pass1_ms": round(float(ms2[1]), 3), "pass2_ms": round(float(ms2[0] - ms2[1]), 3)} if a.two_pass else {}),
             "gpu_ms": round(float(ms.value), 3), "gpu_GBps_out": round(total / ms.value * 1e-6, 1), "gpu_GBps_in": round(len(raw) / ms.value * 1e-6, 1),
             "blocks_ok": int((status == 0).sum()), "bytes_equal_zlib": bool(same and (status == 0).all()),
             "h2d_of_the_file_at_50GBps_ms": round(len(raw) / 50e9 * 1e3, 2),

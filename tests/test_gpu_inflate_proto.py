@@ -16,20 +16,32 @@ from tests.test_inflate import PAYLOADS, raw_deflate
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "emu", "gpu_inflate_emu.cpp")
 LIB = os.path.join(ROOT, "tests", "emu", "libgpu_inflate_emu.so")
-DEPS = [SRC, os.path.join(ROOT, "tests", "emu", "hip_emu.h"), os.path.join(ROOT, "kindel_amd", "csrc", "kd_gpu_inflate.h")]
+DEPS = [SRC, os.path.join(ROOT, "tests", "emu", "hip_emu.h"), os.path.join(ROOT, "kindel_amd", "csrc", "kd_gpu_inflate.h"),
+        os.path.join(ROOT, "kindel_amd", "csrc", "kd_gpu_inflate2.h")]
 
 
 class GiBlock(C.Structure):
     _fields_ = [("in_off", C.c_uint64), ("out_off", C.c_uint64), ("in_len", C.c_uint32), ("out_len", C.c_uint32)]
 
 
-@pytest.fixture(scope="module")
-def proto():
+class _Proto:
+    """One of the two GPU inflaters behind the same call: the one-pass kernel (a wavefront per block, rounds 3 - 5) or round 6's two-pass
+    pair (kd_gpu_inflate2.h: a lane per block records the matches, a wavefront per block resolves them)."""
+
+    def __init__(self, dll, two_pass):
+        self.dll, self.two_pass = dll, two_pass
+        self.gi_inflate_blocks = dll.gi_inflate_blocks2 if two_pass else dll.gi_inflate_blocks
+        self.gi_crc_blocks = dll.gi_crc_blocks
+
+
+@pytest.fixture(scope="module", params=["one_pass", "two_pass"])
+def proto(request):
     import __graft_entry__ as g
     dll = C.CDLL(g.build_inflate_emu())
-    dll.gi_inflate_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-    dll.gi_inflate_blocks.restype = C.c_int
-    return dll
+    for f in (dll.gi_inflate_blocks, dll.gi_inflate_blocks2):
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        f.restype = C.c_int
+    return _Proto(dll, request.param == "two_pass")
 
 
 def inflate_blocks(dll, streams, sizes):

@@ -14,6 +14,15 @@ from kindel_amd import synth
 REF = "/root/reference/tests"
 
 
+@pytest.fixture(autouse=True, params=["1", "2"], ids=["inflate_one_pass", "inflate_two_pass"])
+def inflate_kernel(request, monkeypatch):
+    """Every test of this module under both GPU inflaters (the engine reads KD_INFLATE when a context is created): the one-pass kernel
+    of rounds 3 - 5 (kd_gpu_inflate.h: a wavefront per BGZF block) and round 6's two-pass pair (kd_gpu_inflate2.h: a lane per block
+    records the matches, a wavefront per block resolves them)."""
+    monkeypatch.setenv("KD_INFLATE", request.param)
+    return request.param
+
+
 def both_ways(lib, path):
     with N.BgzfPlan(path, lib=lib) as plan:
         e1 = N.Engine(plan.contig_lens, lib=lib)

@@ -577,8 +577,11 @@ def test_bench_step_through_rccl_at_world_size_one():
     env["NCCL_DEBUG"] = "INFO"
     two = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--rccl-at-1"] + common, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert two.returncode == 0, two.stderr[-3000:]
-    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
-    b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    def line(out):      # (RCCL's INFO lines share the stream: the bench line may not start its line)
+        hits = [l[l.index('{"metric"'):] for l in out.splitlines() if '{"metric"' in l]
+        assert hits, out[-3000:]
+        return json.loads(hits[-1])
+    a, b = line(one.stdout), line(two.stdout + "\n" + two.stderr)
     assert b["n_gpus"] == 1 and "rccl_at_1" in b and "rccl_at_1" not in a
     assert b["fasta_sha256"] == a["fasta_sha256"] and b["consensus_len"] == a["consensus_len"]
     log = two.stdout + two.stderr
