@@ -366,67 +366,134 @@ def _masked(L, mask_ends):
     return m
 
 
-def cdr_start_consensuses(weights, deletions, clip_start_weights, clip_start_depth, clip_decay_threshold, mask_ends):
-    """Returns list of Region instances for right clipped consensuses of clip-dominant region (kindel.py:156-213)"""
-    W, S = _tab(weights).astype(np.int64), _tab(clip_start_weights).astype(np.int64)
-    L = W.shape[0]
-    d = np.asarray(deletions, np.int64)[:L]
-    csd = np.asarray(clip_start_depth, np.int64)[:L]
+def _masked_at(pos, L, mask_ends):
+    """_masked(L, mask_ends)[pos] for an array of positions"""
+    pos = np.asarray(pos, np.int64)
+    return (pos < mask_ends) | (pos >= (L - mask_ends if mask_ends else 0))
+
+
+def cdr_scan_inputs(W, d, X, clip_decay_threshold, mask_ends, L, offset=0, depth=None):
+    """What one direction's clip-dominant-region scan reads of a contig, SPARSE: for the rows [offset, offset + n) of the contig's
+    tables (W: [n,5] weights, d: [n] deletions, X: [n,5] clip start / end weights; L = the whole contig's length)
+      cand      the unmasked sites whose clip depth dominates  (csd / (sum(w) + d + 1) > 0.5, kindel.py:183 / :244)   + their
+      cand_ch   consensus(X[site])[0]
+      ext       the sites an extension runs over               (csd > (sum(w) + d) * clip_decay_threshold, :202 / :256)  + their
+      ext_ch    consensus(X[site])[0]
+    as int64 positions in the contig (ascending) and uint8 characters.  Every predicate is a function of ONE site's counters, so
+    the rows of a shard give the shard's part and the parts of all shards, concatenated, are the contig's (shard.realign_patches:
+    a few bytes per clip-dominant site cross the links instead of the tables)."""
+    W, X = np.asarray(W, np.int64), np.asarray(X, np.int64)
+    d = np.asarray(d, np.int64)
+    if depth is None:
+        depth = X[:, 0] + X[:, 1] + X[:, 2] + X[:, 3]                   # the alignment's clip_start_depth / clip_end_depth: A,T,G,C without N (kindel.py:90-95)
+    depth = np.asarray(depth, np.int64)
     wsum = W.sum(axis=1)
-    cand = (2 * csd > wsum + d + 1) & ~_masked(L, mask_ends)            # csd/(sum+d+1) > 0.5, :183
-    ext = csd > (wsum + d).astype(np.float64) * clip_decay_threshold    # :202
-    stops = np.flatnonzero(~ext)
-    chars = _cns_chars(S)
+    pos = np.arange(offset, offset + W.shape[0], dtype=np.int64)
+    cand = (2 * depth > wsum + d + 1) & ~_masked_at(pos, L, mask_ends)
+    ext = depth > (wsum + d).astype(np.float64) * clip_decay_threshold
+    chars = _cns_chars(X)
+    return dict(cand=pos[cand], cand_ch=chars[cand].astype(np.uint8), ext=pos[ext], ext_ch=chars[ext].astype(np.uint8))
+
+
+def cdr_scan_concat(parts):
+    """The scan inputs of a contig from its shards' parts (disjoint row ranges, any order)."""
+    out = {}
+    for k in ("cand", "ext"):
+        p = np.concatenate([np.asarray(x[k], np.int64) for x in parts]) if parts else np.zeros(0, np.int64)
+        c = np.concatenate([np.asarray(x[k + "_ch"], np.uint8) for x in parts]) if parts else np.zeros(0, np.uint8)
+        o = np.argsort(p, kind="stable")
+        out[k], out[k + "_ch"] = p[o], c[o]
+    return out
+
+
+def _ext_runs(ext):
+    """-> (first, last): for every entry of the ascending position list `ext`, the index of the first / last entry of its run of
+    consecutive positions"""
+    n = len(ext)
+    if n == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    brk = np.flatnonzero(np.diff(ext) != 1)                   # a run ends at brk[k], the next starts at brk[k] + 1
+    starts = np.concatenate([[0], brk + 1])
+    ends = np.concatenate([brk, [n - 1]])
+    run = np.searchsorted(starts, np.arange(n), side="right") - 1
+    return starts[run], ends[run]
+
+
+def cdr_start_regions(L, inp):
+    """cdr_start_consensuses (kindel.py:156-213) over sparse scan inputs: a region opens at the first unmasked clip-dominant site
+    no earlier region covers and runs to the first site that fails the extension test (that site is its `end`: not covered, its
+    base not included) -- or to the contig's last site, whose base IS included while `end` still names it (:196-208)."""
+    ext, ext_ch = inp["ext"], inp["ext_ch"]
+    _, last = _ext_runs(ext)
     regions = []
-    covered_to = -1  # regions are created left to right and only grow rightwards
-    for pos in np.flatnonzero(cand).tolist():
+    for pos in inp["cand"].tolist():
         if any(r.start <= pos < r.end for r in regions):
             continue
-        k = np.searchsorted(stops, pos)
-        if k < len(stops):
-            end_pos = int(stops[k])
-            seq = chars[pos:end_pos].tobytes().decode()
-        else:  # ran to the end of the contig without break: end_pos is the last index, its base included
-            end_pos = L - 1
-            seq = chars[pos:L].tobytes().decode()
-        regions.append(Region(pos, end_pos, seq, "→"))
+        i = int(np.searchsorted(ext, pos))
+        if i == len(ext) or int(ext[i]) != pos:              # the extension stops at once
+            regions.append(Region(pos, pos, "", "\u2192"))
+            continue
+        j = int(last[i])
+        end_site = int(ext[j]) + 1                            # the first site behind the run
+        seq = ext_ch[i:j + 1].tobytes().decode()
+        regions.append(Region(pos, end_site if end_site <= L - 1 else L - 1, seq, "\u2192"))
     for region in regions:
         logging.debug(region)
-    del covered_to
     return regions
 
 
-def cdr_end_consensuses(weights, deletions, clip_end_weights, clip_end_depth, clip_decay_threshold, mask_ends):
-    """Returns list of Region instances for left clipped consensuses of clip-dominant region (kindel.py:216-275)"""
-    W, E = _tab(weights).astype(np.int64), _tab(clip_end_weights).astype(np.int64)
-    L = W.shape[0]
-    d = np.asarray(deletions, np.int64)[:L]
-    ced = np.asarray(clip_end_depth, np.int64)[:L]
-    wsum = W.sum(axis=1)
-    cand = (2 * ced > wsum + d + 1) & ~_masked(L, mask_ends)            # :244
-    ext = ced > (wsum + d).astype(np.float64) * clip_decay_threshold    # :256
-    stops = np.flatnonzero(~ext)
-    chars = _cns_chars(E)
+def cdr_end_regions(L, inp):
+    """cdr_end_consensuses (kindel.py:216-275) over sparse scan inputs: from the right; a region ends behind an unmasked
+    clip-dominant site, its extension walks down from the site in front of it, and the region's `start` is the site the walk
+    stops at (covered, its base not included) -- or site 0 with its base included when the walk never stops (:251-270)."""
+    ext, ext_ch = inp["ext"], inp["ext_ch"]
+    first, _ = _ext_runs(ext)
     regions = []
-    for pos in np.flatnonzero(cand)[::-1].tolist():
+    for pos, ch in zip(inp["cand"][::-1].tolist(), inp["cand_ch"][::-1].tolist()):
         if any(r.start <= pos < r.end for r in regions):
             continue
         end_pos = pos + 1
         if pos == 0:  # reversed_weights[L:] is empty: for-else with nothing accumulated (:251,268-270)
-            regions.append(Region(pos, end_pos, "", "←"))
+            regions.append(Region(pos, end_pos, "", "\u2190"))
             continue
-        k = np.searchsorted(stops, pos - 1, side="right") - 1  # largest stop index <= pos-1
-        if k >= 0:
-            b = int(stops[k])  # extension breaks here; start_pos = b, bases b+1 .. pos
-            start_pos = b
-            seq = chars[b + 1:pos + 1].tobytes().decode() if b < pos - 1 else ""
-        else:  # never broke: walked down to site 0, bases 0 .. pos
-            start_pos = 0
-            seq = chars[0:pos + 1].tobytes().decode()
-        regions.append(Region(start_pos, end_pos, seq, "←"))
+        i = int(np.searchsorted(ext, pos - 1))
+        if i == len(ext) or int(ext[i]) != pos - 1:          # the walk stops at once, at pos - 1: nothing accumulated
+            regions.append(Region(pos - 1, end_pos, "", "\u2190"))
+            continue
+        f = int(first[i])
+        b = int(ext[f]) - 1                                   # the site the walk stops at (-1: it never stops)
+        seq = ext_ch[f:i + 1].tobytes().decode() + chr(ch)    # bases b + 1 .. pos - 1 (extension sites) and pos
+        regions.append(Region(b if b >= 0 else 0, end_pos, seq, "\u2190"))
     for region in regions:
         logging.debug(region)
     return regions
+
+
+def cdr_start_consensuses(weights, deletions, clip_start_weights, clip_start_depth, clip_decay_threshold, mask_ends):
+    """Returns list of Region instances for right clipped consensuses of clip-dominant region (kindel.py:156-213)"""
+    W, S = _tab(weights), _tab(clip_start_weights)
+    L = W.shape[0]
+    return cdr_start_regions(L, cdr_scan_inputs(W, np.asarray(deletions, np.int64)[:L], S, clip_decay_threshold, mask_ends, L,
+                                                depth=np.asarray(clip_start_depth, np.int64)[:L]))
+
+
+def cdr_end_consensuses(weights, deletions, clip_end_weights, clip_end_depth, clip_decay_threshold, mask_ends):
+    """Returns list of Region instances for left clipped consensuses of clip-dominant region (kindel.py:216-275)"""
+    W, E = _tab(weights), _tab(clip_end_weights)
+    L = W.shape[0]
+    return cdr_end_regions(L, cdr_scan_inputs(W, np.asarray(deletions, np.int64)[:L], E, clip_decay_threshold, mask_ends, L,
+                                              depth=np.asarray(clip_end_depth, np.int64)[:L]))
+
+
+def pair_cdrs(fwd_cdrs, rev_cdrs):
+    """kindel.py:305-316: every right-clipped region with the first left-clipped region it shares a site with"""
+    paired_cdrs = []
+    for f in fwd_cdrs:
+        for r in rev_cdrs:
+            if max(f.start, r.start) < min(f.end, r.end):  # set(range) & set(range) non-empty, :314
+                paired_cdrs.append((f, r))
+                break
+    return paired_cdrs
 
 
 def cdrp_consensuses(weights, deletions, clip_start_weights, clip_end_weights, clip_start_depth, clip_end_depth,
@@ -436,13 +503,7 @@ def cdrp_consensuses(weights, deletions, clip_start_weights, clip_end_weights, c
                                      clip_decay_threshold, mask_ends)
     rev_cdrs = cdr_end_consensuses(weights, deletions, clip_end_weights, clip_end_depth,
                                    clip_decay_threshold, mask_ends)
-    paired_cdrs = []
-    for f in fwd_cdrs:
-        for r in rev_cdrs:
-            if max(f.start, r.start) < min(f.end, r.end):  # set(range) & set(range) non-empty, :314
-                paired_cdrs.append((f, r))
-                break
-    return paired_cdrs
+    return pair_cdrs(fwd_cdrs, rev_cdrs)
 
 
 def merge_by_lcs(s1, s2, min_overlap):
@@ -668,9 +729,9 @@ def bam_to_consensus_sharded(bam_path, rank, world, device="cpu", dev_index=0, g
                              clip_decay_threshold=0.1, mask_ends=50, trim_ends=False, uppercase=False, threads=0, lib=None):
     """bam_to_consensus (kindel.py:488-555) with the per-contig loop (:143-151, :501-551) spread over `world` ranks, one GPU
     each (kindel_amd/shard.py: sharded ingest, shard-local pileup, one all-gather).  Call on every rank of an initialised
-    torch.distributed group; every rank returns the same result tuple.  realign=True (round 5): the clip-dominant regions are
-    found on whole-contig tables summed over the shards (shard.realign_patches: one all-reduce per contig), every rank patches
-    its part."""
+    torch.distributed group; every rank returns the same result tuple.  realign=True: every rank evaluates the clip-dominant-region
+    predicates on its own sites, the sparse results are gathered (shard.realign_patches: no table crosses the links), every rank runs
+    the same scans over them and patches its part."""
     from . import shard
     out = shard.pileup_consensus_sharded(bam_path, rank, world, device=device, dev_index=dev_index, group=group, min_depth=min_depth,
                                          threads=threads, lib=lib,

@@ -513,46 +513,54 @@ def ingest_sharded(path, rank, world, device="cpu", group=None, threads=0, lib=N
                 mode="sharded", stats=dict(decoded_records=n, neighbour_records=extra, blocks=(blocks[rank], blocks[rank + 1])))
 
 
-def _full_tables(eng, cid, interval, device, group, world, channels=None):
-    """Contig cid's tables over ALL shards.  A context commits the sites of its interval [g_lo, g_hi) AND the halo site g_hi (the
-    consensus of site g_hi - 1 looks one site ahead), which the next rank commits too: each rank keeps the columns of its own
-    interval only, then the sum over the ranks is the whole contig's table.  One all-reduce (counts as int64: a sum of uint32)."""
-    import torch
-    import torch.distributed as dist
-    t = eng.tables(cid, channels)
-    if world == 1:
-        return t
-    b = eng.contig_base(cid)
-    lo, hi = max(0, min(t.shape[1], int(interval[0]) - b)), max(0, min(t.shape[1], int(interval[1]) - b))
-    t[:, :lo] = 0
-    t[:, hi:] = 0
-    x = torch.from_numpy(t.astype(np.int64)).to(device)
-    dist.all_reduce(x, group=group)
-    return x.cpu().numpy().astype(np.uint32)
-
-
 def realign_patches(eng, order, lens, interval, device, group, world, min_overlap, clip_decay_threshold, mask_ends, keep=None):
-    """--realign across ranks (round 5; kindel.py:502-513): the clip-dominant regions of a contig are found on its WHOLE tables, so
-    every rank sums the shards' tables (_full_tables: one all-reduce per contig that has records) and runs the same host scans on
-    the same numbers -- identical patches everywhere, no broadcast.  -> {cid: merged patches (kindel.merge_cdrps)}
-    (This is the one place a table crosses the links: 16 channels x 8 bytes per site, off by default like --realign itself, and
-    small beside the host scans it feeds -- the reference's own Python loops over every site.)"""
+    """--realign across ranks (kindel.py:502-513) WITHOUT a table crossing the links (round 6; round 5 summed the shards' tables with
+    one all-reduce per contig: 128 bytes per site, 640 MB per rank on a 5 Mbp contig -- the collective SURVEY 8e rejected).  The
+    clip-dominant-region scans (kindel.py:156-275) read a contig through per-site predicates only -- "the clip depth dominates
+    here", "an extension runs over this site" -- and a site's counters are complete on the rank that owns it, so every rank
+    evaluates the predicates on ITS sites (kindel.cdr_scan_inputs over the rows of its interval), the SPARSE results -- position and
+    consensus character of the few sites where a predicate holds: nine bytes each -- are gathered in one small collective for all
+    contigs, and every rank runs the same scans over the same concatenated lists (kindel.cdr_start_regions / cdr_end_regions):
+    identical patches everywhere, a region that crosses a cut is simply a run of sites whose entries came from two ranks.
+    -> {cid: merged patches (kindel.merge_cdrps)}; keep (tests): the gathered scan inputs per contig.
+    An exception on one rank alone travels in the gathered object and is raised on every rank (no rank waits in a collective)."""
+    import torch.distributed as dist
     from . import _native as N
     from . import kindel as K
+    mine, err = {}, None
+    try:
+        for cid in order:
+            L = int(lens[cid])
+            b = eng.contig_base(cid)
+            a0, a1 = max(0, min(L, int(interval[0]) - b)), max(0, min(L, int(interval[1]) - b))      # this rank's rows of the contig
+            if a1 <= a0:
+                continue
+            t = eng.tables(cid, np.arange(N.KD_CH_CLIP_STARTS, dtype=np.uint32))     # weights, deletions, clip start / end weights: what the scans read
+            W = np.ascontiguousarray(t[0:5, a0:a1].T)
+            d = t[N.KD_CH_DEL, a0:a1]
+            S = np.ascontiguousarray(t[N.KD_CH_CSW:N.KD_CH_CSW + 5, a0:a1].T)
+            E = np.ascontiguousarray(t[N.KD_CH_CEW:N.KD_CH_CEW + 5, a0:a1].T)
+            mine[cid] = (K.cdr_scan_inputs(W, d, S, clip_decay_threshold, mask_ends, L, offset=a0),
+                         K.cdr_scan_inputs(W, d, E, clip_decay_threshold, mask_ends, L, offset=a0))
+    except Exception as e:   # noqa: BLE001
+        err = (type(e).__name__, str(e))
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, (mine, err), group=group)
+    else:
+        parts = [(mine, err)]
+    first_err = next((e for _, e in parts if e), None)
+    if first_err:
+        raise {"KeyError": KeyError, "IndexError": IndexError, "MemoryError": MemoryError, "OSError": OSError}.get(first_err[0], RuntimeError)(
+            "realign across ranks: " + first_err[1])
     patches = {}
     for cid in order:
-        t = _full_tables(eng, cid, interval, device, group, world,
-                         channels=np.arange(N.KD_CH_CLIP_STARTS, dtype=np.uint32))    # weights, deletions, clip start / end weights: what the scans read
-        if keep is not None:
-            keep[cid] = t
         L = int(lens[cid])
-        W = np.ascontiguousarray(t[0:5, :L].T)
-        S = np.ascontiguousarray(t[N.KD_CH_CSW:N.KD_CH_CSW + 5, :L].T)
-        E = np.ascontiguousarray(t[N.KD_CH_CEW:N.KD_CH_CEW + 5, :L].T)
-        csd = (S[:, 0] + S[:, 1] + S[:, 2] + S[:, 3]).astype(np.int64).tolist()      # A,T,G,C without N (kindel.py:90-95)
-        ced = (E[:, 0] + E[:, 1] + E[:, 2] + E[:, 3]).astype(np.int64).tolist()
-        cdrps = K.cdrp_consensuses(K.SiteDicts(W), t[N.KD_CH_DEL].astype(np.int64).tolist(), K.SiteDicts(S), K.SiteDicts(E), csd, ced,
-                                   clip_decay_threshold, mask_ends)
+        s_in = K.cdr_scan_concat([m[cid][0] for m, _ in parts if cid in m])
+        e_in = K.cdr_scan_concat([m[cid][1] for m, _ in parts if cid in m])
+        if keep is not None:
+            keep[cid] = (s_in, e_in)
+        cdrps = K.pair_cdrs(K.cdr_start_regions(L, s_in), K.cdr_end_regions(L, e_in))
         patches[cid] = K.merge_cdrps(cdrps, min_overlap)
     return patches
 
@@ -594,7 +602,7 @@ def pileup_consensus_sharded(path, rank, world, device="cpu", dev_index=0, group
             seqs, changes, minmax = stitch(eng, ing["interval"], device, group, intervals=ing["intervals"])
         else:
             from . import kindel as K
-            kept = {} if realign.get("keep_tables") else None
+            kept = {} if realign.get("keep_scan_inputs") else None
             patches = realign_patches(eng, ing["order"], ing["lens"], ing["interval"], device, group, world, realign["min_overlap"],
                                       realign["clip_decay_threshold"], realign["mask_ends"], keep=kept)
             plans = {cid: K._patch_plan(int(ing["lens"][cid]), patches.get(cid)) for cid in ing["order"]}
@@ -639,4 +647,4 @@ def pileup_consensus_sharded(path, rank, world, device="cpu", dev_index=0, group
         if eng is not None:
             eng.close()
     return dict(seqs=seqs, changes=changes, minmax=minmax, names=ing["names"], lens=ing["lens"], order=ing["order"], mode=ing["mode"],
-                stats=ing["stats"], patches=patches, tables=kept if realign else None)
+                stats=ing["stats"], patches=patches, scan_inputs=kept if realign else None)

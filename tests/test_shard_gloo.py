@@ -311,7 +311,7 @@ def test_realign_across_ranks_matches_the_reference_golden(emu_lib, tmp_path, ke
             assert reports[g["name"]] == g["realign_report"].replace("{bam_path}", path)
 
 
-def _worker_tables(rank, world, port, emu_path, path, q):
+def _worker_scan_inputs(rank, world, port, emu_path, path, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -321,16 +321,18 @@ def _worker_tables(rank, world, port, emu_path, path, q):
     lib = N.Library(emu_path)
     N._default = lib
     out = shard.pileup_consensus_sharded(path, rank, world, device="cpu", lib=lib,
-                                         realign=dict(min_overlap=7, clip_decay_threshold=0.1, mask_ends=50, keep_tables=True))
-    q.put((rank, {c: t.tobytes() for c, t in out["tables"].items()}, out["intervals"] if "intervals" in out else None))
+                                         realign=dict(min_overlap=7, clip_decay_threshold=0.1, mask_ends=50, keep_scan_inputs=True))
+    q.put((rank, {c: [{k: v.tolist() for k, v in side.items()} for side in pair] for c, pair in out["scan_inputs"].items()}))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 5])
-def test_tables_summed_over_the_shards_equal_the_whole_file_tables(emu_lib, tmp_path, world):
-    """What --realign across ranks scans (shard._full_tables): every channel of every contig, summed over the ranks' own columns,
-    equals the single-process tables -- also at the cut sites, which two neighbouring contexts both commit (the halo site)."""
+def test_scan_inputs_gathered_over_the_shards_equal_the_whole_file_scan_inputs(emu_lib, tmp_path, world):
+    """What --realign across ranks scans (round 6: shard.realign_patches gathers the SPARSE per-site predicates of every rank's own
+    sites, no table crosses the links): the clip-dominant candidates and extension sites of every contig, with their consensus
+    characters, concatenated over the ranks == those of the single-process tables -- also at the cut sites, which two neighbouring
+    contexts both commit (the halo site: only its owner reports it)."""
     from kindel_amd import synth, _native as N
     from kindel_amd import kindel as K
     batch = synth.to_numpy(synth.short_reads([3000, 1500, 2200], 25, seed=77, clip_p=0.5))
@@ -339,7 +341,7 @@ def test_tables_summed_over_the_shards_equal_the_whole_file_tables(emu_lib, tmp_
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_tables, args=(r, world, port, emu_lib.path, path, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_scan_inputs, args=(r, world, port, emu_lib.path, path, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted(q.get(timeout=900) for _ in range(world))
@@ -349,12 +351,19 @@ def test_tables_summed_over_the_shards_equal_the_whole_file_tables(emu_lib, tmp_
     N._default = emu_lib
     pl = K.pileup_file(path)
     try:
-        for rank, tabs, _ in results:
-            assert sorted(tabs) == sorted(pl.order)
+        n_sites = 0
+        for rank, got in results:
+            assert sorted(got) == sorted(pl.order)
             for cid in pl.order:
-                want = pl.engine.tables(cid)[:N.KD_CH_CLIP_STARTS]      # the 16 channels the CDR scans read
-                got = np.frombuffer(tabs[cid], np.uint32).reshape(want.shape)
-                assert np.array_equal(got, want), (rank, cid, np.argwhere(got != want)[:5])
+                t = pl.engine.tables(cid)
+                L = int(pl.lens[cid])
+                W = np.ascontiguousarray(t[0:5, :L].T)
+                for side, ch in ((0, N.KD_CH_CSW), (1, N.KD_CH_CEW)):
+                    want = K.cdr_scan_inputs(W, t[N.KD_CH_DEL, :L], np.ascontiguousarray(t[ch:ch + 5, :L].T), 0.1, 50, L)
+                    for k in ("cand", "cand_ch", "ext", "ext_ch"):
+                        assert got[cid][side][k] == want[k].tolist(), (rank, cid, side, k)
+                    n_sites += len(want["ext"])
+        assert n_sites > 0      # (clip_p = 0.5: there ARE extension sites)
     finally:
         pl.engine.close()
 
