@@ -90,14 +90,14 @@ def main():
     """python -m oracle.refbaseline [config] -> profiles/reference_python_baseline.json (needs /root/reference)"""
     if not reference_available():
         sys.exit("needs /root/reference")
-    from kindel_amd import synth
+    from tools import synth
     cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
     c = dict(synth.CONFIGS[cfg])
     # the sample is a prefix of the contig at full depth: generate just that much of the workload
     c["contig_lens"] = [200_000] if cfg == "C3" else list(c["contig_lens"])
     batch = synth.to_numpy(synth.make(c))
     out = time_reference(batch, 0)
-    out["workload"] = "%s error model and depth (synthetic, seed as in kindel_amd/synth.py), contig shortened to %d sites for generation" % (
+    out["workload"] = "%s error model and depth (synthetic, seed as in tools/synth.py), contig shortened to %d sites for generation" % (
         cfg, int(c["contig_lens"][0]))
     out["where"] = "build container (%d host cores), %s" % (os.cpu_count(), time.strftime("%Y-%m-%d"))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

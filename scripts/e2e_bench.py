@@ -18,7 +18,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from kindel_amd import _native as N, kindel as K, synth  # noqa: E402
+from kindel_amd import _native as N, kindel as K  # noqa: E402
+from tools import synth  # noqa: E402
 
 
 def _quota():

@@ -49,7 +49,8 @@ def main():
     args = ap.parse_args()
     import torch
     from kindel_amd import _native as N
-    from kindel_amd import shard, synth
+    from kindel_amd import shard
+    from tools import synth
 
     dev = "cuda:0"
     tb = synth.make(args.config, device=dev)

@@ -66,7 +66,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the zlib comparison and the host decoder (variants: timing only)")
     a = ap.parse_args()
     import torch
-    from kindel_amd import _native as N, synth
+    from kindel_amd import _native as N
+    from tools import synth
     dll = C.CDLL(a.lib or build())
     dll.gi_inflate_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     dll.gi_inflate_blocks.restype = C.c_int

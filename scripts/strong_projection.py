@@ -33,7 +33,8 @@ def main():
     args = ap.parse_args()
     import torch
     from kindel_amd import _native as N
-    from kindel_amd import shard, synth
+    from kindel_amd import shard
+    from tools import synth
 
     if os.environ.get("KD_BENCH_LIB"):   # a differently built library (A/B of a variant, scripts/README.md): never the default
         N._default = N.Library(os.environ["KD_BENCH_LIB"])

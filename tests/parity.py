@@ -211,7 +211,8 @@ def check_as_shards(lib, host, world, dev="cpu", tb=None, window=0):
     consensus, change codes and depth ranges as well as every shard's tables inside its interval (and at its halo site)
     must equal the oracle's, bit for bit.  tb: the device-resident batch (torch) to push instead of the host arrays.
     -> the intervals."""
-    from kindel_amd import shard, synth
+    from kindel_amd import shard
+    from tools import synth
     src = tb if tb is not None else host
     lens = host["contig_lens"]
     base, S = shard.g_layout(lens)

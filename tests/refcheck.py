@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-from kindel_amd import synth
+from tools import synth
 from oracle import oracle as ko
 from tests import parity as P
 

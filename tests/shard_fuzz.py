@@ -10,7 +10,7 @@ import torch.multiprocessing as mp
 
 def make_files(n, seed0, tmp, structured=False):
     import numpy as np
-    from kindel_amd import synth
+    from tools import synth
     from tests import parity as P, reference_fuzz as RF
     files = []
     for seed in range(seed0, seed0 + n):

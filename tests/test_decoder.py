@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from kindel_amd import _native as N
-from kindel_amd import synth
+from tools import synth
 from oracle import quirk_cases, samio_py
 from tests import parity as P
 

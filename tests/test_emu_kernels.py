@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 from kindel_amd import _native as N
-from kindel_amd import shard, synth
+from kindel_amd import shard
+from tools import synth
 from oracle import oracle as ko
 from tests import parity as P
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from kindel_amd import _native as N
-from kindel_amd import synth
+from tools import synth
 
 REF = "/root/reference/tests"
 

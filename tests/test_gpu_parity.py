@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 from kindel_amd import _native as N
-from kindel_amd import shard, synth
+from kindel_amd import shard
+from tools import synth
 from oracle import oracle as ko
 from tests import parity as P
 
@@ -295,12 +296,10 @@ def test_features_and_derived_arrays(hip_lib, tmp_path):
 
 def test_fetch_all_equals_per_contig_fetch(hip_lib):
     P.check_fetch_all(hip_lib, P.load_fixture("minimap2__1.1.multi"))
-    from kindel_amd import synth
     P.check_fetch_all(hip_lib, synth.to_numpy(synth.make("C4", scale=0.02)))
 
 
 def test_multi_tile_items_carry_rows_between_tiles(hip_lib):
-    from kindel_amd import synth
     batch = synth.to_numpy(synth.short_reads([2000, 900], 3000, seed=9, planted=False))   # ~58000 reads, 3 windows of 1024
     for window, slice_reads in ((1024, 32768), (640, 4096), (256, 3000)):
         P.assert_matches_oracle(P.Run(hip_lib, batch, window=window, slice_reads=slice_reads), what="w%d s%d" % (window, slice_reads))
@@ -310,7 +309,6 @@ def test_mostly_clipped_reads_and_deep_sites(hip_lib):
     """k_prep writes a compact record for every clipped / inserted read (ballot-compacted per wavefront, one region of the
     record array per wavefront), k_cold_lane walks the regions (more than one round of 256 where most reads are clipped) and
     lets neighbouring lanes that aim at one site add once (as does k_ins_insert).  Deep, clip-heavy input exercises all of it."""
-    from kindel_amd import synth
     batch = synth.to_numpy(synth.short_reads([2500, 1200], 2500, seed=13, clip_p=0.6, indel_p=0.3))
     assert len(batch["contig"]) > 3 * 8192
     for mode in (N.KD_MODE_AUTO, N.KD_MODE_COOP, N.KD_MODE_STRIP):
@@ -320,7 +318,6 @@ def test_mostly_clipped_reads_and_deep_sites(hip_lib):
 def test_insertion_hash_collision_is_detected_and_reseeded(hip_lib, monkeypatch):
     """KD_TEST_INS_COLLIDE leaves two possible insertion keys in the first attempt: the verification must notice, kd_finalize
     must clean up, re-seed and redo the reduction (incl. the speculatively picked winners)."""
-    from kindel_amd import synth
     batch = synth.to_numpy(synth.short_reads([20000], 60, seed=21, indel_p=0.5))
     monkeypatch.setenv("KD_TEST_INS_COLLIDE", "1")
     P.assert_matches_oracle(P.Run(hip_lib, batch))
@@ -328,7 +325,6 @@ def test_insertion_hash_collision_is_detected_and_reseeded(hip_lib, monkeypatch)
 
 def test_profile_modes(hip_lib):
     """kd_profile_enable: 1 = hipEvents around every launch, 2 = only around k_window (what bench.py times with)."""
-    from kindel_amd import synth
     batch = synth.to_numpy(synth.short_reads([20000], 30, seed=4))
     eng = N.Engine(batch["contig_lens"], lib=hip_lib)
     try:

@@ -7,7 +7,7 @@ from contextlib import redirect_stderr, redirect_stdout
 import numpy as np
 import pytest
 
-from kindel_amd import synth
+from tools import synth
 from tests import parity as P
 
 ROOT = P.ROOT

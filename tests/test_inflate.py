@@ -89,7 +89,7 @@ def test_corrupted_streams_never_crash_or_overrun(emu_lib):
 
 
 def test_bgzf_reader_uses_it(emu_lib, tmp_path):
-    from kindel_amd import synth
+    from tools import synth
     batch = synth.to_numpy(synth.short_reads([3000], 40, seed=2))
     p = str(tmp_path / "x.bam")
     N.write_bam(p, batch, lib=emu_lib)
@@ -185,7 +185,7 @@ def test_bgzf_crc_is_verified(emu_lib, tmp_path):
     """A BGZF block whose CRC-32 trailer does not match its inflated bytes is refused (htslib: "CRC32 checksum mismatch"),
     whole-file and streamed; the untouched file decodes."""
     import struct
-    from kindel_amd import synth
+    from tools import synth
     batch = synth.to_numpy(synth.short_reads([3000], 40, seed=4))
     p = str(tmp_path / "x.bam")
     N.write_bam(p, batch, lib=emu_lib)

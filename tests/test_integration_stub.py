@@ -6,7 +6,7 @@ import importlib
 
 import pytest
 
-from kindel_amd import synth
+from tools import synth
 from oracle import refrun
 from tests import parity as P
 from tests.integration_stub import Stub

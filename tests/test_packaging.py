@@ -7,7 +7,7 @@ import sys
 
 import pytest
 
-from kindel_amd import synth
+from tools import synth
 from tests import parity as P
 from tests import refcheck as RC
 

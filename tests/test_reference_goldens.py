@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from kindel_amd import _native as N
-from kindel_amd import synth
+from tools import synth
 from tests import parity as P
 from tests import refcheck as RC
 

@@ -27,7 +27,8 @@ def _worker(rank, world, port, emu_path, lens, seed, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from kindel_amd import _native as N
-    from kindel_amd import shard, synth
+    from kindel_amd import shard
+    from tools import synth
     lib = N.Library(emu_path)
     tb = synth.short_reads(lens, 10, seed=seed, shard=(rank, world))   # each rank synthesises its own interval
     batch = synth.to_numpy(tb)
@@ -54,7 +55,8 @@ def _worker_routed(rank, world, port, emu_path, lens, depth, seed, pad, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from kindel_amd import _native as N
-    from kindel_amd import shard, synth
+    from kindel_amd import shard
+    from tools import synth
     lib = N.Library(emu_path)
     full = synth.to_numpy(synth.short_reads(lens, depth, seed=seed))
     ivs = shard.partition_weighted(lens, full["contig"], full["pos0"], full["seq_len"], world)
@@ -83,7 +85,8 @@ def _worker_attached(rank, world, port, emu_path, lens, depth, seed, pad, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from kindel_amd import _native as N
-    from kindel_amd import shard, synth
+    from kindel_amd import shard
+    from tools import synth
     lib = N.Library(emu_path)
     full = synth.to_numpy(synth.short_reads(lens, depth, seed=seed))
     ivs = shard.partition_weighted(lens, full["contig"], full["pos0"], full["seq_len"], world)
@@ -123,7 +126,7 @@ def _worker_attached(rank, world, port, emu_path, lens, depth, seed, pad, q):
     (2, [6000, 5000], 8, 200),          # rows that are too small: headers only, the sizes announced
 ])
 def test_attached_exchange_row(emu_lib, world, lens, depth, pad):
-    from kindel_amd import synth
+    from tools import synth
     from oracle import oracle as ko
     seed = 37
     ctx = mp.get_context("spawn")
@@ -156,7 +159,8 @@ def test_attached_exchange_row(emu_lib, world, lens, depth, pad):
     (2, [6000, 5000], 8, 64),           # a row size that is too small: the second, exactly sized gather
 ])
 def test_routed_shards_from_one_batch(emu_lib, world, lens, depth, pad):
-    from kindel_amd import shard, synth
+    from kindel_amd import shard
+    from tools import synth
     from oracle import oracle as ko
     seed = 31
     ctx = mp.get_context("spawn")
@@ -191,7 +195,7 @@ def test_routed_shards_from_one_batch(emu_lib, world, lens, depth, pad):
 
 
 def test_two_rank_stitch_matches_oracle(emu_lib):
-    from kindel_amd import synth
+    from tools import synth
     from oracle import oracle as ko
     lens, seed, world = [9000, 7000, 3000], 21, 2
     ctx = mp.get_context("spawn")
@@ -261,7 +265,7 @@ def test_one_file_across_ranks_matches_the_reference_golden(emu_lib, tmp_path, k
     """`kindel consensus --gpus N x.bam` underneath: every rank opens the file and decodes only the BGZF blocks of its share
     (+ the neighbouring reads that reach into its interval), one all-gather stitches -- consensus, report and change codes equal
     what the unmodified reference produced for the fixture (tests/golden), on every rank."""
-    from kindel_amd import synth
+    from tools import synth
     from tests import parity as P
     gold = P.golden_outputs()[key]["contigs"]
     path = str(tmp_path / (key + ".bam"))
@@ -295,7 +299,7 @@ def test_realign_across_ranks_matches_the_reference_golden(emu_lib, tmp_path, ke
     """`kindel consensus --realign --gpus N` (round 5): the clip tables of the shards are summed (one all-reduce per contig), every rank
     finds the same clip-dominant regions and patches its part -- the consensus and the report (with its region list) equal what
     the unmodified reference printed for the fixture with realign=True, on every rank."""
-    from kindel_amd import synth
+    from tools import synth
     from tests import parity as P
     gold = [g for g in P.golden_outputs()[key]["contigs"] if "realign_consensus" in g]
     assert gold
@@ -333,7 +337,8 @@ def test_scan_inputs_gathered_over_the_shards_equal_the_whole_file_scan_inputs(e
     sites, no table crosses the links): the clip-dominant candidates and extension sites of every contig, with their consensus
     characters, concatenated over the ranks == those of the single-process tables -- also at the cut sites, which two neighbouring
     contexts both commit (the halo site: only its owner reports it)."""
-    from kindel_amd import synth, _native as N
+    from tools import synth
+    from kindel_amd import _native as N
     from kindel_amd import kindel as K
     batch = synth.to_numpy(synth.short_reads([3000, 1500, 2200], 25, seed=77, clip_p=0.5))
     path = str(tmp_path / "t.bam")
@@ -370,7 +375,7 @@ def test_scan_inputs_gathered_over_the_shards_equal_the_whole_file_scan_inputs(e
 
 def test_one_file_across_ranks_synthetic_multi_contig(emu_lib, tmp_path):
     """Many contigs, more ranks than some shares deserve (empty intervals), reads with leading clips across the cuts: vs the oracle."""
-    from kindel_amd import synth
+    from tools import synth
     from oracle import oracle as ko
     batch = synth.to_numpy(synth.short_reads([4000, 2500, 300, 5000], 12, seed=41, clip_p=0.3))
     path = str(tmp_path / "m.bam")
@@ -390,7 +395,7 @@ def test_one_file_across_ranks_synthetic_multi_contig(emu_lib, tmp_path):
 
 def test_a_reference_exception_reaches_every_rank(emu_lib, tmp_path):
     """A base outside A,C,G,T,N in one rank's share: KeyError on every rank (kindel.py:51-52), not a hang."""
-    from kindel_amd import synth
+    from tools import synth
     batch = synth.to_numpy(synth.short_reads([6000], 10, seed=43))
     seq4 = batch["seq4"].copy()
     i = len(batch["contig"]) // 4                     # a read in the first rank's share
@@ -461,7 +466,7 @@ def _worker_one_rank_fails(rank, world, port, emu_path, path, what, q):
 def test_a_failure_of_one_rank_alone_reaches_every_rank(emu_lib, tmp_path, what):
     """One rank failing where the others do not -- the whole-file fallback's decode (a SAM text file: no BGZF spans), the engine's
     tables -- must not leave the others waiting in the next collective: the failure travels through the gather."""
-    from kindel_amd import synth
+    from tools import synth
     batch = synth.to_numpy(synth.short_reads([4000], 8, seed=44))
     bam = str(tmp_path / "ok.bam")
     synth.write_bam(bam, batch, sort_order="coordinate", block_bytes=1500)

@@ -64,7 +64,7 @@ def short_reads(contig_lens, depth, read_len=150, seed=0, device="cpu", planted=
     nib = NIB.to(dev)
     refs = []
     if shard is not None:
-        from . import shard as _sh
+        from kindel_amd import shard as _sh
         _base, _ = _sh.g_layout(contig_lens)
         _lo, _hi = _sh.partition(contig_lens, shard[1])[shard[0]]
     for c, L in enumerate(contig_lens):
@@ -230,7 +230,7 @@ def long_reads(contig_lens, depth, seed=0, device="cpu", median_len=10_000, min_
     qspan = qcum[first + blocks - 1] - (qcum[first] - qadv[first])
     start = (torch.rand(n, generator=g, device=dev, dtype=torch.float64) * (L - rspan - 1).clamp(min=1)).to(torch.int64)
     if shard is not None:
-        from . import shard as _sh
+        from kindel_amd import shard as _sh
         keep = _sh.reads_touching(contig_lens, torch.zeros(n, dtype=torch.int32, device=dev), start, start + rspan,
                                  shard[0], shard[1])
     else:
