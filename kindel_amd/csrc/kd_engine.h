@@ -58,7 +58,8 @@ struct KdEngine {
     Buf b_rinfo, b_cold, b_irreg, b_long, b_winlo, b_winhi, b_itemoff, b_itemwin, b_readev, b_readpool, b_order, b_bincnt, b_binoff, b_rows, b_rowinfo, b_rowoff, b_longacc, b_coldcnt, b_coldev, b_coldpool;
     Buf b_stage[9];
     Buf b_gi_file, b_gi_blocks, b_gi_out, b_gi_bstat, b_gi_start, b_gi_cnt, b_gi_tot, b_gi_recat;   // device-side ingest (kd_ingest.h)
-    Buf b_gi_tok, b_gi_ntok;   // the two-pass inflate's token lists and their lengths (kd_gpu_inflate2.h)
+    Buf b_gi_tok, b_gi_ntok, b_gi_work;   // the two-pass inflate's token lists, their lengths, and the groups' work counters (kd_gpu_inflate2.h)
+    static constexpr uint32_t GI_MAX_GROUPS = 64;
     Buf b_sortrows, b_sortseg;   // unsorted input: per-workgroup bin counts / starts and their segment totals (kd_plan.h)
     Buf b_smallcig;   // a batch with fewer than 4 CIGAR words: its padded copy
     Buf b_srec;   // an unsorted batch's regular reads in window order: KdSortRec[] (k_sort_scatter_reads)
@@ -174,7 +175,7 @@ struct KdEngine {
         for (Buf &b : b_stage) release(b);
         for (Buf &b : b_gin) release(b);
         release(b_srec); release(b_smallcig); release(b_sortrows); release(b_sortseg); release(b_longorder);
-        for (Buf *g : {&b_gi_file, &b_gi_blocks, &b_gi_out, &b_gi_bstat, &b_gi_start, &b_gi_cnt, &b_gi_tot, &b_gi_recat, &b_gi_tok, &b_gi_ntok}) release(*g);
+        for (Buf *g : {&b_gi_file, &b_gi_blocks, &b_gi_out, &b_gi_bstat, &b_gi_start, &b_gi_cnt, &b_gi_tot, &b_gi_recat, &b_gi_tok, &b_gi_ntok, &b_gi_work}) release(*g);
         if (d_tab) rt.free(d_tab);
         if (d_clen) rt.free(d_clen);
         if (d_cbase) rt.free(d_cbase);
@@ -287,7 +288,14 @@ struct KdEngine {
         // chip has slots: halve until ~4 wavefronts per CU are there
         uint32_t prep_per = KD_PREP_PER_THREAD;
         if (const char *e = getenv("KD_PREP_PER")) prep_per = (uint32_t)std::min(KD_PREP_PER_THREAD, std::max(KD_PREP_UNROLL, atoi(e) / KD_PREP_UNROLL * KD_PREP_UNROLL));   // (knob: measurement)
-        else while (prep_per > KD_PREP_UNROLL && n / ((uint64_t)KD_PREP_BLOCK * prep_per) < (uint64_t)4 * rt.n_cus()) prep_per /= 2;   // (1/8 of C3, 2.08 M reads: 4 / 8 / 16 / 32 / 64 reads per lane = 0.157 / 0.103 / 0.076 / 0.088 / 0.114 ms)
+        else {
+            // (round 6, scripts/exp/prep_per_sweep.sh on the shards of C3's strong decomposition -- k_prep ms at 8 / 16 / 32 / 64 reads per lane:
+            //  16.7 M reads 0.464 / 0.283 / 0.227 / 0.216, 8.3 M 0.254 / 0.166 / 0.136 / 0.175, 4.2 M 0.147 / 0.101 / 0.102 / 0.141, 2.1 M
+            //  0.096 / 0.085 / 0.089 / 0.125: a lane's chain of dependent loads is what a launch waits for, so down to 16 reads per lane
+            //  the launch should hold ~14 wavefronts per CU; below that only a batch too small for 4 per CU goes on halving)
+            while (prep_per > 16u && n / ((uint64_t)KD_PREP_BLOCK * prep_per) < (uint64_t)14 * rt.n_cus()) prep_per /= 2;
+            while (prep_per > KD_PREP_UNROLL && n / ((uint64_t)KD_PREP_BLOCK * prep_per) < (uint64_t)4 * rt.n_cus()) prep_per /= 2;
+        }
         const uint32_t prep_chunk = KD_PREP_BLOCK * prep_per, cold_region = KD_WAVE * prep_per;
         const unsigned prep_grid = (unsigned)((n + prep_chunk - 1) / prep_chunk);
         const unsigned prep_regions = prep_grid;     // one region of compact cold-read records per wavefront of k_prep
@@ -708,7 +716,7 @@ struct KdEngine {
         // resolves them); 1: the one-pass kernel of rounds 3 - 5 (a wavefront per block).  The token lists: 4 / 3 of the inflated size
         const bool two_pass = knob_inflate == 2;
         const size_t tok_words = two_pass ? (size_t)gi2_tok_off(total_out, n_blocks) + 16 : 0;
-        if (two_pass && ((rc = ensure(b_gi_tok, tok_words * 4)) || (rc = ensure(b_gi_ntok, (size_t)n_blocks * 4)))) return rc;
+        if (two_pass && ((rc = ensure(b_gi_tok, tok_words * 4)) || (rc = ensure(b_gi_ntok, (size_t)n_blocks * 4)) || (rc = ensure(b_gi_work, (size_t)GI_MAX_GROUPS * 4)))) return rc;
         if ((rc = ensure(b_gi_file, file_bytes + 64)) || (rc = ensure(b_gi_blocks, (size_t)n_blocks * sizeof(GiBlock))) ||
             (rc = ensure(b_gi_out, total_out + 64)) || (rc = ensure(b_gi_bstat, (size_t)n_blocks * 4)) || (rc = ensure(b_gi_start, (size_t)n_blocks * 8)) ||
             (rc = ensure(b_gi_cnt, (size_t)n_blocks * 8 * 3)) || (rc = ensure(b_gi_tot, 64)))
@@ -722,26 +730,41 @@ struct KdEngine {
         // inflated while the next piece is on its way
         {
             const GiBlock *hb = (const GiBlock *)blocks;
-            uint32_t next_block = 0;
+            uint32_t next_block = 0, group = 0;
+            if (two_pass && (rt.memset(b_gi_work.p, 0, (size_t)GI_MAX_GROUPS * 4) || rt.side_fork())) return hipfail("ingest: side streams");
             auto after = [&](size_t there) -> int {
                 uint32_t e = next_block;
                 while (e < n_blocks && hb[e].in_off + hb[e].in_len + 8 <= there) e++;     // (+ 8: the block's trailer; the kernel's last dword load ends inside it)
                 if (there >= file_bytes) e = n_blocks;
-                // one wavefront works ~20 ms on a block and launches on one stream run one after the other: a launch of fewer blocks
-                // than two rounds of the chip's slots (26 wavefronts per CU) leaves most of it idle for that long
-                if (e == next_block || (e < n_blocks && e - next_block < 52u * (uint32_t)rt.n_cus() && !getenv("KD_UPLOAD_CHUNK"))) return 0;
+                // one-pass: one wavefront works ~20 ms on a block and launches on one stream run one after the other: a launch of fewer
+                // blocks than two rounds of the chip's slots (26 wavefronts per CU) leaves most of it idle for that long.
+                // two-pass: a LANE works that long on its block; the groups go to side streams in turn, so that the groups whose bytes have
+                // arrived share the chip (a group alone cannot fill it: 16 384 blocks are one wavefront per CU) -- smaller groups, and the
+                // last ones as many as the group counters allow
+                const uint32_t min_group = two_pass ? std::max<uint32_t>(32u * (uint32_t)rt.n_cus(), (n_blocks + GI_MAX_GROUPS - 2u) / (GI_MAX_GROUPS - 1u))
+                                                    : 52u * (uint32_t)rt.n_cus();
+                if (e == next_block || (e < n_blocks && e - next_block < min_group && !getenv("KD_UPLOAD_CHUNK"))) return 0;
+                if (two_pass && group + 1u >= GI_MAX_GROUPS && e < n_blocks) return 0;      // (tests with tiny upload pieces: the last counter takes the rest)
                 const uint32_t cnt = e - next_block;
-                const int bad = two_pass
-                    ? (rt.launch("k_inflate_tokens", k_inflate_tokens, (cnt + 63u) / 64u, KD_WAVE, 0, (const uint8_t *)b_gi_file.p, d_blocks + next_block, cnt,
-                                 (uint8_t *)b_gi_out.p, (uint32_t *)b_gi_tok.p, (uint32_t *)b_gi_ntok.p + next_block, bstat + next_block, next_block) ||
-                       rt.launch("k_inflate_resolve", k_inflate_resolve, cnt, KD_WAVE, 0, d_blocks + next_block, cnt, (uint8_t *)b_gi_out.p,
-                                 (const uint32_t *)b_gi_tok.p, (const uint32_t *)b_gi_ntok.p + next_block, (const uint32_t *)(bstat + next_block), next_block))
-                    : rt.launch("k_gpu_inflate", k_gpu_inflate, cnt, KD_WAVE, 0, (const uint8_t *)b_gi_file.p, d_blocks + next_block, cnt,
-                                (uint8_t *)b_gi_out.p, bstat + next_block);
+                int bad;
+                if (two_pass) {
+                    const int sd = (int)(group % (uint32_t)Rt::N_SIDE);
+                    const unsigned waves = (unsigned)std::min<uint32_t>((cnt + 63u) / 64u, 4u * (uint32_t)rt.n_cus());      // what can be resident; the rest through the counter
+                    bad = rt.side_after_upload(sd) ||
+                          rt.launch_side(sd, "k_inflate_tokens", k_inflate_tokens, waves, KD_WAVE, 0, (const uint8_t *)b_gi_file.p, d_blocks + next_block, cnt,
+                                         (uint8_t *)b_gi_out.p, (uint32_t *)b_gi_tok.p, (uint32_t *)b_gi_ntok.p + next_block, bstat + next_block, next_block,
+                                         (uint32_t *)b_gi_work.p + group) ||
+                          rt.launch_side(sd, "k_inflate_resolve", k_inflate_resolve, cnt, KD_WAVE, 0, d_blocks + next_block, cnt, (uint8_t *)b_gi_out.p,
+                                         (const uint32_t *)b_gi_tok.p, (const uint32_t *)b_gi_ntok.p + next_block, (const uint32_t *)(bstat + next_block), next_block);
+                    group++;
+                } else
+                    bad = rt.launch("k_gpu_inflate", k_gpu_inflate, cnt, KD_WAVE, 0, (const uint8_t *)b_gi_file.p, d_blocks + next_block, cnt,
+                                    (uint8_t *)b_gi_out.p, bstat + next_block);
                 next_block = e;
                 return bad;
             };
             if (rt.upload(b_gi_file.p, file, file_bytes, after)) return hipfail("ingest: upload / k_gpu_inflate");
+            if (two_pass && rt.side_join()) return hipfail("ingest: side streams");
         }
         const bool trace = getenv("KD_INGEST_TRACE") != nullptr;
         const clk::time_point t_up = clk::now();

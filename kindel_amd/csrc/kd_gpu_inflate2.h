@@ -36,6 +36,7 @@
 #define GI2_DRAIN()
 #endif
 
+struct __attribute__((packed, aligned(1))) KdChunk16 { uint32_t x, y, z, w; };      // 16 bytes at any address (one global_load_dwordx4)
 #define GI2_LIT 286u       // sorted-symbol entries of the literal / length code
 #define GI2_SLOTS 316u     // + 30 of the distance code
 // Token (u32): bits 0-8 literals since the last token (0 .. 510) | bits 9-16 match length - 3 | bits 17-31 distance - 1;
@@ -119,41 +120,83 @@ struct Gi2Cnt15 {
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // pass 1: one LANE per block.  comp: the file (readable 8 bytes past every block's input); out: the inflated bytes of all blocks (the
-// literals are written here); tokens: the match tokens, block b's from gi2_tok_off(out_off, b); n_tok[b] tokens; status[b].
+// literals are written here); tokens: the match tokens, block b's from gi2_tok_off(out_off, b0 + b); n_tok[b] tokens; status[b].
+// blocks / n_tok / status point at the launch's first block, b0 = that block's index in the file (the token regions are laid out by it).
+// work: a zeroed counter.  The launch holds what the chip can keep resident (four wavefronts per CU); a lane that has finished its block
+// takes the next one from the counter -- a file of 68 568 blocks is 1 072 wavefronts' worth, 48 more than the 1 024 that fit: without
+// this the launch took two rounds for 5 % more work (measured: 54 ms against 26 ms for the same file at a quarter of the depth).
+//
+// The bit reader (round 6, second version): a 64-bit window (lo, hi) of the stream and a bit offset, read with ONE v_alignbit_b32 per
+// code word (the code and its extra bits -- at most 28 bits -- come out of the same 32); the input arrives 16 bytes at a time into
+// registers, the NEXT 16 requested one buffer ahead.  (The first version kept a 64-bit shift register and asked for the next dword inside
+// the refill that consumed the last one: the compiler had to wait for the load on the spot -- a memory round trip every fourth
+// symbol -- and 64-bit shifts are quarter rate.)
 // ---------------------------------------------------------------------------------------------------------------------------------
-// (blocks / n_tok / status point at the launch's first block, b0 = that block's index in the file: the token regions are laid out by it)
+#ifndef KD_EMU
+__device__ __forceinline__ uint32_t gi2_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+#else
+static inline uint32_t gi2_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31u)); }
+#endif
+struct Gi2In {      // one lane's view of its block's compressed bytes
+    const uint8_t *in;
+    uint32_t in_cap;                // bytes that may be read (the block's input + 8)
+    uint32_t q0, q1, q2, q3;        // the 16 bytes the window is fed from
+    uint32_t n0, n1, n2, n3;        // the 16 bytes behind them (requested when q was filled)
+    uint32_t qi, qat;               // next dword of q; byte offset of n in the input
+    uint32_t lo, hi, bo, wpos;      // the window: stream bits from byte wpos on, bo of them consumed
+    __device__ __forceinline__ void ld16(uint32_t at, uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d) const {
+        if (at + 16u <= in_cap) {
+            const KdChunk16 v = *reinterpret_cast<const KdChunk16 *>(in + at);
+            a = v.x; b = v.y; c = v.z; d = v.w;
+        } else {
+            a = at + 4u <= in_cap ? reinterpret_cast<const GiU32 *>(in + at)->v : 0u;
+            b = at + 8u <= in_cap ? reinterpret_cast<const GiU32 *>(in + at + 4u)->v : 0u;
+            c = at + 12u <= in_cap ? reinterpret_cast<const GiU32 *>(in + at + 8u)->v : 0u;
+            d = 0u;
+        }
+    }
+    __device__ __forceinline__ void start(uint32_t at) {      // the stream from byte `at` of the input on
+        ld16(at, q0, q1, q2, q3);
+        ld16(at + 16u, n0, n1, n2, n3);
+        qat = at + 16u;
+        lo = q0; hi = q1; qi = 2u; bo = 0u; wpos = at;
+    }
+    __device__ __forceinline__ uint32_t next_dword() {
+        const uint32_t d = qi == 0u ? q0 : qi == 1u ? q1 : qi == 2u ? q2 : q3;
+        if (++qi == 4u) {
+            q0 = n0; q1 = n1; q2 = n2; q3 = n3; qi = 0u;
+            qat += 16u;
+            ld16(qat, n0, n1, n2, n3);
+        }
+        return d;
+    }
+    __device__ __forceinline__ void norm() {                   // bo < 32 afterwards (at most 32 bits are consumed between two calls)
+        if (bo >= 32u) { lo = hi; hi = next_dword(); bo -= 32u; wpos += 4u; }
+    }
+    __device__ __forceinline__ uint32_t peek() const { return gi2_alignbit(hi, lo, bo); }      // the next 32 bits (after norm())
+    __device__ __forceinline__ unsigned long long bits_used() const { return 8ull * wpos + bo; }
+};
+
 __global__ void __launch_bounds__(64) k_inflate_tokens(const uint8_t *comp, const GiBlock *blocks, uint32_t n_blocks, uint8_t *out,
-                                                       uint32_t *tokens, uint32_t *n_tok, uint32_t *status, uint32_t b0) {
+                                                       uint32_t *tokens, uint32_t *n_tok, uint32_t *status, uint32_t b0, uint32_t *work) {
     __shared__ uint16_t slots[GI2_SLOTS * 64u];      // entry i of lane l: bits 0-8 i-th coded symbol in (length, value) order | bits 12-15 code length of symbol i
     const uint32_t lane = threadIdx.x;
-    const uint32_t b = blockIdx.x * 64u + lane;
-    if (b >= n_blocks) return;                       // (no wavefront-wide operation anywhere in this kernel)
+#define GI2_SLOT(i) slots[(uint32_t)(i) * 64u + lane]
+    // (no wavefront-wide operation anywhere in this kernel: every lane is on its own)
+    for (uint32_t b = blockIdx.x * 64u + lane; b < n_blocks; b = gridDim.x * 64u + atomicAdd(work, 1u)) {
     const GiBlock B = blocks[b];
-    const uint8_t *in = comp + B.in_off;
     uint8_t *dst = out + B.out_off;
     uint32_t *tk = tokens + gi2_tok_off(B.out_off, (unsigned long long)b0 + b);
     const uint32_t tok_cap = (uint32_t)(gi2_tok_off(B.out_off + B.out_len, (unsigned long long)b0 + b + 1ull) - gi2_tok_off(B.out_off, (unsigned long long)b0 + b));
-    const uint32_t in_cap = B.in_len + 8u;           // bytes that may be read
-#define GI2_SLOT(i) slots[(uint32_t)(i) * 64u + lane]
-    // ---- bit reader: >= 32 bits in bb after a refill; `pre` is the next dword, requested one refill ahead ----
-    unsigned long long bb = 0;
-    uint32_t bc = 0, ip = 0;
-    auto ld = [&](uint32_t at) -> uint32_t { return at + 4u <= in_cap ? reinterpret_cast<const GiU32 *>(in + at)->v : 0u; };
-    uint32_t pre = ld(0);
-    auto refill = [&]() {
-        if (bc < 32u) { bb |= (unsigned long long)pre << bc; bc += 32u; ip += 4u; pre = ld(ip); }
-    };
-    auto take = [&](uint32_t n) -> uint32_t {
-        const uint32_t v = (uint32_t)(bb & ((1ull << n) - 1ull));
-        bb >>= n; bc -= n;
-        return v;
-    };
+    Gi2In s;
+    s.in = comp + B.in_off; s.in_cap = B.in_len + 8u;
+    s.start(0u);
     uint32_t pos = 0, run = 0, ntok = 0, err = GI_OK;
     Gi2Code<15> c_lit, c_dist;
     // canonical code over the lengths in the high nibbles of entries [s0, s0 + n): c, and the symbols' ranks into the low bits
     auto build15 = [&](uint32_t s0, uint32_t n, Gi2Code<15> &c) -> bool {
         Gi2Cnt15 k;
-        for (uint32_t s = 0; s < n; s++) k.add((uint32_t)GI2_SLOT(s0 + s) >> 12, 1u);
+        for (uint32_t x = 0; x < n; x++) k.add((uint32_t)GI2_SLOT(s0 + x) >> 12, 1u);
         uint32_t cnt[15];
 #pragma unroll
         for (int l = 1; l <= 15; l++) cnt[l - 1] = k.get((uint32_t)l);
@@ -162,31 +205,35 @@ __global__ void __launch_bounds__(64) k_inflate_tokens(const uint8_t *comp, cons
         uint32_t sum = 0;
 #pragma unroll
         for (int l = 1; l <= 15; l++) { o.add((uint32_t)l, sum); sum += cnt[l - 1]; }
-        for (uint32_t s = 0; s < n; s++) {
-            const uint32_t l = (uint32_t)GI2_SLOT(s0 + s) >> 12;
+        for (uint32_t x = 0; x < n; x++) {
+            const uint32_t l = (uint32_t)GI2_SLOT(s0 + x) >> 12;
             if (!l) continue;
             const uint32_t r = o.get(l);
             o.add(l, 1u);
-            GI2_SLOT(s0 + r) = (uint16_t)((GI2_SLOT(s0 + r) & 0xf000u) | s);
+            GI2_SLOT(s0 + r) = (uint16_t)((GI2_SLOT(s0 + r) & 0xf000u) | x);
         }
         return true;
     };
     for (bool last = false; !last && err == GI_OK;) {
-        refill();
-        last = take(1) != 0;
-        const uint32_t type = take(2);
+        s.norm();
+        uint32_t p = s.peek();
+        last = (p & 1u) != 0;
+        const uint32_t type = (p >> 1) & 3u;
+        s.bo += 3u;
         if (type == 0) {
             // stored: to the byte boundary, LEN / NLEN, then LEN bytes straight from the input
-            take(bc & 7u);
-            refill();
-            const uint32_t len = take(16), nlen = take(16);
+            s.bo = (s.bo + 7u) & ~7u;
+            s.norm();
+            p = s.peek();
+            s.bo += 32u;
+            const uint32_t len = p & 0xffffu, nlen = p >> 16;
             if ((len ^ nlen) != 0xffffu) { err = GI_E_STORED; break; }
             if (pos + len > B.out_len) { err = GI_E_SIZE; break; }
-            const uint32_t at = ip - bc / 8u;        // the bit buffer holds whole bytes: the next unread input byte
+            const uint32_t at = s.wpos + s.bo / 8u;  // the next unread input byte
             if (at > B.in_len || len > B.in_len - at) { err = GI_E_INPUT; break; }
-            for (uint32_t i = 0; i < len; i++) dst[pos + i] = in[at + i];
+            for (uint32_t i = 0; i < len; i++) dst[pos + i] = s.in[at + i];
             pos += len; run += len;
-            ip = at + len; bb = 0; bc = 0; pre = ld(ip);
+            s.start(at + len);
             continue;
         }
         if (type == 3) { err = GI_E_BTYPE; break; }
@@ -204,8 +251,8 @@ __global__ void __launch_bounds__(64) k_inflate_tokens(const uint8_t *comp, cons
             for (uint32_t r = 0; r < 288u; r++)      // ranks: 256 .. 279 (7 bits), 0 .. 143 and 280 .. 287 (8), 144 .. 255 (9)
                 GI2_SLOT(r) = (uint16_t)(r < 24u ? 256u + r : r < 168u ? r - 24u : r < 176u ? 280u + (r - 168u) : 144u + (r - 176u));
         } else {
-            refill();
-            const uint32_t hlit = take(5) + 257u, hdist = take(5) + 1u, hclen = take(4) + 4u;
+            const uint32_t hlit = ((p >> 3) & 31u) + 257u, hdist = ((p >> 8) & 31u) + 1u, hclen = ((p >> 13) & 15u) + 4u;
+            s.bo += 14u;
             if (hlit > 286u || hdist > 30u) { err = GI_E_CODES; break; }
             // the code-length code: 19 symbols of at most 7 bits, entirely in registers
             unsigned long long cll = 0;              // 3 bits per symbol
@@ -213,7 +260,7 @@ __global__ void __launch_bounds__(64) k_inflate_tokens(const uint8_t *comp, cons
                 const uint32_t ord[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 #pragma unroll
                 for (int i = 0; i < 19; i++) {
-                    if ((uint32_t)i < hclen) { refill(); cll |= (unsigned long long)take(3) << (3u * ord[i]); }
+                    if ((uint32_t)i < hclen) { s.norm(); cll |= (unsigned long long)(s.peek() & 7u) << (3u * ord[i]); s.bo += 3u; }
                 }
             }
             Gi2Code<7> c_cl;
@@ -221,7 +268,7 @@ __global__ void __launch_bounds__(64) k_inflate_tokens(const uint8_t *comp, cons
             {
                 unsigned long long k7 = 0;           // 5 bits per length 0 .. 7
 #pragma unroll
-                for (int s = 0; s < 19; s++) k7 += 1ull << (5u * ((uint32_t)(cll >> (3u * s)) & 7u));
+                for (int x = 0; x < 19; x++) k7 += 1ull << (5u * ((uint32_t)(cll >> (3u * x)) & 7u));
                 uint32_t cnt[7];
 #pragma unroll
                 for (int l = 1; l <= 7; l++) cnt[l - 1] = (uint32_t)(k7 >> (5u * l)) & 31u;
@@ -231,12 +278,12 @@ __global__ void __launch_bounds__(64) k_inflate_tokens(const uint8_t *comp, cons
 #pragma unroll
                 for (int l = 1; l <= 7; l++) { o7 += (unsigned long long)sum << (5u * l); sum += cnt[l - 1]; }
 #pragma unroll
-                for (int s = 0; s < 19; s++) {
-                    const uint32_t l = (uint32_t)(cll >> (3u * s)) & 7u;
+                for (int x = 0; x < 19; x++) {
+                    const uint32_t l = (uint32_t)(cll >> (3u * x)) & 7u;
                     if (l) {
                         const uint32_t r = (uint32_t)(o7 >> (5u * l)) & 31u;
                         o7 += 1ull << (5u * l);
-                        if (r < 12u) srt0 |= (unsigned long long)s << (5u * r); else srt1 |= (unsigned long long)s << (5u * (r - 12u));
+                        if (r < 12u) srt0 |= (unsigned long long)x << (5u * r); else srt1 |= (unsigned long long)x << (5u * (r - 12u));
                     }
                 }
             }
@@ -244,20 +291,22 @@ __global__ void __launch_bounds__(64) k_inflate_tokens(const uint8_t *comp, cons
             uint32_t n = 0, prev = 0;
             bool bad = false;
             while (n < hlit + hdist) {
-                refill();
+                s.norm();
+                p = s.peek();
                 uint32_t len, r;
-                if (!gi2_decode<7>(c_cl, gi2_brev((uint32_t)bb) >> 25, len, r) || r >= 19u) { bad = true; break; }
-                take(len);
+                if (!gi2_decode<7>(c_cl, gi2_brev(p) >> 25, len, r) || r >= 19u) { bad = true; break; }
                 const uint32_t sy = (uint32_t)((r < 12u ? srt0 >> (5u * r) : srt1 >> (5u * (r - 12u))) & 31ull);
+                const uint32_t x = p >> len;         // the bits behind the code word
                 uint32_t rep = 1, v = sy;
-                if (sy == 16u) { if (!n) { bad = true; break; } v = prev; rep = 3u + take(2); }
-                else if (sy == 17u) { v = 0; rep = 3u + take(3); }
-                else if (sy == 18u) { v = 0; rep = 11u + take(7); }
+                if (sy == 16u) { if (!n) { bad = true; break; } v = prev; rep = 3u + (x & 3u); len += 2u; }
+                else if (sy == 17u) { v = 0; rep = 3u + (x & 7u); len += 3u; }
+                else if (sy == 18u) { v = 0; rep = 11u + (x & 127u); len += 7u; }
                 else if (sy > 18u) { bad = true; break; }
+                s.bo += len;
                 if (n + rep > hlit + hdist) { bad = true; break; }
                 if (v) for (uint32_t k = 0; k < rep; k++) {
-                    const uint32_t s = n + k;
-                    GI2_SLOT(s < hlit ? s : GI2_LIT + (s - hlit)) = (uint16_t)(v << 12);
+                    const uint32_t y = n + k;
+                    GI2_SLOT(y < hlit ? y : GI2_LIT + (y - hlit)) = (uint16_t)(v << 12);
                 }
                 n += rep; prev = v;
             }
@@ -267,32 +316,35 @@ __global__ void __launch_bounds__(64) k_inflate_tokens(const uint8_t *comp, cons
         }
         // ---- the symbols of this block ----
         for (;;) {
-            refill();
+            s.norm();
+            p = s.peek();
             uint32_t len, r;
-            if (!gi2_decode<15>(c_lit, gi2_brev((uint32_t)bb) >> 17, len, r) || r >= (fixed ? 288u : GI2_LIT)) { err = GI_E_SYMBOL; break; }
-            take(len);
+            if (!gi2_decode<15>(c_lit, gi2_brev(p) >> 17, len, r) || r >= (fixed ? 288u : GI2_LIT)) { err = GI_E_SYMBOL; break; }
             const uint32_t sy = (uint32_t)GI2_SLOT(r) & 0x1ffu;
             if (sy < 256u) {
+                s.bo += len;
                 if (pos >= B.out_len) { err = GI_E_SIZE; break; }
                 dst[pos++] = (uint8_t)sy;
                 run++;
                 continue;
             }
-            if (sy == 256u) break;
+            if (sy == 256u) { s.bo += len; break; }
             if (sy > 285u) { err = GI_E_SYMBOL; break; }
             const uint32_t k = sy - 257u;
             uint32_t mlen;
             if (k < 8u) mlen = 3u + k;
             else if (k == 28u) mlen = 258u;
-            else { const uint32_t e = (k - 4u) >> 2; mlen = 3u + ((4u + (k & 3u)) << e) + take(e); }
-            refill();
-            if (!gi2_decode<15>(c_dist, gi2_brev((uint32_t)bb) >> 17, len, r) || r >= 30u) { err = GI_E_SYMBOL; break; }
-            take(len);
+            else { const uint32_t e = (k - 4u) >> 2; mlen = 3u + ((4u + (k & 3u)) << e) + ((p >> len) & ((1u << e) - 1u)); len += e; }
+            s.bo += len;
+            s.norm();
+            p = s.peek();
+            if (!gi2_decode<15>(c_dist, gi2_brev(p) >> 17, len, r) || r >= 30u) { err = GI_E_SYMBOL; break; }
             const uint32_t dc = fixed ? r : ((uint32_t)GI2_SLOT(GI2_LIT + r) & 0x1ffu);
             if (dc > 29u) { err = GI_E_SYMBOL; break; }
             uint32_t dist;
             if (dc < 4u) dist = dc + 1u;
-            else { const uint32_t e = (dc >> 1) - 1u; dist = 1u + ((2u + (dc & 1u)) << e) + take(e); }
+            else { const uint32_t e = (dc >> 1) - 1u; dist = 1u + ((2u + (dc & 1u)) << e) + ((p >> len) & ((1u << e) - 1u)); len += e; }
+            s.bo += len;
             if (dist > pos) { err = GI_E_DIST; break; }
             if (pos + mlen > B.out_len) { err = GI_E_SIZE; break; }
             if (ntok + 2u > tok_cap) { err = GI_E_SIZE; break; }      // (cannot happen for a stream that fits its output: one token per >= 3 bytes)
@@ -302,11 +354,12 @@ __global__ void __launch_bounds__(64) k_inflate_tokens(const uint8_t *comp, cons
             pos += mlen;
         }
         // consumed more than the block holds?
-        if (err == GI_OK && 8ull * ip - bc > 8ull * B.in_len) err = GI_E_INPUT;
+        if (err == GI_OK && s.bits_used() > 8ull * B.in_len) err = GI_E_INPUT;
     }
     if (err == GI_OK && pos != B.out_len) err = GI_E_SIZE;
     n_tok[b] = ntok;
     status[b] = err;
+    }
 #undef GI2_SLOT
 }
 

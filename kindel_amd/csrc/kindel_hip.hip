@@ -57,6 +57,8 @@ struct HipRt {
         if (stage_buf) { (void)hipHostFree(stage_buf); stage_buf = nullptr; stage_cap = 0; }
         for (int k = 0; k < 2; k++) { if (up_pin[k]) { (void)hipHostFree(up_pin[k]); up_pin[k] = nullptr; } if (up_ev[k]) { (void)hipEventDestroy(up_ev[k]); up_ev[k] = nullptr; } }
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
+        for (int i = 0; i < N_SIDE; i++) { if (side[i]) { (void)hipStreamDestroy(side[i]); side[i] = nullptr; } if (side_ev[i]) { (void)hipEventDestroy(side_ev[i]); side_ev[i] = nullptr; } }
+        if (fork_ev) { (void)hipEventDestroy(fork_ev); fork_ev = nullptr; }
         if (ev_copy) { (void)hipEventDestroy(ev_copy); ev_copy = nullptr; }
         if (own_stream && stream) { (void)hipSetDevice(dev); (void)hipStreamDestroy(stream); }
         stream = nullptr;
@@ -228,6 +230,7 @@ struct HipRt {
             if (bad(hipMemcpyAsync((uint8_t *)dst + o, up_pin[k], len, hipMemcpyHostToDevice, copy_stream)) || bad(hipEventRecord(up_ev[k], copy_stream)) ||
                 bad(hipStreamWaitEvent(stream, up_ev[k], 0)))
                 return 1;
+            last_up = k;
             if (after(o + len)) return 1;
         }
         return 0;
@@ -287,6 +290,10 @@ struct HipRt {
 
     template <class K, class... A>
     int launch(const char *name, K k, unsigned grid, unsigned block, size_t shmem, A... args) {
+        return launch_on(stream, name, k, grid, block, shmem, args...);
+    }
+    template <class K, class... A>
+    int launch_on(hipStream_t st, const char *name, K k, unsigned grid, unsigned block, size_t shmem, A... args) {
         if (bad(hipSetDevice(dev))) return 1;
         if (shmem > 48 * 1024 &&
             bad(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)))
@@ -295,18 +302,49 @@ struct HipRt {
         const bool timed = (prof == 1 || (prof == 2 && (!strcmp(name, "k_window") || !strcmp(name, "k_strip"))));
         if (timed) {
             if (bad(hipEventCreate(&p.a)) || bad(hipEventCreate(&p.b))) return 1;
-            if (bad(hipEventRecord(p.a, stream))) return 1;
+            if (bad(hipEventRecord(p.a, st))) return 1;
         }
         if (trace) fprintf(stderr, "[kd] %s grid %u block %u lds %zu\n", name, grid, block, shmem);
         if (guard) guard_last_kernel() = name;
-        k<<<dim3(grid), dim3(block), shmem, stream>>>(args...);
+        k<<<dim3(grid), dim3(block), shmem, st>>>(args...);
         if (bad(hipGetLastError())) return 1;
-        if ((trace == 1 || guard) && bad(hipStreamSynchronize(stream))) return 1;
+        if ((trace == 1 || guard) && bad(hipStreamSynchronize(st))) return 1;
         if (timed) {
-            if (bad(hipEventRecord(p.b, stream))) return 1;
+            if (bad(hipEventRecord(p.b, st))) return 1;
             p.name = name;
             pending.push_back(p);
         }
+        return 0;
+    }
+    // ---- side streams (the device-side ingest's inflate groups: each group needs only the file's bytes up to its last block, and a group
+    // alone leaves most of the chip idle -- a lane works ~20 ms on its block whatever the group's size): side_fork() orders the side
+    // streams behind what the main stream has queued so far, side_after_upload(i) behind the upload piece recorded last, launch_side(i, ...)
+    // launches there, side_join() puts the main stream behind all of them ----
+    static constexpr int N_SIDE = 4;
+    hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t side_ev[N_SIDE] = {nullptr, nullptr, nullptr, nullptr}, fork_ev = nullptr;
+    int last_up = -1;
+    int side_fork() {
+        if (bad(hipSetDevice(dev))) return 1;
+        if (!fork_ev && bad(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming))) return 1;
+        if (bad(hipEventRecord(fork_ev, stream))) return 1;
+        for (int i = 0; i < N_SIDE; i++) {
+            if (!side[i] && bad(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking))) return 1;
+            if (!side_ev[i] && bad(hipEventCreateWithFlags(&side_ev[i], hipEventDisableTiming))) return 1;
+            if (bad(hipStreamWaitEvent(side[i], fork_ev, 0))) return 1;
+        }
+        last_up = -1;
+        return 0;
+    }
+    int side_after_upload(int i) { return last_up >= 0 ? bad(hipStreamWaitEvent(side[i % N_SIDE], up_ev[last_up], 0)) : 0; }
+    template <class K, class... A>
+    int launch_side(int i, const char *name, K k, unsigned grid, unsigned block, size_t shmem, A... args) {
+        return launch_on(side[i % N_SIDE], name, k, grid, block, shmem, args...);
+    }
+    int memset_side(int i, void *p, int v, size_t n) { return n ? bad(hipMemsetAsync(p, v, n, side[i % N_SIDE])) : 0; }
+    int side_join() {
+        for (int i = 0; i < N_SIDE; i++)
+            if (side[i] && (bad(hipEventRecord(side_ev[i], side[i])) || bad(hipStreamWaitEvent(stream, side_ev[i], 0)))) return 1;
         return 0;
     }
 

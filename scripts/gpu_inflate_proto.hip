@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC scripts/gpu_inflate_proto.hip -o exp/libgpu_inflate_proto.so
 // C-ABI for scripts/gpu_inflate_proto.py: all pointers are DEVICE pointers but `ms`.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "gpu_inflate_proto.h"
 #include "../kindel_amd/csrc/kd_gpu_inflate2.h"
 
@@ -36,11 +37,16 @@ extern "C" int gi_inflate_blocks2(const uint8_t *comp, const GiBlock *blocks, ui
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) return 1;
     uint32_t *tokens = nullptr, *n_tok = nullptr;
     const size_t n_tokens = (size_t)gi2_tok_off(total_out, n_blocks) + 16;
-    if (hipMalloc(&tokens, n_tokens * 4) != hipSuccess || hipMalloc(&n_tok, ((size_t)n_blocks + 1) * 4) != hipSuccess) return 4;
+    if (hipMalloc(&tokens, n_tokens * 4) != hipSuccess || hipMalloc(&n_tok, ((size_t)n_blocks + 2) * 4) != hipSuccess) return 4;
+    uint32_t *work = n_tok + n_blocks + 1;
+    int cus = 256;
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, 0) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+    const unsigned waves = (unsigned)std::min<size_t>(((size_t)n_blocks + 63) / 64, (size_t)4 * cus);
     float best = 1e30f, best1 = 1e30f;
     for (int r = 0; r < (repeat > 0 ? repeat : 1); r++) {
+        hipMemsetAsync(work, 0, 4, 0);
         hipEventRecord(e0, 0);
-        k_inflate_tokens<<<(n_blocks + 63) / 64, 64, 0, 0>>>(comp, blocks, n_blocks, out, tokens, n_tok, status, 0u);
+        k_inflate_tokens<<<waves, 64, 0, 0>>>(comp, blocks, n_blocks, out, tokens, n_tok, status, 0u, work);
         hipEventRecord(e1, 0);
         k_inflate_resolve<<<n_blocks, 64, 0, 0>>>(blocks, n_blocks, out, tokens, n_tok, status, 0u);
         hipEventRecord(e2, 0);

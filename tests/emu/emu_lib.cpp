@@ -60,6 +60,14 @@ struct EmuRt {
         emu::launch(k, dim3(grid), dim3(block), shmem, args...);
         return 0;
     }
+    // (side streams: everything runs at once, in order, here)
+    static constexpr int N_SIDE = 4;
+    int side_fork() { return 0; }
+    int side_after_upload(int) { return 0; }
+    int side_join() { return 0; }
+    int memset_side(int, void *p, int v, size_t n) { ::memset(p, v, n); return 0; }
+    template <class K, class... A>
+    int launch_side(int, const char *name, K k, unsigned grid, unsigned block, size_t shmem, A... args) { return launch(name, k, grid, block, shmem, args...); }
     void profile_enable(int) {}
     int profile_get(uint32_t *n_rows, char *, uint64_t *, double *) { *n_rows = 0; return 0; }
     void profile_reset() {}
