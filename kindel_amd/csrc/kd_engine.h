@@ -749,9 +749,9 @@ struct KdEngine {
                 int bad;
                 if (two_pass) {
                     const int sd = (int)(group % (uint32_t)Rt::N_SIDE);
-                    const unsigned waves = (unsigned)std::min<uint32_t>((cnt + 63u) / 64u, 4u * (uint32_t)rt.n_cus());      // what can be resident; the rest through the counter
+                    const unsigned wgs = (unsigned)std::min<uint32_t>((cnt + GI2_WG - 1u) / GI2_WG, (uint32_t)rt.n_cus());      // what can be resident (a workgroup = a CU's LDS); the rest through the counter
                     bad = rt.side_after_upload(sd) ||
-                          rt.launch_side(sd, "k_inflate_tokens", k_inflate_tokens, waves, KD_WAVE, 0, (const uint8_t *)b_gi_file.p, d_blocks + next_block, cnt,
+                          rt.launch_side(sd, "k_inflate_tokens", k_inflate_tokens, wgs, GI2_WG, (size_t)GI2_LDS_BYTES, (const uint8_t *)b_gi_file.p, d_blocks + next_block, cnt,
                                          (uint8_t *)b_gi_out.p, (uint32_t *)b_gi_tok.p, (uint32_t *)b_gi_ntok.p + next_block, bstat + next_block, next_block,
                                          (uint32_t *)b_gi_work.p + group) ||
                           rt.launch_side(sd, "k_inflate_resolve", k_inflate_resolve, cnt, KD_WAVE, 0, d_blocks + next_block, cnt, (uint8_t *)b_gi_out.p,
@@ -1257,7 +1257,7 @@ struct KdEngine {
         return KD_OK;
     }
 
-    int knob_inflate = 1;             // KD_INFLATE=1 / 2: which GPU inflate the device-side ingest uses (ingest_bam)
+    int knob_inflate = 2;             // KD_INFLATE=2 (default since round 6: the two-pass inflate, kd_gpu_inflate2.h) / 1 (the one-pass kernel of rounds 3 - 5): which GPU inflate the device-side ingest uses
     bool knob_zero_copy = true;       // KD_ZERO_COPY=0 (tests, measurement): kd_step / kd_finish copy the FASTA behind the consensus kernel even into pinned memory
     int knob_ins_site_flags = -1;     // KD_INS_SITE_FLAGS=0 / 1 (tests, measurement): the insertion reduction's site test per event / once per site, whatever the counts
     bool knob_cold_tail = true;       // the cold records' workgroups ride in k_window's launch (kd_window.h: KdColdTail) instead of k_cold_lane's own: the memory-bound

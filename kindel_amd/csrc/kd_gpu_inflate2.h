@@ -32,8 +32,10 @@
 // between two rounds of pass 2: the round's stores must have reached the L2 before the next round's loads (which bypass the L1) ask for them
 #ifndef KD_EMU
 #define GI2_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define GI2_NO_IF_CONVERT() asm volatile("" ::: "memory")      // an asm statement cannot be executed speculatively: the block around it stays a branch
 #else
 #define GI2_DRAIN()
+#define GI2_NO_IF_CONVERT()
 #endif
 
 struct __attribute__((packed, aligned(1))) KdChunk16 { uint32_t x, y, z, w; };      // 16 bytes at any address (one global_load_dwordx4)
@@ -119,7 +121,7 @@ struct Gi2Cnt15 {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// pass 1: one LANE per block.  comp: the file (readable 8 bytes past every block's input); out: the inflated bytes of all blocks (the
+// pass 1: one LANE per block.  comp: the file (readable 32 bytes past every block's input); out: the inflated bytes of all blocks (the
 // literals are written here); tokens: the match tokens, block b's from gi2_tok_off(out_off, b0 + b); n_tok[b] tokens; status[b].
 // blocks / n_tok / status point at the launch's first block, b0 = that block's index in the file (the token regions are laid out by it).
 // work: a zeroed counter.  The launch holds what the chip can keep resident (four wavefronts per CU); a lane that has finished its block
@@ -139,34 +141,36 @@ static inline uint32_t gi2_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { ret
 #endif
 struct Gi2In {      // one lane's view of its block's compressed bytes
     const uint8_t *in;
-    uint32_t in_cap;                // bytes that may be read (the block's input + 8)
+    uint32_t in_cap;                // the last byte offset a 16-byte load may start at (the block's input + 16)
     uint32_t q0, q1, q2, q3;        // the 16 bytes the window is fed from
     uint32_t n0, n1, n2, n3;        // the 16 bytes behind them (requested when q was filled)
     uint32_t qi, qat;               // next dword of q; byte offset of n in the input
     uint32_t lo, hi, bo, wpos;      // the window: stream bits from byte wpos on, bo of them consumed
+    // 16 bytes of the input from byte `at` on -- ONE load whatever `at` is (a guarded second path made the compiler wait for the
+    // load where it is issued): past the block's end the stream reads what lies behind it (the next block's header; the file buffer
+    // is readable 32 bytes past every block), and a runaway cursor is held at the block's end + 16 -- what is decoded from there on
+    // is wrong either way and ends in GI_E_INPUT / GI_E_SIZE
     __device__ __forceinline__ void ld16(uint32_t at, uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d) const {
-        if (at + 16u <= in_cap) {
-            const KdChunk16 v = *reinterpret_cast<const KdChunk16 *>(in + at);
-            a = v.x; b = v.y; c = v.z; d = v.w;
-        } else {
-            a = at + 4u <= in_cap ? reinterpret_cast<const GiU32 *>(in + at)->v : 0u;
-            b = at + 8u <= in_cap ? reinterpret_cast<const GiU32 *>(in + at + 4u)->v : 0u;
-            c = at + 12u <= in_cap ? reinterpret_cast<const GiU32 *>(in + at + 8u)->v : 0u;
-            d = 0u;
-        }
+        const KdChunk16 v = *reinterpret_cast<const KdChunk16 *>(in + (at < in_cap ? at : in_cap));
+        a = v.x; b = v.y; c = v.z; d = v.w;
     }
     __device__ __forceinline__ void start(uint32_t at) {      // the stream from byte `at` of the input on
         ld16(at, q0, q1, q2, q3);
         ld16(at + 16u, n0, n1, n2, n3);
-        qat = at + 16u;
+        qat = at + 16u;                                        // (n is requested: q's first dword is taken here, not by next_dword)
         lo = q0; hi = q1; qi = 2u; bo = 0u; wpos = at;
     }
     __device__ __forceinline__ uint32_t next_dword() {
         const uint32_t d = qi == 0u ? q0 : qi == 1u ? q1 : qi == 2u ? q2 : q3;
-        if (++qi == 4u) {
+        ++qi;
+        // The 16 bytes behind q are REQUESTED when q's first dword is taken and MOVED into q when its last one is: two different
+        // moments, so that the request writes n in place (nothing reads n there) and the wait for it sits three dwords -- a dozen
+        // symbols -- later.  (Requested in the same branch that moves n into q, the compiler loads into temporaries, waits on the
+        // spot and copies: a memory round trip per 16 bytes, and with four wavefronts' 256 input streams the L1 holds none of them.)
+        if (qi == 1u) { qat += 16u; ld16(qat, n0, n1, n2, n3); }
+        if (qi == 4u) {
+            GI2_NO_IF_CONVERT();      // (a real branch: as selects, the moves read n -- and wait for its load -- on every call)
             q0 = n0; q1 = n1; q2 = n2; q3 = n3; qi = 0u;
-            qat += 16u;
-            ld16(qat, n0, n1, n2, n3);
         }
         return d;
     }
@@ -177,19 +181,26 @@ struct Gi2In {      // one lane's view of its block's compressed bytes
     __device__ __forceinline__ unsigned long long bits_used() const { return 8ull * wpos + bo; }
 };
 
-__global__ void __launch_bounds__(64) k_inflate_tokens(const uint8_t *comp, const GiBlock *blocks, uint32_t n_blocks, uint8_t *out,
-                                                       uint32_t *tokens, uint32_t *n_tok, uint32_t *status, uint32_t b0, uint32_t *work) {
-    __shared__ uint16_t slots[GI2_SLOTS * 64u];      // entry i of lane l: bits 0-8 i-th coded symbol in (length, value) order | bits 12-15 code length of symbol i
-    const uint32_t lane = threadIdx.x;
+// A workgroup is FOUR wavefronts -- one per SIMD of the CU, placed there by construction -- and takes the CU's whole LDS (4 x 40 448 bytes,
+// dynamic).  (As four one-wavefront workgroups the same launch was 1.6 x faster with two and 2.2 x with four wavefronts per CU than with
+// one: single-wavefront workgroups do not reliably land on different SIMDs; profiles/r06_inflate_pass1_experiments.txt.)
+#define GI2_WG 256u
+#define GI2_LDS_BYTES (GI2_SLOTS * GI2_WG * 2u)
+__global__ void __launch_bounds__(GI2_WG) k_inflate_tokens(const uint8_t *comp, const GiBlock *blocks, uint32_t n_blocks, uint8_t *out,
+                                                           uint32_t *tokens, uint32_t *n_tok, uint32_t *status, uint32_t b0, uint32_t *work) {
+    KD_DYN_SHARED(uint16_t, slots_all);
+    uint16_t *slots = slots_all + (threadIdx.x >> 6) * (GI2_SLOTS * 64u);      // this wavefront's part
+    // entry i of lane l: bits 0-8 i-th coded symbol in (length, value) order | bits 12-15 code length of symbol i
+    const uint32_t lane = threadIdx.x & 63u;
 #define GI2_SLOT(i) slots[(uint32_t)(i) * 64u + lane]
-    // (no wavefront-wide operation anywhere in this kernel: every lane is on its own)
-    for (uint32_t b = blockIdx.x * 64u + lane; b < n_blocks; b = gridDim.x * 64u + atomicAdd(work, 1u)) {
+    // (no wavefront-wide operation, no barrier anywhere in this kernel: every lane is on its own)
+    for (uint32_t b = blockIdx.x * GI2_WG + threadIdx.x; b < n_blocks; b = gridDim.x * GI2_WG + atomicAdd(work, 1u)) {
     const GiBlock B = blocks[b];
     uint8_t *dst = out + B.out_off;
     uint32_t *tk = tokens + gi2_tok_off(B.out_off, (unsigned long long)b0 + b);
     const uint32_t tok_cap = (uint32_t)(gi2_tok_off(B.out_off + B.out_len, (unsigned long long)b0 + b + 1ull) - gi2_tok_off(B.out_off, (unsigned long long)b0 + b));
     Gi2In s;
-    s.in = comp + B.in_off; s.in_cap = B.in_len + 8u;
+    s.in = comp + B.in_off; s.in_cap = B.in_len + 16u;
     s.start(0u);
     uint32_t pos = 0, run = 0, ntok = 0, err = GI_OK;
     Gi2Code<15> c_lit, c_dist;
@@ -324,7 +335,10 @@ __global__ void __launch_bounds__(64) k_inflate_tokens(const uint8_t *comp, cons
             if (sy < 256u) {
                 s.bo += len;
                 if (pos >= B.out_len) { err = GI_E_SIZE; break; }
-                dst[pos++] = (uint8_t)sy;
+#ifndef GI2_EXP_NOSTORE      // (measurement builds only: scripts/gpu_inflate_proto.hip -DGI2_EXP_NOSTORE -- what the literal stores cost)
+                dst[pos] = (uint8_t)sy;
+#endif
+                pos++;
                 run++;
                 continue;
             }

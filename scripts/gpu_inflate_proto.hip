@@ -3,6 +3,7 @@
 // C-ABI for scripts/gpu_inflate_proto.py: all pointers are DEVICE pointers but `ms`.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include "gpu_inflate_proto.h"
 #include "../kindel_amd/csrc/kd_gpu_inflate2.h"
 
@@ -41,12 +42,15 @@ extern "C" int gi_inflate_blocks2(const uint8_t *comp, const GiBlock *blocks, ui
     uint32_t *work = n_tok + n_blocks + 1;
     int cus = 256;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, 0) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
-    const unsigned waves = (unsigned)std::min<size_t>(((size_t)n_blocks + 63) / 64, (size_t)4 * cus);
+    const int wpc = getenv("GI2_WPC") ? atoi(getenv("GI2_WPC")) : 4;      // (experiment: resident wavefronts per CU the launch asks for)
+    const unsigned wgs = (unsigned)std::min<size_t>(((size_t)n_blocks + GI2_WG - 1) / GI2_WG, (size_t)cus);      // one workgroup of four wavefronts per CU
+    (void)wpc;
+    if (hipFuncSetAttribute((const void *)k_inflate_tokens, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GI2_LDS_BYTES) != hipSuccess) return 5;
     float best = 1e30f, best1 = 1e30f;
     for (int r = 0; r < (repeat > 0 ? repeat : 1); r++) {
         hipMemsetAsync(work, 0, 4, 0);
         hipEventRecord(e0, 0);
-        k_inflate_tokens<<<waves, 64, 0, 0>>>(comp, blocks, n_blocks, out, tokens, n_tok, status, 0u, work);
+        k_inflate_tokens<<<wgs, GI2_WG, GI2_LDS_BYTES, 0>>>(comp, blocks, n_blocks, out, tokens, n_tok, status, 0u, work);
         hipEventRecord(e1, 0);
         k_inflate_resolve<<<n_blocks, 64, 0, 0>>>(blocks, n_blocks, out, tokens, n_tok, status, 0u);
         hipEventRecord(e2, 0);

@@ -26,8 +26,8 @@ extern "C" int gi_inflate_blocks2(const uint8_t *comp, const GiBlock *blocks, ui
     for (int k = 0; k < 16; k++) canary[k] = 0xA5A5A5A5u;
     // (a launch smaller than the work: the lanes that finish first take the rest from the counter, as on the GPU)
     uint32_t work = 0;
-    const unsigned waves = std::max(1u, ((n_blocks + 63) / 64 + 1) / 2);
-    emu::launch(k_inflate_tokens, dim3(waves), dim3(64), 0, comp, blocks, n_blocks, out, tokens, n_tok, status, 0u, &work);
+    const unsigned wgs = std::max(1u, ((n_blocks + GI2_WG - 1) / GI2_WG + 1) / 2);
+    emu::launch(k_inflate_tokens, dim3(wgs), dim3(GI2_WG), GI2_LDS_BYTES, comp, blocks, n_blocks, out, tokens, n_tok, status, 0u, &work);
     emu::launch(k_inflate_resolve, dim3(n_blocks), dim3(64), 0, blocks, n_blocks, out, (const uint32_t *)tokens, (const uint32_t *)n_tok, (const uint32_t *)status, 0u);
     int rc = 0;
     for (int k = 0; k < 16; k++) if (canary[k] != 0xA5A5A5A5u) rc = 7;      // wrote past the token regions

@@ -46,7 +46,7 @@ def proto(request):
 
 def inflate_blocks(dll, streams, sizes):
     """streams: raw DEFLATE byte strings, sizes: announced output sizes -> (list of outputs, status array)"""
-    comp = b"".join(streams) + b"\0" * 16
+    comp = b"".join(streams) + b"\0" * 64
     blocks = (GiBlock * len(streams))()
     at = out_at = 0
     for k, (z, n) in enumerate(zip(streams, sizes)):
