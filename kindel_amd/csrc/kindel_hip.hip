@@ -53,6 +53,8 @@ struct HipRt {
     }
     void shutdown() {
         profile_reset();
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        ev_pool.clear();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; }
         if (stage_buf) { (void)hipHostFree(stage_buf); stage_buf = nullptr; stage_cap = 0; }
         for (int k = 0; k < 2; k++) { if (up_pin[k]) { (void)hipHostFree(up_pin[k]); up_pin[k] = nullptr; } if (up_ev[k]) { (void)hipEventDestroy(up_ev[k]); up_ev[k] = nullptr; } }
@@ -215,7 +217,6 @@ struct HipRt {
             if (!up_ev[k] && bad(hipEventCreateWithFlags(&up_ev[k], hipEventDisableTiming))) return 1;
         }
         unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
-        if (const char *e = getenv("KD_UPLOAD_THREADS")) nt = (unsigned)std::max(1, atoi(e));
         size_t c = 0;
         for (size_t o = 0; o < n; o += UP_CHUNK, c++) {
             const size_t len = std::min(UP_CHUNK, n - o);
@@ -301,7 +302,7 @@ struct HipRt {
         Pending p;
         const bool timed = (prof == 1 || (prof == 2 && (!strcmp(name, "k_window") || !strcmp(name, "k_strip"))));
         if (timed) {
-            if (bad(hipEventCreate(&p.a)) || bad(hipEventCreate(&p.b))) return 1;
+            if (!(p.a = take_event()) || !(p.b = take_event())) return 1;
             if (bad(hipEventRecord(p.a, st))) return 1;
         }
         if (trace) fprintf(stderr, "[kd] %s grid %u block %u lds %zu\n", name, grid, block, shmem);
@@ -348,7 +349,20 @@ struct HipRt {
         return 0;
     }
 
-    void profile_enable(int mode) { prof = mode; }
+    // timing events are kept and reused: hipEventCreate / hipEventDestroy around every timed launch cost the timed region of bench.py
+    // -- which must measure its dominant kernel live -- tens of microseconds per step (round 6: the same steps ran 1.47 ms in a loop
+    // without events and 1.55 ms in bench.py's)
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t take_event() {
+        if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (bad(hipEventCreate(&e))) return nullptr;
+        return e;
+    }
+    void profile_enable(int mode) {
+        prof = mode;
+        if (mode) for (int k = (int)ev_pool.size(); k < 64; k++) { hipEvent_t e = nullptr; if (hipEventCreate(&e) == hipSuccess) ev_pool.push_back(e); else break; }
+    }
     int drain() {
         if (pending.empty()) return 0;
         if (bad(hipStreamSynchronize(stream))) return 1;
@@ -358,7 +372,7 @@ struct HipRt {
                 auto &r = rows[p.name];
                 r.first++; r.second += ms;
             }
-            (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+            ev_pool.push_back(p.a); ev_pool.push_back(p.b);
         }
         pending.clear();
         return 0;

@@ -582,3 +582,21 @@ def test_bench_step_through_rccl_at_world_size_one():
     assert b["fasta_sha256"] == a["fasta_sha256"] and b["consensus_len"] == a["consensus_len"]
     log = two.stdout + two.stderr
     assert "NCCL INFO" in log and ("RCCL" in log or "rccl" in log or "nranks 1" in log), log[-1500:]      # the library that ran is RCCL
+
+
+def test_guard_subprocess_fence_faults_on_an_overread_and_clean_runs_pass():
+    """KD_GUARD=1 (kindel_hip.hip, round 6: every device buffer mapped by itself so that its last byte is the last mapped byte of its
+    address range, a caller's device batch copied into fenced buffers of exactly the promised sizes): (1) the fence WORKS on this box --
+    a batch whose seq4_bytes is declared 256 bytes short makes k_window read past its copy and the process dies of a GPU memory fault
+    whose report names the buffer and the kernel (scripts/exp/guard_selftest.py); (2) a clean run -- smoke()'s two paths, a step
+    sequence with inputs changed in place -- passes under the fence.  In processes of their own: a GPU fault takes its process down."""
+    env = dict(os.environ, PYTHONPATH=ROOT, KD_GUARD="1")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "exp", "guard_selftest.py")], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert bad.returncode != 0, bad.stdout[-500:]
+    assert "Memory access fault" in bad.stderr and "[kd guard] SIGABRT; last kernel launched: k_window" in bad.stderr and "b_gin[k]" in bad.stderr, bad.stderr[-1500:]
+    ok = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke(); from tests import test_gpu_parity as T; from kindel_amd import _native as N; "
+                         "T._step_sequence(N.default_library()); print('GUARDED-OK')"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert ok.returncode == 0 and "GUARDED-OK" in ok.stdout and "[kd guard] on" in ok.stderr, (ok.returncode, ok.stdout[-800:], ok.stderr[-1500:])
+    env.pop("KD_GUARD")
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "exp", "guard_selftest.py")], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert plain.returncode == 0, plain.stderr[-800:]      # (without the fence the same call reads the caller's larger tensor: nothing happens)
