@@ -216,7 +216,7 @@ struct HipRt {
             if (!up_pin[k] && bad(hipHostMalloc(&up_pin[k], UP_CHUNK, hipHostMallocDefault))) return 1;
             if (!up_ev[k] && bad(hipEventCreateWithFlags(&up_ev[k], hipEventDisableTiming))) return 1;
         }
-        unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        const unsigned nt = std::max(1u, std::min(16u, kd_host_threads()));      // (the cores the cgroup grants, not the 256 the box shows; 8 copied a 32 MiB piece slower than the link moves it)
         size_t c = 0;
         for (size_t o = 0; o < n; o += UP_CHUNK, c++) {
             const size_t len = std::min(UP_CHUNK, n - o);
