@@ -6,6 +6,7 @@
 
 #include <csignal>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -57,7 +58,8 @@ struct HipRt {
         ev_pool.clear();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; }
         if (stage_buf) { (void)hipHostFree(stage_buf); stage_buf = nullptr; stage_cap = 0; }
-        for (int k = 0; k < 2; k++) { if (up_pin[k]) { (void)hipHostFree(up_pin[k]); up_pin[k] = nullptr; } if (up_ev[k]) { (void)hipEventDestroy(up_ev[k]); up_ev[k] = nullptr; } }
+        if (up_ring) { (void)hipHostFree(up_ring); up_ring = nullptr; }
+        for (int k = 0; k < UP_SLOTS; k++) if (up_ev[k]) { (void)hipEventDestroy(up_ev[k]); up_ev[k] = nullptr; }
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
         for (int i = 0; i < N_SIDE; i++) { if (side[i]) { (void)hipStreamDestroy(side[i]); side[i] = nullptr; } if (side_ev[i]) { (void)hipEventDestroy(side_ev[i]); side_ev[i] = nullptr; } }
         if (fork_ev) { (void)hipEventDestroy(fork_ev); fork_ev = nullptr; }
@@ -205,36 +207,59 @@ struct HipRt {
     // measured on the GPU node, 40 % of the device-side ingest), and after every piece `after(bytes_there)` may launch work on the
     // compute stream that needs only the bytes [0, bytes_there): it is ordered behind that piece's copy by an event.
     hipStream_t copy_stream = nullptr;
-    void *up_pin[2] = {nullptr, nullptr};
-    hipEvent_t up_ev[2] = {nullptr, nullptr};
-    static constexpr size_t UP_CHUNK = (size_t)32 << 20;
+    // (round 6: worker threads that live for the whole upload, each copying WHOLE 4 MiB pieces into slots of one pinned ring, the
+    // calling thread moving the pieces on in order as they become ready.  Before: two 32 MiB buffers and a fresh set of threads per
+    // piece -- a thousand thread creations per 2 GB file, and the link idle while a piece was being filled: 54 - 104 ms for 2 GB.)
+    static constexpr int UP_SLOTS = 16;
+    static constexpr size_t UP_PIECE = (size_t)4 << 20;
+    void *up_ring = nullptr;
+    hipEvent_t up_ev[UP_SLOTS] = {};
     template <class F>
     int upload(void *dst, const uint8_t *src, size_t n, F &&after) {
         if (bad(hipSetDevice(dev))) return 1;
         if (!copy_stream && bad(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking))) return 1;
-        for (int k = 0; k < 2; k++) {
-            if (!up_pin[k] && bad(hipHostMalloc(&up_pin[k], UP_CHUNK, hipHostMallocDefault))) return 1;
+        if (!up_ring && bad(hipHostMalloc(&up_ring, UP_SLOTS * UP_PIECE, hipHostMallocDefault))) return 1;
+        for (int k = 0; k < UP_SLOTS; k++)
             if (!up_ev[k] && bad(hipEventCreateWithFlags(&up_ev[k], hipEventDisableTiming))) return 1;
+        size_t piece = UP_PIECE;
+        if (const char *e = getenv("KD_UPLOAD_CHUNK")) piece = std::min(UP_PIECE, (size_t)std::max(1, atoi(e)));      // (tests: many tiny pieces)
+        const size_t n_pieces = (n + piece - 1) / piece;
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(UP_SLOTS / 2, kd_host_threads()), n_pieces));
+        std::vector<std::atomic<unsigned char>> ready(n_pieces);
+        for (auto &r : ready) r.store(0, std::memory_order_relaxed);
+        std::atomic<size_t> issued{0};      // pieces whose copy to the device has been queued (their slot's event is recorded)
+        std::atomic<bool> stop{false};
+        std::vector<std::thread> th;
+        for (unsigned w = 0; w < nt; w++)
+            th.emplace_back([&, w] {
+                for (size_t c = w; c < n_pieces && !stop.load(std::memory_order_relaxed); c += nt) {
+                    const int slot = (int)(c % UP_SLOTS);
+                    if (c >= (size_t)UP_SLOTS) {      // the slot's last occupant must have left for the device
+                        while (issued.load(std::memory_order_acquire) <= c - UP_SLOTS && !stop.load(std::memory_order_relaxed)) std::this_thread::yield();
+                        if (stop.load(std::memory_order_relaxed)) return;
+                        (void)hipSetDevice(dev);
+                        (void)hipEventSynchronize(up_ev[slot]);
+                    }
+                    const size_t o = c * piece;
+                    memcpy((uint8_t *)up_ring + (size_t)slot * UP_PIECE, src + o, std::min(piece, n - o));
+                    ready[c].store(1, std::memory_order_release);
+                }
+            });
+        int rc = 0;
+        for (size_t c = 0; c < n_pieces && !rc; c++) {
+            while (!ready[c].load(std::memory_order_acquire)) std::this_thread::yield();
+            const int slot = (int)(c % UP_SLOTS);
+            const size_t o = c * piece, len = std::min(piece, n - o);
+            if (bad(hipMemcpyAsync((uint8_t *)dst + o, (uint8_t *)up_ring + (size_t)slot * UP_PIECE, len, hipMemcpyHostToDevice, copy_stream)) ||
+                bad(hipEventRecord(up_ev[slot], copy_stream)) || bad(hipStreamWaitEvent(stream, up_ev[slot], 0)))
+                rc = 1;
+            last_up = slot;
+            issued.store(c + 1, std::memory_order_release);
+            if (!rc && after(o + len)) rc = 1;
         }
-        const unsigned nt = std::max(1u, std::min(16u, kd_host_threads()));      // (the cores the cgroup grants, not the 256 the box shows; 8 copied a 32 MiB piece slower than the link moves it)
-        size_t c = 0;
-        for (size_t o = 0; o < n; o += UP_CHUNK, c++) {
-            const size_t len = std::min(UP_CHUNK, n - o);
-            const int k = (int)(c & 1);
-            if (c >= 2 && bad(hipEventSynchronize(up_ev[k]))) return 1;      // the copy that read this buffer two pieces ago is done
-            const size_t per = (len / nt + 4095) & ~(size_t)4095;
-            std::vector<std::thread> th;
-            for (unsigned t = 1; t < nt && (size_t)t * per < len; t++)
-                th.emplace_back([=] { memcpy((uint8_t *)up_pin[k] + (size_t)t * per, src + o + (size_t)t * per, std::min(per, len - (size_t)t * per)); });
-            memcpy(up_pin[k], src + o, std::min(per, len));
-            for (auto &x : th) x.join();
-            if (bad(hipMemcpyAsync((uint8_t *)dst + o, up_pin[k], len, hipMemcpyHostToDevice, copy_stream)) || bad(hipEventRecord(up_ev[k], copy_stream)) ||
-                bad(hipStreamWaitEvent(stream, up_ev[k], 0)))
-                return 1;
-            last_up = k;
-            if (after(o + len)) return 1;
-        }
-        return 0;
+        stop.store(true);
+        for (auto &x : th) x.join();
+        return rc;
     }
 
     // a pinned host buffer for a step's closing round trip (status words + run metadata), grown on demand
