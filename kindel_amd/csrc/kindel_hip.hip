@@ -7,6 +7,7 @@
 #include <csignal>
 #include <map>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -246,8 +247,12 @@ struct HipRt {
                 }
             });
         int rc = 0;
+        typedef std::chrono::steady_clock clk;
+        double t_wait = 0, t_api = 0, t_after = 0;      // (KD_INGEST_TRACE: where the calling thread's time goes)
         for (size_t c = 0; c < n_pieces && !rc; c++) {
+            const clk::time_point t0 = clk::now();
             while (!ready[c].load(std::memory_order_acquire)) std::this_thread::yield();
+            const clk::time_point t1 = clk::now();
             const int slot = (int)(c % UP_SLOTS);
             const size_t o = c * piece, len = std::min(piece, n - o);
             if (bad(hipMemcpyAsync((uint8_t *)dst + o, (uint8_t *)up_ring + (size_t)slot * UP_PIECE, len, hipMemcpyHostToDevice, copy_stream)) ||
@@ -255,10 +260,17 @@ struct HipRt {
                 rc = 1;
             last_up = slot;
             issued.store(c + 1, std::memory_order_release);
+            const clk::time_point t2 = clk::now();
             if (!rc && after(o + len)) rc = 1;
+            const clk::time_point t3 = clk::now();
+            t_wait += std::chrono::duration<double, std::milli>(t1 - t0).count(); t_api += std::chrono::duration<double, std::milli>(t2 - t1).count();
+            t_after += std::chrono::duration<double, std::milli>(t3 - t2).count();
         }
         stop.store(true);
         for (auto &x : th) x.join();
+        if (getenv("KD_INGEST_TRACE"))
+            fprintf(stderr, "kd upload: %zu pieces, %u copy threads; calling thread waited %.1f ms for filled pieces, %.1f ms in the copy / event calls, %.1f ms in the launches behind the pieces\n",
+                    n_pieces, nt, t_wait, t_api, t_after);
         return rc;
     }
 
@@ -346,9 +358,11 @@ struct HipRt {
     // alone leaves most of the chip idle -- a lane works ~20 ms on its block whatever the group's size): side_fork() orders the side
     // streams behind what the main stream has queued so far, side_after_upload(i) behind the upload piece recorded last, launch_side(i, ...)
     // launches there, side_join() puts the main stream behind all of them ----
-    static constexpr int N_SIDE = 4;
-    hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t side_ev[N_SIDE] = {nullptr, nullptr, nullptr, nullptr}, fork_ev = nullptr;
+    // (eight: a group holds its stream for one block's decode latency + its resolve pass, ~45 ms, and a 2 GB file delivers a group of
+    // 8 192 blocks every ~8 ms: with four streams the groups queued behind each other for 100 ms after the last byte had arrived)
+    static constexpr int N_SIDE = 8;
+    hipStream_t side[N_SIDE] = {};
+    hipEvent_t side_ev[N_SIDE] = {}, fork_ev = nullptr;
     int last_up = -1;
     int side_fork() {
         if (bad(hipSetDevice(dev))) return 1;

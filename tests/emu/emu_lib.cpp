@@ -61,7 +61,7 @@ struct EmuRt {
         return 0;
     }
     // (side streams: everything runs at once, in order, here)
-    static constexpr int N_SIDE = 4;
+    static constexpr int N_SIDE = 8;
     int side_fork() { return 0; }
     int side_after_upload(int) { return 0; }
     int side_join() { return 0; }
