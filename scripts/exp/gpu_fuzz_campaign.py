@@ -10,7 +10,7 @@ from tests import fuzz
 lib = N.default_library()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 t0 = time.time(); bad = 0; n = {"mixed": 0, "long": 0, "wild": 0, "valid": 0}
-seed = 100000
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100000      # (round 6: another range under KD_GUARD=1)
 while time.time() - t0 < budget:
     seed += 1
     rng = np.random.default_rng(seed)
