@@ -163,6 +163,10 @@ enum {
     KDO_B_N_LONG,       // per batch: entries in the long-CIGAR list
     KDO_B_N_REG,        // per batch: regular reads
     KDO_B_FILL,         // per batch: entries of k_window's boundary table written by gap fills (k_prep's budget)
+    KDO_B_BOUND_LO,     // per batch: the boundary table's first written entry (the granule of the batch's first read): everything in front
+                        //   of it reads as that entry (0)
+    KDO_B_BOUND_HI1,    // per batch: 1 + the table's last written entry (behind the granule of the batch's last read: "no more reads"):
+                        //   everything behind it reads as that entry; 0 = the table's own last entry
     KDO_WQ_LEFT,        // k_window's work queue: hot windows that still have slices nobody has taken
     KDO_WQ_TICKET,      // k_window's self-planned work queue (kd_window.h): window tickets handed out,
     KDO_WQ_PUB,         //   windows whose owner has published its slice count,
@@ -200,6 +204,8 @@ enum {
 #define KDS_B_N_LONG (KDO_B_N_LONG * KDS_STRIDE)
 #define KDS_B_N_REG (KDO_B_N_REG * KDS_STRIDE)
 #define KDS_B_FILL (KDO_B_FILL * KDS_STRIDE)
+#define KDS_B_BOUND_LO (KDO_B_BOUND_LO * KDS_STRIDE)
+#define KDS_B_BOUND_HI1 (KDO_B_BOUND_HI1 * KDS_STRIDE)
 #define KDS_WQ_LEFT (KDO_WQ_LEFT * KDS_STRIDE)
 #define KDS_WQ_TICKET (KDO_WQ_TICKET * KDS_STRIDE)
 #define KDS_WQ_PUB (KDO_WQ_PUB * KDS_STRIDE)

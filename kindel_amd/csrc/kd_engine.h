@@ -464,6 +464,11 @@ struct KdEngine {
                 KdReads walk_R = R;
                 KdWq Q;       // k_window plans for itself (kd_window.h): the boundary table its ranges come from
                 Q.bound32 = (const uint32_t *)b_bound.p; Q.bound64 = nullptr; Q.gran = 64u; Q.reps = 1u; Q.nb = (uint32_t)(S / 64);
+                {   // k_prep wrote the table from the granule of the batch's first read to the one behind its last (kd_prep.h): clamp to that
+                    const uint64_t hi1 = h_status[KDS_B_BOUND_HI1];
+                    if (hi1 && hi1 - 1 < Q.nb) Q.nb = (uint32_t)(hi1 - 1);
+                    Q.jlo = (uint32_t)std::min<uint64_t>(h_status[KDS_B_BOUND_LO], Q.nb);
+                }
                 Q.n_win = n_win; Q.span_slot = span_slot; Q.hot = nullptr; Q.cut = static_cut >= 2 ? static_cut : 0u;
                 if (in_order) {
                     if (use_coop && rt.launch("k_plan_ranges", k_plan_ranges, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0, info, (kd_u64)ne, w0,
@@ -510,7 +515,7 @@ struct KdEngine {
                     if (use_coop && rt.launch("k_plan_ranges_sorted", k_plan_ranges_sorted, (n_win + KD_BLOCK - 1) / KD_BLOCK, KD_BLOCK, 0,
                                   (const kd_u64 *)bo, n_bins, w0, n_win, W, slice, wl, wh, io, (const kd_u64 *)d_status, span_slot, reps))
                         return hipfail("k_sort_*");
-                    Q.bound32 = nullptr; Q.bound64 = (const kd_u64 *)bo; Q.gran = W; Q.reps = reps; Q.nb = n_bins;
+                    Q.bound32 = nullptr; Q.bound64 = (const kd_u64 *)bo; Q.gran = W; Q.reps = reps; Q.nb = n_bins; Q.jlo = 0;
                     walk_info = (const KdRInfo *)b_srec.p;
                     walk_R.seq_off = (const kd_u64 *)b_srec.p + 2; walk_R.cig_off = (const kd_u64 *)b_srec.p + 3; walk_R.n_cig = nullptr;
                     walk_R.osh = 1;
@@ -528,7 +533,7 @@ struct KdEngine {
                         rt.launch("k_sort_scan", k_sort_scan, 1u, KD_SCAN_WIDE, 0, bc, bo, n_bins, d_status) ||
                         rt.launch("k_sort_scatter", k_sort_scatter<1>, gr, KD_BLOCK, 0, info, (kd_u64)ne, W, bc, (const kd_u64 *)bo, ord))
                         return hipfail("k_sort_*");
-                    Q.bound32 = nullptr; Q.bound64 = (const kd_u64 *)bo; Q.gran = W; Q.reps = 1u; Q.nb = n_bins;
+                    Q.bound32 = nullptr; Q.bound64 = (const kd_u64 *)bo; Q.gran = W; Q.reps = 1u; Q.nb = n_bins; Q.jlo = 0;
                     order = ord;
                 }
                 if (!use_coop) {

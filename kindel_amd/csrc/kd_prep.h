@@ -225,19 +225,24 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
                 const uint32_t pk = pcb + (uint32_t)(ppos > 0 ? ppos : 0);
                 a_unsorted += (ok && pk > gkey) ? 1u : 0u;
                 // k_window's BOUNDARY TABLE (kd_window.h: KdWq): bound[j] = first read that starts at or behind site 64 j.  A read in
-                // a later granule than its predecessor fills the granules in between (the batch's first read: from granule 0) --
-                // by itself when that is one or two entries (deep coverage: every granule holds reads), the whole wavefront
-                // together when it is a gap in the coverage.  Meaningless for an unsorted batch (which is bucket-sorted instead,
-                // the table unused) -- and there every forward jump would look like a gap to fill: a wavefront that sees ONE read
-                // start in front of its predecessor stops filling for good (random order: the first 64 reads it looks at), and
-                // fills of more than 64 entries draw on a budget of 4 x the table (a sorted batch fills every entry once).
+                // a later granule than its predecessor fills the granules in between -- by itself when that is one or two entries
+                // (deep coverage: every granule holds reads), the whole wavefront together when it is a gap in the coverage.
+                // The granules in FRONT of the batch's first read and BEHIND its last one are not written at all (round 6: on a
+                // shard of a strong-scaling run they are seven eighths of the table, filled by the first and the last wavefront
+                // while every other one had left -- a third of this kernel's time there, scripts/exp/prep_slowest_wave.sh): two
+                // status words name the table's first and last written entry, a reader clamps to them (kd_wq_bound).
+                // Meaningless for an unsorted batch (which is bucket-sorted instead, the table unused) -- and there every forward
+                // jump would look like a gap to fill: a wavefront that sees ONE read start in front of its predecessor stops
+                // filling for good (random order: the first 64 reads it looks at), and fills of more than 64 entries draw on a
+                // budget of 4 x the table (a sorted batch fills every entry once).
                 if (bound) {
                     if (kd_ballot(ok && pk > gkey)) fill_on = false;          // (wave-uniform)
                     // (a POS behind the last contig's end -- the read is an IndexError further down -- must not index past the
                     // table's nb + 1 entries: both granules are clamped to nb, which leaves such a read nothing to fill)
                     const uint32_t kj = (gkey >> 6) < nb ? (gkey >> 6) : nb;
                     const uint32_t pj = (pk >> 6) < nb ? (pk >> 6) : nb;
-                    const uint32_t b0 = i == 0 ? 0u : pj + 1u;                // first granule to fill
+                    const uint32_t b0 = i == 0 ? kj : pj + 1u;                // first granule to fill (the batch's first read: its own)
+                    if (ok && i == 0) status[KDS_B_BOUND_LO] = (kd_u64)kj;
                     uint32_t cnt = (fill_on && ok && kj >= b0) ? kj - b0 + 1u : 0u;
                     if (cnt <= 2u) {
                         if (cnt) bound[b0] = (uint32_t)i;
@@ -254,13 +259,11 @@ k_prep(KdReads rd, KdTabs T, KdRInfo *rinfo, KdColdRec *cold_rec, uint32_t *cold
                         }
                         for (uint32_t x = t; x < fn; x += KD_WAVE) bound[f0 + x] = fv;
                     }
-                    // behind the batch's last read: "none" = the number of reads
-                    if (tail_wave) {   // (uniform: the wavefront that holds the batch's last read)
-                        const unsigned long long lm = kd_ballot(ok && i + 1 == rd.n);
-                        if (lm) {
-                            const uint32_t f0 = kd_shfl(kj, (uint32_t)__builtin_ctzll(lm)) + 1u;
-                            for (uint32_t x = f0 + t; x <= nb; x += KD_WAVE) bound[x] = (uint32_t)rd.n;
-                        }
+                    // behind the batch's last read: ONE entry "none" = the number of reads (a last read in the table's last granule
+                    // leaves that granule's entry as it is: the reader's clamp ends there anyway)
+                    if (tail_wave && ok && i + 1 == rd.n) {
+                        if (kj < nb) bound[kj + 1u] = (uint32_t)rd.n;
+                        status[KDS_B_BOUND_HI1] = (kd_u64)(kj < nb ? kj + 1u : nb) + 1ull;
                     }
                 }
             }

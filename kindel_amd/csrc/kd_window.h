@@ -488,13 +488,15 @@ struct KdWq {
     const uint32_t *bound32;   // k_prep's table (gran 64), or NULL:
     const kd_u64 *bound64;     //   the bin offsets of the bucket sort (entry b * reps = first slot of bin b)
     uint32_t gran, reps;
-    uint32_t nb;               // last valid index of the table (= its entry for "behind the last site")
+    uint32_t nb;               // last valid index of the table (= its entry for "behind the last site"; k_prep's table: its last WRITTEN entry)
+    uint32_t jlo;              // first valid index (k_prep leaves the granules in front of the batch's first read unwritten: they read as this entry)
     KdHot *hot;                // [n_win]
     uint32_t n_win, span_slot;
     uint32_t cut;              // > 0: STATIC queue -- workgroup b tallies part (b mod cut) of window (b / cut), see k_window
 };
 __device__ __forceinline__ kd_u64 kd_wq_bound(const KdWq &Q, kd_u64 j) {
     j = j < Q.nb ? j : Q.nb;
+    j = j > Q.jlo ? j : Q.jlo;
     return Q.bound32 ? (kd_u64)Q.bound32[j] : Q.bound64[j * Q.reps];
 }
 // candidate range of local window w: entries that start in [wlo - back, whi + maxlead), `back` = what an entry in front of the

@@ -39,7 +39,7 @@
         const unsigned long long pc_t2 = wall_clock64();                                                           \
         if (threadIdx.x == 0) {                                                                                    \
             atomicAdd(&status[KDS_DBG0 + 8 * KDS_STRIDE], pc_t1 - pc_t0); atomicAdd(&status[KDS_DBG0 + 9 * KDS_STRIDE], pc_t2 - pc_t1);   \
-            atomicMax(&status[KDS_DBG0 + 10 * KDS_STRIDE], pc_t2 - pc_t0); atomicMax(&status[KDS_DBG0 + 11 * KDS_STRIDE], ~pc_t0);        \
+            atomicMax(&status[KDS_DBG0 + 10 * KDS_STRIDE], ((pc_t2 - pc_t0) << 20) | (blockIdx.x < 0xfffffu ? blockIdx.x : 0xfffffu)); atomicMax(&status[KDS_DBG0 + 11 * KDS_STRIDE], ~pc_t0);        \
             atomicMax(&status[KDS_DBG0 + 12 * KDS_STRIDE], pc_t2); atomicAdd(&status[KDS_DBG0 + 13 * KDS_STRIDE], 1ULL);                  \
         }                                                                                                          \
     }
@@ -55,7 +55,8 @@
         fprintf(stderr, "\n");                                                                                     \
         const double nw_ = (double)(h)[KDS_DBG0 + 13 * KDS_STRIDE];                                                \
         if (nw_ > 0)                                                                                               \
-            fprintf(stderr, "k_prep wavefronts (last batch; 100 MHz ticks as us): %.0f waves, loop avg %.2f us, tail avg %.2f us, longest %.2f us, first start -> last end %.2f us\n", \
-                    nw_, (h)[KDS_DBG0 + 8 * KDS_STRIDE] / nw_ / 100.0, (h)[KDS_DBG0 + 9 * KDS_STRIDE] / nw_ / 100.0, (h)[KDS_DBG0 + 10 * KDS_STRIDE] / 100.0, \
+            fprintf(stderr, "k_prep wavefronts (last batch; 100 MHz ticks as us): %.0f waves, loop avg %.2f us, tail avg %.2f us, longest %.2f us (wavefront %llu), first start -> last end %.2f us\n", \
+                    nw_, (h)[KDS_DBG0 + 8 * KDS_STRIDE] / nw_ / 100.0, (h)[KDS_DBG0 + 9 * KDS_STRIDE] / nw_ / 100.0, ((h)[KDS_DBG0 + 10 * KDS_STRIDE] >> 20) / 100.0, \
+                    (unsigned long long)((h)[KDS_DBG0 + 10 * KDS_STRIDE] & 0xfffffu), \
                     ((double)(h)[KDS_DBG0 + 12 * KDS_STRIDE] - (double)(~(h)[KDS_DBG0 + 11 * KDS_STRIDE])) / 100.0);    \
     }
