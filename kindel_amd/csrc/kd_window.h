@@ -25,6 +25,9 @@
 // Only regular reads are handled here; their clip_starts / clip_ends counters and insertion events are done by
 // k_cold_lane / k_long_expand, irregular reads by k_pileup_wave.
 #define KD_HCH 19
+#ifndef KD_EXP_DELETE
+#define KD_EXP_DELETE 0    // TIMING EXPERIMENTS only (wrong tables; scripts/exp/kwindow_deletions.sh): 1 no adds of the plain reads inside the window, 2 no
+#endif                     // base loads there, 4 no complex walk, 8 no flush -- how much of k_window's time hangs on each
 #define KD_HCH_DEL 6u
 #define KD_HCH_CSW 7u
 #define KD_HCH_CEW 13u
@@ -253,6 +256,11 @@ __device__ __forceinline__ bool kd_walk_short(const KdReads &rd, kd_u64 i, const
     if (nc > 2) w2 = cg[2];
     if (nc > 3) w3 = cg[3];
     const KdChunk *src = reinterpret_cast<const KdChunk *>(KD_SEQ_AT(rd, i));
+    // (round 6) the read's FIRST chunk of bases is requested here, next to the CIGAR words, not behind their decoding: where it lies
+    // does not depend on them, and it is the first chunk the loop below wants for every read the window's left edge does not cut --
+    // one memory round trip less in a chain of seven (scripts/exp/kwindow_deletions.sh: the 23 % of C3's reads with a clip or an
+    // indel cost k_window 0.28 of its 1.02 ms, 2.8 x a plain read each, and what they wait for is this chain, not their adds)
+    const KdChunk first = src[0];
     uint32_t n_seg_ops = 0;
     for (uint32_t k = 0; k < nc; k++) {
         const uint32_t cw = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : k == 3 ? w3 : cg[k];
@@ -311,14 +319,15 @@ __device__ __forceinline__ bool kd_walk_short(const KdReads &rd, kd_u64 i, const
     }
     if (ns == 0) return true;
     int32_t c = a0 >> 5, cb = (b0 - 1) >> 5;
-    KdChunk cur = src[c];
+    KdChunk cur = first;
+    if (c != 0) cur = src[c];
     for (;;) {
         // the step after this one: next chunk of the segment, or the first chunk of the next segment
         const bool adv = c + 1 > cb;
         const bool more = !adv || ns > 1;
         const int32_t cn = adv ? (a1 >> 5) : c + 1;
         KdChunk nxt = cur;
-        if (more) nxt = src[cn];
+        if (more && cn != c) nxt = src[cn];      // (a segment that starts in the chunk its predecessor ended in: the chunk is here)
         kd_add_chunk_masked(hist0, cur, 32 * c, a0, b0, x0, g0);
         if (!more) break;
         if (adv) {
@@ -403,6 +412,9 @@ __device__ __forceinline__ void kd_add8_ptr(unsigned char *h, unsigned char *hq,
     kd_codes8(v, rh, rl);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
+#ifdef KD_EXP_SKIP_BASES   // (TIMING EXPERIMENT only, wrong tables: the last n bases of every dword are not added -- what removing n / 8 of the hot path's
+        if (b >= 8 - KD_EXP_SKIP_BASES) continue;   //  ds_add instructions could buy at most, scripts/exp/kwindow_fewer_adds.sh)
+#endif
         const uint32_t code = (((b & 1) ? rl : rh) >> (8 * (b >> 1))) & 0xffu;
         unsigned char *a = ((b & 1) ? hq : h) + code + KD_HPITCHB * (b >> 1);
         atomicAdd(reinterpret_cast<uint32_t *>(a), (b & 1) ? vq : vp);
@@ -425,11 +437,21 @@ __device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const
     const KdChunk *src = reinterpret_cast<const KdChunk *>(KD_SEQ_AT(rd, i));
     const uint32_t r4 = (ROT && cb == 4) ? rot & 3u : 0u;        // slot c holds chunk (c + r4) & 3 (slots 0-3 of a read with a fifth chunk)
     const uint32_t c0 = r4, c1 = ROT ? (1u + r4) & 3u : 1u, c2 = ROT ? (2u + r4) & 3u : 2u, c3 = ROT ? (3u + r4) & 3u : 3u;
+#if KD_EXP_DELETE & 2      // (TIMING EXPERIMENT: no base loads on this path -- lane-varying constants instead)
+    KdChunk k0; { const uint32_t z = (uint32_t)i * 0x9E3779B1u; k0.x = z; k0.y = z * 3u; k0.z = z * 5u; k0.w = z * 7u; (void)src; }
+    KdChunk k1 = k0, k2 = k0, k3 = k0, k4 = k0;
+#else
     KdChunk k0 = src[c0], k1 = k0, k2 = k0, k3 = k0, k4 = k0;
     if (cb >= 1) k1 = src[c1];
     if (cb >= 2) k2 = src[c2];
     if (cb >= 3) k3 = src[c3];
     if (cb >= 4) k4 = src[4];
+#endif
+#if KD_EXP_DELETE & 1      // (TIMING EXPERIMENT: the loads stay, nothing is added)
+    asm volatile("" :: "v"(k0.x), "v"(k0.w), "v"(k1.x), "v"(k1.w), "v"(k2.x), "v"(k2.w), "v"(k3.x), "v"(k3.w), "v"(k4.x), "v"(k4.w));
+    (void)Wh; (void)hist0; (void)c0; (void)c1; (void)c2; (void)c3;
+    return;
+#endif
     const int32_t p = grel & 1;
     unsigned char *h = reinterpret_cast<unsigned char *>(hist0) + KD_MUL24S(grel >> 1, KD_HPITCHB);
     unsigned char *hq = h + KD_HPITCHB * p;
@@ -785,9 +807,13 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                         else { ri.gstart = (uint32_t)wlo + (cm & 1023u); ri.span_cls = ((cm >> 10) & 1023u) << KD_SPAN_SHIFT; ri.lead = (cm >> 20) & 127u; ri.pad = (cm >> 27) << 24; }
                         const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);
                         const int32_t foot_end = grel + (int32_t)(ri.span_cls >> KD_SPAN_SHIFT);
+#if KD_EXP_DELETE & 4      // (TIMING EXPERIMENT: no complex walk)
+                        (void)grel; (void)foot_end;
+#else
                         if (!kd_walk_short(rd, i, ri, wlo, We, Wh, hist0)) {   // more than three segments: general walk
                             kd_walk_ops(rd, i, ri.pad >> 24, 0u, ri.pad >> 24, grel, 0, (int32_t)ri.lead, foot_end, We, Wh, hist0);
                         }
+#endif
                     }
                     continue;
                 }
@@ -845,7 +871,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
         // the wavefront clocks.)
         // LDS channel -> table channel (KD_CH_*): weights 0-4, deletions 5, csw 6-10, cew 11-15; 0xff = bad slot
         bool bad = false;
-        for (uint32_t xw = t; xw < (uint32_t)Wh; xw += KD_BLOCK) {
+        for (uint32_t xw = t; xw < ((KD_EXP_DELETE & 8) ? 0u : (uint32_t)Wh); xw += KD_BLOCK) {     // (& 8: TIMING EXPERIMENT, no flush)
             uint32_t v[KD_HCH];
 #pragma unroll
             for (uint32_t ch = 0; ch < KD_HCH; ch++) v[ch] = hist[xw * KD_HPITCH + ch];
