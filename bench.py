@@ -42,8 +42,8 @@ def algorithmic_bytes(n_reads, query_bases, cigar_ops, sites):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)      # (the round-end driver's own choice: --steps 20 --warmup 5; a step is 1.5 ms)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C3", help="C2 | C3 | C4 | C5 (SURVEY.md section 8d)")
     ap.add_argument("--synth", action="append", default=[], metavar="KEY=VALUE",
                     help="override a synthetic-generator parameter (sensitivity runs; not the BASELINE workload)")
