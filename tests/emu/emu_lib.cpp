@@ -22,7 +22,14 @@ struct EmuRt {
     // for and the engine asks for exactly what it needs (kd_engine.h: ensure, push_device) -- the CPU counterpart of the product's
     // KD_GUARD: an access past a buffer's end lands in the sanitizer's red zone instead of in head-room
     bool exact = getenv("KD_EMU_EXACT") != nullptr;
-    void *alloc(size_t bytes, const char * = "") { return exact ? malloc(bytes ? bytes : 1) : aligned_alloc(256, (bytes + 255) & ~size_t(255)); }
+    // KD_EMU_FILL=<byte>: every allocation starts out filled with it -- what hipMalloc hands out in a long-lived process is not zero pages
+    // either; a kernel that reads what nobody wrote shows in the results (tests/test_emu_kernels.py: test_poisoned_device_memory_...)
+    void *alloc(size_t bytes, const char * = "") {
+        const size_t n = exact ? (bytes ? bytes : 1) : ((bytes + 255) & ~size_t(255));
+        void *p = exact ? malloc(n) : aligned_alloc(256, n ? n : 256);
+        if (p) if (const char *e = getenv("KD_EMU_FILL")) ::memset(p, atoi(e), n);
+        return p;
+    }
     bool exact_sizes() const { return exact; }
     void free(void *p) { ::free(p); }
     int memset(void *p, int v, size_t n) { ::memset(p, v, n); return 0; }

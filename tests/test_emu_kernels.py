@@ -643,3 +643,30 @@ def test_finish_writes_the_fasta_itself_or_copies_it(emu_lib, monkeypatch, zero_
         assert bool((out[4096:] == 0xEE).all())
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("fill", ["165", "255"])
+def test_poisoned_device_memory_changes_nothing(emu_lib, monkeypatch, fill):
+    """Every "device" allocation starts out filled with a poison byte (KD_EMU_FILL; hipMalloc does not hand out zero pages in a long-lived
+    process either): whatever a kernel reads must have been written by the engine first.  Pins, among others, round 6's boundary table
+    (kd_prep.h): k_prep no longer writes the granules in front of the batch's first read and behind its last one, k_window's range
+    look-ups are clamped to the written range -- reads in the MIDDLE of a long contig, alone and as shards of it, a coverage gap, an
+    unsorted batch, long reads, several pushes."""
+    monkeypatch.setenv("KD_EMU_FILL", fill)
+    tb = synth.to_numpy(synth.short_reads([40000], 25, seed=77))
+    # keep only the reads that start in [14 000, 19 000) and [23 000, 26 000): 14 000 sites of nothing in front, a gap, 14 000 behind
+    keep = np.flatnonzero(((tb["pos0"] >= 14000) & (tb["pos0"] < 19000)) | ((tb["pos0"] >= 23000) & (tb["pos0"] < 26000)))
+    mid = dict(tb)
+    for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+        mid[k] = tb[k][keep]
+    for window, n_pushes in ((0, 1), (128, 1), (448, 3)):
+        P.assert_matches_oracle(P.Run(emu_lib, mid, window=window, n_pushes=n_pushes), what="middle of a contig, window %d" % window)
+    P.check_as_shards(emu_lib, mid, 4)
+    rng = np.random.default_rng(5)
+    shuf = dict(mid)
+    perm = rng.permutation(len(keep))
+    for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+        shuf[k] = mid[k][perm]
+    P.assert_matches_oracle(P.Run(emu_lib, shuf, window=256), what="the same reads in random order")
+    lb = synth.to_numpy(synth.long_reads([30000], 6, seed=9, median_len=3000, min_len=1500, max_len=6000))
+    P.assert_matches_oracle(P.Run(emu_lib, lb, window=256), what="long reads")
