@@ -27,7 +27,7 @@
 #define KD_HCH 19
 #ifndef KD_EXP_DELETE
 #define KD_EXP_DELETE 0    // TIMING EXPERIMENTS only (wrong tables; scripts/exp/kwindow_deletions.sh): 1 no adds of the plain reads inside the window, 2 no
-#endif                     // base loads there, 4 no complex walk, 8 no flush -- how much of k_window's time hangs on each
+#endif                     // base loads there, 4 no complex walk, 8 no flush, 16 no zeroing, 32 no classification, 64 no fetch of the tiles' keys
 #define KD_HCH_DEL 6u
 #define KD_HCH_CSW 7u
 #define KD_HCH_CEW 13u
@@ -717,14 +717,14 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
         for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
             const kd_u64 j = first + u * KD_BLOCK + t;
             p_sc[u] = KD_CLS_SKIP; p_gs[u] = 0; p_ld[u] = 0;
-            if (j < last) {
+            if (j < last && !(KD_EXP_DELETE & 64)) {      // (& 64: TIMING EXPERIMENT, the tiles' keys are not fetched)
                 const KdRInfo ri = KD_RI(rinfo, rd, order ? (kd_u64)order[j] : j);
                 p_gs[u] = ri.gstart; p_sc[u] = ri.span_cls; p_ld[u] = (ri.lead & 0xffffffu) | (ri.pad & 0xff000000u);
             }
         }
         {   // Wh is a multiple of 4 (W is a multiple of 64): zero with 16-byte stores
             uint4 *h4 = reinterpret_cast<uint4 *>(hist);
-            for (uint32_t x = t; x < nh / 4; x += KD_BLOCK) h4[x] = make_uint4(0u, 0u, 0u, 0u);
+            for (uint32_t x = t; x < ((KD_EXP_DELETE & 16) ? 0u : nh / 4); x += KD_BLOCK) h4[x] = make_uint4(0u, 0u, 0u, 0u);   // (& 16: TIMING EXPERIMENT, no zeroing)
         }
         KD_MARK(c_zero)
         uint32_t par = 0;
@@ -732,6 +732,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
             // classify the tile's reads: plain (single aligned run) / complex; drop those outside the window
 #pragma unroll
             for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
+                if (KD_EXP_DELETE & 32) continue;      // (TIMING EXPERIMENT: nothing is classified, the lists stay empty)
                 const kd_u64 gs = p_gs[u], span = p_sc[u] >> KD_SPAN_SHIFT;
                 if (!ROWS) {
                     const kd_u64 j = tb + u * KD_BLOCK + t;
@@ -778,7 +779,7 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
             for (uint32_t u = 0; u < KD_TILE_PER_THREAD; u++) {
                 const kd_u64 j = tb + KD_TILE + u * KD_BLOCK + t;
                 p_sc[u] = KD_CLS_SKIP;
-                if (j < last) {
+                if (j < last && !(KD_EXP_DELETE & 64)) {
                     const KdRInfo ri = KD_RI(rinfo, rd, order ? (kd_u64)order[j] : j);
                     p_gs[u] = ri.gstart; p_sc[u] = ri.span_cls; p_ld[u] = (ri.lead & 0xffffffu) | (ri.pad & 0xff000000u);
                 }
