@@ -600,3 +600,29 @@ def test_guard_subprocess_fence_faults_on_an_overread_and_clean_runs_pass():
     env.pop("KD_GUARD")
     plain = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "exp", "guard_selftest.py")], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert plain.returncode == 0, plain.stderr[-800:]      # (without the fence the same call reads the caller's larger tensor: nothing happens)
+
+
+def test_reads_in_the_middle_of_a_long_contig_over_dirty_device_memory(hip_lib):
+    """Round 6: k_prep writes k_window's boundary table only between the batch's first and last read, k_window's look-ups are clamped to
+    that range (kd_prep.h, kd_engine.h).  hipMalloc does not hand out zero pages in a long-lived process: device memory is dirtied first
+    (allocated, filled with 0xA5, freed), then reads that cover only the middle of a long contig -- a third of nothing in front, a gap, a
+    third behind -- run alone, in three pushes, as four shards and in random order.  The CPU twin with a poisoned emulator:
+    tests/test_emu_kernels.py::test_poisoned_device_memory_changes_nothing."""
+    import torch
+    dirt = [torch.full((64 << 20,), 0xA5, dtype=torch.uint8, device="cuda") for _ in range(8)]
+    torch.cuda.synchronize()
+    del dirt
+    torch.cuda.empty_cache()
+    tb = synth.to_numpy(synth.short_reads([600000], 30, seed=78))
+    keep = np.flatnonzero(((tb["pos0"] >= 210000) & (tb["pos0"] < 290000)) | ((tb["pos0"] >= 350000) & (tb["pos0"] < 390000)))
+    mid = dict(tb)
+    for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+        mid[k] = tb[k][keep]
+    for window, n_pushes in ((0, 1), (448, 3)):
+        P.assert_matches_oracle(P.Run(hip_lib, mid, window=window, n_pushes=n_pushes), what="middle of a contig, window %d" % window)
+    P.check_as_shards(hip_lib, mid, 4, dev="cuda")
+    shuf = dict(mid)
+    perm = np.random.default_rng(6).permutation(len(keep))
+    for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+        shuf[k] = mid[k][perm]
+    P.assert_matches_oracle(P.Run(hip_lib, shuf), what="the same reads in random order")
