@@ -27,7 +27,8 @@
 #define KD_HCH 19
 #ifndef KD_EXP_DELETE
 #define KD_EXP_DELETE 0    // TIMING EXPERIMENTS only (wrong tables; scripts/exp/kwindow_deletions.sh): 1 no adds of the plain reads inside the window, 2 no
-#endif                     // base loads there, 4 no complex walk, 8 no flush, 16 no zeroing, 32 no classification, 64 no fetch of the tiles' keys
+#endif                     // base loads there, 4 no complex walk, 8 no flush, 16 no zeroing, 32 no classification, 64 no fetch of the tiles' keys,
+                           // 128 the plain reads' chunk loads wave-uniform (one line per load instruction instead of 64)
 #define KD_HCH_DEL 6u
 #define KD_HCH_CSW 7u
 #define KD_HCH_CEW 13u
@@ -434,7 +435,12 @@ __device__ __forceinline__ void kd_walk_inner(const KdReads &rd, kd_u64 i, const
     const int32_t cb = (len - 1) >> 5;
     if (cb > 4) { kd_walk_plain(rd, i, ri, wlo, Wi, Wh, hist0); return; }
     const int32_t grel = (int32_t)(ri.gstart - (uint32_t)wlo);   // 0 <= grel, grel + len <= W
+#if KD_EXP_DELETE & 128    // (TIMING EXPERIMENT: every lane of the wavefront fetches the FIRST lane's read -- the same five requests, one line each instead of 64)
+    const kd_u64 so_ = KD_SOFF(rd, i);
+    const KdChunk *src = reinterpret_cast<const KdChunk *>(rd.seq4 + (((kd_u64)kd_readfirstlane((uint32_t)(so_ >> 32)) << 32) | kd_readfirstlane((uint32_t)so_)));
+#else
     const KdChunk *src = reinterpret_cast<const KdChunk *>(KD_SEQ_AT(rd, i));
+#endif
     const uint32_t r4 = (ROT && cb == 4) ? rot & 3u : 0u;        // slot c holds chunk (c + r4) & 3 (slots 0-3 of a read with a fifth chunk)
     const uint32_t c0 = r4, c1 = ROT ? (1u + r4) & 3u : 1u, c2 = ROT ? (2u + r4) & 3u : 2u, c3 = ROT ? (3u + r4) & 3u : 3u;
 #if KD_EXP_DELETE & 2      // (TIMING EXPERIMENT: no base loads on this path -- lane-varying constants instead)
