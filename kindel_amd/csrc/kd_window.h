@@ -826,7 +826,11 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                 }
                 if (!ROWS) rr -= rows_c;
                 if (rr < rows_i) {
+#ifdef KD_EXP_ADJ      // (EXPERIMENT: a wavefront's lanes take ADJACENT list entries -- neighbouring reads, neighbouring memory -- instead of entries
+                    const uint32_t r = rr, e = r * KD_WAVE + lane;      //  `rows` apart; 1: with the chunk rotation of deep tiles, 2: without)
+#else
                     const uint32_t r = rr, e = lane * rows_i + r;
+#endif
                     if (e < ni) {
                         const uint32_t le = l_plain[e];
                         const kd_u64 j = tb + (le & 1023u), i = order ? (kd_u64)order[j] : j;
@@ -834,6 +838,9 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                         if (ROWS || !KD_LIST_CARRY || (le >> 20) == 0u) ri = KD_RI(rinfo, rd, i);
                         else { ri.gstart = (uint32_t)wlo + ((le >> 10) & 1023u); ri.span_cls = (le >> 20) << KD_SPAN_SHIFT; ri.lead = 0; ri.pad = 0; }
                         if (ROWS) kd_walk_row(rd, i, ri, wlo, Wi, lane + 17u * r, hist0);
+#ifdef KD_EXP_ADJ
+                        else if (KD_EXP_ADJ == 1) kd_walk_inner<true>(rd, i, ri, wlo, We, Wh, hist0, lane);
+#endif
                         else if (deep) kd_walk_inner<true>(rd, i, ri, wlo, We, Wh, hist0, lane);
                         else kd_walk_inner<false>(rd, i, ri, wlo, We, Wh, hist0, 0u);
                     }
