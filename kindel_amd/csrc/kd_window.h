@@ -827,7 +827,11 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                 if (!ROWS) rr -= rows_c;
                 if (rr < rows_i) {
 #ifdef KD_EXP_ADJ      // (EXPERIMENT: a wavefront's lanes take ADJACENT list entries -- neighbouring reads, neighbouring memory -- instead of entries
-                    const uint32_t r = rr, e = r * KD_WAVE + lane;      //  `rows` apart; 1: with the chunk rotation of deep tiles, 2: without)
+                    //  `rows` apart; 1: with the chunk rotation of deep tiles, 2: without; 3 / 4: PAIRS / QUADS of lanes on adjacent entries, each
+                    //  lane of a group from another chunk, the groups `rows` apart)
+                    const uint32_t r = rr;
+                    const uint32_t e = KD_EXP_ADJ == 3 ? 2u * ((lane >> 1) * rows_i + r) + (lane & 1u)
+                                     : KD_EXP_ADJ == 4 ? 4u * ((lane >> 2) * rows_i + r) + (lane & 3u) : r * KD_WAVE + lane;
 #else
                     const uint32_t r = rr, e = lane * rows_i + r;
 #endif
@@ -840,6 +844,8 @@ k_window(KdReads rd, const KdRInfo *rinfo, const uint32_t *order, KdTabs T, KdWq
                         if (ROWS) kd_walk_row(rd, i, ri, wlo, Wi, lane + 17u * r, hist0);
 #ifdef KD_EXP_ADJ
                         else if (KD_EXP_ADJ == 1) kd_walk_inner<true>(rd, i, ri, wlo, We, Wh, hist0, lane);
+                        else if (KD_EXP_ADJ == 3) kd_walk_inner<true>(rd, i, ri, wlo, We, Wh, hist0, (lane & 1u) * 2u);
+                        else if (KD_EXP_ADJ == 4) kd_walk_inner<true>(rd, i, ri, wlo, We, Wh, hist0, lane & 3u);
 #endif
                         else if (deep) kd_walk_inner<true>(rd, i, ri, wlo, We, Wh, hist0, lane);
                         else kd_walk_inner<false>(rd, i, ri, wlo, We, Wh, hist0, 0u);
