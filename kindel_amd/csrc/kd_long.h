@@ -46,12 +46,12 @@ __device__ __forceinline__ void kd_block_scan_incl2(kd_u64 &a, kd_u64 &b, kd_u64
 // is the last op that touches r, and its own reach is kept apart as the trailing clip)
 struct KdAdv { uint32_t r, q; };
 __device__ __forceinline__ KdAdv kd_op_advance(uint32_t w, uint32_t k) {
-    const uint32_t len = w >> 4, op = w & 15u;
-    const bool small = len < KD_LONG_MAX_OP;
-    const bool m = op == 0 || op == 7 || op == 8;
-    KdAdv a;
-    a.r = (small && (m || op == 2)) ? len : 0u;
-    a.q = (small && (m || op == 1 || (op == 4 && k == 0))) ? len : 0u;
+    const uint32_t op = w & 15u;
+    const uint32_t lens = w < (KD_LONG_MAX_OP << 4) ? w >> 4 : 0u;      // the length when it is below KD_LONG_MAX_OP
+    const bool m = ((0x181u >> op) & 1u) != 0;                          // M, =, X
+    KdAdv a;      // (bitwise on purpose: selects, no branches)
+    a.r = (m | (op == 2)) ? lens : 0u;
+    a.q = (m | (op == 1) | ((op == 4) & (k == 0))) ? lens : 0u;
     return a;
 }
 
@@ -61,6 +61,7 @@ __device__ __forceinline__ KdAdv kd_op_advance(uint32_t w, uint32_t k) {
 // gaps (longest-processing-time-first list scheduling).  One workgroup: a counting sort over 128 length classes (CIGAR words, two
 // mantissa bits per power of two), descending.
 #define KD_LONG_ORDER_BLOCK 1024
+#define KD_LONG_ORDER_PER 16u
 #define KD_LONG_ORDER_MAX (1u << 20)     // (more long reads than this: list order -- a tail of one read no longer shows)
 __global__ void __launch_bounds__(KD_LONG_ORDER_BLOCK)
 k_long_order(KdReads rd, const uint32_t *long_list, uint32_t n_long, uint32_t *order) {
@@ -73,26 +74,44 @@ k_long_order(KdReads rd, const uint32_t *long_list, uint32_t n_long, uint32_t *o
         const uint32_t lg = 31u - (uint32_t)__builtin_clz(v);
         return 127u - ((lg << 2) | ((v >> (lg - 2u)) & 3u));      // 0 = the longest class
     };
-    // pass 1: a read's class from its CIGAR word count (two dependent loads per read: four reads per turn in flight), kept in the
-    // second half of `order` (2 x n_long words) for pass 2
+    // pass 1: a read's class from its CIGAR word count (two dependent loads per read), kept in the second half of `order`
+    // (2 x n_long words) for pass 2.  (round 6) KD_LONG_ORDER_PER reads per thread and turn, their loads all in flight together:
+    // the kernel is ONE workgroup, so its time is the number of dependent memory round trips it makes -- four reads per turn were
+    // ten round trips on C5's 17 699 long reads, and the 128 classes were scanned by one thread (128 dependent LDS
+    // read-modify-writes): 20 us together.
     uint32_t *cl = order + n_long;
-    for (uint32_t b0 = t; b0 < n_long; b0 += 4u * KD_LONG_ORDER_BLOCK) {
-        uint32_t i4[4], n4[4];
+    for (uint32_t b0 = t; b0 < n_long; b0 += KD_LONG_ORDER_PER * KD_LONG_ORDER_BLOCK) {
+        uint32_t i_[KD_LONG_ORDER_PER], n_[KD_LONG_ORDER_PER];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) { const uint32_t b = b0 + u * KD_LONG_ORDER_BLOCK; i4[u] = b < n_long ? long_list[b] : 0u; }
+        for (uint32_t u = 0; u < KD_LONG_ORDER_PER; u++) { const uint32_t b = b0 + u * KD_LONG_ORDER_BLOCK; i_[u] = b < n_long ? long_list[b] : 0u; }
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) { const uint32_t b = b0 + u * KD_LONG_ORDER_BLOCK; n4[u] = b < n_long ? rd.n_cig[i4[u]] : 0u; }
+        for (uint32_t u = 0; u < KD_LONG_ORDER_PER; u++) { const uint32_t b = b0 + u * KD_LONG_ORDER_BLOCK; n_[u] = b < n_long ? rd.n_cig[i_[u]] : 0u; }
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) {
+        for (uint32_t u = 0; u < KD_LONG_ORDER_PER; u++) {
             const uint32_t b = b0 + u * KD_LONG_ORDER_BLOCK;
-            if (b < n_long) { const uint32_t c = cls(n4[u]); cl[b] = c; atomicAdd(&s_cnt[c], 1u); }
+            if (b < n_long) { const uint32_t c = cls(n_[u]); cl[b] = c; atomicAdd(&s_cnt[c], 1u); }
         }
+        // (one atomic per class a wavefront holds -- ballot loops over the classes present -- measured: 0.017 -> 0.092 ms, dropped)
     }
     __syncthreads();
-    if (t == 0) { uint32_t run = 0; for (uint32_t k = 0; k < 128; k++) { const uint32_t v = s_cnt[k]; s_cnt[k] = run; run += v; } }
+    if (t < KD_WAVE) {      // exclusive scan of the 128 class counts: lane t takes classes 2t and 2t + 1
+        const uint32_t v0 = s_cnt[2u * t], v1 = s_cnt[2u * t + 1u];
+        const uint32_t ex = kd_wave_scan_add(v0 + v1) - (v0 + v1);
+        s_cnt[2u * t] = ex; s_cnt[2u * t + 1u] = ex + v0;
+    }
     __syncthreads();
-    // (slots of a class are handed out in any order: which of two reads of one length class starts first does not matter)
-    for (uint32_t b = t; b < n_long; b += KD_LONG_ORDER_BLOCK) order[atomicAdd(&s_cnt[cl[b]], 1u)] = b;
+    // (slots of a class are handed out in any order: which of two reads of one length class starts first does not matter; a thread
+    // reads back the classes it wrote itself)
+    for (uint32_t b0 = t; b0 < n_long; b0 += KD_LONG_ORDER_PER * KD_LONG_ORDER_BLOCK) {
+        uint32_t c_[KD_LONG_ORDER_PER];
+#pragma unroll
+        for (uint32_t u = 0; u < KD_LONG_ORDER_PER; u++) { const uint32_t b = b0 + u * KD_LONG_ORDER_BLOCK; c_[u] = b < n_long ? cl[b] : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < KD_LONG_ORDER_PER; u++) {
+            const uint32_t b = b0 + u * KD_LONG_ORDER_BLOCK;
+            if (b < n_long) order[atomicAdd(&s_cnt[c_[u]], 1u)] = b;
+        }
+    }
 }
 
 // k_prep_long: the regularity rules of kd_scan_cigar (kd_prep.h) applied op-parallel: every op checks itself against its own
@@ -112,17 +131,26 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
     const uint32_t b = order ? order[x] : x;         // (k_long_order: longest first)
     const kd_u64 i = long_list[b];
     const uint32_t c = rd.contig[i];
-    const int64_t L = T.contig_len[c];
-    const int64_t pos0 = rd.pos0[i];
-    const int64_t sl = rd.seq_len[i];
-    const uint32_t nc = rd.n_cig[i];
+    // (wave-uniform values, said so: the per-tile limits below are then scalar arithmetic)
+    const int64_t L = (int64_t)kd_readfirstlane64((kd_u64)T.contig_len[c]);
+    const int64_t pos0 = (int64_t)kd_readfirstlane64((kd_u64)(int64_t)rd.pos0[i]);
+    const int64_t sl = (int64_t)kd_readfirstlane64((kd_u64)rd.seq_len[i]);
+    const uint32_t nc = kd_readfirstlane(rd.n_cig[i]);
     const uint32_t *cg = rd.cigar + rd.cig_off[i];
     if (lane < 4) s_acc[wave][lane] = 0;
-    kd_u64 aligned = 0, walked = 0, n_ins = 0, insb = 0;
+    kd_u64 aligned = 0, walked = 0, insb = 0;
+    uint32_t n_ins = 0;
     bool bad = false, cold = false;
     uint32_t first_nfs = 0xffffffffu, last_rel = 0;
-    int64_t c_r = pos0, c_q = 0;      // coordinates in front of the tile
+    int64_t c_r = pos0, c_q = 0;      // coordinates in front of the tile (wave-uniform)
+    const int32_t sl_c = (int32_t)(sl < (int64_t)(1 << 28) ? sl : (int64_t)(1 << 28));     // (an op's length is below 2^28)
     uint32_t w_nxt = lane < nc ? cg[lane] : 15u, w_nxt2 = lane + KD_WAVE < nc ? cg[lane + KD_WAVE] : 15u;      // (op 15, length 0: moves nothing)
+    // (round 6) The rules are applied BRANCH-FREE on 32-bit tile-relative coordinates: an op's start is (c_r + rr, c_q + qq) with
+    // 0 <= rr, qq < 2^29 (64 advances below 2^23), an op's length is below 2^28, and what they are compared with -- the contig's and
+    // the read's ends seen from the tile's origin, L - c_r and sl - c_q -- is clamped to [-2, 2^30] once per tile: every comparison
+    // below has the same outcome as on the 64-bit coordinates (a limit of -2 or less is "behind everything", 2^30 or more "never
+    // reached": `rr + len > lim`, `rr > lim + 1`, `min(len, lim - rr)` all agree).  The first version walked the four op kinds as
+    // divergent branches of 64-bit arithmetic: ~200 instructions per tile of 64 ops, the kernel's whole time (0.094 ms on C5).
     for (uint32_t base = 0; base < nc; base += KD_WAVE) {
         const uint32_t k = base + lane;
         const uint32_t w = w_nxt;
@@ -131,30 +159,34 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
         const KdAdv adv = kd_op_advance(w, k);
         const uint32_t ra = adv.r, qa = adv.q;
         const uint32_t ir = kd_wave_scan_add(ra), iq = kd_wave_scan_add(qa);
-        const int64_t r = c_r + (int64_t)(ir - ra), q = c_q + (int64_t)(iq - qa);
-        const int64_t len = w >> 4;
+        const int64_t dL = L - c_r, dQ = sl - c_q;
+        const int32_t lim_r = (int32_t)(dL < -2 ? -2 : dL > (int64_t)(1 << 30) ? (int64_t)(1 << 30) : dL);
+        const int32_t lim_q = (int32_t)(dQ < -2 ? -2 : dQ > (int64_t)(1 << 30) ? (int64_t)(1 << 30) : dQ);
+        const int32_t rr = (int32_t)(ir - ra), qq = (int32_t)(iq - qa);
+        const int32_t len = (int32_t)(w >> 4);
         const uint32_t op = w & 15u;
-        if (len >= (int64_t)KD_LONG_MAX_OP && (op <= 2 || op == 4 || op == 7 || op == 8)) bad = true;
-        if (op == 0 || op == 7 || op == 8) {
-            if (r + len > L || q + len > sl) bad = true;
-            aligned += (kd_u64)len; walked += (kd_u64)len; last_rel = k;
-        } else if (op == 1) {
-            cold = true;
-            if (r > L) bad = true;
-            const int64_t q0 = q < sl ? q : sl, q1 = q + len < sl ? q + len : sl;
-            n_ins++; insb += (kd_u64)(q1 - q0); walked += (kd_u64)len; last_rel = k;
-        } else if (op == 2) {
-            if (r + len > L + 1) bad = true;
-            walked += (kd_u64)len; last_rel = k;
-        } else if (op == 4) {
-            cold = true; walked += (kd_u64)len;
-            if (k == 0) { if (r > L || len > sl) bad = true; }
-            else {
-                if (k < first_nfs) first_nfs = k;
-                if (r - 1 > L) bad = true;   // clip_starts[r - 1] must exist (kindel.py:75)
-                const int64_t n_adv = r < L ? (len < L - r ? len : L - r) : 0;
-                if (n_adv > sl - q || (len > n_adv && q + n_adv >= sl)) bad = true;
-                last_rel = k;
+        const bool is_m = op == 0 || op == 7 || op == 8, is_i = op == 1, is_d = op == 2, is_s = op == 4;
+        const bool rel = is_m || is_i || is_d || is_s;
+        bad |= rel && (uint32_t)len >= KD_LONG_MAX_OP;
+        bad |= is_m && (rr + len > lim_r || qq + len > lim_q);
+        bad |= is_i && rr > lim_r;
+        bad |= is_d && rr + len > lim_r + 1;
+        cold |= is_i || is_s;
+        aligned += is_m ? (kd_u64)(uint32_t)len : 0ULL;
+        walked += rel ? (kd_u64)(uint32_t)len : 0ULL;
+        {   // an insertion's bases: seq[q : q + len], clamped like a Python slice
+            const int32_t q0 = qq < lim_q ? qq : lim_q, q1 = qq + len < lim_q ? qq + len : lim_q;
+            n_ins += is_i ? 1u : 0u;
+            insb += is_i ? (kd_u64)(uint32_t)(q1 - q0) : 0ULL;
+        }
+        if (rel && !(is_s && k == 0)) last_rel = k;
+        if (kd_ballot(is_s) != 0ULL) {      // (wave-uniform: a read's first and last tile, if any)
+            if (is_s && k == 0) bad |= rr > lim_r || len > sl_c;
+            if (is_s && k != 0) {
+                first_nfs = k < first_nfs ? k : first_nfs;
+                bad |= rr > lim_r + 1;        // clip_starts[r - 1] must exist (kindel.py:75)
+                const int32_t n_adv = rr < lim_r ? (len < lim_r - rr ? len : lim_r - rr) : 0;
+                bad |= n_adv > lim_q - qq || (len > n_adv && qq + n_adv >= lim_q);
             }
         }
         c_r += (int64_t)kd_readlane(ir, KD_WAVE - 1); c_q += (int64_t)kd_readlane(iq, KD_WAVE - 1);
@@ -162,7 +194,7 @@ k_prep_long(KdReads rd, KdTabs T, KdRInfo *rinfo, const uint32_t *long_list, uin
     KD_WAVE_SYNC();
     if (aligned) atomicAdd(&s_acc[wave][0], aligned);
     if (walked) atomicAdd(&s_acc[wave][1], walked);
-    if (n_ins) atomicAdd(&s_acc[wave][2], n_ins);
+    if (n_ins) atomicAdd(&s_acc[wave][2], (kd_u64)n_ins);
     if (insb) atomicAdd(&s_acc[wave][3], insb);
     const bool any_bad = kd_ballot(bad) != 0ULL, any_cold = kd_ballot(cold) != 0ULL;
     first_nfs = kd_wave_min(first_nfs);
@@ -220,7 +252,8 @@ k_long_reduce(const KdLongAcc *long_acc, const uint32_t *long_list, uint32_t n_l
     KdLongAcc a;
     a.aligned = a.walked = a.insb = 0; a.n_ins = a.lead = a.row_span = a.clip_adv = a.pad = 0; a.regular = 1;
     const bool live = b < n_long;
-    if (live) a = long_acc[b];
+    uint32_t i = 0, gs = 0;      // (the read and its G-start, wanted behind the scans: requested here, next to the record)
+    if (live) { a = long_acc[b]; i = long_list[b]; gs = rinfo[i].gstart; }
     const kd_u64 n_irreg = live && !a.regular ? 1 : 0;
     const kd_u64 row_dw = (a.row_span + 7u) / 8u;     // 8 symbols per dword
     kd_u64 i_ev = a.n_ins, i_pool = a.insb, i_irreg = n_irreg, i_row = row_dw, tot_ev, tot_pool, tot_irreg, tot_row;
@@ -244,11 +277,10 @@ k_long_reduce(const KdLongAcc *long_acc, const uint32_t *long_list, uint32_t n_l
     if (t == 10) s_base[3] = tot_row ? atomicAdd(&status[KDS_B_ROW_DWORDS], tot_row) : 0;
     __syncthreads();
     if (live) {
-        const uint32_t i = long_list[b];
         if (a.n_ins) { read_ev[i] = (uint32_t)(s_base[0] + i_ev - a.n_ins); read_pool[i] = s_base[1] + i_pool - a.insb; }
         if (!a.regular) irreg_list[s_base[2] + i_irreg - 1] = i;
         KdRInfo e;
-        e.gstart = rinfo[i].gstart; e.lead = 0; e.pad = 0;
+        e.gstart = gs; e.lead = 0; e.pad = 0;
         e.span_cls = a.regular ? ((a.row_span << KD_SPAN_SHIFT) | KD_INFO_PLAIN | KD_CLS_REG) : KD_CLS_SKIP;
         row_info[b] = e;
         row_off[b] = 4ULL * (s_base[3] + i_row - row_dw);     // byte offset, as KdReads::seq_off wants it
@@ -315,11 +347,10 @@ __device__ __forceinline__ uint32_t kd_zero_nibbles(uint32_t x) {
 __global__ void __launch_bounds__(KD_LONG_BLOCK, KD_LONG_OCC)
 k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint32_t *long_list, uint32_t n_long,
               const KdLongAcc *long_acc, const kd_u64 *row_off, uint8_t *rows, kd_u64 *status, const uint32_t *order) {
-    // per wavefront: the tile's ops (reference start, query start, CIGAR word, first piece), the chunk's piece -> op table
-    // and dwords, a copy of the query bases the tile consumes
-    __shared__ uint32_t s_r_[KD_LONG_WAVES][KD_WAVE], s_q_[KD_LONG_WAVES][KD_WAVE], s_w_[KD_LONG_WAVES][KD_WAVE],
-        s_pb_[KD_LONG_WAVES][KD_WAVE], s_pt_[KD_LONG_WAVES][KD_WAVE], s_out_[KD_LONG_WAVES][KD_WAVE],
-        s_insb_[KD_LONG_WAVES][KD_WAVE];
+    // per wavefront: the tile's ops (one 16-byte record each: reference start, query start, CIGAR word, first piece | "+ins" flag), the
+    // chunk's piece -> op table and dwords, a copy of the query bases the tile consumes
+    __shared__ uint4 s_op_[KD_LONG_WAVES][KD_WAVE];
+    __shared__ uint32_t s_pt_[KD_LONG_WAVES][KD_WAVE], s_out_[KD_LONG_WAVES][KD_WAVE];
     __shared__ uint32_t s_seq_[KD_LONG_WAVES][KD_LONG_SEQ_LDS / 4 + 4];
     const uint32_t lane = threadIdx.x & (KD_WAVE - 1), wave = threadIdx.x / KD_WAVE;
     const uint32_t x = blockIdx.x * KD_LONG_WAVES + wave;
@@ -328,14 +359,14 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
     const kd_u64 i = long_list[b];
     const uint32_t sc = rinfo[i].span_cls;
     if ((sc & 3u) != KD_CLS_LONG) return;   // LONG after k_prep_long = regular long read
-    uint32_t *s_r = s_r_[wave], *s_q = s_q_[wave], *s_w = s_w_[wave], *s_pb = s_pb_[wave], *s_pt = s_pt_[wave],
-             *s_out = s_out_[wave], *s_insb = s_insb_[wave], *s_seq = s_seq_[wave];
+    uint4 *s_op = s_op_[wave];
+    uint32_t *s_pt = s_pt_[wave], *s_out = s_out_[wave], *s_seq = s_seq_[wave];
     const KdLongAcc acc = long_acc[b];
-    const uint32_t nc = rd.n_cig[i];
+    const uint32_t nc = kd_readfirstlane(rd.n_cig[i]);
     const uint32_t c = rd.contig[i];
     const int64_t L = T.contig_len[c];
     const kd_u64 cb = T.contig_base[c];
-    const int64_t sl = rd.seq_len[i];
+    const uint32_t sl = kd_readfirstlane(rd.seq_len[i]);
     const uint32_t pos0 = (uint32_t)rd.pos0[i];
     const kd_u64 g0 = cb + pos0;               // G-site of row symbol 0
     const uint8_t *seq = rd.seq4 + rd.seq_off[i];
@@ -351,12 +382,16 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
     uint32_t last_ins = 0;                     // 1 + r of the last I op seen (0: none)
     uint32_t trail_r = 0, trail_q = 0;         // the trailing clip's coordinates (its lane)
     bool bad = false, trail = false;
-    // the row dword under construction: carried from chunk to chunk, tile to tile
-    uint32_t cj = 0xffffffffu, cval = 0, cins = 0;
-#define KD_ROW_FINISH(v, ib) ((((v) + (ib) * KD_ROW_INS) & 0x0f0f0f0fu) << 4 | ((((v) + (ib) * KD_ROW_INS) >> 4) & 0x0f0f0f0fu))   /* "+ins" twins, BAM nibble order */
+    // the row dword under construction: carried from chunk to chunk, tile to tile.  A dword in the making holds a site's symbol in bits
+    // 0-2 of its nibble and "an insertion precedes this site" in bit 3 (one OR per piece); KD_ROW_FINISH turns the flag into the "+ins"
+    // twin (symbol + KD_ROW_INS = symbol + 8 - 1) and the nibbles into BAM order
+    uint32_t cj = 0xffffffffu, cval = 0;
+    static_assert(KD_ROW_INS == 7u && KD_ROW_DEL < 8u, "the +ins flag is bit 3 of a symbol's nibble");
+#define KD_ROW_FINISH(v) (((((v) - (((v) >> 3) & 0x11111111u)) & 0x0f0f0f0fu) << 4) | ((((v) - (((v) >> 3) & 0x11111111u)) >> 4) & 0x0f0f0f0fu))
     // (CIGAR words two tiles ahead, the first 256 bytes of the next tile's query bases one tile ahead: in flight while a tile is worked on)
     uint32_t w_nxt = lane < nc ? cg[lane] : 15u, w_nxt2 = lane + KD_WAVE < nc ? cg[lane + KD_WAVE] : 15u;
-    uint32_t sq_pre = 4u * lane < (uint32_t)((sl + 1) >> 1) + 8u ? reinterpret_cast<const KdU32u *>(seq + 4u * lane)->v : 0u;
+    const uint32_t seq_bytes = (sl >> 1) + (sl & 1u) + 8u;      // the read's packed bases + the 8-byte fetch window (include/kindel_hip.h: seq4_bytes + 16 are readable)
+    uint32_t sq_pre = 4u * lane < seq_bytes ? reinterpret_cast<const KdU32u *>(seq + 4u * lane)->v : 0u;
     for (uint32_t base = 0; base <= nc; base += KD_WAVE) {   // (<=: the terminator behind the last op is a piece too)
         const uint32_t k = base + lane;
         const uint32_t w = w_nxt;
@@ -369,15 +404,15 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
         const uint32_t r_op = c_r + ir - ra, q_op = c_q + iq - qa;
         const uint32_t tot_q = kd_readlane(iq, KD_WAVE - 1);
         // pieces: an M / D run touches the dwords of its first to its last site; an I op and the terminator are one each
-        const bool is_run = ra != 0, is_ins = op == 1 && k < nc;
+        const bool is_run = ra != 0, is_ins = (op == 1) & (k < nc);
         bool dup = false, insf = false;        // insf: an insertion sits in front of this run's first site (or of the terminator)
         if (has_ins) {   // (wave-uniform) a second I op on the same site: the nearest I op before it has the same r
             const uint32_t m = kd_wave_scan_max(is_ins ? r_op + 1u : 0u);
             uint32_t prev = kd_shfl_up(m, 1u);
             if (lane == 0) prev = 0;
             prev = prev > last_ins ? prev : last_ins;
-            dup = is_ins && prev == r_op + 1u;
-            insf = (is_run || k == nc) && prev == r_op + 1u;
+            dup = is_ins & (prev == r_op + 1u);
+            insf = (is_run | (k == nc)) & (prev == r_op + 1u);
             const uint32_t tile_last = kd_readlane(m, KD_WAVE - 1);
             last_ins = tile_last > last_ins ? tile_last : last_ins;
         }
@@ -385,11 +420,11 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
         const uint32_t ipb = kd_wave_scan_add(cnt);
         const uint32_t n_pieces = kd_readlane(ipb, KD_WAVE - 1);
         KD_WAVE_SYNC();                        // (the last tile's pieces are done with the arrays)
-        s_r[lane] = r_op; s_q[lane] = q_op; s_w[lane] = w; s_pb[lane] = (ipb - cnt) | (insf ? 0x80000000u : 0u);
+        s_op[lane] = make_uint4(r_op, q_op, w, (ipb - cnt) | (insf ? 0x80000000u : 0u));
         // the query bases of the tile (+ the 8-base fetch window): copied when they fit
         const uint32_t qb = c_q & ~7u;                                      // first copied base: a dword boundary of the read's bytes
         uint32_t q_end = c_q + tot_q;
-        q_end = (int64_t)q_end < sl ? q_end : (uint32_t)sl;
+        q_end = q_end < sl ? q_end : sl;
         const uint32_t need = q_end > qb ? ((q_end - qb + 1u) >> 1) + 8u : 0u;   // bytes
         const bool staged = need <= KD_LONG_SEQ_LDS;
         if (staged) {
@@ -399,14 +434,14 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
         }
         {   // the next tile's copy starts at the dword of its first base
             const uint32_t ob = ((c_q + tot_q) & ~7u) >> 1;
-            sq_pre = ob + 4u * lane < (uint32_t)((sl + 1) >> 1) + 8u ? reinterpret_cast<const KdU32u *>(seq + ob + 4u * lane)->v : 0u;
+            sq_pre = ob + 4u * lane < seq_bytes ? reinterpret_cast<const KdU32u *>(seq + ob + 4u * lane)->v : 0u;
         }
         KD_WAVE_SYNC();                        // the tile's arrays are written
         if (has_ins) {   // (wave-uniform) event / pool slots of the tile's I ops
             uint32_t ni = 0, nb = 0;
             if (is_ins) {
-                const int64_t q0 = (int64_t)q_op < sl ? (int64_t)q_op : sl, q1 = (int64_t)q_op + len < sl ? (int64_t)q_op + len : sl;
-                ni = 1; nb = (uint32_t)(q1 - q0);
+                const uint32_t q0 = q_op < sl ? q_op : sl, q1 = q_op + len < sl ? q_op + len : sl;
+                ni = 1; nb = q1 - q0;
             }
             const uint32_t i_ni = kd_wave_scan_add(ni), i_nb = kd_wave_scan_add(nb);
             if (is_ins) {
@@ -416,7 +451,7 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
                     atomicAdd(&status[KDS_INTERNAL], 1ULL);
                 } else if (kd_commit(T, g)) {
                     ins.ev_site[e] = (uint32_t)g; ins.ev_len[e] = nb; ins.ev_off[e] = po;
-                    const uint32_t q0 = (int64_t)q_op < sl ? q_op : (uint32_t)sl;
+                    const uint32_t q0 = q_op < sl ? q_op : sl;
                     for (uint32_t x0 = 0; x0 < nb; x0 += 8u) {       // 8 bases per fetch, one base code per pool byte
                         const uint32_t qq = q0 + x0;
                         uint32_t z = staged ? kd_fetch8_lin_lds(s_seq, (qq >> 1) - (qb >> 1), qq & 1u) : kd_fetch8_lin(seq, qq);
@@ -429,74 +464,66 @@ k_long_expand(KdReads rd, KdTabs T, KdIns ins, const KdRInfo *rinfo, const uint3
             }
             e_base += kd_readlane(i_ni, KD_WAVE - 1); p_base += kd_readlane(i_nb, KD_WAVE - 1);
         }
-        if (op == 4 && k < nc) {
-            if (k == 0) {      // leading clip, kindel.py:64-73: clip_ends[r]
-                if (kd_commit(T, g0)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g0], 1u);
-            } else {           // non-first clip, kindel.py:74-81: clip_starts[r - 1] (index -1 wraps to the last slot)
-                const int64_t x = (int64_t)pos0 + r_op - 1;
-                const kd_u64 g = cb + (kd_u64)(x < 0 ? x + L + 1 : x);
-                if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
-                trail = true; trail_r = r_op; trail_q = q_op;
+        if (kd_ballot((op == 4) & (k < nc)) != 0ULL) {      // (wave-uniform: the read's first and last tile, if any)
+            if (op == 4 && k < nc) {
+                if (k == 0) {      // leading clip, kindel.py:64-73: clip_ends[r]
+                    if (kd_commit(T, g0)) atomicAdd(&tab[(kd_u64)KDC_CLIP_ENDS * S + g0], 1u);
+                } else {           // non-first clip, kindel.py:74-81: clip_starts[r - 1] (index -1 wraps to the last slot)
+                    const int64_t x = (int64_t)pos0 + r_op - 1;
+                    const kd_u64 g = cb + (kd_u64)(x < 0 ? x + L + 1 : x);
+                    if (kd_commit(T, g)) atomicAdd(&tab[(kd_u64)KDC_CLIP_STARTS * S + g], 1u);
+                    trail = true; trail_r = r_op; trail_q = q_op;
+                }
             }
         }
-        // ---- the tile's pieces, 64 at a time ----
+        // ---- the tile's pieces, 64 at a time: the same instructions for every lane whatever its piece is ----
         uint32_t op_in = 0;                    // 1 + the op the chunk's first piece continues (0: it starts an op)
-        const uint32_t n_chunks_pieces = n_pieces;
-        for (uint32_t p0 = 0; p0 < n_chunks_pieces; p0 += KD_WAVE) {
-            s_pt[lane] = 0; s_out[lane] = 0; s_insb[lane] = 0;
+        for (uint32_t p0 = 0; p0 < n_pieces; p0 += KD_WAVE) {
+            s_pt[lane] = 0; s_out[lane] = 0;
             KD_WAVE_SYNC();
-            { const uint32_t pb = ipb - cnt; if (cnt && pb >= p0 && pb < p0 + KD_WAVE) s_pt[pb - p0] = lane + 1u; }
+            { const uint32_t pb = ipb - cnt; if ((cnt != 0) & (pb >= p0) & (pb < p0 + KD_WAVE)) s_pt[pb - p0] = lane + 1u; }
             KD_WAVE_SYNC();
             uint32_t oi = kd_wave_scan_max(s_pt[lane]);
             oi = oi > op_in ? oi : op_in;      // (op indices grow with the piece number)
             op_in = kd_readlane(oi, KD_WAVE - 1);
             const uint32_t p = p0 + lane;
             const bool live = p < n_pieces;
-            const uint32_t ko = oi - 1u;       // (a live piece always has its op: piece 0 starts one)
-            uint32_t j = 0, val = 0, ib = 0;
-            if (live) {
-                const uint32_t r_k = s_r[ko], w_k = s_w[ko], pbf = s_pb[ko], idx = p - (pbf & 0x7fffffffu);
-                if (idx == 0 && (pbf >> 31)) ib = 1u << (4u * (r_k & 7u));   // "+ins" flag of the run's first site
-                const uint32_t ln = w_k >> 4, o = w_k & 15u;
-                j = (r_k >> 3) + idx;
-                if (o == 0 || o == 7 || o == 8 || o == 2) {
-                    const uint32_t a = r_k > 8u * j ? r_k : 8u * j, e8 = r_k + ln < 8u * j + 8u ? r_k + ln : 8u * j + 8u;
-                    const uint32_t n = e8 - a, ps = a - 8u * j;
-                    const uint32_t msk = n == 8u ? 0xffffffffu : ((1u << (4u * n)) - 1u);
-                    uint32_t sym = 0x11111111u * KD_ROW_DEL;
-                    if (o != 2) {
-                        const uint32_t qq = s_q[ko] + (a - r_k);
-                        sym = kd_rowcodes8(staged ? kd_fetch8_lin_lds(s_seq, (qq >> 1) - (qb >> 1), qq & 1u) : kd_fetch8_lin(seq, qq));
-                        if (kd_zero_nibbles(sym) & msk) bad = true;     // a base outside A,C,G,T,N (KeyError in the reference)
-                    }
-                    val = (sym & msk) << (4u * ps);
-                }                                           // (else: the terminator: the slot behind the last site exists)
-            }
+            const uint4 rec = s_op[live ? oi - 1u : 0u];       // (a live piece always has its op: piece 0 starts one)
+            const uint32_t r_k = rec.x, q_k = rec.y, w_k = rec.z, pbf = rec.w;
+            const uint32_t idx = p - (pbf & 0x7fffffffu);
+            const uint32_t ln = w_k >> 4, o = w_k & 15u;
+            const uint32_t j = live ? (r_k >> 3) + idx : 0u;
+            const bool run = live & (((0x185u >> o) & 1u) != 0);              // M, D, =, X (else: the terminator -- the slot behind the last site exists)
+            // the run's sites inside row dword j: [a, e8), n of them from nibble ps on
+            const uint32_t a = r_k > 8u * j ? r_k : 8u * j, e8 = r_k + ln < 8u * j + 8u ? r_k + ln : 8u * j + 8u;
+            const uint32_t n = run ? e8 - a : 8u, ps = (a - 8u * j) & 7u;
+            const uint32_t msk = 0xffffffffu >> (32u - 4u * n);               // (1 <= n <= 8)
+            const uint32_t qq = q_k + (a - r_k);
+            uint32_t sym;
+            if (staged) sym = kd_rowcodes8(kd_fetch8_lin_lds(s_seq, run && o != 2 ? (qq >> 1) - (qb >> 1) : 0u, qq & 1u));      // (wave-uniform)
+            else sym = run && o != 2 ? kd_rowcodes8(kd_fetch8_lin(seq, qq)) : 0u;
+            if (run & (o != 2) & ((kd_zero_nibbles(sym) & msk) != 0)) bad = true;     // a base outside A,C,G,T,N (KeyError in the reference)
+            sym = o == 2 ? 0x11111111u * KD_ROW_DEL : sym;
+            uint32_t val = run ? (sym & msk) << (4u * ps) : 0u;
+            if (live & (idx == 0) & ((pbf >> 31) != 0)) val |= 8u << (4u * (r_k & 7u));   // "+ins" flag of the run's first site
             const uint32_t jf = kd_readfirstlane(j);
             if (cj != 0xffffffffu && cj != jf) {            // the carried dword is complete
-                if (lane == 0) {
-                    row[cj] = KD_ROW_FINISH(cval, cins);
-                }
-                cval = 0; cins = 0;
-            } else if (cj == 0xffffffffu) { cval = 0; cins = 0; }
-            if (live) {
-                if (val) atomicOr(&s_out[j - jf], val);
-                if (ib) atomicOr(&s_insb[j - jf], ib);
-            }
+                if (lane == 0) row[cj] = KD_ROW_FINISH(cval);
+                cval = 0;
+            } else if (cj == 0xffffffffu) cval = 0;
+            if (val) atomicOr(&s_out[j - jf], val);
             KD_WAVE_SYNC();
             const uint32_t last_lane = n_pieces - p0 < KD_WAVE ? n_pieces - p0 - 1u : KD_WAVE - 1u;
             const uint32_t jl = kd_readlane(j, last_lane);      // (last_lane: wave-uniform)
-            uint32_t v = s_out[lane], vb = s_insb[lane];
-            if (lane == 0) { v |= cval; vb |= cins; }
-            if (jf + lane < jl) {
-                row[jf + lane] = KD_ROW_FINISH(v, vb);
-            }
+            uint32_t v = s_out[lane];
+            if (lane == 0) v |= cval;
+            if (jf + lane < jl) row[jf + lane] = KD_ROW_FINISH(v);
             cj = jl;
-            cval = kd_readlane(v, jl - jf); cins = kd_readlane(vb, jl - jf);
+            cval = kd_readlane(v, jl - jf);
         }
         c_r += kd_readlane(ir, KD_WAVE - 1); c_q += tot_q;
     }
-    if (cj != 0xffffffffu && lane == 0) row[cj] = KD_ROW_FINISH(cval, cins);
+    if (cj != 0xffffffffu && lane == 0) row[cj] = KD_ROW_FINISH(cval);
 #undef KD_ROW_FINISH
     // ---- soft clips: weights of the clipped bases (clip_end_weights in front of the read, clip_start_weights behind it) ----
     if ((cg[0] & 15u) == 4u && acc.lead) {

@@ -198,6 +198,8 @@ k_sort_scatter(const KdRInfo *rinfo, kd_u64 n_reads, uint32_t W, uint32_t *bin_f
         i = j;
     }
 }
+// (Round 6 measured the three passes as ONE workgroup with its counters in LDS for the 17 699 rows of C5 -- one launch instead of a
+// memset and three: 0.025 ms against 3 x 0.0065, a single workgroup's chain of round trips is longer than two more launches; dropped.)
 // candidate range of window w0 + w in `order`: whole bins covering [wlo - maxspan, whi + maxlead)
 __global__ void __launch_bounds__(KD_BLOCK)
 k_plan_ranges_sorted(const kd_u64 *bin_off, uint32_t n_bins, uint32_t w0, uint32_t n_win, uint32_t W, uint32_t slice,

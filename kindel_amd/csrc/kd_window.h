@@ -386,6 +386,8 @@ __device__ __forceinline__ void kd_walk_row(const KdReads &rd, kd_u64 i, const K
     const int32_t ca = xa >> 5, n = ((xb - 1) >> 5) - ca + 1;
     int32_t cpos = (int32_t)(rot % (uint32_t)n);
     const uint32_t o = (rot / (uint32_t)n) & 3u;
+    // (one chunk ahead.  Round 6 measured THREE, as kd_walk_plain has them -- a window's part of a row is 14 chunks, i.e. 14 dependent
+    // round trips per window with three wavefronts' worth of rows to hide them: k_window_rows 0.141 -> 0.147 ms on C5, dropped.)
     KdChunk cur = src[ca + cpos];
     for (int32_t t = 0; t < n; t++) {
         const int32_t c = ca + cpos;
