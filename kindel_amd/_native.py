@@ -539,8 +539,13 @@ class Engine:
     def step_device(self, ptrs, n_reads, seq4_bytes, cigar_words, out, min_depth=1):
         """One whole step over a device-resident batch (kd_step: reset + record loop + insertion reduction + consensus + all
         contigs' consensus bytes into `out`, ideally pinned).  -> contig_off uint64[n_contigs + 1]"""
-        b = self._struct(ptrs, n_reads)
-        b.seq4_bytes, b.cigar_words = seq4_bytes, cigar_words
+        # (a step loop calls this with the same batch again and again: the kd_batch struct is kept while the addresses and sizes are the same)
+        key = (tuple(ptrs[name] for name, _ in _BATCH_FIELDS), n_reads, seq4_bytes, cigar_words)
+        if getattr(self, "_step_key", None) != key:
+            b = self._struct(ptrs, n_reads)
+            b.seq4_bytes, b.cigar_words = seq4_bytes, cigar_words
+            self._step_key, self._step_struct = key, b
+        b = self._step_struct
         ln = C.c_uint64(0)
         off = np.zeros(len(self.contig_lens) + 1, np.uint64)
         self._n_patches = 0

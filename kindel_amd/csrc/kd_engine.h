@@ -230,6 +230,7 @@ struct KdEngine {
             return hipfail("k_reset");
         batch_status_clean = true;
         reads_pushed = 0; finalized = false; have_cns = false; have_inskeys = false;
+        errors_pending = false;
         return KD_OK;
     }
 
@@ -651,11 +652,15 @@ struct KdEngine {
                 return hipfail("k_pileup_wave_irreg");
             // the batch's last kernel: the clip counters / insertion events of the clipped and inserted regular reads, and -- its
             // last workgroup -- the error classification (kd_errors.h: leaves at once when nothing was flagged)
-            if (n_cold && !cold_fused ? rt.launch("k_cold_lane", k_cold_lane, prep_regions + 1u, KD_BLOCK, 0, R, T, I, (const KdColdRec *)cold,
-                                   (const uint32_t *)b_coldcnt.p, (const kd_u64 *)b_coldev.p, (const kd_u64 *)b_coldpool.p, cold_region, d_status,
-                                   (const KdRInfo *)rinfo, n_contigs)
-                       : rt.launch("k_errors", k_errors, 1u, KD_BLOCK, 0, R, T, (const KdRInfo *)rinfo, n_contigs, d_status, 1u))
-                return hipfail("k_cold_lane");
+            if (n_cold && !cold_fused) {
+                if (rt.launch("k_cold_lane", k_cold_lane, prep_regions + 1u, KD_BLOCK, 0, R, T, I, (const KdColdRec *)cold,
+                              (const uint32_t *)b_coldcnt.p, (const kd_u64 *)b_coldev.p, (const kd_u64 *)b_coldpool.p, cold_region, d_status,
+                              (const KdRInfo *)rinfo, n_contigs))
+                    return hipfail("k_cold_lane");
+            } else if (defer_errors) {      // (kd_step: finish() launches it if the status words ask for it)
+                errors_pending = true; err_R = R; err_windowed = 1u;
+            } else if (rt.launch("k_errors", k_errors, 1u, KD_BLOCK, 0, R, T, (const KdRInfo *)rinfo, n_contigs, d_status, 1u))
+                return hipfail("k_errors");
         } else {
             // (k_pileup_wave looks a read's insertion slots up by read index: spell the regular reads' out)
             if (n_cold && rt.launch("k_cold_slots", k_cold_slots, prep_regions, KD_BLOCK, 0, (const KdColdRec *)cold, (const uint32_t *)b_coldcnt.p,
@@ -828,6 +833,13 @@ struct KdEngine {
     // Two halves, so that kd_step can queue the consensus behind the reduction and read everything back in ONE round trip:
     // finalize_launch() queues the kernels, finalize_check() looks at the status words the caller has fetched since.
     bool fin_launched = false;      // the hash reduction ran (there were insertion events)
+    // kd_step: the batch's error classification (k_errors: one workgroup that leaves after two loads unless a kernel flagged something)
+    // is not queued behind the record loop but launched by finish() WHEN the step's status words say a read was flagged -- the words
+    // it looks at are the ones finish() reads back anyway, and the batch's arrays are the caller's until kd_step returns.  One dispatch
+    // and one dependent gap less on every step (round 6: 3.5 + ~5 us; a 1/8 shard of C3 is 0.32 ms); a flagged step pays one more
+    // round trip.  Only kd_step: between kd_push_batch calls the classification must see a batch before the next one overwrites rinfo.
+    bool defer_errors = false, errors_pending = false;
+    KdReads err_R; uint32_t err_windowed = 0;
     bool cns_meta_fresh = false;    // k_ins_flag has just left the consensus run's per-contig words initialised
     KdInsTab fin_H;
     kd_u64 *meta_coff() const { return d_status + KDS_COUNT; }
@@ -1244,6 +1256,14 @@ struct KdEngine {
             return hipfail("kd_finish: d2h");
         memcpy(h_status.data(), st, KDS_COUNT * 8);
         const void *meta = st + KDS_COUNT * 8;
+        if (errors_pending) {       // kd_step left the batch's error classification to this moment (defer_errors)
+            errors_pending = false;
+            if ((err_windowed && h_status[KDS_BAD_BASE] != 0) || h_status[KDS_ERR_READ] != ~0ULL) {
+                if (rt.launch("k_errors", k_errors, 1u, KD_BLOCK, 0, err_R, tabs(), (const KdRInfo *)b_rinfo.p, n_contigs, d_status, err_windowed))
+                    return hipfail("k_errors");
+                if ((rc = fetch_status())) return rc;
+            }
+        }
         bool redone = false;
         if ((rc = finalize_check(nullptr, &redone))) return rc;
         if (redone) {     // a hash collision was repaired (never seen outside the tests): the consensus once more, read back on its own
@@ -1276,7 +1296,11 @@ struct KdEngine {
     // hardware: removed in round 6)
     int step(const kd_batch &B, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out, uint64_t *contig_off) {
         int rc;
-        if ((rc = reset()) || (rc = push_device(B))) return rc;
+        defer_errors = true; errors_pending = false;
+        rc = reset();
+        if (!rc) rc = push_device(B);
+        defer_errors = false;
+        if (rc) { errors_pending = false; return rc; }
         return finish(min_depth, seq_out, cap, len_out, contig_off);
     }
 };

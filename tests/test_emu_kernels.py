@@ -388,6 +388,46 @@ def test_step_equals_the_classic_sequence(emu_lib):
         eng.close()
 
 
+def _step_on(eng, batch, out):
+    arrs = {name: np.ascontiguousarray(batch[name], dt) for name, dt in N._BATCH_FIELDS}
+    ptrs = {k: v.ctypes.data for k, v in arrs.items()}       # (on the emulator "device" memory is host memory)
+    return eng.step_device(ptrs, len(arrs["contig"]), arrs["seq4"].size, arrs["cigar"].size, out), arrs
+
+
+def test_step_raises_the_reference_exception_and_the_next_step_is_clean(emu_lib):
+    """kd_step leaves the batch's error classification (k_errors) to the moment its status words come back: every case the
+    reference raises for must raise the same through kd_step as through the call sequence -- and a good step on the SAME context
+    right behind a flagged one must not see anything of it."""
+    good = synth.to_numpy(synth.short_reads([300], 8, seed=5))
+    want = P.Run(emu_lib, good)
+    n_raising = 0
+    for key in QUIRKS:
+        exc = P.quirk_expect(QUIRKS[key])
+        if not exc or key.startswith("__"):
+            continue
+        batch = P.sam_to_batch(QUIRKS[key]["sam"])
+        if list(batch["contig_lens"]) != [300]:
+            lens = list(batch["contig_lens"])
+            good_k = synth.to_numpy(synth.short_reads(lens, 4, seed=5)) if min(lens) >= 160 else None
+        else:
+            good_k = good
+        eng = N.Engine(batch["contig_lens"], lib=emu_lib)
+        try:
+            out = np.zeros(int(sum(batch["contig_lens"])) * 2 + 4096, np.uint8)
+            with pytest.raises(exc):
+                _step_on(eng, batch, out)
+            n_raising += 1
+            if good_k is not None:
+                run = want if good_k is good else P.Run(emu_lib, good_k)
+                off, _keep = _step_on(eng, good_k, out)
+                for cid in run.order:
+                    assert out[int(off[cid]): int(off[cid + 1])].tobytes() == run.cns[cid][0], key
+                    assert np.array_equal(eng.tables(cid), run.tables[cid]), key
+        finally:
+            eng.close()
+    assert n_raising >= 5
+
+
 def _finish_vs_classic(lib, batch, window=0, slice_reads=0, out_cap=None, n_pushes=1):
     """kd_finish (one round trip) against kd_finalize + kd_consensus_run + kd_consensus_fetch per contig, on the same pushes."""
     run = P.Run(lib, batch, window=window, slice_reads=slice_reads, n_pushes=n_pushes)

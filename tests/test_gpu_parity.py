@@ -552,6 +552,51 @@ def _step_sequence(lib):
         eng.close()
 
 
+def test_step_raises_the_reference_exception_and_the_next_step_is_clean(hip_lib):
+    """kd_step launches the batch's error classification (k_errors) only when its status words come back flagged (round 6): a base
+    outside A,C,G,T,N planted in place raises KeyError through kd_step, a read moved behind its contig's end IndexError, and with the
+    inputs repaired the SAME context steps clean, tables and consensus against the oracle."""
+    import torch
+    tb = synth.short_reads([60_000, 20_000], 30, seed=37, device="cuda:0")
+    eng = N.Engine(tb["contig_lens"], lib=hip_lib)
+    out = torch.empty(200_000, dtype=torch.uint8, pin_memory=True).numpy()
+
+    def step():
+        torch.cuda.synchronize()
+        return eng.step_device(synth.device_ptrs(tb), tb["contig"].numel(), tb["seq4_bytes"], tb["cigar_words"], out)
+
+    def clean():
+        off = step()
+        host = synth.to_numpy(tb)
+        for cid in ko.contig_order(host):
+            oa = ko.parse_records(host, cid)
+            assert out[int(off[cid]): int(off[cid + 1])].tobytes().decode() == oa.consensus_sequence()[0], cid
+            t = eng.tables(cid)
+            assert np.array_equal(t[0:5, :oa.L].T, oa.weights) and np.array_equal(t[18], oa.ins_totals)
+
+    try:
+        clean()
+        ncig = tb["n_cig"].cpu().numpy()
+        i = int(np.flatnonzero(ncig == 1)[len(ncig) // 3])          # a plain read somewhere in the middle
+        so = int(tb["seq_off"][i])
+        keep = int(tb["seq4"][so + 3])
+        tb["seq4"][so + 3] = 0x35                                   # 'M' / 'R': neither in the reference's weight dict
+        with pytest.raises(KeyError):
+            step()
+        with pytest.raises(KeyError):                               # ... and again: nothing of the flagged step sticks
+            step()
+        tb["seq4"][so + 3] = keep
+        clean()
+        pos_keep = int(tb["pos0"][i])
+        tb["pos0"][i] = int(tb["contig_lens"][int(tb["contig"][i])]) - 10      # runs off the reference: list index out of range
+        with pytest.raises(IndexError):
+            step()
+        tb["pos0"][i] = pos_keep
+        clean()
+    finally:
+        eng.close()
+
+
 def test_step_repeats_and_inputs_changed_in_place(hip_lib):
     """kd_step: see _step_sequence.  (Rounds 3 - 5 also had an opt-in hipGraph replay of a repeated step and its test here; removed in
     round 6 with the replay: DESIGN section 3.)"""
