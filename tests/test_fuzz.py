@@ -5,6 +5,7 @@ import pytest
 
 from kindel_amd import _native as N
 from tests import fuzz
+from tests import parity as P
 
 MODES = [N.KD_MODE_GLOBAL, N.KD_MODE_AUTO, N.KD_MODE_COOP, N.KD_MODE_STRIP]   # AUTO = k_window (lane per read), COOP = k_window_coop
 
@@ -60,6 +61,81 @@ def test_fuzz_long_cigars_of_several_segments_emulated(emu_lib):
     trailing clip anywhere in them.  (Written for round 5's expansion by 512-word segments, which was measured slower and dropped --
     profiles/r05_long_expand_segments_nogo.json; kept as long-CIGAR coverage: kd_long.h has no segments.)"""
     assert _long_campaign(emu_lib, range(310, 316), n_reads=30, long_ops=(480, 2600), contig_lens=(30000, 14000)) >= 8
+
+
+def _one_wild_long_read(rng, contig_lens, n_valid, ops_range, big=None):
+    """A valid long-read batch with ONE read rebuilt without any validity constraint (ops_range CIGAR ops of any kind and length 0 - 11,
+    POS anywhere from in front of the contig to behind its end, a query a few bases short or long) -- so that the exception the
+    reference raises, if any, is THAT read's and can be compared by type.  big = (op, length): one op of the wild read gets that length
+    (k_prep_long routes a read with an op of 2^23 bases or more to the exact walk)."""
+    batch = fuzz.random_batch(rng, n_valid, contig_lens=contig_lens, wild=0.0, sort=False, long_ops=ops_range)
+    i = int(rng.integers(0, n_valid))
+    n_ops = int(rng.integers(*ops_range))
+    ops = [(int(rng.integers(0, 12)), int(rng.integers(0, 9))) for _ in range(n_ops)]
+    if big is not None:
+        ops[int(rng.integers(0, n_ops))] = (big[1], big[0])
+    qlen = sum(ln for ln, op in ops if op in (0, 1, 4, 7, 8) and ln < (1 << 20))
+    sl = max(0, qlen + int(rng.integers(-3, 4)))
+    L = int(batch["contig_lens"][int(batch["contig"][i])])
+    nib = rng.choice([1, 2, 4, 8, 15, 3], sl, p=[0.2495, 0.2495, 0.2495, 0.2495, 0.0015, 0.0005]).astype(np.uint8)
+    nn = np.concatenate([nib, np.zeros(len(nib) & 1, np.uint8)])
+    packed = ((nn[0::2] << 4) | nn[1::2]).astype(np.uint8)
+    batch["seq_off"][i] = len(batch["seq4"])
+    batch["seq4"] = np.concatenate([batch["seq4"], packed, np.zeros(32, np.uint8)])
+    batch["cig_off"][i] = len(batch["cigar"])
+    batch["cigar"] = np.concatenate([batch["cigar"], np.asarray([(ln << 4) | op for ln, op in ops] + [0, 0], np.uint32)])
+    batch["n_cig"][i] = n_ops
+    batch["seq_len"][i] = sl
+    batch["pos0"][i] = int(rng.integers(-3, L + 4)) if rng.random() < 0.5 else int(rng.integers(max(0, L - 40 * n_ops // 9), L + 4))
+    batch["flag"][i] = 0
+    return batch
+
+
+def _wild_long_campaign(lib, seeds, ops_range, modes, big=None, contig_lens=(6000, 2500)):
+    """-> {"ok": n, exception name: n}.  The engine must end exactly as the oracle does: the same tables, or the same exception type."""
+    out = {}
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        batch = _one_wild_long_read(rng, contig_lens, 24, ops_range, big=big)
+        kind, val = fuzz.oracle_outcome(batch)
+        for mode in modes:
+            if kind == "raise":
+                with pytest.raises(val):
+                    P.Run(lib, batch, mode=mode, window=[64, 256][seed % 2])
+            else:
+                P.assert_matches_oracle(P.Run(lib, batch, mode=mode, window=[64, 256][seed % 2]))
+        key = val.__name__ if kind == "raise" else "ok"
+        out[key] = out.get(key, 0) + 1
+    return out
+
+
+def test_fuzz_one_wild_read_of_several_tiles_emulated(emu_lib):
+    """k_prep_long decides op-parallel, tile of 64 ops by tile, whether a long read is regular -- since round 6 branch-free on 32-bit
+    tile-relative coordinates against limits clamped per tile (kd_long.h).  The valid long-read campaigns never show it an invalid read
+    of more than one tile: here one read per batch is anything at all (65 - 400 ops: runs off either end of its contig in any tile,
+    clips in the middle, a query too short or too long, bases outside the dict) and the engine must raise the reference's exception
+    for it, by type, or produce the reference's tables."""
+    out = _wild_long_campaign(emu_lib, range(7100, 7160), (65, 400), [N.KD_MODE_AUTO, N.KD_MODE_GLOBAL])
+    assert out.get("ok", 0) >= 3 and out.get("IndexError", 0) >= 5 and out.get("KeyError", 0) >= 2, out
+    out = _wild_long_campaign(emu_lib, range(7200, 7230), (17, 64), [N.KD_MODE_AUTO])
+    assert sum(out.values()) == 30, out
+
+
+@pytest.mark.parametrize("op,length", [(0, 1 << 23), (2, 1 << 23), (1, 1 << 23), (4, (1 << 23) + 5), (3, 1 << 24), (0, (1 << 28) - 1), (2, (1 << 23) - 1)])
+def test_fuzz_one_wild_read_with_a_huge_op_emulated(emu_lib, op, length):
+    """An op of 2^23 bases or more (M, I, D, S, N; and one just below the line) inside a long CIGAR: the read goes to the exact walk,
+    the scans' 32-bit tile sums stay in range, and the outcome is the reference's."""
+    out = _wild_long_campaign(emu_lib, range(7300 + op * 10, 7304 + op * 10), (65, 200), [N.KD_MODE_AUTO], big=(op, length))
+    assert sum(out.values()) == 4, out
+
+
+@pytest.mark.gpu
+def test_fuzz_one_wild_read_of_several_tiles_gpu(hip_lib):
+    out = _wild_long_campaign(hip_lib, range(7100, 7400), (65, 400), [N.KD_MODE_AUTO])
+    assert out.get("ok", 0) >= 10 and out.get("IndexError", 0) >= 25 and out.get("KeyError", 0) >= 10, out
+    for k, (op, length) in enumerate([(0, 1 << 23), (2, 1 << 23), (1, 1 << 23), (4, (1 << 23) + 5), (3, 1 << 24), (2, (1 << 23) - 1)]):
+        out = _wild_long_campaign(hip_lib, range(7500 + 10 * k, 7506 + 10 * k), (65, 200), [N.KD_MODE_AUTO], big=(op, length))
+        assert sum(out.values()) == 6, out
 
 
 def _mixed_campaign(lib, seeds, sizes):
