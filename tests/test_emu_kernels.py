@@ -379,11 +379,25 @@ def test_step_equals_the_classic_sequence(emu_lib):
         arrs = {name: np.ascontiguousarray(batch[name], dt) for name, dt in N._BATCH_FIELDS}
         ptrs = {k: v.ctypes.data for k, v in arrs.items()}       # (on the emulator "device" memory is host memory)
         out = np.zeros(8192, np.uint8)
-        for _ in range(2):
-            off = eng.step_device(ptrs, len(arrs["contig"]), arrs["seq4"].size, arrs["cigar"].size, out)
+
+        def same(off):
             for cid in run.order:
                 assert out[int(off[cid]): int(off[cid + 1])].tobytes() == run.cns[cid][0]
                 assert np.array_equal(eng.tables(cid), run.tables[cid])
+
+        for _ in range(4):
+            same(eng.step_device(ptrs, len(arrs["contig"]), arrs["seq4"].size, arrs["cigar"].size, out))
+        # the call sequence in between, a smaller batch through kd_step, the first one again
+        eng.reset()
+        eng.push(batch)
+        same(eng.finish(out))
+        half = P.subset(batch, 0, len(batch["contig"]) // 2)
+        run_half = P.Run(emu_lib, half)
+        off, _keep = _step_on(eng, half, out)
+        for cid in run_half.order:
+            assert out[int(off[cid]): int(off[cid + 1])].tobytes() == run_half.cns[cid][0]
+            assert np.array_equal(eng.tables(cid), run_half.tables[cid])
+        same(eng.step_device(ptrs, len(arrs["contig"]), arrs["seq4"].size, arrs["cigar"].size, out))
     finally:
         eng.close()
 
