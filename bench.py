@@ -64,6 +64,9 @@ def main():
                          "hands over for an unsorted FILE -- bases and CIGAR words lie in record order too; index: only the per-read arrays "
                          "are permuted, every read's bases / CIGAR stay where the sorted batch had them (rounds 1 - 2; a layout no file produces)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline-leg", action="store_true",
+                    help="an EXTRA leg behind the measurement (never the headline, off by default so that a profiler's per-kernel averages of the default "
+                         "command stay those of the timed steps): the same steps taken in turn by two contexts on two host threads")
     ap.add_argument("--cpu-sample", type=float, default=0.0, help="fraction of reads for the CPU baseline (0 = auto)")
     ap.add_argument("--rccl-at-1", action="store_true",
                     help="N = 1 only: initialise torch.distributed with backend nccl (= RCCL) at world size 1, register the exchange row and run the step's "
@@ -243,6 +246,48 @@ def main():
         dt = float(tmax[0].item())
         info = eng.batch_info()
         stats = eng.stats()
+        # EXTRA LEG, never the headline: the same K steps taken in turn by TWO contexts on two host threads (each its own stream, tables
+        # and pinned output) -- independent steps pipelined: one step's consensus tail (the FASTA leaving over the host link) under the
+        # next one's k_prep.  A throughput figure for a stream of batches; `value` / `ms_per_step` above stay ONE context, one step after
+        # the other.  (scripts/exp/pipeline_ab.py has depth 3 too.)
+        pipelined = None
+        if world == 1 and args.pipeline_leg and not args.shuffle:
+            try:
+                import threading
+                eng2 = N.Engine(np.asarray(contig_lens, np.uint32), device=dev_index, mode=mode)
+                if args.window or args.slice:
+                    eng2.set_tuning(args.window, args.slice)
+                pinned2 = torch.empty_like(pinned, pin_memory=True).numpy()
+                pair = ((eng, pinned_np), (eng2, pinned2))
+                try:
+                    for e_, o_ in pair:
+                        for _ in range(2):
+                            off2 = e_.step_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"], o_)
+                    go = threading.Barrier(3)
+
+                    def worker(j, n_steps):
+                        go.wait()
+                        for _ in range(n_steps):
+                            pair[j][0].step_device(ptrs, n_reads, batch["seq4_bytes"], batch["cigar_words"], pair[j][1])
+
+                    ths = [threading.Thread(target=worker, args=(j, args.steps // 2 + (j < args.steps % 2))) for j in range(2)]
+                    for t_ in ths:
+                        t_.start()
+                    barrier()
+                    go.wait()
+                    tp0 = time.perf_counter()
+                    for t_ in ths:
+                        t_.join()
+                    eng.sync(); eng2.sync()
+                    dtp = time.perf_counter() - tp0
+                    n_out = int(off2[-1])
+                    same = bytes(memoryview(pinned_np[:n_out])) == bytes(memoryview(pinned2[:n_out])) == b"".join(seqs_c)
+                    pipelined = dict(contexts=2, steps=args.steps, ms_per_step=round(dtp / args.steps * 1e3, 4), events_per_s=aligned_g / (dtp / args.steps),
+                                     same_fasta=bool(same), note="extra leg, not `value`: independent steps taken in turn by two contexts on two host threads")
+                finally:
+                    eng2.close()
+            except Exception as e:      # (the extra leg must never cost the bench line)
+                pipelined = dict(error=repr(e)[:200])
         if coll:   # host assembly of the stitched FASTA, outside the timed region (checksum only)
             assert exch.need(state["gathered"]) <= exch.pad, "an exchange row did not fit its agreed size"
             rows = np.ascontiguousarray(state["gathered"].cpu().numpy())
@@ -295,6 +340,7 @@ def main():
                 fasta_sha256=fasta_sha, consensus_len=sum(len(s) for s in seqs), gen_seconds=round(t_gen, 1),
                 library_sha256=_library_sha(N),
                 engine_stats=stats,
+                **(dict(pipelined=pipelined) if pipelined else {}),
             )
         return dict(out=out, eng=eng, batch=batch, contig_lens=contig_lens, seqs=seqs, aligned_g=aligned_g, step=step, barrier=barrier)
 
