@@ -263,6 +263,7 @@ struct KdEngine {
     int push_device(const kd_batch &B_in) {
         kd_batch B = B_in;
         const uint64_t n = B.n_reads;
+        if (!defer_errors) errors_pending = false;      // (a kd_step that failed half-way leaves nothing for a later kd_finish to classify)
         if (!n) return KD_OK;
         if (rt.exact_sizes()) {
             // include/kindel_hip.h: n entries per read array, cigar_words words, seq4_bytes + 16 readable bytes of packed bases --
