@@ -209,7 +209,7 @@ int kd_set_exchange(kd_ctx *ctx, void *dev_row, uint64_t cap);
 /* One whole step over a DEVICE-resident batch in one call: kd_reset + kd_push_batch_device + kd_finalize + kd_consensus_run (no
  * patches) + kd_consensus_fetch_all(seq_out ...), i.e. parse_records' loop and consensus_sequence's loop (kindel.py:40-81,
  * :384-430) for every contig of the batch, queued back to back with two host round trips.  seq_out should be pinned host memory
- * (hipHostMalloc / hipHostRegister: pinned memory makes the closing copy asynchronous).  Errors as kd_finalize.
+ * (hipHostMalloc / hipHostRegister: the consensus kernel then writes the bytes there itself).  Errors as kd_finalize (the batch's error classification runs when the step's status words ask for it).
  * (ABI 1 had an opt-in hipGraph replay of a repeated step -- kd_set_step_graph, an int *replayed here -- removed in
  * ABI 2: it measured nothing over the eager sequence and was the one path that faulted on hardware) */
 int kd_step(kd_ctx *ctx, const kd_batch *dev_batch, uint32_t min_depth, uint8_t *seq_out, uint64_t cap, uint64_t *len_out,
