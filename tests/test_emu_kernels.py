@@ -487,6 +487,45 @@ def test_finish_equals_finalize_consensus_fetch(emu_lib):
     _finish_vs_classic(emu_lib, synth.to_numpy(synth.short_reads([3000, 900], 15, seed=5, indel_p=0.0, planted=0)))
 
 
+@pytest.mark.parametrize("iv", [(1237, 4999), (3, 11001), (6082, 6083), (0, 12288), (5000, 7001)])
+def test_row_left_by_finish_equals_the_row_on_demand_at_any_alignment(emu_lib, iv):
+    """The exchange row kd_finish leaves behind (kd_set_exchange) against the row on demand (kd_exchange_row) for intervals that start
+    and end at any byte alignment -- inside a contig, over contig boundaries, of one site -- and rows of every size down to the bare
+    header, over two steps.  (Written for round 6's experiment of having k_cns_emit write the row itself,
+    scripts/exp/patches/row_by_emit.patch: measured no gain, not adopted; the test stays.)"""
+    lens = [6000, 5000, 300]
+    full = synth.to_numpy(synth.short_reads(lens, 12, seed=3))
+    S = int(shard.g_layout(lens)[1])
+    keep = shard.reads_of_rank(lens, *shard.footprints(lens, full), 0, 1, intervals=[iv])
+    sub = dict(full)
+    for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+        sub[k] = full[k][keep]
+    meta = 16 + (len(lens) + 1) * 8 + len(lens) * 8
+    fixed = meta + (min(iv[1], S) - min(iv[0], S))
+    for pad in (None, (fixed + 64 + 7) // 8 * 8, 304, 40, 16):
+        eng = N.Engine(np.asarray(lens, np.uint32), lib=emu_lib)
+        try:
+            eng.set_tuning(256, 0)
+            eng.set_shard(*iv)
+            p = pad or shard.row_pad(eng, iv, 1) + 8192
+            ex = shard.Exchange(eng, iv, "cpu", pad=p).attach()
+            out = np.zeros(sum(lens) * 2 + 4096, np.uint8)
+            for _ in range(2):
+                eng.reset()
+                eng.push(sub)
+                eng.finish(out)
+            left = ex.collect().clone()
+            ex.detach()
+            on_demand = shard.Exchange(eng, iv, "cpu", pad=p).run()
+            assert ex.need(left) == ex.need(on_demand), (iv, pad)
+            # what a row holds: everything up to its announced size if that fits, the first bytes that fit if its fixed part does, else
+            # header + metadata (or the header alone)
+            n = min(ex.need(left), p) if fixed <= p else (meta if meta <= p else 16)
+            assert bool((left[0, :n] == on_demand[0, :n]).all()), (iv, pad)
+        finally:
+            eng.close()
+
+
 def test_finish_with_more_consensus_bytes_than_sites(emu_lib):
     """The closing round trip copies as many bytes as a consensus without net insertions has; a consensus that is longer (majority
     insertions, no deletions) gets the rest in a second copy."""
