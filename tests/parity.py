@@ -305,3 +305,136 @@ def assert_matches_long_golden(run, entry, what=""):
         seq, ch, _, _ = run.cns[cid]
         assert seq.decode() == rec["consensus"], tag + "consensus"
         assert changes_str(ch) == rec["changes"], tag + "changes"
+
+
+def many_contigs_batch(n, seed=5):
+    """More contigs than a 16-bit field or a 65 535-wide launch dimension holds (a fragmented assembly, a metagenome): n contigs of
+    64 - 119 sites with one to three reads each -- 40M, 20M2I18M and 5S20M3D15M in turn, positions at random, sorted by (contig, pos).
+    Built with numpy in one go (tools/synth.py loops over the contigs)."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(64, 120, n).astype(np.uint32)
+    contig = np.repeat(np.arange(n, dtype=np.uint32), rng.integers(1, 4, n))
+    m = len(contig)
+    kind = rng.integers(0, 3, m)
+    pos0 = (rng.random(m) * (lens[contig] - np.array([40, 38, 38])[kind] + 1)).astype(np.int32)
+    order = np.lexsort((pos0, contig))
+    contig, kind, pos0 = contig[order], kind[order], pos0[order]
+    M, I, D, S = 0, 1, 2, 4
+    shapes = [[40 << 4 | M], [20 << 4 | M, 2 << 4 | I, 18 << 4 | M], [5 << 4 | S, 20 << 4 | M, 3 << 4 | D, 15 << 4 | M]]
+    n_cig = np.array([1, 3, 4], np.uint32)[kind]
+    cig_off = np.concatenate([[0], np.cumsum(n_cig)[:-1]]).astype(np.uint64)
+    cigar = np.zeros(int(n_cig.sum()) + 2, np.uint32)
+    for k, words in enumerate(shapes):
+        sel = np.nonzero(kind == k)[0]
+        for j, w in enumerate(words):
+            cigar[cig_off[sel] + np.uint64(j)] = w
+    nib = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, (m, 40))]
+    seq4 = np.zeros(m * 20 + 24, np.uint8)
+    seq4[: m * 20] = (nib[:, 0::2] << 4 | nib[:, 1::2]).reshape(-1)
+    return dict(contig=contig, pos0=pos0, flag=np.zeros(m, np.uint32), seq_off=np.arange(m, dtype=np.uint64) * np.uint64(20),
+                seq_len=np.full(m, 40, np.uint32), cig_off=cig_off, n_cig=n_cig, seq4=seq4, cigar=cigar, contig_lens=lens,
+                seq4_bytes=m * 20, cigar_words=int(n_cig.sum()), contig_names=np.asarray(["c%d" % i for i in range(n)]))
+
+
+def check_many_contigs(lib, n, world=3, sample=60):
+    """many_contigs_batch(n) through kd_finish and the per-contig read-outs: a sample of contigs (the first, the last, the ones either
+    side of 65 535 / 65 536, a random set) against the oracle -- tables, insertion dicts, consensus, change codes, depth range -- and
+    the same batch as `world` shards stitched from their exchange rows against the one context's FASTA, every contig."""
+    from kindel_amd import shard
+    b = many_contigs_batch(n)
+    lens = b["contig_lens"]
+    eng = N.Engine(lens, lib=lib)
+    try:
+        out = np.zeros(int(lens.sum()) * 2 + 4096, np.uint8)
+        eng.push(b)
+        off = eng.finish(out)
+        rng = np.random.default_rng(1)
+        pick = sorted(set([0, n - 1] + [c for c in (65534, 65535, 65536, 65537) if c < n] + [int(x) for x in rng.integers(0, n, sample)]))
+        for cid in pick:
+            oa = ko.parse_records(b, cid)
+            L, t = oa.L, eng.tables(cid)
+            assert np.array_equal(t[0:5, :L].T, oa.weights) and np.array_equal(t[5], oa.deletions) and np.array_equal(t[18], oa.ins_totals), cid
+            assert np.array_equal(t[6:11, :L].T, oa.clip_start_weights) and np.array_equal(t[16], oa.clip_starts), cid
+            site, count, strings = eng.insertions(cid)
+            assert sorted((int(p), s, int(c)) for p, c, s in zip(site, count, strings)) == sorted(oa.insertions), cid
+            oseq, och = oa.consensus_sequence(min_depth=1)
+            assert out[int(off[cid]): int(off[cid + 1])].tobytes().decode() == oseq, cid
+            seq, ch, mm, _ = eng.consensus_fetch(cid)
+            assert seq.decode() == oseq and [None if c == 0 else chr(c) for c in ch] == och and mm == oa.depth_minmax(), cid
+        whole = [out[int(off[c]): int(off[c + 1])].tobytes() for c in range(n)]
+    finally:
+        eng.close()
+    ivs = shard.partition_weighted(lens, b["contig"], b["pos0"], b["seq_len"], world)
+    g_lo, g_hi = shard.footprints(lens, b)
+    rows = []
+    for r in range(world):
+        keep = shard.reads_of_rank(lens, g_lo, g_hi, r, world, intervals=ivs)
+        sub = dict(b)
+        for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+            sub[k] = b[k][keep]
+        eng = N.Engine(lens, lib=lib)
+        try:
+            eng.set_shard(*ivs[r])
+            ex = shard.Exchange(eng, ivs[r], eng.memory_device, intervals=ivs).attach()
+            eng.push(sub)
+            eng.finish(out)
+            rows.append(np.ascontiguousarray(ex.collect().cpu().numpy()[0]))
+            ex.detach()
+        finally:
+            eng.close()
+    seqs, _changes, _minmax = shard.assemble(rows, lens, world, intervals=ivs)
+    assert seqs == whole
+    return len(pick)
+
+
+def check_huge_g_space(lib, depth=12, region=60000, seed=4):
+    """Sites beyond 2^31 in G-space (a human-sized reference, 4.2 G sites in four contigs, can only be run as shards -- its tables are
+    319 GB -- but every shard must be right wherever it lies): the reads of a `region`-site contig are moved to three places of the big
+    layout -- straddling G-site 2^31, in the middle of the third contig (G ~ 3.3 G) and at the very end of the last one (the last sites
+    of G-space) -- and each place is run as a shard of exactly that interval.  The oracle cannot hold a 1.1 G-site contig's tables;
+    the check is translation: the shard's exchange row (consensus bytes, change codes, depth range) must equal the small contig's own
+    consensus as the oracle computes it."""
+    from kindel_amd import shard
+    from tools import synth
+    small = synth.to_numpy(synth.short_reads([region], depth, seed=seed))
+    oa = ko.parse_records(small, 0)
+    oseq, och = oa.consensus_sequence(min_depth=1)
+    omm = oa.depth_minmax()
+    lens = np.asarray([1_100_000_000, 1_100_000_000, 1_100_000_000, 900_000_000], np.uint32)
+    base, S = shard.g_layout(lens)
+    assert S > (1 << 32) - (1 << 27) and S < (1 << 32)
+    places = [(1, (1 << 31) - int(base[1]) - region // 2), (2, 1_050_000_000), (3, int(lens[3]) - region)]
+    for cid, off in places:
+        lo = int(base[cid]) + off
+        hi = lo + region + (1 if cid == 3 else 0)        # (the last contig's slot `len`: the end of the contig is the region's end)
+        if cid == 1:
+            assert lo < (1 << 31) < hi
+        b = dict(small)
+        b["contig_lens"] = lens
+        b["contig"] = np.full_like(small["contig"], cid)
+        b["pos0"] = (small["pos0"].astype(np.int64) + off).astype(np.int32)
+        eng = N.Engine(lens, lib=lib)
+        try:
+            eng.set_shard(lo, hi)
+            ex = shard.Exchange(eng, (lo, hi), eng.memory_device, pad=(2 * region + region // 8 + 65536) // 64 * 64).attach()
+            out = np.zeros(2 * region + 4096, np.uint8)
+            eng.push(b)
+            coff = eng.finish(out)
+            row = np.ascontiguousarray(ex.collect().cpu().numpy()[0])
+            ex.detach()
+        finally:
+            eng.close()
+        n = len(lens)
+        assert out[int(coff[cid]): int(coff[cid + 1])].tobytes().decode() == oseq, ("bytes", cid)
+        assert int(coff[n]) == len(oseq)
+        need = int(row[:8].view(np.uint64)[0])
+        rcoff = row[16: 16 + (n + 1) * 8].view(np.uint64)
+        rmm = row[16 + (n + 1) * 8: 16 + (n + 1) * 8 + n * 8].view(np.uint32).reshape(n, 2)
+        o = 16 + (n + 1) * 8 + n * 8
+        sites = min(hi, S) - lo
+        assert need == o + sites + len(oseq) and need <= len(row)
+        ch = row[o: o + region]
+        assert [None if c == 0 else chr(c) for c in ch] == och, ("changes", cid)
+        assert row[o + sites + int(rcoff[cid]): o + sites + int(rcoff[cid + 1])].tobytes().decode() == oseq, ("row bytes", cid)
+        assert int(rmm[cid][1]) == omm[1] and int(rmm[cid][0]) == omm[0], ("depth range", cid, rmm[cid], omm)
+    return len(places)

@@ -763,3 +763,16 @@ def test_poisoned_device_memory_changes_nothing(emu_lib, monkeypatch, fill):
     P.assert_matches_oracle(P.Run(emu_lib, shuf, window=256), what="the same reads in random order")
     lb = synth.to_numpy(synth.long_reads([30000], 6, seed=9, median_len=3000, min_len=1500, max_len=6000))
     P.assert_matches_oracle(P.Run(emu_lib, lb, window=256), what="long reads")
+
+
+def test_more_contigs_than_sixteen_bits_hold(emu_lib):
+    """66 000 short contigs (a fragmented assembly, a metagenome): contig indices, per-contig metadata, the exchange row's offsets and
+    every launch sized by the contig count beyond 65 535 -- a sample of contigs against the oracle, three shards against one context."""
+    assert P.check_many_contigs(emu_lib, 66000) >= 50
+
+
+def test_sites_beyond_two_to_the_thirty_one(emu_lib):
+    """4.2 G sites of G-space in four contigs; shards straddling G-site 2^31, at G ~ 3.3 G and at the last sites of G-space equal the
+    same reads on a small contig of their own (tests/parity.py: check_huge_g_space)."""
+    assert P.check_huge_g_space(emu_lib, depth=6, region=20000) == 3
+

@@ -671,3 +671,15 @@ def test_reads_in_the_middle_of_a_long_contig_over_dirty_device_memory(hip_lib):
     for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
         shuf[k] = mid[k][perm]
     P.assert_matches_oracle(P.Run(hip_lib, shuf), what="the same reads in random order")
+
+
+def test_more_contigs_than_sixteen_bits_hold(hip_lib):
+    """200 001 short contigs on the GPU (tests/parity.py: check_many_contigs): a sample against the oracle, four shards against one context."""
+    assert P.check_many_contigs(hip_lib, 200001, world=4, sample=200) >= 150
+
+
+def test_sites_beyond_two_to_the_thirty_one(hip_lib):
+    """4.2 G sites of G-space in four contigs on the GPU: shards straddling G-site 2^31, at G ~ 3.3 G and at the last sites of G-space
+    equal the same reads on a small contig of their own (tests/parity.py: check_huge_g_space)."""
+    assert P.check_huge_g_space(hip_lib, depth=40, region=300000) == 3
+
