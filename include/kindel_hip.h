@@ -300,7 +300,8 @@ uint32_t kd_stream_contig_len(const kd_stream *s, uint32_t i);
  * next one, so one thread can decode batch k+1 while another still reads batch k. */
 int kd_stream_next(kd_stream *s, const kd_batch **batch);
 /* Records come out with contig = map[refID] from the next kd_stream_next on (map: one entry per @SQ line; 0xffffffff = "no record
- * may lie here": KD_E_ARG if one does; n = 0 restores the identity).  For a header far larger than what the records touch (a
+ * may lie here": KD_E_ARG if one does; 0xfffffffe = "records here are dropped": one of several passes over a file whose reference
+ * does not fit the device at once, each with a group of contigs laid out; n = 0 restores the identity).  For a header far larger than what the records touch (a
  * human-genome @SQ table, reads on one small contig): the reference lays out only the RNAMEs it sees (kindel.py:143-151) -- the
  * caller scans the file once for the contigs in use, creates its context over those, and streams with this map. */
 int kd_stream_set_contig_map(kd_stream *s, const uint32_t *map, uint32_t n);

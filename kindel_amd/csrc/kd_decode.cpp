@@ -1350,14 +1350,24 @@ int kd_stream_next(kd_stream *s, const kd_batch **batch) {
     if (rc) { s->err = g_decode_error; return rc; }
     if (!got) return KD_OK;
     if (!s->cmap.empty()) {
+        size_t w = 0;      // records kept so far (0xfffffffe: the records of this @SQ entry are dropped -- another pass's contigs)
         for (size_t i = 0; i < f.contig.size(); i++) {
-            uint32_t &c = f.contig.data()[i];
+            const uint32_t c = f.contig[i];
             const uint32_t m = c < s->cmap.size() ? s->cmap[c] : 0xffffffffu;
             if (m == 0xffffffffu) {
                 s->err = "kd_stream_set_contig_map: a record lies on @SQ entry " + std::to_string(c) + ", which the map leaves out";
                 return KD_E_ARG;
             }
-            c = m;
+            if (m == 0xfffffffeu) continue;
+            f.contig[w] = m;
+            if (w != i) {      // (the payload stays where it is: the offsets say where)
+                f.pos0[w] = f.pos0[i]; f.flag[w] = f.flag[i]; f.seq_off[w] = f.seq_off[i]; f.seq_len[w] = f.seq_len[i];
+                f.cig_off[w] = f.cig_off[i]; f.n_cig[w] = f.n_cig[i];
+            }
+            w++;
+        }
+        if (w != f.contig.size()) {
+            f.contig.resize(w); f.pos0.resize(w); f.flag.resize(w); f.seq_off.resize(w); f.seq_len.resize(w); f.cig_off.resize(w); f.n_cig.resize(w);
         }
     }
     finish_view(f);

@@ -225,27 +225,37 @@ def _is_regular_file(path):
         return True      # (let the decoder report what is wrong with the path)
 
 
-def _contigs_in_use(bam_path, threads, chunk_bytes, lib):
-    """One streamed pass over the file: the @SQ entries that have records, in file order of the header."""
+def _contigs_in_use(bam_path, threads, chunk_bytes, lib, with_order=False):
+    """One streamed pass over the file: the @SQ entries that have records, in file order of the header.
+    with_order: -> (those, the same entries in order of first appearance in the file: kindel.py:143-151)."""
     st = N.Stream(bam_path, threads=threads, chunk_bytes=chunk_bytes, lib=lib)
     try:
         seen = np.zeros(len(st.contig_lens), bool)
+        order = []
         while True:
             b = st.next_batch()
             if b is None:
                 break
-            seen[np.unique(b["contig"])] = True
-        return np.flatnonzero(seen)
+            c = np.asarray(b["contig"])
+            if with_order and len(c):
+                u, first = np.unique(c, return_index=True)
+                order.extend(int(x) for x in u[np.argsort(first, kind="stable")] if not seen[x])
+            seen[np.unique(c)] = True
+        return (np.flatnonzero(seen), order) if with_order else np.flatnonzero(seen)
     finally:
         st.close()
 
 
-def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=None, ingest=None):
+def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=None, ingest=None, contigs=None):
     """Decode + device record loop of one SAM / BAM file -> Pileup.  stream: False = the whole file decoded as ONE batch (only the
     contigs with records laid out); True = streamed over the whole header, whatever its size; None (default) = streamed, a header
     beyond STREAM_MAX_SITES scanned first for the contigs in use.  ingest: "host" (default: the native host decoder feeds the GPU) or "gpu"
     (opt-in, also KINDEL_INGEST=gpu: the BGZF blocks are inflated and the BAM records walked ON the GPU, kd_push_bam_gpu; a file
-    that path cannot read -- SAM text, plain gzip, CG-tag CIGARs, a header larger than STREAM_MAX_SITES -- takes the host path)."""
+    that path cannot read -- SAM text, plain gzip, CG-tag CIGARs, a header larger than STREAM_MAX_SITES -- takes the host path).
+    contigs: header indices -- only these @SQ entries are laid out and only their records counted (one of several passes over a
+    file whose reference does not fit the GPU at once: bam_to_consensus); streamed through the host decoder."""
+    if contigs is not None:
+        stream, ingest = True, "host"
     if stream is None and not _is_regular_file(bam_path):
         # the default route may open the file a second time (a large header: _contigs_in_use; the opt-in device-side ingest falling
         # back to the host decoder); an input that can be read only once (a pipe, /dev/stdin) is decoded in ONE pass as a whole,
@@ -280,13 +290,13 @@ def pileup_file(bam_path, device=0, lib=None, threads=0, chunk_bytes=0, stream=N
                     raise KeyError("no @SQ lines in header")
                 return Pileup(None, [], np.zeros(0, np.uint32), [], bam_path)
             names, lens = list(st.contig_names), st.contig_lens
-            if total > STREAM_MAX_SITES and not stream:
+            if contigs is not None or (total > STREAM_MAX_SITES and not stream):
                 # a header far larger than what the records touch: lay out the contigs in use only (a second pass over the
-                # file: regular files only, see above)
-                keep = _contigs_in_use(bam_path, threads, chunk_bytes, lib)
+                # file: regular files only, see above) -- or the caller's choice of contigs
+                keep = np.asarray(sorted(int(c) for c in contigs), np.int64) if contigs is not None else _contigs_in_use(bam_path, threads, chunk_bytes, lib)
                 if len(keep) == 0:
                     return Pileup(None, [], np.zeros(0, np.uint32), [], bam_path)
-                cmap = np.full(len(lens), 0xFFFFFFFF, np.uint32)
+                cmap = np.full(len(lens), 0xFFFFFFFE if contigs is not None else 0xFFFFFFFF, np.uint32)      # (records elsewhere: dropped / an error)
                 cmap[keep] = np.arange(len(keep), dtype=np.uint32)
                 st.set_contig_map(cmap)
                 names, lens = [names[int(i)] for i in keep], lens[keep]
@@ -695,11 +705,9 @@ def build_report(ref_id, weights, changes, cdr_patches, bam_path, realign, min_d
                    clip_decay_threshold, trim_ends, uppercase)
 
 
-def bam_to_consensus(bam_path, realign=False, min_depth=1, min_overlap=9, clip_decay_threshold=0.1, mask_ends=50,
-                     trim_ends=False, uppercase=False):
-    """bam_to_consensus of kindel.py:488-555: same arguments, same result tuple."""
-    consensuses, refs_changes, refs_reports = [], {}, {}
-    pl = pileup_file(bam_path)
+def _consensus_of_pileup(pl, bam_path, realign, min_depth, min_overlap, clip_decay_threshold, mask_ends, trim_ends, uppercase):
+    """The per-contig loop of kindel.py:501-551 over one Pileup (closed on the way out) -> [(ref_id, SeqRecord, changes, report)] in
+    pl.order."""
     try:
         patches = {}
         for cid in pl.order:
@@ -713,16 +721,75 @@ def bam_to_consensus(bam_path, realign=False, min_depth=1, min_overlap=9, clip_d
         done = _device_consensus_all(pl, patches, trim_ends, min_depth, uppercase)
     finally:
         pl.close()      # everything below is host data: the context -- tables, stream, pinned buffers -- goes now (no context: no records)
+    out = []
     for cid in pl.order:
         ref_id = pl.names[cid]
         seq, ch, mm = done[cid]
         report = _report(ref_id, mm, ch, patches[cid], bam_path, realign, min_depth, min_overlap, clip_decay_threshold,
                          trim_ends, uppercase)
-        consensuses.append(consensus_seqrecord(seq, ref_id))
+        out.append((ref_id, consensus_seqrecord(seq, ref_id), _changes_list(ch), report))
+    return out
+
+
+def _contig_groups(lens, used, n_groups):
+    """`used` (header indices, ascending) cut into at most n_groups runs of about equal total sites; a run is never empty."""
+    if n_groups >= len(used):
+        return [[int(c)] for c in used]
+    sites = np.asarray([int(lens[int(c)]) + 1 for c in used], np.float64)
+    cum = np.cumsum(sites)
+    cuts = np.searchsorted(cum, cum[-1] * np.arange(1, n_groups) / n_groups, side="left") + 1
+    edges = sorted(set([0] + [int(min(x, len(used))) for x in cuts] + [len(used)]))
+    return [[int(c) for c in used[a:b]] for a, b in zip(edges[:-1], edges[1:]) if b > a]
+
+
+def bam_to_consensus(bam_path, realign=False, min_depth=1, min_overlap=9, clip_decay_threshold=0.1, mask_ends=50,
+                     trim_ends=False, uppercase=False):
+    """bam_to_consensus of kindel.py:488-555: same arguments, same result tuple.
+
+    The reference allocates per RNAME as it meets it (kindel.py:143-151) and holds one contig's tables at a time in effect; here the
+    contigs in use are laid out together on the device (76 B of tables per site and 20 more of working arrays: 288 GB hold ~2.5 G
+    sites).  A reference that does not fit -- MemoryError from the device allocation -- is processed in GROUPS of contigs, one
+    streamed pass over the file per group (halved until a group fits); the result is the same tuple, contigs in order of first
+    appearance.  Regular files only: a pipe cannot be read twice."""
+    args = (realign, min_depth, min_overlap, clip_decay_threshold, mask_ends, trim_ends, uppercase)
+    try:
+        rows = _consensus_of_pileup(pileup_file(bam_path), bam_path, *args)
+    except MemoryError:
+        if not _is_regular_file(bam_path):
+            raise
+        rows = _consensus_in_groups(bam_path, args)
+    consensuses, refs_changes, refs_reports = [], {}, {}
+    for ref_id, rec, changes, report in rows:
+        consensuses.append(rec)
         refs_reports[ref_id] = report
-        refs_changes[ref_id] = _changes_list(ch)
+        refs_changes[ref_id] = changes
     result = namedtuple("result", ["consensuses", "refs_changes", "refs_reports"])
     return result(consensuses, refs_changes, refs_reports)
+
+
+def _consensus_in_groups(bam_path, args):
+    """bam_to_consensus for a reference whose tables do not fit the device at once: the contigs in use (one scanning pass: which, and
+    in which order they first appear) in groups of consecutive header entries, every group a streamed pass of its own over the file
+    with only its contigs laid out.  Twice as many groups after every MemoryError, down to one contig per group."""
+    st = N.Stream(bam_path)
+    try:
+        names, lens = list(st.contig_names), st.contig_lens
+    finally:
+        st.close()
+    used, order = _contigs_in_use(bam_path, 0, 0, None, with_order=True)
+    n_groups = 2
+    while True:
+        groups = _contig_groups(lens, used, n_groups)
+        try:
+            by_name = {}
+            for grp in groups:
+                for row in _consensus_of_pileup(pileup_file(bam_path, contigs=grp), bam_path, *args):
+                    by_name[row[0]] = row
+            return [by_name[names[c]] for c in order if names[c] in by_name]
+        except MemoryError:
+            if n_groups >= len(used):      # one contig per group and it still does not fit
+                raise
+            n_groups = min(2 * n_groups, len(used))
 
 
 def bam_to_consensus_sharded(bam_path, rank, world, device="cpu", dev_index=0, group=None, realign=False, min_depth=1, min_overlap=9,

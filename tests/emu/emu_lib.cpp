@@ -25,6 +25,9 @@ struct EmuRt {
     // KD_EMU_FILL=<byte>: every allocation starts out filled with it -- what hipMalloc hands out in a long-lived process is not zero pages
     // either; a kernel that reads what nobody wrote shows in the results (tests/test_emu_kernels.py: test_poisoned_device_memory_...)
     void *alloc(size_t bytes, const char * = "") {
+        // KD_EMU_ALLOC_CAP=<bytes>: a larger single allocation fails, as hipMalloc does for tables that do not fit the GPU (tests of the
+        // out-of-memory paths: kindel.bam_to_consensus lays a reference that does not fit out in groups of contigs)
+        if (const char *e = getenv("KD_EMU_ALLOC_CAP")) if (bytes > (size_t)strtoull(e, nullptr, 10)) return nullptr;
         const size_t n = exact ? (bytes ? bytes : 1) : ((bytes + 255) & ~size_t(255));
         void *p = exact ? malloc(n) : aligned_alloc(256, n ? n : 256);
         if (p) if (const char *e = getenv("KD_EMU_FILL")) ::memset(p, atoi(e), n);

@@ -277,3 +277,49 @@ def test_contexts_are_released_without_the_cycle_collector(api_on_emu, tmp_path)
     finally:
         gc.enable()
         N.Engine.__init__ = real_init
+
+
+def _six_contig_bam(tmp_path):
+    """Six contigs, two of them without a record, the others met in the file in the order 4, 0, 5, 2 (not the header's)."""
+    from tools import synth
+    lens = [5000, 3000, 9000, 2500, 4000, 7000]
+    b = synth.to_numpy(synth.short_reads(lens, 12, seed=21))
+    keep = np.flatnonzero((b["contig"] != 1) & (b["contig"] != 3))
+    rank = np.asarray([1, 9, 3, 9, 0, 2])[b["contig"][keep]]
+    keep = keep[np.argsort(rank, kind="stable")]
+    sub = dict(b)
+    for k in ("contig", "pos0", "flag", "seq_off", "seq_len", "cig_off", "n_cig"):
+        sub[k] = b[k][keep]
+    p = str(tmp_path / "six.bam")
+    synth.write_bam(p, sub, sort_order="unsorted")
+    return p, lens
+
+
+@pytest.mark.parametrize("realign", [False, True])
+def test_reference_that_does_not_fit_the_device_goes_in_groups_of_contigs(api_on_emu, tmp_path, monkeypatch, realign):
+    """bam_to_consensus on a reference whose tables the device cannot hold at once (here: the emulator refuses any single allocation
+    above KD_EMU_ALLOC_CAP, as hipMalloc refuses tables beyond the GPU's memory): the contigs in use go in groups, one streamed pass
+    over the file each (the records of the other groups dropped by the stream's contig map), halved until a group fits -- the same
+    result tuple as the one pass, contigs in order of first appearance; a contig that does not fit by itself is the MemoryError it
+    was."""
+    from kindel_amd import kindel as K
+    from kindel_amd import _native as N
+    path, lens = _six_contig_bam(tmp_path)
+    want = K.bam_to_consensus(path, realign=realign, min_overlap=7)
+    assert [c.name for c in want.consensuses] == ["ctg4_cns", "ctg0_cns", "ctg5_cns", "ctg2_cns"]
+    table_bytes = lambda sites: N.KD_NCH * 4 * sites
+    for cap_sites, passes in ((16000, 2), (9500, 4)):      # 25 000 sites in use: halves of ~12 500 fit the first cap, single contigs the second
+        calls = []
+        real = K.pileup_file
+        monkeypatch.setattr(K, "pileup_file", lambda *a, **k: (calls.append(k.get("contigs")), real(*a, **k))[1])
+        monkeypatch.setenv("KD_EMU_ALLOC_CAP", str(table_bytes(cap_sites)))
+        got = K.bam_to_consensus(path, realign=realign, min_overlap=7)
+        monkeypatch.delenv("KD_EMU_ALLOC_CAP")
+        monkeypatch.setattr(K, "pileup_file", real)
+        assert [(c.name, c.sequence) for c in got.consensuses] == [(c.name, c.sequence) for c in want.consensuses]
+        assert got.refs_changes == want.refs_changes and got.refs_reports == want.refs_reports
+        assert list(got.refs_reports) == list(want.refs_reports)          # (dict order: first appearance)
+        assert calls[0] is None and len([c for c in calls if c is not None]) >= passes, calls
+    monkeypatch.setenv("KD_EMU_ALLOC_CAP", str(table_bytes(8000)))      # ctg2 (9 000 sites) does not fit by itself
+    with pytest.raises(MemoryError):
+        K.bam_to_consensus(path, realign=realign)
