@@ -770,7 +770,9 @@ def bam_to_consensus(bam_path, realign=False, min_depth=1, min_overlap=9, clip_d
 def _consensus_in_groups(bam_path, args):
     """bam_to_consensus for a reference whose tables do not fit the device at once: the contigs in use (one scanning pass: which, and
     in which order they first appear) in groups of consecutive header entries, every group a streamed pass of its own over the file
-    with only its contigs laid out.  Twice as many groups after every MemoryError, down to one contig per group."""
+    with only its contigs laid out.  Twice as many groups after every MemoryError, down to one contig per group.  (A file with failing
+    reads on several contigs raises the exception of the first GROUP that has one -- header order -- where the one pass raises the first
+    contig's in order of appearance: the same exception types, possibly another read's.)"""
     st = N.Stream(bam_path)
     try:
         names, lens = list(st.contig_names), st.contig_lens
