@@ -323,3 +323,20 @@ def test_reference_that_does_not_fit_the_device_goes_in_groups_of_contigs(api_on
     monkeypatch.setenv("KD_EMU_ALLOC_CAP", str(table_bytes(8000)))      # ctg2 (9 000 sites) does not fit by itself
     with pytest.raises(MemoryError):
         K.bam_to_consensus(path, realign=realign)
+
+
+@pytest.mark.parametrize("chunk", [0, 4096])
+def test_pileup_of_chosen_contigs_drops_the_other_records(api_on_emu, tmp_path, chunk):
+    """pileup_file(contigs=...): only those @SQ entries are laid out, the stream drops the records of the others (contig map value
+    0xfffffffe) -- also when whole chunks of the file hold nothing but dropped records; the tables are those of the one pass."""
+    from kindel_amd import kindel as K
+    from tools import synth
+    lens = [5000, 3000, 9000, 2500, 4000, 7000]
+    p = str(tmp_path / "six_sorted.bam")
+    synth.write_bam(p, synth.to_numpy(synth.short_reads(lens, 12, seed=21)), block_bytes=2000)
+    with K.pileup_file(p) as full:
+        for grp in ([5], [0], [2, 3], [1, 4, 5]):
+            with K.pileup_file(p, contigs=grp, chunk_bytes=chunk) as pl:
+                assert list(pl.names) == ["ctg%d" % c for c in grp] and (chunk == 0 or pl.ingest["batches"] > 20)
+                for k, c in enumerate(grp):
+                    assert np.array_equal(pl.tables(k), full.tables(c)), (chunk, grp, c)
