@@ -99,25 +99,43 @@ class Run:
             eng.close()
 
 
+def _same(got, want, tag):
+    """np.array_equal with a failure message that NAMES the cells: an intermittent difference must leave its address behind."""
+    got, want = np.asarray(got), np.asarray(want)
+    if got.shape == want.shape and np.array_equal(got, want):
+        return
+    if got.shape != want.shape:
+        raise AssertionError("%s: shape %s vs %s" % (tag, got.shape, want.shape))
+    idx = np.argwhere(got != want)
+    cells = [(tuple(int(x) for x in i), int(got[tuple(i)]), int(want[tuple(i)])) for i in idx[:16]]
+    raise AssertionError("%s: %d of %d cells differ; (index, engine, oracle): %s; index range %s .. %s" % (
+        tag, len(idx), got.size, cells, idx.min(axis=0).tolist(), idx.max(axis=0).tolist()))
+
+
 def assert_matches_oracle(run, min_depth=1, what=""):
     for cid in run.order:
         oa = ko.parse_records(run.batch, cid)
         t, L = run.tables[cid], oa.L
         tag = "%s contig %d: " % (what, cid)
-        assert np.array_equal(t[0:5, :L].T, oa.weights), tag + "weights"
+        _same(t[0:5, :L].T, oa.weights, tag + "weights [site, A T G C N]")
         assert not t[0:5, L].any(), tag + "weights slot L must stay empty"
-        assert np.array_equal(t[5], oa.deletions), tag + "deletions"
-        assert np.array_equal(t[6:11, :L].T, oa.clip_start_weights), tag + "clip_start_weights"
-        assert np.array_equal(t[11:16, :L].T, oa.clip_end_weights), tag + "clip_end_weights"
-        assert np.array_equal(t[16], oa.clip_starts), tag + "clip_starts"
-        assert np.array_equal(t[17], oa.clip_ends), tag + "clip_ends"
-        assert np.array_equal(t[18], oa.ins_totals), tag + "insertion totals"
-        assert sorted(run.ins[cid]) == sorted(oa.insertions), tag + "insertion dicts"
+        _same(t[5], oa.deletions, tag + "deletions")
+        _same(t[6:11, :L].T, oa.clip_start_weights, tag + "clip_start_weights")
+        _same(t[11:16, :L].T, oa.clip_end_weights, tag + "clip_end_weights")
+        _same(t[16], oa.clip_starts, tag + "clip_starts")
+        _same(t[17], oa.clip_ends, tag + "clip_ends")
+        _same(t[18], oa.ins_totals, tag + "insertion totals")
+        if sorted(run.ins[cid]) != sorted(oa.insertions):
+            a, b = set(run.ins[cid]), set(oa.insertions)
+            raise AssertionError(tag + "insertion dicts: engine only %s, oracle only %s" % (sorted(a - b)[:8], sorted(b - a)[:8]))
         seq, ch, mm, _ = run.cns[cid]
         oseq, och = oa.consensus_sequence(min_depth=min_depth)
-        assert seq.decode() == oseq, tag + "consensus"
+        if seq.decode() != oseq:
+            s_ = seq.decode()
+            k = next((i for i, (x, y) in enumerate(zip(s_, oseq)) if x != y), min(len(s_), len(oseq)))
+            raise AssertionError(tag + "consensus: lengths %d / %d, first difference at byte %d: %r vs %r" % (len(s_), len(oseq), k, s_[k:k + 12], oseq[k:k + 12]))
         assert [None if c == 0 else chr(c) for c in ch] == och, tag + "changes"
-        assert mm == oa.depth_minmax(), tag + "depth min/max"
+        assert mm == oa.depth_minmax(), tag + "depth min/max %s vs %s" % (mm, oa.depth_minmax())
     return True
 
 

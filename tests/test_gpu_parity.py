@@ -305,14 +305,17 @@ def test_multi_tile_items_carry_rows_between_tiles(hip_lib):
         P.assert_matches_oracle(P.Run(hip_lib, batch, window=window, slice_reads=slice_reads), what="w%d s%d" % (window, slice_reads))
 
 
-def test_mostly_clipped_reads_and_deep_sites(hip_lib):
+@pytest.mark.parametrize("mode", [N.KD_MODE_AUTO, N.KD_MODE_COOP, N.KD_MODE_STRIP])
+def test_mostly_clipped_reads_and_deep_sites(hip_lib, mode):
     """k_prep writes a compact record for every clipped / inserted read (ballot-compacted per wavefront, one region of the
     record array per wavefront), k_cold_lane walks the regions (more than one round of 256 where most reads are clipped) and
-    lets neighbouring lanes that aim at one site add once (as does k_ins_insert).  Deep, clip-heavy input exercises all of it."""
+    lets neighbouring lanes that aim at one site add once (as does k_ins_insert).  Deep, clip-heavy input exercises all of it.
+    (One test per mode and a failure message that names the cells: this test failed ONCE in a plain suite run of round 6's last
+    session -- the only failure in a dozen runs, plain and fenced, of that library, not reproduced in 1 000 repeats:
+    profiles/r06_one_unreproduced_test_failure.txt.)"""
     batch = synth.to_numpy(synth.short_reads([2500, 1200], 2500, seed=13, clip_p=0.6, indel_p=0.3))
     assert len(batch["contig"]) > 3 * 8192
-    for mode in (N.KD_MODE_AUTO, N.KD_MODE_COOP, N.KD_MODE_STRIP):
-        P.assert_matches_oracle(P.Run(hip_lib, batch, mode=mode), what="mode %d" % mode)
+    P.assert_matches_oracle(P.Run(hip_lib, batch, mode=mode), what="mode %d" % mode)
 
 
 def test_insertion_hash_collision_is_detected_and_reseeded(hip_lib, monkeypatch):
