@@ -16,7 +16,12 @@ from tests import parity as P            # noqa: E402
 from tools import synth                  # noqa: E402
 
 loops = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-dirty = len(sys.argv) > 2 and sys.argv[2] == "dirty"      # device memory dirtied before every run (hipMalloc hands recycled pages out as they are)
+dirty = len(sys.argv) > 2 and sys.argv[2] == "dirty"
+if len(sys.argv) > 2 and sys.argv[2] == "aged":      # the process first runs the suite's tests in front of the one that failed (a long-lived process: thousands of contexts)
+    import pytest
+    rc = pytest.main(["-m", "gpu", "-q", "-x", "-p", "no:faulthandler", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                      "-k", "quirk_case or reference_fixture or window_tunings or unsorted_input or known_answers or fetch_all or multi_tile"])
+    print("aged by pytest.main: rc", rc, flush=True)      # device memory dirtied before every run (hipMalloc hands recycled pages out as they are)
 lib = N.default_library()
 batch = synth.to_numpy(synth.short_reads([2500, 1200], 2500, seed=13, clip_p=0.6, indel_p=0.3))
 oas = {cid: ko.parse_records(batch, cid) for cid in ko.contig_order(batch)}
